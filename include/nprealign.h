@@ -1,0 +1,191 @@
+/*
+ * nprealign.h -- C ABI of libnprealign.so: batched banded five-state pair-HMM realignment of
+ * nanopore reads on MI355X (gfx950), the drop-in for the reference's per-read `cactus_realign`
+ * subprocess.
+ *
+ * What it replaces.  The reference has no FFI for this path: it has a PROCESS boundary.  One
+ * `cactus_realign` process is forked per SAM record by sonLib's system() at
+ *     nanopore/analyses/utils.py:587            (realign; fan-out loop utils.py:565-570,
+ *                                                gather/splice utils.py:591-609)
+ *     nanopore/analyses/alignmentUncertainty.py:41        (rescore the original alignment)
+ *     nanopore/analyses/marginAlignSnpCaller.py:136-146   (dump all posterior match probabilities)
+ * with inputs "reference FASTA, read FASTA, exonerate cigar on stdin, --diagonalExpansion,
+ * --splitMatrixBiggerThanThis, --gapGamma, --matchGamma, --loadHmm" and outputs "one cigar line
+ * on stdout (+ score), optional `refPos readPos prob` TSV".  Each entry point below cites the
+ * piece of that contract it stands for.  INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every input buffer (borrowed for the
+ * duration of the call); every function returns NPR_OK (0) or a negative NPR_ERR_* code and, where an
+ * `err` buffer is given, writes a message into it; no exceptions, no globals, no stdout.  One
+ * npr_ctx per (thread, device); calls on one ctx must be serialised by the caller.  There is NO CPU
+ * fallback: npr_create fails with NPR_ERR_NO_DEVICE when no gfx950 GPU / HIP runtime is usable.
+ *
+ * Coordinates: X = reference, Y = read; cigar ops are (op,len) int32 pairs with SAM op codes
+ * 0 = M, 1 = I (read only), 2 = D (reference only) -- the mapping realignSamFile3TargetFn relies on
+ * (utils.py:602) and getExonerateCigarFormatString emits (utils.py:173).
+ */
+#ifndef NPREALIGN_H
+#define NPREALIGN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPR_ABI_VERSION 1
+
+/* error codes */
+#define NPR_OK 0
+#define NPR_ERR_INVALID (-1)       /* bad argument / guide cigar is not a global alignment (utils.py:381-382) */
+#define NPR_ERR_ZERO_PROB (-2)     /* total probability of the banded model is zero */
+#define NPR_ERR_CAPACITY (-3)      /* an output buffer (ops / posterior pairs) was too small */
+#define NPR_ERR_MODEL (-4)         /* HMM has a transition outside the five-state cell update */
+#define NPR_ERR_NO_DEVICE (-5)     /* no usable gfx950 device: there is no CPU fallback */
+#define NPR_ERR_HIP (-6)           /* HIP runtime error (message in err / npr_last_error) */
+#define NPR_ERR_BAND_TOO_WIDE (-7) /* an anti-diagonal has more in-band cells than the kernels support */
+#define NPR_ERR_NOMEM (-8)
+#define NPR_ERR_STATE (-9)         /* call sequence violated (e.g. finish before run) */
+
+/* cigar op codes (SAM numbering) */
+#define NPR_OP_M 0
+#define NPR_OP_I 1
+#define NPR_OP_D 2
+
+/* band construction */
+#define NPR_BAND_ANCHOR 0 /* cactus_realign's: anchors from the guide's M columns +- diagonalExpansion,
+                             rectangles between distant anchors, split above splitMatrixBiggerThanThis^2 */
+#define NPR_BAND_FIXED 1  /* fixed width W around the guide path (BASELINE.json "band=100/200") */
+
+/* what to return per read: the three call sites of cactus_realign */
+#define NPR_MODE_REALIGN 0          /* utils.py:587: new MEA cigar + score */
+#define NPR_MODE_RESCORE_ORIGINAL 1 /* alignmentUncertainty.py:41: --rescoreOriginalAlignment
+                                       --rescoreByPosteriorProbIgnoringGaps: guide ops kept, score = mean
+                                       posterior of its M columns */
+#define NPR_MODE_ALL_POSTERIORS 2   /* marginAlignSnpCaller.py:136-146: --outputAllPosteriorProbs; the MEA
+                                       cigar is produced as well (stdout of that call) */
+
+#define NPR_MAX_MODELS 8
+
+typedef struct npr_ctx npr_ctx;
+typedef struct npr_batch npr_batch;
+typedef struct npr_plan npr_plan;
+
+/* The command-line options of cactus_realign used by the reference's three call strings. */
+typedef struct {
+    int32_t band_mode;           /* NPR_BAND_* */
+    int32_t diagonal_expansion;  /* --diagonalExpansion=10 (utils.py:587) */
+    int32_t constraint_trim;     /* anchors trimmed at both ends of each gapless block (cPecan default 14) */
+    int64_t split_threshold;     /* --splitMatrixBiggerThanThis: 3000 realign (utils.py:587), 100 analyses
+                                    (alignmentUncertainty.py:41, marginAlignSnpCaller.py:136) */
+    int32_t fixed_width;         /* W for NPR_BAND_FIXED */
+    double gap_gamma;            /* --gapGamma  (abstractMapper.py:25 default 0.5) */
+    double match_gamma;          /* --matchGamma (abstractMapper.py:25 default 0.0) */
+    double posterior_threshold;  /* 0.01 */
+    int32_t mode;                /* NPR_MODE_* */
+    int32_t max_pairs_per_base;  /* capacity of the sparse posterior list per read base (0 -> 6) */
+} npr_params;
+
+typedef struct {
+    int32_t status;    /* NPR_OK or NPR_ERR_* for this read only: one bad read does not fail the batch */
+    int32_t n_segments;
+    int64_t cells;     /* in-band lattice cells processed (forward + backward + posterior test each) */
+    double loglik;     /* natural-log total probability summed over segments */
+    double loglik_bwd; /* same from the backward pass (consistency check) */
+    double score;      /* REALIGN / ALL_POSTERIORS: mean posterior of the MEA pairs; RESCORE: mean posterior of
+                          the guide's M columns -- what the reference reads back as pA.score
+                          (alignmentUncertainty.py:48) */
+    int64_t n_ops;     /* number of (op,len) pairs of the output cigar */
+    int64_t n_pairs;   /* number of posterior pairs >= threshold */
+} npr_read_result;
+
+typedef struct {
+    int64_t n_reads, n_tasks;
+    int64_t cells;          /* total in-band cells of the batch */
+    int64_t diagonals;      /* total anti-diagonals */
+    int64_t max_width;      /* widest anti-diagonal (cells) */
+    int64_t device_bytes;   /* device memory held by the batch */
+    int64_t slots;          /* resident wavefront slots used by the DP launch */
+    int32_t kernel_variant; /* 0 = generic LDS-ring kernel, 1 = register systolic kernel */
+} npr_batch_stats;
+
+/* ---- library / context ---- */
+int32_t npr_abi_version(void);
+const char *npr_strerror(int32_t code);
+
+/* device_id >= 0.  Fails with NPR_ERR_NO_DEVICE if HIP or the device is unavailable. */
+int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen);
+void npr_destroy(npr_ctx *ctx);
+const char *npr_last_error(npr_ctx *ctx);
+
+/* --loadHmm=<file> (utils.py:586-587): the 25 transition and 80 emission PROBABILITIES exactly as they
+ * stand in the two-line model file (nanopore/mappers/blasr_hmm_0.txt).  slot in [0, NPR_MAX_MODELS): reads
+ * pick a slot through `model_slot` (per-read-type models, scripts/modifyHmm.py).  T == NULL installs the
+ * stock model used when the reference passes no --loadHmm (abstractMapper.py:36-37). */
+int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double *E80);
+
+/* ---- batch: replaces the per-read fan-out / gather of utils.py:557-609 ---- */
+/* Stage 1 (host + H2D): band construction, packing, upload.  Sequences are ASCII (ACGT, any case; anything
+ * else is N), reference slice i = ref[ref_off[i] .. ref_off[i+1]), read i likewise (aR.query, utils.py:570);
+ * guide i = (op,len) pairs guide_ops[2*guide_off[i] .. 2*guide_off[i+1]) and must be GLOBAL over both
+ * sequences (the chained records of utils.py:313-386).  model_slot may be NULL (all 0). */
+int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
+                         const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
+                         const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
+                         npr_batch **out);
+/* Stage 2 (device): forward + backward + posterior extraction for every read of the batch; inputs are
+ * resident in HBM.  Blocks until done; kernel_ms (nullable) receives the HIP-event time of the DP launch
+ * measured on the context's stream.  May be called repeatedly (benchmarks). */
+int32_t npr_batch_run(npr_batch *b, float *kernel_ms);
+/* Stage 3 (D2H + host): sparse posteriors back, MEA chain / rescore, cigars. */
+int32_t npr_batch_finish(npr_batch *b);
+void npr_batch_destroy(npr_batch *b);
+
+int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
+/* results, valid after npr_batch_finish */
+int32_t npr_batch_results(const npr_batch *b, npr_read_result *out /* [n_reads] */);
+/* output cigars, CSR: ops_off[n_reads+1] (in op pairs), ops[2*ops_off[n_reads]].  Pass ops == NULL to get
+ * only the offsets (two-pass sizing). */
+int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_t cap_pairs);
+/* sparse posteriors (>= threshold), CSR by read, sorted by (x, y); x is the 0-based reference coordinate in
+ * the read's slice, y the 0-based read coordinate: the `refPos readPos prob` TSV of
+ * --outputAllPosteriorProbs (marginAlignSnpCaller.py:149). */
+int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32_t *y, float *p, int64_t cap);
+
+/* debugging / parity aid: dense per-cell match-state forward and backward values of read i, task-major,
+ * band order, as (mantissa, exponent) block-floating-point pairs (value = mant * 2^exp).  Runs the read
+ * again on the device.  Buffers sized npr_read_result.cells. */
+int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, float *Bm_v,
+                        int32_t *Bm_e, int64_t cap);
+
+/* One call = create + run + finish + copy-out + destroy, for callers that do not need staging. */
+int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
+                          const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
+                          const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
+                          npr_read_result *results, int64_t *ops_off, int32_t *ops, int64_t cap_op_pairs);
+
+/* ---- host logic, callable without a GPU (unit tests of the boundary) ---- */
+/* band / segmentation of one read (cactus_realign stages a5.1-a5.2 of SURVEY.md 8a) */
+int32_t npr_plan_create(const npr_params *params, int64_t lX, int64_t lY, const int32_t *guide_ops,
+                        int64_t n_guide_ops, npr_plan **out);
+void npr_plan_destroy(npr_plan *pl);
+int32_t npr_plan_segments(const npr_plan *pl);
+/* info8 = xs, ys, xe, ye, ragged_start, ragged_end, D, cells */
+int32_t npr_plan_segment_info(const npr_plan *pl, int32_t seg, int64_t *info8);
+/* lattice-clipped band: lo[D+1], n[D+1] */
+int32_t npr_plan_segment_band(const npr_plan *pl, int32_t seg, int32_t *lo, int32_t *n);
+/* MEA chain + cigar from sparse posteriors (stage a5.6).  Returns number of op pairs or NPR_ERR_*. */
+int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y, const float *p, int64_t n,
+                      double gap_gamma, double match_gamma, int32_t *ops, int64_t cap_pairs, double *score);
+/* mean posterior over the M columns of a cigar (stage a5.7) */
+int32_t npr_rescore(const int32_t *guide_ops, int64_t n_guide_ops, const int32_t *x, const int32_t *y,
+                    const float *p, int64_t n, double *score);
+/* ASCII -> base codes 0..4 (A,C,G,T,N) */
+void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+"""ctypes binding of libnprealign.so (C ABI: include/nprealign.h).
+
+The library is the only execution path of the realigner: if it is missing this module raises
+ImportError-like RuntimeError on first use, and `Context()` raises when no gfx950 device is usable.
+There is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnprealign.so")
+
+OK = 0
+ERR_INVALID, ERR_ZERO_PROB, ERR_CAPACITY, ERR_MODEL, ERR_NO_DEVICE, ERR_HIP, ERR_BAND_TOO_WIDE, ERR_NOMEM, \
+    ERR_STATE = -1, -2, -3, -4, -5, -6, -7, -8, -9
+OP_M, OP_I, OP_D = 0, 1, 2
+BAND_ANCHOR, BAND_FIXED = 0, 1
+MODE_REALIGN, MODE_RESCORE_ORIGINAL, MODE_ALL_POSTERIORS = 0, 1, 2
+MAX_MODELS = 8
+E_DEAD = -(1 << 28)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("band_mode", C.c_int32),
+        ("diagonal_expansion", C.c_int32),
+        ("constraint_trim", C.c_int32),
+        ("split_threshold", C.c_int64),
+        ("fixed_width", C.c_int32),
+        ("gap_gamma", C.c_double),
+        ("match_gamma", C.c_double),
+        ("posterior_threshold", C.c_double),
+        ("mode", C.c_int32),
+        ("max_pairs_per_base", C.c_int32),
+    ]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("n_segments", C.c_int32),
+        ("cells", C.c_int64),
+        ("loglik", C.c_double),
+        ("loglik_bwd", C.c_double),
+        ("score", C.c_double),
+        ("n_ops", C.c_int64),
+        ("n_pairs", C.c_int64),
+    ]
+
+
+RESULT_DTYPE = np.dtype([("status", np.int32), ("n_segments", np.int32), ("cells", np.int64),
+                         ("loglik", np.float64), ("loglik_bwd", np.float64), ("score", np.float64),
+                         ("n_ops", np.int64), ("n_pairs", np.int64)], align=True)
+
+
+class BatchStats(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int64),
+        ("n_tasks", C.c_int64),
+        ("cells", C.c_int64),
+        ("diagonals", C.c_int64),
+        ("max_width", C.c_int64),
+        ("device_bytes", C.c_int64),
+        ("slots", C.c_int64),
+        ("kernel_variant", C.c_int32),
+    ]
+
+
+class NprError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = "%s failed: %s (%d)" % (where, strerror(code), code)
+        if detail:
+            msg += " -- " + detail
+        RuntimeError.__init__(self, msg)
+
+
+# every symbol include/nprealign.h declares
+EXPORTS = [
+    "npr_abi_version", "npr_strerror", "npr_create", "npr_destroy", "npr_last_error", "npr_set_hmm",
+    "npr_batch_create", "npr_batch_run", "npr_batch_finish", "npr_batch_destroy", "npr_batch_get_stats",
+    "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_realign_batch",
+    "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
+    "npr_plan_segment_band", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
+]
+
+_lib = None
+
+
+def load():
+    """Loads libnprealign.so; raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libnprealign.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `make -C nanopore_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.npr_abi_version.restype = i32
+    L.npr_strerror.restype = C.c_char_p
+    L.npr_strerror.argtypes = [i32]
+    L.npr_create.restype = i32
+    L.npr_create.argtypes = [i32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.npr_destroy.restype = None
+    L.npr_destroy.argtypes = [vp]
+    L.npr_last_error.restype = C.c_char_p
+    L.npr_last_error.argtypes = [vp]
+    L.npr_set_hmm.restype = i32
+    L.npr_set_hmm.argtypes = [vp, i32, vp, vp]
+    L.npr_batch_create.restype = i32
+    L.npr_batch_create.argtypes = [vp, C.POINTER(Params), i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.npr_batch_run.restype = i32
+    L.npr_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
+    L.npr_batch_finish.restype = i32
+    L.npr_batch_finish.argtypes = [vp]
+    L.npr_batch_destroy.restype = None
+    L.npr_batch_destroy.argtypes = [vp]
+    L.npr_batch_get_stats.restype = i32
+    L.npr_batch_get_stats.argtypes = [vp, C.POINTER(BatchStats)]
+    L.npr_batch_results.restype = i32
+    L.npr_batch_results.argtypes = [vp, vp]
+    L.npr_batch_ops.restype = i32
+    L.npr_batch_ops.argtypes = [vp, vp, vp, i64]
+    L.npr_batch_pairs.restype = i32
+    L.npr_batch_pairs.argtypes = [vp, vp, vp, vp, vp, i64]
+    L.npr_batch_dense.restype = i32
+    L.npr_batch_dense.argtypes = [vp, i64, vp, vp, vp, vp, i64]
+    L.npr_realign_batch.restype = i32
+    L.npr_realign_batch.argtypes = [vp, C.POINTER(Params), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]
+    L.npr_plan_create.restype = i32
+    L.npr_plan_create.argtypes = [C.POINTER(Params), i64, i64, vp, i64, C.POINTER(vp)]
+    L.npr_plan_destroy.restype = None
+    L.npr_plan_destroy.argtypes = [vp]
+    L.npr_plan_segments.restype = i32
+    L.npr_plan_segments.argtypes = [vp]
+    L.npr_plan_segment_info.restype = i32
+    L.npr_plan_segment_info.argtypes = [vp, i32, vp]
+    L.npr_plan_segment_band.restype = i32
+    L.npr_plan_segment_band.argtypes = [vp, i32, vp, vp]
+    L.npr_mea_cigar.restype = i64
+    L.npr_mea_cigar.argtypes = [i64, i64, vp, vp, vp, i64, dbl, dbl, vp, i64, C.POINTER(dbl)]
+    L.npr_rescore.restype = i32
+    L.npr_rescore.argtypes = [vp, i64, vp, vp, vp, i64, C.POINTER(dbl)]
+    L.npr_encode_bases.restype = None
+    L.npr_encode_bases.argtypes = [vp, i64, vp]
+    _lib = L
+    return L
+
+
+def strerror(code):
+    return load().npr_strerror(code).decode()
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

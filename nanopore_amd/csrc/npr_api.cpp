@@ -1,0 +1,724 @@
+// npr_api.cpp -- the C ABI of libnprealign (include/nprealign.h): context, model slots, batch staging,
+// launch of the DP kernels, result gathering.  Replaces the per-read process fan-out / temp-file gather
+// of nanopore/analyses/utils.py:557-609 by one batched call.  There is no CPU execution path for the DP:
+// without a usable gfx950 device npr_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "npr_device.h"
+#include "npr_internal.h"
+
+using namespace npr;
+
+struct npr_plan {
+    Plan plan;
+};
+
+struct npr_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cu_count = 0;
+    size_t total_mem = 0;
+    bool model_set[NPR_MAX_MODELS] = {};
+    DevModel models[NPR_MAX_MODELS];
+    DevModel *d_models = nullptr;
+    std::string last_error;
+    int host_threads = 1;
+};
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    hipError_t alloc(size_t n) {
+        release();
+        count = n;
+        if (n == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    size_t bytes() const { return count * sizeof(T); }
+    ~DevBuf() { release(); }
+};
+
+int32_t fail(npr_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->last_error = what;
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                  \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) return fail((ctx), NPR_ERR_HIP, #expr, _e);   \
+    } while (0)
+
+template <typename F>
+void parallel_for(int64_t n, int threads, F f) {
+    threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(threads, n)));
+    if (threads == 1) {
+        for (int64_t i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace
+
+struct npr_batch {
+    npr_ctx *ctx = nullptr;
+    npr_params params{};
+    int64_t n_reads = 0;
+    // host copies needed by finish()
+    std::vector<int64_t> ref_len, read_len;
+    std::vector<int32_t> guide_ops;
+    std::vector<int64_t> guide_off;
+    std::vector<int32_t> read_status;    // planning status per read
+    std::vector<int32_t> read_first_task, read_ntasks;
+    std::vector<Task> tasks;             // device order (sorted longest first)
+    std::vector<int32_t> task_of;        // [read_first_task[r] + s] -> index into tasks
+    std::vector<int64_t> task_cells;     // in-band lattice cells per task (device order)
+    std::vector<TaskOut> outs;
+    npr_batch_stats stats{};
+    // device
+    DevBuf<Task> d_tasks;
+    DevBuf<TaskOut> d_outs;
+    DevBuf<int32_t> d_queue;
+    DevBuf<uint8_t> d_seq;
+    DevBuf<int32_t> d_lo, d_n;
+    DevBuf<uint32_t> d_coff;
+    DevBuf<float> d_Fv;
+    DevBuf<int32_t> d_Fe;
+    DevBuf<int32_t> d_px, d_py;
+    DevBuf<float> d_pp;
+    int64_t slot_stride = 0;
+    int grid = 0;
+    int wcap = 0;
+    size_t lds_bytes = 0;
+    bool ran = false, finished = false;
+    // results
+    std::vector<npr_read_result> results;
+    std::vector<int64_t> ops_off;
+    std::vector<int32_t> ops;
+    std::vector<int64_t> pair_off;
+    std::vector<Pair> pairs;
+};
+
+extern "C" {
+
+int32_t npr_abi_version(void) { return NPR_ABI_VERSION; }
+
+const char *npr_strerror(int32_t code) {
+    switch (code) {
+        case NPR_OK: return "ok";
+        case NPR_ERR_INVALID: return "invalid argument or guide alignment not global";
+        case NPR_ERR_ZERO_PROB: return "total probability is zero inside the band";
+        case NPR_ERR_CAPACITY: return "output capacity exceeded";
+        case NPR_ERR_MODEL: return "unsupported or malformed HMM";
+        case NPR_ERR_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
+        case NPR_ERR_HIP: return "HIP runtime error";
+        case NPR_ERR_BAND_TOO_WIDE: return "band wider than the kernels support";
+        case NPR_ERR_NOMEM: return "out of memory";
+        case NPR_ERR_STATE: return "call sequence violated";
+        default: return "unknown error";
+    }
+}
+
+int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
+    auto say = [&](const char *msg, hipError_t e) {
+        if (err && errlen) std::snprintf(err, errlen, "%s%s%s", msg, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    };
+    if (!out || device_id < 0) {
+        say("npr_create: bad arguments", hipSuccess);
+        return NPR_ERR_INVALID;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        say("npr_create: no HIP device visible", e);
+        return NPR_ERR_NO_DEVICE;
+    }
+    if (device_id >= count) {
+        say("npr_create: device index out of range", hipSuccess);
+        return NPR_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        say("npr_create: hipGetDeviceProperties", e);
+        return NPR_ERR_NO_DEVICE;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        if (err && errlen) std::snprintf(err, errlen, "npr_create: device %d is %s, this library is built for gfx950 only", device_id, prop.gcnArchName);
+        return NPR_ERR_NO_DEVICE;
+    }
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) {
+        say("npr_create: hipSetDevice", e);
+        return NPR_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<npr_ctx> ctx(new (std::nothrow) npr_ctx);
+    if (!ctx) return NPR_ERR_NOMEM;
+    ctx->device = device_id;
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->total_mem = prop.totalGlobalMem;
+    ctx->host_threads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void **>(&ctx->d_models), sizeof(DevModel) * NPR_MAX_MODELS)) != hipSuccess) {
+        say("npr_create: stream/event/model allocation", e);
+        return NPR_ERR_HIP;
+    }
+    *out = ctx.release();
+    // slot 0 defaults to the stock model (no --loadHmm)
+    return npr_set_hmm(*out, 0, nullptr, nullptr);
+}
+
+void npr_destroy(npr_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_models) (void)hipFree(ctx->d_models);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *npr_last_error(npr_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double *E80) {
+    if (!ctx || slot < 0 || slot >= NPR_MAX_MODELS) return NPR_ERR_INVALID;
+    double T[25], E[80];
+    if (T25 && E80) {
+        std::memcpy(T, T25, sizeof(T));
+        std::memcpy(E, E80, sizeof(E));
+    } else if (!T25 && !E80) {
+        stock_model(T, E);
+    } else {
+        return fail(ctx, NPR_ERR_INVALID, "npr_set_hmm: T and E must both be given or both be NULL");
+    }
+    DevModel m;
+    const int32_t rc = make_dev_model(T, E, m);
+    if (rc != NPR_OK) return fail(ctx, rc, "npr_set_hmm: model has a transition outside the five-state cell update, or a negative / non-finite entry");
+    ctx->models[slot] = m;
+    ctx->model_set[slot] = true;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_models + slot, &m, sizeof(DevModel), hipMemcpyHostToDevice));
+    return NPR_OK;
+}
+
+// --------------------------------------------------------------------------------------------------
+// batch
+// --------------------------------------------------------------------------------------------------
+
+int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
+                         const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
+                         const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
+                         npr_batch **out) {
+    if (!ctx || !params || !out || n_reads < 0) return NPR_ERR_INVALID;
+    if (n_reads > 0 && (!ref_off || !read_off || !guide_off)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: null offsets");
+    *out = nullptr;
+    std::unique_ptr<npr_batch> b(new (std::nothrow) npr_batch);
+    if (!b) return NPR_ERR_NOMEM;
+    b->ctx = ctx;
+    b->params = *params;
+    if (b->params.max_pairs_per_base <= 0) b->params.max_pairs_per_base = 6;
+    b->n_reads = n_reads;
+    b->ref_len.resize(n_reads);
+    b->read_len.resize(n_reads);
+    b->read_status.assign(n_reads, NPR_OK);
+    b->read_first_task.assign(n_reads, 0);
+    b->read_ntasks.assign(n_reads, 0);
+    b->guide_off.assign(guide_off, guide_off + (n_reads ? n_reads + 1 : 0));
+    if (n_reads) b->guide_ops.assign(guide_ops, guide_ops + 2 * guide_off[n_reads]);
+
+    // 1. plan every read (host threads; the analogue of the reference's one-job-per-read fan-out)
+    std::vector<Plan> plans(n_reads);
+    parallel_for(n_reads, ctx->host_threads, [&](int64_t i) {
+        const int64_t lX = ref_off[i + 1] - ref_off[i], lY = read_off[i + 1] - read_off[i];
+        b->ref_len[i] = lX;
+        b->read_len[i] = lY;
+        int32_t rc = NPR_OK;
+        const int32_t slot = model_slot ? model_slot[i] : 0;
+        if (slot < 0 || slot >= NPR_MAX_MODELS || !ctx->model_set[slot]) rc = NPR_ERR_MODEL;
+        if (rc == NPR_OK) rc = build_plan(b->params, lX, lY, guide_ops + 2 * guide_off[i], guide_off[i + 1] - guide_off[i], plans[i]);
+        if (rc == NPR_OK) {
+            const int maxw = generic_max_wcap();
+            for (const Segment &s : plans[i].segs)
+                if (s.max_width > maxw) rc = NPR_ERR_BAND_TOO_WIDE;
+        }
+        if (rc != NPR_OK) plans[i].segs.clear();
+        b->read_status[i] = rc;
+    });
+
+    // 2. flatten into tasks, longest first
+    struct Ref {
+        int64_t read;
+        int32_t seg;
+        int64_t cells;
+    };
+    std::vector<Ref> order;
+    int64_t seq_bytes = 0, band_entries = 0;
+    for (int64_t i = 0; i < n_reads; ++i) {
+        b->read_first_task[i] = static_cast<int32_t>(order.size());
+        b->read_ntasks[i] = static_cast<int32_t>(plans[i].segs.size());
+        for (size_t s = 0; s < plans[i].segs.size(); ++s) order.push_back({i, static_cast<int32_t>(s), plans[i].segs[s].cells});
+        if (!plans[i].segs.empty()) seq_bytes += b->ref_len[i] + b->read_len[i];
+    }
+    const int64_t ntasks = static_cast<int64_t>(order.size());
+    if (ntasks >= (int64_t(1) << 31)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: too many tasks");
+    std::vector<int32_t> rank(ntasks);
+    std::iota(rank.begin(), rank.end(), 0);
+    std::stable_sort(rank.begin(), rank.end(), [&](int32_t a, int32_t c) { return order[a].cells > order[c].cells; });
+    b->task_of.assign(ntasks, 0);
+    for (int64_t k = 0; k < ntasks; ++k) b->task_of[rank[k]] = static_cast<int32_t>(k);
+
+    // sequences: codes, reference slice then read, per read
+    std::vector<uint8_t> h_seq(seq_bytes);
+    std::vector<int64_t> seq_x(n_reads, 0), seq_y(n_reads, 0);
+    {
+        int64_t pos = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            if (plans[i].segs.empty()) continue;
+            seq_x[i] = pos;
+            pos += b->ref_len[i];
+            seq_y[i] = pos;
+            pos += b->read_len[i];
+        }
+        parallel_for(n_reads, ctx->host_threads, [&](int64_t i) {
+            if (plans[i].segs.empty()) return;
+            for (int64_t k = 0; k < b->ref_len[i]; ++k) h_seq[seq_x[i] + k] = encode_base(ref[ref_off[i] + k]);
+            for (int64_t k = 0; k < b->read_len[i]; ++k) h_seq[seq_y[i] + k] = encode_base(read[read_off[i] + k]);
+        });
+    }
+
+    b->tasks.resize(ntasks);
+    b->task_cells.resize(ntasks);
+    std::vector<int64_t> band_base(ntasks);
+    int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
+    for (int64_t k = 0; k < ntasks; ++k) {
+        const Ref &r = order[rank[k]];
+        const Segment &s = plans[r.read].segs[r.seg];
+        band_base[k] = band_entries;
+        band_entries += s.D() + 1;
+        Task &t = b->tasks[k];
+        t.x_off = seq_x[r.read] + s.xs;
+        t.y_off = seq_y[r.read] + s.ys;
+        t.band_off = band_base[k];
+        t.lX = static_cast<int32_t>(s.xe - s.xs);
+        t.lY = static_cast<int32_t>(s.ye - s.ys);
+        t.D = static_cast<int32_t>(s.D());
+        t.flags = (s.ragged_start ? 1 : 0) | (s.ragged_end ? 2 : 0);
+        t.model = model_slot ? model_slot[r.read] : 0;
+        t.xs = static_cast<int32_t>(s.xs);
+        t.ys = static_cast<int32_t>(s.ys);
+        t.read = static_cast<int32_t>(r.read);
+        const int64_t cap = std::min<int64_t>(s.cells, static_cast<int64_t>(b->params.max_pairs_per_base) * std::min(t.lX, t.lY) + 64);
+        t.pair_cap = static_cast<int32_t>(std::min<int64_t>(cap, INT32_MAX));
+        t.pair_off = pair_total;
+        pair_total += t.pair_cap;
+        b->task_cells[k] = s.cells;
+        total_cells += s.cells;
+        max_width = std::max<int64_t>(max_width, s.max_width);
+    }
+    std::vector<int32_t> h_lo(band_entries), h_n(band_entries);
+    std::vector<uint32_t> h_coff(band_entries);
+    std::vector<int64_t> pad_cells(ntasks);
+    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
+        const Ref &r = order[rank[k]];
+        const Segment &s = plans[r.read].segs[r.seg];
+        uint64_t off = 0;
+        for (int64_t d = 0; d <= s.D(); ++d) {
+            h_lo[band_base[k] + d] = s.lo[d];
+            h_n[band_base[k] + d] = s.n[d];
+            h_coff[band_base[k] + d] = static_cast<uint32_t>(off);
+            off += (static_cast<uint64_t>(s.n[d]) + 3) & ~uint64_t(3);  // 16-byte aligned rows
+        }
+        pad_cells[k] = static_cast<int64_t>(off);
+    });
+    for (int64_t k = 0; k < ntasks; ++k) {
+        if (pad_cells[k] >= (int64_t(1) << 32)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: segment too large");
+        b->tasks[k].cells_pad = static_cast<int32_t>(std::min<int64_t>(pad_cells[k], INT32_MAX));
+        max_pad = std::max(max_pad, pad_cells[k]);
+    }
+
+    // 3. device buffers
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    b->wcap = static_cast<int>((std::max<int64_t>(max_width, 64) + 3) & ~int64_t(3));
+    b->lds_bytes = generic_lds_bytes(b->wcap);
+    const int waves_by_lds = static_cast<int>(std::max<size_t>(1, (160 * 1024) / (b->lds_bytes + 256)));
+    const int waves_per_cu = std::min(16, waves_by_lds);
+    int64_t grid = std::min<int64_t>(ntasks, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
+    grid = std::max<int64_t>(grid, 1);
+    b->slot_stride = (max_pad + 63) & ~int64_t(63);
+    // keep the scratch inside the memory actually free
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    const int64_t fixed = seq_bytes + band_entries * 12 + pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
+    const int64_t budget = static_cast<int64_t>(free_b * 0.9) - fixed;
+    if (b->slot_stride > 0) {
+        const int64_t fit = budget / (b->slot_stride * 8);
+        if (fit < 1) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for one forward scratch region");
+        grid = std::min(grid, fit);
+    }
+    b->grid = static_cast<int>(grid);
+    hipError_t e;
+    if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
+        (e = b->d_queue.alloc(4)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
+        (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
+        (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_px.alloc(pair_total)) != hipSuccess ||
+        (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess ||
+        (e = b->d_Fv.alloc(b->slot_stride * grid)) != hipSuccess || (e = b->d_Fe.alloc(b->slot_stride * grid)) != hipSuccess)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    if (ntasks) {
+        HIP_TRY(ctx, hipMemcpy(b->d_tasks.p, b->tasks.data(), b->d_tasks.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_seq.p, h_seq.data(), b->d_seq.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_lo.p, h_lo.data(), b->d_lo.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_n.p, h_n.data(), b->d_n.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.data(), b->d_coff.bytes(), hipMemcpyHostToDevice));
+    }
+    b->outs.resize(ntasks);
+    b->stats.n_reads = n_reads;
+    b->stats.n_tasks = ntasks;
+    b->stats.cells = total_cells;
+    b->stats.diagonals = band_entries;
+    b->stats.max_width = max_width;
+    b->stats.slots = grid;
+    b->stats.kernel_variant = 0;
+    b->stats.device_bytes = fixed + b->slot_stride * grid * 8;
+    *out = b.release();
+    return NPR_OK;
+}
+
+static KernelArgs make_args(npr_batch *b) {
+    KernelArgs a{};
+    a.tasks = b->d_tasks.p;
+    a.outs = b->d_outs.p;
+    a.queue = b->d_queue.p;
+    a.ntasks = static_cast<int32_t>(b->tasks.size());
+    a.models = b->ctx->d_models;
+    a.seq = b->d_seq.p;
+    a.lo = b->d_lo.p;
+    a.n = b->d_n.p;
+    a.coff = b->d_coff.p;
+    a.Fv = b->d_Fv.p;
+    a.Fe = b->d_Fe.p;
+    a.slot_stride = b->slot_stride;
+    a.px = b->d_px.p;
+    a.py = b->d_py.p;
+    a.pp = b->d_pp.p;
+    a.threshold = static_cast<float>(b->params.posterior_threshold);
+    a.wcap = b->wcap;
+    return a;
+}
+
+int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
+    if (!b) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (b->tasks.empty()) {
+        b->ran = true;
+        return NPR_OK;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 4, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    const int rc = launch_generic(make_args(b), b->grid, b->lds_bytes, false, ctx->stream);
+    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_generic launch", static_cast<hipError_t>(rc));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    b->ran = true;
+    b->finished = false;
+    return NPR_OK;
+}
+
+int32_t npr_batch_finish(npr_batch *b) {
+    if (!b) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    if (!b->ran) return fail(ctx, NPR_ERR_STATE, "npr_batch_finish before npr_batch_run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
+    std::vector<int64_t> dst(ntasks + 1, 0);
+    std::vector<int32_t> hx, hy;
+    std::vector<float> hp;
+    if (ntasks) {
+        HIP_TRY(ctx, hipMemcpy(b->outs.data(), b->d_outs.p, b->d_outs.bytes(), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < ntasks; ++k) dst[k + 1] = dst[k] + std::min(b->outs[k].npairs, b->tasks[k].pair_cap);
+        const int64_t total = dst[ntasks];
+        DevBuf<int64_t> d_dst;
+        DevBuf<int32_t> d_cx, d_cy;
+        DevBuf<float> d_cp;
+        hipError_t e;
+        if ((e = d_dst.alloc(ntasks + 1)) != hipSuccess || (e = d_cx.alloc(total)) != hipSuccess ||
+            (e = d_cy.alloc(total)) != hipSuccess || (e = d_cp.alloc(total)) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc", e);
+        HIP_TRY(ctx, hipMemcpyAsync(d_dst.p, dst.data(), d_dst.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        if (total) {
+            CompactArgs ca{b->d_tasks.p, b->d_outs.p, d_dst.p, static_cast<int32_t>(ntasks), b->d_px.p, b->d_py.p, b->d_pp.p, d_cx.p, d_cy.p, d_cp.p};
+            const int rc = launch_compact(ca, ctx->stream);
+            if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_compact launch", static_cast<hipError_t>(rc));
+            hx.resize(total), hy.resize(total), hp.resize(total);
+            HIP_TRY(ctx, hipMemcpyAsync(hx.data(), d_cx.p, d_cx.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(hy.data(), d_cy.p, d_cy.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(hp.data(), d_cp.p, d_cp.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+
+    // per read: merge its segments' pairs (sorted by (x,y)), then MEA / rescore
+    const int64_t n = b->n_reads;
+    b->results.assign(n, npr_read_result{});
+    b->pair_off.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t c = 0;
+        for (int32_t s = 0; s < b->read_ntasks[i]; ++s) {
+            const int32_t k = b->task_of[b->read_first_task[i] + s];
+            c += dst[k + 1] - dst[k];
+        }
+        b->pair_off[i + 1] = b->pair_off[i] + c;
+    }
+    b->pairs.resize(b->pair_off[n]);
+    std::vector<std::vector<int32_t>> per_read_ops(n);
+    const double LN2 = 0.69314718055994530942;
+    parallel_for(n, ctx->host_threads, [&](int64_t i) {
+        npr_read_result &r = b->results[i];
+        r.status = b->read_status[i];
+        r.n_segments = b->read_ntasks[i];
+        if (r.status != NPR_OK) return;
+        Pair *pp = b->pairs.data() + b->pair_off[i];
+        int64_t c = 0;
+        for (int32_t s = 0; s < b->read_ntasks[i]; ++s) {
+            const int32_t k = b->task_of[b->read_first_task[i] + s];
+            const TaskOut &o = b->outs[k];
+            if (o.status != NPR_OK && r.status == NPR_OK) r.status = o.status;
+            r.cells += b->task_cells[k];
+            if (o.tot_m > 0.f) r.loglik += (std::log2(static_cast<double>(o.tot_m)) + o.tot_e) * LN2;
+            if (o.btot_m > 0.f) r.loglik_bwd += (std::log2(static_cast<double>(o.btot_m)) + o.btot_e) * LN2;
+            for (int64_t q = dst[k]; q < dst[k + 1]; ++q) pp[c++] = Pair{hx[q], hy[q], hp[q]};
+        }
+        std::sort(pp, pp + c, [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
+        r.n_pairs = c;
+        if (r.status != NPR_OK) return;
+        const int32_t *g = b->guide_ops.data() + 2 * b->guide_off[i];
+        const int64_t ng = b->guide_off[i + 1] - b->guide_off[i];
+        if (b->params.mode == NPR_MODE_RESCORE_ORIGINAL) {
+            // --rescoreOriginalAlignment: ops verbatim (alignmentUncertainty.py:51-52), new score
+            for (int64_t q = 0; q < ng; ++q)
+                if (g[2 * q + 1] > 0) per_read_ops[i].insert(per_read_ops[i].end(), {g[2 * q], g[2 * q + 1]});
+            r.score = rescore(g, ng, pp, c);
+        } else {
+            const int32_t rc = mea_cigar(b->ref_len[i], b->read_len[i], pp, c, b->params.gap_gamma, b->params.match_gamma, per_read_ops[i], r.score);
+            if (rc != NPR_OK) r.status = rc;
+        }
+        r.n_ops = static_cast<int64_t>(per_read_ops[i].size() / 2);
+    });
+    b->ops_off.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) b->ops_off[i + 1] = b->ops_off[i] + static_cast<int64_t>(per_read_ops[i].size() / 2);
+    b->ops.resize(2 * b->ops_off[n]);
+    for (int64_t i = 0; i < n; ++i) std::copy(per_read_ops[i].begin(), per_read_ops[i].end(), b->ops.begin() + 2 * b->ops_off[i]);
+    b->finished = true;
+    return NPR_OK;
+}
+
+void npr_batch_destroy(npr_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    delete b;
+}
+
+int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st) {
+    if (!b || !st) return NPR_ERR_INVALID;
+    *st = b->stats;
+    return NPR_OK;
+}
+
+int32_t npr_batch_results(const npr_batch *b, npr_read_result *out) {
+    if (!b || (!out && b->n_reads)) return NPR_ERR_INVALID;
+    if (!b->finished) return NPR_ERR_STATE;
+    std::copy(b->results.begin(), b->results.end(), out);
+    return NPR_OK;
+}
+
+int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_t cap_pairs) {
+    if (!b || !ops_off) return NPR_ERR_INVALID;
+    if (!b->finished) return NPR_ERR_STATE;
+    std::copy(b->ops_off.begin(), b->ops_off.end(), ops_off);
+    if (!ops) return NPR_OK;
+    if (cap_pairs < b->ops_off[b->n_reads]) return NPR_ERR_CAPACITY;
+    std::copy(b->ops.begin(), b->ops.end(), ops);
+    return NPR_OK;
+}
+
+int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32_t *y, float *p, int64_t cap) {
+    if (!b || !pair_off) return NPR_ERR_INVALID;
+    if (!b->finished) return NPR_ERR_STATE;
+    std::copy(b->pair_off.begin(), b->pair_off.end(), pair_off);
+    if (!x) return NPR_OK;
+    const int64_t total = b->pair_off[b->n_reads];
+    if (cap < total) return NPR_ERR_CAPACITY;
+    for (int64_t i = 0; i < total; ++i) x[i] = b->pairs[i].x, y[i] = b->pairs[i].y, p[i] = b->pairs[i].p;
+    return NPR_OK;
+}
+
+int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, float *Bm_v, int32_t *Bm_e, int64_t cap) {
+    if (!b || read_index < 0 || read_index >= b->n_reads || !Fm_v || !Fm_e || !Bm_v || !Bm_e) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    if (b->read_status[read_index] != NPR_OK) return b->read_status[read_index];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t written = 0;
+    DevBuf<float> d_Bv;
+    DevBuf<int32_t> d_Be;
+    DevBuf<TaskOut> d_out1;
+    hipError_t e;
+    if ((e = d_Bv.alloc(b->slot_stride)) != hipSuccess || (e = d_Be.alloc(b->slot_stride)) != hipSuccess || (e = d_out1.alloc(1)) != hipSuccess)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_dense: hipMalloc", e);
+    // band rows are needed to strip the row padding
+    for (int32_t s = 0; s < b->read_ntasks[read_index]; ++s) {
+        const int32_t k = b->task_of[b->read_first_task[read_index] + s];
+        const Task &t = b->tasks[k];
+        KernelArgs a = make_args(b);
+        a.tasks = b->d_tasks.p + k;
+        a.ntasks = 1;
+        a.outs = d_out1.p;
+        a.Bv = d_Bv.p;
+        a.Be = d_Be.p;
+        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 4, ctx->stream));
+        const int rc = launch_generic(a, 1, b->lds_bytes, true, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_generic<dense> launch", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int32_t> n(t.D + 1);
+        std::vector<uint32_t> co(t.D + 1);
+        HIP_TRY(ctx, hipMemcpy(n.data(), b->d_n.p + t.band_off, sizeof(int32_t) * (t.D + 1), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(co.data(), b->d_coff.p + t.band_off, sizeof(uint32_t) * (t.D + 1), hipMemcpyDeviceToHost));
+        std::vector<float> fv(t.cells_pad), bv(t.cells_pad);
+        std::vector<int32_t> fe(t.cells_pad), be(t.cells_pad);
+        HIP_TRY(ctx, hipMemcpy(fv.data(), b->d_Fv.p, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fe.data(), b->d_Fe.p, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(bv.data(), d_Bv.p, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(be.data(), d_Be.p, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
+        for (int32_t d = 0; d <= t.D; ++d)
+            for (int32_t j = 0; j < n[d]; ++j) {
+                if (written >= cap) return NPR_ERR_CAPACITY;
+                Fm_v[written] = fv[co[d] + j], Fm_e[written] = fe[co[d] + j];
+                Bm_v[written] = bv[co[d] + j], Bm_e[written] = be[co[d] + j];
+                ++written;
+            }
+    }
+    b->ran = false;  // the pair buffers of this read were overwritten by the debug launch
+    return NPR_OK;
+}
+
+int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
+                          const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
+                          const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
+                          npr_read_result *results, int64_t *ops_off, int32_t *ops, int64_t cap_op_pairs) {
+    npr_batch *b = nullptr;
+    int32_t rc = npr_batch_create(ctx, params, n_reads, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot, &b);
+    if (rc == NPR_OK) rc = npr_batch_run(b, nullptr);
+    if (rc == NPR_OK) rc = npr_batch_finish(b);
+    if (rc == NPR_OK && results) rc = npr_batch_results(b, results);
+    if (rc == NPR_OK && ops_off) rc = npr_batch_ops(b, ops_off, ops, cap_op_pairs);
+    npr_batch_destroy(b);
+    return rc;
+}
+
+// --------------------------------------------------------------------------------------------------
+// host logic without a GPU
+// --------------------------------------------------------------------------------------------------
+
+int32_t npr_plan_create(const npr_params *params, int64_t lX, int64_t lY, const int32_t *guide_ops, int64_t n_guide_ops, npr_plan **out) {
+    if (!params || !out) return NPR_ERR_INVALID;
+    std::unique_ptr<npr_plan> pl(new (std::nothrow) npr_plan);
+    if (!pl) return NPR_ERR_NOMEM;
+    const int32_t rc = build_plan(*params, lX, lY, guide_ops, n_guide_ops, pl->plan);
+    if (rc != NPR_OK) return rc;
+    *out = pl.release();
+    return NPR_OK;
+}
+
+void npr_plan_destroy(npr_plan *pl) { delete pl; }
+
+int32_t npr_plan_segments(const npr_plan *pl) { return pl ? static_cast<int32_t>(pl->plan.segs.size()) : NPR_ERR_INVALID; }
+
+int32_t npr_plan_segment_info(const npr_plan *pl, int32_t seg, int64_t *info8) {
+    if (!pl || !info8 || seg < 0 || seg >= static_cast<int32_t>(pl->plan.segs.size())) return NPR_ERR_INVALID;
+    const Segment &s = pl->plan.segs[seg];
+    info8[0] = s.xs, info8[1] = s.ys, info8[2] = s.xe, info8[3] = s.ye;
+    info8[4] = s.ragged_start, info8[5] = s.ragged_end, info8[6] = s.D(), info8[7] = s.cells;
+    return NPR_OK;
+}
+
+int32_t npr_plan_segment_band(const npr_plan *pl, int32_t seg, int32_t *lo, int32_t *n) {
+    if (!pl || !lo || !n || seg < 0 || seg >= static_cast<int32_t>(pl->plan.segs.size())) return NPR_ERR_INVALID;
+    const Segment &s = pl->plan.segs[seg];
+    std::copy(s.lo.begin(), s.lo.end(), lo);
+    std::copy(s.n.begin(), s.n.end(), n);
+    return NPR_OK;
+}
+
+int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y, const float *p, int64_t n,
+                      double gap_gamma, double match_gamma, int32_t *ops, int64_t cap_pairs, double *score) {
+    if (lX < 0 || lY < 0 || n < 0 || (n && (!x || !y || !p))) return NPR_ERR_INVALID;
+    std::vector<Pair> pairs(n);
+    for (int64_t i = 0; i < n; ++i) pairs[i] = Pair{x[i], y[i], p[i]};
+    std::sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
+    std::vector<int32_t> out;
+    double sc = 0.0;
+    const int32_t rc = mea_cigar(lX, lY, pairs.data(), n, gap_gamma, match_gamma, out, sc);
+    if (rc != NPR_OK) return rc;
+    if (score) *score = sc;
+    const int64_t k = static_cast<int64_t>(out.size() / 2);
+    if (k > cap_pairs || (k && !ops)) return NPR_ERR_CAPACITY;
+    std::copy(out.begin(), out.end(), ops);
+    return k;
+}
+
+int32_t npr_rescore(const int32_t *guide_ops, int64_t n_guide_ops, const int32_t *x, const int32_t *y, const float *p, int64_t n, double *score) {
+    if (!score || n < 0 || n_guide_ops < 0) return NPR_ERR_INVALID;
+    std::vector<Pair> pairs(n);
+    for (int64_t i = 0; i < n; ++i) pairs[i] = Pair{x[i], y[i], p[i]};
+    std::sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
+    *score = rescore(guide_ops, n_guide_ops, pairs.data(), n);
+    return NPR_OK;
+}
+
+void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes) {
+    for (int64_t i = 0; i < n; ++i) codes[i] = encode_base(ascii[i]);
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+// npr_cell.h -- device arithmetic of one DP cell (DESIGN.md "Device arithmetic").
+//
+// A cell holds the five state probabilities in block floating point: five linear fp32 mantissas v[s]
+// sharing one int32 binary exponent e, value_s = v[s] * 2^e, max_s v[s] in [0.5, 1).  That is the
+// log-sum-exp recurrence of cactus_realign's five-state machine with the
+// integer part of log2 carried exactly and the fractional part carried linearly, so the inner loop needs
+// no exp/log and never leaves fp32 range however long the read is.  Every operation is a single-rounding
+// IEEE op; oracle/realign_oracle_f32.c restates the same sequence on the CPU and the parity tests demand
+// bit-identical results -- keep the two in step.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "npr_device.h"
+
+namespace npr {
+
+struct Cell {
+    float m, sx, sy, lx, ly;  // states 0, 1, 2, 3, 4
+    int e;
+};
+
+__device__ __forceinline__ Cell dead_cell() { return Cell{0.f, 0.f, 0.f, 0.f, 0.f, E_DEAD}; }
+
+// 2^k for k <= 0, flushed to zero below 2^-100
+__device__ __forceinline__ float scale2(int k) { return k < -100 ? 0.0f : __builtin_ldexpf(1.0f, k); }
+
+__device__ __forceinline__ void normalise(Cell &c, int eref) {
+    const float vmax = fmaxf(fmaxf(c.m, c.sx), fmaxf(fmaxf(c.sy, c.lx), c.ly));
+    if (vmax > 0.0f) {
+        int k;
+        (void)__builtin_frexpf(vmax, &k);
+        c.m = __builtin_ldexpf(c.m, -k);
+        c.sx = __builtin_ldexpf(c.sx, -k);
+        c.sy = __builtin_ldexpf(c.sy, -k);
+        c.lx = __builtin_ldexpf(c.lx, -k);
+        c.ly = __builtin_ldexpf(c.ly, -k);
+        c.e = eref + k;
+    } else {
+        c = dead_cell();
+    }
+}
+
+// transition probabilities held in registers (wave-uniform)
+struct Trans {
+    float mm, sxm, sym, lxm, lym;  // -> match
+    float msx, sxsx, sysx;         // -> shortGapX
+    float msy, sysy, sxsy;         // -> shortGapY
+    float mlx, lxlx;               // -> longGapX
+    float mly, lyly;               // -> longGapY
+};
+
+__device__ __forceinline__ Trans load_trans(const float *T) {
+    Trans t;
+    t.mm = T[0], t.msx = T[1], t.msy = T[2], t.mlx = T[3], t.mly = T[4];
+    t.sxm = T[5], t.sxsx = T[6], t.sxsy = T[7];
+    t.sym = T[10], t.sysx = T[11], t.sysy = T[12];
+    t.lxm = T[15], t.lxlx = T[18];
+    t.lym = T[20], t.lyly = T[24];
+    return t;
+}
+
+// forward: L = (x-1,y), M = (x-1,y-1), U = (x,y-1); em/exs/exl/eys/eyl the emissions of the bases consumed
+__device__ __forceinline__ Cell fwd_cell(const Trans &t, const Cell &L, const Cell &M, const Cell &U, float em,
+                                         float exs, float exl, float eys, float eyl) {
+    const int eref = max(L.e, max(M.e, U.e));
+    const float fL = scale2(L.e - eref), fM = scale2(M.e - eref), fU = scale2(U.e - eref);
+    Cell c;
+    float a;
+    a = t.mm * M.m;
+    a = __builtin_fmaf(t.sxm, M.sx, a);
+    a = __builtin_fmaf(t.sym, M.sy, a);
+    a = __builtin_fmaf(t.lxm, M.lx, a);
+    a = __builtin_fmaf(t.lym, M.ly, a);
+    c.m = (fM * em) * a;
+    a = t.msx * L.m;
+    a = __builtin_fmaf(t.sxsx, L.sx, a);
+    a = __builtin_fmaf(t.sysx, L.sy, a);
+    c.sx = (fL * exs) * a;
+    a = t.mlx * L.m;
+    a = __builtin_fmaf(t.lxlx, L.lx, a);
+    c.lx = (fL * exl) * a;
+    a = t.msy * U.m;
+    a = __builtin_fmaf(t.sysy, U.sy, a);
+    a = __builtin_fmaf(t.sxsy, U.sx, a);
+    c.sy = (fU * eys) * a;
+    a = t.mly * U.m;
+    a = __builtin_fmaf(t.lyly, U.ly, a);
+    c.ly = (fU * eyl) * a;
+    normalise(c, eref);
+    return c;
+}
+
+// backward: Ms = (x+1,y+1), Xs = (x+1,y), Ys = (x,y+1); emissions of the bases those moves consume
+__device__ __forceinline__ Cell bwd_cell(const Trans &t, const Cell &Ms, const Cell &Xs, const Cell &Ys, float em,
+                                         float exs, float exl, float eys, float eyl) {
+    const int eref = max(Ms.e, max(Xs.e, Ys.e));
+    const float fM = scale2(Ms.e - eref), fX = scale2(Xs.e - eref), fY = scale2(Ys.e - eref);
+    const float am = (fM * em) * Ms.m;
+    const float asx = (fX * exs) * Xs.sx;
+    const float alx = (fX * exl) * Xs.lx;
+    const float asy = (fY * eys) * Ys.sy;
+    const float aly = (fY * eyl) * Ys.ly;
+    Cell c;
+    float b;
+    b = t.mm * am;
+    b = __builtin_fmaf(t.msx, asx, b);
+    b = __builtin_fmaf(t.mlx, alx, b);
+    b = __builtin_fmaf(t.msy, asy, b);
+    b = __builtin_fmaf(t.mly, aly, b);
+    c.m = b;
+    b = t.sxm * am;
+    b = __builtin_fmaf(t.sxsx, asx, b);
+    b = __builtin_fmaf(t.sxsy, asy, b);
+    c.sx = b;
+    b = t.sym * am;
+    b = __builtin_fmaf(t.sysy, asy, b);
+    b = __builtin_fmaf(t.sysx, asx, b);
+    c.sy = b;
+    b = t.lxm * am;
+    b = __builtin_fmaf(t.lxlx, alx, b);
+    c.lx = b;
+    b = t.lym * am;
+    b = __builtin_fmaf(t.lyly, aly, b);
+    c.ly = b;
+    normalise(c, eref);
+    return c;
+}
+
+__device__ __forceinline__ float dot5(const float *w, const Cell &c) {
+    float a = w[0] * c.m;
+    a = __builtin_fmaf(w[1], c.sx, a);
+    a = __builtin_fmaf(w[2], c.sy, a);
+    a = __builtin_fmaf(w[3], c.lx, a);
+    a = __builtin_fmaf(w[4], c.ly, a);
+    return a;
+}
+
+// posterior match probability of a cell: (Fv*Bv) * 2^(eF+eB-eTot) * (1/totMant)
+__device__ __forceinline__ float posterior(float fv, int fe, float bv, int be, int tot_e, float inv_tot) {
+    int s = fe + be - tot_e;
+    s = min(max(s, -200), 200);
+    return __builtin_ldexpf(fv * bv, s) * inv_tot;
+}
+
+}  // namespace npr

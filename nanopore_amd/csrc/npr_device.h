@@ -1,0 +1,75 @@
+// npr_device.h -- structures shared between the host API and the HIP kernels of libnprealign.
+#pragma once
+#include <cstdint>
+
+#include "npr_internal.h"
+
+namespace npr {
+
+// One banded DP problem on the device (a Segment of a read).
+struct Task {
+    int64_t x_off;     // first reference base code of the segment in d_seq
+    int64_t y_off;     // first read base code of the segment in d_seq
+    int64_t band_off;  // first anti-diagonal entry in d_lo / d_n / d_coff
+    int64_t pair_off;  // first slot of this task in the posterior pair buffers
+    int32_t lX, lY;    // segment spans
+    int32_t D;         // lX + lY
+    int32_t pair_cap;  // slots available at pair_off
+    int32_t flags;     // bit0 ragged start, bit1 ragged end
+    int32_t model;     // model slot
+    int32_t xs, ys;    // offset of the segment inside the read's slice (added to emitted coordinates)
+    int32_t read;      // owning read
+    int32_t cells_pad; // padded cell count (scratch use)
+};
+
+struct TaskOut {
+    float tot_m;      // total probability = tot_m * 2^tot_e (forward)
+    int32_t tot_e;
+    float btot_m;     // same from the backward pass
+    int32_t btot_e;
+    int32_t npairs;   // pairs >= threshold found (may exceed pair_cap -> status NPR_ERR_CAPACITY)
+    int32_t status;
+};
+
+struct KernelArgs {
+    const Task *tasks;
+    TaskOut *outs;
+    int32_t *queue;  // work-queue head
+    int32_t ntasks;
+    const DevModel *models;
+    const uint8_t *seq;
+    const int32_t *lo;
+    const int32_t *n;
+    const uint32_t *coff;  // per anti-diagonal: offset of its first cell inside the task (cells padded to x4)
+    float *Fv;             // forward match-state scratch, one region of slot_stride cells per resident wave
+    int32_t *Fe;
+    int64_t slot_stride;
+    int32_t *px;  // sparse posterior output
+    int32_t *py;
+    float *pp;
+    float threshold;
+    int32_t wcap;  // ring capacity (cells per anti-diagonal) of the generic kernel
+    float *Bv;     // dense dump of the backward match state (debug launches only)
+    int32_t *Be;
+};
+
+struct CompactArgs {
+    const Task *tasks;
+    const TaskOut *outs;
+    const int64_t *dst_off;
+    int32_t ntasks;
+    const int32_t *px;
+    const int32_t *py;
+    const float *pp;
+    int32_t *cx;
+    int32_t *cy;
+    float *cp;
+};
+
+// launchers (npr_kernels.hip)
+int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, void *stream);
+int launch_compact(const CompactArgs &a, void *stream);
+size_t generic_lds_bytes(int wcap);
+int generic_max_wcap();
+
+}  // namespace npr

@@ -1,0 +1,286 @@
+// npr_kernels.hip -- HIP kernels of libnprealign for gfx950 (MI355X, CDNA4).
+//
+// k_dp_generic: the banded five-state pair-HMM forward / backward / posterior pass of cactus_realign
+// (reference call sites nanopore/analyses/utils.py:587,
+// alignmentUncertainty.py:41, marginAlignSnpCaller.py:136-146) for ARBITRARY bands.
+//   * one DP problem (task) per 64-lane wavefront; lanes stride over the cells of an anti-diagonal;
+//   * the two previous anti-diagonals live in an LDS ring (SoA, conflict-free), HMM tables in LDS;
+//   * persistent wavefronts pull tasks from an atomic queue (tasks are sorted longest-first);
+//   * forward and backward of a task are fused in one launch: the forward match-state values are
+//     streamed to a per-wavefront HBM scratch region (coalesced) and streamed back by the backward sweep,
+//     which emits the sparse posterior list by ballot/popcount compaction.
+// No MFMA: this is a recurrence, not a contraction.
+#include <hip/hip_runtime.h>
+
+#include "npr_cell.h"
+#include "npr_device.h"
+
+namespace npr {
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int MODEL_FLOATS = sizeof(DevModel) / sizeof(float);
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct Ring {
+    float *base;
+    int wcap;
+    __device__ __forceinline__ float *comp(int slot, int c) const { return base + (slot * 6 + c) * wcap; }
+    __device__ __forceinline__ Cell get(int slot, int j) const {
+        Cell c;
+        c.m = comp(slot, 0)[j];
+        c.sx = comp(slot, 1)[j];
+        c.sy = comp(slot, 2)[j];
+        c.lx = comp(slot, 3)[j];
+        c.ly = comp(slot, 4)[j];
+        c.e = reinterpret_cast<const int *>(comp(slot, 5))[j];
+        return c;
+    }
+    __device__ __forceinline__ void put(int slot, int j, const Cell &c) const {
+        comp(slot, 0)[j] = c.m;
+        comp(slot, 1)[j] = c.sx;
+        comp(slot, 2)[j] = c.sy;
+        comp(slot, 3)[j] = c.lx;
+        comp(slot, 4)[j] = c.ly;
+        reinterpret_cast<int *>(comp(slot, 5))[j] = c.e;
+    }
+};
+
+// index of the cell with in-diagonal coordinate xmy on a diagonal whose band is (lo, n); -1 if outside
+__device__ __forceinline__ int band_index(int xmy, int lo, int n) {
+    const int t = xmy - lo;
+    const int j = t >> 1;
+    return (t >= 0 && j < n) ? j : -1;
+}
+
+template <bool DENSE>
+__global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ring ring{reinterpret_cast<float *>(smem), a.wcap};
+    float *lmodel = reinterpret_cast<float *>(smem) + 18 * a.wcap;
+    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..1] totals hand-off
+
+    const int lane = threadIdx.x;
+    float *const Fv = a.Fv + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
+    int32_t *const Fe = a.Fe + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
+
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(a.queue, 1);
+        t = uniform(t);
+        if (t >= a.ntasks) break;
+        const Task tk = a.tasks[t];
+        const int lX = tk.lX, lY = tk.lY, D = tk.D;
+        const uint8_t *X = a.seq + tk.x_off;
+        const uint8_t *Y = a.seq + tk.y_off;
+        const int32_t *blo = a.lo + tk.band_off;
+        const int32_t *bn = a.n + tk.band_off;
+        const uint32_t *bco = a.coff + tk.band_off;
+        const int rs = tk.flags & 1, re = (tk.flags >> 1) & 1;
+
+        __syncthreads();  // previous task's LDS reads are done
+        {
+            const float *gm = reinterpret_cast<const float *>(a.models + tk.model);
+            for (int i = lane; i < MODEL_FLOATS; i += WAVE) lmodel[i] = gm[i];
+        }
+        __syncthreads();
+        const DevModel *mdl = reinterpret_cast<const DevModel *>(lmodel);
+        const Trans tr = load_trans(mdl->T);
+
+        // ------------------------------- forward -------------------------------
+        int lo1 = 0, n1 = 0, lo2 = 0, n2 = 0;  // bands of d-1 and d-2
+        for (int d = 0; d <= D; ++d) {
+            const int lo = blo[d], n = bn[d];
+            const uint32_t co = bco[d];
+            const int cur = d % 3, s1 = (d + 2) % 3, s2 = (d + 1) % 3;
+            for (int j = lane; j < n; j += WAVE) {
+                const int xmy = lo + 2 * j;
+                const int x = (d + xmy) >> 1, y = (d - xmy) >> 1;
+                Cell c = dead_cell();
+                if (x >= 0 && y >= 0 && x <= lX && y <= lY) {
+                    if (d == 0) {
+                        c.m = mdl->start[rs * 5 + 0];
+                        c.sx = mdl->start[rs * 5 + 1];
+                        c.sy = mdl->start[rs * 5 + 2];
+                        c.lx = mdl->start[rs * 5 + 3];
+                        c.ly = mdl->start[rs * 5 + 4];
+                        normalise(c, 0);
+                    } else {
+                        const int jL = (x > 0 && d >= 1) ? band_index(xmy - 1, lo1, n1) : -1;
+                        const int jU = (y > 0 && d >= 1) ? band_index(xmy + 1, lo1, n1) : -1;
+                        const int jM = (x > 0 && y > 0 && d >= 2) ? band_index(xmy, lo2, n2) : -1;
+                        const Cell L = jL >= 0 ? ring.get(s1, jL) : dead_cell();
+                        const Cell U = jU >= 0 ? ring.get(s1, jU) : dead_cell();
+                        const Cell M = jM >= 0 ? ring.get(s2, jM) : dead_cell();
+                        const int cx = x > 0 ? X[x - 1] : 4, cy = y > 0 ? Y[y - 1] : 4;
+                        c = fwd_cell(tr, L, M, U, mdl->em[cx * 5 + cy], mdl->ex[5 + cx], mdl->ex[15 + cx],
+                                     mdl->ey[10 + cy], mdl->ey[20 + cy]);
+                    }
+                }
+                ring.put(cur, j, c);
+                Fv[co + j] = c.m;
+                Fe[co + j] = c.e;
+            }
+            __syncthreads();
+            lo2 = lo1, n2 = n1, lo1 = lo, n1 = n;
+        }
+        // total probability at the end corner (lX, lY) of anti-diagonal D
+        if (lane == 0) {
+            float tm = 0.f;
+            int te = E_DEAD;
+            const int je = band_index(lX - lY, lo1, n1);
+            if (je >= 0) {
+                const Cell c = ring.get(D % 3, je);
+                const float raw = dot5(mdl->end + re * 5, c);
+                if (raw > 0.f) {
+                    int k;
+                    tm = __builtin_frexpf(raw, &k);
+                    te = c.e + k;
+                }
+            }
+            reinterpret_cast<float *>(lmisc)[0] = tm;
+            lmisc[1] = te;
+        }
+        __syncthreads();
+        const float tot_m = reinterpret_cast<float *>(lmisc)[0];
+        const int tot_e = lmisc[1];
+        __syncthreads();
+
+        TaskOut out;
+        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
+        out.status = NPR_OK;
+        if (!(tot_m > 0.f)) {
+            out.status = NPR_ERR_ZERO_PROB;
+            if (lane == 0) a.outs[t] = out;
+            continue;
+        }
+
+        // ------------------------------- backward + posteriors -------------------------------
+        const float inv_tot = 1.0f / tot_m;
+        int cnt = 0;
+        lo1 = n1 = lo2 = n2 = 0;  // bands of d+1 and d+2
+        for (int d = D; d >= 0; --d) {
+            const int lo = blo[d], n = bn[d];
+            const uint32_t co = bco[d];
+            const int cur = d % 3, s1 = (d + 1) % 3, s2 = (d + 2) % 3;
+            for (int j0 = 0; j0 < n; j0 += WAVE) {
+                const int j = j0 + lane;
+                bool hit = false;
+                float p = 0.f;
+                int x = 0, y = 0;
+                if (j < n) {
+                    const int xmy = lo + 2 * j;
+                    x = (d + xmy) >> 1, y = (d - xmy) >> 1;
+                    Cell c = dead_cell();
+                    if (x >= 0 && y >= 0 && x <= lX && y <= lY) {
+                        if (d == D) {
+                            c.m = mdl->end[re * 5 + 0];
+                            c.sx = mdl->end[re * 5 + 1];
+                            c.sy = mdl->end[re * 5 + 2];
+                            c.lx = mdl->end[re * 5 + 3];
+                            c.ly = mdl->end[re * 5 + 4];
+                            normalise(c, 0);
+                        } else {
+                            const int jX = (x < lX) ? band_index(xmy + 1, lo1, n1) : -1;
+                            const int jY = (y < lY) ? band_index(xmy - 1, lo1, n1) : -1;
+                            const int jM = (x < lX && y < lY && d + 2 <= D) ? band_index(xmy, lo2, n2) : -1;
+                            const Cell Xs = jX >= 0 ? ring.get(s1, jX) : dead_cell();
+                            const Cell Ys = jY >= 0 ? ring.get(s1, jY) : dead_cell();
+                            const Cell Ms = jM >= 0 ? ring.get(s2, jM) : dead_cell();
+                            const int cx = x < lX ? X[x] : 4, cy = y < lY ? Y[y] : 4;
+                            c = bwd_cell(tr, Ms, Xs, Ys, mdl->em[cx * 5 + cy], mdl->ex[5 + cx], mdl->ex[15 + cx],
+                                         mdl->ey[10 + cy], mdl->ey[20 + cy]);
+                        }
+                        if (x >= 1 && y >= 1) {
+                            p = posterior(Fv[co + j], Fe[co + j], c.m, c.e, tot_e, inv_tot);
+                            hit = p >= a.threshold;
+                        }
+                    }
+                    ring.put(cur, j, c);
+                    if (DENSE) {
+                        a.Bv[co + j] = c.m;
+                        a.Be[co + j] = c.e;
+                    }
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                    const int slot = cnt + rank;
+                    if (hit && slot < tk.pair_cap) {
+                        a.px[tk.pair_off + slot] = x - 1 + tk.xs;
+                        a.py[tk.pair_off + slot] = y - 1 + tk.ys;
+                        a.pp[tk.pair_off + slot] = p;
+                    }
+                    cnt += __popcll(mask);
+                }
+            }
+            __syncthreads();
+            lo2 = lo1, n2 = n1, lo1 = lo, n1 = n;
+        }
+        if (lane == 0) {
+            const int j0 = band_index(0, lo1, n1);
+            if (j0 >= 0) {
+                const Cell c = ring.get(0, j0);
+                const float raw = dot5(mdl->start + rs * 5, c);
+                if (raw > 0.f) {
+                    int k;
+                    out.btot_m = __builtin_frexpf(raw, &k);
+                    out.btot_e = c.e + k;
+                }
+            }
+            out.npairs = cnt;
+            if (cnt > tk.pair_cap) out.status = NPR_ERR_CAPACITY;
+            a.outs[t] = out;
+        }
+    }
+}
+
+// gathers each task's posterior pairs into one dense buffer for a single D2H copy
+__global__ void __launch_bounds__(256) k_compact(CompactArgs a) {
+    for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
+        const Task tk = a.tasks[t];
+        const int n = min(a.outs[t].npairs, tk.pair_cap);
+        const int64_t dst = a.dst_off[t];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            a.cx[dst + i] = a.px[tk.pair_off + i];
+            a.cy[dst + i] = a.py[tk.pair_off + i];
+            a.cp[dst + i] = a.pp[tk.pair_off + i];
+        }
+    }
+}
+
+}  // namespace
+
+size_t generic_lds_bytes(int wcap) { return sizeof(float) * (18 * static_cast<size_t>(wcap) + MODEL_FLOATS + 4); }
+
+int generic_max_wcap() {
+    // 160 KiB of LDS per workgroup on gfx950
+    return static_cast<int>((160 * 1024 / sizeof(float) - MODEL_FLOATS - 4) / 18) & ~3;
+}
+
+int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (dense) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+        if (e != hipSuccess) return static_cast<int>(e);
+        hipLaunchKernelGGL(k_dp_generic<true>, dim3(grid), dim3(WAVE), lds_bytes, s, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+        if (e != hipSuccess) return static_cast<int>(e);
+        hipLaunchKernelGGL(k_dp_generic<false>, dim3(grid), dim3(WAVE), lds_bytes, s, a);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_compact(const CompactArgs &a, void *stream) {
+    const int grid = a.ntasks < 4096 ? (a.ntasks > 0 ? a.ntasks : 1) : 4096;
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace npr

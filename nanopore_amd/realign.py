@@ -1,0 +1,286 @@
+"""Batched realignment API over the C ABI (libnprealign.so).
+
+`Context.realign()` is the in-process replacement of the reference's per-read fan-out
+(nanopore/analyses/utils.py:557-609: one jobTree job + one `cactus_realign` process per SAM record):
+all reads of a SAM file go to the GPU in one call.  Device work only -- no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BAND_ANCHOR, BAND_FIXED, MODE_ALL_POSTERIORS, MODE_REALIGN, MODE_RESCORE_ORIGINAL, NprError,
+                   Params, ptr)
+
+
+def make_params(band_mode=BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000,
+                fixed_width=0, gap_gamma=0.5, match_gamma=0.0, posterior_threshold=0.01, mode=MODE_REALIGN,
+                max_pairs_per_base=0):
+    """Defaults are the realign call string of nanopore/analyses/utils.py:587 and
+    AbstractMapper.realignSamFile's gammas (nanopore/mappers/abstractMapper.py:25)."""
+    return Params(band_mode, diagonal_expansion, constraint_trim, split_threshold, fixed_width, gap_gamma,
+                  match_gamma, posterior_threshold, mode, max_pairs_per_base)
+
+
+def _csr(seqs):
+    """list of bytes/str -> (uint8 buffer, int64 offsets)."""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    buf = np.empty(int(off[-1]), dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        if isinstance(s, str):
+            s = s.encode("ascii")
+        buf[off[i]:off[i + 1]] = np.frombuffer(s, dtype=np.uint8) if not isinstance(s, np.ndarray) else s
+    return buf, off
+
+
+def _csr_ops(guides):
+    lens = np.fromiter((len(g) for g in guides), dtype=np.int64, count=len(guides))
+    off = np.zeros(len(guides) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    ops = np.zeros((int(off[-1]), 2), dtype=np.int32)
+    for i, g in enumerate(guides):
+        if len(g):
+            ops[off[i]:off[i + 1]] = np.asarray(g, dtype=np.int32).reshape(-1, 2)
+    return ops, off
+
+
+class Batch(object):
+    """A staged batch: inputs resident in HBM after construction."""
+
+    def __init__(self, ctx, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None):
+        self._L = _lib.load()
+        self.ctx = ctx
+        self.n_reads = len(ref_off) - 1
+        self._keep = (ref, ref_off, read, read_off, guide_ops, guide_off, model_slot)
+        h = C.c_void_p()
+        rc = self._L.npr_batch_create(ctx._h, C.byref(params), self.n_reads, ptr(ref), ptr(ref_off), ptr(read),
+                                      ptr(read_off), ptr(guide_ops), ptr(guide_off), ptr(model_slot), C.byref(h))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_create", ctx.last_error())
+        self._h = h
+
+    def stats(self):
+        st = _lib.BatchStats()
+        self._L.npr_batch_get_stats(self._h, C.byref(st))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def run(self):
+        """Device DP pass (forward + backward + posterior extraction).  Returns kernel milliseconds
+        measured with HIP events on the library's stream."""
+        ms = C.c_float(0)
+        rc = self._L.npr_batch_run(self._h, C.byref(ms))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_run", self.ctx.last_error())
+        return ms.value
+
+    def finish(self):
+        rc = self._L.npr_batch_finish(self._h)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_finish", self.ctx.last_error())
+
+    def results(self):
+        out = np.zeros(self.n_reads, dtype=_lib.RESULT_DTYPE)
+        assert out.dtype.itemsize == C.sizeof(_lib.ReadResult)
+        rc = self._L.npr_batch_results(self._h, ptr(out))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_results")
+        return out
+
+    def ops(self):
+        """-> (ops_off[n+1], ops[k,2]) CSR of output cigars."""
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        rc = self._L.npr_batch_ops(self._h, ptr(off), None, 0)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_ops")
+        ops = np.zeros((int(off[-1]), 2), dtype=np.int32)
+        rc = self._L.npr_batch_ops(self._h, ptr(off), ptr(ops), len(ops))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_ops")
+        return off, ops
+
+    def pairs(self):
+        """-> (pair_off[n+1], x, y, p) sparse posterior match probabilities sorted by (x, y)."""
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        rc = self._L.npr_batch_pairs(self._h, ptr(off), None, None, None, 0)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_pairs")
+        k = int(off[-1])
+        x = np.zeros(k, dtype=np.int32)
+        y = np.zeros(k, dtype=np.int32)
+        p = np.zeros(k, dtype=np.float32)
+        rc = self._L.npr_batch_pairs(self._h, ptr(off), ptr(x), ptr(y), ptr(p), k)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_pairs")
+        return off, x, y, p
+
+    def dense(self, read_index, cells):
+        fv = np.zeros(cells, dtype=np.float32)
+        fe = np.zeros(cells, dtype=np.int32)
+        bv = np.zeros(cells, dtype=np.float32)
+        be = np.zeros(cells, dtype=np.int32)
+        rc = self._L.npr_batch_dense(self._h, read_index, ptr(fv), ptr(fe), ptr(bv), ptr(be), cells)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_dense", self.ctx.last_error())
+        return fv, fe, bv, be
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.npr_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One realigner context = one GPU + one HIP stream.  Raises if no gfx950 device is usable."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self._L.npr_create(device, C.byref(h), err, 512)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_create", err.value.decode(errors="replace"))
+        self._h = h
+        self.device = device
+
+    def last_error(self):
+        return self._L.npr_last_error(self._h).decode(errors="replace")
+
+    def set_hmm(self, hmm=None, slot=0):
+        """hmm: object with .transitions (25) and .emissions (80) (nanopore_amd.hmm.Hmm), or None for
+        the stock model used when the reference passes no --loadHmm."""
+        if hmm is None:
+            rc = self._L.npr_set_hmm(self._h, slot, None, None)
+        else:
+            T = np.ascontiguousarray(hmm.transitions, dtype=np.float64)
+            E = np.ascontiguousarray(hmm.emissions, dtype=np.float64)
+            if T.size != 25 or E.size != 80:
+                raise ValueError("HMM must have 25 transitions and 80 emissions")
+            rc = self._L.npr_set_hmm(self._h, slot, ptr(T), ptr(E))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_set_hmm", self.last_error())
+
+    def stage(self, params, refs, reads, guides, model_slot=None):
+        """refs/reads: lists of ASCII sequences (str/bytes); guides: list of [(op,len),...]."""
+        ref, ref_off = _csr(refs)
+        read, read_off = _csr(reads)
+        gops, goff = _csr_ops(guides)
+        ms = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
+        return Batch(self, params, ref, ref_off, read, read_off, gops, goff, ms)
+
+    def stage_csr(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None):
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        read = np.ascontiguousarray(read, dtype=np.uint8)
+        ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        guide_ops = np.ascontiguousarray(guide_ops, dtype=np.int32).reshape(-1, 2)
+        guide_off = np.ascontiguousarray(guide_off, dtype=np.int64)
+        ms = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
+        return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms)
+
+    def realign(self, params, refs, reads, guides, model_slot=None, want_pairs=False):
+        """One batched call: returns list of dicts (status, score, loglik, cells, ops[, x, y, p])."""
+        b = self.stage(params, refs, reads, guides, model_slot)
+        try:
+            b.run()
+            b.finish()
+            res = b.results()
+            off, ops = b.ops()
+            out = []
+            if want_pairs:
+                poff, x, y, p = b.pairs()
+            for i in range(b.n_reads):
+                d = dict(status=int(res["status"][i]), score=float(res["score"][i]), loglik=float(res["loglik"][i]),
+                         loglik_bwd=float(res["loglik_bwd"][i]), cells=int(res["cells"][i]),
+                         n_segments=int(res["n_segments"][i]),
+                         ops=[(int(a), int(c)) for a, c in ops[off[i]:off[i + 1]]])
+                if want_pairs:
+                    d["x"] = x[poff[i]:poff[i + 1]].copy()
+                    d["y"] = y[poff[i]:poff[i + 1]].copy()
+                    d["p"] = p[poff[i]:poff[i + 1]].copy()
+                out.append(d)
+            return out
+        finally:
+            b.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.npr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- host logic (no GPU needed) ----
+
+def plan(params, lX, lY, guide):
+    L = _lib.load()
+    g = np.ascontiguousarray(np.asarray(guide, dtype=np.int32).reshape(-1, 2))
+    h = C.c_void_p()
+    rc = L.npr_plan_create(C.byref(params), lX, lY, ptr(g), len(g), C.byref(h))
+    if rc != _lib.OK:
+        raise NprError(rc, "npr_plan_create")
+    out = []
+    try:
+        for s in range(L.npr_plan_segments(h)):
+            info = np.zeros(8, dtype=np.int64)
+            L.npr_plan_segment_info(h, s, ptr(info))
+            D = int(info[6])
+            lo = np.zeros(D + 1, dtype=np.int32)
+            n = np.zeros(D + 1, dtype=np.int32)
+            L.npr_plan_segment_band(h, s, ptr(lo), ptr(n))
+            out.append(dict(xs=int(info[0]), ys=int(info[1]), xe=int(info[2]), ye=int(info[3]),
+                            ragged_start=int(info[4]), ragged_end=int(info[5]), D=D, cells=int(info[7]), lo=lo,
+                            n=n))
+    finally:
+        L.npr_plan_destroy(h)
+    return out
+
+
+def mea_cigar(lX, lY, x, y, p, gap_gamma=0.5, match_gamma=0.0):
+    L = _lib.load()
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    cap = 2 * len(x) + 8
+    ops = np.zeros((cap, 2), dtype=np.int32)
+    score = C.c_double(0)
+    k = L.npr_mea_cigar(lX, lY, ptr(x), ptr(y), ptr(p), len(x), gap_gamma, match_gamma, ptr(ops), cap,
+                        C.byref(score))
+    if k < 0:
+        raise NprError(int(k), "npr_mea_cigar")
+    return [(int(a), int(c)) for a, c in ops[:k]], score.value
+
+
+def rescore(guide, x, y, p):
+    L = _lib.load()
+    g = np.ascontiguousarray(np.asarray(guide, dtype=np.int32).reshape(-1, 2))
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    score = C.c_double(0)
+    rc = L.npr_rescore(ptr(g), len(g), ptr(x), ptr(y), ptr(p), len(x), C.byref(score))
+    if rc != _lib.OK:
+        raise NprError(rc, "npr_rescore")
+    return score.value
+
+
+def encode(seq):
+    L = _lib.load()
+    if isinstance(seq, str):
+        seq = seq.encode("ascii")
+    a = np.frombuffer(seq, dtype=np.uint8)
+    out = np.zeros(len(a), dtype=np.uint8)
+    L.npr_encode_bases(ptr(a), len(a), ptr(out))
+    return out

@@ -1,0 +1,136 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Two bars (DESIGN.md "Parity"):
+  * bit-exact against the oracle's fp32 mirror of the device arithmetic (posteriors, totals, dense
+    forward/backward values, cigars);
+  * within 1e-4 of the double-precision log-space oracle on posteriors and renormalised log-probabilities.
+"""
+import numpy as np
+import pytest
+
+from helpers import load_model_arrays, oracle_hmm, orc, random_pair, cigar_spans
+
+pytestmark = pytest.mark.gpu
+
+LN2 = np.log(2.0)
+
+
+def _hmm_obj(name):
+    from nanopore_amd.hmm import Hmm
+    from helpers import MODEL_DIR
+    import os
+    return Hmm.loadHmm(os.path.join(MODEL_DIR, name))
+
+
+def _pairs_dict(x, y, p):
+    return {(int(a), int(b)): float(c) for a, b, c in zip(x, y, p)}
+
+
+def _run_case(gpu_ctx, rng, n_reads, lmin, lmax, kw, model="blasr_hmm_0.txt", indel=0.12, max_indel=4):
+    from nanopore_amd import realign as R
+    gpu_ctx.set_hmm(_hmm_obj(model))
+    h = oracle_hmm(model)
+    refs, reads, guides, raw = [], [], [], []
+    for _ in range(n_reads):
+        X, Y, ops = random_pair(rng, int(rng.integers(lmin, lmax + 1)), indel=indel, max_indel=max_indel)
+        raw.append((X, Y, ops))
+        refs.append(bytes(b"ACGT"[c] for c in X))
+        reads.append(bytes(b"ACGT"[c] for c in Y))
+        guides.append(ops)
+    out = gpu_ctx.realign(R.make_params(**kw), refs, reads, guides, want_pairs=True)
+    okw = dict(kw)
+    okw.pop("max_pairs_per_base", None)
+    P = orc.make_params(**okw)
+    for (X, Y, ops), g in zip(raw, out):
+        m32 = orc.realign_read(h, P, X, Y, ops, precision=1)
+        m64 = orc.realign_read(h, P, X, Y, ops, precision=0)
+        assert g["status"] == 0 and m32["status"] == 0 and m64["status"] == 0
+        assert g["cells"] == m32["cells"] == m64["cells"]
+        # --- bit-exact against the fp32 mirror ---
+        gp = _pairs_dict(g["x"], g["y"], g["p"])
+        mp = _pairs_dict(m32["px"], m32["py"], m32["pp"].astype(np.float32))
+        assert gp.keys() == mp.keys()
+        assert all(np.float32(gp[k]) == np.float32(mp[k]) for k in gp), "posterior differs from fp32 mirror"
+        assert g["ops"] == m32["ops"], "cigar differs from fp32 mirror"
+        assert g["score"] == pytest.approx(m32["score"], abs=1e-12)
+        assert g["loglik"] == pytest.approx(m32["total_ll"], rel=1e-12, abs=1e-9)
+        # --- tolerance against the fp64 log-space oracle ---
+        dp = _pairs_dict(m64["px"], m64["py"], m64["pp"])
+        for k in set(gp) | set(dp):
+            a, b = gp.get(k), dp.get(k)
+            if a is None or b is None:
+                # a pair may sit on either side of the 0.01 threshold
+                assert abs((a if a is not None else b) - kw.get("posterior_threshold", 0.01)) < 1e-4
+            else:
+                assert abs(a - b) < 1e-4
+        assert g["loglik"] == pytest.approx(m64["total_ll"], rel=2e-6)
+        assert g["loglik_bwd"] == pytest.approx(g["loglik"], rel=2e-6)
+        assert cigar_spans(g["ops"]) == (len(X), len(Y))
+    return out
+
+
+def test_fixed_band_small(gpu_ctx):
+    rng = np.random.default_rng(11)
+    _run_case(gpu_ctx, rng, 24, 5, 300, dict(band_mode=1, fixed_width=40))
+
+
+def test_fixed_band_wider_than_wave(gpu_ctx):
+    rng = np.random.default_rng(12)
+    _run_case(gpu_ctx, rng, 8, 300, 600, dict(band_mode=1, fixed_width=200))
+    _run_case(gpu_ctx, rng, 4, 300, 500, dict(band_mode=1, fixed_width=700))
+
+
+def test_anchor_band_with_splits(gpu_ctx):
+    rng = np.random.default_rng(13)
+    _run_case(gpu_ctx, rng, 16, 50, 500, dict(band_mode=0, diagonal_expansion=10, constraint_trim=2,
+                                             split_threshold=12), indel=0.2, max_indel=40)
+    _run_case(gpu_ctx, rng, 8, 200, 800, dict(band_mode=0, diagonal_expansion=10, constraint_trim=14,
+                                            split_threshold=3000))
+
+
+def test_models_20_40_and_stock(gpu_ctx):
+    rng = np.random.default_rng(14)
+    for m in ("blasr_hmm_20.txt", "blasr_hmm_40.txt"):
+        _run_case(gpu_ctx, rng, 6, 100, 300, dict(band_mode=1, fixed_width=60), model=m)
+
+
+def test_dense_forward_backward_bit_exact(gpu_ctx):
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(15)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    h = oracle_hmm()
+    X, Y, ops = random_pair(rng, 400)
+    kw = dict(band_mode=1, fixed_width=100)
+    seg = orc.plan(len(X), len(Y), ops, orc.make_params(**kw))[0]
+    b = gpu_ctx.stage(R.make_params(**kw), [bytes(b"ACGT"[c] for c in X)], [bytes(b"ACGT"[c] for c in Y)], [ops])
+    fv, fe, bv, be = b.dense(0, seg["cells"])
+    b.close()
+    m = orc.fb_f32(h, X, Y, seg["lo"], seg["n"])
+    assert (fe == m["Fm_e"]).all() and (fv == m["Fm_v"]).all()
+    assert (be == m["Bm_e"]).all() and (bv == m["Bm_v"]).all()
+    # renormalised log-probabilities vs the fp64 oracle: subtract the per-read maximum (an offset)
+    d = orc.fb_f64(h, X, Y, seg["lo"], seg["n"])
+    alive = np.isfinite(d["Fm"]) & (fv > 0)
+    lf = (np.log2(fv[alive].astype(np.float64)) + fe[alive]) * LN2
+    assert np.abs((lf - d["Fm"][alive])).max() < 1e-4
+    aliveb = np.isfinite(d["Bm"]) & (bv > 0)
+    lb = (np.log2(bv[aliveb].astype(np.float64)) + be[aliveb]) * LN2
+    assert np.abs((lb - d["Bm"][aliveb])).max() < 1e-4
+
+
+def test_edge_cases(gpu_ctx):
+    from nanopore_amd import realign as R
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    P = R.make_params(band_mode=1, fixed_width=20)
+    # single base, pure insertion / deletion guides, N bases, an invalid (non-global) guide
+    refs = [b"A", b"ACGT", b"ACGTNNACGT", b"ACGTACGT", b"ACGT"]
+    reads = [b"A", b"ACGTTT", b"ACGTNNACGT", b"ACG", b"ACGT"]
+    guides = [[(0, 1)], [(0, 4), (1, 2)], [(0, 10)], [(0, 3), (2, 5)], [(0, 3)]]
+    out = gpu_ctx.realign(P, refs, reads, guides)
+    assert [o["status"] for o in out[:4]] == [0, 0, 0, 0]
+    assert out[4]["status"] == -1  # guide does not span the sequences: per-read error, batch survives
+    for o, r, q in zip(out[:4], refs, reads):
+        assert cigar_spans(o["ops"]) == (len(r), len(q))
+    assert out[0]["ops"] == [(0, 1)]
+    # empty batch
+    assert gpu_ctx.realign(P, [], [], []) == []
