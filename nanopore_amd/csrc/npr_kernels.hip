@@ -22,7 +22,32 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int MODEL_FLOATS = sizeof(DevModel) / sizeof(float);
 
+// Wave-uniform values are forced into SGPRs explicitly.  Left to itself hipcc keeps values loaded through
+// the vector path (the task descriptor, band rows) in VGPRs and wraps their scalar uses in waterfall loops
+// -- around the whole task body here, which both serialises and (ROCm 7.2) hangs the kernel.
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniformf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+    return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// the task descriptor with every field in SGPRs
+struct UTask {
+    int64_t x_off, y_off, band_off, pair_off;
+    int lX, lY, D, pair_cap, flags, model, xs, ys;
+};
+__device__ __forceinline__ UTask load_task(const Task *p) {
+    UTask u;
+    u.x_off = uniform64(p->x_off), u.y_off = uniform64(p->y_off);
+    u.band_off = uniform64(p->band_off), u.pair_off = uniform64(p->pair_off);
+    u.lX = uniform(p->lX), u.lY = uniform(p->lY), u.D = uniform(p->D), u.pair_cap = uniform(p->pair_cap);
+    u.flags = uniform(p->flags), u.model = uniform(p->model), u.xs = uniform(p->xs), u.ys = uniform(p->ys);
+    return u;
+}
 
 struct Ring {
     float *base;
@@ -66,12 +91,12 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
     float *const Fv = a.Fv + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
     int32_t *const Fe = a.Fe + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
 
-    for (;;) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(a.queue, 1);
-        t = uniform(t);
-        if (t >= a.ntasks) break;
-        const Task tk = a.tasks[t];
+    // The first task of every wavefront is static (t = blockIdx.x); later ones come from the atomic queue.
+    // The loop is kept free of break/continue and every loop-carried value is an SGPR: with a divergent
+    // fetch at the loop head hipcc (ROCm 7.2) structurised the task loop as a divergent loop and hung.
+    int t = blockIdx.x;
+    while (t < a.ntasks) {
+        const UTask tk = load_task(a.tasks + t);
         const int lX = tk.lX, lY = tk.lY, D = tk.D;
         const uint8_t *X = a.seq + tk.x_off;
         const uint8_t *Y = a.seq + tk.y_off;
@@ -92,8 +117,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
         // ------------------------------- forward -------------------------------
         int lo1 = 0, n1 = 0, lo2 = 0, n2 = 0;  // bands of d-1 and d-2
         for (int d = 0; d <= D; ++d) {
-            const int lo = blo[d], n = bn[d];
-            const uint32_t co = bco[d];
+            const int lo = uniform(blo[d]), n = uniform(bn[d]);
+            const uint32_t co = static_cast<uint32_t>(uniform(static_cast<int>(bco[d])));
             const int cur = d % 3, s1 = (d + 2) % 3, s2 = (d + 1) % 3;
             for (int j = lane; j < n; j += WAVE) {
                 const int xmy = lo + 2 * j;
@@ -144,26 +169,23 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             lmisc[1] = te;
         }
         __syncthreads();
-        const float tot_m = reinterpret_cast<float *>(lmisc)[0];
-        const int tot_e = lmisc[1];
+        const float tot_m = uniformf(reinterpret_cast<float *>(lmisc)[0]);
+        const int tot_e = uniform(lmisc[1]);
         __syncthreads();
 
         TaskOut out;
         out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
         out.status = NPR_OK;
-        if (!(tot_m > 0.f)) {
-            out.status = NPR_ERR_ZERO_PROB;
-            if (lane == 0) a.outs[t] = out;
-            continue;
-        }
+        const bool alive = tot_m > 0.f;  // wave-uniform (SGPR compare)
+        if (!alive) out.status = NPR_ERR_ZERO_PROB;
 
         // ------------------------------- backward + posteriors -------------------------------
         const float inv_tot = 1.0f / tot_m;
         int cnt = 0;
         lo1 = n1 = lo2 = n2 = 0;  // bands of d+1 and d+2
-        for (int d = D; d >= 0; --d) {
-            const int lo = blo[d], n = bn[d];
-            const uint32_t co = bco[d];
+        for (int d = alive ? D : -1; d >= 0; --d) {
+            const int lo = uniform(blo[d]), n = uniform(bn[d]);
+            const uint32_t co = static_cast<uint32_t>(uniform(static_cast<int>(bco[d])));
             const int cur = d % 3, s1 = (d + 1) % 3, s2 = (d + 2) % 3;
             for (int j0 = 0; j0 < n; j0 += WAVE) {
                 const int j = j0 + lane;
@@ -220,7 +242,7 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             lo2 = lo1, n2 = n1, lo1 = lo, n1 = n;
         }
         if (lane == 0) {
-            const int j0 = band_index(0, lo1, n1);
+            const int j0 = alive ? band_index(0, lo1, n1) : -1;
             if (j0 >= 0) {
                 const Cell c = ring.get(0, j0);
                 const float raw = dot5(mdl->start + rs * 5, c);
@@ -234,13 +256,17 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             if (cnt > tk.pair_cap) out.status = NPR_ERR_CAPACITY;
             a.outs[t] = out;
         }
+        // next task
+        int nt = 0;
+        if (lane == 0) nt = atomicAdd(a.queue, 1);
+        t = uniform(nt) + static_cast<int>(gridDim.x);
     }
 }
 
 // gathers each task's posterior pairs into one dense buffer for a single D2H copy
 __global__ void __launch_bounds__(256) k_compact(CompactArgs a) {
     for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
-        const Task tk = a.tasks[t];
+        const UTask tk = load_task(a.tasks + t);
         const int n = min(a.outs[t].npairs, tk.pair_cap);
         const int64_t dst = a.dst_off[t];
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
