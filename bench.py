@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X realigner.
+
+Metric (BASELINE.json): banded pair-HMM DP cells/s (whole job), plus reads/s.  A "step" is one pass of the
+hot path -- forward + backward + posterior extraction of every read of one synthetic batch -- with the
+inputs already resident in HBM (npr_batch_run).  Default workload: the shape the north-star target is
+quoted on, ~10 kb reads x 50 kb reference slices, band 200, blasr_hmm_0 (BASELINE.md section 3,
+"north-star shape"); `--workload c2` runs BASELINE.json configs[1] (1 k reads x 1 kb, band 100).
+
+    python bench.py --gpus N --steps K --warmup W
+N>1 is launched by torch.distributed.run, one rank per GPU; reads shard over ranks with no data-path
+collective (weak scaling: every rank realigns its own batch of the same shape); one RCCL gather of the packed
+per-read results to rank 0 closes the job (summary only, outside the timed steps).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+BYTES_PER_CELL = 40.0   # fp32 forward store 5x4 B + backward-time reload 5x4 B
+
+
+def load_model(name="blasr_hmm_0.txt"):
+    from nanopore_amd.hmm import Hmm
+    return Hmm.loadHmm(os.path.join(ROOT, "nanopore_amd", "mappers", name))
+
+
+def build_workload(name, n_reads, rank):
+    from nanopore_amd import synth
+    h = load_model()
+    if name == "northstar":
+        w, W = synth.config_north_star(h.transitions, h.emissions, n_reads=n_reads, seed=1003 + 7919 * rank)
+        label = "synthetic ~10kb reads x 50kb reference slices, band 200, blasr_hmm_0 (north-star shape)"
+    elif name == "c2":
+        w, W = synth.make_workload(1001 + 7919 * rank, n_reads, 1000, h.transitions, h.emissions), 100
+        label = "synthetic 1k reads x 1kb, band 100, blasr_hmm_0 (BASELINE.json configs[1])"
+    elif name == "c3":
+        w, W = synth.config_c3(h.transitions, h.emissions, n_reads=n_reads)
+        label = "synthetic E. coli-sized reference x ~8kb reads, band 200 (BASELINE.json configs[2])"
+    else:
+        raise SystemExit("unknown workload %s" % name)
+    return h, w, W, label
+
+
+def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
+    """The build's fp64 log-space CPU oracle (kind "port": the reference binary cactus_realign is absent from
+    the snapshot) timed on this host's cores over a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    from nanopore_amd.realign import encode
+    cores = os.cpu_count() or 1
+    oh = orc.make_hmm(h.transitions, h.emissions)
+    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
+
+    def run(k):
+        X = encode(bytes(w["ref"][:w["ref_off"][k]]))
+        Y = encode(bytes(w["read"][:w["read_off"][k]]))
+        t0 = time.time()
+        r = orc.realign_batch(oh, P, X, w["ref_off"][:k + 1], Y, w["read_off"][:k + 1],
+                              w["guide_ops"][:w["guide_off"][k]], w["guide_off"][:k + 1], precision=0,
+                              threads=cores, native=True)
+        return r, time.time() - t0
+
+    # pilot (one read per core) to size the timed sample for ~budget_s of wall time
+    n = len(cells_per_read)
+    k0 = min(n, cores)
+    r, dt = run(k0)
+    rate = float(r["cells"].sum()) / max(dt, 1e-3)
+    k = int(min(n, max(k0, round(rate * budget_s / max(float(np.mean(cells_per_read)), 1.0)))))
+    if k > k0:
+        r, dt = run(k)
+    cells = int(r["cells"].sum())
+    return {"value": cells / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the same batch (%d cells), fp64 log-space oracle, OpenMP over reads, "
+                      "gcc -O3 -march=native, %.1f s" % (k, cells, dt)}, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3"])
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 4096 northstar, 1000 c2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from nanopore_amd import realign as R
+    n_reads = args.reads or {"northstar": 4096, "c2": 1000, "c3": 50000}[args.workload]
+    h, w, W, label = build_workload(args.workload, n_reads, rank)
+    ctx = R.Context(local_rank)
+    ctx.set_hmm(h)
+    batch = ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"],
+                          w["read_off"], w["guide_ops"], w["guide_off"])
+    st = batch.stats()
+    cells = st["cells"]
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(batch.run())  # blocks until the DP launch has finished on the library's stream
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([cells, n_reads], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_cells, total_reads = int(c[0].item()), int(c[1].item())
+    else:
+        total_cells, total_reads = cells, n_reads
+
+    # close the job: results to the host, MEA cigars, and the one gather the path has (summary to rank 0)
+    t1 = time.perf_counter()
+    batch.finish()
+    res = batch.results()
+    finish_s = time.perf_counter() - t1
+    gather_ms = None
+    if dist is not None:
+        from nanopore_amd import dist as npd
+        off, ops = batch.ops()
+        payload = npd.pack_results(np.arange(n_reads) + rank * n_reads, res["status"], res["score"], off, ops)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        got = npd.gather_to_root(payload, device="cuda:%d" % local_rank)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            status, _, _ = npd.merge_in_input_order(got, n_reads * world)
+            assert (status == 0).all()
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        kms = float(np.mean(kernel_ms))
+        achieved = BYTES_PER_CELL * cells / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "DP cells/sec (banded pair-HMM realign: forward + backward + posterior per cell)",
+            "value": total_cells * args.steps / elapsed,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": label, "reads_per_gpu": n_reads, "band": W, "cells_per_gpu": int(cells),
+                       "tasks": int(st["n_tasks"]), "resident_wavefronts": int(st["slots"]),
+                       "kernel_variant": int(st["kernel_variant"]), "parallelism": "reads sharded x%d" % world},
+            "reads_per_s": total_reads * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_dp", "kernel_ms": kms, "algorithmic_bytes_per_cell": BYTES_PER_CELL},
+            "ok_reads": int((res["status"] == 0).sum()),
+            "finish_s": finish_s,
+            "gather_ms": gather_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, r = cpu_baseline(h, w, W, res["cells"])
+            out["cpu_baseline"] = cb
+            # the sample doubles as an end-of-run parity probe: GPU cigars vs the fp64 oracle's
+            off, ops = batch.ops()
+            k = len(r["ops"])
+            same = sum(1 for i in range(k) if np.array_equal(ops[off[i]:off[i + 1]], r["ops"][i]))
+            out["cigar_identical_to_fp64_oracle"] = "%d/%d" % (same, k)
+        print(json.dumps(out))
+    batch.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -293,6 +293,19 @@ static inline double logadd(double a, double b) {
     return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
 }
 
+/* Per-thread scratch that only grows: the forward array of a 10 kb x band-200 read is 160 MB, and a fresh
+ * malloc/free of that per read turns the multi-threaded baseline into a page-fault benchmark. */
+static _Thread_local double *tl_buf[2] = {NULL, NULL};
+static _Thread_local size_t tl_cap[2] = {0, 0};
+static double *scratch(int which, size_t n) {
+    if (tl_cap[which] < n) {
+        free(tl_buf[which]);
+        tl_buf[which] = (double *)malloc(sizeof(double) * n);
+        tl_cap[which] = tl_buf[which] ? n : 0;
+    }
+    return tl_buf[which];
+}
+
 /* move type of the destination state: 0 = diagonal (match), 1 = x only, 2 = y only */
 static const int MOVE[5] = {0, 1, 2, 1, 2};
 
@@ -318,7 +331,7 @@ int32_t orc_fb_f64(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
     off[0] = 0;
     for (int64_t d = 0; d <= D; d++) off[d + 1] = off[d] + n[d];
     const int64_t cells = off[D + 1];
-    double *F = (double *)malloc(sizeof(double) * 5 * (size_t)cells);
+    double *F = scratch(0, 5 * (size_t)cells);
     int32_t rc = 0;
 
     /* ---- forward (a5.3) ---- */
@@ -372,7 +385,7 @@ int32_t orc_fb_f64(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
         for (int64_t d = 0; d <= D; d++)
             if (n[d] > wmax) wmax = n[d];
         double *ring = (double *)malloc(sizeof(double) * 5 * 3 * (size_t)wmax);
-        double *Bmatch = (double *)malloc(sizeof(double) * (size_t)cells);
+        double *Bmatch = scratch(1, (size_t)cells);
         double totb = NEG_INF;
         for (int64_t d = D; d >= 0; d--) {
             double *cur = ring + 5 * wmax * (d % 3);
@@ -439,10 +452,8 @@ int32_t orc_fb_f64(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
                 }
             }
         }
-        free(Bmatch);
     }
     if (npairs) *npairs = np;
-    free(F);
     free(off);
     return rc;
 }
