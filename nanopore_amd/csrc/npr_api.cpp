@@ -129,6 +129,8 @@ struct npr_batch {
     int grid = 0;
     int wcap = 0;
     size_t lds_bytes = 0;
+    int variant = 0;  // 0 generic LDS-ring kernel, 1 register staircase kernel
+    int stair_R = 0;
     bool ran = false, finished = false;
     // results
     std::vector<npr_read_result> results;
@@ -331,6 +333,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->task_cells.resize(ntasks);
     std::vector<int64_t> band_base(ntasks);
     int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
+    bool all_stair = true;
     for (int64_t k = 0; k < ntasks; ++k) {
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
@@ -355,6 +358,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         b->task_cells[k] = s.cells;
         total_cells += s.cells;
         max_width = std::max<int64_t>(max_width, s.max_width);
+        all_stair = all_stair && s.staircase;
     }
     std::vector<int32_t> h_lo(band_entries), h_n(band_entries);
     std::vector<uint32_t> h_coff(band_entries);
@@ -381,8 +385,18 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     b->wcap = static_cast<int>((std::max<int64_t>(max_width, 64) + 3) & ~int64_t(3));
     b->lds_bytes = generic_lds_bytes(b->wcap);
-    const int waves_by_lds = static_cast<int>(std::max<size_t>(1, (160 * 1024) / (b->lds_bytes + 256)));
-    const int waves_per_cu = std::min(16, waves_by_lds);
+    // kernel choice: the register kernel needs staircase bands of at most 256 cells per anti-diagonal
+    const char *force = std::getenv("NPR_KERNEL");  // "generic" forces the LDS-ring kernel (A/B runs, tests)
+    b->variant = (all_stair && max_width <= 256 && ntasks > 0 && !(force && std::strcmp(force, "generic") == 0)) ? 1 : 0;
+    b->stair_R = max_width <= 64 ? 1 : (max_width <= 128 ? 2 : 4);
+    int waves_per_cu;
+    if (b->variant == 1) {
+        waves_per_cu = b->stair_R == 1 ? 24 : (b->stair_R == 2 ? 16 : 8);
+    } else {
+        const int waves_by_lds = static_cast<int>(std::max<size_t>(1, (160 * 1024) / (b->lds_bytes + 256)));
+        waves_per_cu = std::min(16, waves_by_lds);
+    }
+    if (const char *w = std::getenv("NPR_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(w));
     int64_t grid = std::min<int64_t>(ntasks, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
     grid = std::max<int64_t>(grid, 1);
     b->slot_stride = (max_pad + 63) & ~int64_t(63);
@@ -419,7 +433,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->stats.diagonals = band_entries;
     b->stats.max_width = max_width;
     b->stats.slots = grid;
-    b->stats.kernel_variant = 0;
+    b->stats.kernel_variant = b->variant;
     b->stats.device_bytes = fixed + b->slot_stride * grid * 8;
     *out = b.release();
     return NPR_OK;
@@ -458,8 +472,9 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     }
     HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 4, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    const int rc = launch_generic(make_args(b), b->grid, b->lds_bytes, false, ctx->stream);
-    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_generic launch", static_cast<hipError_t>(rc));
+    const int rc = b->variant == 1 ? launch_stair(make_args(b), b->stair_R, b->grid, ctx->stream)
+                                   : launch_generic(make_args(b), b->grid, b->lds_bytes, false, ctx->stream);
+    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));

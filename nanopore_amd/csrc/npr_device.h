@@ -69,6 +69,8 @@ struct CompactArgs {
 // launchers (npr_kernels.hip)
 int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, void *stream);
 int launch_compact(const CompactArgs &a, void *stream);
+int launch_stair(const KernelArgs &a, int R, int grid, void *stream);
+size_t stair_lds_bytes();
 size_t generic_lds_bytes(int wcap);
 int generic_max_wcap();
 

@@ -41,6 +41,14 @@ void finish_segment(Segment &s) {
         s.cells += w;
         s.max_width = std::max(s.max_width, w);
     }
+    s.staircase = true;
+    for (size_t d = 1; d < s.lo.size(); ++d) {
+        const int32_t step = s.lo[d] - s.lo[d - 1];
+        if (step != 1 && step != -1) {
+            s.staircase = false;
+            break;
+        }
+    }
 }
 
 // Band of a segment from its chain of lattice points pts[0]=(0,0) ... pts.back()=(lX,lY) (segment-local,

@@ -20,6 +20,7 @@ struct Segment {
     std::vector<int32_t> n;   // [D+1] in-band cells on each anti-diagonal
     int64_t cells = 0;
     int32_t max_width = 0;
+    bool staircase = true;  // consecutive diagonals' first x-y differ by exactly +-1 (register kernel eligible)
     int64_t D() const { return (xe - xs) + (ye - ys); }
 };
 

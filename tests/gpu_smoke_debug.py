@@ -25,3 +25,11 @@ print('ran', ms, flush=True)
 b.finish()
 print('finished', b.results(), flush=True)
 print(b.ops())
+off, x, y, p = b.pairs()
+print('pairs', len(x), 'lX', len(X), 'lY', len(Y))
+print(np.stack([x, y]).T[:30].tolist())
+print(p[:30].tolist())
+os.environ['NPR_KERNEL'] = 'generic'
+b2 = ctx.stage(P, [bytes(b"ACGT"[c] for c in X)], [bytes(b"ACGT"[c] for c in Y)], [ops])
+b2.run(); b2.finish(); off2, x2, y2, p2 = b2.pairs()
+print('generic pairs', len(x2)); print(np.stack([x2, y2]).T[:30].tolist()); print(p2[:30].tolist())

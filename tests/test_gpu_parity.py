@@ -77,7 +77,21 @@ def test_fixed_band_small(gpu_ctx):
 def test_fixed_band_wider_than_wave(gpu_ctx):
     rng = np.random.default_rng(12)
     _run_case(gpu_ctx, rng, 8, 300, 600, dict(band_mode=1, fixed_width=200))
-    _run_case(gpu_ctx, rng, 4, 300, 500, dict(band_mode=1, fixed_width=700))
+    _run_case(gpu_ctx, rng, 4, 300, 500, dict(band_mode=1, fixed_width=700))  # generic kernel (> 256 cells)
+    _run_case(gpu_ctx, rng, 4, 400, 700, dict(band_mode=1, fixed_width=400))  # register kernel, 4 cells per lane
+
+
+def test_generic_and_register_kernels_agree(gpu_ctx, monkeypatch):
+    """The LDS-ring kernel (any band) and the register staircase kernel share the cell arithmetic: forcing
+    the generic kernel on a staircase batch must reproduce the same bits."""
+    rng = np.random.default_rng(16)
+    st = np.random.default_rng(16).bit_generator.state
+    a = _run_case(gpu_ctx, rng, 6, 200, 900, dict(band_mode=1, fixed_width=100), indel=0.2, max_indel=30)
+    monkeypatch.setenv("NPR_KERNEL", "generic")
+    rng2 = np.random.default_rng(16)
+    b = _run_case(gpu_ctx, rng2, 6, 200, 900, dict(band_mode=1, fixed_width=100), indel=0.2, max_indel=30)
+    for u, v in zip(a, b):
+        assert u["ops"] == v["ops"] and np.array_equal(u["p"], v["p"]) and u["loglik"] == v["loglik"]
 
 
 def test_anchor_band_with_splits(gpu_ctx):
