@@ -1,0 +1,86 @@
+"""Multi-GPU path on CPU: world_size 2 over gloo.  Reads shard with no data-path collective; one
+variable-length gather brings packed results to rank 0 where the input order is restored."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nanopore_amd import dist as npd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_results(idx):
+    """Deterministic per-read results a rank would produce for its reads."""
+    status = (idx % 7 == 3).astype(np.int64) * -2
+    score = idx / 100.0
+    nops = idx % 4 + 1
+    off = np.zeros(len(idx) + 1, dtype=np.int64)
+    np.cumsum(nops, out=off[1:])
+    ops = np.zeros((int(off[-1]), 2), dtype=np.int32)
+    for k, i in enumerate(idx):
+        for j in range(int(nops[k])):
+            ops[off[k] + j] = (j % 3, int(i) + j + 1)
+    return status, score, off, ops
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    work = np.arange(n_total)[::-1] % 13 + 1
+    mine = npd.shard_indices(work, world, rank)
+    status, score, off, ops = _fake_results(mine)
+    got = npd.gather_to_root(npd.pack_results(mine, status, score, off, ops))
+    if rank == 0:
+        st, sc, ol = npd.merge_in_input_order(got, n_total)
+        q.put((st.tolist(), sc.tolist(), [o.tolist() for o in ol]))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shards_partition_and_balance():
+    work = np.random.default_rng(1).integers(1, 1000, size=1001)
+    parts = [npd.shard_indices(work, 8, r) for r in range(8)]
+    allidx = np.sort(np.concatenate(parts))
+    assert (allidx == np.arange(1001)).all()
+    loads = np.array([work[p].sum() for p in parts])
+    assert loads.max() / loads.mean() < 1.05
+
+
+def test_pack_unpack_round_trip():
+    idx = np.array([5, 9, 2])
+    status, score, off, ops = _fake_results(idx)
+    rec, o = npd.unpack_results(npd.pack_results(idx, status, score, off, ops))
+    assert rec["idx"].tolist() == [5, 9, 2] and (o == ops).all() and rec["nops"].tolist() == (off[1:] - off[:-1]).tolist()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gather_restores_input_order():
+    n_total = 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    st, sc, ol = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    status, score, off, ops = _fake_results(np.arange(n_total))
+    assert st == status.tolist() and sc == score.tolist()
+    for i in range(n_total):
+        assert ol[i] == ops[off[i]:off[i + 1]].tolist()

@@ -1,0 +1,203 @@
+"""The CPU oracle checked against an independent implementation and against its own invariants.
+
+The reference holds no golden vectors for this path (PARITY UNPINNED), so the oracle is pinned
+by (1) an independent unbanded probability-space numpy forward/backward written differently on purpose
+(helpers.full_matrix_reference), (2) invariants the algorithm must satisfy, (3) the committed golden
+fixtures (test_golden.py).
+"""
+import numpy as np
+import pytest
+
+from helpers import cigar_spans, full_matrix_reference, load_model_arrays, oracle_hmm, orc, random_pair
+
+LN2 = np.log(2.0)
+
+
+@pytest.mark.parametrize("model", ["blasr_hmm_0.txt", "blasr_hmm_20.txt", "blasr_hmm_40.txt"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_full_band_matches_independent_numpy(model, seed):
+    rng = np.random.default_rng(seed)
+    T, E, _ = load_model_arrays(model)
+    h = orc.make_hmm(T, E)
+    X, Y, ops = random_pair(rng, int(rng.integers(5, 45)))
+    seg = orc.plan(len(X), len(Y), ops, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=10000))[0]
+    assert seg["cells"] == (len(X) + 1) * (len(Y) + 1)
+    r = orc.fb_f64(h, X, Y, seg["lo"], seg["n"])
+    tot, post, _, _ = full_matrix_reference(T, E, X, Y)
+    assert r["rc"] == 0
+    assert r["total_ll"] == pytest.approx(np.log(tot), abs=1e-10)
+    assert r["total_ll_bwd"] == pytest.approx(np.log(tot), abs=1e-10)
+    ref = {(x, y): post[x, y] for x in range(len(X)) for y in range(len(Y)) if post[x, y] >= 0.01}
+    got = {(int(x), int(y)): p for x, y, p in zip(r["px"], r["py"], r["pp"])}
+    assert got.keys() == ref.keys()
+    assert max(abs(ref[k] - got[k]) for k in ref) < 1e-11
+
+
+def test_dense_stock_like_model_with_switch_transitions():
+    """A model that uses all 15 transitions of the five-state cell update (short-gap switches non-zero)."""
+    rng = np.random.default_rng(5)
+    from nanopore_amd.hmm import stockHmm
+    s = stockHmm()
+    h = orc.make_hmm(s.transitions, s.emissions)
+    X, Y, ops = random_pair(rng, 30)
+    seg = orc.plan(len(X), len(Y), ops, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=10000))[0]
+    r = orc.fb_f64(h, X, Y, seg["lo"], seg["n"])
+    tot, post, _, _ = full_matrix_reference(s.transitions, s.emissions, X, Y)
+    assert r["total_ll"] == pytest.approx(np.log(tot), abs=1e-10)
+    m = orc.fb_f32(h, X, Y, seg["lo"], seg["n"])
+    assert (np.log2(m["tot_m"]) + m["tot_e"]) * LN2 == pytest.approx(np.log(tot), abs=1e-4)
+    got = {(int(x), int(y)): p for x, y, p in zip(m["px"], m["py"], m["pp"])}
+    for (x, y), p in got.items():
+        assert abs(post[x, y] - p) < 1e-5
+
+
+def test_ragged_ends_against_numpy():
+    rng = np.random.default_rng(6)
+    T, E, _ = load_model_arrays()
+    Tm = T.reshape(5, 5)
+    h = orc.make_hmm(T, E)
+    X, Y, ops = random_pair(rng, 25)
+    seg = orc.plan(len(X), len(Y), ops, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=10000))[0]
+    r = orc.fb_f64(h, X, Y, seg["lo"], seg["n"], ragged_start=1, ragged_end=1)
+    start = np.array([0, 0, 0, 1.0, 1.0])
+    end = np.array([Tm[0, 3], Tm[0, 3], Tm[0, 4], Tm[3, 3], Tm[4, 4]])
+    tot, post, _, _ = full_matrix_reference(T, E, X, Y, start=start, end=end)
+    assert r["total_ll"] == pytest.approx(np.log(tot), abs=1e-10)
+    assert r["total_ll_bwd"] == pytest.approx(np.log(tot), abs=1e-10)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_banded_invariants_and_fp32_mirror(seed):
+    rng = np.random.default_rng(100 + seed)
+    h = oracle_hmm()
+    X, Y, ops = random_pair(rng, int(rng.integers(50, 600)), indel=0.15, max_indel=12)
+    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=int(rng.choice([20, 64, 100, 200])))
+    seg = orc.plan(len(X), len(Y), ops, P)[0]
+    r = orc.fb_f64(h, X, Y, seg["lo"], seg["n"])
+    assert r["rc"] == 0
+    assert r["total_ll_bwd"] == pytest.approx(r["total_ll"], rel=1e-12)      # F-total == B-total
+    assert ((r["pp"] >= 0.01) & (r["pp"] <= 1.0 + 1e-9)).all()
+    rowsum = np.bincount(r["py"], weights=r["pp"], minlength=len(Y))
+    colsum = np.bincount(r["px"], weights=r["pp"], minlength=len(X))
+    assert rowsum.max() <= 1.0 + 1e-9 and colsum.max() <= 1.0 + 1e-9          # a base pairs at most once
+    m = orc.fb_f32(h, X, Y, seg["lo"], seg["n"])
+    assert m["rc"] == 0
+    ll32 = (np.log2(m["tot_m"]) + m["tot_e"]) * LN2
+    assert ll32 == pytest.approx(r["total_ll"], rel=2e-6)
+    d64 = {(int(x), int(y)): p for x, y, p in zip(r["px"], r["py"], r["pp"])}
+    d32 = {(int(x), int(y)): float(p) for x, y, p in zip(m["px"], m["py"], m["pp"])}
+    for k in set(d64) | set(d32):
+        a, b = d64.get(k), d32.get(k)
+        if a is None or b is None:
+            assert abs((a if a is not None else b) - 0.01) < 1e-4
+        else:
+            assert abs(a - b) < 1e-4
+    # renormalised log-probabilities: the tolerance north_star states (1e-4) on every live cell
+    alive = np.isfinite(r["Fm"]) & (m["Fm_v"] > 0)
+    lf = (np.log2(m["Fm_v"][alive].astype(np.float64)) + m["Fm_e"][alive]) * LN2
+    assert np.abs(lf - r["Fm"][alive]).max() < 1e-4
+    alive = np.isfinite(r["Bm"]) & (m["Bm_v"] > 0)
+    lb = (np.log2(m["Bm_v"][alive].astype(np.float64)) + m["Bm_e"][alive]) * LN2
+    assert np.abs(lb - r["Bm"][alive]).max() < 1e-4
+    # dead cells agree
+    assert ((m["Fm_v"] == 0) == ~np.isfinite(r["Fm"])).all()
+
+
+def _check_band(seg, lX, lY):
+    lo, n, D = seg["lo"].astype(np.int64), seg["n"].astype(np.int64), seg["D"]
+    d = np.arange(D + 1)
+    hi = lo + 2 * (n - 1)
+    assert (n >= 1).all()
+    assert ((lo - d) % 2 == 0).all()                                  # parity of the anti-diagonal
+    assert (lo >= np.maximum(-d, d - 2 * lY)).all() and (hi <= np.minimum(d, 2 * lX - d)).all()  # inside lattice
+    assert lo[0] == 0 and n[0] == 1 and lo[D] == lX - lY and n[D] == 1  # corners are in the band
+    # every diagonal can be reached from the previous one by an x- or a y-step
+    assert (np.maximum(lo[1:], lo[:-1] - 1) <= np.minimum(hi[1:], hi[:-1] + 1)).all()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_band_construction_invariants(seed):
+    rng = np.random.default_rng(200 + seed)
+    X, Y, ops = random_pair(rng, int(rng.integers(20, 500)), indel=0.2, max_indel=int(rng.integers(1, 60)))
+    for kw in (dict(band_mode=orc.BAND_FIXED, fixed_width=int(rng.integers(2, 80))),
+               dict(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=int(rng.integers(0, 5)),
+                    split_threshold=int(rng.integers(1, 40))),
+               dict(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)):
+        segs = orc.plan(len(X), len(Y), ops, orc.make_params(**kw))
+        assert segs[0]["xs"] == 0 and segs[0]["ys"] == 0 and segs[-1]["xe"] == len(X) and segs[-1]["ye"] == len(Y)
+        assert segs[0]["ragged_start"] == 0 and segs[-1]["ragged_end"] == 0
+        for a, b in zip(segs[:-1], segs[1:]):
+            assert a["ragged_end"] == 1 and b["ragged_start"] == 1
+            assert a["xe"] <= b["xs"] and a["ye"] <= b["ys"]                    # segments never overlap
+        for s in segs:
+            _check_band(s, s["xe"] - s["xs"], s["ye"] - s["ys"])
+        if kw["band_mode"] == orc.BAND_FIXED:
+            assert len(segs) == 1
+            lo = segs[0]["lo"].astype(np.int64)
+            assert (np.abs(np.diff(lo)) == 1).all()                           # a fixed-width band is a staircase
+
+
+def test_anchor_band_stripe_width_and_split():
+    # 200 matches, trim 0: a stripe of half-width diagonalExpansion around the main diagonal
+    ops = [(0, 200)]
+    s = orc.plan(200, 200, ops, orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=0))[0]
+    mid = s["n"][100:300]
+    assert set(mid.tolist()) == {11, 12}
+    # a 50 x 40 unanchored rectangle with threshold 20 (area 2000 > 400) is cut: both sides keep min(gap/2, 20)
+    ops = [(0, 30), (2, 50), (1, 40), (0, 30)]
+    segs = orc.plan(110, 100, ops, orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=0,
+                                                  split_threshold=20))
+    assert len(segs) == 2
+    assert (segs[0]["xe"], segs[0]["ye"]) == (30 + 20, 30 + 20)
+    assert (segs[1]["xs"], segs[1]["ys"]) == (81 - 20, 71 - 20)
+    # not global -> rejected (utils.py:381-382)
+    with pytest.raises(ValueError):
+        orc.plan(10, 10, [(0, 9)], orc.make_params())
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_mea_fenwick_equals_bruteforce_and_cigar_is_global(seed):
+    rng = np.random.default_rng(300 + seed)
+    h = oracle_hmm()
+    X, Y, ops = random_pair(rng, int(rng.integers(30, 400)), indel=0.2, max_indel=8)
+    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=60)
+    seg = orc.plan(len(X), len(Y), ops, P)[0]
+    r = orc.fb_f64(h, X, Y, seg["lo"], seg["n"])
+    for gg, mg in ((0.5, 0.0), (0.0, 0.0), (0.9, 0.3)):
+        a, sa = orc.mea_cigar(len(X), len(Y), r["px"], r["py"], r["pp"], gg, mg)
+        b, sb = orc.mea_cigar(len(X), len(Y), r["px"], r["py"], r["pp"], gg, mg, brute_force=True)
+        assert a == b and sa == sb
+        assert cigar_spans(a) == (len(X), len(Y))                               # utils.py:381-382 / :602
+        assert all(k > 0 for _, k in a) and all(a[i][0] != a[i + 1][0] for i in range(len(a) - 1))
+        assert 0.0 <= sa <= 1.0
+    # no pairs at all: everything is unaligned
+    assert orc.mea_cigar(7, 5, [], [], [])[0] == [(2, 7), (1, 5)]
+
+
+def test_identical_sequences_realign_to_all_match_and_rescore():
+    rng = np.random.default_rng(9)
+    h = oracle_hmm()
+    X = rng.integers(0, 4, size=300).astype(np.uint8)
+    ops = [(0, 300)]
+    P = orc.make_params(band_mode=orc.BAND_ANCHOR)
+    r = orc.realign_read(h, P, X, X, ops)
+    assert r["status"] == 0 and r["ops"] == [(0, 300)] and r["score"] > 0.95
+    P2 = orc.make_params(band_mode=orc.BAND_ANCHOR, split_threshold=100, mode=orc.MODE_RESCORE_ORIGINAL)
+    r2 = orc.realign_read(h, P2, X, X, ops)
+    assert r2["ops"] == ops                                                    # alignmentUncertainty.py:51-52
+    assert r2["score"] == pytest.approx(orc.rescore(ops, r2["px"], r2["py"], r2["pp"]))
+    assert r2["score"] == pytest.approx(r["score"], abs=1e-6)
+    # a guide that is wrong everywhere rescoring to ~0
+    bad = [(1, 300), (2, 300)]
+    r3 = orc.realign_read(h, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=40, mode=orc.MODE_RESCORE_ORIGINAL), X, X, bad)
+    assert r3["ops"] == bad and r3["score"] == 0.0
+
+
+def test_unsupported_transition_rejected_by_mirror():
+    T, E, _ = load_model_arrays()
+    T = T.copy()
+    T[3 * 5 + 1] = 0.01  # longGapX -> shortGapX is not part of the five-state cell update
+    h = orc.make_hmm(T, E)
+    m = orc.fb_f32(h, np.zeros(3, np.uint8), np.zeros(3, np.uint8), np.array([0, -1, -2, -1, 0, 1, 0], np.int32),
+                   np.array([1, 2, 3, 3, 3, 2, 1], np.int32))
+    assert m["rc"] == -4
