@@ -128,13 +128,18 @@ int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double 
 
 /* ---- batch: replaces the per-read fan-out / gather of utils.py:557-609 ---- */
 /* Stage 1 (host + H2D): band construction, packing, upload.  Sequences are ASCII (ACGT, any case; anything
- * else is N), reference slice i = ref[ref_off[i] .. ref_off[i+1]), read i likewise (aR.query, utils.py:570);
+ * else is N).  The reference side is a table of n_refs sequences, ref[ref_off[k] .. ref_off[k+1]) -- the
+ * contigs of the reference FASTA (argv[1] of cactus_realign) -- and read i is aligned against sequence
+ * ref_index[i] (the cigar's target name, utils.py:570); ref_index == NULL means n_refs == n_reads and read i
+ * uses sequence i (per-read slices).  read i = read[read_off[i] .. read_off[i+1]) (aR.query, utils.py:570);
  * guide i = (op,len) pairs guide_ops[2*guide_off[i] .. 2*guide_off[i+1]) and must be GLOBAL over both
- * sequences (the chained records of utils.py:313-386).  model_slot may be NULL (all 0). */
-int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
-                         const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
-                         const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
-                         npr_batch **out);
+ * sequences (the chained records of utils.py:313-386).  Only the parts of a reference sequence that a read's
+ * band touches are uploaded, so a 4.6 Mb contig shared by 50 k reads costs nothing extra.
+ * model_slot may be NULL (all 0). */
+int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                         const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                         const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                         const int64_t *guide_off, const int32_t *model_slot, npr_batch **out);
 /* Stage 2 (device): forward + backward + posterior extraction for every read of the batch; inputs are
  * resident in HBM.  Blocks until done; kernel_ms (nullable) receives the HIP-event time of the DP launch
  * measured on the context's stream.  May be called repeatedly (benchmarks). */
@@ -161,10 +166,11 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
                         int32_t *Bm_e, int64_t cap);
 
 /* One call = create + run + finish + copy-out + destroy, for callers that do not need staging. */
-int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
-                          const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
-                          const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
-                          npr_read_result *results, int64_t *ops_off, int32_t *ops, int64_t cap_op_pairs);
+int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                          const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                          const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                          const int64_t *guide_off, const int32_t *model_slot, npr_read_result *results,
+                          int64_t *ops_off, int32_t *ops, int64_t cap_op_pairs);
 
 /* ---- host logic, callable without a GPU (unit tests of the boundary) ---- */
 /* band / segmentation of one read (cactus_realign stages a5.1-a5.2 of SURVEY.md 8a) */

@@ -111,7 +111,7 @@ def load():
     L.npr_set_hmm.restype = i32
     L.npr_set_hmm.argtypes = [vp, i32, vp, vp]
     L.npr_batch_create.restype = i32
-    L.npr_batch_create.argtypes = [vp, C.POINTER(Params), i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.npr_batch_create.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.npr_batch_run.restype = i32
     L.npr_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
     L.npr_batch_finish.restype = i32
@@ -129,7 +129,7 @@ def load():
     L.npr_batch_dense.restype = i32
     L.npr_batch_dense.argtypes = [vp, i64, vp, vp, vp, vp, i64]
     L.npr_realign_batch.restype = i32
-    L.npr_realign_batch.argtypes = [vp, C.POINTER(Params), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]
+    L.npr_realign_batch.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]
     L.npr_plan_create.restype = i32
     L.npr_plan_create.argtypes = [C.POINTER(Params), i64, i64, vp, i64, C.POINTER(vp)]
     L.npr_plan_destroy.restype = None

@@ -1,0 +1,318 @@
+"""Host-side mirror of the part of nanopore/analyses/utils.py that sits on the realign path.
+
+Same function names, argument meaning and error behaviour as the reference, Python 3, no pysam / jobTree /
+sonLib (all absent from the snapshot).  What changes is the engine: where the reference fans out one jobTree
+job and one `cactus_realign` process per SAM record (utils.py:565-570, :576-589) and gathers temp cigar files
+(:591-609), `realignSamFile` sends every record of the SAM file to the GPU in ONE batched call through the C
+ABI (include/nprealign.h) and splices the returned cigars back in file order.
+
+Reference lines are cited per function.  There is no CPU fallback: without libnprealign.so and a gfx950
+device `realignSamFile` raises.
+"""
+import os
+import sys
+
+from .. import bioio
+from .. import sam as pysam  # attribute-compatible subset
+from ..bioio import (PairwiseAlignment, cigarRead, cigarReadFromString, fastaRead, fastaWrite, fastqRead,
+                     reverseComplement)
+from ..hmm import Hmm, SYMBOL_NUMBER
+from .hmm_math import (fromMatrix, modifyHmmEmissionsByExpectedVariationRate,  # noqa: F401  (re-exported)
+                       normaliseHmmByReferenceGCContent, setHmmIndelEmissionsToBeFlat, toMatrix)
+
+# cactus_realign options hard-coded in the reference's call strings
+REALIGN_DIAGONAL_EXPANSION = 10          # utils.py:587
+REALIGN_SPLIT_MATRIX_BIGGER_THAN = 3000  # utils.py:587
+ANALYSIS_SPLIT_MATRIX_BIGGER_THAN = 100  # alignmentUncertainty.py:41, marginAlignSnpCaller.py:136
+CONSTRAINT_DIAGONAL_TRIM = 14            # cactus_realign default, never overridden by the reference
+
+
+def pathToBaseNanoporeDir():
+    """Directory that holds the package (utils.py:76-79): model files live in <base>/nanopore_amd/mappers."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.dirname(os.path.dirname(here))
+
+
+def trainedModelPath(trainedModelFile):
+    """nanopore/mappers/<file> of the reference (abstractMapper.py:35)."""
+    return os.path.join(pathToBaseNanoporeDir(), "nanopore_amd", "mappers", trainedModelFile)
+
+
+def getFastaDictionary(fastaFile):
+    """First word of each FASTA header -> sequence; names must be unique (utils.py:233-238)."""
+    out = {}
+    for name, seq in fastaRead(fastaFile):
+        key = name.split()[0]
+        assert key not in out, "Duplicate fasta sequence name %s" % key
+        out[key] = seq
+    return out
+
+
+def getFastqDictionary(fastqFile):
+    """First word of each FASTQ header -> sequence (utils.py:240-245)."""
+    out = {}
+    for name, seq, _ in fastqRead(fastqFile):
+        key = name.split()[0]
+        assert key not in out, "Duplicate fastq sequence name %s" % key
+        out[key] = seq
+    return out
+
+
+def samIterator(sam):
+    """Records that have a reference (utils.py:287-293)."""
+    for aR in sam:
+        if aR.rname != -1:
+            yield aR
+
+
+def getAbsoluteReadOffset(alignedRead, refSeq, readSeq):
+    """Absolute coordinate in the read of the first non-clipped base; negative for reverse strand
+    (utils.py:157-166)."""
+    readOffset = alignedRead.cigar[0][1] if alignedRead.cigar[0][0] == 5 else 0
+    if alignedRead.is_reverse:
+        readOffset = -(len(readSeq) - 1 - readOffset)
+    return readOffset + alignedRead.qstart
+
+
+def getExonerateCigarFormatString(alignedRead, sam):
+    """SAM record -> exonerate cigar line, query (read) first, target (reference) second; only M/I/D survive,
+    clips are dropped; input score is the literal 1 (utils.py:168-180)."""
+    for op, length in alignedRead.cigar:
+        assert op in (0, 1, 2, 4, 5)
+    letters = {0: "M", 1: "I", 2: "D"}
+    cigarString = " ".join("%s %i" % (letters[op], length) for op, length in alignedRead.cigar if op in letters)
+    complete = "cigar: %s %i %i + %s %i %i + 1 %s" % (
+        alignedRead.qname, 0, alignedRead.qend - alignedRead.qstart, sam.getrname(alignedRead.rname), alignedRead.pos,
+        alignedRead.aend, cigarString)
+    pA = cigarReadFromString(complete)  # validates the line
+    matches = sum(op.length for op in pA.operationList if op.type == PairwiseAlignment.PAIRWISE_MATCH)
+    assert matches == sum(1 for q, r in alignedRead.aligned_pairs if q is not None and r is not None)
+    return complete
+
+
+# ---------------------------------------------------------------------------------------------------------
+# chaining: local hits -> one global alignment per (read, reference)
+# ---------------------------------------------------------------------------------------------------------
+
+def _blockCoordinates(aR, refSeq, readSeq):
+    """(first ref pos, first signed read pos, last ref pos, last signed read pos, #aligned pairs)."""
+    offset = getAbsoluteReadOffset(aR, refSeq, readSeq)
+    pairs = [(q, r) for q, r in aR.aligned_pairs if q is not None and r is not None and r < len(refSeq)]
+    sign = -1 if aR.is_reverse else 1
+    signed = lambda q: sign * abs(offset + q)  # noqa: E731
+    return pairs[0][1], signed(pairs[0][0]), pairs[-1][1], signed(pairs[-1][0]), len(pairs)
+
+
+def chainFn(alignedReads, refSeq, readSeq, scoreFn=None, maxGap=200):
+    """Highest-scoring co-linear chain of local alignments on one strand; score = number of aligned pairs;
+    two blocks chain when the second starts after the first ends in both sequences and the summed gap is at
+    most maxGap (utils.py:388-426; quadratic, like the reference)."""
+    coords = {id(aR): _blockCoordinates(aR, refSeq, readSeq) for aR in alignedReads}
+    own = {id(aR): (scoreFn(aR, refSeq, readSeq) if scoreFn else coords[id(aR)][4]) for aR in alignedReads}
+    best = dict(own)
+    back = {}
+    order = sorted(alignedReads, key=lambda aR: coords[id(aR)][0])
+    for i, aR in enumerate(order):
+        rStart, qStart, _, _, _ = coords[id(aR)]
+        for aR2 in order[:i]:
+            _, _, rEnd2, qEnd2, _ = coords[id(aR2)]
+            if (rStart > rEnd2 and qStart > qEnd2 and aR.is_reverse == aR2.is_reverse
+                    and rStart - rEnd2 + qStart - qEnd2 <= maxGap and own[id(aR)] + best[id(aR2)] > best[id(aR)]):
+                best[id(aR)] = own[id(aR)] + best[id(aR2)]
+                back[id(aR)] = aR2
+    aR = sorted(order, key=lambda a: best[id(a)])[-1]
+    chain = [aR]
+    while id(aR) in back:
+        aR = back[id(aR)]
+        chain.append(aR)
+    chain.reverse()
+    return chain
+
+
+def mergeChainedAlignedReads(chainedAlignedReads, refSequence, readSequence):
+    """One GLOBAL record for a chain: pos 0, SEQ = whole read (reverse-complemented for the minus strand),
+    cigar spanning the entire reference and the entire read with explicit D / I between and around the
+    blocks (utils.py:295-386; asserts :381-382)."""
+    first = chainedAlignedReads[0]
+    cAR = pysam.AlignedRead()
+    cAR.qname = first.qname
+    cAR.rname = first.rname
+    cAR.pos = 0
+    cAR.flag = 0x10 if first.is_reverse else 0
+    cAR.seq = reverseComplement(readSequence) if first.is_reverse else readSequence
+    cigarList = []
+    pPos = 0
+    pQPos = -(len(readSequence) - 1) if first.is_reverse else 0
+    for aR in chainedAlignedReads:
+        assert aR.is_reverse == first.is_reverse
+        assert aR.pos >= pPos
+        if aR.pos > pPos:
+            cigarList.append((2, aR.pos - pPos))
+            pPos = aR.pos
+        qPos = getAbsoluteReadOffset(aR, refSequence, readSequence)
+        assert qPos >= pQPos
+        if qPos > pQPos:
+            cigarList.append((1, qPos - pQPos))
+            pQPos = qPos
+        for op, length in aR.cigar:
+            assert op in (0, 1, 2, 4, 5)
+            if op in (0, 1, 2):
+                cigarList.append((op, length))
+            if op in (0, 2):
+                pPos += length
+            if op in (0, 1):
+                pQPos += length
+    assert pPos <= len(refSequence)
+    if pPos < len(refSequence):
+        cigarList.append((2, len(refSequence) - pPos))
+    if first.is_reverse:
+        assert pQPos <= 1
+        if pQPos < 1:
+            cigarList.append((1, 1 - pQPos))
+    else:
+        assert pQPos <= len(readSequence)
+        if pQPos < len(readSequence):
+            cigarList.append((1, len(readSequence) - pQPos))
+    # merge neighbours of the same type so that the record is a canonical cigar
+    merged = []
+    for op, length in cigarList:
+        if merged and merged[-1][0] == op:
+            merged[-1] = (op, merged[-1][1] + length)
+        else:
+            merged.append((op, length))
+    assert sum(n for op, n in merged if op in (0, 2)) == len(refSequence)
+    assert sum(n for op, n in merged if op in (0, 1)) == len(readSequence)
+    cAR.cigar = merged
+    return cAR
+
+
+def chainSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, chainFn=chainFn):
+    """At most one global alignment per (read, reference) (utils.py:441-469)."""
+    sam = pysam.Samfile(samFile, "r")
+    refSequences = getFastaDictionary(referenceFastaFile)
+    readSequences = getFastqDictionary(readFastqFile)
+    buckets = {}
+    for aR in samIterator(sam):
+        if aR.qname not in readSequences:
+            raise RuntimeError("Aligned read name: %s not in read sequences names" % aR.qname)
+        buckets.setdefault((aR.qname, aR.rname), []).append(aR)
+    out = pysam.Samfile(outputSamFile, "wh", template=sam)
+    chained = []
+    for (readName, refID), alignedReads in buckets.items():
+        refSeq = refSequences[sam.getrname(refID)]
+        readSeq = readSequences[readName]
+        chained.append(mergeChainedAlignedReads(chainFn(alignedReads, refSeq, readSeq), refSeq, readSeq))
+    chained.sort(key=lambda a: (a.rname, a.pos, a.qname))
+    for cAR in chained:
+        out.write(cAR)
+    sam.close()
+    out.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# realign (the hot path)
+# ---------------------------------------------------------------------------------------------------------
+
+_shared_ctx = {}
+
+
+def _context(device=0):
+    from .. import realign
+    if device not in _shared_ctx:
+        _shared_ctx[device] = realign.Context(device)
+    return _shared_ctx[device]
+
+
+def _loadHmmInto(ctx, hmmFile, slot=0):
+    ctx.set_hmm(None if hmmFile is None else Hmm.loadHmm(hmmFile), slot=slot)
+
+
+def _guideOf(aR):
+    return [(op, length) for op, length in aR.cigar if op in (0, 1, 2)]
+
+
+def realignRecords(sam, records, refSequences, gapGamma, matchGamma, hmmFile, mode=None, splitThreshold=None,
+                   ctx=None, want_pairs=False):
+    """All records to the GPU in one batched call.  Returns the list of per-record result dicts in input
+    order.  Replaces the child-per-record fan-out of utils.py:565-570 and the cactus_realign call :587."""
+    from .. import realign
+    ctx = ctx or _context()
+    _loadHmmInto(ctx, hmmFile)
+    names = sorted(refSequences)
+    index = {n: i for i, n in enumerate(names)}
+    params = realign.make_params(
+        band_mode=realign.BAND_ANCHOR, diagonal_expansion=REALIGN_DIAGONAL_EXPANSION,
+        constraint_trim=CONSTRAINT_DIAGONAL_TRIM,
+        split_threshold=REALIGN_SPLIT_MATRIX_BIGGER_THAN if splitThreshold is None else splitThreshold,
+        gap_gamma=gapGamma, match_gamma=matchGamma, mode=realign.MODE_REALIGN if mode is None else mode)
+    reads, guides, ref_index = [], [], []
+    for aR in records:
+        for op, _ in aR.cigar:
+            assert op in (0, 1, 2, 4, 5)
+        reads.append(aR.query)
+        guides.append(_guideOf(aR))
+        ref_index.append(index[sam.getrname(aR.rname)])
+        # the realigner expects the global records chainSamFile produces (utils.py:492-496)
+        refLen = len(refSequences[sam.getrname(aR.rname)])
+        if aR.pos != 0 or aR.aend != refLen:
+            raise RuntimeError("Record %s is not a global alignment of its reference (pos %s, aend %s, reference length "
+                               "%s): chain the SAM file first" % (aR.qname, aR.pos, aR.aend, refLen))
+    return ctx.realign(params, [refSequences[n] for n in names], reads, guides, ref_index=ref_index,
+                       want_pairs=want_pairs)
+
+
+def realignSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, hmmFile, gapGamma, matchGamma, ctx=None):
+    """realignSamFile2TargetFn + realignCigarTargetFn + realignSamFile3TargetFn (utils.py:557-609) as one
+    batched GPU call: output SAM == input SAM with only each record's CIGAR replaced, same order, header
+    copied (utils.py:596-605)."""
+    refSequences = getFastaDictionary(referenceFastaFile)
+    sam = pysam.Samfile(samFile, "r")
+    records = list(samIterator(sam))
+    results = realignRecords(sam, records, refSequences, gapGamma, matchGamma, hmmFile, ctx=ctx)
+    failed = [(aR.qname, r["status"]) for aR, r in zip(records, results) if r["status"] != 0]
+    if failed:
+        # the reference's system() raises on a non-zero exit of cactus_realign and the job tree reports failed
+        # jobs (pipeline.py:209-210); a batch does the same after the fact
+        raise RuntimeError("Realignment failed for %d record(s), first: %s" % (len(failed), failed[0]))
+    out = pysam.Samfile(outputSamFile, "wh", template=sam)
+    for aR, r in zip(records, results):
+        assert len(r["ops"]) > 0 or len(aR.query) == 0          # exactly one cigar per record (utils.py:588-589)
+        aR.cigar = [(op, length) for op, length in r["ops"]]    # utils.py:602
+        out.write(aR)
+    sam.close()
+    out.close()
+    return results
+
+
+def learnModelFromSamFileTargetFn(target, samFile, readFastqFile, referenceFastaFile, outputModel):
+    """EM training of the HMM (utils.py:471-531) -- SURVEY.md 8f next #2: the same forward/backward kernel plus
+    expected-count accumulation.  Not built yet: fail loudly rather than silently using another model."""
+    raise NotImplementedError("EM training (cactus_expectationMaximisation, utils.py:471-531) is scheduled as the next "
+                              "row after the hot path (SURVEY.md 8f #2) and is not implemented in this build")
+
+
+def realignSamFileTargetFn(target, samFile, outputSamFile, readFastqFile, referenceFastaFile, gapGamma, matchGamma,
+                           hmmFile=None, trainHmmFile=False, chainFn=chainFn):
+    """Chains and then realigns the resulting global alignments (utils.py:540-555).  `target` only supplies the
+    temp directory, as in the reference; pass a nanopore_amd.bioio.Target (or None for a private one)."""
+    own = target is None
+    target = target or bioio.Target()
+    try:
+        tempSamFile = os.path.join(target.getGlobalTempDir(), "temp.sam")
+        chainSamFile(samFile, tempSamFile, readFastqFile, referenceFastaFile, chainFn)
+        if hmmFile is not None and trainHmmFile:
+            learnModelFromSamFileTargetFn(target, tempSamFile, readFastqFile, referenceFastaFile, hmmFile)
+        else:
+            assert not trainHmmFile
+        return realignSamFile(tempSamFile, outputSamFile, readFastqFile, referenceFastaFile, hmmFile, gapGamma, matchGamma)
+    finally:
+        if own:
+            target.cleanup()
+
+
+def writePosteriorProbs(path, x, y, p):
+    """`refPosition readPosition posteriorProb` per line: the --outputAllPosteriorProbs / --outputPosteriorProbs TSV
+    parsed at marginAlignSnpCaller.py:149."""
+    with open(path, "w") as fh:
+        for a, b, c in zip(x, y, p):
+            fh.write("%i\t%i\t%s\n" % (a, b, repr(float(c))))

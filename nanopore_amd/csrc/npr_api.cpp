@@ -126,11 +126,15 @@ struct npr_batch {
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
-    int grid = 0;
-    int wcap = 0;
-    size_t lds_bytes = 0;
-    int variant = 0;  // 0 generic LDS-ring kernel, 1 register staircase kernel
-    int stair_R = 0;
+    // One DP launch per kernel class present in the batch (tasks are grouped by class, longest first).
+    struct Launch {
+        int cls;      // 0..2 register staircase kernel with 1/2/4 cells per lane, 3 generic LDS ring, 4 generic global ring
+        int first, count, grid, wcap;
+        size_t lds;
+        int64_t cells;
+    };
+    std::vector<Launch> launches;
+    DevBuf<float> d_ring;
     bool ran = false, finished = false;
     // results
     std::vector<npr_read_result> results;
@@ -248,11 +252,13 @@ int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double 
 // batch
 // --------------------------------------------------------------------------------------------------
 
-int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
-                         const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
-                         const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
-                         npr_batch **out) {
-    if (!ctx || !params || !out || n_reads < 0) return NPR_ERR_INVALID;
+int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                         const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                         const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                         const int64_t *guide_off, const int32_t *model_slot, npr_batch **out) {
+    if (!ctx || !params || !out || n_reads < 0 || n_refs < 0) return NPR_ERR_INVALID;
+    if (!ref_index && n_refs != n_reads) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: without ref_index, n_refs must equal n_reads");
+    auto ref_of = [&](int64_t i) -> int64_t { return ref_index ? ref_index[i] : i; };
     if (n_reads > 0 && (!ref_off || !read_off || !guide_off)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: null offsets");
     *out = nullptr;
     std::unique_ptr<npr_batch> b(new (std::nothrow) npr_batch);
@@ -272,7 +278,13 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     // 1. plan every read (host threads; the analogue of the reference's one-job-per-read fan-out)
     std::vector<Plan> plans(n_reads);
     parallel_for(n_reads, ctx->host_threads, [&](int64_t i) {
-        const int64_t lX = ref_off[i + 1] - ref_off[i], lY = read_off[i + 1] - read_off[i];
+        const int64_t k = ref_of(i);
+        if (k < 0 || k >= n_refs) {
+            b->ref_len[i] = b->read_len[i] = 0;
+            b->read_status[i] = NPR_ERR_INVALID;
+            return;
+        }
+        const int64_t lX = ref_off[k + 1] - ref_off[k], lY = read_off[i + 1] - read_off[i];
         b->ref_len[i] = lX;
         b->read_len[i] = lY;
         int32_t rc = NPR_OK;
@@ -280,9 +292,8 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         if (slot < 0 || slot >= NPR_MAX_MODELS || !ctx->model_set[slot]) rc = NPR_ERR_MODEL;
         if (rc == NPR_OK) rc = build_plan(b->params, lX, lY, guide_ops + 2 * guide_off[i], guide_off[i + 1] - guide_off[i], plans[i]);
         if (rc == NPR_OK) {
-            const int maxw = generic_max_wcap();
             for (const Segment &s : plans[i].segs)
-                if (s.max_width > maxw) rc = NPR_ERR_BAND_TOO_WIDE;
+                if (s.max_width > (1 << 22)) rc = NPR_ERR_BAND_TOO_WIDE;
         }
         if (rc != NPR_OK) plans[i].segs.clear();
         b->read_status[i] = rc;
@@ -300,48 +311,62 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         b->read_first_task[i] = static_cast<int32_t>(order.size());
         b->read_ntasks[i] = static_cast<int32_t>(plans[i].segs.size());
         for (size_t s = 0; s < plans[i].segs.size(); ++s) order.push_back({i, static_cast<int32_t>(s), plans[i].segs[s].cells});
-        if (!plans[i].segs.empty()) seq_bytes += b->ref_len[i] + b->read_len[i];
     }
     const int64_t ntasks = static_cast<int64_t>(order.size());
     if (ntasks >= (int64_t(1) << 31)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: too many tasks");
     std::vector<int32_t> rank(ntasks);
     std::iota(rank.begin(), rank.end(), 0);
-    std::stable_sort(rank.begin(), rank.end(), [&](int32_t a, int32_t c) { return order[a].cells > order[c].cells; });
+    // kernel class of a segment: the register kernel takes staircase bands of at most 256 cells per
+    // anti-diagonal; wider ones go to the generic kernel (LDS ring while it fits, global ring beyond)
+    const char *force = std::getenv("NPR_KERNEL");  // "generic": no register kernel (A/B runs, tests)
+    const bool force_generic = force && std::strcmp(force, "generic") == 0;
+    const int lds_max_w = generic_max_wcap();
+    auto class_of = [&](const Segment &s) {
+        if (!force_generic && s.staircase && s.max_width <= 256) return s.max_width <= 64 ? 0 : (s.max_width <= 128 ? 1 : 2);
+        return s.max_width <= lds_max_w ? 3 : 4;
+    };
+    std::vector<int8_t> cls_of(ntasks);
+    for (int64_t k = 0; k < ntasks; ++k) cls_of[k] = static_cast<int8_t>(class_of(plans[order[k].read].segs[order[k].seg]));
+    std::stable_sort(rank.begin(), rank.end(), [&](int32_t a, int32_t c) {
+        return cls_of[a] != cls_of[c] ? cls_of[a] < cls_of[c] : order[a].cells > order[c].cells;
+    });
     b->task_of.assign(ntasks, 0);
     for (int64_t k = 0; k < ntasks; ++k) b->task_of[rank[k]] = static_cast<int32_t>(k);
 
-    // sequences: codes, reference slice then read, per read
-    std::vector<uint8_t> h_seq(seq_bytes);
-    std::vector<int64_t> seq_x(n_reads, 0), seq_y(n_reads, 0);
-    {
-        int64_t pos = 0;
-        for (int64_t i = 0; i < n_reads; ++i) {
-            if (plans[i].segs.empty()) continue;
-            seq_x[i] = pos;
-            pos += b->ref_len[i];
-            seq_y[i] = pos;
-            pos += b->read_len[i];
-        }
-        parallel_for(n_reads, ctx->host_threads, [&](int64_t i) {
-            if (plans[i].segs.empty()) return;
-            for (int64_t k = 0; k < b->ref_len[i]; ++k) h_seq[seq_x[i] + k] = encode_base(ref[ref_off[i] + k]);
-            for (int64_t k = 0; k < b->read_len[i]; ++k) h_seq[seq_y[i] + k] = encode_base(read[read_off[i] + k]);
-        });
+    // sequences: per task, only the part of the reference and of the read its segment spans
+    std::vector<int64_t> task_x(ntasks), task_y(ntasks);
+    seq_bytes = 0;
+    for (int64_t k = 0; k < ntasks; ++k) {
+        const Ref &r = order[rank[k]];
+        const Segment &s = plans[r.read].segs[r.seg];
+        task_x[k] = seq_bytes;
+        seq_bytes += s.xe - s.xs;
+        task_y[k] = seq_bytes;
+        seq_bytes += s.ye - s.ys;
     }
+    std::vector<uint8_t> h_seq(seq_bytes);
+    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
+        const Ref &r = order[rank[k]];
+        const Segment &s = plans[r.read].segs[r.seg];
+        const uint8_t *xsrc = ref + ref_off[ref_of(r.read)] + s.xs;
+        const uint8_t *ysrc = read + read_off[r.read] + s.ys;
+        for (int64_t q = 0; q < s.xe - s.xs; ++q) h_seq[task_x[k] + q] = encode_base(xsrc[q]);
+        for (int64_t q = 0; q < s.ye - s.ys; ++q) h_seq[task_y[k] + q] = encode_base(ysrc[q]);
+    });
 
     b->tasks.resize(ntasks);
     b->task_cells.resize(ntasks);
     std::vector<int64_t> band_base(ntasks);
     int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
-    bool all_stair = true;
+    int64_t cls_count[5] = {0, 0, 0, 0, 0}, cls_width[5] = {0, 0, 0, 0, 0}, cls_cells[5] = {0, 0, 0, 0, 0};
     for (int64_t k = 0; k < ntasks; ++k) {
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
         band_base[k] = band_entries;
         band_entries += s.D() + 1;
         Task &t = b->tasks[k];
-        t.x_off = seq_x[r.read] + s.xs;
-        t.y_off = seq_y[r.read] + s.ys;
+        t.x_off = task_x[k];
+        t.y_off = task_y[k];
         t.band_off = band_base[k];
         t.lX = static_cast<int32_t>(s.xe - s.xs);
         t.lY = static_cast<int32_t>(s.ye - s.ys);
@@ -358,7 +383,10 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         b->task_cells[k] = s.cells;
         total_cells += s.cells;
         max_width = std::max<int64_t>(max_width, s.max_width);
-        all_stair = all_stair && s.staircase;
+        const int c = cls_of[rank[k]];
+        ++cls_count[c];
+        cls_width[c] = std::max<int64_t>(cls_width[c], s.max_width);
+        cls_cells[c] += s.cells;
     }
     std::vector<int32_t> h_lo(band_entries), h_n(band_entries);
     std::vector<uint32_t> h_coff(band_entries);
@@ -383,37 +411,51 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
 
     // 3. device buffers
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    b->wcap = static_cast<int>((std::max<int64_t>(max_width, 64) + 3) & ~int64_t(3));
-    b->lds_bytes = generic_lds_bytes(b->wcap);
-    // kernel choice: the register kernel needs staircase bands of at most 256 cells per anti-diagonal
-    const char *force = std::getenv("NPR_KERNEL");  // "generic" forces the LDS-ring kernel (A/B runs, tests)
-    b->variant = (all_stair && max_width <= 256 && ntasks > 0 && !(force && std::strcmp(force, "generic") == 0)) ? 1 : 0;
-    b->stair_R = max_width <= 64 ? 1 : (max_width <= 128 ? 2 : 4);
-    int waves_per_cu;
-    if (b->variant == 1) {
-        waves_per_cu = b->stair_R == 1 ? 24 : (b->stair_R == 2 ? 16 : 8);
-    } else {
-        const int waves_by_lds = static_cast<int>(std::max<size_t>(1, (160 * 1024) / (b->lds_bytes + 256)));
-        waves_per_cu = std::min(16, waves_by_lds);
-    }
-    if (const char *w = std::getenv("NPR_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(w));
-    int64_t grid = std::min<int64_t>(ntasks, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
-    grid = std::max<int64_t>(grid, 1);
     b->slot_stride = (max_pad + 63) & ~int64_t(63);
-    // keep the scratch inside the memory actually free
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
     const int64_t fixed = seq_bytes + band_entries * 12 + pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
     const int64_t budget = static_cast<int64_t>(free_b * 0.9) - fixed;
+    int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
-        const int64_t fit = budget / (b->slot_stride * 8);
+        fit = budget / (b->slot_stride * 8);
         if (fit < 1) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for one forward scratch region");
-        grid = std::min(grid, fit);
     }
-    b->grid = static_cast<int>(grid);
+    int64_t max_grid = 1, ring_floats = 0, first = 0;
+    for (int c = 0; c < 5; ++c) {
+        if (!cls_count[c]) continue;
+        npr_batch::Launch L{};
+        L.cls = c;
+        L.first = static_cast<int>(first);
+        L.count = static_cast<int>(cls_count[c]);
+        L.cells = cls_cells[c];
+        first += cls_count[c];
+        int waves_per_cu;
+        if (c <= 2) {  // VGPR-limited: 53 / 85 / 147 registers
+            waves_per_cu = c == 0 ? 28 : (c == 1 ? 20 : 12);
+            L.wcap = 0;
+            L.lds = stair_lds_bytes();
+        } else if (c == 3) {
+            L.wcap = static_cast<int>((std::max<int64_t>(cls_width[c], 64) + 3) & ~int64_t(3));
+            L.lds = generic_lds_bytes(L.wcap);
+            waves_per_cu = std::min<int>(16, static_cast<int>(std::max<size_t>(1, (160 * 1024) / (L.lds + 256))));
+        } else {
+            L.wcap = static_cast<int>((cls_width[c] + 3) & ~int64_t(3));
+            L.lds = generic_lds_bytes(0);
+            waves_per_cu = 8;
+        }
+        if (const char *w = std::getenv("NPR_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(w));
+        int64_t grid = std::min<int64_t>(L.count, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
+        grid = std::max<int64_t>(1, std::min(grid, fit));
+        L.grid = static_cast<int>(grid);
+        if (c == 4) ring_floats = grid * 18 * L.wcap;
+        max_grid = std::max(max_grid, grid);
+        b->launches.push_back(L);
+    }
+    const int64_t grid = ntasks ? max_grid : 0;
     hipError_t e;
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
-        (e = b->d_queue.alloc(4)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
+        (e = b->d_queue.alloc(8)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
         (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
         (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_px.alloc(pair_total)) != hipSuccess ||
         (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess ||
@@ -433,8 +475,12 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->stats.diagonals = band_entries;
     b->stats.max_width = max_width;
     b->stats.slots = grid;
-    b->stats.kernel_variant = b->variant;
-    b->stats.device_bytes = fixed + b->slot_stride * grid * 8;
+    {   // report the class that carries most cells
+        int64_t best = -1;
+        for (const auto &L : b->launches)
+            if (L.cells > best) best = L.cells, b->stats.kernel_variant = L.cls <= 2 ? 1 : 0;
+    }
+    b->stats.device_bytes = fixed + b->slot_stride * grid * 8 + ring_floats * 4;
     *out = b.release();
     return NPR_OK;
 }
@@ -457,7 +503,7 @@ static KernelArgs make_args(npr_batch *b) {
     a.py = b->d_py.p;
     a.pp = b->d_pp.p;
     a.threshold = static_cast<float>(b->params.posterior_threshold);
-    a.wcap = b->wcap;
+    a.ring = b->d_ring.p;
     return a;
 }
 
@@ -470,11 +516,19 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         b->ran = true;
         return NPR_OK;
     }
-    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    const int rc = b->variant == 1 ? launch_stair(make_args(b), b->stair_R, b->grid, ctx->stream)
-                                   : launch_generic(make_args(b), b->grid, b->lds_bytes, false, ctx->stream);
-    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
+    for (const auto &L : b->launches) {
+        KernelArgs a = make_args(b);
+        a.tasks += L.first;
+        a.outs += L.first;
+        a.ntasks = L.count;
+        a.queue += L.cls;
+        a.wcap = L.wcap;
+        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, ctx->stream)
+                                  : launch_generic(a, L.grid, L.lds, false, L.cls == 4, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
@@ -633,8 +687,19 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
         a.outs = d_out1.p;
         a.Bv = d_Bv.p;
         a.Be = d_Be.p;
-        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 4, ctx->stream));
-        const int rc = launch_generic(a, 1, b->lds_bytes, true, ctx->stream);
+        // width of this task decides LDS vs global ring
+        std::vector<int32_t> wn(t.D + 1);
+        HIP_TRY(ctx, hipMemcpy(wn.data(), b->d_n.p + t.band_off, sizeof(int32_t) * (t.D + 1), hipMemcpyDeviceToHost));
+        const int w = (*std::max_element(wn.begin(), wn.end()) + 3) & ~3;
+        const bool global_ring = w > generic_max_wcap();
+        DevBuf<float> ring1;
+        if (global_ring) {
+            if ((e = ring1.alloc(static_cast<size_t>(18) * w)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_dense: hipMalloc", e);
+            a.ring = ring1.p;
+        }
+        a.wcap = std::max(w, 64);
+        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
+        const int rc = launch_generic(a, 1, generic_lds_bytes(global_ring ? 0 : a.wcap), true, global_ring, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_generic<dense> launch", static_cast<hipError_t>(rc));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<int32_t> n(t.D + 1);
@@ -659,12 +724,13 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
     return NPR_OK;
 }
 
-int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, const uint8_t *ref,
-                          const int64_t *ref_off, const uint8_t *read, const int64_t *read_off,
-                          const int32_t *guide_ops, const int64_t *guide_off, const int32_t *model_slot,
-                          npr_read_result *results, int64_t *ops_off, int32_t *ops, int64_t cap_op_pairs) {
+int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                          const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                          const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                          const int64_t *guide_off, const int32_t *model_slot, npr_read_result *results,
+                          int64_t *ops_off, int32_t *ops, int64_t cap_op_pairs) {
     npr_batch *b = nullptr;
-    int32_t rc = npr_batch_create(ctx, params, n_reads, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot, &b);
+    int32_t rc = npr_batch_create(ctx, params, n_reads, n_refs, ref, ref_off, ref_index, read, read_off, guide_ops, guide_off, model_slot, &b);
     if (rc == NPR_OK) rc = npr_batch_run(b, nullptr);
     if (rc == NPR_OK) rc = npr_batch_finish(b);
     if (rc == NPR_OK && results) rc = npr_batch_results(b, results);

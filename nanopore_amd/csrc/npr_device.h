@@ -51,6 +51,7 @@ struct KernelArgs {
     int32_t wcap;  // ring capacity (cells per anti-diagonal) of the generic kernel
     float *Bv;     // dense dump of the backward match state (debug launches only)
     int32_t *Be;
+    float *ring;   // generic kernel, global-ring variant: 18*wcap floats per resident wave (bands too wide for LDS)
 };
 
 struct CompactArgs {
@@ -67,7 +68,7 @@ struct CompactArgs {
 };
 
 // launchers (npr_kernels.hip)
-int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, void *stream);
+int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, bool global_ring, void *stream);
 int launch_compact(const CompactArgs &a, void *stream);
 int launch_stair(const KernelArgs &a, int R, int grid, void *stream);
 size_t stair_lds_bytes();

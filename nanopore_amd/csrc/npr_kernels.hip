@@ -80,11 +80,15 @@ __device__ __forceinline__ int band_index(int xmy, int lo, int n) {
     return (t >= 0 && j < n) ? j : -1;
 }
 
-template <bool DENSE>
+// GLOBAL_RING: the three-diagonal ring lives in a per-wavefront HBM/L2 region instead of LDS, for the rare
+// anti-diagonals wider than the 160 KiB of LDS can hold (unanchored rectangles up to
+// splitMatrixBiggerThanThis = 3000 cells across).  One wavefront owns the region, and __syncthreads() between
+// anti-diagonals carries the workgroup-scope release/acquire that orders its own stores and loads.
+template <bool DENSE, bool GLOBAL_RING>
 __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Ring ring{reinterpret_cast<float *>(smem), a.wcap};
-    float *lmodel = reinterpret_cast<float *>(smem) + 18 * a.wcap;
+    Ring ring{GLOBAL_RING ? a.ring + static_cast<int64_t>(blockIdx.x) * 18 * a.wcap : reinterpret_cast<float *>(smem), a.wcap};
+    float *lmodel = reinterpret_cast<float *>(smem) + (GLOBAL_RING ? 0 : 18 * a.wcap);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..1] totals hand-off
 
     const int lane = threadIdx.x;
@@ -279,28 +283,27 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a) {
 
 }  // namespace
 
-size_t generic_lds_bytes(int wcap) { return sizeof(float) * (18 * static_cast<size_t>(wcap) + MODEL_FLOATS + 4); }
+// wcap <= 0: global-ring variant (LDS holds only the model tables)
+size_t generic_lds_bytes(int wcap) { return sizeof(float) * (18 * static_cast<size_t>(wcap > 0 ? wcap : 0) + MODEL_FLOATS + 4); }
 
 int generic_max_wcap() {
     // 160 KiB of LDS per workgroup on gfx950
     return static_cast<int>((160 * 1024 / sizeof(float) - MODEL_FLOATS - 4) / 18) & ~3;
 }
 
-int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, void *stream) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e;
-    if (dense) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-        if (e != hipSuccess) return static_cast<int>(e);
-        hipLaunchKernelGGL(k_dp_generic<true>, dim3(grid), dim3(WAVE), lds_bytes, s, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-        if (e != hipSuccess) return static_cast<int>(e);
-        hipLaunchKernelGGL(k_dp_generic<false>, dim3(grid), dim3(WAVE), lds_bytes, s, a);
-    }
+template <bool DENSE, bool GLOBAL_RING>
+static int launch_generic_t(const KernelArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<DENSE, GLOBAL_RING>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+    hipLaunchKernelGGL((k_dp_generic<DENSE, GLOBAL_RING>), dim3(grid), dim3(WAVE), lds_bytes, s, a);
     return static_cast<int>(hipGetLastError());
+}
+
+int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, bool global_ring, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dense) return global_ring ? launch_generic_t<true, true>(a, grid, lds_bytes, s) : launch_generic_t<true, false>(a, grid, lds_bytes, s);
+    return global_ring ? launch_generic_t<false, true>(a, grid, lds_bytes, s) : launch_generic_t<false, false>(a, grid, lds_bytes, s);
 }
 
 int launch_compact(const CompactArgs &a, void *stream) {

@@ -49,14 +49,17 @@ def _csr_ops(guides):
 class Batch(object):
     """A staged batch: inputs resident in HBM after construction."""
 
-    def __init__(self, ctx, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None):
+    def __init__(self, ctx, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None,
+                 ref_index=None):
         self._L = _lib.load()
         self.ctx = ctx
-        self.n_reads = len(ref_off) - 1
-        self._keep = (ref, ref_off, read, read_off, guide_ops, guide_off, model_slot)
+        self.n_reads = len(read_off) - 1
+        n_refs = len(ref_off) - 1
+        self._keep = (ref, ref_off, read, read_off, guide_ops, guide_off, model_slot, ref_index)
         h = C.c_void_p()
-        rc = self._L.npr_batch_create(ctx._h, C.byref(params), self.n_reads, ptr(ref), ptr(ref_off), ptr(read),
-                                      ptr(read_off), ptr(guide_ops), ptr(guide_off), ptr(model_slot), C.byref(h))
+        rc = self._L.npr_batch_create(ctx._h, C.byref(params), self.n_reads, n_refs, ptr(ref), ptr(ref_off),
+                                      ptr(ref_index), ptr(read), ptr(read_off), ptr(guide_ops), ptr(guide_off),
+                                      ptr(model_slot), C.byref(h))
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_create", ctx.last_error())
         self._h = h
@@ -167,15 +170,18 @@ class Context(object):
         if rc != _lib.OK:
             raise NprError(rc, "npr_set_hmm", self.last_error())
 
-    def stage(self, params, refs, reads, guides, model_slot=None):
-        """refs/reads: lists of ASCII sequences (str/bytes); guides: list of [(op,len),...]."""
+    def stage(self, params, refs, reads, guides, model_slot=None, ref_index=None):
+        """refs/reads: lists of ASCII sequences (str/bytes); guides: list of [(op,len),...].
+        ref_index[i] = which entry of `refs` read i aligns to (None: read i <-> refs[i])."""
         ref, ref_off = _csr(refs)
         read, read_off = _csr(reads)
         gops, goff = _csr_ops(guides)
         ms = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
-        return Batch(self, params, ref, ref_off, read, read_off, gops, goff, ms)
+        ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
+        return Batch(self, params, ref, ref_off, read, read_off, gops, goff, ms, ri)
 
-    def stage_csr(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None):
+    def stage_csr(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None,
+                  ref_index=None):
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         read = np.ascontiguousarray(read, dtype=np.uint8)
         ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
@@ -183,11 +189,12 @@ class Context(object):
         guide_ops = np.ascontiguousarray(guide_ops, dtype=np.int32).reshape(-1, 2)
         guide_off = np.ascontiguousarray(guide_off, dtype=np.int64)
         ms = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
-        return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms)
+        ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
+        return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms, ri)
 
-    def realign(self, params, refs, reads, guides, model_slot=None, want_pairs=False):
+    def realign(self, params, refs, reads, guides, model_slot=None, want_pairs=False, ref_index=None):
         """One batched call: returns list of dicts (status, score, loglik, cells, ops[, x, y, p])."""
-        b = self.stage(params, refs, reads, guides, model_slot)
+        b = self.stage(params, refs, reads, guides, model_slot, ref_index)
         try:
             b.run()
             b.finish()

@@ -1,0 +1,141 @@
+"""End-to-end through the reference's plugin surface on the GPU (BASELINE.json configs[0], "plumbing"):
+local hits -> chainSamFile -> realignSamFile (one batched C-ABI call) -> mapping.sam, then the
+AlignmentUncertainty analysis, on the reference's own test data, each checked against the CPU oracle."""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, cigar_spans, oracle_hmm, orc
+from seed_mapper import write_local_hits_sam
+
+pytestmark = pytest.mark.gpu
+
+C1 = os.path.join(ROOT, "tests", "golden", "c1")
+
+
+def _mild_channel():
+    """~94 % identity, short indels: a read the seed-and-chain step can anchor densely."""
+    T = np.zeros((5, 5))
+    T[0] = [0.94, 0.03, 0.03, 0.0, 0.0]
+    T[1] = [0.7, 0.3, 0, 0, 0]
+    T[2] = [0.7, 0, 0.3, 0, 0]
+    T[3] = [1.0, 0, 0, 0, 0]
+    T[4] = [1.0, 0, 0, 0, 0]
+    E = np.full(80, 1.0 / 16.0)
+    E[:16] = (np.full((4, 4), 0.06 / 12) + np.eye(4) * (0.235 - 0.06 / 12)).reshape(-1)
+    return T.reshape(-1), E
+
+
+def _slice_inputs(tmp_path, ref_span=(10000, 16000), seed=5, mild=False):
+    """A 6 kb slice of the reference's test reference, and a read made from its middle 5 kb by the error
+    channel of blasr_hmm_0 (the reference's own test reads are unrelated repeats: no co-linear homology)."""
+    from nanopore_amd import bioio, synth
+    from helpers import load_model_arrays
+    rname, rseq = next(iter(bioio.fastaRead(os.path.join(C1, "reference.fa"))))
+    ref = rseq[ref_span[0]:ref_span[1]].upper()
+    codes = np.array(["ACGT".index(c) if c in "ACGT" else 0 for c in ref[500:5500]], dtype=np.uint8)
+    T, E, _ = load_model_arrays()
+    if mild:
+        T, E = _mild_channel()
+    rc, roff, _, _ = synth.error_channel(np.random.default_rng(seed), codes, np.array([0, len(codes)]), T, E)
+    read = "".join("ACGT"[c] for c in rc)
+    fq = tmp_path / "reads.fq"
+    fa = tmp_path / "ref.fa"
+    fq.write_text("@read_1 synthetic\n%s\n+\n%s\n" % (read, "I" * len(read)))
+    bioio.fastaWrite(str(fa), rname.split()[0], ref)
+    return str(fq), str(fa), {"read_1": read}, {rname.split()[0]: ref}
+
+
+@pytest.mark.parametrize("mild", [True, False], ids=["dense_anchors", "sparse_anchors_wide_rectangles"])
+def test_mapper_realign_matches_oracle(tmp_path, gpu_ctx, mild):
+    from nanopore_amd import realign, sam as pysam
+    from nanopore_amd.analyses import utils
+    from nanopore_amd.analyses.alignmentUncertainty import AlignmentUncertainty
+    from nanopore_amd.mappers import variants as V
+    fq, fa, reads, refs = _slice_inputs(tmp_path, mild=mild)
+    mapping = str(tmp_path / "mapping.sam")
+    assert write_local_hits_sam(mapping, refs, reads, k=12, min_len=14) >= 10
+    # keep a copy of the chained input to feed the oracle the same guide
+    chained = str(tmp_path / "chained.sam")
+    utils.chainSamFile(mapping, chained, fq, fa)
+    mapper = V.LastParamsRealignTrainedModel(fq, "fake_readtype", fa, mapping)
+    mapper.run()
+    mapper.cleanup()
+    out = list(pysam.Samfile(mapping, "r"))
+    src = list(pysam.Samfile(chained, "r"))
+    assert len(out) == len(src) == 1
+    ref = next(iter(refs.values()))
+    read = next(iter(reads.values()))
+    for o, s in zip(out, src):
+        assert (o.qname, o.pos, o.seq, o.flag) == (s.qname, 0, s.seq, s.flag)        # only the CIGAR changes (utils.py:602)
+        assert cigar_spans(o.cigar) == (len(ref), len(read))
+        X, Y = realign.encode(ref), realign.encode(read)
+        guide = [(op, n) for op, n in s.cigar]
+        P = orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000,
+                            gap_gamma=0.5, match_gamma=0.0)
+        m32 = orc.realign_read(oracle_hmm(), P, X, Y, guide, precision=1)
+        assert m32["status"] == 0
+        assert o.cigar == m32["ops"], "realigned cigar differs from the oracle (fp32 mirror)"
+        m64 = orc.realign_read(oracle_hmm(), P, X, Y, guide, precision=0)
+        assert o.cigar == m64["ops"], "realigned cigar differs from the fp64 oracle"
+        assert o.cigar != guide                                                      # the realigner did something
+    # AlignmentUncertainty on the realigned SAM (rescore mode, split 100): XML schema + oracle scores
+    adir = tmp_path / "analysis_AlignmentUncertainty"
+    adir.mkdir()
+    an = AlignmentUncertainty(fq, "fake_readtype", fa, mapping, str(adir))
+    node = an.run(ctx=gpu_ctx)
+    an.cleanup()
+    assert (adir / "DONE").exists()
+    root = ET.parse(str(adir / "alignmentUncertainty.xml")).getroot()
+    assert root.tag == "alignmentUncertainty"
+    assert set(root.attrib) == {"averagePosteriorMatchProbabilityPerRead", "averagePosteriorMatchProbability",
+                                "averagePosteriorMatchProbabilitesPerRead", "alignedPairsInCigar"}
+    P2 = orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=100,
+                         mode=orc.MODE_RESCORE_ORIGINAL)
+    want = orc.realign_read(oracle_hmm(), P2, X, Y, [(op, n) for op, n in out[0].cigar], precision=0)
+    got = float(root.attrib["averagePosteriorMatchProbabilitesPerRead"])
+    assert got == pytest.approx(want["score"], abs=1e-5)
+    assert int(root.attrib["alignedPairsInCigar"]) == sum(n for op, n in out[0].cigar if op == 0)
+    assert float(root.attrib["averagePosteriorMatchProbability"]) == pytest.approx(got, abs=1e-12)
+
+
+def test_full_size_reference_test_data_runs(tmp_path, gpu_ctx):
+    """The full 32.7 kb read against the full 57.5 kb reference (wide unanchored rectangles: exercises the
+    generic kernel's LDS and global rings and the split rule).  Checked through invariants only."""
+    from nanopore_amd import bioio, sam as pysam
+    from nanopore_amd.analyses import utils
+    name, seq, _ = next(iter(bioio.fastqRead(os.path.join(C1, "reads.fq"))))
+    rname, rseq = next(iter(bioio.fastaRead(os.path.join(C1, "reference.fa"))))
+    fq = tmp_path / "reads.fq"
+    fq.write_text("@%s\n%s\n+\n%s\n" % (name, seq, "I" * len(seq)))
+    mapping = str(tmp_path / "mapping.sam")
+    write_local_hits_sam(mapping, {rname.split()[0]: rseq}, {name.split()[0]: seq}, k=18, min_len=24)
+    out = str(tmp_path / "realigned.sam")
+    res = utils.realignSamFileTargetFn(None, mapping, out, str(fq), os.path.join(C1, "reference.fa"), 0.5, 0.0,
+                                       utils.trainedModelPath("blasr_hmm_0.txt"))
+    recs = list(pysam.Samfile(out, "r"))
+    assert len(recs) == 1 and len(res) == 1 and res[0]["status"] == 0
+    assert cigar_spans(recs[0].cigar) == (len(rseq), len(seq))
+    assert res[0]["loglik"] == pytest.approx(res[0]["loglik_bwd"], rel=1e-5)
+    assert res[0]["n_segments"] >= 1 and res[0]["cells"] > 1e6
+
+
+def test_all_posteriors_mode_and_tsv(tmp_path, gpu_ctx):
+    """marginAlignSnpCaller.py:136-149: --outputAllPosteriorProbs TSV = 3 numeric columns, col0 a valid
+    reference index, col1 a valid index into aR.query."""
+    from nanopore_amd import realign as R
+    from nanopore_amd.analyses import utils
+    from nanopore_amd.hmm import Hmm
+    rng = np.random.default_rng(3)
+    from helpers import random_pair
+    X, Y, g = random_pair(rng, 500)
+    gpu_ctx.set_hmm(Hmm.loadHmm(utils.trainedModelPath("blasr_hmm_20.txt")))
+    P = R.make_params(band_mode=R.BAND_ANCHOR, split_threshold=100, mode=R.MODE_ALL_POSTERIORS)
+    o = gpu_ctx.realign(P, [bytes(b"ACGT"[c] for c in X)], [bytes(b"ACGT"[c] for c in Y)], [g], want_pairs=True)[0]
+    assert o["status"] == 0 and len(o["p"]) > 400 and cigar_spans(o["ops"]) == (len(X), len(Y))
+    tsv = tmp_path / "probs.tsv"
+    utils.writePosteriorProbs(str(tsv), o["x"], o["y"], o["p"])
+    rows = [list(map(float, ln.split())) for ln in open(tsv)]
+    assert all(len(r) == 3 and 0 <= int(r[0]) < len(X) and 0 <= int(r[1]) < len(Y) and 0.01 <= r[2] <= 1.0001 for r in rows)
