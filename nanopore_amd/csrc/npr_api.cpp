@@ -431,8 +431,8 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         L.cells = cls_cells[c];
         first += cls_count[c];
         int waves_per_cu;
-        if (c <= 2) {  // VGPR-limited: 53 / 85 / 147 registers
-            waves_per_cu = c == 0 ? 28 : (c == 1 ? 20 : 12);
+        if (c <= 2) {  // VGPR-limited: 82 / 95 / 151 registers -> 5 / 5 / 3 waves per SIMD
+            waves_per_cu = c == 0 ? 20 : (c == 1 ? 20 : 12);
             L.wcap = 0;
             L.lds = stair_lds_bytes();
         } else if (c == 3) {

@@ -21,23 +21,27 @@ struct Cell {
 
 __device__ __forceinline__ Cell dead_cell() { return Cell{0.f, 0.f, 0.f, 0.f, 0.f, E_DEAD}; }
 
-// 2^k for k <= 0, flushed to zero below 2^-100
-__device__ __forceinline__ float scale2(int k) { return k < -100 ? 0.0f : __builtin_ldexpf(1.0f, k); }
+// 2^k for -126 <= k <= 0 built from its bit pattern, 0 below (k is an exponent difference, never positive).
+// Integer ops only: v_ldexp_f32 issues at about half the rate of a plain VALU op on gfx950 (tools/valu_rates).
+__device__ __forceinline__ float scale2(int k) {
+    const int t = k + 127;
+    return __builtin_bit_cast(float, (t > 0 ? t : 0) << 23);
+}
 
+// Renormalise so that the largest mantissa lands in [0.5, 1): multiply by 2^(126 - E) where E is the biased
+// exponent field of the largest value (exact: a power of two), and add E - 126 to the shared exponent.
+// A zero cell becomes the dead cell.  (A subnormal maximum, E = 0, is scaled by 2^126 and stays below 0.5:
+// harmless, and the CPU mirror does exactly the same.)
 __device__ __forceinline__ void normalise(Cell &c, int eref) {
     const float vmax = fmaxf(fmaxf(c.m, c.sx), fmaxf(fmaxf(c.sy, c.lx), c.ly));
-    if (vmax > 0.0f) {
-        int k;
-        (void)__builtin_frexpf(vmax, &k);
-        c.m = __builtin_ldexpf(c.m, -k);
-        c.sx = __builtin_ldexpf(c.sx, -k);
-        c.sy = __builtin_ldexpf(c.sy, -k);
-        c.lx = __builtin_ldexpf(c.lx, -k);
-        c.ly = __builtin_ldexpf(c.ly, -k);
-        c.e = eref + k;
-    } else {
-        c = dead_cell();
-    }
+    const int bits = __builtin_bit_cast(int, vmax) & 0x7f800000;
+    const float inv = __builtin_bit_cast(float, 0x7e800000 - bits);  // 2^(126 - E)
+    c.m *= inv;
+    c.sx *= inv;
+    c.sy *= inv;
+    c.lx *= inv;
+    c.ly *= inv;
+    c.e = vmax > 0.0f ? eref + (bits >> 23) - 126 : E_DEAD;
 }
 
 // transition probabilities held in registers (wave-uniform)

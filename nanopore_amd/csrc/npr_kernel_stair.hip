@@ -153,12 +153,197 @@ struct BandRow {
 
 typedef const __attribute__((address_space(4))) int32_t *cptr32;
 
+// Everything wave-uniform a step needs.
+struct StepEnv {
+    const DevModel *mdl;
+    const char *ltab;
+    Trans tr;
+    const uint8_t *X, *Y;
+    int lX, lY;
+    int lane;
+};
+
+// A cell outside the band keeps whatever mantissas the arithmetic produced and only gets the dead exponent:
+// every consumer multiplies it by scale2(E_DEAD - eref) = 0, so the mantissas never matter.
+__device__ __forceinline__ void kill_outside(Cell &c, int j, int n) {
+    if (j >= n) c.e = E_DEAD;
+}
+
+template <int R>
+__device__ __forceinline__ void emissions(const StepEnv &E, const Bases<R> &bx, const Bases<R> &by, int r, float &em,
+                                          float &exs, float &exl, float &eys, float &eyl) {
+    constexpr int OFF_EM = offsetof(DevModel, em), OFF_EX = offsetof(DevModel, ex), OFF_EY = offsetof(DevModel, ey);
+    em = *reinterpret_cast<const float *>(E.ltab + OFF_EM + 5 * bx.b[r] + by.b[r]);
+    exs = *reinterpret_cast<const float *>(E.ltab + OFF_EX + 20 + bx.b[r]);
+    exl = *reinterpret_cast<const float *>(E.ltab + OFF_EX + 60 + bx.b[r]);
+    eys = *reinterpret_cast<const float *>(E.ltab + OFF_EY + 40 + by.b[r]);
+    eyl = *reinterpret_cast<const float *>(E.ltab + OFF_EY + 80 + by.b[r]);
+}
+
+// One forward anti-diagonal.  `io` holds diagonal d-2 on entry and diagonal d on exit; `p1` holds d-1.  The two
+// register sets swap roles every step (the caller unrolls by two), so no diagonal is ever copied.
+template <int R>
+__device__ __forceinline__ void fwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Bases<R> &cX, Bases<R> &cY,
+                                         Feed &fx, Feed &fy, int d, int lo, int n, int lo1, int lo2, const int (&jr)[R]) {
+    const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
+    const int s = lo - lo1;          // +1: x-step, -1: y-step
+    const int sm = (lo - lo2) >> 1;  // index shift into the d-2 frame: -1, 0, +1
+    if (sm > 0) {
+        io = shift_up<R>(io);
+    } else if (sm < 0) {
+        io = shift_down<R>(io);
+    }
+    if (s > 0) {
+        bases_up<R>(cX, feed_get<+1>(fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
+        const Diag<R> U = shift_up<R>(p1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float em, exs, exl, eys, eyl;
+            emissions<R>(E, cX, cY, r, em, exs, exl, eys, eyl);
+            Cell c = fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
+            kill_outside(c, jr[r], n);
+            io.c[r] = c;
+        }
+    } else {
+        bases_down<R>(cY, feed_get<+1>(fy, E.Y, E.lY, y0 - 1, E.lane));
+        const Diag<R> L = shift_down<R>(p1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float em, exs, exl, eys, eyl;
+            emissions<R>(E, cX, cY, r, em, exs, exl, eys, eyl);
+            Cell c = fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
+            kill_outside(c, jr[r], n);
+            io.c[r] = c;
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void store_row(float *Fv, int32_t *Fe, const Diag<R> &C, uint32_t co, int n, int lane) {
+    if (R * lane < n) {
+        if constexpr (R == 1) {
+            Fv[co + lane] = C.c[0].m;
+            Fe[co + lane] = C.c[0].e;
+        } else if constexpr (R == 2) {
+            *reinterpret_cast<float2 *>(Fv + co + 2 * lane) = make_float2(C.c[0].m, C.c[1].m);
+            *reinterpret_cast<int2 *>(Fe + co + 2 * lane) = make_int2(C.c[0].e, C.c[1].e);
+        } else {
+            *reinterpret_cast<float4 *>(Fv + co + 4 * lane) = make_float4(C.c[0].m, C.c[1].m, C.c[2].m, C.c[3].m);
+            *reinterpret_cast<int4 *>(Fe + co + 4 * lane) = make_int4(C.c[0].e, C.c[1].e, C.c[2].e, C.c[3].e);
+        }
+    }
+}
+
+template <int R>
+struct FRow {  // forward match values of one anti-diagonal
+    float v[R];
+    int e[R];
+};
+
+template <int R>
+__device__ __forceinline__ void load_row(const float *Fv, const int32_t *Fe, FRow<R> &f, uint32_t co, int n, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) f.v[r] = 0.f, f.e[r] = E_DEAD;
+    if (R * lane < n) {
+        if constexpr (R == 1) {
+            f.v[0] = Fv[co + lane];
+            f.e[0] = Fe[co + lane];
+        } else if constexpr (R == 2) {
+            const float2 q = *reinterpret_cast<const float2 *>(Fv + co + 2 * lane);
+            const int2 g = *reinterpret_cast<const int2 *>(Fe + co + 2 * lane);
+            f.v[0] = q.x, f.v[1] = q.y, f.e[0] = g.x, f.e[1] = g.y;
+        } else {
+            const float4 q = *reinterpret_cast<const float4 *>(Fv + co + 4 * lane);
+            const int4 g = *reinterpret_cast<const int4 *>(Fe + co + 4 * lane);
+            f.v[0] = q.x, f.v[1] = q.y, f.v[2] = q.z, f.v[3] = q.w;
+            f.e[0] = g.x, f.e[1] = g.y, f.e[2] = g.z, f.e[3] = g.w;
+        }
+    }
+}
+
+struct PairSink {
+    int32_t *px, *py;
+    float *pp;
+    int64_t off;
+    int cap, xs, ys;
+    float threshold;
+};
+
+// posteriors of one anti-diagonal (d >= 2: from there on the forward match value is zero wherever x < 1 or y < 1;
+// d = 0 is the start cell, whose match state holds the start probability)
+template <int R>
+__device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, const FRow<R> &f, int d, int lo, int n,
+                                           int tot_e, float inv_tot, const int (&jr)[R], int lane, int &cnt) {
+    const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
+    float p[R];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        p[r] = posterior(f.v[r], f.e[r], B.c[r].m, B.c[r].e, tot_e, inv_tot);
+        any |= (p[r] >= S.threshold) && (jr[r] < n);
+    }
+    if (d >= 2 && __ballot(any)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool hit = (p[r] >= S.threshold) && (jr[r] < n);
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                if (hit && slot < S.cap) {
+                    S.px[S.off + slot] = x0 + jr[r] - 1 + S.xs;
+                    S.py[S.off + slot] = y0 - jr[r] - 1 + S.ys;
+                    S.pp[S.off + slot] = p[r];
+                }
+                cnt += __popcll(mask);
+            }
+        }
+    }
+}
+
+// One backward anti-diagonal.  `io` holds diagonal d+2 on entry and d on exit; `s1` holds d+1; lo1/lo2 are the
+// first x-y of d+1 and d+2.
+template <int R>
+__device__ __forceinline__ void bwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Bases<R> &bX, Bases<R> &bY,
+                                         Feed &fx, Feed &fy, int d, int lo, int n, int lo1, int lo2, const int (&jr)[R]) {
+    const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
+    const int s = lo1 - lo;          // the forward step d -> d+1: +1 x-step, -1 y-step
+    const int sm = (lo - lo2) >> 1;  // index shift into the d+2 frame
+    if (sm > 0) {
+        io = shift_up<R>(io);
+    } else if (sm < 0) {
+        io = shift_down<R>(io);
+    }
+    if (s > 0) {
+        // x decreased by one in every slot: X[x] moves up a slot, slot 0 takes X[x0]
+        bases_down<R>(bX, feed_get<-1>(fx, E.X, E.lX, x0, E.lane));
+        const Diag<R> Ys = shift_down<R>(s1);  // (x, y+1) is index j-1 on d+1; (x+1, y) keeps index j
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float em, exs, exl, eys, eyl;
+            emissions<R>(E, bX, bY, r, em, exs, exl, eys, eyl);
+            Cell c = bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
+            kill_outside(c, jr[r], n);
+            io.c[r] = c;
+        }
+    } else {
+        bases_up<R>(bY, feed_get<-1>(fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
+        const Diag<R> Xs = shift_up<R>(s1);    // (x+1, y) is index j+1 on d+1; (x, y+1) keeps index j
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float em, exs, exl, eys, eyl;
+            emissions<R>(E, bX, bY, r, em, exs, exl, eys, eyl);
+            Cell c = bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
+            kill_outside(c, jr[r], n);
+            io.c[r] = c;
+        }
+    }
+}
+
 template <int R>
 __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmodel = reinterpret_cast<float *>(smem);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // 8 ints: cell hand-off
-    const char *ltab = reinterpret_cast<const char *>(lmodel);    // byte-addressed table look-ups
 
     const int lane = threadIdx.x;
     float *const Fv = a.Fv + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
@@ -174,8 +359,6 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
                       pair_off = uni64(tp->pair_off);
         const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap),
                   flags = uni(tp->flags), model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
-        const uint8_t *X = a.seq + x_off;
-        const uint8_t *Y = a.seq + y_off;
         // band rows through the scalar cache: these arrays are never written by the kernel
         cptr32 blo = (cptr32)(a.lo + band_off);
         cptr32 bn = (cptr32)(a.n + band_off);
@@ -188,101 +371,77 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
             for (int i = lane; i < MODEL_FLOATS; i += WAVE) lmodel[i] = gm[i];
         }
         __syncthreads();
-        const DevModel *mdl = reinterpret_cast<const DevModel *>(lmodel);
-        Trans tr = load_trans(mdl->T);
-        tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
-        tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
-        tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
-        tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
-        // byte offsets of the tables inside the staged model
-        constexpr int OFF_EM = offsetof(DevModel, em), OFF_EX = offsetof(DevModel, ex), OFF_EY = offsetof(DevModel, ey);
+        StepEnv E;
+        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
+        E.ltab = reinterpret_cast<const char *>(lmodel);
+        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
+        {
+            // A VALU op with an SGPR source issues ~1.7x slower on gfx950 (tools/valu_rates: v_fma_f32 v,s,v,v
+            // 4.7 vs 2.7 cycles), so with one cell per lane the 15 transitions stay in VGPRs.  With more cells
+            // per lane the 15 registers would cost a wave of occupancy per SIMD, which costs more: SGPRs there.
+            Trans tr = load_trans(E.mdl->T);
+            if constexpr (R >= 2) {
+                tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
+                tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
+                tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
+                tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
+            }
+            E.tr = tr;
+        }
+        const DevModel *mdl = E.mdl;
 
         // =============================== forward ===============================
-        Diag<R> P1 = dead_diag<R>(), P2 = dead_diag<R>();
+        // A holds the even anti-diagonals, B the odd ones.
+        Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
         Bases<R> cX, cY;  // X[x-1]*4 and Y[y-1]*4 of every slot
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            cX.b[r] = base4(X, lX, jr[r] - 1);  // d = 0: x0 = 0, y0 = 0
-            cY.b[r] = base4(Y, lY, -jr[r] - 1);
+            cX.b[r] = base4(E.X, lX, jr[r] - 1);  // d = 0: x0 = 0, y0 = 0
+            cY.b[r] = base4(E.Y, lY, -jr[r] - 1);
         }
         Feed fx, fy;
-        feed_init<+1>(fx, X, lX, 64 * R - 1, lane);  // first x-step injects X[1 + 64R - 2]
-        feed_init<+1>(fy, Y, lY, 0, lane);           // first y-step injects Y[0]
-        int lo1 = 0, lo2 = 0;
-        BandRow row{blo[0], bn[0], static_cast<uint32_t>(bco[0])};
-        for (int d = 0; d <= D; ++d) {
-            const BandRow cur = row;
-            if (d < D) row = BandRow{blo[d + 1], bn[d + 1], static_cast<uint32_t>(bco[d + 1])};  // one row ahead
-            const int lo = cur.lo, n = cur.n;
-            const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
-            Diag<R> C;
-            if (d == 0) {
+        feed_init<+1>(fx, E.X, lX, 64 * R - 1, lane);  // first x-step injects X[1 + 64R - 2]
+        feed_init<+1>(fy, E.Y, lY, 0, lane);           // first y-step injects Y[0]
+        BandRow r0{blo[0], bn[0], static_cast<uint32_t>(bco[0])};
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    Cell c = dead_cell();
-                    if (jr[r] == 0) {
-                        c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
-                        c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
-                        normalise(c, 0);
-                    }
-                    C.c[r] = c;
-                }
-            } else {
-                const int s = lo - lo1;               // +1: x-step, -1: y-step
-                const int sm = (lo - lo2) >> 1;       // shift of the d-2 frame: -1, 0, +1 (d == 1: unused, P2 dead)
-                Diag<R> L, U, M;
-                if (s > 0) {
-                    bases_up<R>(cX, feed_get<+1>(fx, X, lX, x0 + 64 * R - 2, lane));
-                    L = P1;
-                    U = shift_up<R>(P1);
-                } else {
-                    bases_down<R>(cY, feed_get<+1>(fy, Y, lY, y0 - 1, lane));
-                    U = P1;
-                    L = shift_down<R>(P1);
-                }
-                if (sm == 0) {
-                    M = P2;
-                } else if (sm > 0) {
-                    M = shift_up<R>(P2);
-                } else {
-                    M = shift_down<R>(P2);
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float em = *reinterpret_cast<const float *>(ltab + OFF_EM + 5 * cX.b[r] + cY.b[r]);
-                    const float exs = *reinterpret_cast<const float *>(ltab + OFF_EX + 20 + cX.b[r]);
-                    const float exl = *reinterpret_cast<const float *>(ltab + OFF_EX + 60 + cX.b[r]);
-                    const float eys = *reinterpret_cast<const float *>(ltab + OFF_EY + 40 + cY.b[r]);
-                    const float eyl = *reinterpret_cast<const float *>(ltab + OFF_EY + 80 + cY.b[r]);
-                    Cell c = fwd_cell(tr, L.c[r], M.c[r], U.c[r], em, exs, exl, eys, eyl);
-                    if (jr[r] >= n) c = dead_cell();
-                    C.c[r] = c;
-                }
+        for (int r = 0; r < R; ++r)
+            if (jr[r] == 0) {
+                Cell c;
+                c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
+                c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
+                normalise(c, 0);
+                A.c[r] = c;
             }
-            // stream the match state to HBM: R consecutive cells per lane
-            if (R * lane < n) {
-                if constexpr (R == 1) {
-                    Fv[cur.co + lane] = C.c[0].m;
-                    Fe[cur.co + lane] = C.c[0].e;
-                } else if constexpr (R == 2) {
-                    *reinterpret_cast<float2 *>(Fv + cur.co + 2 * lane) = make_float2(C.c[0].m, C.c[1].m);
-                    *reinterpret_cast<int2 *>(Fe + cur.co + 2 * lane) = make_int2(C.c[0].e, C.c[1].e);
-                } else {
-                    *reinterpret_cast<float4 *>(Fv + cur.co + 4 * lane) = make_float4(C.c[0].m, C.c[1].m, C.c[2].m, C.c[3].m);
-                    *reinterpret_cast<int4 *>(Fe + cur.co + 4 * lane) = make_int4(C.c[0].e, C.c[1].e, C.c[2].e, C.c[3].e);
-                }
-            }
-            P2 = P1;
-            P1 = C;
-            lo2 = lo1, lo1 = lo;
+        store_row<R>(Fv, Fe, A, r0.co, r0.n, lane);
+        int lo1 = r0.lo, lo2 = r0.lo;  // first x-y of d-1 and d-2
+        BandRow nx{0, 0, 0};
+        if (D >= 1) nx = BandRow{blo[1], bn[1], static_cast<uint32_t>(bco[1])};
+        int d = 1;
+        for (; d + 1 <= D; d += 2) {
+            BandRow cur = nx;
+            nx = BandRow{blo[d + 1], bn[d + 1], static_cast<uint32_t>(bco[d + 1])};  // one row ahead
+            fwd_step<R>(E, B, A, cX, cY, fx, fy, d, cur.lo, cur.n, lo1, lo2, jr);
+            store_row<R>(Fv, Fe, B, cur.co, cur.n, lane);
+            lo2 = lo1, lo1 = cur.lo;
+            cur = nx;
+            if (d + 2 <= D) nx = BandRow{blo[d + 2], bn[d + 2], static_cast<uint32_t>(bco[d + 2])};
+            fwd_step<R>(E, A, B, cX, cY, fx, fy, d + 1, cur.lo, cur.n, lo1, lo2, jr);
+            store_row<R>(Fv, Fe, A, cur.co, cur.n, lane);
+            lo2 = lo1, lo1 = cur.lo;
+        }
+        if (d <= D) {  // D odd: one more step, into B
+            fwd_step<R>(E, B, A, cX, cY, fx, fy, d, nx.lo, nx.n, lo1, lo2, jr);
+            store_row<R>(Fv, Fe, B, nx.co, nx.n, lane);
+            lo2 = lo1, lo1 = nx.lo;
         }
         // total probability at the end corner: cell j = (lX - lY - lo_D) / 2 of the last diagonal
         {
             const int je = (lX - lY - lo1) >> 1;
+            const bool oddD = D & 1;
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (jr[r] == je) {
-                    const Cell &c = P1.c[r];
+                    const Cell c = oddD ? B.c[r] : A.c[r];
                     const float raw = dot5(mdl->end + re * 5, c);
                     float tm = 0.f;
                     int te = E_DEAD;
@@ -310,140 +469,67 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
         int cnt = 0;
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
-            Diag<R> S1 = dead_diag<R>(), S2 = dead_diag<R>();  // diagonals d+1 and d+2
+            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            // P holds diagonals D, D-2, ...; Q holds D-1, D-3, ...
+            Diag<R> P = dead_diag<R>(), Q = dead_diag<R>();
             Bases<R> bX, bY;  // X[x]*4 and Y[y]*4 of every slot
+            BandRow cur{blo[D], bn[D], static_cast<uint32_t>(bco[D])};
             {
-                const int x0 = (D + lo1) >> 1, y0 = (D - lo1) >> 1;
+                const int x0 = (D + cur.lo) >> 1, y0 = (D - cur.lo) >> 1;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    bX.b[r] = base4(X, lX, x0 + jr[r]);
-                    bY.b[r] = base4(Y, lY, y0 - jr[r]);
+                    bX.b[r] = base4(E.X, lX, x0 + jr[r]);
+                    bY.b[r] = base4(E.Y, lY, y0 - jr[r]);
+                    if (jr[r] < cur.n && x0 + jr[r] == lX && y0 - jr[r] == lY) {
+                        Cell c;
+                        c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
+                        c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
+                        normalise(c, 0);
+                        P.c[r] = c;
+                    }
                 }
-                // first backward x-step injects X[x0 - 1] at slot 0; first y-step injects Y[y0 - 1 - (64R-1)] on top
-                feed_init<-1>(fx, X, lX, x0 - 1, lane);
-                feed_init<-1>(fy, Y, lY, y0 - 64 * R, lane);
+                // first backward x-step injects X[x0 - 1] at slot 0; first y-step injects Y[y0 - 64R] on top
+                feed_init<-1>(fx, E.X, lX, x0 - 1, lane);
+                feed_init<-1>(fy, E.Y, lY, y0 - 64 * R, lane);
             }
-            int hi1 = 0, hi2 = 0;  // lo of d+1, d+2
-            BandRow brow{blo[D], bn[D], static_cast<uint32_t>(bco[D])};
-            // forward values of the current diagonal, loaded one diagonal ahead
-            float fv[R];
-            int fe[R];
-            auto loadF = [&](const BandRow &w, float (&v)[R], int (&e)[R]) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) v[r] = 0.f, e[r] = E_DEAD;
-                if (R * lane < w.n) {
-                    if constexpr (R == 1) {
-                        v[0] = Fv[w.co + lane];
-                        e[0] = Fe[w.co + lane];
-                    } else if constexpr (R == 2) {
-                        const float2 q = *reinterpret_cast<const float2 *>(Fv + w.co + 2 * lane);
-                        const int2 g = *reinterpret_cast<const int2 *>(Fe + w.co + 2 * lane);
-                        v[0] = q.x, v[1] = q.y, e[0] = g.x, e[1] = g.y;
-                    } else {
-                        const float4 q = *reinterpret_cast<const float4 *>(Fv + w.co + 4 * lane);
-                        const int4 g = *reinterpret_cast<const int4 *>(Fe + w.co + 4 * lane);
-                        v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w, e[0] = g.x, e[1] = g.y, e[2] = g.z, e[3] = g.w;
-                    }
-                }
-            };
-            loadF(brow, fv, fe);
-            for (int d = D; d >= 0; --d) {
-                const BandRow cur = brow;
-                float fvn[R];
-                int fen[R];
-                if (d > 0) {
-                    brow = BandRow{blo[d - 1], bn[d - 1], static_cast<uint32_t>(bco[d - 1])};
-                    loadF(brow, fvn, fen);  // issued a whole diagonal ahead of its use
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) fvn[r] = 0.f, fen[r] = E_DEAD;
-                }
-                const int lo = cur.lo, n = cur.n;
-                const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
-                Diag<R> C;
-                if (d == D) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        Cell c = dead_cell();
-                        if (jr[r] < n && x0 + jr[r] == lX && y0 - jr[r] == lY) {
-                            c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
-                            c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
-                            normalise(c, 0);
-                        }
-                        C.c[r] = c;
-                    }
-                } else {
-                    const int s = hi1 - lo;            // the forward step d -> d+1: +1 x-step, -1 y-step
-                    const int sm = (lo - hi2) >> 1;    // index shift into the d+2 frame (d+2 > D: S2 dead)
-                    Diag<R> Xs, Ys, Ms;
-                    if (s > 0) {
-                        // x decreased by one for every slot: X[x] moves up a slot, slot 0 takes X[x0]
-                        bases_down<R>(bX, feed_get<-1>(fx, X, lX, x0, lane));
-                        Xs = S1;               // (x+1, y) has the same index on d+1
-                        Ys = shift_down<R>(S1);  // (x, y+1) is index j-1 on d+1
-                    } else {
-                        bases_up<R>(bY, feed_get<-1>(fy, Y, lY, y0 - (64 * R - 1), lane));
-                        Xs = shift_up<R>(S1);
-                        Ys = S1;
-                    }
-                    if (d + 2 > D || sm == 0) {
-                        Ms = S2;
-                    } else if (sm > 0) {
-                        Ms = shift_up<R>(S2);
-                    } else {
-                        Ms = shift_down<R>(S2);
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float em = *reinterpret_cast<const float *>(ltab + OFF_EM + 5 * bX.b[r] + bY.b[r]);
-                        const float exs = *reinterpret_cast<const float *>(ltab + OFF_EX + 20 + bX.b[r]);
-                        const float exl = *reinterpret_cast<const float *>(ltab + OFF_EX + 60 + bX.b[r]);
-                        const float eys = *reinterpret_cast<const float *>(ltab + OFF_EY + 40 + bY.b[r]);
-                        const float eyl = *reinterpret_cast<const float *>(ltab + OFF_EY + 80 + bY.b[r]);
-                        Cell c = bwd_cell(tr, Ms.c[r], Xs.c[r], Ys.c[r], em, exs, exl, eys, eyl);
-                        if (jr[r] >= n) c = dead_cell();
-                        C.c[r] = c;
-                    }
-                }
-                // posteriors of this diagonal
-                float p[R];
-                bool anyhit = false;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    p[r] = posterior(fv[r], fe[r], C.c[r].m, C.c[r].e, tot_e, inv_tot);
-                    // pairs need x >= 1 and y >= 1: from d = 2 on, the forward match value is zero elsewhere
-                    // (d = 0 is the start cell, whose match state holds the start probability)
-                    anyhit |= (p[r] >= a.threshold) && (jr[r] < n) && (d >= 2);
-                }
-                if (__ballot(anyhit)) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const bool hit = (p[r] >= a.threshold) && (jr[r] < n);
-                        const unsigned long long mask = __ballot(hit);
-                        if (mask) {
-                            const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                            if (hit && slot < pair_cap) {
-                                a.px[pair_off + slot] = x0 + jr[r] - 1 + xs;
-                                a.py[pair_off + slot] = y0 - jr[r] - 1 + ys;
-                                a.pp[pair_off + slot] = p[r];
-                            }
-                            cnt += __popcll(mask);
-                        }
-                    }
-                }
-                S2 = S1;
-                S1 = C;
-                hi2 = hi1, hi1 = lo;
-#pragma unroll
-                for (int r = 0; r < R; ++r) fv[r] = fvn[r], fe[r] = fen[r];
+            FRow<R> fa, fb;  // forward rows: fa pairs with P's diagonals, fb with Q's; loaded one diagonal ahead
+            load_row<R>(Fv, Fe, fa, cur.co, cur.n, lane);
+            BandRow nxt = cur;
+            if (D >= 1) {
+                nxt = BandRow{blo[D - 1], bn[D - 1], static_cast<uint32_t>(bco[D - 1])};
+                load_row<R>(Fv, Fe, fb, nxt.co, nxt.n, lane);
             }
-            // total from the backward side: cell (0,0) is slot 0 of diagonal 0
+            emit_pairs<R>(sink, P, fa, D, cur.lo, cur.n, tot_e, inv_tot, jr, lane, cnt);
+            int hi1 = cur.lo, hi2 = cur.lo;  // first x-y of d+1 and d+2
+            int d2 = D - 1;
+            for (; d2 - 1 >= 0; d2 -= 2) {
+                cur = nxt;
+                nxt = BandRow{blo[d2 - 1], bn[d2 - 1], static_cast<uint32_t>(bco[d2 - 1])};
+                load_row<R>(Fv, Fe, fa, nxt.co, nxt.n, lane);  // for the step after this one
+                bwd_step<R>(E, Q, P, bX, bY, fx, fy, d2, cur.lo, cur.n, hi1, hi2, jr);
+                emit_pairs<R>(sink, Q, fb, d2, cur.lo, cur.n, tot_e, inv_tot, jr, lane, cnt);
+                hi2 = hi1, hi1 = cur.lo;
+                cur = nxt;
+                if (d2 - 2 >= 0) {
+                    nxt = BandRow{blo[d2 - 2], bn[d2 - 2], static_cast<uint32_t>(bco[d2 - 2])};
+                    load_row<R>(Fv, Fe, fb, nxt.co, nxt.n, lane);
+                }
+                bwd_step<R>(E, P, Q, bX, bY, fx, fy, d2 - 1, cur.lo, cur.n, hi1, hi2, jr);
+                emit_pairs<R>(sink, P, fa, d2 - 1, cur.lo, cur.n, tot_e, inv_tot, jr, lane, cnt);
+                hi2 = hi1, hi1 = cur.lo;
+            }
+            if (d2 >= 0) {  // d2 == 0 left over (D odd): into Q
+                bwd_step<R>(E, Q, P, bX, bY, fx, fy, d2, nxt.lo, nxt.n, hi1, hi2, jr);
+                emit_pairs<R>(sink, Q, fb, d2, nxt.lo, nxt.n, tot_e, inv_tot, jr, lane, cnt);
+            }
+            // total from the backward side: cell (0,0) is slot 0 of diagonal 0 (in P when D is even)
             if (lane == 0) {
-                const float raw = dot5(mdl->start + rs * 5, S1.c[0]);
+                const Cell c0 = (D & 1) ? Q.c[0] : P.c[0];
+                const float raw = dot5(mdl->start + rs * 5, c0);
                 if (raw > 0.f) {
                     int k;
                     out.btot_m = __builtin_frexpf(raw, &k);
-                    out.btot_e = S1.c[0].e + k;
+                    out.btot_e = c0.e + k;
                 }
             }
         }

@@ -67,20 +67,30 @@ static void model32_init(model32 *m, const orc_hmm *h) {
 
 static inline int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 
-/* 2^k for k <= 0, flushed to zero below 2^-100 */
-static inline float scale2(int32_t k) { return k < -100 ? 0.0f : ldexpf(1.0f, k); }
+static inline float from_bits(int32_t b) {
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+static inline int32_t to_bits(float f) {
+    int32_t b;
+    memcpy(&b, &f, 4);
+    return b;
+}
 
+/* 2^k for -126 <= k <= 0 from its bit pattern, 0 below (k is an exponent difference, never positive) */
+static inline float scale2(int32_t k) {
+    const int32_t t = k + 127;
+    return from_bits((t > 0 ? t : 0) << 23);
+}
+
+/* multiply by 2^(126 - E), E the biased exponent field of the largest value; shared exponent += E - 126 */
 static inline void normalise(cell32 *c, int32_t eref) {
-    float vmax = fmaxf(fmaxf(c->v[0], c->v[1]), fmaxf(fmaxf(c->v[2], c->v[3]), c->v[4]));
-    if (vmax > 0.0f) {
-        int k;
-        (void)frexpf(vmax, &k);
-        for (int s = 0; s < 5; s++) c->v[s] = ldexpf(c->v[s], -k);
-        c->e = eref + k;
-    } else {
-        for (int s = 0; s < 5; s++) c->v[s] = 0.0f;
-        c->e = E_DEAD;
-    }
+    const float vmax = fmaxf(fmaxf(c->v[0], c->v[1]), fmaxf(fmaxf(c->v[2], c->v[3]), c->v[4]));
+    const int32_t bits = to_bits(vmax) & 0x7f800000;
+    const float inv = from_bits(0x7e800000 - bits);
+    for (int s = 0; s < 5; s++) c->v[s] = c->v[s] * inv;
+    c->e = vmax > 0.0f ? eref + (bits >> 23) - 126 : E_DEAD;
 }
 
 static const cell32 DEAD = {{0.f, 0.f, 0.f, 0.f, 0.f}, E_DEAD};

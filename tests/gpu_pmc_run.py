@@ -1,0 +1,13 @@
+"""One staged batch, a few DP launches: the target of rocprofv3 --pmc passes."""
+import os, sys
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+from nanopore_amd import realign as R, synth
+from nanopore_amd.hmm import Hmm
+h = Hmm.loadHmm('/root/repo/nanopore_amd/mappers/blasr_hmm_0.txt')
+n = int(sys.argv[1]); L = int(sys.argv[2]); W = int(sys.argv[3])
+w = synth.make_workload(7, n, L, h.transitions, h.emissions, flank=0)
+ctx = R.Context(0); ctx.set_hmm(h)
+b = ctx.stage_csr(R.make_params(band_mode=1, fixed_width=W), w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
+st = b.stats()
+ms = [b.run() for _ in range(2)]
+print('cells', st['cells'], 'ms', ms, flush=True)
