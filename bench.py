@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 BYTES_PER_CELL = 40.0   # fp32 forward store 5x4 B + backward-time reload 5x4 B
+# HBM bytes per cell actually moved by k_dp_stair<2>, from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the
+# gfx950 FETCH_SIZE correction of guides/MI355X_MICROARCH.md): profiles/r01_pmc_k_dp_stair2_4096x10kb_w200.csv.
+# Below the algorithmic 40 B by design: only the match state is stored for the backward sweep (8 B + 8 B).
+MEASURED_TRAFFIC_BYTES_PER_CELL = 17.03
 
 
 def load_model(name="blasr_hmm_0.txt"):
@@ -101,12 +105,21 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # test hook: NPR_BENCH_SHARE_GPU=1 lets N ranks share cuda:0 with gloo collectives, to exercise the
+    # multi-rank code path on a one-GPU box (RCCL refuses two ranks on one device); never used by the driver
+    share = os.environ.get("NPR_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if share else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from nanopore_amd import realign as R
     n_reads = args.reads or {"northstar": 4096, "c2": 1000, "c3": 50000}[args.workload]
@@ -134,10 +147,10 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([cells, n_reads], dtype=torch.int64, device="cuda")
+        c = torch.tensor([cells, n_reads], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells, total_reads = int(c[0].item()), int(c[1].item())
     else:
@@ -155,7 +168,7 @@ def main():
         payload = npd.pack_results(np.arange(n_reads) + rank * n_reads, res["status"], res["score"], off, ops)
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        got = npd.gather_to_root(payload, device="cuda:%d" % local_rank)
+        got = npd.gather_to_root(payload, device=("cpu" if share else "cuda:%d" % local_rank))
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
@@ -184,7 +197,9 @@ def main():
                        "kernel_variant": int(st["kernel_variant"]), "parallelism": "reads sharded x%d" % world},
             "reads_per_s": total_reads * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": MEASURED_TRAFFIC_BYTES_PER_CELL * cells / 1e9,
+                         "traffic_unit": "GB per launch (PMC-derived bytes/cell x cells of this launch)",
                          "kernel": "k_dp", "kernel_ms": kms, "algorithmic_bytes_per_cell": BYTES_PER_CELL},
             "ok_reads": int((res["status"] == 0).sum()),
             "finish_s": finish_s,

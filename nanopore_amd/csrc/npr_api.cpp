@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,12 @@ struct npr_ctx {
     DevModel *d_models = nullptr;
     std::string last_error;
     int host_threads = 1;
+    // Forward-value scratch (one region per resident wavefront) lives with the context and only grows: a
+    // hipMalloc of ~100 GB costs seconds, far more than the DP pass it serves.  Batches on one context run one
+    // at a time (include/nprealign.h), so they can share it.
+    float *arena_Fv = nullptr;
+    int32_t *arena_Fe = nullptr;
+    size_t arena_cells = 0;
 };
 
 namespace {
@@ -76,6 +83,20 @@ int32_t fail(npr_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuc
         hipError_t _e = (expr);                                             \
         if (_e != hipSuccess) return fail((ctx), NPR_ERR_HIP, #expr, _e);   \
     } while (0)
+
+// NPR_TIMING=1 prints host-stage wall times to stderr (bring-up / DESIGN.md host-inclusive numbers)
+struct StageTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char *what;
+    explicit StageTimer(const char *w) : on(std::getenv("NPR_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+    void lap(const char *label) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[npr timing] %s / %s: %.1f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 template <typename F>
 void parallel_for(int64_t n, int threads, F f) {
@@ -121,8 +142,7 @@ struct npr_batch {
     DevBuf<uint8_t> d_seq;
     DevBuf<int32_t> d_lo, d_n;
     DevBuf<uint32_t> d_coff;
-    DevBuf<float> d_Fv;
-    DevBuf<int32_t> d_Fe;
+    size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -219,6 +239,8 @@ void npr_destroy(npr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_models) (void)hipFree(ctx->d_models);
+    if (ctx->arena_Fv) (void)hipFree(ctx->arena_Fv);
+    if (ctx->arena_Fe) (void)hipFree(ctx->arena_Fe);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -275,6 +297,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->guide_off.assign(guide_off, guide_off + (n_reads ? n_reads + 1 : 0));
     if (n_reads) b->guide_ops.assign(guide_ops, guide_ops + 2 * guide_off[n_reads]);
 
+    StageTimer tm("batch_create");
     // 1. plan every read (host threads; the analogue of the reference's one-job-per-read fan-out)
     std::vector<Plan> plans(n_reads);
     parallel_for(n_reads, ctx->host_threads, [&](int64_t i) {
@@ -299,6 +322,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         b->read_status[i] = rc;
     });
 
+    tm.lap("plan");
     // 2. flatten into tasks, longest first
     struct Ref {
         int64_t read;
@@ -409,13 +433,14 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         max_pad = std::max(max_pad, pad_cells[k]);
     }
 
+    tm.lap("flatten + encode + band arrays");
     // 3. device buffers
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     b->slot_stride = (max_pad + 63) & ~int64_t(63);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
     const int64_t fixed = seq_bytes + band_entries * 12 + pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
-    const int64_t budget = static_cast<int64_t>(free_b * 0.9) - fixed;
+    const int64_t budget = static_cast<int64_t>((free_b + ctx->arena_cells * 8) * 0.9) - fixed;
     int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
         fit = budget / (b->slot_stride * 8);
@@ -458,9 +483,19 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         (e = b->d_queue.alloc(8)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
         (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
         (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_px.alloc(pair_total)) != hipSuccess ||
-        (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess ||
-        (e = b->d_Fv.alloc(b->slot_stride * grid)) != hipSuccess || (e = b->d_Fe.alloc(b->slot_stride * grid)) != hipSuccess)
+        (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(grid);
+    if (b->scratch_cells > ctx->arena_cells) {
+        if (ctx->arena_Fv) (void)hipFree(ctx->arena_Fv);
+        if (ctx->arena_Fe) (void)hipFree(ctx->arena_Fe);
+        ctx->arena_Fv = nullptr, ctx->arena_Fe = nullptr, ctx->arena_cells = 0;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_Fv), b->scratch_cells * sizeof(float))) != hipSuccess ||
+            (e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_Fe), b->scratch_cells * sizeof(int32_t))) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc of the forward scratch", e);
+        ctx->arena_cells = b->scratch_cells;
+    }
+    tm.lap("hipMalloc");
     if (ntasks) {
         HIP_TRY(ctx, hipMemcpy(b->d_tasks.p, b->tasks.data(), b->d_tasks.bytes(), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(b->d_seq.p, h_seq.data(), b->d_seq.bytes(), hipMemcpyHostToDevice));
@@ -468,6 +503,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         HIP_TRY(ctx, hipMemcpy(b->d_n.p, h_n.data(), b->d_n.bytes(), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.data(), b->d_coff.bytes(), hipMemcpyHostToDevice));
     }
+    tm.lap("H2D");
     b->outs.resize(ntasks);
     b->stats.n_reads = n_reads;
     b->stats.n_tasks = ntasks;
@@ -496,8 +532,8 @@ static KernelArgs make_args(npr_batch *b) {
     a.lo = b->d_lo.p;
     a.n = b->d_n.p;
     a.coff = b->d_coff.p;
-    a.Fv = b->d_Fv.p;
-    a.Fe = b->d_Fe.p;
+    a.Fv = b->ctx->arena_Fv;
+    a.Fe = b->ctx->arena_Fe;
     a.slot_stride = b->slot_stride;
     a.px = b->d_px.p;
     a.py = b->d_py.p;
@@ -542,6 +578,7 @@ int32_t npr_batch_finish(npr_batch *b) {
     npr_ctx *ctx = b->ctx;
     if (!b->ran) return fail(ctx, NPR_ERR_STATE, "npr_batch_finish before npr_batch_run");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    StageTimer tm("batch_finish");
     const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
     std::vector<int64_t> dst(ntasks + 1, 0);
     std::vector<int32_t> hx, hy;
@@ -570,6 +607,7 @@ int32_t npr_batch_finish(npr_batch *b) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
 
+    tm.lap("compact + D2H");
     // per read: merge its segments' pairs (sorted by (x,y)), then MEA / rescore
     const int64_t n = b->n_reads;
     b->results.assign(n, npr_read_result{});
@@ -617,10 +655,12 @@ int32_t npr_batch_finish(npr_batch *b) {
         }
         r.n_ops = static_cast<int64_t>(per_read_ops[i].size() / 2);
     });
+    tm.lap("sort + MEA + cigar");
     b->ops_off.assign(n + 1, 0);
     for (int64_t i = 0; i < n; ++i) b->ops_off[i + 1] = b->ops_off[i] + static_cast<int64_t>(per_read_ops[i].size() / 2);
     b->ops.resize(2 * b->ops_off[n]);
     for (int64_t i = 0; i < n; ++i) std::copy(per_read_ops[i].begin(), per_read_ops[i].end(), b->ops.begin() + 2 * b->ops_off[i]);
+    tm.lap("gather ops");
     b->finished = true;
     return NPR_OK;
 }
@@ -708,8 +748,8 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
         HIP_TRY(ctx, hipMemcpy(co.data(), b->d_coff.p + t.band_off, sizeof(uint32_t) * (t.D + 1), hipMemcpyDeviceToHost));
         std::vector<float> fv(t.cells_pad), bv(t.cells_pad);
         std::vector<int32_t> fe(t.cells_pad), be(t.cells_pad);
-        HIP_TRY(ctx, hipMemcpy(fv.data(), b->d_Fv.p, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(fe.data(), b->d_Fe.p, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fv.data(), ctx->arena_Fv, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fe.data(), ctx->arena_Fe, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(bv.data(), d_Bv.p, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(be.data(), d_Be.p, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
         for (int32_t d = 0; d <= t.D; ++d)

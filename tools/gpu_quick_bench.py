@@ -1,6 +1,6 @@
 """Bring-up throughput probe (not the contract bench): synthetic fixed-band batch, kernel ms."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from helpers import *
 from nanopore_amd import realign as R

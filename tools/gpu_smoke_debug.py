@@ -1,7 +1,7 @@
 import sys, time, faulthandler
 faulthandler.enable()
 faulthandler.dump_traceback_later(15, exit=True)
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from helpers import *
 import os

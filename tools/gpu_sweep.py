@@ -1,10 +1,10 @@
 """Bring-up sweep (not the contract bench): kernel ms for the north-star-like batch under env knobs."""
 import os, sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from nanopore_amd import realign as R, synth
 from nanopore_amd.hmm import Hmm
-h = Hmm.loadHmm('/root/repo/nanopore_amd/mappers/blasr_hmm_0.txt')
+h = Hmm.loadHmm(os.path.join(ROOT, 'nanopore_amd', 'mappers', 'blasr_hmm_0.txt'))
 n = int(sys.argv[1]); L = int(sys.argv[2]); W = int(sys.argv[3])
 w = synth.make_workload(7, n, L, h.transitions, h.emissions, flank=0)
 ctx = R.Context(0); ctx.set_hmm(h)
