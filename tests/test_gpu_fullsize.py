@@ -1,0 +1,105 @@
+"""BASELINE.json-sized inputs on the GPU, checked through size-independent properties (and a sample against the
+oracle): forward total == backward total, a base is paired at most once (posterior row / column sums <= 1),
+output cigars are global, per-read-type models (config 5) select the right tables."""
+import numpy as np
+import pytest
+
+from helpers import load_model_arrays, orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(buf):
+    from nanopore_amd.realign import encode
+    return encode(bytes(buf))
+
+
+def _check_invariants(w, res, off, ops, poff, px, py, pp):
+    n = len(w["ref_off"]) - 1
+    assert (res["status"] == 0).all()
+    assert np.allclose(res["loglik"], res["loglik_bwd"], rtol=2e-6)
+    for i in range(n):
+        o = ops[off[i]:off[i + 1]]
+        lx, ly = w["ref_off"][i + 1] - w["ref_off"][i], w["read_off"][i + 1] - w["read_off"][i]
+        assert int(o[o[:, 0] != 1, 1].sum()) == lx and int(o[o[:, 0] != 2, 1].sum()) == ly
+        x, y, p = px[poff[i]:poff[i + 1]], py[poff[i]:poff[i + 1]], pp[poff[i]:poff[i + 1]]
+        assert (p >= 0.01).all() and p.max() <= 1.0 + 1e-5
+        assert np.bincount(y, weights=p, minlength=ly).max() <= 1.0 + 1e-4
+        assert np.bincount(x, weights=p, minlength=lx).max() <= 1.0 + 1e-4
+        assert (np.diff(x.astype(np.int64) * (ly + 1) + y) > 0).all()          # sorted by (x, y), no duplicates
+
+
+def test_north_star_shape_properties_and_oracle_sample(gpu_ctx):
+    """~10 kb reads x 50 kb slices, W = 200 (the shape the north-star target is quoted on)."""
+    from nanopore_amd import realign as R, synth
+    from nanopore_amd.hmm import Hmm
+    from helpers import MODEL_DIR
+    T, E, _ = load_model_arrays()
+    w, W = synth.config_north_star(T, E, n_reads=96)
+    gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
+    b = gpu_ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"],
+                          w["read_off"], w["guide_ops"], w["guide_off"])
+    assert b.stats()["kernel_variant"] == 1
+    b.run()
+    b.finish()
+    res = b.results()
+    off, ops = b.ops()
+    poff, px, py, pp = b.pairs()
+    b.close()
+    _check_invariants(w, res, off, ops, poff, px, py, pp)
+    assert res["cells"].min() > 1e6
+    # the realigner recovers from the degraded guide: most reads come back closer to the truth than the guide
+    # sample: two reads against the oracle's fp32 mirror (bit-exact) -- ~4e6 cells each
+    h = orc.make_hmm(T, E)
+    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
+    for i in (0, 57):
+        X = _codes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]])
+        Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
+        g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
+        m = orc.realign_read(h, P, X, Y, g, precision=1)
+        assert m["cells"] == res["cells"][i]
+        assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
+        order = np.lexsort((m["py"], m["px"]))
+        assert np.array_equal(pp[poff[i]:poff[i + 1]], m["pp"].astype(np.float32)[order])
+
+
+def test_long_reads_and_per_read_type_models(gpu_ctx):
+    """Config 5 in miniature: 10-50 kb reads, three read types with their own HMM slot (hmm_0 / 20 / 40)."""
+    from nanopore_amd import realign as R, synth
+    from nanopore_amd.hmm import Hmm
+    from helpers import MODEL_DIR
+    T, E, _ = load_model_arrays()
+    w = synth.make_workload(1005, 12, 30000, T, E, flank=400, uniform_len=(10000, 50000))
+    slot = np.arange(12, dtype=np.int32) % 3
+    for s, name in enumerate(("blasr_hmm_0.txt", "blasr_hmm_20.txt", "blasr_hmm_40.txt")):
+        gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/" + name), slot=s)
+    P = R.make_params(band_mode=R.BAND_FIXED, fixed_width=200)
+    b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"], model_slot=slot)
+    b.run()
+    b.finish()
+    res = b.results()
+    off, ops = b.ops()
+    poff, px, py, pp = b.pairs()
+    b.close()
+    _check_invariants(w, res, off, ops, poff, px, py, pp)
+    assert (w["read_off"][1:] - w["read_off"][:-1]).max() > 30000
+    # each read used ITS model: the oracle with the matching model reproduces the log-likelihood, another does not
+    PO = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=200)
+    for i in (0, 1, 2):
+        X = _codes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]])
+        Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
+        g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
+        lls = []
+        for name in ("blasr_hmm_0.txt", "blasr_hmm_20.txt", "blasr_hmm_40.txt"):
+            Tm, Em, _ = load_model_arrays(name)
+            lls.append(orc.realign_read(orc.make_hmm(Tm, Em), PO, X, Y, g, precision=1)["total_ll"])
+        assert res["loglik"][i] == pytest.approx(lls[slot[i]], rel=1e-12)
+        assert all(abs(res["loglik"][i] - lls[k]) > 1.0 for k in range(3) if k != slot[i])
+    gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"), slot=0)
+
+
+def test_invalid_model_slot_is_a_per_read_error(gpu_ctx):
+    from nanopore_amd import realign as R
+    P = R.make_params(band_mode=R.BAND_FIXED, fixed_width=20)
+    out = gpu_ctx.realign(P, [b"ACGTACGT", b"ACGTACGT"], [b"ACGTACGT", b"ACGTACGT"], [[(0, 8)], [(0, 8)]], model_slot=[0, 7])
+    assert out[0]["status"] == 0 and out[1]["status"] == -4
