@@ -159,6 +159,15 @@ int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_
  * --outputAllPosteriorProbs (marginAlignSnpCaller.py:149). */
 int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32_t *y, float *p, int64_t cap);
 
+/* Baum-Welch E-step over the staged batch with the models currently installed: what
+ * `cactus_realign --outputExpectations` produces per alignment and cactus_expectationMaximisation sums over all of
+ * them in every EM iteration (nanopore/analyses/utils.py:509-528).  T_exp[slot*25 + from*5 + to] and
+ * E_exp[slot*80 + state*16 + x*4 + y] receive the expected transition / emission counts of the reads that use model
+ * `slot` (gap states: a base's count is spread evenly over the other index), loglik[slot] the summed natural-log
+ * likelihood.  Arrays are NPR_MAX_MODELS slots long and are overwritten.  The band / split plan of the batch is
+ * unaffected, so the call can be repeated after npr_set_hmm for the next iteration. */
+int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, double *loglik, float *kernel_ms);
+
 /* debugging / parity aid: dense per-cell match-state forward and backward values of read i, task-major,
  * band order, as (mantissa, exponent) block-floating-point pairs (value = mant * 2^exp).  Runs the read
  * again on the device.  Buffers sized npr_read_result.cells. */

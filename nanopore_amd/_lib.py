@@ -81,7 +81,8 @@ class NprError(RuntimeError):
 EXPORTS = [
     "npr_abi_version", "npr_strerror", "npr_create", "npr_destroy", "npr_last_error", "npr_set_hmm",
     "npr_batch_create", "npr_batch_run", "npr_batch_finish", "npr_batch_destroy", "npr_batch_get_stats",
-    "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_realign_batch",
+    "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_batch_expectations",
+    "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
     "npr_plan_segment_band", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
 ]
@@ -126,6 +127,8 @@ def load():
     L.npr_batch_ops.argtypes = [vp, vp, vp, i64]
     L.npr_batch_pairs.restype = i32
     L.npr_batch_pairs.argtypes = [vp, vp, vp, vp, vp, i64]
+    L.npr_batch_expectations.restype = i32
+    L.npr_batch_expectations.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.npr_batch_dense.restype = i32
     L.npr_batch_dense.argtypes = [vp, i64, vp, vp, vp, vp, i64]
     L.npr_realign_batch.restype = i32

@@ -284,11 +284,66 @@ def realignSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, hm
     return results
 
 
-def learnModelFromSamFileTargetFn(target, samFile, readFastqFile, referenceFastaFile, outputModel):
-    """EM training of the HMM (utils.py:471-531) -- SURVEY.md 8f next #2: the same forward/backward kernel plus
-    expected-count accumulation.  Not built yet: fail loudly rather than silently using another model."""
-    raise NotImplementedError("EM training (cactus_expectationMaximisation, utils.py:471-531) is scheduled as the next "
-                              "row after the hot path (SURVEY.md 8f #2) and is not implemented in this build")
+EM_SPLIT_MATRIX_BIGGER_THAN = 300  # options.optionsToRealign, utils.py:511
+
+
+def stageSamFile(samFile, referenceFastaFile, splitThreshold, gapGamma=0.5, matchGamma=0.0, mode=None, ctx=None):
+    """Stages every record of a chained SAM file on the GPU (band planning + upload); returns (batch, sam, records)."""
+    from .. import realign
+    ctx = ctx or _context()
+    refSequences = getFastaDictionary(referenceFastaFile)
+    sam = pysam.Samfile(samFile, "r")
+    records = list(samIterator(sam))
+    names = sorted(refSequences)
+    index = {n: i for i, n in enumerate(names)}
+    params = realign.make_params(band_mode=realign.BAND_ANCHOR, diagonal_expansion=REALIGN_DIAGONAL_EXPANSION,
+                                 constraint_trim=CONSTRAINT_DIAGONAL_TRIM, split_threshold=splitThreshold,
+                                 gap_gamma=gapGamma, match_gamma=matchGamma,
+                                 mode=realign.MODE_REALIGN if mode is None else mode)
+    batch = ctx.stage(params, [refSequences[n] for n in names], [aR.query for aR in records], [_guideOf(aR) for aR in records],
+                      ref_index=[index[sam.getrname(aR.rname)] for aR in records])
+    return batch, sam, records
+
+
+def learnModelFromSamFileTargetFn(target, samFile, readFastqFile, referenceFastaFile, outputModel, options=None, ctx=None):
+    """Does expectation maximisation on a (chained) sam file to learn the hmm for it (utils.py:471-531).  The
+    unnormalised model goes to <outputModel>_unnormalised (skipped if it exists, :527), the XML summary to
+    <outputModel>.xml (:518), and learnModelFromSamFileTargetFn2 normalises it into <outputModel>."""
+    from .. import em
+    refSequences = getFastaDictionary(referenceFastaFile)
+    readSequences = getFastqDictionary(readFastqFile)
+    sam = pysam.Samfile(samFile, "r")
+    for aR in sam:  # the global-alignment shape the trainer relies on (utils.py:492-501)
+        assert aR.pos == 0
+        assert aR.qstart == 0
+        assert aR.qend == len(readSequences[aR.qname])
+        assert aR.aend == len(refSequences[sam.getrname(aR.rname)])
+        if aR.is_reverse:
+            assert aR.query.upper() == reverseComplement(readSequences[aR.qname]).upper()
+        else:
+            assert aR.query.upper() == readSequences[aR.qname].upper()
+    sam.close()
+    if options is None:
+        options = em.Options()
+    options.outputXMLModelFile = outputModel + ".xml"
+    unnormalisedOutputModel = outputModel + "_unnormalised"
+    if not os.path.exists(unnormalisedOutputModel):
+        batch, sam, _ = stageSamFile(samFile, referenceFastaFile, EM_SPLIT_MATRIX_BIGGER_THAN, ctx=ctx)
+        try:
+            em.expectationMaximisationTrials(batch, unnormalisedOutputModel, options,
+                                             log=(target.logToMaster if target is not None else None))
+        finally:
+            batch.close()
+            sam.close()
+    learnModelFromSamFileTargetFn2(target, unnormalisedOutputModel, outputModel)
+
+
+def learnModelFromSamFileTargetFn2(target, unnormalisedOutputModel, outputModel):
+    """Flat indel emissions, reference base frequencies normalised to GC 0.5 (utils.py:533-538)."""
+    hmm = Hmm.loadHmm(unnormalisedOutputModel)
+    setHmmIndelEmissionsToBeFlat(hmm)
+    normaliseHmmByReferenceGCContent(hmm, 0.5)
+    hmm.write(outputModel)
 
 
 def realignSamFileTargetFn(target, samFile, outputSamFile, readFastqFile, referenceFastaFile, gapGamma, matchGamma,

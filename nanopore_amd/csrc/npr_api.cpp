@@ -44,6 +44,8 @@ struct npr_ctx {
     float *arena_Fv = nullptr;
     int32_t *arena_Fe = nullptr;
     size_t arena_cells = 0;
+    float *arena_Fx = nullptr;  // E-step only: four more forward planes
+    size_t arena_fx_cells = 0;
 };
 
 namespace {
@@ -155,6 +157,7 @@ struct npr_batch {
     };
     std::vector<Launch> launches;
     DevBuf<float> d_ring;
+    int64_t n_lds_tasks = 0, lds_width = 0, global_width = 0;  // tasks whose bands fit the LDS ring / widest of each kind
     bool ran = false, finished = false;
     // results
     std::vector<npr_read_result> results;
@@ -241,6 +244,7 @@ void npr_destroy(npr_ctx *ctx) {
     if (ctx->d_models) (void)hipFree(ctx->d_models);
     if (ctx->arena_Fv) (void)hipFree(ctx->arena_Fv);
     if (ctx->arena_Fe) (void)hipFree(ctx->arena_Fe);
+    if (ctx->arena_Fx) (void)hipFree(ctx->arena_Fx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -478,6 +482,8 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         b->launches.push_back(L);
     }
     const int64_t grid = ntasks ? max_grid : 0;
+    for (int c = 0; c < 4; ++c) b->n_lds_tasks += cls_count[c], b->lds_width = std::max(b->lds_width, cls_width[c]);
+    b->global_width = cls_width[4];
     hipError_t e;
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
         (e = b->d_queue.alloc(8)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
@@ -702,6 +708,113 @@ int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32
     const int64_t total = b->pair_off[b->n_reads];
     if (cap < total) return NPR_ERR_CAPACITY;
     for (int64_t i = 0; i < total; ++i) x[i] = b->pairs[i].x, y[i] = b->pairs[i].y, p[i] = b->pairs[i].p;
+    return NPR_OK;
+}
+
+int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, double *loglik, float *kernel_ms) {
+    if (!b || !T_exp || !E_exp || !loglik) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::fill(T_exp, T_exp + NPR_MAX_MODELS * 25, 0.0);
+    std::fill(E_exp, E_exp + NPR_MAX_MODELS * 80, 0.0);
+    std::fill(loglik, loglik + NPR_MAX_MODELS, 0.0);
+    if (kernel_ms) *kernel_ms = 0.f;
+    const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
+    if (!ntasks) return NPR_OK;
+    // launch geometry: everything goes through the generic kernel (LDS ring while the band fits, global ring beyond)
+    struct L {
+        int first, count, wcap, grid;
+        size_t lds;
+        bool global_ring;
+    };
+    std::vector<L> launches;
+    int64_t max_grid = 1;
+    if (b->n_lds_tasks) {
+        L l{};
+        l.first = 0, l.count = static_cast<int>(b->n_lds_tasks);
+        l.wcap = static_cast<int>((std::max<int64_t>(b->lds_width, 64) + 3) & ~int64_t(3));
+        l.lds = generic_lds_bytes(l.wcap) + em_extra_lds_bytes();
+        l.global_ring = l.lds > 160 * 1024;  // the bins take 12 KiB of the LDS the ring would otherwise have
+        if (l.global_ring) l.lds = generic_lds_bytes(0) + em_extra_lds_bytes();
+        const int waves = std::min<int>(12, static_cast<int>(std::max<size_t>(1, (160 * 1024) / (l.lds + 256))));
+        l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * waves)));
+        launches.push_back(l);
+    }
+    if (ntasks > b->n_lds_tasks) {
+        L l{};
+        l.first = static_cast<int>(b->n_lds_tasks), l.count = static_cast<int>(ntasks - b->n_lds_tasks);
+        l.wcap = static_cast<int>((b->global_width + 3) & ~int64_t(3));
+        l.lds = generic_lds_bytes(0) + em_extra_lds_bytes();
+        l.global_ring = true;
+        l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * 8)));
+        launches.push_back(l);
+    }
+    size_t ring_floats = 0;
+    for (auto &l : launches) {
+        // the forward scratch of this batch was sized for the DP launches' grid: stay inside it
+        l.grid = static_cast<int>(std::min<int64_t>(l.grid, b->stats.slots));
+        max_grid = std::max<int64_t>(max_grid, l.grid);
+        if (l.global_ring) ring_floats = std::max(ring_floats, static_cast<size_t>(l.grid) * 18 * l.wcap);
+    }
+    const size_t fx_cells = static_cast<size_t>(max_grid) * 4 * static_cast<size_t>(b->slot_stride);
+    hipError_t e;
+    if (fx_cells > ctx->arena_fx_cells) {
+        if (ctx->arena_Fx) (void)hipFree(ctx->arena_Fx);
+        ctx->arena_Fx = nullptr, ctx->arena_fx_cells = 0;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_Fx), fx_cells * sizeof(float))) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc of the forward planes", e);
+        ctx->arena_fx_cells = fx_cells;
+    }
+    DevBuf<float> ring;
+    DevBuf<double> d_T, d_E;
+    if ((e = ring.alloc(ring_floats)) != hipSuccess || (e = d_T.alloc(NPR_MAX_MODELS * 25)) != hipSuccess ||
+        (e = d_E.alloc(NPR_MAX_MODELS * EM_BINS)) != hipSuccess)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc", e);
+    HIP_TRY(ctx, hipMemsetAsync(d_T.p, 0, d_T.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_E.p, 0, d_E.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    int qi = 0;
+    for (const auto &l : launches) {
+        KernelArgs a = make_args(b);
+        a.tasks += l.first;
+        a.outs += l.first;
+        a.ntasks = l.count;
+        a.queue += qi++;
+        a.wcap = l.wcap;
+        a.ring = ring.p;
+        a.Fx = ctx->arena_Fx;
+        a.em_T = d_T.p;
+        a.em_E = d_E.p;
+        const int rc = launch_em(a, l.grid, l.lds, l.global_ring, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "E-step kernel launch", static_cast<hipError_t>(rc));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    std::vector<double> hE(NPR_MAX_MODELS * EM_BINS);
+    HIP_TRY(ctx, hipMemcpy(T_exp, d_T.p, d_T.bytes(), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hE.data(), d_E.p, d_E.bytes(), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(b->outs.data(), b->d_outs.p, b->d_outs.bytes(), hipMemcpyDeviceToHost));
+    for (int m = 0; m < NPR_MAX_MODELS; ++m) {
+        const double *s = hE.data() + m * EM_BINS;
+        double *d = E_exp + m * 80;
+        for (int i = 0; i < 16; ++i) d[i] = s[i];
+        for (int x = 0; x < 4; ++x)
+            for (int y = 0; y < 4; ++y) {
+                d[16 + x * 4 + y] = 0.25 * s[16 + x];  // shortGapX: count of reference base x
+                d[48 + x * 4 + y] = 0.25 * s[20 + x];  // longGapX
+                d[32 + x * 4 + y] = 0.25 * s[24 + y];  // shortGapY: count of read base y
+                d[64 + x * 4 + y] = 0.25 * s[28 + y];  // longGapY
+            }
+    }
+    const double LN2 = 0.69314718055994530942;
+    for (int64_t k = 0; k < ntasks; ++k) {
+        const TaskOut &o = b->outs[k];
+        if (o.status != NPR_OK) return fail(ctx, o.status, "npr_batch_expectations: a segment has zero probability under the model");
+        loglik[b->tasks[k].model] += (std::log2(static_cast<double>(o.tot_m)) + o.tot_e) * LN2;
+    }
+    b->ran = false;  // the task outputs now belong to the E-step
     return NPR_OK;
 }
 

@@ -52,7 +52,14 @@ struct KernelArgs {
     float *Bv;     // dense dump of the backward match state (debug launches only)
     int32_t *Be;
     float *ring;   // generic kernel, global-ring variant: 18*wcap floats per resident wave (bands too wide for LDS)
+    // Baum-Welch E-step launches only (k_dp_generic<.., EM = true>)
+    float *Fx;       // forward sx, sy, lx, ly planes: 4 * slot_stride floats per resident wave
+    double *em_T;    // [NPR_MAX_MODELS][25] expected transition counts, accumulated with atomics
+    double *em_E;    // [NPR_MAX_MODELS][EM_BINS] expected emission counts (compact bins, see EM_BINS)
 };
+
+// compact emission bins of the E-step: 16 match [x*4+y], 4 shortGapX [x], 4 longGapX [x], 4 shortGapY [y], 4 longGapY [y]
+constexpr int EM_BINS = 32;
 
 struct CompactArgs {
     const Task *tasks;
@@ -69,6 +76,8 @@ struct CompactArgs {
 
 // launchers (npr_kernels.hip)
 int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, bool global_ring, void *stream);
+int launch_em(const KernelArgs &a, int grid, size_t lds_bytes, bool global_ring, void *stream);
+size_t em_extra_lds_bytes();
 int launch_compact(const CompactArgs &a, void *stream);
 int launch_stair(const KernelArgs &a, int R, int grid, void *stream);
 size_t stair_lds_bytes();

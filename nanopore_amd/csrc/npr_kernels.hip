@@ -84,12 +84,19 @@ __device__ __forceinline__ int band_index(int xmy, int lo, int n) {
 // anti-diagonals wider than the 160 KiB of LDS can hold (unanchored rectangles up to
 // splitMatrixBiggerThanThis = 3000 cells across).  One wavefront owns the region, and __syncthreads() between
 // anti-diagonals carries the workgroup-scope release/acquire that orders its own stores and loads.
-template <bool DENSE, bool GLOBAL_RING>
+// EM: Baum-Welch E-step (cactus_realign --outputExpectations, summed by
+// cactus_expectationMaximisation at nanopore/analyses/utils.py:509-528).  The forward sweep keeps all five
+// states per cell in HBM; the backward sweep, after finishing a cell, adds the posterior probability of every
+// transition INTO that cell to 15 per-lane accumulators and the emitted symbols' posterior to per-lane LDS bins;
+// the wavefront reduces them at the end of the task and adds them to the model's global counts (fp64 atomics).
+template <bool DENSE, bool GLOBAL_RING, bool EM>
 __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ring ring{GLOBAL_RING ? a.ring + static_cast<int64_t>(blockIdx.x) * 18 * a.wcap : reinterpret_cast<float *>(smem), a.wcap};
     float *lmodel = reinterpret_cast<float *>(smem) + (GLOBAL_RING ? 0 : 18 * a.wcap);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..1] totals hand-off
+    float *lbins = reinterpret_cast<float *>(lmisc + 4);          // EM only: (EM_BINS + 15) rows of 64 lanes
+    float *const Fx = EM ? a.Fx + static_cast<int64_t>(blockIdx.x) * 4 * a.slot_stride : nullptr;
 
     const int lane = threadIdx.x;
     float *const Fv = a.Fv + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
@@ -151,6 +158,12 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
                 ring.put(cur, j, c);
                 Fv[co + j] = c.m;
                 Fe[co + j] = c.e;
+                if (EM) {
+                    Fx[co + j] = c.sx;
+                    Fx[a.slot_stride + co + j] = c.sy;
+                    Fx[2 * a.slot_stride + co + j] = c.lx;
+                    Fx[3 * a.slot_stride + co + j] = c.ly;
+                }
             }
             __syncthreads();
             lo2 = lo1, n2 = n1, lo1 = lo, n1 = n;
@@ -187,10 +200,27 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
         const float inv_tot = 1.0f / tot_m;
         int cnt = 0;
         lo1 = n1 = lo2 = n2 = 0;  // bands of d+1 and d+2
+        float acc[15];            // EM: expected transition counts of this lane
+        if (EM) {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) acc[i] = 0.f;
+            for (int i = 0; i < EM_BINS; ++i) lbins[i * WAVE + lane] = 0.f;
+        }
         for (int d = alive ? D : -1; d >= 0; --d) {
             const int lo = uniform(blo[d]), n = uniform(bn[d]);
             const uint32_t co = static_cast<uint32_t>(uniform(static_cast<int>(bco[d])));
             const int cur = d % 3, s1 = (d + 1) % 3, s2 = (d + 2) % 3;
+            // EM: band rows of the predecessors' diagonals
+            int lom1 = 0, nm1 = 0, lom2 = 0, nm2 = 0;
+            uint32_t com1 = 0, com2 = 0;
+            if (EM && d >= 1) {
+                lom1 = uniform(blo[d - 1]), nm1 = uniform(bn[d - 1]);
+                com1 = static_cast<uint32_t>(uniform(static_cast<int>(bco[d - 1])));
+            }
+            if (EM && d >= 2) {
+                lom2 = uniform(blo[d - 2]), nm2 = uniform(bn[d - 2]);
+                com2 = static_cast<uint32_t>(uniform(static_cast<int>(bco[d - 2])));
+            }
             for (int j0 = 0; j0 < n; j0 += WAVE) {
                 const int j = j0 + lane;
                 bool hit = false;
@@ -219,9 +249,53 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
                             c = bwd_cell(tr, Ms, Xs, Ys, mdl->em[cx * 5 + cy], mdl->ex[5 + cx], mdl->ex[15 + cx],
                                          mdl->ey[10 + cy], mdl->ey[20 + cy]);
                         }
-                        if (x >= 1 && y >= 1) {
+                        if (x >= 1 && y >= 1 && !EM) {
                             p = posterior(Fv[co + j], Fe[co + j], c.m, c.e, tot_e, inv_tot);
                             hit = p >= a.threshold;
+                        }
+                        if (EM && d >= 1 && c.e != E_DEAD) {
+                            const int ss = static_cast<int>(a.slot_stride);
+                            const int ex = x > 0 ? X[x - 1] : 4, ey = y > 0 ? Y[y - 1] : 4;  // bases consumed INTO this cell
+                            const int jM = (x > 0 && y > 0 && d >= 2) ? band_index(xmy, lom2, nm2) : -1;
+                            const int jL = (x > 0) ? band_index(xmy - 1, lom1, nm1) : -1;
+                            const int jU = (y > 0) ? band_index(xmy + 1, lom1, nm1) : -1;
+                            if (jM >= 0) {
+                                const uint32_t q = com2 + jM;
+                                const int s = min(max(Fe[q] + c.e - tot_e, -200), 200);
+                                const float w = __builtin_ldexpf(mdl->em[ex * 5 + ey] * c.m * inv_tot, s);
+                                const float t0 = Fv[q] * tr.mm * w, t1 = Fx[q] * tr.sxm * w, t2 = Fx[ss + q] * tr.sym * w,
+                                            t3 = Fx[2 * ss + q] * tr.lxm * w, t4 = Fx[3 * ss + q] * tr.lym * w;
+                                acc[0] += t0, acc[1] += t1, acc[2] += t2, acc[3] += t3, acc[4] += t4;
+                                if (ex < 4 && ey < 4) lbins[(ex * 4 + ey) * WAVE + lane] += (t0 + t1) + (t2 + t3) + t4;
+                            }
+                            if (jL >= 0) {
+                                const uint32_t q = com1 + jL;
+                                const int s = min(max(Fe[q] + c.e - tot_e, -200), 200);
+                                const float g = __builtin_ldexpf(inv_tot, s);
+                                const float ws = mdl->ex[5 + ex] * c.sx * g, wl = mdl->ex[15 + ex] * c.lx * g;
+                                const float fm = Fv[q];
+                                const float t0 = fm * tr.msx * ws, t1 = Fx[q] * tr.sxsx * ws, t2 = Fx[ss + q] * tr.sysx * ws;
+                                const float u0 = fm * tr.mlx * wl, u1 = Fx[2 * ss + q] * tr.lxlx * wl;
+                                acc[5] += t0, acc[6] += t1, acc[7] += t2, acc[8] += u0, acc[9] += u1;
+                                if (ex < 4) {
+                                    lbins[(16 + ex) * WAVE + lane] += (t0 + t1) + t2;
+                                    lbins[(20 + ex) * WAVE + lane] += u0 + u1;
+                                }
+                            }
+                            if (jU >= 0) {
+                                const uint32_t q = com1 + jU;
+                                const int s = min(max(Fe[q] + c.e - tot_e, -200), 200);
+                                const float g = __builtin_ldexpf(inv_tot, s);
+                                const float ws = mdl->ey[10 + ey] * c.sy * g, wl = mdl->ey[20 + ey] * c.ly * g;
+                                const float fm = Fv[q];
+                                const float t0 = fm * tr.msy * ws, t1 = Fx[ss + q] * tr.sysy * ws, t2 = Fx[q] * tr.sxsy * ws;
+                                const float u0 = fm * tr.mly * wl, u1 = Fx[3 * ss + q] * tr.lyly * wl;
+                                acc[10] += t0, acc[11] += t1, acc[12] += t2, acc[13] += u0, acc[14] += u1;
+                                if (ey < 4) {
+                                    lbins[(24 + ey) * WAVE + lane] += (t0 + t1) + t2;
+                                    lbins[(28 + ey) * WAVE + lane] += u0 + u1;
+                                }
+                            }
                         }
                     }
                     ring.put(cur, j, c);
@@ -244,6 +318,24 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             }
             __syncthreads();
             lo2 = lo1, n2 = n1, lo1 = lo, n1 = n;
+        }
+        if (EM && alive) {
+            // transition accumulators -> LDS rows EM_BINS .. EM_BINS+14, then one lane per row sums 64 values
+#pragma unroll
+            for (int i = 0; i < 15; ++i) lbins[(EM_BINS + i) * WAVE + lane] = acc[i];
+            __syncthreads();
+            if (lane < EM_BINS + 15) {
+                double sum = 0.0;
+                for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
+                if (lane < EM_BINS) {
+                    atomicAdd(a.em_E + tk.model * EM_BINS + lane, sum);
+                } else {
+                    // accumulator order -> T[from*5+to]
+                    const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};
+                    atomicAdd(a.em_T + tk.model * 25 + map[lane - EM_BINS], sum);
+                }
+            }
+            __syncthreads();
         }
         if (lane == 0) {
             const int j0 = alive ? band_index(0, lo1, n1) : -1;
@@ -291,20 +383,28 @@ int generic_max_wcap() {
     return static_cast<int>((160 * 1024 / sizeof(float) - MODEL_FLOATS - 4) / 18) & ~3;
 }
 
-template <bool DENSE, bool GLOBAL_RING>
+template <bool DENSE, bool GLOBAL_RING, bool EM>
 static int launch_generic_t(const KernelArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<DENSE, GLOBAL_RING>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<DENSE, GLOBAL_RING, EM>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL((k_dp_generic<DENSE, GLOBAL_RING>), dim3(grid), dim3(WAVE), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_dp_generic<DENSE, GLOBAL_RING, EM>), dim3(grid), dim3(WAVE), lds_bytes, s, a);
     return static_cast<int>(hipGetLastError());
 }
 
 int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, bool global_ring, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dense) return global_ring ? launch_generic_t<true, true>(a, grid, lds_bytes, s) : launch_generic_t<true, false>(a, grid, lds_bytes, s);
-    return global_ring ? launch_generic_t<false, true>(a, grid, lds_bytes, s) : launch_generic_t<false, false>(a, grid, lds_bytes, s);
+    if (dense) return global_ring ? launch_generic_t<true, true, false>(a, grid, lds_bytes, s) : launch_generic_t<true, false, false>(a, grid, lds_bytes, s);
+    return global_ring ? launch_generic_t<false, true, false>(a, grid, lds_bytes, s) : launch_generic_t<false, false, false>(a, grid, lds_bytes, s);
 }
+
+// lds_bytes must include em_extra_lds_bytes()
+int launch_em(const KernelArgs &a, int grid, size_t lds_bytes, bool global_ring, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return global_ring ? launch_generic_t<false, true, true>(a, grid, lds_bytes, s) : launch_generic_t<false, false, true>(a, grid, lds_bytes, s);
+}
+
+size_t em_extra_lds_bytes() { return sizeof(float) * (EM_BINS + 15) * WAVE; }
 
 int launch_compact(const CompactArgs &a, void *stream) {
     const int grid = a.ntasks < 4096 ? (a.ntasks > 0 ? a.ntasks : 1) : 4096;

@@ -1,0 +1,138 @@
+"""Expectation maximisation of the five-state pair-HMM.
+
+Stands in for cactus.bar.cactus_expectationMaximisation, which the reference drives from
+nanopore/analyses/utils.py:471-531 (`learnModelFromSamFileTargetFn`) and which is absent from the snapshot.  Its
+option names are kept (`Options`, utils.py:509-523).  Where the original runs `cactus_realign --outputExpectations`
+over chunks of alignments as jobTree jobs in every iteration, here one staged GPU batch serves every iteration of
+every trial: `Batch.expectations()` is the E-step (C ABI `npr_batch_expectations`), the M-step is the few lines of
+`normalise` below.  Outputs: the two-line model file and the `hmm.txt.xml` that nanopore/analyses/hmm.py:15-86 and
+nanopore/metaAnalyses/hmmMetaAnalysis.py read (`transition from/to/avg/std`, `emission state/x/y/avg/std`,
+`hmm runningLikelihoods`).
+"""
+import xml.etree.ElementTree as ET
+from xml.dom import minidom
+
+import numpy as np
+
+from .hmm import Hmm, STATE_NUMBER, SYMBOL_NUMBER
+
+# the transitions of the five-state cell update (from, to); everything else stays 0
+USED_TRANSITIONS = [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (3, 0), (3, 3),
+                    (4, 0), (4, 4)]
+# the shipped models carry no short-gap switches (13 transitions); EM from a random start trains all 15
+
+
+class Options(object):
+    """Option names of cactus_expectationMaximisation.Options as set at utils.py:509-523."""
+
+    def __init__(self):
+        self.modelType = "fiveStateAsymmetric"
+        self.optionsToRealign = "--diagonalExpansion=10 --splitMatrixBiggerThanThis=300"
+        self.randomStart = True
+        self.trials = 3
+        self.outputTrialHmms = True
+        self.iterations = 100
+        self.maxAlignmentLengthPerJob = 700000
+        self.maxAlignmentLengthToSample = 50000000
+        self.outputXMLModelFile = None
+        self.trainEmissions = True
+        self.seed = None  # this build: seed of the random starts (None = nondeterministic, like the reference)
+
+
+def randomise(hmm, rng):
+    """Random start: random probabilities on the used transitions, random emissions, everything normalised."""
+    T = np.zeros((STATE_NUMBER, STATE_NUMBER))
+    for a, b in USED_TRANSITIONS:
+        T[a, b] = rng.random() + 1e-3
+    T /= T.sum(axis=1, keepdims=True)
+    hmm.transitions = [float(v) for v in T.reshape(-1)]
+    k = SYMBOL_NUMBER * SYMBOL_NUMBER
+    E = rng.random((STATE_NUMBER, k)) + 1e-3
+    E /= E.sum(axis=1, keepdims=True)
+    hmm.emissions = [float(v) for v in E.reshape(-1)]
+    return hmm
+
+
+def normalise(hmm, T_exp, E_exp, trainEmissions=True):
+    """M-step: transition rows and (optionally) each state's emission block renormalised from expected counts."""
+    T = np.array(T_exp, dtype=np.float64).reshape(STATE_NUMBER, STATE_NUMBER)
+    old = np.array(hmm.transitions).reshape(STATE_NUMBER, STATE_NUMBER)
+    for a in range(STATE_NUMBER):
+        s = T[a].sum()
+        old[a] = T[a] / s if s > 0 else old[a]
+    hmm.transitions = [float(v) for v in old.reshape(-1)]
+    if trainEmissions:
+        k = SYMBOL_NUMBER * SYMBOL_NUMBER
+        E = np.array(E_exp, dtype=np.float64).reshape(STATE_NUMBER, k)
+        cur = np.array(hmm.emissions).reshape(STATE_NUMBER, k)
+        for s_ in range(STATE_NUMBER):
+            tot = E[s_].sum()
+            if tot > 0:
+                cur[s_] = E[s_] / tot
+        hmm.emissions = [float(v) for v in cur.reshape(-1)]
+    return hmm
+
+
+def expectationMaximisation(batch, hmm, iterations, trainEmissions=True, slot=0, log=None):
+    """Runs `iterations` EM iterations on a staged batch whose reads all use model `slot`; updates `hmm` in place.
+    Returns the running likelihoods (log-likelihood of the data under the model BEFORE each update)."""
+    running = []
+    for it in range(iterations):
+        batch.ctx.set_hmm(hmm, slot=slot)
+        T, E, ll, _ = batch.expectations()
+        hmm.likelihood = float(ll[slot])
+        running.append(hmm.likelihood)
+        normalise(hmm, T[slot], E[slot], trainEmissions)
+        if log:
+            log("EM iteration %d: log-likelihood %s" % (it, hmm.likelihood))
+    return running
+
+
+def writeXML(path, trialHmms, runningLikelihoods):
+    """hmm.txt.xml: per-transition / per-emission mean and standard deviation over trials plus every trial's
+    running likelihoods (schema read by nanopore/analyses/hmm.py:31-36, :43-44, :62-66, :80-82)."""
+    root = ET.Element("hmms")
+    Ts = np.array([h.transitions for h in trialHmms])
+    Es = np.array([h.emissions for h in trialHmms])
+    for a in range(STATE_NUMBER):
+        for b in range(STATE_NUMBER):
+            v = Ts[:, a * STATE_NUMBER + b]
+            ET.SubElement(root, "transition", {"from": str(a), "to": str(b), "avg": str(float(v.mean())), "std": str(float(v.std()))})
+    bases = "ACGT"
+    k = SYMBOL_NUMBER * SYMBOL_NUMBER
+    for s in range(STATE_NUMBER):
+        for x in range(SYMBOL_NUMBER):
+            for y in range(SYMBOL_NUMBER):
+                v = Es[:, s * k + x * SYMBOL_NUMBER + y]
+                ET.SubElement(root, "emission", {"state": str(s), "x": bases[x], "y": bases[y], "avg": str(float(v.mean())),
+                                                 "std": str(float(v.std()))})
+    for h, rl in zip(trialHmms, runningLikelihoods):
+        ET.SubElement(root, "hmm", {"runningLikelihoods": " ".join(str(v) for v in rl), "likelihood": str(h.likelihood)})
+    with open(path, "w") as fh:
+        fh.write(minidom.parseString(ET.tostring(root, "utf-8")).toprettyxml(indent="  "))
+
+
+def expectationMaximisationTrials(batch, outputModel, options, startHmm=None, log=None):
+    """`options.trials` independent EM runs (random starts when options.randomStart), the trial with the highest
+    final likelihood is written to `outputModel`; the XML summary goes to options.outputXMLModelFile."""
+    rng = np.random.default_rng(options.seed)
+    trialHmms, running = [], []
+    for trial in range(options.trials):
+        hmm = Hmm() if startHmm is None else startHmm.copy()
+        if options.randomStart or startHmm is None:
+            randomise(hmm, rng)
+        rl = expectationMaximisation(batch, hmm, options.iterations, options.trainEmissions, log=log)
+        # likelihood of the final parameters
+        batch.ctx.set_hmm(hmm)
+        _, _, ll, _ = batch.expectations()
+        hmm.likelihood = float(ll[0])
+        rl.append(hmm.likelihood)
+        trialHmms.append(hmm)
+        running.append(rl)
+        if options.outputTrialHmms:
+            hmm.write("%s_%d" % (outputModel, trial))
+    best = max(trialHmms, key=lambda h: h.likelihood)
+    best.write(outputModel)
+    if options.outputXMLModelFile:
+        writeXML(options.outputXMLModelFile, trialHmms, running)
+    return best, trialHmms, running

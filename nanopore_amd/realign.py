@@ -118,6 +118,17 @@ class Batch(object):
             raise NprError(rc, "npr_batch_pairs")
         return off, x, y, p
 
+    def expectations(self):
+        """Baum-Welch E-step with the installed models: (T_exp[slots,25], E_exp[slots,80], loglik[slots], kernel ms)."""
+        T = np.zeros((_lib.MAX_MODELS, 25))
+        E = np.zeros((_lib.MAX_MODELS, 80))
+        ll = np.zeros(_lib.MAX_MODELS)
+        ms = C.c_float(0)
+        rc = self._L.npr_batch_expectations(self._h, ptr(T), ptr(E), ptr(ll), C.byref(ms))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_expectations", self.ctx.last_error())
+        return T, E, ll, ms.value
+
     def dense(self, read_index, cells):
         fv = np.zeros(cells, dtype=np.float32)
         fe = np.zeros(cells, dtype=np.int32)
@@ -192,8 +203,7 @@ class Context(object):
         ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
         return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms, ri)
 
-    def realign(self, params, refs, reads, guides, model_slot=None, want_pairs=False, ref_index=None):
-        """One batched call: returns list of dicts (status, score, loglik, cells, ops[, x, y, p])."""
+    def _realign_once(self, params, refs, reads, guides, model_slot, want_pairs, ref_index):
         b = self.stage(params, refs, reads, guides, model_slot, ref_index)
         try:
             b.run()
@@ -216,6 +226,31 @@ class Context(object):
             return out
         finally:
             b.close()
+
+    def realign(self, params, refs, reads, guides, model_slot=None, want_pairs=False, ref_index=None):
+        """One batched call: returns list of dicts (status, score, loglik, cells, ops[, x, y, p]).
+
+        Reads whose sparse posterior list overflowed its capacity (NPR_ERR_CAPACITY: a diffuse model can put up to
+        1/threshold pairs on a base) are re-run with a four times larger `max_pairs_per_base` until they fit."""
+        out = self._realign_once(params, refs, reads, guides, model_slot, want_pairs, ref_index)
+        per_base = params.max_pairs_per_base if params.max_pairs_per_base > 0 else 6
+        limit = int(1.0 / max(params.posterior_threshold, 1e-6)) + 1
+        while per_base < limit:
+            again = [i for i, o in enumerate(out) if o["status"] == _lib.ERR_CAPACITY]
+            if not again:
+                break
+            per_base = min(4 * per_base, limit)
+            p2 = Params.from_buffer_copy(params)
+            p2.max_pairs_per_base = per_base
+            if ref_index is None:
+                sub_refs, sub_index = [refs[i] for i in again], None
+            else:
+                sub_refs, sub_index = refs, [ref_index[i] for i in again]
+            sub = self._realign_once(p2, sub_refs, [reads[i] for i in again], [guides[i] for i in again],
+                                     None if model_slot is None else [model_slot[i] for i in again], want_pairs, sub_index)
+            for i, o in zip(again, sub):
+                out[i] = o
+        return out
 
     def close(self):
         if getattr(self, "_h", None):

@@ -84,6 +84,9 @@ def lib(native=False):
         L.orc_fb_f32.argtypes = [C.POINTER(Hmm), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_int32, C.c_float] + [C.c_void_p] * 11 + [
                                      C.c_int64, C.c_void_p]
+        L.orc_expectations_f64.restype = C.c_int32
+        L.orc_expectations_f64.argtypes = [C.POINTER(Hmm), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mea_cigar.restype = C.c_int64
         L.orc_mea_cigar.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_double),
@@ -197,6 +200,21 @@ def fb_f32(hmm, X, Y, lo, n, ragged_start=0, ragged_end=0, threshold=0.01, dense
     k = npairs.value
     return dict(rc=rc, tot_m=tm.value, tot_e=te.value, btot_m=bm.value, btot_e=be.value, Fm_v=Fv, Fm_e=Fe,
                 Bm_v=Bv, Bm_e=Be, px=px[:k].copy(), py=py[:k].copy(), pp=pp[:k].copy())
+
+
+def expectations(hmm, X, Y, lo, n, ragged_start=0, ragged_end=0):
+    """Baum-Welch expected transition (25) and emission (80) counts of one banded segment, and its log-likelihood."""
+    L = lib()
+    X = np.ascontiguousarray(X, dtype=np.uint8)
+    Y = np.ascontiguousarray(Y, dtype=np.uint8)
+    lo = np.ascontiguousarray(lo, dtype=np.int32)
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    T = np.zeros(25)
+    E = np.zeros(80)
+    ll = C.c_double(0)
+    rc = L.orc_expectations_f64(C.byref(hmm), _p(X), len(X), _p(Y), len(Y), _p(lo), _p(n), ragged_start, ragged_end,
+                                _p(T), _p(E), C.addressof(ll))
+    return dict(rc=rc, T=T, E=E, total_ll=ll.value)
 
 
 def mea_cigar(lX, lY, px, py, pp, gap_gamma=0.5, match_gamma=0.0, brute_force=False):

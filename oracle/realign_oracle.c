@@ -459,6 +459,65 @@ int32_t orc_fb_f64(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Baum-Welch expectations.
+ * ------------------------------------------------------------------------------------------ */
+int32_t orc_expectations_f64(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t *Y, int64_t lY,
+                             const int32_t *lo, const int32_t *n, int32_t ragged_start, int32_t ragged_end,
+                             double *T_exp, double *E_exp, double *total_ll) {
+    const int64_t D = lX + lY;
+    int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(D + 2));
+    off[0] = 0;
+    for (int64_t d = 0; d <= D; d++) off[d + 1] = off[d] + n[d];
+    const int64_t cells = off[D + 1];
+    double *F = (double *)malloc(sizeof(double) * 5 * (size_t)cells);
+    double *B = (double *)malloc(sizeof(double) * 5 * (size_t)cells);
+    double tot = 0.0, totb = 0.0;
+    int32_t rc = orc_fb_f64(h, X, lX, Y, lY, lo, n, ragged_start, ragged_end, 2.0, &tot, &totb, NULL, NULL, F, B, NULL,
+                            NULL, NULL, 0, NULL);
+    if (total_ll) *total_ll = tot;
+    if (rc == 0) {
+        model64 m;
+        model64_init(&m, h);
+        for (int64_t d = 1; d <= D; d++)
+            for (int64_t j = 0; j < n[d]; j++) {
+                const int64_t xmy = lo[d] + 2 * j, x = (d + xmy) / 2, y = (d - xmy) / 2;
+                if (x < 0 || y < 0 || x > lX || y > lY) continue;
+                const double *bc = B + 5 * (off[d] + j);
+                const int64_t iM = (x > 0 && y > 0) ? cell_index(lo, n, off, D, d - 2, xmy) : -1;
+                const int64_t iL = (x > 0) ? cell_index(lo, n, off, D, d - 1, xmy - 1) : -1;
+                const int64_t iU = (y > 0) ? cell_index(lo, n, off, D, d - 1, xmy + 1) : -1;
+                for (int t = 0; t < 5; t++) {
+                    const int64_t ip = MOVE[t] == 0 ? iM : (MOVE[t] == 1 ? iL : iU);
+                    if (ip < 0 || bc[t] == NEG_INF) continue;
+                    const int cx = x > 0 ? X[x - 1] : 4, cy = y > 0 ? Y[y - 1] : 4;
+                    const double e = MOVE[t] == 0 ? m.lEm[cx][cy] : (MOVE[t] == 1 ? m.lEx[t][cx] : m.lEy[t][cy]);
+                    double into = 0.0;
+                    for (int s = 0; s < 5; s++) {
+                        const double lp = F[5 * ip + s] + m.lT[s][t] + e + bc[t] - tot;
+                        if (lp == NEG_INF || lp != lp) continue;
+                        const double p = exp(lp);
+                        T_exp[s * 5 + t] += p;
+                        into += p;
+                    }
+                    if (MOVE[t] == 0) {
+                        if (cx < 4 && cy < 4) E_exp[cx * 4 + cy] += into;
+                    } else if (MOVE[t] == 1) {
+                        if (cx < 4)
+                            for (int q = 0; q < 4; q++) E_exp[t * 16 + cx * 4 + q] += 0.25 * into;
+                    } else {
+                        if (cy < 4)
+                            for (int q = 0; q < 4; q++) E_exp[t * 16 + q * 4 + cy] += 0.25 * into;
+                    }
+                }
+            }
+    }
+    free(F);
+    free(B);
+    free(off);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * MEA chain + cigar.  SURVEY 8a row a5.6.
  * ------------------------------------------------------------------------------------------ */
 

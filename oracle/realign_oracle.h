@@ -107,6 +107,15 @@ int32_t orc_fb_f64(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
                    double *Fall, double *Ball, int32_t *px, int32_t *py, double *pp, int64_t cap,
                    int64_t *npairs);
 
+/* Baum-Welch E-step over one banded segment (cactus_realign --outputExpectations, the
+ * quantity cactus_expectationMaximisation sums at nanopore/analyses/utils.py:509-528): expected number of uses of
+ * every transition, T_exp[from*5+to], and expected emission counts E_exp[state*16 + x*4 + y] (for the gap states the
+ * count of a base is spread evenly over the four values of the other index, so that the state's marginal is the
+ * count).  Cells consuming an N contribute to transitions but not to emissions.  Adds into the arrays. */
+int32_t orc_expectations_f64(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t *Y, int64_t lY,
+                             const int32_t *lo, const int32_t *n, int32_t ragged_start, int32_t ragged_end,
+                             double *T_exp, double *E_exp, double *total_ll);
+
 /* fp32 mirror of the device arithmetic (block floating point: five linear fp32 mantissas sharing one
  * int32 binary exponent per cell).  Restates DESIGN.md "device arithmetic" operation by operation so
  * that its results are bit-identical to the HIP kernels'.  Outputs as above except Fm/Bm are given

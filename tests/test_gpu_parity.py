@@ -148,3 +148,25 @@ def test_edge_cases(gpu_ctx):
     assert out[0]["ops"] == [(0, 1)]
     # empty batch
     assert gpu_ctx.realign(P, [], [], []) == []
+
+
+def test_posterior_capacity_overflow_is_reported_and_retried(gpu_ctx):
+    """A sparse posterior list that does not fit its capacity is a per-read NPR_ERR_CAPACITY from the C ABI; the
+    Python layer re-runs such reads with a larger capacity and ends with the same answer."""
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(17)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    cases = [random_pair(rng, 600) for _ in range(3)]
+    refs = [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases]
+    reads = [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases]
+    guides = [g for _, _, g in cases]
+    tight = R.make_params(band_mode=1, fixed_width=100, max_pairs_per_base=1)
+    b = gpu_ctx.stage(tight, refs, reads, guides)
+    b.run()
+    b.finish()
+    assert (b.results()["status"] == -3).all()       # ~1.8 pairs per base do not fit 1 per base
+    b.close()
+    a = gpu_ctx.realign(tight, refs, reads, guides, want_pairs=True)
+    c = gpu_ctx.realign(R.make_params(band_mode=1, fixed_width=100), refs, reads, guides, want_pairs=True)
+    for u, v in zip(a, c):
+        assert u["status"] == 0 and u["ops"] == v["ops"] and np.array_equal(u["p"], v["p"])

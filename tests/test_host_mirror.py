@@ -140,6 +140,36 @@ def test_mapper_class_surface():
     m.cleanup()
 
 
-def test_em_is_a_loud_not_implemented(tmp_path):
-    with pytest.raises(NotImplementedError):
-        utils.learnModelFromSamFileTargetFn(None, "a", "b", "c", "d")
+def test_em_m_step_and_xml(tmp_path):
+    """M-step = renormalised expected counts; the XML has the schema analyses/hmm.py reads."""
+    import xml.etree.ElementTree as ET
+    import numpy as np
+    from nanopore_amd import em
+    from nanopore_amd.hmm import Hmm
+    rng = np.random.default_rng(1)
+    h = em.randomise(Hmm(), rng)
+    T = np.array(h.transitions).reshape(5, 5)
+    assert np.allclose(T.sum(axis=1), 1.0) and int((T > 0).sum()) == 15
+    assert np.allclose(np.array(h.emissions).reshape(5, 16).sum(axis=1), 1.0)
+    Texp = np.zeros(25)
+    Texp[[0, 1, 2]] = [6.0, 3.0, 1.0]          # only the match row observed
+    Eexp = np.zeros(80)
+    Eexp[:16] = np.arange(16)
+    before = list(h.transitions)
+    em.normalise(h, Texp, Eexp, trainEmissions=True)
+    assert h.transitions[:5] == [0.6, 0.3, 0.1, 0.0, 0.0]
+    assert h.transitions[5:] == before[5:]      # rows without counts keep their values
+    assert np.allclose(h.emissions[:16], np.arange(16) / 120.0)
+    h.likelihood = -12.5
+    xml = tmp_path / "hmm.txt.xml"
+    em.writeXML(str(xml), [h, h.copy()], [[-20.0, -13.0, -12.5], [-19.0, -12.5]])
+    root = ET.parse(str(xml)).getroot()
+    assert len(root.findall("transition")) == 25 and len(root.findall("emission")) == 80 and len(root.findall("hmm")) == 2
+    t = root.findall("transition")[1]
+    assert (t.attrib["from"], t.attrib["to"]) == ("0", "1") and float(t.attrib["avg"]) == pytest.approx(0.3) and float(t.attrib["std"]) == 0.0
+    e = [x for x in root.findall("emission") if x.attrib["state"] == "0"][5]
+    assert (e.attrib["x"], e.attrib["y"]) == ("C", "C")
+    assert [float(v) for v in root.findall("hmm")[0].attrib["runningLikelihoods"].split()] == [-20.0, -13.0, -12.5]
+    o = em.Options()                              # option names of utils.py:509-523
+    assert (o.modelType, o.trials, o.iterations, o.randomStart, o.trainEmissions) == ("fiveStateAsymmetric", 3, 100, True, True)
+    assert "--splitMatrixBiggerThanThis=300" in o.optionsToRealign
