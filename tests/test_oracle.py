@@ -201,3 +201,46 @@ def test_unsupported_transition_rejected_by_mirror():
     m = orc.fb_f32(h, np.zeros(3, np.uint8), np.zeros(3, np.uint8), np.array([0, -1, -2, -1, 0, 1, 0], np.int32),
                    np.array([1, 2, 3, 3, 3, 2, 1], np.int32))
     assert m["rc"] == -4
+
+
+def test_expectations_match_independent_numpy():
+    """Baum-Welch expected counts (SURVEY 8f #2) against counts computed from the independent numpy forward/backward."""
+    rng = np.random.default_rng(31)
+    T, E, _ = load_model_arrays()
+    h = orc.make_hmm(T, E)
+    X, Y, ops = random_pair(rng, 30)
+    X[7] = 4  # an N: contributes to transitions, not to emissions
+    seg = orc.plan(len(X), len(Y), ops, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=10000))[0]
+    r = orc.expectations(h, X, Y, seg["lo"], seg["n"])
+    tot, _, F, B = full_matrix_reference(T, E, X, Y)
+    Tm = np.asarray(T).reshape(5, 5)
+    Em = np.full((5, 5), 1.0 / 16.0)
+    Em[:4, :4] = np.asarray(E[:16]).reshape(4, 4)
+    Ex = {s: np.append(np.asarray(E[16 * s:16 * s + 16]).reshape(4, 4).sum(axis=1), 0.25) for s in range(5)}
+    Ey = {s: np.append(np.asarray(E[16 * s:16 * s + 16]).reshape(4, 4).sum(axis=0), 0.25) for s in range(5)}
+    Texp, Eexp = np.zeros((5, 5)), np.zeros(80)
+    for x in range(len(X) + 1):
+        for y in range(len(Y) + 1):
+            if x > 0 and y > 0:
+                w = F[x - 1, y - 1] * Tm[:, 0] * Em[X[x - 1], Y[y - 1]] * B[x, y, 0] / tot
+                Texp[:, 0] += w
+                if X[x - 1] < 4 and Y[y - 1] < 4:
+                    Eexp[X[x - 1] * 4 + Y[y - 1]] += w.sum()
+            if x > 0:
+                for t in (1, 3):
+                    w = F[x - 1, y] * Tm[:, t] * Ex[t][X[x - 1]] * B[x, y, t] / tot
+                    Texp[:, t] += w
+                    if X[x - 1] < 4:
+                        Eexp[t * 16 + X[x - 1] * 4:t * 16 + X[x - 1] * 4 + 4] += 0.25 * w.sum()
+            if y > 0:
+                for t in (2, 4):
+                    w = F[x, y - 1] * Tm[:, t] * Ey[t][Y[y - 1]] * B[x, y, t] / tot
+                    Texp[:, t] += w
+                    if Y[y - 1] < 4:
+                        Eexp[t * 16 + Y[y - 1]:t * 16 + 16:4] += 0.25 * w.sum()
+    assert r["rc"] == 0
+    assert np.abs(r["T"] - Texp.reshape(-1)).max() < 1e-11
+    assert np.abs(r["E"] - Eexp).max() < 1e-11
+    assert r["total_ll"] == pytest.approx(np.log(tot), abs=1e-10)
+    # every path has one transition per alignment column
+    assert max(len(X), len(Y)) <= r["T"].sum() <= len(X) + len(Y)
