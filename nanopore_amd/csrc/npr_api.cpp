@@ -31,6 +31,11 @@ struct npr_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // one side stream per kernel class so that the classes of a mixed batch run concurrently instead of each
+    // leaving the chip idle during its tail
+    static constexpr int kSideStreams = 6;
+    hipStream_t side[kSideStreams] = {};
+    hipEvent_t side_done[kSideStreams] = {};
     int cu_count = 0;
     size_t total_mem = 0;
     bool model_set[NPR_MAX_MODELS] = {};
@@ -154,6 +159,7 @@ struct npr_batch {
         int first, count, grid, wcap;
         size_t lds;
         int64_t cells;
+        int slot_base;  // first forward-scratch region of this launch
     };
     std::vector<Launch> launches;
     DevBuf<float> d_ring;
@@ -227,6 +233,12 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
     ctx->cu_count = prop.multiProcessorCount;
     ctx->total_mem = prop.totalGlobalMem;
     ctx->host_threads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+    for (int i = 0; i < npr_ctx::kSideStreams; ++i)
+        if ((e = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->side_done[i], hipEventDisableTiming)) != hipSuccess) {
+            say("npr_create: side stream allocation", e);
+            return NPR_ERR_HIP;
+        }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void **>(&ctx->d_models), sizeof(DevModel) * NPR_MAX_MODELS)) != hipSuccess) {
@@ -248,6 +260,10 @@ void npr_destroy(npr_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < npr_ctx::kSideStreams; ++i) {
+        if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
+        if (ctx->side_done[i]) (void)hipEventDestroy(ctx->side_done[i]);
+    }
     delete ctx;
 }
 
@@ -461,7 +477,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         first += cls_count[c];
         int waves_per_cu;
         if (c <= 2) {  // VGPR-limited: 82 / 95 / 151 registers -> 5 / 5 / 3 waves per SIMD
-            waves_per_cu = c == 0 ? 20 : (c == 1 ? 20 : 12);
+            waves_per_cu = c == 2 ? 12 : 20;
             L.wcap = 0;
             L.lds = stair_lds_bytes();
         } else if (c == 3) {
@@ -475,13 +491,25 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         }
         if (const char *w = std::getenv("NPR_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(w));
         int64_t grid = std::min<int64_t>(L.count, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
-        grid = std::max<int64_t>(1, std::min(grid, fit));
-        L.grid = static_cast<int>(grid);
-        if (c == 4) ring_floats = grid * 18 * L.wcap;
-        max_grid = std::max(max_grid, grid);
+        L.grid = static_cast<int>(std::max<int64_t>(1, grid));
         b->launches.push_back(L);
     }
-    const int64_t grid = ntasks ? max_grid : 0;
+    // the launches run concurrently, each on its own scratch regions: the regions of all of them must fit
+    int64_t sum_grid = 0;
+    for (auto &L : b->launches) sum_grid += L.grid;
+    if (sum_grid > fit) {
+        if (fit < static_cast<int64_t>(b->launches.size())) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for one forward scratch region per kernel class");
+        const double shrink = static_cast<double>(fit) / static_cast<double>(sum_grid);
+        for (auto &L : b->launches) L.grid = std::max(1, static_cast<int>(L.grid * shrink));
+    }
+    sum_grid = 0;
+    for (auto &L : b->launches) {
+        L.slot_base = static_cast<int>(sum_grid);
+        sum_grid += L.grid;
+        if (L.cls == 4) ring_floats = static_cast<int64_t>(L.grid) * 18 * L.wcap;
+        max_grid = std::max<int64_t>(max_grid, L.grid);
+    }
+    const int64_t grid = ntasks ? sum_grid : 0;
     for (int c = 0; c < 4; ++c) b->n_lds_tasks += cls_count[c], b->lds_width = std::max(b->lds_width, cls_width[c]);
     b->global_width = cls_width[4];
     hipError_t e;
@@ -560,17 +588,28 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     }
     HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (const auto &L : b->launches) {
+    // all classes at once, the smallest first, each on its own stream; the main stream waits for all of them,
+    // so ev0 -> ev1 brackets the whole DP pass
+    std::vector<const npr_batch::Launch *> order;
+    for (const auto &L : b->launches) order.push_back(&L);
+    std::sort(order.begin(), order.end(), [](const npr_batch::Launch *x, const npr_batch::Launch *y) { return x->cells < y->cells; });
+    for (size_t i = 0; i < order.size(); ++i) {
+        const npr_batch::Launch &L = *order[i];
+        const bool last = i + 1 == order.size();
+        hipStream_t s = last ? ctx->stream : ctx->side[i % npr_ctx::kSideStreams];
+        if (!last) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev0, 0));
         KernelArgs a = make_args(b);
         a.tasks += L.first;
         a.outs += L.first;
         a.ntasks = L.count;
         a.queue += L.cls;
         a.wcap = L.wcap;
-        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, ctx->stream)
-                                  : launch_generic(a, L.grid, L.lds, false, L.cls == 4, ctx->stream);
+        a.slot_base = L.slot_base;
+        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, s) : launch_generic(a, L.grid, L.lds, false, L.cls == 4, s);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
+        if (!last) HIP_TRY(ctx, hipEventRecord(ctx->side_done[i % npr_ctx::kSideStreams], s));
     }
+    for (size_t i = 0; i + 1 < order.size(); ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[i % npr_ctx::kSideStreams], 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));

@@ -44,6 +44,7 @@ struct KernelArgs {
     float *Fv;             // forward match-state scratch, one region of slot_stride cells per resident wave
     int32_t *Fe;
     int64_t slot_stride;
+    int32_t slot_base;     // first scratch region of this launch (concurrent launches own disjoint regions)
     int32_t *px;  // sparse posterior output
     int32_t *py;
     float *pp;

@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // 8 ints: cell hand-off
 
     const int lane = threadIdx.x;
-    float *const Fv = a.Fv + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
-    int32_t *const Fe = a.Fe + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
+    float *const Fv = a.Fv + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
+    int32_t *const Fe = a.Fe + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
     int jr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) jr[r] = R * lane + r;

@@ -99,8 +99,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
     float *const Fx = EM ? a.Fx + static_cast<int64_t>(blockIdx.x) * 4 * a.slot_stride : nullptr;
 
     const int lane = threadIdx.x;
-    float *const Fv = a.Fv + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
-    int32_t *const Fe = a.Fe + static_cast<int64_t>(blockIdx.x) * a.slot_stride;
+    float *const Fv = a.Fv + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
+    int32_t *const Fe = a.Fe + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
 
     // The first task of every wavefront is static (t = blockIdx.x); later ones come from the atomic queue.
     // The loop is kept free of break/continue and every loop-carried value is an SGPR: with a divergent

@@ -8,7 +8,7 @@ Two bars (DESIGN.md "Parity"):
 import numpy as np
 import pytest
 
-from helpers import load_model_arrays, oracle_hmm, orc, random_pair, cigar_spans
+from helpers import load_model_arrays, oracle_hmm, orc, random_pair, cigar_spans  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
