@@ -157,6 +157,7 @@ struct npr_batch {
     struct Launch {
         int cls;      // 0..2 register staircase kernel with 1/2/4 cells per lane, 3 generic LDS ring, 4 generic global ring
         int first, count, grid, wcap;
+        int threads;  // generic kernel: workgroup size (wavefronts per task x 64)
         size_t lds;
         int64_t cells;
         int slot_base;  // first forward-scratch region of this launch
@@ -481,13 +482,17 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
             L.wcap = 0;
             L.lds = stair_lds_bytes();
         } else if (c == 3) {
+            // several wavefronts per task: these tasks are big, their forward scratch caps how many can be
+            // resident, and one wavefront each would leave the SIMDs idle
             L.wcap = static_cast<int>((std::max<int64_t>(cls_width[c], 64) + 3) & ~int64_t(3));
             L.lds = generic_lds_bytes(L.wcap);
-            waves_per_cu = std::min<int>(16, static_cast<int>(std::max<size_t>(1, (160 * 1024) / (L.lds + 256))));
+            L.threads = 256;
+            waves_per_cu = std::max<int>(1, std::min<int>(4, static_cast<int>((160 * 1024) / (L.lds + 256))));  // workgroups per CU
         } else {
             L.wcap = static_cast<int>((cls_width[c] + 3) & ~int64_t(3));
             L.lds = generic_lds_bytes(0);
-            waves_per_cu = 8;
+            L.threads = 512;
+            waves_per_cu = 2;  // workgroups per CU
         }
         if (const char *w = std::getenv("NPR_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(w));
         int64_t grid = std::min<int64_t>(L.count, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
@@ -605,7 +610,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.queue += L.cls;
         a.wcap = L.wcap;
         a.slot_base = L.slot_base;
-        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, s) : launch_generic(a, L.grid, L.lds, false, L.cls == 4, s);
+        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, s) : launch_generic(a, L.grid, L.threads, L.lds, false, L.cls == 4, s);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
         if (!last) HIP_TRY(ctx, hipEventRecord(ctx->side_done[i % npr_ctx::kSideStreams], s));
     }
@@ -891,7 +896,7 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
         }
         a.wcap = std::max(w, 64);
         HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
-        const int rc = launch_generic(a, 1, generic_lds_bytes(global_ring ? 0 : a.wcap), true, global_ring, ctx->stream);
+        const int rc = launch_generic(a, 1, 256, generic_lds_bytes(global_ring ? 0 : a.wcap), true, global_ring, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_generic<dense> launch", static_cast<hipError_t>(rc));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<int32_t> n(t.D + 1);

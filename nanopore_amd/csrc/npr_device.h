@@ -76,7 +76,7 @@ struct CompactArgs {
 };
 
 // launchers (npr_kernels.hip)
-int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, bool global_ring, void *stream);
+int launch_generic(const KernelArgs &a, int grid, int threads, size_t lds_bytes, bool dense, bool global_ring, void *stream);
 int launch_em(const KernelArgs &a, int grid, size_t lds_bytes, bool global_ring, void *stream);
 size_t em_extra_lds_bytes();
 int launch_compact(const CompactArgs &a, void *stream);

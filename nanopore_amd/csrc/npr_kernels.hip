@@ -3,7 +3,9 @@
 // k_dp_generic: the banded five-state pair-HMM forward / backward / posterior pass of cactus_realign
 // (reference call sites nanopore/analyses/utils.py:587,
 // alignmentUncertainty.py:41, marginAlignSnpCaller.py:136-146) for ARBITRARY bands.
-//   * one DP problem (task) per 64-lane wavefront; lanes stride over the cells of an anti-diagonal;
+//   * one DP problem (task) per workgroup of 1, 4 or 8 wavefronts (the wider the band, the more wavefronts, so
+//     that big tasks -- whose forward scratch limits how many can be resident -- still fill the chip); threads
+//     stride over the cells of an anti-diagonal;
 //   * the two previous anti-diagonals live in an LDS ring (SoA, conflict-free), HMM tables in LDS;
 //   * persistent wavefronts pull tasks from an atomic queue (tasks are sorted longest-first);
 //   * forward and backward of a task are fused in one launch: the forward match-state values are
@@ -90,7 +92,7 @@ __device__ __forceinline__ int band_index(int xmy, int lo, int n) {
 // transition INTO that cell to 15 per-lane accumulators and the emitted symbols' posterior to per-lane LDS bins;
 // the wavefront reduces them at the end of the task and adds them to the model's global counts (fp64 atomics).
 template <bool DENSE, bool GLOBAL_RING, bool EM>
-__global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
+__global__ void __launch_bounds__(512) k_dp_generic(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ring ring{GLOBAL_RING ? a.ring + static_cast<int64_t>(blockIdx.x) * 18 * a.wcap : reinterpret_cast<float *>(smem), a.wcap};
     float *lmodel = reinterpret_cast<float *>(smem) + (GLOBAL_RING ? 0 : 18 * a.wcap);
@@ -98,7 +100,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
     float *lbins = reinterpret_cast<float *>(lmisc + 4);          // EM only: (EM_BINS + 15) rows of 64 lanes
     float *const Fx = EM ? a.Fx + static_cast<int64_t>(blockIdx.x) * 4 * a.slot_stride : nullptr;
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int nthreads = blockDim.x;  // 64, 256 or 512 (the E-step variant always runs 64)
     float *const Fv = a.Fv + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
     int32_t *const Fe = a.Fe + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
 
@@ -119,7 +122,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
         __syncthreads();  // previous task's LDS reads are done
         {
             const float *gm = reinterpret_cast<const float *>(a.models + tk.model);
-            for (int i = lane; i < MODEL_FLOATS; i += WAVE) lmodel[i] = gm[i];
+            for (int i = tid; i < MODEL_FLOATS; i += nthreads) lmodel[i] = gm[i];
+            if (tid == 0) lmisc[2] = 0;  // posterior pair counter of the workgroup
         }
         __syncthreads();
         const DevModel *mdl = reinterpret_cast<const DevModel *>(lmodel);
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             const int lo = uniform(blo[d]), n = uniform(bn[d]);
             const uint32_t co = static_cast<uint32_t>(uniform(static_cast<int>(bco[d])));
             const int cur = d % 3, s1 = (d + 2) % 3, s2 = (d + 1) % 3;
-            for (int j = lane; j < n; j += WAVE) {
+            for (int j = tid; j < n; j += nthreads) {
                 const int xmy = lo + 2 * j;
                 const int x = (d + xmy) >> 1, y = (d - xmy) >> 1;
                 Cell c = dead_cell();
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             lo2 = lo1, n2 = n1, lo1 = lo, n1 = n;
         }
         // total probability at the end corner (lX, lY) of anti-diagonal D
-        if (lane == 0) {
+        if (tid == 0) {
             float tm = 0.f;
             int te = E_DEAD;
             const int je = band_index(lX - lY, lo1, n1);
@@ -198,13 +202,12 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
 
         // ------------------------------- backward + posteriors -------------------------------
         const float inv_tot = 1.0f / tot_m;
-        int cnt = 0;
         lo1 = n1 = lo2 = n2 = 0;  // bands of d+1 and d+2
         float acc[15];            // EM: expected transition counts of this lane
         if (EM) {
 #pragma unroll
             for (int i = 0; i < 15; ++i) acc[i] = 0.f;
-            for (int i = 0; i < EM_BINS; ++i) lbins[i * WAVE + lane] = 0.f;
+            for (int i = 0; i < EM_BINS; ++i) lbins[i * WAVE + lane] = 0.f;  // (the E-step runs one wavefront per task)
         }
         for (int d = alive ? D : -1; d >= 0; --d) {
             const int lo = uniform(blo[d]), n = uniform(bn[d]);
@@ -221,8 +224,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
                 lom2 = uniform(blo[d - 2]), nm2 = uniform(bn[d - 2]);
                 com2 = static_cast<uint32_t>(uniform(static_cast<int>(bco[d - 2])));
             }
-            for (int j0 = 0; j0 < n; j0 += WAVE) {
-                const int j = j0 + lane;
+            for (int j0 = 0; j0 < n; j0 += nthreads) {
+                const int j = j0 + tid;
                 bool hit = false;
                 float p = 0.f;
                 int x = 0, y = 0;
@@ -305,15 +308,16 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
                     }
                 }
                 const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                    const int slot = cnt + rank;
+                if (mask) {  // wave-uniform: one LDS atomic per wavefront reserves the slots of its hits
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&lmisc[2], __popcll(mask));
+                    base = uniform(base);
+                    const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
                     if (hit && slot < tk.pair_cap) {
                         a.px[tk.pair_off + slot] = x - 1 + tk.xs;
                         a.py[tk.pair_off + slot] = y - 1 + tk.ys;
                         a.pp[tk.pair_off + slot] = p;
                     }
-                    cnt += __popcll(mask);
                 }
             }
             __syncthreads();
@@ -337,7 +341,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             }
             __syncthreads();
         }
-        if (lane == 0) {
+        if (tid == 0) {
+            const int cnt = lmisc[2];
             const int j0 = alive ? band_index(0, lo1, n1) : -1;
             if (j0 >= 0) {
                 const Cell c = ring.get(0, j0);
@@ -352,10 +357,10 @@ __global__ void __launch_bounds__(WAVE) k_dp_generic(KernelArgs a) {
             if (cnt > tk.pair_cap) out.status = NPR_ERR_CAPACITY;
             a.outs[t] = out;
         }
-        // next task
-        int nt = 0;
-        if (lane == 0) nt = atomicAdd(a.queue, 1);
-        t = uniform(nt) + static_cast<int>(gridDim.x);
+        // next task: one fetch per workgroup, handed to every wavefront through LDS
+        if (tid == 0) lmisc[3] = atomicAdd(a.queue, 1) + static_cast<int>(gridDim.x);
+        __syncthreads();
+        t = uniform(lmisc[3]);
     }
 }
 
@@ -384,24 +389,24 @@ int generic_max_wcap() {
 }
 
 template <bool DENSE, bool GLOBAL_RING, bool EM>
-static int launch_generic_t(const KernelArgs &a, int grid, size_t lds_bytes, hipStream_t s) {
+static int launch_generic_t(const KernelArgs &a, int grid, int threads, size_t lds_bytes, hipStream_t s) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_generic<DENSE, GLOBAL_RING, EM>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL((k_dp_generic<DENSE, GLOBAL_RING, EM>), dim3(grid), dim3(WAVE), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_dp_generic<DENSE, GLOBAL_RING, EM>), dim3(grid), dim3(threads), lds_bytes, s, a);
     return static_cast<int>(hipGetLastError());
 }
 
-int launch_generic(const KernelArgs &a, int grid, size_t lds_bytes, bool dense, bool global_ring, void *stream) {
+int launch_generic(const KernelArgs &a, int grid, int threads, size_t lds_bytes, bool dense, bool global_ring, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dense) return global_ring ? launch_generic_t<true, true, false>(a, grid, lds_bytes, s) : launch_generic_t<true, false, false>(a, grid, lds_bytes, s);
-    return global_ring ? launch_generic_t<false, true, false>(a, grid, lds_bytes, s) : launch_generic_t<false, false, false>(a, grid, lds_bytes, s);
+    if (dense) return global_ring ? launch_generic_t<true, true, false>(a, grid, threads, lds_bytes, s) : launch_generic_t<true, false, false>(a, grid, threads, lds_bytes, s);
+    return global_ring ? launch_generic_t<false, true, false>(a, grid, threads, lds_bytes, s) : launch_generic_t<false, false, false>(a, grid, threads, lds_bytes, s);
 }
 
 // lds_bytes must include em_extra_lds_bytes()
 int launch_em(const KernelArgs &a, int grid, size_t lds_bytes, bool global_ring, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return global_ring ? launch_generic_t<false, true, true>(a, grid, lds_bytes, s) : launch_generic_t<false, false, true>(a, grid, lds_bytes, s);
+    return global_ring ? launch_generic_t<false, true, true>(a, grid, WAVE, lds_bytes, s) : launch_generic_t<false, false, true>(a, grid, WAVE, lds_bytes, s);
 }
 
 size_t em_extra_lds_bytes() { return sizeof(float) * (EM_BINS + 15) * WAVE; }
