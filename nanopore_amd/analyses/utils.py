@@ -74,6 +74,78 @@ def getAbsoluteReadOffset(alignedRead, refSeq, readSeq):
     return readOffset + alignedRead.qstart
 
 
+class AlignedPair(object):
+    """An aligned pair of positions (utils.py:81-155).  readPos is the absolute position in the read sequence of the
+    FASTQ (for reverse-strand records counted from the other end, as the reference does)."""
+
+    def __init__(self, refPos, refSeq, readPos, isReversed, readSeq, pPair):
+        assert 0 <= refPos < len(refSeq)
+        assert 0 <= readPos < len(readSeq)
+        self.refPos = refPos
+        self.refSeq = refSeq
+        self.readPos = readPos
+        self.isReversed = isReversed
+        self.readSeq = readSeq
+        self.pPair = pPair  # the previous aligned pair
+
+    def isMatch(self):
+        return self.getRefBase().upper() == self.getReadBase().upper() and self.getRefBase().upper() in "ACTG"
+
+    def isMismatch(self):
+        return (self.getRefBase().upper() != self.getReadBase().upper() and self.getRefBase().upper() in "ACTG"
+                and self.getReadBase().upper() in "ACTG")
+
+    def getRefBase(self):
+        return self.refSeq[self.refPos]
+
+    def getReadBase(self):
+        if self.isReversed:
+            return reverseComplement(self.readSeq[self.readPos])
+        return self.readSeq[self.readPos]
+
+    def getSignedReadPos(self):
+        return -self.readPos if self.isReversed else self.readPos
+
+    def getPrecedingReadInsertionLength(self, globalAlignment=False):
+        if self.pPair is None:
+            if globalAlignment:
+                if self.isReversed:
+                    assert len(self.readSeq) - self.readPos - 1 >= 0
+                    return len(self.readSeq) - self.readPos - 1
+                return self.readPos
+            return 0
+        return self._indelLength(self.readPos, self.pPair.readPos)
+
+    def getPrecedingReadDeletionLength(self, globalAlignment=False):
+        if self.pPair is None:
+            if globalAlignment:
+                return self.refPos
+            return 0
+        return self._indelLength(self.refPos, self.pPair.refPos)
+
+    @staticmethod
+    def _indelLength(pos, pPos):
+        length = abs(pPos - pos) - 1
+        assert length >= 0
+        return length
+
+    @staticmethod
+    def iterator(alignedRead, refSeq, readSeq):
+        """Aligned pairs of a SAM record, checked against the sequences (utils.py:136-155)."""
+        readOffset = getAbsoluteReadOffset(alignedRead, refSeq, readSeq)
+        pPair = None
+        assert len(alignedRead.seq) <= len(readSeq)
+        for readPos, refPos in alignedRead.aligned_pairs:
+            if readPos is not None and refPos is not None:
+                assert alignedRead.pos <= refPos < alignedRead.aend
+                if refPos >= len(refSeq):  # the reference masks an off-by-one of some mappers here (utils.py:145-147)
+                    continue
+                aP = AlignedPair(refPos, refSeq, abs(readOffset + readPos), alignedRead.is_reverse, readSeq, pPair)
+                assert aP.getReadBase().upper() == alignedRead.query[readPos].upper()
+                pPair = aP
+                yield aP
+
+
 def getExonerateCigarFormatString(alignedRead, sam):
     """SAM record -> exonerate cigar line, query (read) first, target (reference) second; only M/I/D survive,
     clips are dropped; input score is the literal 1 (utils.py:168-180)."""
