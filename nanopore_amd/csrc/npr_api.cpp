@@ -155,7 +155,8 @@ struct npr_batch {
     int64_t slot_stride = 0;
     // One DP launch per kernel class present in the batch (tasks are grouped by class, longest first).
     struct Launch {
-        int cls;      // 0..2 register staircase kernel with 1/2/4 cells per lane, 3 generic LDS ring, 4 generic global ring
+        int cls;      // 0..2 register staircase kernel with 1/2/4 cells per lane; 3..5 generic kernel with an LDS ring for
+                      // bands of at most 512 / 1024 / 2270 cells; 6 generic kernel with the ring in HBM/L2
         int first, count, grid, wcap;
         int threads;  // generic kernel: workgroup size (wavefronts per task x 64)
         size_t lds;
@@ -366,9 +367,13 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     const char *force = std::getenv("NPR_KERNEL");  // "generic": no register kernel (A/B runs, tests)
     const bool force_generic = force && std::strcmp(force, "generic") == 0;
     const int lds_max_w = generic_max_wcap();
+    // the LDS ring is sized by the widest band of a launch and decides how many workgroups share a CU, so the
+    // LDS-ring tasks are launched in three width classes
     auto class_of = [&](const Segment &s) {
         if (!force_generic && s.staircase && s.max_width <= 256) return s.max_width <= 64 ? 0 : (s.max_width <= 128 ? 1 : 2);
-        return s.max_width <= lds_max_w ? 3 : 4;
+        if (s.max_width <= 512) return 3;
+        if (s.max_width <= 1024) return 4;
+        return s.max_width <= lds_max_w ? 5 : 6;
     };
     std::vector<int8_t> cls_of(ntasks);
     for (int64_t k = 0; k < ntasks; ++k) cls_of[k] = static_cast<int8_t>(class_of(plans[order[k].read].segs[order[k].seg]));
@@ -403,7 +408,8 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->task_cells.resize(ntasks);
     std::vector<int64_t> band_base(ntasks);
     int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
-    int64_t cls_count[5] = {0, 0, 0, 0, 0}, cls_width[5] = {0, 0, 0, 0, 0}, cls_cells[5] = {0, 0, 0, 0, 0};
+    constexpr int kClasses = 7;
+    int64_t cls_count[kClasses] = {}, cls_width[kClasses] = {}, cls_cells[kClasses] = {};
     for (int64_t k = 0; k < ntasks; ++k) {
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
@@ -468,7 +474,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         if (fit < 1) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for one forward scratch region");
     }
     int64_t max_grid = 1, ring_floats = 0, first = 0;
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < kClasses; ++c) {
         if (!cls_count[c]) continue;
         npr_batch::Launch L{};
         L.cls = c;
@@ -481,13 +487,14 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
             waves_per_cu = c == 2 ? 12 : 20;
             L.wcap = 0;
             L.lds = stair_lds_bytes();
-        } else if (c == 3) {
+        } else if (c <= 5) {
             // several wavefronts per task: these tasks are big, their forward scratch caps how many can be
             // resident, and one wavefront each would leave the SIMDs idle
             L.wcap = static_cast<int>((std::max<int64_t>(cls_width[c], 64) + 3) & ~int64_t(3));
             L.lds = generic_lds_bytes(L.wcap);
-            L.threads = 256;
-            waves_per_cu = std::max<int>(1, std::min<int>(4, static_cast<int>((160 * 1024) / (L.lds + 256))));  // workgroups per CU
+            const int wg_per_cu = std::max<int>(1, static_cast<int>((160 * 1024) / (L.lds + 256)));
+            L.threads = wg_per_cu >= 2 ? 256 : 512;                     // a lone workgroup on a CU gets 8 wavefronts
+            waves_per_cu = std::min(wg_per_cu, 2048 / L.threads);        // workgroups per CU
         } else {
             L.wcap = static_cast<int>((cls_width[c] + 3) & ~int64_t(3));
             L.lds = generic_lds_bytes(0);
@@ -511,12 +518,12 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     for (auto &L : b->launches) {
         L.slot_base = static_cast<int>(sum_grid);
         sum_grid += L.grid;
-        if (L.cls == 4) ring_floats = static_cast<int64_t>(L.grid) * 18 * L.wcap;
+        if (L.cls == 6) ring_floats = static_cast<int64_t>(L.grid) * 18 * L.wcap;
         max_grid = std::max<int64_t>(max_grid, L.grid);
     }
     const int64_t grid = ntasks ? sum_grid : 0;
-    for (int c = 0; c < 4; ++c) b->n_lds_tasks += cls_count[c], b->lds_width = std::max(b->lds_width, cls_width[c]);
-    b->global_width = cls_width[4];
+    for (int c = 0; c < 6; ++c) b->n_lds_tasks += cls_count[c], b->lds_width = std::max(b->lds_width, cls_width[c]);
+    b->global_width = cls_width[6];
     hipError_t e;
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
         (e = b->d_queue.alloc(8)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
@@ -610,7 +617,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.queue += L.cls;
         a.wcap = L.wcap;
         a.slot_base = L.slot_base;
-        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, s) : launch_generic(a, L.grid, L.threads, L.lds, false, L.cls == 4, s);
+        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, s) : launch_generic(a, L.grid, L.threads, L.lds, false, L.cls == 6, s);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
         if (!last) HIP_TRY(ctx, hipEventRecord(ctx->side_done[i % npr_ctx::kSideStreams], s));
     }

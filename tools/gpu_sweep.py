@@ -9,7 +9,10 @@ n = int(sys.argv[1]); L = int(sys.argv[2]); W = int(sys.argv[3])  # W = 0: the r
 w = synth.make_workload(7, n, L, h.transitions, h.emissions, flank=0)
 ctx = R.Context(0); ctx.set_hmm(h)
 for wpc in sys.argv[4:]:
-    os.environ['NPR_WAVES_PER_CU'] = wpc
+    if wpc == 'auto':
+        os.environ.pop('NPR_WAVES_PER_CU', None)
+    else:
+        os.environ['NPR_WAVES_PER_CU'] = wpc
     t0 = time.time()
     P = R.make_params(band_mode=1, fixed_width=W) if W > 0 else R.make_params(band_mode=0)
     b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
