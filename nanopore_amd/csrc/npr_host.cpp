@@ -229,13 +229,25 @@ void push_op(std::vector<int32_t> &ops, size_t first, int32_t op, int64_t len) {
 
 int32_t mea_cigar(int64_t lX, int64_t lY, const Pair *pairs, int64_t n, double gap_gamma, double match_gamma,
                   std::vector<int32_t> &ops, double &score) {
-    std::vector<int64_t> rowgap(lX + 1, PROB_ONE), colgap(lY + 1, PROB_ONE), q(n);
+    // Gap mass of a row (reference base) / column (read base) = 1 - sum of the match posteriors on it.  Rows are
+    // summed by scanning the (x,y)-sorted list, columns in an array over the read positions the pairs touch:
+    // nothing here is sized by the reference length (a chained record spans a whole contig, utils.py:381).
+    std::vector<int64_t> q(n), rowsum(n);
+    int32_t ymin = 0, ymax = -1;
     for (int64_t i = 0; i < n; ++i) {
         if (pairs[i].x < 0 || pairs[i].x >= lX || pairs[i].y < 0 || pairs[i].y >= lY) return NPR_ERR_INVALID;
         q[i] = static_cast<int64_t>(std::floor(static_cast<double>(pairs[i].p) * static_cast<double>(PROB_ONE)));
-        rowgap[pairs[i].x] -= q[i];
-        colgap[pairs[i].y] -= q[i];
+        if (i == 0 || pairs[i].y < ymin) ymin = pairs[i].y;
+        if (i == 0 || pairs[i].y > ymax) ymax = pairs[i].y;
     }
+    for (int64_t g = 0; g < n;) {
+        int64_t h = g, sum = 0;
+        while (h < n && pairs[h].x == pairs[g].x) sum += q[h++];
+        for (int64_t i = g; i < h; ++i) rowsum[i] = sum;
+        g = h;
+    }
+    std::vector<int64_t> colsum(n ? ymax - ymin + 1 : 0, 0);
+    for (int64_t i = 0; i < n; ++i) colsum[pairs[i].y - ymin] += q[i];
     const int64_t floor_w = static_cast<int64_t>(std::floor(match_gamma * static_cast<double>(PROB_ONE)));
     struct Cand {
         int32_t x, y;
@@ -244,26 +256,26 @@ int32_t mea_cigar(int64_t lX, int64_t lY, const Pair *pairs, int64_t n, double g
     std::vector<Cand> c;
     c.reserve(n);
     for (int64_t i = 0; i < n; ++i) {
-        const int64_t gap = std::max<int64_t>(rowgap[pairs[i].x], 0) + std::max<int64_t>(colgap[pairs[i].y], 0);
+        const int64_t gap = std::max<int64_t>(PROB_ONE - rowsum[i], 0) + std::max<int64_t>(PROB_ONE - colsum[pairs[i].y - ymin], 0);
         const int64_t w = q[i] - static_cast<int64_t>(std::floor(gap_gamma * static_cast<double>(gap)));
         if (w > floor_w) c.push_back({pairs[i].x, pairs[i].y, q[i], w});
     }
     // input is sorted by (x,y); filtering keeps the order
     const int64_t m = static_cast<int64_t>(c.size());
     std::vector<int64_t> total(m), back(m);
-    PrefixMax tree(lY);
+    PrefixMax tree(n ? ymax - ymin + 1 : 0);  // keyed by y - ymin
     Best overall;
     for (int64_t g = 0; g < m;) {
         int64_t h = g;
         while (h < m && c[h].x == c[g].x) ++h;
         for (int64_t i = g; i < h; ++i) {
-            const Best b = tree.query(c[i].y);
+            const Best b = tree.query(c[i].y - ymin);
             total[i] = c[i].w + b.score;
             back[i] = b.who;
         }
         for (int64_t i = g; i < h; ++i) {
             const Best v{total[i], i};
-            tree.insert(c[i].y, v);
+            tree.insert(c[i].y - ymin, v);
             if (v.beats(overall)) overall = v;
         }
         g = h;
