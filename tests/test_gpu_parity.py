@@ -170,3 +170,33 @@ def test_posterior_capacity_overflow_is_reported_and_retried(gpu_ctx):
     c = gpu_ctx.realign(R.make_params(band_mode=1, fixed_width=100), refs, reads, guides, want_pairs=True)
     for u, v in zip(a, c):
         assert u["status"] == 0 and u["ops"] == v["ops"] and np.array_equal(u["p"], v["p"])
+
+
+def test_base_dependent_gap_emissions(gpu_ctx):
+    """Gap-state emissions that depend on the base (and the flat N emission next to them): every shipped model is
+    flat there, so this is the only place the per-base gap tables are exercised."""
+    from nanopore_amd import realign as R
+    from nanopore_amd.hmm import Hmm
+    rng = np.random.default_rng(18)
+    T, E, _ = load_model_arrays()
+    E = E.copy()
+    for s in range(1, 5):  # non-uniform gap emissions, still normalised
+        blk = rng.random((4, 4)) + 0.2
+        E[16 * s:16 * s + 16] = (blk / blk.sum()).reshape(-1)
+    hm = Hmm()
+    hm.transitions, hm.emissions = [float(v) for v in T], [float(v) for v in E]
+    gpu_ctx.set_hmm(hm)
+    h = orc.make_hmm(T, E)
+    cases = [random_pair(rng, int(rng.integers(100, 500))) for _ in range(5)]
+    cases[0][0][20:24] = 4  # N bases take the flat N emission
+    refs = [bytes(b"ACGTN"[c] for c in X) for X, _, _ in cases]
+    reads = [bytes(b"ACGTN"[c] for c in Y) for _, Y, _ in cases]
+    for W in (60, 200):
+        P = R.make_params(band_mode=1, fixed_width=W)
+        out = gpu_ctx.realign(P, refs, reads, [g for _, _, g in cases], want_pairs=True)
+        for (X, Y, g), o in zip(cases, out):
+            m = orc.realign_read(h, orc.make_params(band_mode=1, fixed_width=W), X, Y, g, precision=1)
+            assert o["status"] == 0 and o["ops"] == m["ops"]
+            order = np.lexsort((m["py"], m["px"]))
+            assert np.array_equal(o["p"], m["pp"].astype(np.float32)[order])
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
