@@ -99,3 +99,27 @@ def test_reverse_strand_record(tmp_path):
     rc = ET.parse(str(out / "coverage_all.xml")).getroot().find("readAlignmentCoverage")
     assert float(rc.attrib["identity"]) == 1.0 and float(rc.attrib["readCoverage"]) == 1.0
     assert float(rc.attrib["referenceCoverage"]) == pytest.approx(8 / 20)
+
+
+def test_margin_align_base_posterior_maths():
+    """calcBasePosteriorProbs / substitution matrices (marginAlignSnpCaller.py:18-35): hand-checkable cases."""
+    from nanopore_amd.analyses import marginAlignSnpCaller as M
+    null, flat = M.getNullSubstitutionMatrix(), M.getJukesCantorTypeSubstitutionMatrix()
+    assert flat[("A", "A")] == 0.8 and flat[("A", "C")] == pytest.approx(0.2 / 3) and null[("G", "T")] == 1.0
+    # all observations are 'C': posterior ~ error(missing -> C)^1, normalised
+    p = M.calcBasePosteriorProbs({"A": 0.0, "C": 1.0, "G": 0.0, "T": 0.0}, "A", null, flat)
+    z = 0.8 + 3 * (0.2 / 3)
+    assert p["C"] == pytest.approx(0.8 / z) and p["A"] == pytest.approx((0.2 / 3) / z) and sum(p.values()) == pytest.approx(1.0)
+    # an even split between A and C: symmetric posteriors for A and C
+    p = M.calcBasePosteriorProbs({"A": 0.5, "C": 0.5, "G": 0.0, "T": 0.0}, "G", null, flat)
+    assert p["A"] == pytest.approx(p["C"]) and p["A"] > p["G"] == pytest.approx(p["T"])
+    from helpers import MODEL_DIR
+    m = M.loadHmmErrorSubstitutionMatrix(MODEL_DIR + "/blasr_hmm_20.txt")
+    for r in "ACGT":
+        assert sum(m[(r, q)] for q in "ACGT") == pytest.approx(1.0) and m[(r, r)] > 0.5
+    calls = M.SnpCalls(totalHeldOut=4)
+    calls.truePositives = [(0.9, 1), (0.4, 2)]
+    calls.falsePositives = [(0.95, 3), (0.1, 4)]
+    assert calls.bucket([0.9, 0.4])[:41] == [2.0] * 41 and calls.bucket([0.9, 0.4])[41] == 1.0
+    assert calls.getRecallByProbability()[0] == 0.5 and calls.getRecallByProbability()[95] == 0.0
+    assert calls.getPrecisionByProbability()[0] == 0.5 and calls.getPrecisionByProbability()[50] == 0.5

@@ -139,3 +139,57 @@ def test_all_posteriors_mode_and_tsv(tmp_path, gpu_ctx):
     utils.writePosteriorProbs(str(tsv), o["x"], o["y"], o["p"])
     rows = [list(map(float, ln.split())) for ln in open(tsv)]
     assert all(len(r) == 3 and 0 <= int(r[0]) < len(X) and 0 <= int(r[1]) < len(Y) and 0.01 <= r[2] <= 1.0001 for r in rows)
+
+
+def test_margin_align_snp_caller_recovers_held_out_snps(tmp_path, gpu_ctx):
+    """marginAlignSnpCaller.py:40-308 in miniature: reads come from the TRUE reference, the aligner sees a MUTATED copy
+    (`_Index.txt` holds the truth, :60-78); with ~40x coverage the marginalised posteriors must call most held-out SNPs."""
+    from helpers import load_model_arrays
+    from nanopore_amd import bioio, synth
+    from nanopore_amd.analyses.marginAlignSnpCaller import MarginAlignSnpCaller
+    from nanopore_amd.analyses import utils
+    rng = np.random.default_rng(11)
+    true = "".join("ACGT"[c] for c in rng.integers(0, 4, size=1500))
+    snps = sorted(rng.choice(np.arange(50, 1450), size=12, replace=False).tolist())
+    mutated = list(true)
+    for i in snps:
+        mutated[i] = "ACGT"[("ACGT".index(true[i]) + 1 + int(rng.integers(0, 3))) % 4]
+    mutated = "".join(mutated)
+    fa = tmp_path / "ref.fa"
+    bioio.fastaWrite(str(fa), "chr", mutated)
+    with open(str(fa) + "_Index.txt", "w") as fh:
+        bioio.fastaWrite(fh, "chr", true)
+        bioio.fastaWrite(fh, "chr_mutated", mutated)
+    # 40 full-length reads through a mild channel; guide = true path (global, pos 0) as a chained SAM
+    T, E = _mild_channel()
+    codes = np.array(["ACGT".index(c) for c in true], dtype=np.uint8)
+    n = 40
+    off = np.arange(n + 1, dtype=np.int64) * len(codes)
+    rc, roff, cols, coff = synth.error_channel(rng, np.tile(codes, n), off, T, E)
+    runs, run_off = synth.columns_to_runs(cols, coff)
+    fq = tmp_path / "reads.fq"
+    samp = tmp_path / "mapping.sam"
+    with open(fq, "w") as fqh, open(samp, "w") as sh:
+        sh.write("@SQ\tSN:chr\tLN:%d\n" % len(true))
+        for i in range(n):
+            read = "".join("ACGT"[c] for c in rc[roff[i]:roff[i + 1]])
+            fqh.write("@read%d\n%s\n+\n%s\n" % (i, read, "I" * len(read)))
+            cigar = "".join("%d%s" % (l, "MID"[o]) for o, l in runs[run_off[i]:run_off[i + 1]])
+            sh.write("\t".join(["read%d" % i, "0", "chr", "1", "255", cigar, "*", "0", "0", read, "*"]) + "\n")
+    out = tmp_path / "analysis_MarginAlignSnpCaller"
+    out.mkdir()
+    an = MarginAlignSnpCaller(str(fq), "2D", str(fa), str(samp), str(out))
+    an.coverages = (1000000, 10)   # keep the test short: all reads, and a 10x subsample with 3 replicates
+    node = an.run(ctx=gpu_ctx, seed=5)
+    an.cleanup()
+    assert (out / "DONE").exists() and (out / "marginaliseConsensus.xml").exists()
+    kids = list(node)
+    assert len(kids) == 4 * 4 * (1 + 3)            # 4 call sets x 4 hmm types x (1 + 3 replicates)
+    best = [k for k in kids if k.tag == "marginAlignMaxExpectedSnpCalls_trained_0" and k.attrib["coverage"] == "1000000"][0]
+    assert best.attrib["totalHeldOut"] == "12" and best.attrib["totalSampledReads"] == "40"
+    assert float(best.attrib["actualCoverage"]) > 30
+    assert float(best.attrib["recall"]) >= 0.75 and float(best.attrib["precision"]) >= 0.75
+    assert len(best.attrib["recallByProbability"].split()) == 101
+    low = [k for k in kids if k.tag == "marginAlignMaxExpectedSnpCalls_trained_0" and k.attrib["coverage"] == "10"]
+    assert len(low) == 3 and all(int(k.attrib["totalSampledReads"]) < 40 for k in low)
+    gpu_ctx.set_hmm(__import__("nanopore_amd.hmm", fromlist=["Hmm"]).Hmm.loadHmm(utils.trainedModelPath("blasr_hmm_0.txt")))
