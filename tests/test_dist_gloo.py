@@ -51,6 +51,41 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
+def _em_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nanopore_amd import em
+    T = np.full((8, 25), float(rank + 1))
+    E = np.arange(8 * 80, dtype=np.float64).reshape(8, 80) * (rank + 1)
+    ll = np.array([-10.0 * (rank + 1)] + [0.0] * 7)
+    T2, E2, ll2 = em.allReduceExpectations(T, E, ll)
+    q.put((rank, T2.tolist(), float(E2[3, 7]), ll2.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_em_expectations_all_reduce():
+    """Sharded EM: expected counts and log-likelihoods are summed over ranks (the training loop's one collective)."""
+    from nanopore_amd import em
+    T, E, ll = np.ones((8, 25)), np.ones((8, 80)), np.zeros(8)
+    a = em.allReduceExpectations(T, E, ll)            # no process group: identity
+    assert a[0] is T and a[1] is E
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_em_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, T2, e37, ll2 in got:
+        assert np.allclose(T2, 3.0) and e37 == (3 * 80 + 7) * 3 and ll2[0] == -30.0
+
+
 def test_shards_partition_and_balance():
     work = np.random.default_rng(1).integers(1, 1000, size=1001)
     parts = [npd.shard_indices(work, 8, r) for r in range(8)]
