@@ -46,8 +46,7 @@ struct npr_ctx {
     // Forward-value scratch (one region per resident wavefront) lives with the context and only grows: a
     // hipMalloc of ~100 GB costs seconds, far more than the DP pass it serves.  Batches on one context run one
     // at a time (include/nprealign.h), so they can share it.
-    float *arena_Fv = nullptr;
-    int32_t *arena_Fe = nullptr;
+    char *arena_F = nullptr;  // 8 bytes per cell
     size_t arena_cells = 0;
     float *arena_Fx = nullptr;  // E-step only: four more forward planes
     size_t arena_fx_cells = 0;
@@ -149,6 +148,7 @@ struct npr_batch {
     DevBuf<uint8_t> d_seq;
     DevBuf<int32_t> d_lo, d_n;
     DevBuf<uint32_t> d_coff;
+    DevBuf<uint32_t> d_ctl;  // register-kernel tasks: frame schedule, two words per anti-diagonal
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
@@ -256,8 +256,7 @@ void npr_destroy(npr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_models) (void)hipFree(ctx->d_models);
-    if (ctx->arena_Fv) (void)hipFree(ctx->arena_Fv);
-    if (ctx->arena_Fe) (void)hipFree(ctx->arena_Fe);
+    if (ctx->arena_F) (void)hipFree(ctx->arena_F);
     if (ctx->arena_Fx) (void)hipFree(ctx->arena_Fx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -291,6 +290,51 @@ int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double 
     HIP_TRY(ctx, hipMemcpy(ctx->d_models + slot, &m, sizeof(DevModel), hipMemcpyHostToDevice));
     return NPR_OK;
 }
+
+// --------------------------------------------------------------------------------------------------
+// Frame schedule of the register kernel (npr_kernel_stair.hip).  The wavefront holds a frame of C = 64*R slots of the
+// current anti-diagonal, slot j = lattice point (x0 + j, y0 - j); every anti-diagonal the frame advances by an X-step
+// (x0 += 1) or a Y-step (y0 += 1).  The band (first x-y `lo`, n cells) must stay inside the frame; where it does, the
+// steps alternate -- then the (x-1, y-1) predecessor sits in the same slot and the kernel moves nothing -- and only
+// when the band reaches a frame edge is a step repeated.  Returns false when the band cannot be followed (an edge
+// that jumps further than the slack allows); `ctl` (two words per anti-diagonal) and `cells` may be null.
+// --------------------------------------------------------------------------------------------------
+namespace {
+
+bool build_stair_schedule(const Segment &s, int R, uint32_t *ctl, int64_t *cells) {
+    const int64_t C = 64 * R, D = s.D();
+    if (s.n.empty() || s.n[0] != 1 || s.max_width >= C) return false;
+    const int64_t j0 = (C - 1) / 2;
+    int64_t flo = s.lo[0] - 2 * j0;  // x-y of slot 0
+    uint64_t off = 0;
+    int kind = 0;  // so that the first step defaults to X
+    for (int64_t d = 0; d <= D; ++d) {
+        const int64_t lo = s.lo[d], n = s.n[d], hi = lo + 2 * (n - 1);
+        if (n < 1) return false;
+        if (d > 0) {
+            const int pref = !kind;
+            const int64_t fa = flo + (pref ? 1 : -1), fb = flo + (pref ? -1 : 1);
+            if (fa <= lo && hi <= fa + 2 * (C - 1)) {
+                kind = pref, flo = fa;
+            } else if (fb <= lo && hi <= fb + 2 * (C - 1)) {
+                kind = !pref, flo = fb;
+            } else {
+                return false;
+            }
+        }
+        const int64_t jlo = (lo - flo) / 2;
+        const int64_t l0 = jlo / R, l1 = (jlo + n + R - 1) / R;
+        if (ctl) {
+            ctl[2 * d] = static_cast<uint32_t>(off);
+            ctl[2 * d + 1] = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 10) | (static_cast<uint32_t>(kind) << 20);
+        }
+        off += static_cast<uint64_t>(R * (l1 - l0));
+    }
+    if (cells) *cells = static_cast<int64_t>(off);
+    return off < (uint64_t(1) << 32);
+}
+
+}  // namespace
 
 // --------------------------------------------------------------------------------------------------
 // batch
@@ -370,13 +414,15 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     // the LDS ring is sized by the widest band of a launch and decides how many workgroups share a CU, so the
     // LDS-ring tasks are launched in three width classes
     auto class_of = [&](const Segment &s) {
-        if (!force_generic && s.staircase && s.max_width <= 256) return s.max_width <= 64 ? 0 : (s.max_width <= 128 ? 1 : 2);
+        if (!force_generic && s.max_width < 256)
+            for (int c = s.max_width < 64 ? 0 : (s.max_width < 128 ? 1 : 2); c <= 2; ++c)
+                if (build_stair_schedule(s, 1 << c, nullptr, nullptr)) return c;
         if (s.max_width <= 512) return 3;
         if (s.max_width <= 1024) return 4;
         return s.max_width <= lds_max_w ? 5 : 6;
     };
     std::vector<int8_t> cls_of(ntasks);
-    for (int64_t k = 0; k < ntasks; ++k) cls_of[k] = static_cast<int8_t>(class_of(plans[order[k].read].segs[order[k].seg]));
+    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) { cls_of[k] = static_cast<int8_t>(class_of(plans[order[k].read].segs[order[k].seg])); });
     std::stable_sort(rank.begin(), rank.end(), [&](int32_t a, int32_t c) {
         return cls_of[a] != cls_of[c] ? cls_of[a] < cls_of[c] : order[a].cells > order[c].cells;
     });
@@ -407,6 +453,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->tasks.resize(ntasks);
     b->task_cells.resize(ntasks);
     std::vector<int64_t> band_base(ntasks);
+    int64_t ctl_entries = 0;
     int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
     constexpr int kClasses = 7;
     int64_t cls_count[kClasses] = {}, cls_width[kClasses] = {}, cls_cells[kClasses] = {};
@@ -435,6 +482,11 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         total_cells += s.cells;
         max_width = std::max<int64_t>(max_width, s.max_width);
         const int c = cls_of[rank[k]];
+        t.ctl_off = -1;
+        if (c <= 2) {
+            t.ctl_off = ctl_entries;
+            ctl_entries += s.D() + 1;
+        }
         ++cls_count[c];
         cls_width[c] = std::max<int64_t>(cls_width[c], s.max_width);
         cls_cells[c] += s.cells;
@@ -442,9 +494,12 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     std::vector<int32_t> h_lo(band_entries), h_n(band_entries);
     std::vector<uint32_t> h_coff(band_entries);
     std::vector<int64_t> pad_cells(ntasks);
+    std::vector<uint32_t> h_ctl(2 * ctl_entries);
     parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
+        int64_t stair_cells = 0;
+        if (b->tasks[k].ctl_off >= 0) build_stair_schedule(s, 1 << cls_of[rank[k]], h_ctl.data() + 2 * b->tasks[k].ctl_off, &stair_cells);
         uint64_t off = 0;
         for (int64_t d = 0; d <= s.D(); ++d) {
             h_lo[band_base[k] + d] = s.lo[d];
@@ -452,7 +507,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
             h_coff[band_base[k] + d] = static_cast<uint32_t>(off);
             off += (static_cast<uint64_t>(s.n[d]) + 3) & ~uint64_t(3);  // 16-byte aligned rows
         }
-        pad_cells[k] = static_cast<int64_t>(off);
+        pad_cells[k] = std::max(static_cast<int64_t>(off), stair_cells);  // either kernel may run the task
     });
     for (int64_t k = 0; k < ntasks; ++k) {
         if (pad_cells[k] >= (int64_t(1) << 32)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: segment too large");
@@ -466,7 +521,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->slot_stride = (max_pad + 63) & ~int64_t(63);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-    const int64_t fixed = seq_bytes + band_entries * 12 + pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
+    const int64_t fixed = seq_bytes + band_entries * 12 + ctl_entries * 8 + pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
     const int64_t budget = static_cast<int64_t>((free_b + ctx->arena_cells * 8) * 0.9) - fixed;
     int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
@@ -483,8 +538,8 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         L.cells = cls_cells[c];
         first += cls_count[c];
         int waves_per_cu;
-        if (c <= 2) {  // VGPR-limited: 82 / 95 / 151 registers -> 5 / 5 / 3 waves per SIMD
-            waves_per_cu = c == 2 ? 12 : 20;
+        if (c <= 2) {  // VGPR-limited: 69 / 82 / 137 registers; measured best at 7 / 5 / 3 waves per SIMD
+            waves_per_cu = c == 0 ? 28 : (c == 1 ? 20 : 12);
             L.wcap = 0;
             L.lds = stair_lds_bytes();
         } else if (c <= 5) {
@@ -528,16 +583,15 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
         (e = b->d_queue.alloc(8)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
         (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
-        (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_px.alloc(pair_total)) != hipSuccess ||
+        (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_ctl.alloc(2 * ctl_entries)) != hipSuccess ||
+        (e = b->d_px.alloc(pair_total)) != hipSuccess ||
         (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(grid);
     if (b->scratch_cells > ctx->arena_cells) {
-        if (ctx->arena_Fv) (void)hipFree(ctx->arena_Fv);
-        if (ctx->arena_Fe) (void)hipFree(ctx->arena_Fe);
-        ctx->arena_Fv = nullptr, ctx->arena_Fe = nullptr, ctx->arena_cells = 0;
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_Fv), b->scratch_cells * sizeof(float))) != hipSuccess ||
-            (e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_Fe), b->scratch_cells * sizeof(int32_t))) != hipSuccess)
+        if (ctx->arena_F) (void)hipFree(ctx->arena_F);
+        ctx->arena_F = nullptr, ctx->arena_cells = 0;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8)) != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc of the forward scratch", e);
         ctx->arena_cells = b->scratch_cells;
     }
@@ -548,6 +602,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
         HIP_TRY(ctx, hipMemcpy(b->d_lo.p, h_lo.data(), b->d_lo.bytes(), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(b->d_n.p, h_n.data(), b->d_n.bytes(), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.data(), b->d_coff.bytes(), hipMemcpyHostToDevice));
+        if (ctl_entries) HIP_TRY(ctx, hipMemcpy(b->d_ctl.p, h_ctl.data(), b->d_ctl.bytes(), hipMemcpyHostToDevice));
     }
     tm.lap("H2D");
     b->outs.resize(ntasks);
@@ -578,8 +633,8 @@ static KernelArgs make_args(npr_batch *b) {
     a.lo = b->d_lo.p;
     a.n = b->d_n.p;
     a.coff = b->d_coff.p;
-    a.Fv = b->ctx->arena_Fv;
-    a.Fe = b->ctx->arena_Fe;
+    a.ctl = b->d_ctl.p;
+    a.F = b->ctx->arena_F;
     a.slot_stride = b->slot_stride;
     a.px = b->d_px.p;
     a.py = b->d_py.p;
@@ -912,8 +967,9 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
         HIP_TRY(ctx, hipMemcpy(co.data(), b->d_coff.p + t.band_off, sizeof(uint32_t) * (t.D + 1), hipMemcpyDeviceToHost));
         std::vector<float> fv(t.cells_pad), bv(t.cells_pad);
         std::vector<int32_t> fe(t.cells_pad), be(t.cells_pad);
-        HIP_TRY(ctx, hipMemcpy(fv.data(), ctx->arena_Fv, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(fe.data(), ctx->arena_Fe, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
+        // slot 0 of the generic layout: mantissa plane, then exponent plane
+        HIP_TRY(ctx, hipMemcpy(fv.data(), ctx->arena_F, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fe.data(), ctx->arena_F + sizeof(float) * b->slot_stride, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(bv.data(), d_Bv.p, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(be.data(), d_Be.p, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
         for (int32_t d = 0; d <= t.D; ++d)

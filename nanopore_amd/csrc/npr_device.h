@@ -20,6 +20,7 @@ struct Task {
     int32_t xs, ys;    // offset of the segment inside the read's slice (added to emitted coordinates)
     int32_t read;      // owning read
     int32_t cells_pad; // padded cell count (scratch use)
+    int64_t ctl_off;   // register-kernel tasks: first anti-diagonal entry in d_ctl (pairs of words), else -1
 };
 
 struct TaskOut {
@@ -41,8 +42,10 @@ struct KernelArgs {
     const int32_t *lo;
     const int32_t *n;
     const uint32_t *coff;  // per anti-diagonal: offset of its first cell inside the task (cells padded to x4)
-    float *Fv;             // forward match-state scratch, one region of slot_stride cells per resident wave
-    int32_t *Fe;
+    const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 10 | kind << 20)
+    char *F;               // forward match-state scratch: one region of 8*slot_stride bytes per resident wave.  The
+                           // register kernel keeps (mantissa, exponent) interleaved per cell; the generic kernel
+                           // keeps a mantissa plane followed by an exponent plane.
     int64_t slot_stride;
     int32_t slot_base;     // first scratch region of this launch (concurrent launches own disjoint regions)
     int32_t *px;  // sparse posterior output

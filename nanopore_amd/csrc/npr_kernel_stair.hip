@@ -1,22 +1,28 @@
-// npr_kernel_stair.hip -- k_dp_stair<R>: the register-resident ("systolic") DP kernel for staircase bands.
+// npr_kernel_stair.hip -- k_dp_stair<R>: the register-resident ("systolic") DP kernel for narrow bands.
 //
 // Same recurrences and the same per-cell arithmetic (npr_cell.h) as k_dp_generic -- cactus_realign's banded
 // five-state forward / backward / posterior pass, SURVEY.md 8a rows a5.3-a5.5, reference call sites
-// nanopore/analyses/utils.py:587, alignmentUncertainty.py:41, marginAlignSnpCaller.py:136-146 -- for the
-// bands every fixed-width configuration (BASELINE.json "band=100/200") and every anchor stripe produces:
-// consecutive anti-diagonals whose first in-band x-y differs by exactly +-1 and that hold at most 64*R cells.
+// nanopore/analyses/utils.py:587, alignmentUncertainty.py:41, marginAlignSnpCaller.py:136-146 -- for bands of fewer
+// than 64*R cells per anti-diagonal whose edges move by one cell per anti-diagonal: every fixed-width configuration
+// (BASELINE.json "band=100/200") and every anchor stripe.
 //
 // Mapping (one read per 64-lane wavefront, no LDS traffic in the recurrence, no MFMA):
-//   * cell j of an anti-diagonal lives in lane j / R, register j % R (blocked), so of the R neighbours a
-//     step needs only ONE per state crosses a lane boundary: a single DPP wave_shl:1 / wave_shr:1 move;
-//   * the two previous anti-diagonals stay in VGPRs (12*R registers each);
-//   * the reference streams through the wavefront towards lower lanes on x-steps and the read towards
-//     higher lanes on y-steps (one DPP move + one v_readlane injection per step), fed by 64-base blocks
-//     prefetched a block ahead: no per-cell sequence loads;
-//   * HMM tables in LDS (emission look-ups), transitions in SGPRs;
-//   * forward match-state values stream to the wavefront's HBM scratch as R-wide vector stores and stream
-//     back one anti-diagonal ahead of use in the backward sweep;
-//   * band rows are read through the scalar cache (constant address space), one anti-diagonal ahead.
+//   * the wavefront holds a FRAME of 64*R lattice points of the current anti-diagonal, slot j = (x0 + j, y0 - j),
+//     slot j in lane j / R, register j % R (blocked).  The frame advances by an X-step (x0 += 1) or a Y-step
+//     (y0 += 1) per anti-diagonal; the band floats inside it (first slot jlo, n cells), selected by wave-uniform lane
+//     masks built on the scalar unit.  The host schedules the frame (build_stair_schedule in npr_api.cpp): X and Y
+//     steps alternate wherever the band fits, and only then is the (x-1, y-1) predecessor in the same slot, so the hot
+//     path never moves the anti-diagonal d-2; two equal steps in a row (drift, long gaps) shift it by one slot;
+//   * of the R neighbours on d-1 only ONE per state crosses a lane boundary: a single DPP wave_shl:1 / wave_shr:1;
+//   * the two previous anti-diagonals stay in VGPRs (6*R registers each) and swap roles every step (the loops are
+//     unrolled by two), so no anti-diagonal is ever copied;
+//   * the reference streams through the wavefront towards lower lanes on X-steps and the read towards higher lanes
+//     on Y-steps (one DPP move + one v_readlane injection per step), fed by 64-base blocks prefetched a block
+//     ahead: no per-cell sequence loads;
+//   * HMM tables in LDS (emission look-ups), transitions in VGPRs (R = 1) or SGPRs;
+//   * forward match-state values stream to the wavefront's HBM scratch as one 8R-byte buffer store per lane and
+//     stream back one anti-diagonal ahead of use in the backward sweep;
+//   * the per-anti-diagonal control words are read through the scalar cache (constant address space), one ahead.
 #include <hip/hip_runtime.h>
 
 #include "npr_cell.h"
@@ -38,23 +44,26 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
     const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
     return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
 }
+__device__ __forceinline__ int fbits(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ float bitsf(int v) { return __builtin_bit_cast(float, v); }
 
-// lane l <- lane l+1 (lane 63 keeps `edge`);  lane l <- lane l-1 (lane 0 keeps `edge`)
+// lane l <- lane l+1 (lane 63 takes `edge`);  lane l <- lane l-1 (lane 0 takes `edge`)
 __device__ __forceinline__ int dpp_from_above(int v, int edge) {
     return __builtin_amdgcn_update_dpp(edge, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 __device__ __forceinline__ int dpp_from_below(int v, int edge) {
     return __builtin_amdgcn_update_dpp(edge, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
-__device__ __forceinline__ float dppf_from_above(float v, float edge) {
-    return __builtin_bit_cast(float, dpp_from_above(__builtin_bit_cast(int, v), __builtin_bit_cast(int, edge)));
+// mantissas: the edge lane takes 0 (bound_ctrl), which needs no `old` register
+__device__ __forceinline__ float dppf_from_above(float v) {
+    return bitsf(__builtin_amdgcn_update_dpp(0, fbits(v), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float dppf_from_below(float v, float edge) {
-    return __builtin_bit_cast(float, dpp_from_below(__builtin_bit_cast(int, v), __builtin_bit_cast(int, edge)));
+__device__ __forceinline__ float dppf_from_below(float v) {
+    return bitsf(__builtin_amdgcn_update_dpp(0, fbits(v), 0x138, 0xf, 0xf, true));
 }
 
 template <int R>
-struct Diag {  // one anti-diagonal in registers: cell j = R*lane + r
+struct Diag {  // one anti-diagonal in registers: slot j = R*lane + r
     Cell c[R];
 };
 
@@ -72,11 +81,11 @@ __device__ __forceinline__ Diag<R> shift_up(const Diag<R> &in) {
     Diag<R> o;
 #pragma unroll
     for (int r = 0; r + 1 < R; ++r) o.c[r] = in.c[r + 1];
-    o.c[R - 1].m = dppf_from_above(in.c[0].m, 0.f);
-    o.c[R - 1].sx = dppf_from_above(in.c[0].sx, 0.f);
-    o.c[R - 1].sy = dppf_from_above(in.c[0].sy, 0.f);
-    o.c[R - 1].lx = dppf_from_above(in.c[0].lx, 0.f);
-    o.c[R - 1].ly = dppf_from_above(in.c[0].ly, 0.f);
+    o.c[R - 1].m = dppf_from_above(in.c[0].m);
+    o.c[R - 1].sx = dppf_from_above(in.c[0].sx);
+    o.c[R - 1].sy = dppf_from_above(in.c[0].sy);
+    o.c[R - 1].lx = dppf_from_above(in.c[0].lx);
+    o.c[R - 1].ly = dppf_from_above(in.c[0].ly);
     o.c[R - 1].e = dpp_from_above(in.c[0].e, E_DEAD);
     return o;
 }
@@ -86,11 +95,11 @@ __device__ __forceinline__ Diag<R> shift_down(const Diag<R> &in) {
     Diag<R> o;
 #pragma unroll
     for (int r = 1; r < R; ++r) o.c[r] = in.c[r - 1];
-    o.c[0].m = dppf_from_below(in.c[R - 1].m, 0.f);
-    o.c[0].sx = dppf_from_below(in.c[R - 1].sx, 0.f);
-    o.c[0].sy = dppf_from_below(in.c[R - 1].sy, 0.f);
-    o.c[0].lx = dppf_from_below(in.c[R - 1].lx, 0.f);
-    o.c[0].ly = dppf_from_below(in.c[R - 1].ly, 0.f);
+    o.c[0].m = dppf_from_below(in.c[R - 1].m);
+    o.c[0].sx = dppf_from_below(in.c[R - 1].sx);
+    o.c[0].sy = dppf_from_below(in.c[R - 1].sy);
+    o.c[0].lx = dppf_from_below(in.c[R - 1].lx);
+    o.c[0].ly = dppf_from_below(in.c[R - 1].ly);
     o.c[0].e = dpp_from_below(in.c[R - 1].e, E_DEAD);
     return o;
 }
@@ -146,12 +155,39 @@ __device__ __forceinline__ int feed_get(Feed &f, const uint8_t *seq, int len, in
     return __builtin_amdgcn_readlane(f.cur, off);
 }
 
-struct BandRow {
-    int lo, n;
-    uint32_t co;
-};
+typedef const __attribute__((address_space(4))) uint32_t *cptr32;
 
-typedef const __attribute__((address_space(4))) int32_t *cptr32;
+// Control word of one anti-diagonal (written by build_stair_schedule, npr_api.cpp): where the band sits in the frame,
+// which step brought the frame here, and where the row starts in the forward scratch.
+struct Ctl {
+    uint32_t co;  // scratch offset (cells) of the first stored lane of the row
+    int jlo, n;   // band = slots [jlo, jlo + n)
+    int kind;     // 1: X-step into this anti-diagonal (x0 += 1), 0: Y-step (y0 += 1)
+};
+__device__ __forceinline__ Ctl read_ctl(cptr32 ctl, int d) {
+    const uint32_t co = ctl[2 * d], w = ctl[2 * d + 1];
+    return Ctl{co, static_cast<int>(w & 1023u), static_cast<int>((w >> 10) & 1023u), static_cast<int>((w >> 20) & 1u)};
+}
+
+__device__ __forceinline__ uint64_t low_lanes(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
+
+// Wave-uniform lane masks of a band inside the frame (scalar unit only).
+template <int R>
+struct Masks {
+    uint64_t cell[R];  // lanes whose slot R*lane + r is inside the band
+    uint64_t lanes;    // lanes holding at least one band cell
+    int l0;            // first such lane
+};
+template <int R>
+__device__ __forceinline__ Masks<R> band_masks(int jlo, int n) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    Masks<R> m;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m.cell[r] = low_lanes((jlo + n - r + R - 1) >> SH) & ~low_lanes((jlo - r + R - 1) >> SH);
+    m.l0 = jlo >> SH;
+    m.lanes = low_lanes((jlo + n + R - 1) >> SH) & ~low_lanes(m.l0);
+    return m;
+}
 
 // Everything wave-uniform a step needs.
 struct StepEnv {
@@ -162,12 +198,6 @@ struct StepEnv {
     int lX, lY;
     int lane;
 };
-
-// A cell outside the band keeps whatever mantissas the arithmetic produced and only gets the dead exponent:
-// every consumer multiplies it by scale2(E_DEAD - eref) = 0, so the mantissas never matter.
-__device__ __forceinline__ void kill_outside(Cell &c, int j, int n) {
-    if (j >= n) c.e = E_DEAD;
-}
 
 template <int R>
 __device__ __forceinline__ void emissions(const StepEnv &E, const Bases<R> &bx, const Bases<R> &by, int r, float &em,
@@ -180,56 +210,71 @@ __device__ __forceinline__ void emissions(const StepEnv &E, const Bases<R> &bx, 
     eyl = *reinterpret_cast<const float *>(E.ltab + OFF_EY + 80 + by.b[r]);
 }
 
-// One forward anti-diagonal.  `io` holds diagonal d-2 on entry and diagonal d on exit; `p1` holds d-1.  The two
-// register sets swap roles every step (the caller unrolls by two), so no diagonal is ever copied.
+// A slot outside the band keeps whatever mantissas the arithmetic produced and only gets the dead exponent: every
+// consumer multiplies it by scale2(E_DEAD - eref) = 0, so the mantissas never matter.
+__device__ __forceinline__ void kill_outside(Cell &c, uint64_t in_band) {
+    c.e = __builtin_amdgcn_inverse_ballot_w64(in_band) ? c.e : E_DEAD;
+}
+
+// One forward anti-diagonal.  `io` holds anti-diagonal d-2 on entry and d on exit; `p1` holds d-1.  `same`: the step
+// into d-1 was of the same kind, so the frame moved two slots along one axis since d-2.
 template <int R>
 __device__ __forceinline__ void fwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Bases<R> &cX, Bases<R> &cY,
-                                         Feed &fx, Feed &fy, int d, int lo, int n, int lo1, int lo2, const int (&jr)[R]) {
-    const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
-    const int s = lo - lo1;          // +1: x-step, -1: y-step
-    const int sm = (lo - lo2) >> 1;  // index shift into the d-2 frame: -1, 0, +1
-    if (sm > 0) {
-        io = shift_up<R>(io);
-    } else if (sm < 0) {
-        io = shift_down<R>(io);
-    }
-    if (s > 0) {
+                                         Feed &fx, Feed &fy, int &x0, int &y0, const Ctl &ct, bool same) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    if (ct.kind) {
+        if (same) io = shift_up<R>(io);
+        x0 += 1;
         bases_up<R>(cX, feed_get<+1>(fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
-        const Diag<R> U = shift_up<R>(p1);
+        const Diag<R> U = shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float em, exs, exl, eys, eyl;
             emissions<R>(E, cX, cY, r, em, exs, exl, eys, eyl);
             Cell c = fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, jr[r], n);
+            kill_outside(c, mk.cell[r]);
             io.c[r] = c;
         }
     } else {
+        if (same) io = shift_down<R>(io);
+        y0 += 1;
         bases_down<R>(cY, feed_get<+1>(fy, E.Y, E.lY, y0 - 1, E.lane));
-        const Diag<R> L = shift_down<R>(p1);
+        const Diag<R> L = shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float em, exs, exl, eys, eyl;
             emissions<R>(E, cX, cY, r, em, exs, exl, eys, eyl);
             Cell c = fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, jr[r], n);
+            kill_outside(c, mk.cell[r]);
             io.c[r] = c;
         }
     }
 }
 
+// Forward rows in HBM: a row holds the lanes [l0, l1) that carry band cells, 8R bytes per lane -- per slot the pair
+// (match mantissa, exponent).  A row is addressed through a raw buffer descriptor rebuilt per row on the scalar unit
+// (base = where lane 0 would land) with a per-lane constant offset, under the row's lane mask: one vector-memory
+// instruction per row (two for R = 4), no per-lane address arithmetic.
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
 template <int R>
-__device__ __forceinline__ void store_row(float *Fv, int32_t *Fe, const Diag<R> &C, uint32_t co, int n, int lane) {
-    if (R * lane < n) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(char *F, uint32_t co, int l0) {
+    return __builtin_amdgcn_make_buffer_rsrc(F + (static_cast<int64_t>(co) - R * l0) * 8, 0, -1, 0x00020000);
+}
+
+template <int R>
+__device__ __forceinline__ void store_row(char *F, const Diag<R> &C, const Ctl &ct, int voff) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc<R>(F, ct.co, mk.l0);
+    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
         if constexpr (R == 1) {
-            Fv[co + lane] = C.c[0].m;
-            Fe[co + lane] = C.c[0].e;
+            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), C.c[0].e}, rs, voff, 0, 0);
         } else if constexpr (R == 2) {
-            *reinterpret_cast<float2 *>(Fv + co + 2 * lane) = make_float2(C.c[0].m, C.c[1].m);
-            *reinterpret_cast<int2 *>(Fe + co + 2 * lane) = make_int2(C.c[0].e, C.c[1].e);
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
         } else {
-            *reinterpret_cast<float4 *>(Fv + co + 4 * lane) = make_float4(C.c[0].m, C.c[1].m, C.c[2].m, C.c[3].m);
-            *reinterpret_cast<int4 *>(Fe + co + 4 * lane) = make_int4(C.c[0].e, C.c[1].e, C.c[2].e, C.c[3].e);
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[2].m), C.c[2].e, fbits(C.c[3].m), C.c[3].e}, rs, voff + 16, 0, 0);
         }
     }
 }
@@ -240,23 +285,23 @@ struct FRow {  // forward match values of one anti-diagonal
     int e[R];
 };
 
+// lanes outside the row keep stale registers: every consumer masks by the band
 template <int R>
-__device__ __forceinline__ void load_row(const float *Fv, const int32_t *Fe, FRow<R> &f, uint32_t co, int n, int lane) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) f.v[r] = 0.f, f.e[r] = E_DEAD;
-    if (R * lane < n) {
+__device__ __forceinline__ void load_row(char *F, FRow<R> &f, const Ctl &ct, int voff) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc<R>(F, ct.co, mk.l0);
+    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
         if constexpr (R == 1) {
-            f.v[0] = Fv[co + lane];
-            f.e[0] = Fe[co + lane];
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y;
         } else if constexpr (R == 2) {
-            const float2 q = *reinterpret_cast<const float2 *>(Fv + co + 2 * lane);
-            const int2 g = *reinterpret_cast<const int2 *>(Fe + co + 2 * lane);
-            f.v[0] = q.x, f.v[1] = q.y, f.e[0] = g.x, f.e[1] = g.y;
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
         } else {
-            const float4 q = *reinterpret_cast<const float4 *>(Fv + co + 4 * lane);
-            const int4 g = *reinterpret_cast<const int4 *>(Fe + co + 4 * lane);
-            f.v[0] = q.x, f.v[1] = q.y, f.v[2] = q.z, f.v[3] = q.w;
-            f.e[0] = g.x, f.e[1] = g.y, f.e[2] = g.z, f.e[3] = g.w;
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
+            f.v[2] = bitsf(g.x), f.e[2] = g.y, f.v[3] = bitsf(g.z), f.e[3] = g.w;
         }
     }
 }
@@ -272,68 +317,66 @@ struct PairSink {
 // posteriors of one anti-diagonal (d >= 2: from there on the forward match value is zero wherever x < 1 or y < 1;
 // d = 0 is the start cell, whose match state holds the start probability)
 template <int R>
-__device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, const FRow<R> &f, int d, int lo, int n,
-                                           int tot_e, float inv_tot, const int (&jr)[R], int lane, int &cnt) {
-    const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
+__device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, const FRow<R> &f, int d, int x0, int y0,
+                                           const Ctl &ct, int tot_e, float inv_tot, const int (&jr)[R], int &cnt) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
     float p[R];
-    bool any = false;
+    uint64_t hit[R], any = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         p[r] = posterior(f.v[r], f.e[r], B.c[r].m, B.c[r].e, tot_e, inv_tot);
-        any |= (p[r] >= S.threshold) && (jr[r] < n);
+        hit[r] = __ballot(p[r] >= S.threshold) & mk.cell[r];
+        any |= hit[r];
     }
-    if (d >= 2 && __ballot(any)) {
+    if (d >= 2 && any) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const bool hit = (p[r] >= S.threshold) && (jr[r] < n);
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                if (hit && slot < S.cap) {
+            if (hit[r]) {
+                const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                const int slot = cnt + before;
+                if (__builtin_amdgcn_inverse_ballot_w64(hit[r]) && slot < S.cap) {
                     S.px[S.off + slot] = x0 + jr[r] - 1 + S.xs;
                     S.py[S.off + slot] = y0 - jr[r] - 1 + S.ys;
                     S.pp[S.off + slot] = p[r];
                 }
-                cnt += __popcll(mask);
+                cnt += __popcll(hit[r]);
             }
         }
     }
 }
 
-// One backward anti-diagonal.  `io` holds diagonal d+2 on entry and d on exit; `s1` holds d+1; lo1/lo2 are the
-// first x-y of d+1 and d+2.
+// One backward anti-diagonal.  `io` holds anti-diagonal d+2 on entry and d on exit; `s1` holds d+1.  k1 is the kind
+// of the forward step d -> d+1, which this call undoes on the frame; `same`: the step d+1 -> d+2 was of that kind too.
 template <int R>
 __device__ __forceinline__ void bwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Bases<R> &bX, Bases<R> &bY,
-                                         Feed &fx, Feed &fy, int d, int lo, int n, int lo1, int lo2, const int (&jr)[R]) {
-    const int x0 = (d + lo) >> 1, y0 = (d - lo) >> 1;
-    const int s = lo1 - lo;          // the forward step d -> d+1: +1 x-step, -1 y-step
-    const int sm = (lo - lo2) >> 1;  // index shift into the d+2 frame
-    if (sm > 0) {
-        io = shift_up<R>(io);
-    } else if (sm < 0) {
-        io = shift_down<R>(io);
-    }
-    if (s > 0) {
+                                         Feed &fx, Feed &fy, int &x0, int &y0, const Ctl &ct, int k1, bool same) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    if (k1) {
+        if (same) io = shift_down<R>(io);  // (x+1, y+1) is slot j-1 of d+2
+        x0 -= 1;
         // x decreased by one in every slot: X[x] moves up a slot, slot 0 takes X[x0]
         bases_down<R>(bX, feed_get<-1>(fx, E.X, E.lX, x0, E.lane));
-        const Diag<R> Ys = shift_down<R>(s1);  // (x, y+1) is index j-1 on d+1; (x+1, y) keeps index j
+        const Diag<R> Ys = shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float em, exs, exl, eys, eyl;
             emissions<R>(E, bX, bY, r, em, exs, exl, eys, eyl);
             Cell c = bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, jr[r], n);
+            kill_outside(c, mk.cell[r]);
             io.c[r] = c;
         }
     } else {
+        if (same) io = shift_up<R>(io);  // (x+1, y+1) is slot j+1 of d+2
+        y0 -= 1;
         bases_up<R>(bY, feed_get<-1>(fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
-        const Diag<R> Xs = shift_up<R>(s1);    // (x+1, y) is index j+1 on d+1; (x, y+1) keeps index j
+        const Diag<R> Xs = shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float em, exs, exl, eys, eyl;
             emissions<R>(E, bX, bY, r, em, exs, exl, eys, eyl);
             Cell c = bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, jr[r], n);
+            kill_outside(c, mk.cell[r]);
             io.c[r] = c;
         }
     }
@@ -346,8 +389,8 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // 8 ints: cell hand-off
 
     const int lane = threadIdx.x;
-    float *const Fv = a.Fv + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
-    int32_t *const Fe = a.Fe + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
+    char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
+    const int voff = 8 * R * lane;  // byte offset of this lane's cells inside a row that starts at lane 0
     int jr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
@@ -355,14 +398,12 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
     int t = blockIdx.x;
     while (t < a.ntasks) {
         const Task *tp = a.tasks + t;
-        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), band_off = uni64(tp->band_off),
+        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off),
                       pair_off = uni64(tp->pair_off);
         const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap),
                   flags = uni(tp->flags), model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
-        // band rows through the scalar cache: these arrays are never written by the kernel
-        cptr32 blo = (cptr32)(a.lo + band_off);
-        cptr32 bn = (cptr32)(a.n + band_off);
-        cptr32 bco = (cptr32)(reinterpret_cast<const int32_t *>(a.coff) + band_off);
+        // control words through the scalar cache: the array is never written by the kernel
+        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
         const int rs = flags & 1, re = (flags >> 1) & 1;
 
         __syncthreads();
@@ -380,7 +421,10 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
             // 4.7 vs 2.7 cycles), so with one cell per lane the 15 transitions stay in VGPRs.  With more cells
             // per lane the 15 registers would cost a wave of occupancy per SIMD, which costs more: SGPRs there.
             Trans tr = load_trans(E.mdl->T);
-            if constexpr (R >= 2) {
+#ifndef NPR_T_SGPR_MIN_R
+#define NPR_T_SGPR_MIN_R 2
+#endif
+            if constexpr (R >= NPR_T_SGPR_MIN_R) {
                 tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
                 tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
                 tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
@@ -394,49 +438,51 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
         // A holds the even anti-diagonals, B the odd ones.
         Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
         Bases<R> cX, cY;  // X[x-1]*4 and Y[y-1]*4 of every slot
+        const Ctl c0 = read_ctl(ctl, 0);
+        const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
+        int x0 = -j0, y0 = j0;  // lattice point of slot 0
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            cX.b[r] = base4(E.X, lX, jr[r] - 1);  // d = 0: x0 = 0, y0 = 0
-            cY.b[r] = base4(E.Y, lY, -jr[r] - 1);
+            cX.b[r] = base4(E.X, lX, x0 + jr[r] - 1);
+            cY.b[r] = base4(E.Y, lY, y0 - jr[r] - 1);
         }
         Feed fx, fy;
-        feed_init<+1>(fx, E.X, lX, 64 * R - 1, lane);  // first x-step injects X[1 + 64R - 2]
-        feed_init<+1>(fy, E.Y, lY, 0, lane);           // first y-step injects Y[0]
-        BandRow r0{blo[0], bn[0], static_cast<uint32_t>(bco[0])};
+        feed_init<+1>(fx, E.X, lX, x0 + 64 * R - 1, lane);  // first X-step injects X[(x0 + 1) + 64R - 2]
+        feed_init<+1>(fy, E.Y, lY, y0, lane);               // first Y-step injects Y[(y0 + 1) - 1]
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (jr[r] == 0) {
+            if (jr[r] == j0) {
                 Cell c;
                 c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
                 c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
                 normalise(c, 0);
                 A.c[r] = c;
             }
-        store_row<R>(Fv, Fe, A, r0.co, r0.n, lane);
-        int lo1 = r0.lo, lo2 = r0.lo;  // first x-y of d-1 and d-2
-        BandRow nx{0, 0, 0};
-        if (D >= 1) nx = BandRow{blo[1], bn[1], static_cast<uint32_t>(bco[1])};
+        store_row<R>(F, A, c0, voff);
+        Ctl nx = c0;
+        if (D >= 1) nx = read_ctl(ctl, 1);
+        int kprev = -1;  // kind of the step into d-1
         int d = 1;
         for (; d + 1 <= D; d += 2) {
-            BandRow cur = nx;
-            nx = BandRow{blo[d + 1], bn[d + 1], static_cast<uint32_t>(bco[d + 1])};  // one row ahead
-            fwd_step<R>(E, B, A, cX, cY, fx, fy, d, cur.lo, cur.n, lo1, lo2, jr);
-            store_row<R>(Fv, Fe, B, cur.co, cur.n, lane);
-            lo2 = lo1, lo1 = cur.lo;
+            Ctl cur = nx;
+            nx = read_ctl(ctl, d + 1);  // one ahead
+            fwd_step<R>(E, B, A, cX, cY, fx, fy, x0, y0, cur, cur.kind == kprev);
+            store_row<R>(F, B, cur, voff);
+            kprev = cur.kind;
             cur = nx;
-            if (d + 2 <= D) nx = BandRow{blo[d + 2], bn[d + 2], static_cast<uint32_t>(bco[d + 2])};
-            fwd_step<R>(E, A, B, cX, cY, fx, fy, d + 1, cur.lo, cur.n, lo1, lo2, jr);
-            store_row<R>(Fv, Fe, A, cur.co, cur.n, lane);
-            lo2 = lo1, lo1 = cur.lo;
+            if (d + 2 <= D) nx = read_ctl(ctl, d + 2);
+            fwd_step<R>(E, A, B, cX, cY, fx, fy, x0, y0, cur, cur.kind == kprev);
+            store_row<R>(F, A, cur, voff);
+            kprev = cur.kind;
         }
         if (d <= D) {  // D odd: one more step, into B
-            fwd_step<R>(E, B, A, cX, cY, fx, fy, d, nx.lo, nx.n, lo1, lo2, jr);
-            store_row<R>(Fv, Fe, B, nx.co, nx.n, lane);
-            lo2 = lo1, lo1 = nx.lo;
+            fwd_step<R>(E, B, A, cX, cY, fx, fy, x0, y0, nx, nx.kind == kprev);
+            store_row<R>(F, B, nx, voff);
+            kprev = nx.kind;
         }
-        // total probability at the end corner: cell j = (lX - lY - lo_D) / 2 of the last diagonal
+        // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
         {
-            const int je = (lX - lY - lo1) >> 1;
+            const int je = lX - x0;
             const bool oddD = D & 1;
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -470,17 +516,16 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
             const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
-            // P holds diagonals D, D-2, ...; Q holds D-1, D-3, ...
+            // P holds anti-diagonals D, D-2, ...; Q holds D-1, D-3, ...
             Diag<R> P = dead_diag<R>(), Q = dead_diag<R>();
             Bases<R> bX, bY;  // X[x]*4 and Y[y]*4 of every slot
-            BandRow cur{blo[D], bn[D], static_cast<uint32_t>(bco[D])};
+            Ctl cur = read_ctl(ctl, D);
             {
-                const int x0 = (D + cur.lo) >> 1, y0 = (D - cur.lo) >> 1;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     bX.b[r] = base4(E.X, lX, x0 + jr[r]);
                     bY.b[r] = base4(E.Y, lY, y0 - jr[r]);
-                    if (jr[r] < cur.n && x0 + jr[r] == lX && y0 - jr[r] == lY) {
+                    if (x0 + jr[r] == lX) {  // the end corner (it is in the band by construction)
                         Cell c;
                         c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
                         c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
@@ -488,50 +533,61 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
                         P.c[r] = c;
                     }
                 }
-                // first backward x-step injects X[x0 - 1] at slot 0; first y-step injects Y[y0 - 64R] on top
+                // first undone X-step injects X[x0 - 1] at slot 0; first undone Y-step injects Y[y0 - 64R] on top
                 feed_init<-1>(fx, E.X, lX, x0 - 1, lane);
                 feed_init<-1>(fy, E.Y, lY, y0 - 64 * R, lane);
             }
-            FRow<R> fa, fb;  // forward rows: fa pairs with P's diagonals, fb with Q's; loaded one diagonal ahead
-            load_row<R>(Fv, Fe, fa, cur.co, cur.n, lane);
-            BandRow nxt = cur;
+            FRow<R> fa, fb;  // forward rows: fa pairs with P's anti-diagonals, fb with Q's; loaded one ahead
+#pragma unroll
+            for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
+            load_row<R>(F, fa, cur, voff);
+            Ctl nxt = cur;
             if (D >= 1) {
-                nxt = BandRow{blo[D - 1], bn[D - 1], static_cast<uint32_t>(bco[D - 1])};
-                load_row<R>(Fv, Fe, fb, nxt.co, nxt.n, lane);
+                nxt = read_ctl(ctl, D - 1);
+                load_row<R>(F, fb, nxt, voff);
             }
-            emit_pairs<R>(sink, P, fa, D, cur.lo, cur.n, tot_e, inv_tot, jr, lane, cnt);
-            int hi1 = cur.lo, hi2 = cur.lo;  // first x-y of d+1 and d+2
+            emit_pairs<R>(sink, P, fa, D, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+            int k1 = cur.kind, k2 = -1;  // kinds of the forward steps d -> d+1 and d+1 -> d+2
             int d2 = D - 1;
             for (; d2 - 1 >= 0; d2 -= 2) {
                 cur = nxt;
-                nxt = BandRow{blo[d2 - 1], bn[d2 - 1], static_cast<uint32_t>(bco[d2 - 1])};
-                load_row<R>(Fv, Fe, fa, nxt.co, nxt.n, lane);  // for the step after this one
-                bwd_step<R>(E, Q, P, bX, bY, fx, fy, d2, cur.lo, cur.n, hi1, hi2, jr);
-                emit_pairs<R>(sink, Q, fb, d2, cur.lo, cur.n, tot_e, inv_tot, jr, lane, cnt);
-                hi2 = hi1, hi1 = cur.lo;
+                nxt = read_ctl(ctl, d2 - 1);
+                load_row<R>(F, fa, nxt, voff);  // for the step after this one
+                bwd_step<R>(E, Q, P, bX, bY, fx, fy, x0, y0, cur, k1, k1 == k2);
+                emit_pairs<R>(sink, Q, fb, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                k2 = k1, k1 = cur.kind;
                 cur = nxt;
                 if (d2 - 2 >= 0) {
-                    nxt = BandRow{blo[d2 - 2], bn[d2 - 2], static_cast<uint32_t>(bco[d2 - 2])};
-                    load_row<R>(Fv, Fe, fb, nxt.co, nxt.n, lane);
+                    nxt = read_ctl(ctl, d2 - 2);
+                    load_row<R>(F, fb, nxt, voff);
                 }
-                bwd_step<R>(E, P, Q, bX, bY, fx, fy, d2 - 1, cur.lo, cur.n, hi1, hi2, jr);
-                emit_pairs<R>(sink, P, fa, d2 - 1, cur.lo, cur.n, tot_e, inv_tot, jr, lane, cnt);
-                hi2 = hi1, hi1 = cur.lo;
+                bwd_step<R>(E, P, Q, bX, bY, fx, fy, x0, y0, cur, k1, k1 == k2);
+                emit_pairs<R>(sink, P, fa, d2 - 1, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                k2 = k1, k1 = cur.kind;
             }
             if (d2 >= 0) {  // d2 == 0 left over (D odd): into Q
-                bwd_step<R>(E, Q, P, bX, bY, fx, fy, d2, nxt.lo, nxt.n, hi1, hi2, jr);
-                emit_pairs<R>(sink, Q, fb, d2, nxt.lo, nxt.n, tot_e, inv_tot, jr, lane, cnt);
+                bwd_step<R>(E, Q, P, bX, bY, fx, fy, x0, y0, nxt, k1, k1 == k2);
+                emit_pairs<R>(sink, Q, fb, d2, x0, y0, nxt, tot_e, inv_tot, jr, cnt);
             }
-            // total from the backward side: cell (0,0) is slot 0 of diagonal 0 (in P when D is even)
-            if (lane == 0) {
-                const Cell c0 = (D & 1) ? Q.c[0] : P.c[0];
-                const float raw = dot5(mdl->start + rs * 5, c0);
-                if (raw > 0.f) {
-                    int k;
-                    out.btot_m = __builtin_frexpf(raw, &k);
-                    out.btot_e = c0.e + k;
+            // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0 (in P when D is even)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (jr[r] == j0) {
+                    const Cell cz = (D & 1) ? Q.c[r] : P.c[r];
+                    const float raw = dot5(mdl->start + rs * 5, cz);
+                    float bm = 0.f;
+                    int be = E_DEAD;
+                    if (raw > 0.f) {
+                        int k;
+                        bm = __builtin_frexpf(raw, &k);
+                        be = cz.e + k;
+                    }
+                    reinterpret_cast<float *>(lmisc)[2] = bm;
+                    lmisc[3] = be;
                 }
-            }
+            __syncthreads();
+            out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
+            out.btot_e = uni(lmisc[3]);
         }
         if (lane == 0) {
             out.npairs = cnt;

@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(512) k_dp_generic(KernelArgs a) {
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int nthreads = blockDim.x;  // 64, 256 or 512 (the E-step variant always runs 64)
-    float *const Fv = a.Fv + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
-    int32_t *const Fe = a.Fe + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
+    float *const Fv = reinterpret_cast<float *>(a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8);
+    int32_t *const Fe = reinterpret_cast<int32_t *>(Fv + a.slot_stride);
 
     // The first task of every wavefront is static (t = blockIdx.x); later ones come from the atomic queue.
     // The loop is kept free of break/continue and every loop-carried value is an SGPR: with a divergent
