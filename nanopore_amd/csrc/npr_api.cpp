@@ -293,40 +293,43 @@ int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double 
 
 // --------------------------------------------------------------------------------------------------
 // Frame schedule of the register kernel (npr_kernel_stair.hip).  The wavefront holds a frame of C = 64*R slots of the
-// current anti-diagonal, slot j = lattice point (x0 + j, y0 - j); every anti-diagonal the frame advances by an X-step
-// (x0 += 1) or a Y-step (y0 += 1).  The band (first x-y `lo`, n cells) must stay inside the frame; where it does, the
-// steps alternate -- then the (x-1, y-1) predecessor sits in the same slot and the kernel moves nothing -- and only
-// when the band reaches a frame edge is a step repeated.  Returns false when the band cannot be followed (an edge
-// that jumps further than the slack allows); `ctl` (two words per anti-diagonal) and `cells` may be null.
+// current anti-diagonal, slot j = lattice point (x0 + j, y0 - j); the frame takes an X-step (x0 += 1) into every odd
+// anti-diagonal and a Y-step (y0 += 1) into every even one, so its first x-y, flo, just alternates.  The band (first
+// x-y `lo`, n cells) must stay inside the frame; when it drifts to an edge the frame is REBASED by one slot
+// (flo +- 2) between two anti-diagonals.  A rebase towards higher x-y may only precede an X-step and one towards
+// lower x-y a Y-step (the kernel re-injects the base that left the wavefront at the step before), so the decision
+// looks one anti-diagonal ahead.  Control words per anti-diagonal: row offset in the forward scratch (cells), and
+// jlo | n << 10 | (rebase + 1) << 20.  Returns false when the band cannot be followed; `ctl` and `cells` may be null.
 // --------------------------------------------------------------------------------------------------
 namespace {
 
 bool build_stair_schedule(const Segment &s, int R, uint32_t *ctl, int64_t *cells) {
-    const int64_t C = 64 * R, D = s.D();
+    const int64_t C = 64 * R, D = s.D(), span = 2 * (C - 1);
     if (s.n.empty() || s.n[0] != 1 || s.max_width >= C) return false;
     const int64_t j0 = (C - 1) / 2;
     int64_t flo = s.lo[0] - 2 * j0;  // x-y of slot 0
     uint64_t off = 0;
-    int kind = 0;  // so that the first step defaults to X
     for (int64_t d = 0; d <= D; ++d) {
         const int64_t lo = s.lo[d], n = s.n[d], hi = lo + 2 * (n - 1);
         if (n < 1) return false;
+        int reb = 0;
         if (d > 0) {
-            const int pref = !kind;
-            const int64_t fa = flo + (pref ? 1 : -1), fb = flo + (pref ? -1 : 1);
-            if (fa <= lo && hi <= fa + 2 * (C - 1)) {
-                kind = pref, flo = fa;
-            } else if (fb <= lo && hi <= fb + 2 * (C - 1)) {
-                kind = !pref, flo = fb;
+            if (d & 1) {  // X-step; the next one is a Y-step
+                const int64_t f = flo + 1;
+                if (hi > f + span || (d < D && s.lo[d + 1] + 2 * (int64_t(s.n[d + 1]) - 1) > f - 1 + span)) reb = 1;
+                flo = f + 2 * reb;
             } else {
-                return false;
+                const int64_t f = flo - 1;
+                if (lo < f || (d < D && s.lo[d + 1] < f + 1)) reb = -1;
+                flo = f + 2 * reb;
             }
+            if (lo < flo || hi > flo + span) return false;
         }
         const int64_t jlo = (lo - flo) / 2;
         const int64_t l0 = jlo / R, l1 = (jlo + n + R - 1) / R;
         if (ctl) {
             ctl[2 * d] = static_cast<uint32_t>(off);
-            ctl[2 * d + 1] = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 10) | (static_cast<uint32_t>(kind) << 20);
+            ctl[2 * d + 1] = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 10) | (static_cast<uint32_t>(reb + 1) << 20);
         }
         off += static_cast<uint64_t>(R * (l1 - l0));
     }

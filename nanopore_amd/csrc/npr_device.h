@@ -42,7 +42,7 @@ struct KernelArgs {
     const int32_t *lo;
     const int32_t *n;
     const uint32_t *coff;  // per anti-diagonal: offset of its first cell inside the task (cells padded to x4)
-    const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 10 | kind << 20)
+    const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 10 | (rebase + 1) << 20)
     char *F;               // forward match-state scratch: one region of 8*slot_stride bytes per resident wave.  The
                            // register kernel keeps (mantissa, exponent) interleaved per cell; the generic kernel
                            // keeps a mantissa plane followed by an exponent plane.

@@ -8,11 +8,13 @@
 //
 // Mapping (one read per 64-lane wavefront, no LDS traffic in the recurrence, no MFMA):
 //   * the wavefront holds a FRAME of 64*R lattice points of the current anti-diagonal, slot j = (x0 + j, y0 - j),
-//     slot j in lane j / R, register j % R (blocked).  The frame advances by an X-step (x0 += 1) or a Y-step
-//     (y0 += 1) per anti-diagonal; the band floats inside it (first slot jlo, n cells), selected by wave-uniform lane
-//     masks built on the scalar unit.  The host schedules the frame (build_stair_schedule in npr_api.cpp): X and Y
-//     steps alternate wherever the band fits, and only then is the (x-1, y-1) predecessor in the same slot, so the hot
-//     path never moves the anti-diagonal d-2; two equal steps in a row (drift, long gaps) shift it by one slot;
+//     slot j in lane j / R, register j % R (blocked).  The frame advances by an X-step (x0 += 1) into every odd
+//     anti-diagonal and a Y-step (y0 += 1) into every even one, so the (x-1, y-1) predecessor always sits in the same
+//     slot, the loop body is straight-line code and nothing but the one crossing neighbour ever moves.  The band floats
+//     inside the frame (first slot jlo, n cells), selected by wave-uniform lane masks built on the scalar unit; when it
+//     drifts to a frame edge the host-made schedule (build_stair_schedule in npr_api.cpp) asks for a REBASE: the whole
+//     register state moves one slot, in place (about one anti-diagonal in twenty on noisy reads; every other one
+//     inside a long gap);
 //   * of the R neighbours on d-1 only ONE per state crosses a lane boundary: a single DPP wave_shl:1 / wave_shr:1;
 //   * the two previous anti-diagonals stay in VGPRs (6*R registers each) and swap roles every step (the loops are
 //     unrolled by two), so no anti-diagonal is ever copied;
@@ -162,11 +164,11 @@ typedef const __attribute__((address_space(4))) uint32_t *cptr32;
 struct Ctl {
     uint32_t co;  // scratch offset (cells) of the first stored lane of the row
     int jlo, n;   // band = slots [jlo, jlo + n)
-    int kind;     // 1: X-step into this anti-diagonal (x0 += 1), 0: Y-step (y0 += 1)
+    int reb;      // frame rebase applied between the previous anti-diagonal and the step into this one: -1, 0, +1
 };
 __device__ __forceinline__ Ctl read_ctl(cptr32 ctl, int d) {
     const uint32_t co = ctl[2 * d], w = ctl[2 * d + 1];
-    return Ctl{co, static_cast<int>(w & 1023u), static_cast<int>((w >> 10) & 1023u), static_cast<int>((w >> 20) & 1u)};
+    return Ctl{co, static_cast<int>(w & 1023u), static_cast<int>((w >> 10) & 1023u), static_cast<int>((w >> 20) & 3u) - 1};
 }
 
 __device__ __forceinline__ uint64_t low_lanes(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
@@ -216,38 +218,136 @@ __device__ __forceinline__ void kill_outside(Cell &c, uint64_t in_band) {
     c.e = __builtin_amdgcn_inverse_ballot_w64(in_band) ? c.e : E_DEAD;
 }
 
-// One forward anti-diagonal.  `io` holds anti-diagonal d-2 on entry and d on exit; `p1` holds d-1.  `same`: the step
-// into d-1 was of the same kind, so the frame moved two slots along one axis since d-2.
+// In-place moves of the whole register state by one slot (frame rebase).  Written as inline assembly on tied
+// operands: expressed in C++ the moved values are new SSA values, and the compiler pays for the join with the
+// not-moved path by copying the state on the hot path.  s_nop: a DPP read of a VGPR written by the previous VALU
+// instruction needs two wait states, which the compiler cannot see through inline assembly.
+__device__ __forceinline__ void rot_up(float &a, float &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void rot_up(int &a, int &b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void dpp_up_inplace(float &v) {
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v));
+}
+__device__ __forceinline__ void dpp_down_inplace(float &v) {
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v));
+}
+// integer registers: the vacated edge lane takes `edge` (uniform)
+__device__ __forceinline__ void dpp_up_inplace(int &v, int edge) {
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %1, 63" : "+v"(v) : "s"(edge));
+}
+__device__ __forceinline__ void dpp_down_inplace(int &v, int edge) {
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(edge));
+}
+
+// slot j <- slot j+1
 template <int R>
-__device__ __forceinline__ void fwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Bases<R> &cX, Bases<R> &cY,
-                                         Feed &fx, Feed &fy, int &x0, int &y0, const Ctl &ct, bool same) {
-    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
-    if (ct.kind) {
-        if (same) io = shift_up<R>(io);
-        x0 += 1;
-        bases_up<R>(cX, feed_get<+1>(fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
-        const Diag<R> U = shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
+__device__ __forceinline__ void diag_up_inplace(Diag<R> &g) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float em, exs, exl, eys, eyl;
-            emissions<R>(E, cX, cY, r, em, exs, exl, eys, eyl);
-            Cell c = fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, mk.cell[r]);
-            io.c[r] = c;
-        }
+    for (int r = 0; r + 1 < R; ++r) {  // rotate: (c0, c1, .., c{R-1}) -> (c1, .., c{R-1}, c0)
+        rot_up(g.c[r].m, g.c[r + 1].m), rot_up(g.c[r].sx, g.c[r + 1].sx), rot_up(g.c[r].sy, g.c[r + 1].sy);
+        rot_up(g.c[r].lx, g.c[r + 1].lx), rot_up(g.c[r].ly, g.c[r + 1].ly), rot_up(g.c[r].e, g.c[r + 1].e);
+    }
+    Cell &t = g.c[R - 1];
+    dpp_up_inplace(t.m), dpp_up_inplace(t.sx), dpp_up_inplace(t.sy), dpp_up_inplace(t.lx), dpp_up_inplace(t.ly);
+    dpp_up_inplace(t.e, E_DEAD);
+}
+// slot j <- slot j-1
+template <int R>
+__device__ __forceinline__ void diag_down_inplace(Diag<R> &g) {
+#pragma unroll
+    for (int r = R - 1; r > 0; --r) {  // rotate: (c0, .., c{R-1}) -> (c{R-1}, c0, .., c{R-2})
+        rot_up(g.c[r].m, g.c[r - 1].m), rot_up(g.c[r].sx, g.c[r - 1].sx), rot_up(g.c[r].sy, g.c[r - 1].sy);
+        rot_up(g.c[r].lx, g.c[r - 1].lx), rot_up(g.c[r].ly, g.c[r - 1].ly), rot_up(g.c[r].e, g.c[r - 1].e);
+    }
+    Cell &t = g.c[0];
+    dpp_down_inplace(t.m), dpp_down_inplace(t.sx), dpp_down_inplace(t.sy), dpp_down_inplace(t.lx), dpp_down_inplace(t.ly);
+    dpp_down_inplace(t.e, E_DEAD);
+}
+template <int R>
+__device__ __forceinline__ void bases_up_inplace(Bases<R> &s, int inject) {
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) rot_up(s.b[r], s.b[r + 1]);
+    dpp_up_inplace(s.b[R - 1], inject);
+}
+template <int R>
+__device__ __forceinline__ void bases_down_inplace(Bases<R> &s, int inject) {
+#pragma unroll
+    for (int r = R - 1; r > 0; --r) rot_up(s.b[r], s.b[r - 1]);
+    dpp_down_inplace(s.b[0], inject);
+}
+
+// Base streams of one sweep plus what a rebase needs to run them backwards by one slot: the base that left the
+// wavefront at the last step of each kind (a rebase towards higher x-y only ever follows a Y-step, one towards lower
+// x-y an X-step: build_stair_schedule).
+template <int R>
+struct Streams {
+    Bases<R> X, Y;
+    Feed fx, fy;
+    int xcap, ycap;
+};
+
+// Frame rebase of the forward sweep, r = +1: (x0, y0) -> (x0 + 1, y0 - 1), every slot takes its upper neighbour.
+template <int R>
+__device__ __forceinline__ void fwd_rebase(const StepEnv &E, int r, Diag<R> &A, Diag<R> &B, Streams<R> &S, int &x0, int &y0) {
+    if (r > 0) {
+        diag_up_inplace<R>(A), diag_up_inplace<R>(B);
+        x0 += 1, y0 -= 1;
+        bases_up_inplace<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
+        bases_up_inplace<R>(S.Y, S.ycap);
     } else {
-        if (same) io = shift_down<R>(io);
-        y0 += 1;
-        bases_down<R>(cY, feed_get<+1>(fy, E.Y, E.lY, y0 - 1, E.lane));
-        const Diag<R> L = shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
+        diag_down_inplace<R>(A), diag_down_inplace<R>(B);
+        x0 -= 1, y0 += 1;
+        bases_down_inplace<R>(S.X, S.xcap);
+        bases_down_inplace<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
+    }
+}
+// ... and of the backward sweep, which undoes the forward one: r is the forward rebase being undone.
+template <int R>
+__device__ __forceinline__ void bwd_rebase(const StepEnv &E, int r, Diag<R> &A, Diag<R> &B, Streams<R> &S, int &x0, int &y0) {
+    if (r > 0) {  // back to lower x-y: (x0 - 1, y0 + 1)
+        diag_down_inplace<R>(A), diag_down_inplace<R>(B);
+        x0 -= 1, y0 += 1;
+        bases_down_inplace<R>(S.X, feed_get<-1>(S.fx, E.X, E.lX, x0, E.lane));
+        bases_down_inplace<R>(S.Y, S.ycap);
+    } else {
+        diag_up_inplace<R>(A), diag_up_inplace<R>(B);
+        x0 += 1, y0 -= 1;
+        bases_up_inplace<R>(S.X, S.xcap);
+        bases_up_inplace<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
+    }
+}
+
+// One forward anti-diagonal.  `io` holds anti-diagonal d-2 on entry and d on exit; `p1` holds d-1.  S.X / S.Y hold
+// X[x-1]*4 and Y[y-1]*4 of every slot.
+template <int R>
+__device__ __forceinline__ void fwd_x_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &x0, const Ctl &ct) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
+    x0 += 1;
+    bases_up<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
+    const Diag<R> U = shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float em, exs, exl, eys, eyl;
-            emissions<R>(E, cX, cY, r, em, exs, exl, eys, eyl);
-            Cell c = fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, mk.cell[r]);
-            io.c[r] = c;
-        }
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+        Cell c = fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
+        kill_outside(c, mk.cell[r]);
+        io.c[r] = c;
+    }
+}
+template <int R>
+__device__ __forceinline__ void fwd_y_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &y0, const Ctl &ct) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
+    y0 += 1;
+    bases_down<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
+    const Diag<R> L = shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+        Cell c = fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
+        kill_outside(c, mk.cell[r]);
+        io.c[r] = c;
     }
 }
 
@@ -346,39 +446,39 @@ __device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, 
     }
 }
 
-// One backward anti-diagonal.  `io` holds anti-diagonal d+2 on entry and d on exit; `s1` holds d+1.  k1 is the kind
-// of the forward step d -> d+1, which this call undoes on the frame; `same`: the step d+1 -> d+2 was of that kind too.
+// One backward anti-diagonal d.  `io` holds anti-diagonal d+2 on entry and d on exit; `s1` holds d+1.  S.X / S.Y hold
+// X[x]*4 and Y[y]*4 of every slot.  The X variant undoes the X-step into d+1 (d even), the Y variant a Y-step.
 template <int R>
-__device__ __forceinline__ void bwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Bases<R> &bX, Bases<R> &bY,
-                                         Feed &fx, Feed &fy, int &x0, int &y0, const Ctl &ct, int k1, bool same) {
+__device__ __forceinline__ void bwd_x_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &x0, const Ctl &ct) {
     const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
-    if (k1) {
-        if (same) io = shift_down<R>(io);  // (x+1, y+1) is slot j-1 of d+2
-        x0 -= 1;
-        // x decreased by one in every slot: X[x] moves up a slot, slot 0 takes X[x0]
-        bases_down<R>(bX, feed_get<-1>(fx, E.X, E.lX, x0, E.lane));
-        const Diag<R> Ys = shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
+    S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
+    x0 -= 1;
+    // x decreased by one in every slot: X[x] moves up a slot, slot 0 takes X[x0]
+    bases_down<R>(S.X, feed_get<-1>(S.fx, E.X, E.lX, x0, E.lane));
+    const Diag<R> Ys = shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float em, exs, exl, eys, eyl;
-            emissions<R>(E, bX, bY, r, em, exs, exl, eys, eyl);
-            Cell c = bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, mk.cell[r]);
-            io.c[r] = c;
-        }
-    } else {
-        if (same) io = shift_up<R>(io);  // (x+1, y+1) is slot j+1 of d+2
-        y0 -= 1;
-        bases_up<R>(bY, feed_get<-1>(fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
-        const Diag<R> Xs = shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+        Cell c = bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
+        kill_outside(c, mk.cell[r]);
+        io.c[r] = c;
+    }
+}
+template <int R>
+__device__ __forceinline__ void bwd_y_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &y0, const Ctl &ct) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
+    y0 -= 1;
+    bases_up<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
+    const Diag<R> Xs = shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float em, exs, exl, eys, eyl;
-            emissions<R>(E, bX, bY, r, em, exs, exl, eys, eyl);
-            Cell c = bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
-            kill_outside(c, mk.cell[r]);
-            io.c[r] = c;
-        }
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+        Cell c = bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
+        kill_outside(c, mk.cell[r]);
+        io.c[r] = c;
     }
 }
 
@@ -435,20 +535,20 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
         const DevModel *mdl = E.mdl;
 
         // =============================== forward ===============================
-        // A holds the even anti-diagonals, B the odd ones.
+        // A holds the even anti-diagonals, B the odd ones; X-steps lead into odd anti-diagonals, Y-steps into even ones.
         Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
-        Bases<R> cX, cY;  // X[x-1]*4 and Y[y-1]*4 of every slot
+        Streams<R> S;  // X[x-1]*4 and Y[y-1]*4 of every slot
         const Ctl c0 = read_ctl(ctl, 0);
         const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
         int x0 = -j0, y0 = j0;  // lattice point of slot 0
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            cX.b[r] = base4(E.X, lX, x0 + jr[r] - 1);
-            cY.b[r] = base4(E.Y, lY, y0 - jr[r] - 1);
+            S.X.b[r] = base4(E.X, lX, x0 + jr[r] - 1);
+            S.Y.b[r] = base4(E.Y, lY, y0 - jr[r] - 1);
         }
-        Feed fx, fy;
-        feed_init<+1>(fx, E.X, lX, x0 + 64 * R - 1, lane);  // first X-step injects X[(x0 + 1) + 64R - 2]
-        feed_init<+1>(fy, E.Y, lY, y0, lane);               // first Y-step injects Y[(y0 + 1) - 1]
+        S.xcap = S.ycap = 16;
+        feed_init<+1>(S.fx, E.X, lX, x0 + 64 * R - 1, lane);  // first X-step injects X[(x0 + 1) + 64R - 2]
+        feed_init<+1>(S.fy, E.Y, lY, y0, lane);               // first Y-step injects Y[(y0 + 1) - 1]
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (jr[r] == j0) {
@@ -461,24 +561,23 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
         store_row<R>(F, A, c0, voff);
         Ctl nx = c0;
         if (D >= 1) nx = read_ctl(ctl, 1);
-        int kprev = -1;  // kind of the step into d-1
         int d = 1;
         for (; d + 1 <= D; d += 2) {
             Ctl cur = nx;
             nx = read_ctl(ctl, d + 1);  // one ahead
-            fwd_step<R>(E, B, A, cX, cY, fx, fy, x0, y0, cur, cur.kind == kprev);
+            if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
+            fwd_x_step<R>(E, B, A, S, x0, cur);
             store_row<R>(F, B, cur, voff);
-            kprev = cur.kind;
             cur = nx;
             if (d + 2 <= D) nx = read_ctl(ctl, d + 2);
-            fwd_step<R>(E, A, B, cX, cY, fx, fy, x0, y0, cur, cur.kind == kprev);
+            if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
+            fwd_y_step<R>(E, A, B, S, y0, cur);
             store_row<R>(F, A, cur, voff);
-            kprev = cur.kind;
         }
-        if (d <= D) {  // D odd: one more step, into B
-            fwd_step<R>(E, B, A, cX, cY, fx, fy, x0, y0, nx, nx.kind == kprev);
+        if (d <= D) {  // D odd: one more X-step, into B
+            if (nx.reb) fwd_rebase<R>(E, nx.reb, A, B, S, x0, y0);
+            fwd_x_step<R>(E, B, A, S, x0, nx);
             store_row<R>(F, B, nx, voff);
-            kprev = nx.kind;
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
         {
@@ -516,64 +615,81 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
             const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
-            // P holds anti-diagonals D, D-2, ...; Q holds D-1, D-3, ...
-            Diag<R> P = dead_diag<R>(), Q = dead_diag<R>();
-            Bases<R> bX, bY;  // X[x]*4 and Y[y]*4 of every slot
+            // A holds the even anti-diagonals again, B the odd ones; fa / fb the forward rows that pair with them,
+            // loaded one anti-diagonal ahead.  S now holds X[x]*4 and Y[y]*4 of every slot.
+            A = dead_diag<R>(), B = dead_diag<R>();
+            const bool oddD = D & 1;
             Ctl cur = read_ctl(ctl, D);
-            {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    bX.b[r] = base4(E.X, lX, x0 + jr[r]);
-                    bY.b[r] = base4(E.Y, lY, y0 - jr[r]);
-                    if (x0 + jr[r] == lX) {  // the end corner (it is in the band by construction)
-                        Cell c;
-                        c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
-                        c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
-                        normalise(c, 0);
-                        P.c[r] = c;
-                    }
+            for (int r = 0; r < R; ++r) {
+                S.X.b[r] = base4(E.X, lX, x0 + jr[r]);
+                S.Y.b[r] = base4(E.Y, lY, y0 - jr[r]);
+                if (x0 + jr[r] == lX) {  // the end corner (it is in the band by construction)
+                    Cell c;
+                    c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
+                    c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
+                    normalise(c, 0);
+                    if (oddD) B.c[r] = c; else A.c[r] = c;
                 }
-                // first undone X-step injects X[x0 - 1] at slot 0; first undone Y-step injects Y[y0 - 64R] on top
-                feed_init<-1>(fx, E.X, lX, x0 - 1, lane);
-                feed_init<-1>(fy, E.Y, lY, y0 - 64 * R, lane);
             }
-            FRow<R> fa, fb;  // forward rows: fa pairs with P's anti-diagonals, fb with Q's; loaded one ahead
+            S.xcap = S.ycap = 16;
+            // first undone X-step injects X[x0 - 1] at slot 0; first undone Y-step injects Y[y0 - 64R] on top
+            feed_init<-1>(S.fx, E.X, lX, x0 - 1, lane);
+            feed_init<-1>(S.fy, E.Y, lY, y0 - 64 * R, lane);
+            FRow<R> fa, fb;
 #pragma unroll
             for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
-            load_row<R>(F, fa, cur, voff);
             Ctl nxt = cur;
-            if (D >= 1) {
+            if (oddD) {
+                load_row<R>(F, fb, cur, voff);
                 nxt = read_ctl(ctl, D - 1);
-                load_row<R>(F, fb, nxt, voff);
+                load_row<R>(F, fa, nxt, voff);
+                emit_pairs<R>(sink, B, fb, D, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+            } else {
+                load_row<R>(F, fa, cur, voff);
+                if (D >= 1) {
+                    nxt = read_ctl(ctl, D - 1);
+                    load_row<R>(F, fb, nxt, voff);
+                }
+                emit_pairs<R>(sink, A, fa, D, x0, y0, cur, tot_e, inv_tot, jr, cnt);
             }
-            emit_pairs<R>(sink, P, fa, D, x0, y0, cur, tot_e, inv_tot, jr, cnt);
-            int k1 = cur.kind, k2 = -1;  // kinds of the forward steps d -> d+1 and d+1 -> d+2
+            // `cur` is the control word of the anti-diagonal above the one computed next: its rebase is undone first
             int d2 = D - 1;
-            for (; d2 - 1 >= 0; d2 -= 2) {
+            if (oddD) {  // peel one even anti-diagonal so that the loop below always starts on an odd one
+                const int reb = cur.reb;
+                cur = nxt;
+                if (d2 >= 1) {
+                    nxt = read_ctl(ctl, d2 - 1);
+                    load_row<R>(F, fb, nxt, voff);
+                }
+                if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
+                bwd_x_step<R>(E, A, B, S, x0, cur);
+                emit_pairs<R>(sink, A, fa, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                d2 -= 1;
+            }
+            for (; d2 >= 1; d2 -= 2) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
+                int reb = cur.reb;
                 cur = nxt;
                 nxt = read_ctl(ctl, d2 - 1);
                 load_row<R>(F, fa, nxt, voff);  // for the step after this one
-                bwd_step<R>(E, Q, P, bX, bY, fx, fy, x0, y0, cur, k1, k1 == k2);
-                emit_pairs<R>(sink, Q, fb, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
-                k2 = k1, k1 = cur.kind;
+                if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
+                bwd_y_step<R>(E, B, A, S, y0, cur);
+                emit_pairs<R>(sink, B, fb, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                reb = cur.reb;
                 cur = nxt;
-                if (d2 - 2 >= 0) {
+                if (d2 >= 2) {
                     nxt = read_ctl(ctl, d2 - 2);
                     load_row<R>(F, fb, nxt, voff);
                 }
-                bwd_step<R>(E, P, Q, bX, bY, fx, fy, x0, y0, cur, k1, k1 == k2);
-                emit_pairs<R>(sink, P, fa, d2 - 1, x0, y0, cur, tot_e, inv_tot, jr, cnt);
-                k2 = k1, k1 = cur.kind;
+                if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
+                bwd_x_step<R>(E, A, B, S, x0, cur);
+                emit_pairs<R>(sink, A, fa, d2 - 1, x0, y0, cur, tot_e, inv_tot, jr, cnt);
             }
-            if (d2 >= 0) {  // d2 == 0 left over (D odd): into Q
-                bwd_step<R>(E, Q, P, bX, bY, fx, fy, x0, y0, nxt, k1, k1 == k2);
-                emit_pairs<R>(sink, Q, fb, d2, x0, y0, nxt, tot_e, inv_tot, jr, cnt);
-            }
-            // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0 (in P when D is even)
+            // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (jr[r] == j0) {
-                    const Cell cz = (D & 1) ? Q.c[r] : P.c[r];
+                    const Cell cz = A.c[r];
                     const float raw = dot5(mdl->start + rs * 5, cz);
                     float bm = 0.f;
                     int be = E_DEAD;
