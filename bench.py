@@ -42,7 +42,8 @@ def build_workload(name, n_reads, rank):
     h = load_model()
     if name == "northstar":
         w, W = synth.config_north_star(h.transitions, h.emissions, n_reads=n_reads, seed=1003 + 7919 * rank)
-        label = "synthetic ~10kb reads x 50kb reference slices, band 200, blasr_hmm_0 (north-star shape)"
+        label = ("synthetic ~10kb reads x 50kb reference slices, band 200, blasr_hmm_0 (north-star shape); guides carry "
+                 "their window's coordinates inside the slice, as the exonerate cigar fed to cactus_realign does")
     elif name == "c2":
         w, W = synth.make_workload(1001 + 7919 * rank, n_reads, 1000, h.transitions, h.emissions), 100
         label = "synthetic 1k reads x 1kb, band 100, blasr_hmm_0 (BASELINE.json configs[1])"
@@ -64,10 +65,17 @@ def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
     P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
 
     def run(k):
-        X = encode(bytes(w["ref"][:w["ref_off"][k]]))
+        if w.get("guide_start") is not None:
+            # the oracle takes the guide's window of every slice (what npr_batch_create_at does on its side)
+            lead, ilen = w["guide_start"][:k, 0], w["interval_len"][:k]
+            X = encode(b"".join(bytes(w["ref"][w["ref_off"][i] + lead[i]:w["ref_off"][i] + lead[i] + ilen[i]]) for i in range(k)))
+            x_off = np.concatenate([[0], np.cumsum(ilen)]).astype(np.int64)
+        else:
+            X = encode(bytes(w["ref"][:w["ref_off"][k]]))
+            x_off = w["ref_off"][:k + 1]
         Y = encode(bytes(w["read"][:w["read_off"][k]]))
         t0 = time.time()
-        r = orc.realign_batch(oh, P, X, w["ref_off"][:k + 1], Y, w["read_off"][:k + 1],
+        r = orc.realign_batch(oh, P, X, x_off, Y, w["read_off"][:k + 1],
                               w["guide_ops"][:w["guide_off"][k]], w["guide_off"][:k + 1], precision=0,
                               threads=cores, native=True)
         return r, time.time() - t0
@@ -92,7 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3"])
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 4096 northstar, 1000 c2)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 5120 northstar, 1000 c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,12 +130,12 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from nanopore_amd import realign as R
-    n_reads = args.reads or {"northstar": 4096, "c2": 1000, "c3": 50000}[args.workload]
+    n_reads = args.reads or {"northstar": 5120, "c2": 1000, "c3": 50000}[args.workload]
     h, w, W, label = build_workload(args.workload, n_reads, rank)
     ctx = R.Context(local_rank)
     ctx.set_hmm(h)
     batch = ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"],
-                          w["read_off"], w["guide_ops"], w["guide_off"])
+                          w["read_off"], w["guide_ops"], w["guide_off"], guide_start=w.get("guide_start"))
     st = batch.stats()
     cells = st["cells"]
 

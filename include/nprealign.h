@@ -140,6 +140,18 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
                          const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
                          const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
                          const int64_t *guide_off, const int32_t *model_slot, npr_batch **out);
+/* The same with guides that carry coordinates, like the exonerate cigar line the reference pipes into cactus_realign
+ * (`cigar: query qstart qend + target tstart tend + score ops`, getExonerateCigarFormatString at
+ * nanopore/analyses/utils.py:173-186, consumed at utils.py:587): guide i starts at reference position
+ * guide_start[2*i] and read position guide_start[2*i+1] (0-based) and spans what its ops consume; the realignment is
+ * confined to that window, exactly as cactus_realign realigns only the sub-sequences a cigar covers.  Output cigars
+ * cover the window; posterior coordinates stay absolute in the sequences.  guide_start == NULL: every guide starts
+ * at (0, 0) and must be global, i.e. npr_batch_create. */
+int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                            const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                            const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                            const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
+                            npr_batch **out);
 /* Stage 2 (device): forward + backward + posterior extraction for every read of the batch; inputs are
  * resident in HBM.  Blocks until done; kernel_ms (nullable) receives the HIP-event time of the DP launch
  * measured on the context's stream.  May be called repeatedly (benchmarks). */

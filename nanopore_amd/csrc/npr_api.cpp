@@ -131,7 +131,8 @@ struct npr_batch {
     npr_params params{};
     int64_t n_reads = 0;
     // host copies needed by finish()
-    std::vector<int64_t> ref_len, read_len;
+    std::vector<int64_t> ref_len, read_len;  // spans of the guide's window
+    std::vector<int64_t> gstart;             // per read: first reference / read position of the window
     std::vector<int32_t> guide_ops;
     std::vector<int64_t> guide_off;
     std::vector<int32_t> read_status;    // planning status per read
@@ -347,6 +348,15 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
                          const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
                          const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
                          const int64_t *guide_off, const int32_t *model_slot, npr_batch **out) {
+    return npr_batch_create_at(ctx, params, n_reads, n_refs, ref, ref_off, ref_index, read, read_off, guide_ops, guide_off,
+                               nullptr, model_slot, out);
+}
+
+int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                            const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                            const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                            const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
+                            npr_batch **out) {
     if (!ctx || !params || !out || n_reads < 0 || n_refs < 0) return NPR_ERR_INVALID;
     if (!ref_index && n_refs != n_reads) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: without ref_index, n_refs must equal n_reads");
     auto ref_of = [&](int64_t i) -> int64_t { return ref_index ? ref_index[i] : i; };
@@ -361,6 +371,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     b->ref_len.resize(n_reads);
     b->read_len.resize(n_reads);
     b->read_status.assign(n_reads, NPR_OK);
+    b->gstart.assign(2 * n_reads, 0);
     b->read_first_task.assign(n_reads, 0);
     b->read_ntasks.assign(n_reads, 0);
     b->guide_off.assign(guide_off, guide_off + (n_reads ? n_reads + 1 : 0));
@@ -376,12 +387,26 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
             b->read_status[i] = NPR_ERR_INVALID;
             return;
         }
-        const int64_t lX = ref_off[k + 1] - ref_off[k], lY = read_off[i + 1] - read_off[i];
+        int64_t lX = ref_off[k + 1] - ref_off[k], lY = read_off[i + 1] - read_off[i];
+        int32_t rc = NPR_OK;
+        if (guide_start) {  // the window the guide covers
+            const int64_t gx = guide_start[2 * i], gy = guide_start[2 * i + 1];
+            int64_t sx = 0, sy = 0;
+            for (int64_t q = guide_off[i]; q < guide_off[i + 1]; ++q) {
+                const int32_t op = guide_ops[2 * q], len = guide_ops[2 * q + 1];
+                if (len < 0) rc = NPR_ERR_INVALID;
+                if (op == NPR_OP_M || op == NPR_OP_D) sx += len;
+                if (op == NPR_OP_M || op == NPR_OP_I) sy += len;
+            }
+            if (gx < 0 || gy < 0 || gx + sx > lX || gy + sy > lY) rc = NPR_ERR_INVALID;
+            b->gstart[2 * i] = gx, b->gstart[2 * i + 1] = gy;
+            lX = sx, lY = sy;
+        }
         b->ref_len[i] = lX;
         b->read_len[i] = lY;
-        int32_t rc = NPR_OK;
         const int32_t slot = model_slot ? model_slot[i] : 0;
         if (slot < 0 || slot >= NPR_MAX_MODELS || !ctx->model_set[slot]) rc = NPR_ERR_MODEL;
+        if (rc != NPR_OK) b->ref_len[i] = b->read_len[i] = 0;
         if (rc == NPR_OK) rc = build_plan(b->params, lX, lY, guide_ops + 2 * guide_off[i], guide_off[i + 1] - guide_off[i], plans[i]);
         if (rc == NPR_OK) {
             for (const Segment &s : plans[i].segs)
@@ -447,8 +472,8 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
     parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
-        const uint8_t *xsrc = ref + ref_off[ref_of(r.read)] + s.xs;
-        const uint8_t *ysrc = read + read_off[r.read] + s.ys;
+        const uint8_t *xsrc = ref + ref_off[ref_of(r.read)] + b->gstart[2 * r.read] + s.xs;
+        const uint8_t *ysrc = read + read_off[r.read] + b->gstart[2 * r.read + 1] + s.ys;
         for (int64_t q = 0; q < s.xe - s.xs; ++q) h_seq[task_x[k] + q] = encode_base(xsrc[q]);
         for (int64_t q = 0; q < s.ye - s.ys; ++q) h_seq[task_y[k] + q] = encode_base(ysrc[q]);
     });
@@ -816,7 +841,10 @@ int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32
     if (!x) return NPR_OK;
     const int64_t total = b->pair_off[b->n_reads];
     if (cap < total) return NPR_ERR_CAPACITY;
-    for (int64_t i = 0; i < total; ++i) x[i] = b->pairs[i].x, y[i] = b->pairs[i].y, p[i] = b->pairs[i].p;
+    for (int64_t r = 0; r < b->n_reads; ++r) {  // internal coordinates are relative to the guide's window
+        const int32_t gx = static_cast<int32_t>(b->gstart[2 * r]), gy = static_cast<int32_t>(b->gstart[2 * r + 1]);
+        for (int64_t i = b->pair_off[r]; i < b->pair_off[r + 1]; ++i) x[i] = b->pairs[i].x + gx, y[i] = b->pairs[i].y + gy, p[i] = b->pairs[i].p;
+    }
     return NPR_OK;
 }
 

@@ -50,16 +50,16 @@ class Batch(object):
     """A staged batch: inputs resident in HBM after construction."""
 
     def __init__(self, ctx, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None,
-                 ref_index=None):
+                 ref_index=None, guide_start=None):
         self._L = _lib.load()
         self.ctx = ctx
         self.n_reads = len(read_off) - 1
         n_refs = len(ref_off) - 1
-        self._keep = (ref, ref_off, read, read_off, guide_ops, guide_off, model_slot, ref_index)
+        self._keep = (ref, ref_off, read, read_off, guide_ops, guide_off, model_slot, ref_index, guide_start)
         h = C.c_void_p()
-        rc = self._L.npr_batch_create(ctx._h, C.byref(params), self.n_reads, n_refs, ptr(ref), ptr(ref_off),
-                                      ptr(ref_index), ptr(read), ptr(read_off), ptr(guide_ops), ptr(guide_off),
-                                      ptr(model_slot), C.byref(h))
+        rc = self._L.npr_batch_create_at(ctx._h, C.byref(params), self.n_reads, n_refs, ptr(ref), ptr(ref_off),
+                                         ptr(ref_index), ptr(read), ptr(read_off), ptr(guide_ops), ptr(guide_off),
+                                         ptr(guide_start), ptr(model_slot), C.byref(h))
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_create", ctx.last_error())
         self._h = h
@@ -181,18 +181,21 @@ class Context(object):
         if rc != _lib.OK:
             raise NprError(rc, "npr_set_hmm", self.last_error())
 
-    def stage(self, params, refs, reads, guides, model_slot=None, ref_index=None):
+    def stage(self, params, refs, reads, guides, model_slot=None, ref_index=None, guide_start=None):
         """refs/reads: lists of ASCII sequences (str/bytes); guides: list of [(op,len),...].
-        ref_index[i] = which entry of `refs` read i aligns to (None: read i <-> refs[i])."""
+        ref_index[i] = which entry of `refs` read i aligns to (None: read i <-> refs[i]).
+        guide_start[i] = (first reference position, first read position) of guide i -- the coordinates of the
+        exonerate cigar line cactus_realign reads; None: every guide is global over both sequences."""
         ref, ref_off = _csr(refs)
         read, read_off = _csr(reads)
         gops, goff = _csr_ops(guides)
         ms = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
         ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
-        return Batch(self, params, ref, ref_off, read, read_off, gops, goff, ms, ri)
+        gs = None if guide_start is None else np.ascontiguousarray(guide_start, dtype=np.int64).reshape(-1, 2)
+        return Batch(self, params, ref, ref_off, read, read_off, gops, goff, ms, ri, gs)
 
     def stage_csr(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None,
-                  ref_index=None):
+                  ref_index=None, guide_start=None):
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         read = np.ascontiguousarray(read, dtype=np.uint8)
         ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
@@ -201,10 +204,11 @@ class Context(object):
         guide_off = np.ascontiguousarray(guide_off, dtype=np.int64)
         ms = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
         ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
-        return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms, ri)
+        gs = None if guide_start is None else np.ascontiguousarray(guide_start, dtype=np.int64).reshape(-1, 2)
+        return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms, ri, gs)
 
-    def _realign_once(self, params, refs, reads, guides, model_slot, want_pairs, ref_index):
-        b = self.stage(params, refs, reads, guides, model_slot, ref_index)
+    def _realign_once(self, params, refs, reads, guides, model_slot, want_pairs, ref_index, guide_start=None):
+        b = self.stage(params, refs, reads, guides, model_slot, ref_index, guide_start)
         try:
             b.run()
             b.finish()
@@ -227,12 +231,12 @@ class Context(object):
         finally:
             b.close()
 
-    def realign(self, params, refs, reads, guides, model_slot=None, want_pairs=False, ref_index=None):
+    def realign(self, params, refs, reads, guides, model_slot=None, want_pairs=False, ref_index=None, guide_start=None):
         """One batched call: returns list of dicts (status, score, loglik, cells, ops[, x, y, p]).
 
         Reads whose sparse posterior list overflowed its capacity (NPR_ERR_CAPACITY: a diffuse model can put up to
         1/threshold pairs on a base) are re-run with a four times larger `max_pairs_per_base` until they fit."""
-        out = self._realign_once(params, refs, reads, guides, model_slot, want_pairs, ref_index)
+        out = self._realign_once(params, refs, reads, guides, model_slot, want_pairs, ref_index, guide_start)
         per_base = params.max_pairs_per_base if params.max_pairs_per_base > 0 else 6
         limit = int(1.0 / max(params.posterior_threshold, 1e-6)) + 1
         while per_base < limit:
@@ -247,7 +251,8 @@ class Context(object):
             else:
                 sub_refs, sub_index = refs, [ref_index[i] for i in again]
             sub = self._realign_once(p2, sub_refs, [reads[i] for i in again], [guides[i] for i in again],
-                                     None if model_slot is None else [model_slot[i] for i in again], want_pairs, sub_index)
+                                     None if model_slot is None else [model_slot[i] for i in again], want_pairs, sub_index,
+                                     None if guide_start is None else [guide_start[i] for i in again])
             for i, o in zip(again, sub):
                 out[i] = o
         return out

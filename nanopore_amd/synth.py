@@ -167,7 +167,7 @@ def pilot_ratio(seed, read_len, T, E, n=256):
 
 
 def make_workload(seed, n_reads, read_len, T, E, flank=0, ref_slice_len=None, genome=None, length_sigma=0.0,
-                  len_min=None, len_max=None, jitter=20, uniform_len=None):
+                  len_min=None, len_max=None, jitter=20, uniform_len=None, windowed=False):
     """Builds one synthetic batch.
 
     read_len      target read length (the reference interval the read is drawn from has this length)
@@ -178,6 +178,9 @@ def make_workload(seed, n_reads, read_len, T, E, flank=0, ref_slice_len=None, ge
                   otherwise every slice is fresh uniform-random sequence
     length_sigma  >0: interval lengths ~ lognormal(mean=read_len, sigma) clipped to [len_min, len_max]
     uniform_len   (lo, hi): interval lengths uniform in [lo, hi] (C5)
+    windowed      False: the guide is made global over the slice by leading / trailing deletions;
+                  True: the guide keeps its own span and comes with `guide_start` = (its first reference position
+                  in the slice, 0), like the coordinates of the exonerate cigar the reference hands to cactus_realign
     Returns dict with ASCII buffers + CSR offsets ready for Context.stage_csr, plus the true alignment.
     """
     rng = np.random.default_rng(seed)
@@ -228,10 +231,10 @@ def make_workload(seed, n_reads, read_len, T, E, flank=0, ref_slice_len=None, ge
         r = runs[run_off[i]:run_off[i + 1]]
         tr = true_runs[run_off[i]:run_off[i + 1]]
         parts, tparts = [], []
-        if lead[i] > 0:
+        if lead[i] > 0 and not windowed:
             parts.append(np.array([[OP_D, lead[i]]], dtype=np.int32))
         parts.append(r)
-        if trail[i] > 0:
+        if trail[i] > 0 and not windowed:
             parts.append(np.array([[OP_D, trail[i]]], dtype=np.int32))
         g = np.concatenate(parts) if parts else np.zeros((0, 2), dtype=np.int32)
         # merge adjacent equal ops created by the wrapping
@@ -246,9 +249,12 @@ def make_workload(seed, n_reads, read_len, T, E, flank=0, ref_slice_len=None, ge
         out_runs.append(g)
         out_off[i + 1] = out_off[i] + len(g)
     guide_ops = np.concatenate(out_runs) if out_runs else np.zeros((0, 2), dtype=np.int32)
+    guide_start = None
+    if windowed:
+        guide_start = np.stack([np.asarray(lead, dtype=np.int64), np.zeros(n_reads, dtype=np.int64)], axis=1)
     return dict(ref=_ASCII[ref_codes], ref_off=ref_off, read=_ASCII[read_codes], read_off=read_off,
                 guide_ops=guide_ops, guide_off=out_off, lead=lead, interval_len=ilen,
-                true_runs=true_runs, true_off=run_off)
+                true_runs=true_runs, true_off=run_off, guide_start=guide_start)
 
 
 # ---- the named configurations of BASELINE.json / BASELINE.md ----
@@ -258,9 +264,12 @@ def config_c2(T, E, n_reads=1000):
     return make_workload(1001, n_reads, 1000, T, E, flank=0), 100
 
 
-def config_north_star(T, E, n_reads=4096, seed=1003):
-    """10 kb reads x 50 kb reference slice, band 200 (BASELINE.json north_star target shape)."""
-    return make_workload(seed, n_reads, 10000, T, E, ref_slice_len=50000), 200
+def config_north_star(T, E, n_reads=4096, seed=1003, windowed=True):
+    """10 kb reads x 50 kb reference slice, band 200 (BASELINE.json north_star target shape).  The guide carries the
+    coordinates of the read's interval inside the slice (`guide_start`), as the exonerate cigar the reference pipes into
+    cactus_realign does (nanopore/analyses/utils.py:173-186,587); windowed=False instead spells the flanks out as
+    leading / trailing deletions of a guide that is global over the 50 kb."""
+    return make_workload(seed, n_reads, 10000, T, E, ref_slice_len=50000, windowed=windowed), 200
 
 
 def config_c3(T, E, n_reads=50000, genome_len=4641652, gc=0.508):

@@ -35,7 +35,7 @@ def test_north_star_shape_properties_and_oracle_sample(gpu_ctx):
     from nanopore_amd.hmm import Hmm
     from helpers import MODEL_DIR
     T, E, _ = load_model_arrays()
-    w, W = synth.config_north_star(T, E, n_reads=96)
+    w, W = synth.config_north_star(T, E, n_reads=96, windowed=False)  # flanks spelled out as 20 kb deletions
     gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
     b = gpu_ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"],
                           w["read_off"], w["guide_ops"], w["guide_off"])
@@ -61,6 +61,57 @@ def test_north_star_shape_properties_and_oracle_sample(gpu_ctx):
         assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
         order = np.lexsort((m["py"], m["px"]))
         assert np.array_equal(pp[poff[i]:poff[i + 1]], m["pp"].astype(np.float32)[order])
+
+
+def test_north_star_windowed_guides_match_explicit_slices(gpu_ctx):
+    """The bench's default shape: the guide carries the coordinates of its window inside the 50 kb slice
+    (npr_batch_create_at).  Same results as staging the windows cut out by hand; posterior coordinates absolute."""
+    from nanopore_amd import realign as R, synth
+    from nanopore_amd.hmm import Hmm
+    from helpers import MODEL_DIR
+    T, E, _ = load_model_arrays()
+    w, W = synth.config_north_star(T, E, n_reads=64)
+    gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
+    P = R.make_params(band_mode=R.BAND_FIXED, fixed_width=W)
+    b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"],
+                          guide_start=w["guide_start"])
+    assert b.stats()["kernel_variant"] == 1
+    b.run(), b.finish()
+    res, (off, ops), (poff, px, py, pp) = b.results(), b.ops(), b.pairs()
+    b.close()
+    # the same windows cut out on the host
+    lead, ilen = w["lead"], w["interval_len"]
+    cut = np.concatenate([w["ref"][w["ref_off"][i] + lead[i]:w["ref_off"][i] + lead[i] + ilen[i]] for i in range(64)])
+    cut_off = np.concatenate([[0], np.cumsum(ilen)])
+    c = gpu_ctx.stage_csr(P, cut, cut_off, w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
+    c.run(), c.finish()
+    res2, (off2, ops2), (poff2, qx, qy, qp) = c.results(), c.ops(), c.pairs()
+    c.close()
+    assert (res["status"] == 0).all() and np.array_equal(res["cells"], res2["cells"]) and res["cells"].max() < 3e6
+    assert np.array_equal(off, off2) and np.array_equal(ops, ops2) and np.array_equal(res["score"], res2["score"])
+    assert np.array_equal(poff, poff2) and np.array_equal(pp, qp) and np.array_equal(py, qy)
+    assert np.array_equal(px, qx + np.repeat(lead, np.diff(poff)).astype(np.int32))
+    # a window that sticks out of the slice is refused for that read only
+    bad = w["guide_start"].copy()
+    bad[3, 0] = 50000 - ilen[3] + 1
+    d = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"], guide_start=bad)
+    d.run(), d.finish()
+    st = d.results()["status"]
+    d.close()
+    assert st[3] != 0 and (np.delete(st, 3) == 0).all()
+    # one read against the oracle's fp32 mirror on the cut-out window
+    h = orc.make_hmm(T, E)
+    PO = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
+    i = 11
+    X = _codes(cut[cut_off[i]:cut_off[i + 1]])
+    Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
+    g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
+    m = orc.realign_read(h, PO, X, Y, g, precision=1)
+    assert m["cells"] == res["cells"][i]
+    assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
+    order = np.lexsort((m["py"], m["px"]))
+    assert np.array_equal(pp[poff[i]:poff[i + 1]], m["pp"].astype(np.float32)[order])
+    assert np.array_equal(px[poff[i]:poff[i + 1]], m["px"][order].astype(np.int32) + lead[i])
 
 
 def test_long_reads_and_per_read_type_models(gpu_ctx):

@@ -28,7 +28,16 @@ def test_workload_is_seeded_and_guides_are_global():
 
 def test_north_star_shape_has_50kb_slices():
     T, E, _ = load_model_arrays()
-    w, W = synth.config_north_star(T, E, n_reads=8)
+    w, W = synth.config_north_star(T, E, n_reads=8, windowed=False)
     assert W == 200 and ((w["ref_off"][1:] - w["ref_off"][:-1]) == 50000).all()
     g = w["guide_ops"][w["guide_off"][0]:w["guide_off"][1]]
-    assert _spans(g)[0] == 50000
+    assert _spans(g)[0] == 50000 and w["guide_start"] is None
+    # default: the guide keeps its own span and carries the coordinates of its window inside the slice
+    v, _ = synth.config_north_star(T, E, n_reads=8)
+    assert ((v["ref_off"][1:] - v["ref_off"][:-1]) == 50000).all() and np.array_equal(v["ref"], w["ref"])
+    for i in range(8):
+        g = v["guide_ops"][v["guide_off"][i]:v["guide_off"][i + 1]]
+        sx, sy = _spans(g)
+        assert sx == v["interval_len"][i] and sy == v["read_off"][i + 1] - v["read_off"][i]
+        assert v["guide_start"][i, 0] == v["lead"][i] and v["guide_start"][i, 1] == 0
+        assert v["guide_start"][i, 0] + sx <= 50000
