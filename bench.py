@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 BYTES_PER_CELL = 40.0   # fp32 forward store 5x4 B + backward-time reload 5x4 B
 # HBM bytes per cell actually moved by k_dp_stair<2>, from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the
-# gfx950 FETCH_SIZE correction of guides/MI355X_MICROARCH.md): profiles/r01_pmc_k_dp_stair2_4096x10kb_w200.csv.
+# gfx950 FETCH_SIZE correction of guides/MI355X_MICROARCH.md): profiles/r01_pmc_k_dp_stair2_5120x10kb_w200.csv.
 # Below the algorithmic 40 B by design: only the match state is stored for the backward sweep (8 B + 8 B).
 MEASURED_TRAFFIC_BYTES_PER_CELL = 16.68
 
