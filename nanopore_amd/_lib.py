@@ -80,7 +80,7 @@ class NprError(RuntimeError):
 # every symbol include/nprealign.h declares
 EXPORTS = [
     "npr_abi_version", "npr_strerror", "npr_create", "npr_destroy", "npr_last_error", "npr_set_hmm",
-    "npr_batch_create", "npr_batch_create_at", "npr_batch_run", "npr_batch_finish", "npr_batch_destroy", "npr_batch_get_stats",
+    "npr_batch_create", "npr_batch_create_at", "npr_batch_run", "npr_batch_finish", "npr_batch_destroy", "npr_batch_get_stats", "npr_batch_class_stats",
     "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_batch_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
@@ -113,6 +113,8 @@ def load():
     L.npr_set_hmm.argtypes = [vp, i32, vp, vp]
     L.npr_batch_create.restype = i32
     L.npr_batch_create.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.npr_batch_class_stats.restype = i32
+    L.npr_batch_class_stats.argtypes = [vp, vp, vp, i32]
     L.npr_batch_create_at.restype = i32
     L.npr_batch_create_at.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.npr_batch_run.restype = i32

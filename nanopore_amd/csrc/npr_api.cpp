@@ -156,17 +156,17 @@ struct npr_batch {
     int64_t slot_stride = 0;
     // One DP launch per kernel class present in the batch (tasks are grouped by class, longest first).
     struct Launch {
-        int cls;      // 0..2 register staircase kernel with 1/2/4 cells per lane; 3..5 generic kernel with an LDS ring for
+        int cls;      // index into kClassTab; (historical note) 0..2 register staircase kernel with 1/2/4 cells per lane; 3..5 generic kernel with an LDS ring for
                       // bands of at most 512 / 1024 / 2270 cells; 6 generic kernel with the ring in HBM/L2
         int first, count, grid, wcap;
         int threads;  // generic kernel: workgroup size (wavefronts per task x 64)
         size_t lds;
         int64_t cells;
+        int64_t width;  // widest anti-diagonal of the class
         int slot_base;  // first forward-scratch region of this launch
     };
     std::vector<Launch> launches;
     DevBuf<float> d_ring;
-    int64_t n_lds_tasks = 0, lds_width = 0, global_width = 0;  // tasks whose bands fit the LDS ring / widest of each kind
     bool ran = false, finished = false;
     // results
     std::vector<npr_read_result> results;
@@ -294,18 +294,18 @@ int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double 
 
 // --------------------------------------------------------------------------------------------------
 // Frame schedule of the register kernel (npr_kernel_stair.hip).  The wavefront holds a frame of C = 64*R slots of the
-// current anti-diagonal, slot j = lattice point (x0 + j, y0 - j); the frame takes an X-step (x0 += 1) into every odd
+// current anti-diagonal (times NW wavefronts for k_dp_wide), slot j = lattice point (x0 + j, y0 - j); the frame takes an X-step (x0 += 1) into every odd
 // anti-diagonal and a Y-step (y0 += 1) into every even one, so its first x-y, flo, just alternates.  The band (first
 // x-y `lo`, n cells) must stay inside the frame; when it drifts to an edge the frame is REBASED by one slot
 // (flo +- 2) between two anti-diagonals.  A rebase towards higher x-y may only precede an X-step and one towards
 // lower x-y a Y-step (the kernel re-injects the base that left the wavefront at the step before), so the decision
 // looks one anti-diagonal ahead.  Control words per anti-diagonal: row offset in the forward scratch (cells), and
-// jlo | n << 10 | (rebase + 1) << 20.  Returns false when the band cannot be followed; `ctl` and `cells` may be null.
+// jlo | n << 13 | (rebase + 1) << 26.  Returns false when the band cannot be followed; `ctl` and `cells` may be null.
 // --------------------------------------------------------------------------------------------------
 namespace {
 
-bool build_stair_schedule(const Segment &s, int R, uint32_t *ctl, int64_t *cells) {
-    const int64_t C = 64 * R, D = s.D(), span = 2 * (C - 1);
+bool build_stair_schedule(const Segment &s, int R, int NW, uint32_t *ctl, int64_t *cells) {
+    const int64_t C = 64 * R * NW, D = s.D(), span = 2 * (C - 1);
     if (s.n.empty() || s.n[0] != 1 || s.max_width >= C) return false;
     const int64_t j0 = (C - 1) / 2;
     int64_t flo = s.lo[0] - 2 * j0;  // x-y of slot 0
@@ -330,7 +330,7 @@ bool build_stair_schedule(const Segment &s, int R, uint32_t *ctl, int64_t *cells
         const int64_t l0 = jlo / R, l1 = (jlo + n + R - 1) / R;
         if (ctl) {
             ctl[2 * d] = static_cast<uint32_t>(off);
-            ctl[2 * d + 1] = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 10) | (static_cast<uint32_t>(reb + 1) << 20);
+            ctl[2 * d + 1] = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26);
         }
         off += static_cast<uint64_t>(R * (l1 - l0));
     }
@@ -338,6 +338,23 @@ bool build_stair_schedule(const Segment &s, int R, uint32_t *ctl, int64_t *cells
     return off < (uint64_t(1) << 32);
 }
 
+}  // namespace
+
+// Kernel classes of a batch, each launched on its own: the register kernel with one wavefront per task (R slots per
+// lane), the register kernel with NW wavefronts per task (k_dp_wide), the generic kernel with an LDS ring in three
+// width classes, the generic kernel with its ring in HBM.
+namespace {
+enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3 };
+struct KClass {
+    int kind, R, NW;
+    int slots() const { return 64 * R * NW; }
+};
+constexpr int kClasses = 11;
+constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STAIR, 4, 1}, {K_WIDE, 1, 8}, {K_WIDE, 1, 16},
+                                        {K_WIDE, 2, 16}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
+                                        {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}};
+constexpr int kFirstGeneric = 7, kQueueSlots = 16;
+inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE; }
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
@@ -441,13 +458,19 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     const int lds_max_w = generic_max_wcap();
     // the LDS ring is sized by the widest band of a launch and decides how many workgroups share a CU, so the
     // LDS-ring tasks are launched in three width classes
+    const char *nowide_env = std::getenv("NPR_NO_WIDE");  // "1": no multi-wavefront register kernel (A/B runs, tests)
+    const bool no_wide = nowide_env && nowide_env[0] == '1';
+    const char *cmin_env = std::getenv("NPR_CLASS_MIN");  // bring-up: smallest register class to use
+    const int cmin = cmin_env ? std::atoi(cmin_env) : 0;
     auto class_of = [&](const Segment &s) {
-        if (!force_generic && s.max_width < 256)
-            for (int c = s.max_width < 64 ? 0 : (s.max_width < 128 ? 1 : 2); c <= 2; ++c)
-                if (build_stair_schedule(s, 1 << c, nullptr, nullptr)) return c;
-        if (s.max_width <= 512) return 3;
-        if (s.max_width <= 1024) return 4;
-        return s.max_width <= lds_max_w ? 5 : 6;
+        if (!force_generic)
+            for (int c = cmin; c < kFirstGeneric; ++c) {
+                if (s.max_width >= kClassTab[c].slots() || (no_wide && kClassTab[c].kind == K_WIDE)) continue;
+                if (build_stair_schedule(s, kClassTab[c].R, kClassTab[c].NW, nullptr, nullptr)) return c;
+            }
+        if (s.max_width <= 512) return kFirstGeneric;
+        if (s.max_width <= 1024) return kFirstGeneric + 1;
+        return s.max_width <= lds_max_w ? kFirstGeneric + 2 : kFirstGeneric + 3;
     };
     std::vector<int8_t> cls_of(ntasks);
     parallel_for(ntasks, ctx->host_threads, [&](int64_t k) { cls_of[k] = static_cast<int8_t>(class_of(plans[order[k].read].segs[order[k].seg])); });
@@ -483,7 +506,6 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     std::vector<int64_t> band_base(ntasks);
     int64_t ctl_entries = 0;
     int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
-    constexpr int kClasses = 7;
     int64_t cls_count[kClasses] = {}, cls_width[kClasses] = {}, cls_cells[kClasses] = {};
     for (int64_t k = 0; k < ntasks; ++k) {
         const Ref &r = order[rank[k]];
@@ -511,7 +533,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         max_width = std::max<int64_t>(max_width, s.max_width);
         const int c = cls_of[rank[k]];
         t.ctl_off = -1;
-        if (c <= 2) {
+        if (is_register_class(c)) {
             t.ctl_off = ctl_entries;
             ctl_entries += s.D() + 1;
         }
@@ -527,7 +549,8 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
         int64_t stair_cells = 0;
-        if (b->tasks[k].ctl_off >= 0) build_stair_schedule(s, 1 << cls_of[rank[k]], h_ctl.data() + 2 * b->tasks[k].ctl_off, &stair_cells);
+        if (b->tasks[k].ctl_off >= 0)
+            build_stair_schedule(s, kClassTab[cls_of[rank[k]]].R, kClassTab[cls_of[rank[k]]].NW, h_ctl.data() + 2 * b->tasks[k].ctl_off, &stair_cells);
         uint64_t off = 0;
         for (int64_t d = 0; d <= s.D(); ++d) {
             h_lo[band_base[k] + d] = s.lo[d];
@@ -564,13 +587,21 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         L.first = static_cast<int>(first);
         L.count = static_cast<int>(cls_count[c]);
         L.cells = cls_cells[c];
+        L.width = cls_width[c];
         first += cls_count[c];
         int waves_per_cu;
-        if (c <= 2) {  // VGPR-limited: 69 / 82 / 137 registers; measured best at 7 / 5 / 3 waves per SIMD
+        if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 69 / 82 / 137 registers; measured best at 7 / 5 / 3 waves per SIMD
             waves_per_cu = c == 0 ? 28 : (c == 1 ? 20 : 12);
             L.wcap = 0;
             L.lds = stair_lds_bytes();
-        } else if (c <= 5) {
+            L.threads = 64;
+        } else if (kClassTab[c].kind == K_WIDE) {  // workgroups per CU by VGPRs: 111 (R = 2) -> 4 waves per SIMD, 168-176 (R = 4) -> 2-3
+            const int nw = kClassTab[c].NW;
+            waves_per_cu = kClassTab[c].R == 1 ? 16 / nw : 1;
+            L.wcap = 0;
+            L.lds = wide_lds_bytes(nw);
+            L.threads = 64 * nw;
+        } else if (kClassTab[c].kind == K_GENERIC_LDS) {
             // several wavefronts per task: these tasks are big, their forward scratch caps how many can be
             // resident, and one wavefront each would leave the SIMDs idle
             L.wcap = static_cast<int>((std::max<int64_t>(cls_width[c], 64) + 3) & ~int64_t(3));
@@ -587,6 +618,10 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         if (const char *w = std::getenv("NPR_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(w));
         int64_t grid = std::min<int64_t>(L.count, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
         L.grid = static_cast<int>(std::max<int64_t>(1, grid));
+        if (std::getenv("NPR_TIMING"))
+            std::fprintf(stderr, "[npr] class %d (kind %d R %d NW %d): %lld tasks, %lld cells, widest %lld, grid %d x %d threads\n", c,
+                         kClassTab[c].kind, kClassTab[c].R, kClassTab[c].NW, (long long)cls_count[c], (long long)cls_cells[c],
+                         (long long)cls_width[c], L.grid, L.threads);
         b->launches.push_back(L);
     }
     // the launches run concurrently, each on its own scratch regions: the regions of all of them must fit
@@ -601,15 +636,13 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     for (auto &L : b->launches) {
         L.slot_base = static_cast<int>(sum_grid);
         sum_grid += L.grid;
-        if (L.cls == 6) ring_floats = static_cast<int64_t>(L.grid) * 18 * L.wcap;
+        if (kClassTab[L.cls].kind == K_GENERIC_GLOBAL) ring_floats = static_cast<int64_t>(L.grid) * 18 * L.wcap;
         max_grid = std::max<int64_t>(max_grid, L.grid);
     }
     const int64_t grid = ntasks ? sum_grid : 0;
-    for (int c = 0; c < 6; ++c) b->n_lds_tasks += cls_count[c], b->lds_width = std::max(b->lds_width, cls_width[c]);
-    b->global_width = cls_width[6];
     hipError_t e;
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
-        (e = b->d_queue.alloc(8)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
+        (e = b->d_queue.alloc(kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
         (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
         (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_ctl.alloc(2 * ctl_entries)) != hipSuccess ||
         (e = b->d_px.alloc(pair_total)) != hipSuccess ||
@@ -643,7 +676,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     {   // report the class that carries most cells
         int64_t best = -1;
         for (const auto &L : b->launches)
-            if (L.cells > best) best = L.cells, b->stats.kernel_variant = L.cls <= 2 ? 1 : 0;
+            if (L.cells > best) best = L.cells, b->stats.kernel_variant = is_register_class(L.cls) ? 1 : 0;
     }
     b->stats.device_bytes = fixed + b->slot_stride * grid * 8 + ring_floats * 4;
     *out = b.release();
@@ -681,7 +714,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         b->ran = true;
         return NPR_OK;
     }
-    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * kQueueSlots, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     // all classes at once, the smallest first, each on its own stream; the main stream waits for all of them,
     // so ev0 -> ev1 brackets the whole DP pass
@@ -700,7 +733,10 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.queue += L.cls;
         a.wcap = L.wcap;
         a.slot_base = L.slot_base;
-        const int rc = L.cls <= 2 ? launch_stair(a, 1 << L.cls, L.grid, s) : launch_generic(a, L.grid, L.threads, L.lds, false, L.cls == 6, s);
+        const KClass &kc = kClassTab[L.cls];
+        const int rc = kc.kind == K_STAIR  ? launch_stair(a, kc.R, L.grid, s)
+                       : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
+                                           : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
         if (!last) HIP_TRY(ctx, hipEventRecord(ctx->side_done[i % npr_ctx::kSideStreams], s));
     }
@@ -711,6 +747,20 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     b->ran = true;
     b->finished = false;
     return NPR_OK;
+}
+
+int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap) {
+    if (!b) return NPR_ERR_INVALID;
+    for (int c = 0; c < kClasses && c < cap; ++c) {
+        if (tasks) tasks[c] = 0;
+        if (cells) cells[c] = 0;
+    }
+    for (const auto &L : b->launches)
+        if (L.cls < cap) {
+            if (tasks) tasks[L.cls] = L.count;
+            if (cells) cells[L.cls] = L.cells;
+        }
+    return kClasses;
 }
 
 int32_t npr_batch_finish(npr_batch *b) {
@@ -866,24 +916,15 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     };
     std::vector<L> launches;
     int64_t max_grid = 1;
-    if (b->n_lds_tasks) {
+    for (const auto &dl : b->launches) {  // one E-step launch per kernel class of the batch (tasks are grouped by class)
         L l{};
-        l.first = 0, l.count = static_cast<int>(b->n_lds_tasks);
-        l.wcap = static_cast<int>((std::max<int64_t>(b->lds_width, 64) + 3) & ~int64_t(3));
+        l.first = dl.first, l.count = dl.count;
+        l.wcap = static_cast<int>((std::max<int64_t>(dl.width, 64) + 3) & ~int64_t(3));
         l.lds = generic_lds_bytes(l.wcap) + em_extra_lds_bytes();
         l.global_ring = l.lds > 160 * 1024;  // the bins take 12 KiB of the LDS the ring would otherwise have
         if (l.global_ring) l.lds = generic_lds_bytes(0) + em_extra_lds_bytes();
-        const int waves = std::min<int>(12, static_cast<int>(std::max<size_t>(1, (160 * 1024) / (l.lds + 256))));
+        const int waves = l.global_ring ? 8 : std::min<int>(12, static_cast<int>(std::max<size_t>(1, (160 * 1024) / (l.lds + 256))));
         l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * waves)));
-        launches.push_back(l);
-    }
-    if (ntasks > b->n_lds_tasks) {
-        L l{};
-        l.first = static_cast<int>(b->n_lds_tasks), l.count = static_cast<int>(ntasks - b->n_lds_tasks);
-        l.wcap = static_cast<int>((b->global_width + 3) & ~int64_t(3));
-        l.lds = generic_lds_bytes(0) + em_extra_lds_bytes();
-        l.global_ring = true;
-        l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * 8)));
         launches.push_back(l);
     }
     size_t ring_floats = 0;
@@ -909,7 +950,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc", e);
     HIP_TRY(ctx, hipMemsetAsync(d_T.p, 0, d_T.bytes(), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_E.p, 0, d_E.bytes(), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * kQueueSlots, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     int qi = 0;
     for (const auto &l : launches) {
@@ -917,7 +958,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         a.tasks += l.first;
         a.outs += l.first;
         a.ntasks = l.count;
-        a.queue += qi++;
+        a.queue += qi++;  // at most kClasses launches, kQueueSlots counters
         a.wcap = l.wcap;
         a.ring = ring.p;
         a.Fx = ctx->arena_Fx;
@@ -988,7 +1029,7 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
             a.ring = ring1.p;
         }
         a.wcap = std::max(w, 64);
-        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * kQueueSlots, ctx->stream));
         const int rc = launch_generic(a, 1, 256, generic_lds_bytes(global_ring ? 0 : a.wcap), true, global_ring, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_generic<dense> launch", static_cast<hipError_t>(rc));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -42,7 +42,7 @@ struct KernelArgs {
     const int32_t *lo;
     const int32_t *n;
     const uint32_t *coff;  // per anti-diagonal: offset of its first cell inside the task (cells padded to x4)
-    const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 10 | (rebase + 1) << 20)
+    const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 13 | (rebase + 1) << 26)
     char *F;               // forward match-state scratch: one region of 8*slot_stride bytes per resident wave.  The
                            // register kernel keeps (mantissa, exponent) interleaved per cell; the generic kernel
                            // keeps a mantissa plane followed by an exponent plane.
@@ -84,6 +84,8 @@ int launch_em(const KernelArgs &a, int grid, size_t lds_bytes, bool global_ring,
 size_t em_extra_lds_bytes();
 int launch_compact(const CompactArgs &a, void *stream);
 int launch_stair(const KernelArgs &a, int R, int grid, void *stream);
+int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
+size_t wide_lds_bytes(int nw);
 size_t stair_lds_bytes();
 size_t generic_lds_bytes(int wcap);
 int generic_max_wcap();

@@ -35,6 +35,9 @@ namespace npr {
 namespace {
 
 constexpr int WAVE = 64;
+#ifndef NPR_T_SGPR_MIN_R
+#define NPR_T_SGPR_MIN_R 2  // transitions in SGPRs from this many slots per lane on (below: VGPRs)
+#endif
 constexpr int MODEL_FLOATS = sizeof(DevModel) / sizeof(float);
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -168,7 +171,7 @@ struct Ctl {
 };
 __device__ __forceinline__ Ctl read_ctl(cptr32 ctl, int d) {
     const uint32_t co = ctl[2 * d], w = ctl[2 * d + 1];
-    return Ctl{co, static_cast<int>(w & 1023u), static_cast<int>((w >> 10) & 1023u), static_cast<int>((w >> 20) & 3u) - 1};
+    return Ctl{co, static_cast<int>(w & 8191u), static_cast<int>((w >> 13) & 8191u), static_cast<int>((w >> 26) & 3u) - 1};
 }
 
 __device__ __forceinline__ uint64_t low_lanes(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
@@ -187,7 +190,9 @@ __device__ __forceinline__ Masks<R> band_masks(int jlo, int n) {
 #pragma unroll
     for (int r = 0; r < R; ++r) m.cell[r] = low_lanes((jlo + n - r + R - 1) >> SH) & ~low_lanes((jlo - r + R - 1) >> SH);
     m.l0 = jlo >> SH;
-    m.lanes = low_lanes((jlo + n + R - 1) >> SH) & ~low_lanes(m.l0);
+    m.lanes = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m.lanes |= m.cell[r];
     return m;
 }
 
@@ -231,10 +236,12 @@ __device__ __forceinline__ void dpp_down_inplace(float &v) {
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(v));
 }
 // integer registers: the vacated edge lane takes `edge` (uniform)
-__device__ __forceinline__ void dpp_up_inplace(int &v, int edge) {
+__device__ __forceinline__ void dpp_up_inplace(int &v, int edge_) {
+    const int edge = uni(edge_);
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %1, 63" : "+v"(v) : "s"(edge));
 }
-__device__ __forceinline__ void dpp_down_inplace(int &v, int edge) {
+__device__ __forceinline__ void dpp_down_inplace(int &v, int edge_) {
+    const int edge = uni(edge_);
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(edge));
 }
 
@@ -521,9 +528,6 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
             // 4.7 vs 2.7 cycles), so with one cell per lane the 15 transitions stay in VGPRs.  With more cells
             // per lane the 15 registers would cost a wave of occupancy per SIMD, which costs more: SGPRs there.
             Trans tr = load_trans(E.mdl->T);
-#ifndef NPR_T_SGPR_MIN_R
-#define NPR_T_SGPR_MIN_R 2
-#endif
             if constexpr (R >= NPR_T_SGPR_MIN_R) {
                 tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
                 tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
@@ -716,9 +720,613 @@ __global__ void __launch_bounds__(WAVE) k_dp_stair(KernelArgs a) {
     }
 }
 
+// =====================================================================================================================
+// k_dp_wide<R, NW>: the same register-resident sweep for bands too wide for one wavefront.  A workgroup of NW wavefronts
+// holds ONE frame of NW*64*R slots, wavefront w the slots [w*64R, (w+1)*64R).  What changes against k_dp_stair:
+//   * the neighbour that crosses a wavefront boundary comes through LDS: after every anti-diagonal each wavefront
+//     publishes its two edge cells (6 values each) and the workgroup takes ONE barrier; the DPP move's `old` operand
+//     (the edge lane's value) is then the neighbour wavefront's edge instead of the dead cell;
+//   * every wavefront runs its own base streams (its window of the sequences is just offset);
+//   * wavefronts whose slots have been outside the band for three anti-diagonals skip the step (they still take the
+//     barrier): the unanchored diamonds of the reference's own band (anchors +- diagonalExpansion, up to
+//     splitMatrixBiggerThanThis = 3000 cells across) alternate with 21-cell stripes, and a stripe costs one wavefront;
+//     a wavefront that the band re-enters rebuilds its streams from memory and restarts from dead cells;
+//   * posterior slots are claimed from one LDS counter (their order is restored by the host's sort).
+// Same cell arithmetic, same frame schedule, same forward-row layout: bit-identical results.
+// =====================================================================================================================
+__device__ __forceinline__ int dpp_from_above_f(float v, float edge) {
+    return __builtin_amdgcn_update_dpp(fbits(edge), fbits(v), 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_from_below_f(float v, float edge) {
+    return __builtin_amdgcn_update_dpp(fbits(edge), fbits(v), 0x138, 0xf, 0xf, false);
+}
+template <int R>
+__device__ __forceinline__ Diag<R> shift_up(const Diag<R> &in, const Cell &edge) {
+    Diag<R> o;
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) o.c[r] = in.c[r + 1];
+    o.c[R - 1].m = bitsf(dpp_from_above_f(in.c[0].m, edge.m));
+    o.c[R - 1].sx = bitsf(dpp_from_above_f(in.c[0].sx, edge.sx));
+    o.c[R - 1].sy = bitsf(dpp_from_above_f(in.c[0].sy, edge.sy));
+    o.c[R - 1].lx = bitsf(dpp_from_above_f(in.c[0].lx, edge.lx));
+    o.c[R - 1].ly = bitsf(dpp_from_above_f(in.c[0].ly, edge.ly));
+    o.c[R - 1].e = dpp_from_above(in.c[0].e, edge.e);
+    return o;
+}
+template <int R>
+__device__ __forceinline__ Diag<R> shift_down(const Diag<R> &in, const Cell &edge) {
+    Diag<R> o;
+#pragma unroll
+    for (int r = 1; r < R; ++r) o.c[r] = in.c[r - 1];
+    o.c[0].m = bitsf(dpp_from_below_f(in.c[R - 1].m, edge.m));
+    o.c[0].sx = bitsf(dpp_from_below_f(in.c[R - 1].sx, edge.sx));
+    o.c[0].sy = bitsf(dpp_from_below_f(in.c[R - 1].sy, edge.sy));
+    o.c[0].lx = bitsf(dpp_from_below_f(in.c[R - 1].lx, edge.lx));
+    o.c[0].ly = bitsf(dpp_from_below_f(in.c[R - 1].ly, edge.ly));
+    o.c[0].e = dpp_from_below(in.c[R - 1].e, edge.e);
+    return o;
+}
+// in-place one-slot moves with the neighbour wavefront's edge cell (uniform) written into the vacated lane
+__device__ __forceinline__ void dpp_up_inplace_f(float &v, float edge) {
+    const int eb = uni(fbits(edge));
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %1, 63" : "+v"(v) : "s"(eb));
+}
+__device__ __forceinline__ void dpp_down_inplace_f(float &v, float edge) {
+    const int eb = uni(fbits(edge));
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(eb));
+}
+template <int R>
+__device__ __forceinline__ void diag_up_inplace(Diag<R> &g, const Cell &edge) {
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) {
+        rot_up(g.c[r].m, g.c[r + 1].m), rot_up(g.c[r].sx, g.c[r + 1].sx), rot_up(g.c[r].sy, g.c[r + 1].sy);
+        rot_up(g.c[r].lx, g.c[r + 1].lx), rot_up(g.c[r].ly, g.c[r + 1].ly), rot_up(g.c[r].e, g.c[r + 1].e);
+    }
+    Cell &t = g.c[R - 1];
+    dpp_up_inplace_f(t.m, edge.m), dpp_up_inplace_f(t.sx, edge.sx), dpp_up_inplace_f(t.sy, edge.sy);
+    dpp_up_inplace_f(t.lx, edge.lx), dpp_up_inplace_f(t.ly, edge.ly);
+    dpp_up_inplace(t.e, uni(edge.e));
+}
+template <int R>
+__device__ __forceinline__ void diag_down_inplace(Diag<R> &g, const Cell &edge) {
+#pragma unroll
+    for (int r = R - 1; r > 0; --r) {
+        rot_up(g.c[r].m, g.c[r - 1].m), rot_up(g.c[r].sx, g.c[r - 1].sx), rot_up(g.c[r].sy, g.c[r - 1].sy);
+        rot_up(g.c[r].lx, g.c[r - 1].lx), rot_up(g.c[r].ly, g.c[r - 1].ly), rot_up(g.c[r].e, g.c[r - 1].e);
+    }
+    Cell &t = g.c[0];
+    dpp_down_inplace_f(t.m, edge.m), dpp_down_inplace_f(t.sx, edge.sx), dpp_down_inplace_f(t.sy, edge.sy);
+    dpp_down_inplace_f(t.lx, edge.lx), dpp_down_inplace_f(t.ly, edge.ly);
+    dpp_down_inplace(t.e, uni(edge.e));
+}
+
+// The edge cells of the workgroup's wavefronts in LDS: [parity of the anti-diagonal][wavefront + 1][side][8 floats];
+// rows 0 and NW + 1 stay dead (the frame's own ends).  side 0 = the wavefront's slot 0, side 1 = its top slot.
+template <int NW>
+struct Edges {
+    float *base;
+    __device__ __forceinline__ float *at(int par, int row, int side) const { return base + ((par * (NW + 2) + row) * 2 + side) * 8; }
+    __device__ __forceinline__ Cell get(int par, int row, int side) const {
+        const float4 q = *reinterpret_cast<const float4 *>(at(par, row, side));
+        const float2 g = *reinterpret_cast<const float2 *>(at(par, row, side) + 4);
+        return Cell{q.x, q.y, q.z, q.w, g.x, fbits(g.y)};
+    }
+    __device__ __forceinline__ void put(int par, int row, int side, const Cell &c) const {
+        *reinterpret_cast<float4 *>(at(par, row, side)) = make_float4(c.m, c.sx, c.sy, c.lx);
+        *reinterpret_cast<float2 *>(at(par, row, side) + 4) = make_float2(c.ly, bitsf(c.e));
+    }
+    static constexpr int floats() { return 2 * (NW + 2) * 2 * 8; }
+};
+
+// this wavefront's two edge cells of anti-diagonal `g` into LDS (lane 0 holds slot 0, lane 63 the top slot)
+template <int R, int NW>
+__device__ __forceinline__ void publish(const Edges<NW> &ed, int par, int wv, const Diag<R> &g) {
+    if (__builtin_amdgcn_inverse_ballot_w64(1ull)) ed.put(par, wv + 1, 0, g.c[0]);
+    if (__builtin_amdgcn_inverse_ballot_w64(1ull << 63)) ed.put(par, wv + 1, 1, g.c[R - 1]);
+}
+
+// band of an anti-diagonal in this wavefront's own slot numbering: [lo, lo + n) with n possibly 0
+struct LocalBand {
+    int lo, n;
+};
+template <int R>
+__device__ __forceinline__ LocalBand local_band(const Ctl &ct, int sb) {
+    const int jl = ct.jlo - sb;
+    const int lo = max(jl, 0), hi = min(jl + ct.n, 64 * R);
+    return LocalBand{hi > lo ? lo : 0, max(hi - lo, 0)};
+}
+
+template <int R>
+__device__ __forceinline__ void store_row_w(char *F, const Diag<R> &C, const Ctl &ct, const Masks<R> &mk, int voff) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc<R>(F, ct.co, ct.jlo >> SH);  // lanes numbered across the whole frame
+    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
+        if constexpr (R == 1) {
+            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), C.c[0].e}, rs, voff, 0, 0);
+        } else if constexpr (R == 2) {
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[2].m), C.c[2].e, fbits(C.c[3].m), C.c[3].e}, rs, voff + 16, 0, 0);
+        }
+    }
+}
+template <int R>
+__device__ __forceinline__ void load_row_w(char *F, FRow<R> &f, const Ctl &ct, const Masks<R> &mk, int voff) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    const __amdgpu_buffer_rsrc_t rs = row_rsrc<R>(F, ct.co, ct.jlo >> SH);
+    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
+        if constexpr (R == 1) {
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y;
+        } else if constexpr (R == 2) {
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
+        } else {
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
+            f.v[2] = bitsf(g.x), f.e[2] = g.y, f.v[3] = bitsf(g.z), f.e[3] = g.w;
+        }
+    }
+}
+
+// The three most recent bands in frame coordinates (kept current across rebases): a wavefront is ACTIVE while any of
+// them, widened by two slots, touches its slots -- then its registers may hold live cells or must receive some.
+struct Recent {
+    int lo0, hi0, lo1, hi1, lo2, hi2;
+    __device__ __forceinline__ void push(const Ctl &ct) {
+        lo2 = lo1, hi2 = hi1, lo1 = lo0, hi1 = hi0, lo0 = ct.jlo, hi0 = ct.jlo + ct.n;
+    }
+    __device__ __forceinline__ void shift(int by) { lo0 += by, hi0 += by, lo1 += by, hi1 += by, lo2 += by, hi2 += by; }
+    __device__ __forceinline__ bool touches(int sb, int width) const {
+        const int lo = min(lo0, min(lo1, lo2)) - 2, hi = max(hi0, max(hi1, hi2)) + 2;
+        return lo < sb + width && hi > sb;
+    }
+};
+
+template <int R, int NW>
+__global__ void __launch_bounds__(WAVE *NW) k_dp_wide(KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lmodel = reinterpret_cast<float *>(smem);
+    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] pair counter, [5] next task
+    const Edges<NW> ed{reinterpret_cast<float *>(lmisc + 8)};
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
+    const int sb = wv * 64 * R;  // first slot of this wavefront
+    char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
+    const int voff = 8 * R * (64 * wv + lane);
+    int jr[R];  // slot numbers across the whole frame
+#pragma unroll
+    for (int r = 0; r < R; ++r) jr[r] = sb + R * lane + r;
+
+    int t = blockIdx.x;
+    while (t < a.ntasks) {
+        const Task *tp = a.tasks + t;
+        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off),
+                      pair_off = uni64(tp->pair_off);
+        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap),
+                  flags = uni(tp->flags), model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
+        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
+        const int rs = flags & 1, re = (flags >> 1) & 1;
+
+        __syncthreads();
+        {
+            const float *gm = reinterpret_cast<const float *>(a.models + model);
+            for (int i = threadIdx.x; i < MODEL_FLOATS; i += WAVE * NW) lmodel[i] = gm[i];
+            // every edge cell dead
+            for (int i = threadIdx.x; i < Edges<NW>::floats() / 8; i += WAVE * NW) {
+                float *c = ed.base + 8 * i;
+                c[0] = c[1] = c[2] = c[3] = c[4] = 0.f, c[5] = bitsf(E_DEAD), c[6] = c[7] = 0.f;
+            }
+            if (threadIdx.x == 0) lmisc[0] = 0, lmisc[1] = E_DEAD, lmisc[2] = 0, lmisc[3] = E_DEAD, lmisc[4] = 0;
+        }
+        __syncthreads();
+        StepEnv E;
+        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
+        E.ltab = reinterpret_cast<const char *>(lmodel);
+        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
+        {
+            Trans tr = load_trans(E.mdl->T);
+            if constexpr (R >= NPR_T_SGPR_MIN_R) {
+                tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
+                tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
+                tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
+                tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
+            }
+            E.tr = tr;
+        }
+        const DevModel *mdl = E.mdl;
+
+        // (re)build this wavefront's streams for the frame at (x0, y0); OFF = -1: forward sweep (X[x-1], Y[y-1] per
+        // slot), 0: backward sweep (X[x], Y[y]).  The captured bases are what sits just outside the wavefront.
+        Streams<R> S;
+        auto fwd_streams = [&](int x0, int y0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                S.X.b[r] = base4(E.X, lX, x0 + jr[r] - 1);
+                S.Y.b[r] = base4(E.Y, lY, y0 - jr[r] - 1);
+            }
+            feed_init<+1>(S.fx, E.X, lX, x0 + sb + 64 * R - 1, lane);
+            feed_init<+1>(S.fy, E.Y, lY, y0 - sb, lane);
+            S.xcap = uni(base4(E.X, lX, x0 + sb - 2));
+            S.ycap = uni(base4(E.Y, lY, y0 - sb - 64 * R - 1));
+        };
+        auto bwd_streams = [&](int x0, int y0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                S.X.b[r] = base4(E.X, lX, x0 + jr[r]);
+                S.Y.b[r] = base4(E.Y, lY, y0 - jr[r]);
+            }
+            feed_init<-1>(S.fx, E.X, lX, x0 + sb - 1, lane);
+            feed_init<-1>(S.fy, E.Y, lY, y0 - sb - 64 * R, lane);
+            S.xcap = uni(base4(E.X, lX, x0 + sb + 64 * R));
+            S.ycap = uni(base4(E.Y, lY, y0 - sb + 1));
+        };
+
+        // =============================== forward ===============================
+        Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
+        const Ctl c0 = read_ctl(ctl, 0);
+        const int j0 = c0.jlo;
+        int x0 = -j0, y0 = j0;
+        Recent rec{c0.jlo, c0.jlo + c0.n, c0.jlo, c0.jlo + c0.n, c0.jlo, c0.jlo + c0.n};
+        bool live = rec.touches(sb, 64 * R);  // this wavefront's registers / streams are current
+        if (live) fwd_streams(x0, y0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (jr[r] == j0) {
+                Cell c;
+                c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
+                c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
+                normalise(c, 0);
+                A.c[r] = c;
+            }
+        {
+            const LocalBand lb = local_band<R>(c0, sb);
+            store_row_w<R>(F, A, c0, band_masks<R>(lb.lo, lb.n), voff);
+            if (live) publish<R, NW>(ed, 0, wv, A);
+        }
+        __syncthreads();
+
+        // one forward step into anti-diagonal d (X-step when d is odd): `io` holds d-2 / d, `p1` holds d-1
+        auto fwd = [&](int d, Diag<R> &io, Diag<R> &p1, const Ctl &ct) {
+            const int par = d & 1;
+            if (ct.reb) {  // uniform over the workgroup
+                if (live) {
+                    if (ct.reb > 0) {
+                        diag_up_inplace<R>(A, ed.get(0, wv + 2, 0)), diag_up_inplace<R>(B, ed.get(1, wv + 2, 0));
+                    } else {
+                        diag_down_inplace<R>(A, ed.get(0, wv, 1)), diag_down_inplace<R>(B, ed.get(1, wv, 1));
+                    }
+                }
+                x0 += ct.reb, y0 -= ct.reb;
+                rec.shift(-ct.reb);
+                if (live) {
+                    if (ct.reb > 0) {
+                        bases_up_inplace<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + sb + 64 * R - 2, lane));
+                        bases_up_inplace<R>(S.Y, S.ycap);
+                    } else {
+                        bases_down_inplace<R>(S.X, S.xcap);
+                        bases_down_inplace<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 - sb - 1, lane));
+                    }
+                }
+                __syncthreads();  // everybody has read the old edges
+                if (live) publish<R, NW>(ed, 0, wv, A), publish<R, NW>(ed, 1, wv, B);
+                __syncthreads();
+            }
+            rec.push(ct);
+            const bool act = rec.touches(sb, 64 * R);
+            if (act) {
+                if (!live) {  // the band has come back into this wavefront: restart from dead cells
+                    A = dead_diag<R>(), B = dead_diag<R>();
+                    fwd_streams(x0, y0);
+                }
+                const LocalBand lb = local_band<R>(ct, sb);
+                const Masks<R> mk = band_masks<R>(lb.lo, lb.n);
+                if (par) {
+                    S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
+                    bases_up<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + 1 + sb + 64 * R - 2, lane));
+                    const Diag<R> U = shift_up<R>(p1, ed.get(par ^ 1, wv + 2, 0));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float em, exs, exl, eys, eyl;
+                        emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+                        Cell c = fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
+                        kill_outside(c, mk.cell[r]);
+                        io.c[r] = c;
+                    }
+                } else {
+                    S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
+                    bases_down<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 + 1 - sb - 1, lane));
+                    const Diag<R> L = shift_down<R>(p1, ed.get(par ^ 1, wv, 1));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float em, exs, exl, eys, eyl;
+                        emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+                        Cell c = fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
+                        kill_outside(c, mk.cell[r]);
+                        io.c[r] = c;
+                    }
+                }
+                store_row_w<R>(F, io, ct, mk, voff);
+                publish<R, NW>(ed, par, wv, io);
+            }
+            live = act;
+            if (par) x0 += 1; else y0 += 1;
+            __syncthreads();
+        };
+
+        Ctl nx = c0;
+        if (D >= 1) nx = read_ctl(ctl, 1);
+        int d = 1;
+        for (; d + 1 <= D; d += 2) {
+            Ctl cur = nx;
+            nx = read_ctl(ctl, d + 1);
+            fwd(d, B, A, cur);
+            cur = nx;
+            if (d + 2 <= D) nx = read_ctl(ctl, d + 2);
+            fwd(d + 1, A, B, cur);
+        }
+        if (d <= D) fwd(d, B, A, nx);
+
+        // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
+        {
+            const int je = lX - x0;
+            const bool oddD = D & 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (live && jr[r] == je) {
+                    const Cell c = oddD ? B.c[r] : A.c[r];
+                    const float raw = dot5(mdl->end + re * 5, c);
+                    if (raw > 0.f) {
+                        int k;
+                        reinterpret_cast<float *>(lmisc)[0] = __builtin_frexpf(raw, &k);
+                        lmisc[1] = c.e + k;
+                    }
+                }
+        }
+        __syncthreads();
+        const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
+        const int tot_e = uni(lmisc[1]);
+
+        TaskOut out;
+        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
+        out.status = NPR_OK;
+        const bool alive = tot_m > 0.f;
+        if (!alive) out.status = NPR_ERR_ZERO_PROB;
+
+        // =============================== backward + posteriors ===============================
+        if (alive) {
+            const float inv_tot = 1.0f / tot_m;
+            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            __syncthreads();
+            for (int i = threadIdx.x; i < Edges<NW>::floats() / 8; i += WAVE * NW) {
+                float *c = ed.base + 8 * i;
+                c[0] = c[1] = c[2] = c[3] = c[4] = 0.f, c[5] = bitsf(E_DEAD);
+            }
+            __syncthreads();
+            A = dead_diag<R>(), B = dead_diag<R>();
+            const bool oddD = D & 1;
+            Ctl cur = read_ctl(ctl, D);
+            rec = Recent{cur.jlo, cur.jlo + cur.n, cur.jlo, cur.jlo + cur.n, cur.jlo, cur.jlo + cur.n};
+            live = rec.touches(sb, 64 * R);
+            if (live) bwd_streams(x0, y0);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (x0 + jr[r] == lX) {
+                    Cell c;
+                    c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
+                    c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
+                    normalise(c, 0);
+                    if (oddD) B.c[r] = c; else A.c[r] = c;
+                }
+            if (live) publish<R, NW>(ed, D & 1, wv, oddD ? B : A);
+            FRow<R> fa, fb;  // forward rows of the even / odd anti-diagonals, loaded one ahead
+#pragma unroll
+            for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
+            auto load = [&](FRow<R> &f, const Ctl &ct) {
+                const LocalBand lb = local_band<R>(ct, sb);
+                load_row_w<R>(F, f, ct, band_masks<R>(lb.lo, lb.n), voff);
+            };
+            // posteriors of anti-diagonal dd (frame at x0, y0), slots claimed from the workgroup's LDS counter
+            auto emit = [&](const Diag<R> &Bd, const FRow<R> &f, int dd, const Ctl &ct) {
+                const LocalBand lb = local_band<R>(ct, sb);
+                const Masks<R> mk = band_masks<R>(lb.lo, lb.n);
+                float p[R];
+                uint64_t hit[R];
+                int total = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    p[r] = posterior(f.v[r], f.e[r], Bd.c[r].m, Bd.c[r].e, tot_e, inv_tot);
+                    hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
+                    total += __popcll(hit[r]);
+                }
+                if (dd >= 2 && total) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(lmisc + 4, total);
+                    base = uni(base);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (hit[r]) {
+                            const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                            const int slot = base + before;
+                            if (__builtin_amdgcn_inverse_ballot_w64(hit[r]) && slot < sink.cap) {
+                                sink.px[sink.off + slot] = x0 + jr[r] - 1 + sink.xs;
+                                sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
+                                sink.pp[sink.off + slot] = p[r];
+                            }
+                            base += __popcll(hit[r]);
+                        }
+                    }
+                }
+            };
+            Ctl nxt = cur;
+            if (oddD) {
+                load(fb, cur);
+                nxt = read_ctl(ctl, D - 1);
+                load(fa, nxt);
+                emit(B, fb, D, cur);
+            } else {
+                load(fa, cur);
+                if (D >= 1) {
+                    nxt = read_ctl(ctl, D - 1);
+                    load(fb, nxt);
+                }
+                emit(A, fa, D, cur);
+            }
+            __syncthreads();
+
+            // one backward step into anti-diagonal dd: undoes the rebase `reb` made before the forward step into dd + 1,
+            // then that step (an X-step when dd is even)
+            auto bwd = [&](int dd, Diag<R> &io, Diag<R> &s1, const Ctl &ct, int reb) {
+                const int par = dd & 1;
+                if (reb) {
+                    if (live) {
+                        if (reb > 0) {
+                            diag_down_inplace<R>(A, ed.get(0, wv, 1)), diag_down_inplace<R>(B, ed.get(1, wv, 1));
+                        } else {
+                            diag_up_inplace<R>(A, ed.get(0, wv + 2, 0)), diag_up_inplace<R>(B, ed.get(1, wv + 2, 0));
+                        }
+                    }
+                    x0 -= reb, y0 += reb;
+                    rec.shift(reb);
+                    if (live) {
+                        if (reb > 0) {
+                            bases_down_inplace<R>(S.X, feed_get<-1>(S.fx, E.X, E.lX, x0 + sb, lane));
+                            bases_down_inplace<R>(S.Y, S.ycap);
+                        } else {
+                            bases_up_inplace<R>(S.X, S.xcap);
+                            bases_up_inplace<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - sb - (64 * R - 1), lane));
+                        }
+                    }
+                    __syncthreads();
+                    if (live) publish<R, NW>(ed, 0, wv, A), publish<R, NW>(ed, 1, wv, B);
+                    __syncthreads();
+                }
+                rec.push(ct);
+                const bool act = rec.touches(sb, 64 * R);
+                if (par) y0 -= 1; else x0 -= 1;  // the frame of dd
+                if (act) {
+                    if (!live) {
+                        A = dead_diag<R>(), B = dead_diag<R>();
+                        bwd_streams(x0 + (par ? 0 : 1), y0 + (par ? 1 : 0));  // the frame before this step is undone
+                    }
+                    const LocalBand lb = local_band<R>(ct, sb);
+                    const Masks<R> mk = band_masks<R>(lb.lo, lb.n);
+                    if (!par) {  // undo the X-step into dd + 1
+                        S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
+                        bases_down<R>(S.X, feed_get<-1>(S.fx, E.X, E.lX, x0 + sb, lane));
+                        const Diag<R> Ys = shift_down<R>(s1, ed.get(par ^ 1, wv, 1));
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            float em, exs, exl, eys, eyl;
+                            emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+                            Cell c = bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
+                            kill_outside(c, mk.cell[r]);
+                            io.c[r] = c;
+                        }
+                    } else {  // undo the Y-step into dd + 1
+                        S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
+                        bases_up<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - sb - (64 * R - 1), lane));
+                        const Diag<R> Xs = shift_up<R>(s1, ed.get(par ^ 1, wv + 2, 0));
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            float em, exs, exl, eys, eyl;
+                            emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
+                            Cell c = bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
+                            kill_outside(c, mk.cell[r]);
+                            io.c[r] = c;
+                        }
+                    }
+                    publish<R, NW>(ed, par, wv, io);
+                }
+                live = act;
+            };
+
+            int d2 = D - 1;
+            if (oddD) {
+                const int reb = cur.reb;
+                cur = nxt;
+                if (d2 >= 1) {
+                    nxt = read_ctl(ctl, d2 - 1);
+                    load(fb, nxt);
+                }
+                bwd(d2, A, B, cur, reb);
+                emit(A, fa, d2, cur);
+                __syncthreads();
+                d2 -= 1;
+            }
+            for (; d2 >= 1; d2 -= 2) {
+                int reb = cur.reb;
+                cur = nxt;
+                nxt = read_ctl(ctl, d2 - 1);
+                load(fa, nxt);
+                bwd(d2, B, A, cur, reb);
+                emit(B, fb, d2, cur);
+                __syncthreads();
+                reb = cur.reb;
+                cur = nxt;
+                if (d2 >= 2) {
+                    nxt = read_ctl(ctl, d2 - 2);
+                    load(fb, nxt);
+                }
+                bwd(d2 - 1, A, B, cur, reb);
+                emit(A, fa, d2 - 1, cur);
+                __syncthreads();
+            }
+            // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (live && jr[r] == j0) {
+                    const Cell cz = A.c[r];
+                    const float raw = dot5(mdl->start + rs * 5, cz);
+                    if (raw > 0.f) {
+                        int k;
+                        reinterpret_cast<float *>(lmisc)[2] = __builtin_frexpf(raw, &k);
+                        lmisc[3] = cz.e + k;
+                    }
+                }
+            __syncthreads();
+            out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
+            out.btot_e = uni(lmisc[3]);
+        }
+        if (threadIdx.x == 0) {
+            const int cnt = lmisc[4];
+            out.npairs = cnt;
+            if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
+            a.outs[t] = out;
+            lmisc[5] = atomicAdd(a.queue, 1);
+        }
+        __syncthreads();
+        t = uni(lmisc[5]) + static_cast<int>(gridDim.x);
+    }
+}
+
 }  // namespace
 
 size_t stair_lds_bytes() { return sizeof(float) * (MODEL_FLOATS + 8); }
+
+size_t wide_lds_bytes(int nw) { return sizeof(float) * (MODEL_FLOATS + 8 + 2 * (nw + 2) * 2 * 8); }
+
+// (R, NW) pairs built: few slots per lane and many wavefronts -- a task's anti-diagonals are only as wide as its
+// diamonds are at that point, the wavefronts outside the band idle, and what bounds a step is one wavefront's latency
+int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = wide_lds_bytes(NW);
+    if (R == 1 && NW == 8)
+        hipLaunchKernelGGL((k_dp_wide<1, 8>), dim3(grid), dim3(WAVE * 8), lds, s, a);
+    else if (R == 1 && NW == 16)
+        hipLaunchKernelGGL((k_dp_wide<1, 16>), dim3(grid), dim3(WAVE * 16), lds, s, a);
+    else if (R == 2 && NW == 16)
+        hipLaunchKernelGGL((k_dp_wide<2, 16>), dim3(grid), dim3(WAVE * 16), lds, s, a);
+    else if (R == 4 && NW == 12)
+        hipLaunchKernelGGL((k_dp_wide<4, 12>), dim3(grid), dim3(WAVE * 12), lds, s, a);
+    else
+        return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipGetLastError());
+}
 
 int launch_stair(const KernelArgs &a, int R, int grid, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -64,6 +64,13 @@ class Batch(object):
             raise NprError(rc, "npr_batch_create", ctx.last_error())
         self._h = h
 
+    def class_stats(self):
+        """(tasks, cells) per kernel class (include/nprealign.h: npr_batch_class_stats)."""
+        t = np.zeros(16, dtype=np.int64)
+        c = np.zeros(16, dtype=np.int64)
+        k = self._L.npr_batch_class_stats(self._h, ptr(t), ptr(c), 16)
+        return t[:k], c[:k]
+
     def stats(self):
         st = _lib.BatchStats()
         self._L.npr_batch_get_stats(self._h, C.byref(st))

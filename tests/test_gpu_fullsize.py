@@ -114,6 +114,54 @@ def test_north_star_windowed_guides_match_explicit_slices(gpu_ctx):
     assert np.array_equal(px[poff[i]:poff[i + 1]], m["px"][order].astype(np.int32) + lead[i])
 
 
+def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
+    """The reference's own band (anchors +- diagonalExpansion 10, trim 14, splitMatrixBiggerThanThis 3000,
+    nanopore/analyses/utils.py:587) on reads from the shipped nanopore model: few anchors survive the trimming, the
+    bands are diamonds hundreds to thousands of cells wide, and the multi-wavefront register kernel (k_dp_wide) takes
+    them.  Its results must be the generic kernel's bit for bit, and the fp32 mirror's."""
+    from nanopore_amd import realign as R, synth
+    from nanopore_amd.hmm import Hmm
+    from helpers import MODEL_DIR
+    T, E, _ = load_model_arrays()
+    w = synth.make_workload(1007, 48, 3000, T, E, flank=0, length_sigma=0.5, len_min=300, len_max=9000)
+    gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
+    P = R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)
+
+    def run():
+        b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
+        tasks, cells = b.class_stats()
+        b.run(), b.finish()
+        out = (b.results(), b.ops(), b.pairs(), tasks, cells, b.stats()["max_width"])
+        b.close()
+        return out
+
+    res, (off, ops), (poff, px, py, pp), tasks, cells, maxw = run()
+    assert (res["status"] == 0).all() and maxw > 1024
+    assert tasks[3:7].sum() > 0.5 * tasks.sum() and cells[3:7].sum() > 0.9 * cells.sum()   # k_dp_wide did the work
+    assert (tasks[3:7] > 0).sum() >= 3                                                      # in several frame sizes
+    monkeypatch.setenv("NPR_NO_WIDE", "1")
+    res2, (off2, ops2), (poff2, qx, qy, qp), tasks2, _, _ = run()
+    assert tasks2[3:7].sum() == 0 and tasks2[7:].sum() == tasks[3:].sum()
+    assert np.array_equal(res["cells"], res2["cells"]) and np.array_equal(res["loglik"], res2["loglik"])
+    assert np.array_equal(res["loglik_bwd"], res2["loglik_bwd"]) and np.array_equal(res["score"], res2["score"])
+    assert np.array_equal(off, off2) and np.array_equal(ops, ops2)
+    assert np.array_equal(poff, poff2) and np.array_equal(px, qx) and np.array_equal(py, qy) and np.array_equal(pp, qp)
+    assert np.abs(res["loglik"] - res["loglik_bwd"]).max() < 1e-2
+    # two reads against the oracle's fp32 mirror
+    h = orc.make_hmm(T, E)
+    PO = orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)
+    order_by_cells = np.argsort(res["cells"])
+    for i in (int(order_by_cells[len(order_by_cells) // 2]), int(order_by_cells[5])):
+        X = _codes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]])
+        Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
+        g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
+        m = orc.realign_read(h, PO, X, Y, g, precision=1)
+        assert m["cells"] == res["cells"][i]
+        assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
+        order = np.lexsort((m["py"], m["px"]))
+        assert np.array_equal(pp[poff[i]:poff[i + 1]], m["pp"].astype(np.float32)[order])
+
+
 def test_long_reads_and_per_read_type_models(gpu_ctx):
     """Config 5 in miniature: 10-50 kb reads, three read types with their own HMM slot (hmm_0 / 20 / 40)."""
     from nanopore_amd import realign as R, synth
