@@ -164,7 +164,7 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
 /* Diagnostics: how the batch's DP problems (segments) were spread over the kernel classes.  tasks[c] / cells[c] for
  * class c (either may be NULL), capacity `cap` entries; returns the number of classes (11):
  *   0-2  register kernel, one wavefront per task, 64 / 128 / 256 slots (k_dp_stair<1|2|4>)
- *   3-6  register kernel, 8-16 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
+ *   3-6  register kernel, 4 / 8 / 16 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
  *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* results, valid after npr_batch_finish */

@@ -1310,15 +1310,18 @@ size_t stair_lds_bytes() { return sizeof(float) * (MODEL_FLOATS + 8); }
 
 size_t wide_lds_bytes(int nw) { return sizeof(float) * (MODEL_FLOATS + 8 + 2 * (nw + 2) * 2 * 8); }
 
-// (R, NW) pairs built: few slots per lane and many wavefronts -- a task's anti-diagonals are only as wide as its
-// diamonds are at that point, the wavefronts outside the band idle, and what bounds a step is one wavefront's latency
+// (R, NW) pairs built: 2x4 = 512 slots, 2x8 = 1024, 2x16 = 2048, 4x12 = 3072.  What bounds a step is ONE wavefront's
+// latency (LDS edge read -> DPP -> ~50 dependent VALU ops -> publish -> barrier), so a wavefront should carry enough
+// slots to amortise it (one slot per lane: 6e10 cells/s on constant 400-800-cell bands, two: 1.1-1.3e11) but not so many
+// that a band narrower than the frame leaves most of the workgroup idle (2048 slots as 4x8: 5.3e10 cells/s on the
+// reference's anchor diamonds, as 2x16: 6.1e10).
 int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = wide_lds_bytes(NW);
-    if (R == 1 && NW == 8)
-        hipLaunchKernelGGL((k_dp_wide<1, 8>), dim3(grid), dim3(WAVE * 8), lds, s, a);
-    else if (R == 1 && NW == 16)
-        hipLaunchKernelGGL((k_dp_wide<1, 16>), dim3(grid), dim3(WAVE * 16), lds, s, a);
+    if (R == 2 && NW == 4)
+        hipLaunchKernelGGL((k_dp_wide<2, 4>), dim3(grid), dim3(WAVE * 4), lds, s, a);
+    else if (R == 2 && NW == 8)
+        hipLaunchKernelGGL((k_dp_wide<2, 8>), dim3(grid), dim3(WAVE * 8), lds, s, a);
     else if (R == 2 && NW == 16)
         hipLaunchKernelGGL((k_dp_wide<2, 16>), dim3(grid), dim3(WAVE * 16), lds, s, a);
     else if (R == 4 && NW == 12)
