@@ -55,12 +55,28 @@ def build_workload(name, n_reads, rank):
     return h, w, W, label
 
 
+def usable_cpus():
+    """CPUs this process may use: os.cpu_count() capped by the scheduler affinity and the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
     """The build's fp64 log-space CPU oracle (kind "port": the reference binary cactus_realign is absent from
     the snapshot) timed on this host's cores over a bounded sample of the same workload."""
     from oracle import oracle as orc
     from nanopore_amd.realign import encode
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     oh = orc.make_hmm(h.transitions, h.emissions)
     P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
 
@@ -90,8 +106,9 @@ def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
         r, dt = run(k)
     cells = int(r["cells"].sum())
     return {"value": cells / dt, "unit": "cells/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the same batch (%d cells), fp64 log-space oracle, OpenMP over reads, "
-                      "gcc -O3 -march=native, %.1f s" % (k, cells, dt)}, r
+            "sample": "first %d reads of the same batch (%d cells), fp64 log-space oracle, OpenMP over reads on %d threads "
+                      "(os.cpu_count() %d, capped by the cgroup CPU quota), gcc -O3 -march=native, %.1f s"
+                      % (k, cells, cores, os.cpu_count() or 1, dt)}, r
 
 
 def main():

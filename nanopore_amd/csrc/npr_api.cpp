@@ -50,6 +50,10 @@ struct npr_ctx {
     size_t arena_cells = 0;
     float *arena_Fx = nullptr;  // E-step only: four more forward planes
     size_t arena_fx_cells = 0;
+    // pinned host staging for the posterior triples of npr_batch_finish (grow-only): a pageable destination halves
+    // the D2H rate and the copy is a GB per batch
+    void *pin_pairs = nullptr;
+    size_t pin_pairs_bytes = 0;
 };
 
 namespace {
@@ -103,6 +107,23 @@ struct StageTimer {
         t0 = t1;
     }
 };
+
+// CPUs this process may actually use: the hardware count capped by the cgroup CPU quota (a container on a 256-core
+// host is often limited to a few cores; running 256 threads inside such a quota is slower than running 16)
+int usable_cpus() {
+    int n = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            const long long q = std::atoll(quota);
+            if (q > 0) n = std::min<int>(n, static_cast<int>(std::max<long long>(1, (q + period - 1) / period)));
+        }
+        std::fclose(f);
+    }
+    if (const char *e = std::getenv("NPR_HOST_THREADS")) n = std::max(1, std::atoi(e));
+    return n;
+}
 
 template <typename F>
 void parallel_for(int64_t n, int threads, F f) {
@@ -235,7 +256,7 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount;
     ctx->total_mem = prop.totalGlobalMem;
-    ctx->host_threads = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+    ctx->host_threads = usable_cpus();
     for (int i = 0; i < npr_ctx::kSideStreams; ++i)
         if ((e = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->side_done[i], hipEventDisableTiming)) != hipSuccess) {
@@ -259,6 +280,7 @@ void npr_destroy(npr_ctx *ctx) {
     if (ctx->d_models) (void)hipFree(ctx->d_models);
     if (ctx->arena_F) (void)hipFree(ctx->arena_F);
     if (ctx->arena_Fx) (void)hipFree(ctx->arena_Fx);
+    if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -771,8 +793,8 @@ int32_t npr_batch_finish(npr_batch *b) {
     StageTimer tm("batch_finish");
     const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
     std::vector<int64_t> dst(ntasks + 1, 0);
-    std::vector<int32_t> hx, hy;
-    std::vector<float> hp;
+    const int32_t *hx = nullptr, *hy = nullptr;
+    const float *hp = nullptr;
     if (ntasks) {
         HIP_TRY(ctx, hipMemcpy(b->outs.data(), b->d_outs.p, b->d_outs.bytes(), hipMemcpyDeviceToHost));
         for (int64_t k = 0; k < ntasks; ++k) dst[k + 1] = dst[k] + std::min(b->outs[k].npairs, b->tasks[k].pair_cap);
@@ -789,10 +811,20 @@ int32_t npr_batch_finish(npr_batch *b) {
             CompactArgs ca{b->d_tasks.p, b->d_outs.p, d_dst.p, static_cast<int32_t>(ntasks), b->d_px.p, b->d_py.p, b->d_pp.p, d_cx.p, d_cy.p, d_cp.p};
             const int rc = launch_compact(ca, ctx->stream);
             if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_compact launch", static_cast<hipError_t>(rc));
-            hx.resize(total), hy.resize(total), hp.resize(total);
-            HIP_TRY(ctx, hipMemcpyAsync(hx.data(), d_cx.p, d_cx.bytes(), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(hy.data(), d_cy.p, d_cy.bytes(), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(hp.data(), d_cp.p, d_cp.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+            const size_t need = static_cast<size_t>(total) * 12;
+            if (need > ctx->pin_pairs_bytes) {
+                if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
+                ctx->pin_pairs = nullptr, ctx->pin_pairs_bytes = 0;
+                if ((e = hipHostMalloc(&ctx->pin_pairs, need + need / 4, hipHostMallocDefault)) != hipSuccess)
+                    return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipHostMalloc", e);
+                ctx->pin_pairs_bytes = need + need / 4;
+            }
+            int32_t *px_h = static_cast<int32_t *>(ctx->pin_pairs), *py_h = px_h + total;
+            float *pp_h = reinterpret_cast<float *>(py_h + total);
+            HIP_TRY(ctx, hipMemcpyAsync(px_h, d_cx.p, d_cx.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(py_h, d_cy.p, d_cy.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(pp_h, d_cp.p, d_cp.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+            hx = px_h, hy = py_h, hp = pp_h;
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }

@@ -199,7 +199,7 @@ struct Best {
 
 class PrefixMax {
   public:
-    explicit PrefixMax(int64_t size) : t_(size + 2) {}
+    PrefixMax(std::vector<Best> &store, int64_t size) : t_(store) { t_.assign(size + 2, Best{}); }
     Best query(int64_t upto_exclusive) const {  // best over keys < upto_exclusive
         Best b;
         for (int64_t i = upto_exclusive; i > 0; i &= i - 1)
@@ -212,7 +212,7 @@ class PrefixMax {
     }
 
   private:
-    std::vector<Best> t_;
+    std::vector<Best> &t_;  // caller-owned storage, reused from read to read
 };
 
 void push_op(std::vector<int32_t> &ops, size_t first, int32_t op, int64_t len) {
@@ -232,7 +232,16 @@ int32_t mea_cigar(int64_t lX, int64_t lY, const Pair *pairs, int64_t n, double g
     // Gap mass of a row (reference base) / column (read base) = 1 - sum of the match posteriors on it.  Rows are
     // summed by scanning the (x,y)-sorted list, columns in an array over the read positions the pairs touch:
     // nothing here is sized by the reference length (a chained record spans a whole contig, utils.py:381).
-    std::vector<int64_t> q(n), rowsum(n);
+    // scratch is kept per host thread and only grows: with hundreds of worker threads, eight fresh 100 KB+ vectors
+    // per read turn into mmap / munmap traffic that serialises them in the kernel
+    struct Cand {
+        int32_t x, y;
+        int64_t q, w;
+    };
+    thread_local std::vector<int64_t> q, rowsum, colsum, total, back, path;
+    thread_local std::vector<Cand> c;
+    thread_local std::vector<Best> tree_store;
+    q.assign(n, 0), rowsum.assign(n, 0);
     int32_t ymin = 0, ymax = -1;
     for (int64_t i = 0; i < n; ++i) {
         if (pairs[i].x < 0 || pairs[i].x >= lX || pairs[i].y < 0 || pairs[i].y >= lY) return NPR_ERR_INVALID;
@@ -246,14 +255,10 @@ int32_t mea_cigar(int64_t lX, int64_t lY, const Pair *pairs, int64_t n, double g
         for (int64_t i = g; i < h; ++i) rowsum[i] = sum;
         g = h;
     }
-    std::vector<int64_t> colsum(n ? ymax - ymin + 1 : 0, 0);
+    colsum.assign(n ? ymax - ymin + 1 : 0, 0);
     for (int64_t i = 0; i < n; ++i) colsum[pairs[i].y - ymin] += q[i];
     const int64_t floor_w = static_cast<int64_t>(std::floor(match_gamma * static_cast<double>(PROB_ONE)));
-    struct Cand {
-        int32_t x, y;
-        int64_t q, w;
-    };
-    std::vector<Cand> c;
+    c.clear();
     c.reserve(n);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t gap = std::max<int64_t>(PROB_ONE - rowsum[i], 0) + std::max<int64_t>(PROB_ONE - colsum[pairs[i].y - ymin], 0);
@@ -262,8 +267,8 @@ int32_t mea_cigar(int64_t lX, int64_t lY, const Pair *pairs, int64_t n, double g
     }
     // input is sorted by (x,y); filtering keeps the order
     const int64_t m = static_cast<int64_t>(c.size());
-    std::vector<int64_t> total(m), back(m);
-    PrefixMax tree(n ? ymax - ymin + 1 : 0);  // keyed by y - ymin
+    total.assign(m, 0), back.assign(m, 0);
+    PrefixMax tree(tree_store, n ? ymax - ymin + 1 : 0);  // keyed by y - ymin
     Best overall;
     for (int64_t g = 0; g < m;) {
         int64_t h = g;
@@ -280,7 +285,7 @@ int32_t mea_cigar(int64_t lX, int64_t lY, const Pair *pairs, int64_t n, double g
         }
         g = h;
     }
-    std::vector<int64_t> path;
+    path.clear();
     for (int64_t i = overall.who; i >= 0; i = back[i]) path.push_back(i);
     std::reverse(path.begin(), path.end());
 
