@@ -861,7 +861,41 @@ int32_t npr_batch_finish(npr_batch *b) {
             if (o.btot_m > 0.f) r.loglik_bwd += (std::log2(static_cast<double>(o.btot_m)) + o.btot_e) * LN2;
             for (int64_t q = dst[k]; q < dst[k + 1]; ++q) pp[c++] = Pair{hx[q], hy[q], hp[q]};
         }
-        std::sort(pp, pp + c, [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
+        // order by (x, y).  The pairs of a read number about two per reference base, so when the reference span is
+        // not much longer than the list a counting sort on x (+ insertion sort of the few pairs sharing an x) beats
+        // a comparison sort several times over; chained records that span a whole contig keep std::sort.
+        const int64_t span = b->ref_len[i];
+        if (c > 64 && span <= 4 * c) {
+            thread_local std::vector<int32_t> start;
+            thread_local std::vector<Pair> tmp;
+            start.assign(span + 2, 0);
+            bool ok = true;
+            for (int64_t q = 0; q < c; ++q) {
+                if (pp[q].x < 0 || pp[q].x >= span) {
+                    ok = false;
+                    break;
+                }
+                ++start[pp[q].x + 1];
+            }
+            if (ok) {
+                for (int64_t x = 0; x < span; ++x) start[x + 1] += start[x];
+                tmp.resize(c);
+                for (int64_t q = 0; q < c; ++q) tmp[start[pp[q].x]++] = pp[q];  // start[x] is now the END of group x
+                int64_t g = 0;
+                for (int64_t q = 0; q < c; ++q) {  // insertion sort inside each x-group
+                    if (q > 0 && tmp[q].x != tmp[q - 1].x) g = q;
+                    Pair v = tmp[q];
+                    int64_t k = q;
+                    while (k > g && tmp[k - 1].y > v.y) tmp[k] = tmp[k - 1], --k;
+                    tmp[k] = v;
+                }
+                std::copy(tmp.begin(), tmp.end(), pp);
+            } else {
+                std::sort(pp, pp + c, [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
+            }
+        } else {
+            std::sort(pp, pp + c, [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
+        }
         r.n_pairs = c;
         if (r.status != NPR_OK) return;
         const int32_t *g = b->guide_ops.data() + 2 * b->guide_off[i];
