@@ -612,8 +612,8 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         L.width = cls_width[c];
         first += cls_count[c];
         int waves_per_cu;
-        if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 69 / 82 / 137 registers; measured best at 7 / 5 / 3 waves per SIMD
-            waves_per_cu = c == 0 ? 28 : (c == 1 ? 20 : 12);
+        if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
+            waves_per_cu = c == 0 ? 28 : (c == 1 ? 24 : 12);
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 64;
