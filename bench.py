@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3"])
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 6144 northstar = one per resident wavefront, 1000 c2)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 12288 northstar = two per resident wavefront, so that the work queue evens out the tail; 1000 c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -147,7 +147,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from nanopore_amd import realign as R
-    n_reads = args.reads or {"northstar": 6144, "c2": 1000, "c3": 50000}[args.workload]
+    n_reads = args.reads or {"northstar": 12288, "c2": 1000, "c3": 50000}[args.workload]
     h, w, W, label = build_workload(args.workload, n_reads, rank)
     ctx = R.Context(local_rank)
     ctx.set_hmm(h)

@@ -135,6 +135,20 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
         b.close()
         return out
 
+    # ragged segment ends inside the wide kernel: a small split threshold cuts the big rectangles, both halves keep
+    # up to 700 cells of them and start / end in the long-gap states
+    P_keep = P
+    P = R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=700,
+                      max_pairs_per_base=40)  # ragged ends blur the posteriors: more pairs per base than the default 6
+    r1, o1, p1, t1, _, w1 = run()
+    monkeypatch.setenv("NPR_NO_WIDE", "1")
+    r2, o2, p2, t2, _, _ = run()
+    monkeypatch.delenv("NPR_NO_WIDE")
+    assert (r1["status"] == 0).all() and r1["n_segments"].max() > 1 and t1[3:7].sum() > 0 and t2[3:7].sum() == 0 and 256 <= w1 <= 1400
+    assert np.array_equal(r1["loglik"], r2["loglik"]) and np.array_equal(r1["loglik_bwd"], r2["loglik_bwd"])
+    assert np.array_equal(o1[1], o2[1]) and np.array_equal(p1[3], p2[3]) and np.array_equal(p1[1], p2[1])
+    P = P_keep
+
     res, (off, ops), (poff, px, py, pp), tasks, cells, maxw = run()
     assert (res["status"] == 0).all() and maxw > 1024
     assert tasks[3:7].sum() > 0.5 * tasks.sum() and cells[3:7].sum() > 0.9 * cells.sum()   # k_dp_wide did the work
