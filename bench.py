@@ -27,9 +27,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 BYTES_PER_CELL = 40.0   # fp32 forward store 5x4 B + backward-time reload 5x4 B
 # HBM bytes per cell actually moved by k_dp_stair<2>, from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the
-# gfx950 FETCH_SIZE correction of guides/MI355X_MICROARCH.md): profiles/r01_pmc_k_dp_stair2_5120x10kb_w200.csv.
+# gfx950 FETCH_SIZE correction of guides/MI355X_MICROARCH.md): profiles/r01_pmc_k_dp_stair2_12288x10kb_w200.csv.
 # Below the algorithmic 40 B by design: only the match state is stored for the backward sweep (8 B + 8 B).
-MEASURED_TRAFFIC_BYTES_PER_CELL = 16.68
+MEASURED_TRAFFIC_BYTES_PER_CELL = 16.79
 
 
 def load_model(name="blasr_hmm_0.txt"):
@@ -225,6 +225,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_CELL * cells / 1e9,
                          "traffic_unit": "GB per launch (PMC-derived bytes/cell x cells of this launch)",
+                         "traffic_frac": MEASURED_TRAFFIC_BYTES_PER_CELL * cells / 1e9 / (kms * 1e-3) / HBM_PEAK_GBPS,
+                         "note": "achieved/frac are quoted on the declared 40 B/cell (SURVEY 8d) and exceed 1 because the "
+                                 "kernel keeps only the match state for the backward sweep (16.8 B/cell measured, "
+                                 "traffic_frac of the HBM peak); the binding resource is VALU issue (profiles/)",
                          "kernel": "k_dp", "kernel_ms": kms, "algorithmic_bytes_per_cell": BYTES_PER_CELL},
             "ok_reads": int((res["status"] == 0).sum()),
             "finish_s": finish_s,
