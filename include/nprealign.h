@@ -209,6 +209,17 @@ int32_t npr_plan_segments(const npr_plan *pl);
 int32_t npr_plan_segment_info(const npr_plan *pl, int32_t seg, int64_t *info8);
 /* lattice-clipped band: lo[D+1], n[D+1] */
 int32_t npr_plan_segment_band(const npr_plan *pl, int32_t seg, int32_t *lo, int32_t *n);
+/* Frame schedule of the register kernels for one segment (host logic, for inspection and tests): the kernels hold a
+ * frame of `slots` lattice points of the current anti-diagonal, slot j = (x0 + j, y0 - j), which takes an X-step
+ * (x0 += 1) into every odd anti-diagonal and a Y-step (y0 += 1) into every even one and may be rebased by one slot
+ * before a step.  Per anti-diagonal d (arrays of D+1): jlo[d] = slot of the first band cell, rebase[d] in {-1,0,+1} =
+ * rebase applied before the step into d (+1, towards higher x-y, only before X-steps; -1 only before Y-steps),
+ * row_off[d] = offset (cells) of its row in the forward scratch, rows holding whole lanes of `slots_per_lane` slots;
+ * *cells = scratch cells of the segment.  slots = 64 * slots_per_lane for k_dp_stair (slots_per_lane 1, 2, 4);
+ * 512, 1024, 2048 (slots_per_lane 2) or 3072 (4) for k_dp_wide.  NPR_ERR_BAND_TOO_WIDE when the band cannot be
+ * followed with that frame. */
+int32_t npr_plan_frame_schedule(const npr_plan *pl, int32_t seg, int32_t slots, int32_t slots_per_lane, int32_t *jlo,
+                                int32_t *rebase, uint32_t *row_off, int64_t *cells);
 /* MEA chain + cigar from sparse posteriors (stage a5.6).  Returns number of op pairs or NPR_ERR_*. */
 int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y, const float *p, int64_t n,
                       double gap_gamma, double match_gamma, int32_t *ops, int64_t cap_pairs, double *score);

@@ -84,7 +84,7 @@ EXPORTS = [
     "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_batch_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
-    "npr_plan_segment_band", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
+    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
 ]
 
 _lib = None
@@ -113,6 +113,8 @@ def load():
     L.npr_set_hmm.argtypes = [vp, i32, vp, vp]
     L.npr_batch_create.restype = i32
     L.npr_batch_create.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.npr_plan_frame_schedule.restype = i32
+    L.npr_plan_frame_schedule.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.npr_batch_class_stats.restype = i32
     L.npr_batch_class_stats.argtypes = [vp, vp, vp, i32]
     L.npr_batch_create_at.restype = i32

@@ -1171,6 +1171,25 @@ int32_t npr_plan_segment_band(const npr_plan *pl, int32_t seg, int32_t *lo, int3
     return NPR_OK;
 }
 
+int32_t npr_plan_frame_schedule(const npr_plan *pl, int32_t seg, int32_t slots, int32_t slots_per_lane, int32_t *jlo,
+                                int32_t *rebase, uint32_t *row_off, int64_t *cells) {
+    if (!pl || seg < 0 || seg >= static_cast<int32_t>(pl->plan.segs.size()) || slots_per_lane < 1 || slots < 64 * slots_per_lane ||
+        slots % (64 * slots_per_lane) != 0)
+        return NPR_ERR_INVALID;
+    const Segment &s = pl->plan.segs[seg];
+    std::vector<uint32_t> ctl(2 * (s.D() + 1));
+    int64_t c = 0;
+    if (!build_stair_schedule(s, slots_per_lane, slots / (64 * slots_per_lane), ctl.data(), &c)) return NPR_ERR_BAND_TOO_WIDE;
+    for (int64_t d = 0; d <= s.D(); ++d) {
+        const uint32_t w = ctl[2 * d + 1];
+        if (row_off) row_off[d] = ctl[2 * d];
+        if (jlo) jlo[d] = static_cast<int32_t>(w & 8191u);
+        if (rebase) rebase[d] = static_cast<int32_t>((w >> 26) & 3u) - 1;
+    }
+    if (cells) *cells = c;
+    return NPR_OK;
+}
+
 int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y, const float *p, int64_t n,
                       double gap_gamma, double match_gamma, int32_t *ops, int64_t cap_pairs, double *score) {
     if (lX < 0 || lY < 0 || n < 0 || (n && (!x || !y || !p))) return NPR_ERR_INVALID;

@@ -302,6 +302,34 @@ def plan(params, lX, lY, guide):
     return out
 
 
+def frame_schedule(params, lX, lY, guide, slots, slots_per_lane, segment=0):
+    """Frame schedule of the register kernels for one segment of the plan (host logic, no GPU needed):
+    dict(jlo, rebase, row_off, cells) or None when a frame of `slots` slots cannot follow the band
+    (include/nprealign.h: npr_plan_frame_schedule)."""
+    L = _lib.load()
+    g = np.ascontiguousarray(np.asarray(guide, dtype=np.int32).reshape(-1, 2))
+    h = C.c_void_p()
+    rc = L.npr_plan_create(C.byref(params), lX, lY, ptr(g), len(g), C.byref(h))
+    if rc != _lib.OK:
+        raise NprError(rc, "npr_plan_create")
+    try:
+        info = np.zeros(8, dtype=np.int64)
+        L.npr_plan_segment_info(h, segment, ptr(info))
+        D = int(info[6])
+        jlo = np.zeros(D + 1, dtype=np.int32)
+        reb = np.zeros(D + 1, dtype=np.int32)
+        off = np.zeros(D + 1, dtype=np.uint32)
+        cells = np.zeros(1, dtype=np.int64)
+        rc = L.npr_plan_frame_schedule(h, segment, slots, slots_per_lane, ptr(jlo), ptr(reb), ptr(off), ptr(cells))
+        if rc == _lib.ERR_BAND_TOO_WIDE:
+            return None
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_plan_frame_schedule")
+        return dict(jlo=jlo, rebase=reb, row_off=off, cells=int(cells[0]))
+    finally:
+        L.npr_plan_destroy(h)
+
+
 def mea_cigar(lX, lY, x, y, p, gap_gamma=0.5, match_gamma=0.0):
     L = _lib.load()
     x = np.ascontiguousarray(x, dtype=np.int32)

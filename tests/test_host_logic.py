@@ -69,3 +69,64 @@ def test_mea_and_rescore_equal_oracle(seed):
 
 def test_encode_bases():
     assert R.encode(b"ACGTacgtNnXU-").tolist() == [0, 1, 2, 3, 0, 1, 2, 3, 4, 4, 4, 4, 4]
+
+
+def _check_frame_schedule(seg, sch, slots, per_lane):
+    """Replays the frame: X-step into odd anti-diagonals, Y-step into even ones, rebases where scheduled."""
+    lo, n, D = seg["lo"].astype(np.int64), seg["n"].astype(np.int64), seg["D"]
+    jlo, reb, off = sch["jlo"].astype(np.int64), sch["rebase"].astype(np.int64), sch["row_off"].astype(np.int64)
+    assert reb[0] == 0 and (np.abs(reb) <= 1).all()
+    d = np.arange(D + 1)
+    assert (reb[(d % 2 == 0)] <= 0).all() and (reb[(d % 2 == 1)] >= 0).all()      # +1 only before X-steps, -1 before Y
+    flo = lo[0] - 2 * jlo[0]                                                         # x-y of slot 0
+    expect_off = 0
+    for k in range(D + 1):
+        if k > 0:
+            flo += (1 if k % 2 else -1) + 2 * reb[k]
+        assert lo[k] - flo == 2 * jlo[k], (k, lo[k], flo, jlo[k])                   # the control word places the band
+        assert 0 <= jlo[k] and jlo[k] + n[k] <= slots                               # ... inside the frame
+        assert off[k] == expect_off
+        expect_off += per_lane * (-(-(jlo[k] + n[k]) // per_lane) - jlo[k] // per_lane)   # whole lanes per row
+    assert sch["cells"] == expect_off and expect_off >= seg["cells"]
+    return int(np.abs(reb).sum())
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_register_kernel_frame_schedule(seed):
+    """build_stair_schedule (npr_api.cpp) through npr_plan_frame_schedule: the band stays inside the frame, rebases
+    obey the parity rule the kernels rely on, rows are laid out as the kernels address them."""
+    rng = np.random.default_rng(900 + seed)
+    followed = rebases = 0
+    for it in range(40):
+        L = int(rng.integers(40, 1500))
+        X, Y, ops = random_pair(rng, L, indel=rng.random() * 0.3, max_indel=int(rng.integers(1, 60)))
+        if it % 2:
+            kw = dict(band_mode=1, fixed_width=int(rng.integers(4, 250)))
+        else:
+            kw = dict(band_mode=0, diagonal_expansion=int(rng.integers(1, 8)) * 2, constraint_trim=int(rng.integers(0, 16)),
+                      split_threshold=int(rng.integers(20, 3000)))
+        P = R.make_params(**kw)
+        for s, seg in enumerate(R.plan(P, len(X), len(Y), ops)):
+            width = int(seg["n"].max())
+            for slots, per_lane in ((64, 1), (128, 2), (256, 4), (512, 2), (1024, 2), (3072, 4)):
+                sch = R.frame_schedule(P, len(X), len(Y), ops, slots, per_lane, segment=s)
+                if width >= slots:
+                    assert sch is None
+                    continue
+                if sch is None:      # allowed (an edge that jumps further than the slack): the batch then uses a bigger frame
+                    continue
+                followed += 1
+                rebases += _check_frame_schedule(seg, sch, slots, per_lane)
+    assert followed > 200 and rebases > 50
+
+
+def test_frame_schedule_long_gap_rebases_every_other_step():
+    """A 600-base deletion inside a W = 100 band: the frame drifts one slot per two anti-diagonals."""
+    ops = [(0, 300), (2, 600), (0, 300)]
+    P = R.make_params(band_mode=1, fixed_width=100)
+    seg = R.plan(P, 1200, 600, ops)[0]
+    sch = R.frame_schedule(P, 1200, 600, ops, 64, 1)
+    assert sch is not None and _check_frame_schedule(seg, sch, 64, 1) >= 250
+    d = np.arange(seg["D"] + 1)
+    inside = (d > 700) & (d < 1100)                                  # anti-diagonals crossing the deletion
+    assert (sch["rebase"][inside & (d % 2 == 1)] == 1).mean() > 0.9
