@@ -164,7 +164,7 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
 /* Diagnostics: how the batch's DP problems (segments) were spread over the kernel classes.  tasks[c] / cells[c] for
  * class c (either may be NULL), capacity `cap` entries; returns the number of classes (11):
  *   0-2  register kernel, one wavefront per task, 64 / 128 / 256 slots (k_dp_stair<1|2|4>)
- *   3-6  register kernel, 4 / 8 / 16 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
+ *   3-6  register kernel, 4 / 8 / 8 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
  *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* results, valid after npr_batch_finish */
@@ -216,7 +216,7 @@ int32_t npr_plan_segment_band(const npr_plan *pl, int32_t seg, int32_t *lo, int3
  * rebase applied before the step into d (+1, towards higher x-y, only before X-steps; -1 only before Y-steps),
  * row_off[d] = offset (cells) of its row in the forward scratch, rows holding whole lanes of `slots_per_lane` slots;
  * *cells = scratch cells of the segment.  slots = 64 * slots_per_lane for k_dp_stair (slots_per_lane 1, 2, 4);
- * 512, 1024, 2048 (slots_per_lane 2) or 3072 (4) for k_dp_wide.  NPR_ERR_BAND_TOO_WIDE when the band cannot be
+ * 512, 1024 (slots_per_lane 2), 2048 or 3072 (4) for k_dp_wide.  NPR_ERR_BAND_TOO_WIDE when the band cannot be
  * followed with that frame. */
 int32_t npr_plan_frame_schedule(const npr_plan *pl, int32_t seg, int32_t slots, int32_t slots_per_lane, int32_t *jlo,
                                 int32_t *rebase, uint32_t *row_off, int64_t *cells);

@@ -373,7 +373,7 @@ struct KClass {
 };
 constexpr int kClasses = 11;
 constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STAIR, 4, 1}, {K_WIDE, 2, 4}, {K_WIDE, 2, 8},
-                                        {K_WIDE, 2, 16}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
+                                        {K_WIDE, 4, 8}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
                                         {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}};
 constexpr int kFirstGeneric = 7, kQueueSlots = 16;
 inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE; }
@@ -619,7 +619,9 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
             L.threads = 64;
         } else if (kClassTab[c].kind == K_WIDE) {  // workgroups per CU by VGPRs: 111 (R = 2) -> 4 waves per SIMD, 168-176 (R = 4) -> 2-3
             const int nw = kClassTab[c].NW;
-            waves_per_cu = kClassTab[c].R == 2 ? 16 / nw : 1;
+            // workgroups per CU: 111 VGPRs (R = 2) and 128 (4 x 8, held there by amdgpu_waves_per_eu) -> 4 waves per SIMD;
+            // 4 x 12: 168 VGPRs, 3 waves per SIMD
+            waves_per_cu = (kClassTab[c].R == 2 || nw <= 8) ? 16 / nw : 1;
             L.wcap = 0;
             L.lds = wide_lds_bytes(nw);
             L.threads = 64 * nw;

@@ -887,7 +887,7 @@ struct Recent {
 };
 
 template <int R, int NW>
-__global__ void __launch_bounds__(WAVE *NW) k_dp_wide(KernelArgs a) {
+__global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((R == 4 && NW == 8) ? 4 : 1))) k_dp_wide(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmodel = reinterpret_cast<float *>(smem);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] pair counter, [5] next task
@@ -1311,11 +1311,12 @@ size_t stair_lds_bytes() { return sizeof(float) * (MODEL_FLOATS + 8); }
 
 size_t wide_lds_bytes(int nw) { return sizeof(float) * (MODEL_FLOATS + 8 + 2 * (nw + 2) * 2 * 8); }
 
-// (R, NW) pairs built: 2x4 = 512 slots, 2x8 = 1024, 2x16 = 2048, 4x12 = 3072.  What bounds a step is ONE wavefront's
+// (R, NW) pairs built: 2x4 = 512 slots, 2x8 = 1024, 4x8 = 2048, 4x12 = 3072.  What bounds a step is ONE wavefront's
 // latency (LDS edge read -> DPP -> ~50 dependent VALU ops -> publish -> barrier), so a wavefront should carry enough
-// slots to amortise it (one slot per lane: 6e10 cells/s on constant 400-800-cell bands, two: 1.1-1.3e11) but not so many
-// that a band narrower than the frame leaves most of the workgroup idle (2048 slots as 4x8: 5.3e10 cells/s on the
-// reference's anchor diamonds, as 2x16: 6.1e10).
+// slots to amortise it (one slot per lane: 6e10 cells/s on constant 400-800-cell bands, two: 1.1-1.3e11), and a CU
+// should hold more than one task to fill the time the others wait: 2048 slots as 2x16 (one workgroup per CU) gives
+// 6.1e10 cells/s on the reference's anchor diamonds, as 4x8 squeezed into 128 VGPRs (68 spilled registers, but two
+// workgroups per CU) 6.5e10.
 int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = wide_lds_bytes(NW);
@@ -1323,8 +1324,8 @@ int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
         hipLaunchKernelGGL((k_dp_wide<2, 4>), dim3(grid), dim3(WAVE * 4), lds, s, a);
     else if (R == 2 && NW == 8)
         hipLaunchKernelGGL((k_dp_wide<2, 8>), dim3(grid), dim3(WAVE * 8), lds, s, a);
-    else if (R == 2 && NW == 16)
-        hipLaunchKernelGGL((k_dp_wide<2, 16>), dim3(grid), dim3(WAVE * 16), lds, s, a);
+    else if (R == 4 && NW == 8)
+        hipLaunchKernelGGL((k_dp_wide<4, 8>), dim3(grid), dim3(WAVE * 8), lds, s, a);
     else if (R == 4 && NW == 12)
         hipLaunchKernelGGL((k_dp_wide<4, 12>), dim3(grid), dim3(WAVE * 12), lds, s, a);
     else
