@@ -801,6 +801,13 @@ __device__ __forceinline__ void diag_down_inplace(Diag<R> &g, const Cell &edge) 
     dpp_down_inplace(t.e, uni(edge.e));
 }
 
+// The per-step barrier of the workgroup.  Only LDS traffic (the edge cells, the pair counter) has to be complete
+// before it: __syncthreads() would also wait for the forward-row stores of this step and for the forward rows the
+// backward sweep loads one anti-diagonal AHEAD.  (A wavefront only ever loads rows it stored itself, so no
+// global-memory ordering between wavefronts is needed.)  Measured neutral on MI355X -- the step is bound by the
+// wavefront's own instruction latency -- but it is the barrier the algorithm needs.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // The edge cells of the workgroup's wavefronts in LDS: [parity of the anti-diagonal][wavefront + 1][side][8 floats];
 // rows 0 and NW + 1 stay dead (the frame's own ends).  side 0 = the wavefront's slot 0, side 1 = its top slot.
 template <int NW>
@@ -1012,9 +1019,9 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                         bases_down_inplace<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 - sb - 1, lane));
                     }
                 }
-                __syncthreads();  // everybody has read the old edges
+                lds_barrier();  // everybody has read the old edges
                 if (live) publish<R, NW>(ed, 0, wv, A), publish<R, NW>(ed, 1, wv, B);
-                __syncthreads();
+                lds_barrier();
             }
             rec.push(ct);
             const bool act = rec.touches(sb, 64 * R);
@@ -1055,7 +1062,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
             }
             live = act;
             if (par) x0 += 1; else y0 += 1;
-            __syncthreads();
+            lds_barrier();
         };
 
         Ctl nx = c0;
@@ -1177,7 +1184,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 }
                 emit(A, fa, D, cur);
             }
-            __syncthreads();
+            lds_barrier();
 
             // one backward step into anti-diagonal dd: undoes the rebase `reb` made before the forward step into dd + 1,
             // then that step (an X-step when dd is even)
@@ -1202,9 +1209,9 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                             bases_up_inplace<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - sb - (64 * R - 1), lane));
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();
                     if (live) publish<R, NW>(ed, 0, wv, A), publish<R, NW>(ed, 1, wv, B);
-                    __syncthreads();
+                    lds_barrier();
                 }
                 rec.push(ct);
                 const bool act = rec.touches(sb, 64 * R);
@@ -1256,7 +1263,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 }
                 bwd(d2, A, B, cur, reb);
                 emit(A, fa, d2, cur);
-                __syncthreads();
+                lds_barrier();
                 d2 -= 1;
             }
             for (; d2 >= 1; d2 -= 2) {
@@ -1266,7 +1273,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 load(fa, nxt);
                 bwd(d2, B, A, cur, reb);
                 emit(B, fb, d2, cur);
-                __syncthreads();
+                lds_barrier();
                 reb = cur.reb;
                 cur = nxt;
                 if (d2 >= 2) {
@@ -1275,7 +1282,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 }
                 bwd(d2 - 1, A, B, cur, reb);
                 emit(A, fa, d2 - 1, cur);
-                __syncthreads();
+                lds_barrier();
             }
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll
