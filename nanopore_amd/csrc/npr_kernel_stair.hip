@@ -1133,12 +1133,15 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
             FRow<R> fa, fb;  // forward rows of the even / odd anti-diagonals, loaded one ahead
 #pragma unroll
             for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
+            // (a wavefront the band does not touch leaves at once: most wavefronts of a wide frame, most of the time)
             auto load = [&](FRow<R> &f, const Ctl &ct) {
+                if (ct.jlo + ct.n <= sb || ct.jlo >= sb + 64 * R) return;
                 const LocalBand lb = local_band<R>(ct, sb);
                 load_row_w<R>(F, f, ct, band_masks<R>(lb.lo, lb.n), voff);
             };
             // posteriors of anti-diagonal dd (frame at x0, y0), slots claimed from the workgroup's LDS counter
             auto emit = [&](const Diag<R> &Bd, const FRow<R> &f, int dd, const Ctl &ct) {
+                if (ct.jlo + ct.n <= sb || ct.jlo >= sb + 64 * R) return;
                 const LocalBand lb = local_band<R>(ct, sb);
                 const Masks<R> mk = band_masks<R>(lb.lo, lb.n);
                 float p[R];
