@@ -1,0 +1,17 @@
+import os, sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from nanopore_amd import realign as R, synth
+from nanopore_amd.hmm import Hmm
+ROOT='/root/repo'
+h = Hmm.loadHmm(os.path.join(ROOT, 'nanopore_amd', 'mappers', 'blasr_hmm_0.txt'))
+n=int(sys.argv[1]); L=int(sys.argv[2]); W=int(sys.argv[3])
+w = synth.make_workload(7, n, L, h.transitions, h.emissions, flank=0)
+ctx = R.Context(0); ctx.set_hmm(h)
+P = R.make_params(band_mode=1, fixed_width=W) if W > 0 else R.make_params(band_mode=0, split_threshold=100)
+b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
+st = b.stats()
+ms = min(b.run() for _ in range(2))
+t0=time.time(); T,E,ll,kms = b.expectations(); t1=time.time()
+T,E,ll,kms2 = b.expectations()
+print('n %d L %d W %d cells %.3e: realign kernel %.1f ms (%.2e cells/s); E-step kernel %.1f ms (%.2e cells/s), wall %.2f s' % (n,L,W,st['cells'],ms,st['cells']/ms*1e3,kms2,st['cells']/kms2*1e3,t1-t0))
