@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 //     publishes its two edge cells (6 values each) and the workgroup takes ONE barrier; the DPP move's `old` operand
 //     (the edge lane's value) is then the neighbour wavefront's edge instead of the dead cell;
 //   * every wavefront runs its own base streams (its window of the sequences is just offset);
-//   * wavefronts whose slots have been outside the band for three anti-diagonals skip the step (they still take the
+//   * wavefronts whose slots are more than four slots away from the band skip the step (they still take the
 //     barrier): the unanchored diamonds of the reference's own band (anchors +- diagonalExpansion, up to
 //     splitMatrixBiggerThanThis = 3000 cells across) alternate with 21-cell stripes, and a stripe costs one wavefront;
 //     a wavefront that the band re-enters rebuilds its streams from memory and restarts from dead cells;
@@ -879,19 +879,13 @@ __device__ __forceinline__ void load_row_w(char *F, FRow<R> &f, const Ctl &ct, c
     }
 }
 
-// The three most recent bands in frame coordinates (kept current across rebases): a wavefront is ACTIVE while any of
-// them, widened by two slots, touches its slots -- then its registers may hold live cells or must receive some.
-struct Recent {
-    int lo0, hi0, lo1, hi1, lo2, hi2;
-    __device__ __forceinline__ void push(const Ctl &ct) {
-        lo2 = lo1, hi2 = hi1, lo1 = lo0, hi1 = hi0, lo0 = ct.jlo, hi0 = ct.jlo + ct.n;
-    }
-    __device__ __forceinline__ void shift(int by) { lo0 += by, hi0 += by, lo1 += by, hi1 += by, lo2 += by, hi2 += by; }
-    __device__ __forceinline__ bool touches(int sb, int width) const {
-        const int lo = min(lo0, min(lo1, lo2)) - 2, hi = max(hi0, max(hi1, hi2)) + 2;
-        return lo < sb + width && hi > sb;
-    }
-};
+// A wavefront is ACTIVE on an anti-diagonal whose band, widened by four slots, touches its slots.  The band's edges move
+// by at most one slot per anti-diagonal and a rebase adds one more, so when the widened band does not touch the
+// wavefront, neither did the bands of the two anti-diagonals before: every cell the wavefront still holds was outside
+// the band when it was made, i.e. is dead already, and so are its published edges.
+__device__ __forceinline__ bool band_near(const Ctl &ct, int sb, int width) {
+    return ct.jlo - 4 < sb + width && ct.jlo + ct.n + 4 > sb;
+}
 
 template <int R, int NW>
 __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((R == 4 && NW == 8) ? 4 : 1))) k_dp_wide(KernelArgs a) {
@@ -978,8 +972,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
         const Ctl c0 = read_ctl(ctl, 0);
         const int j0 = c0.jlo;
         int x0 = -j0, y0 = j0;
-        Recent rec{c0.jlo, c0.jlo + c0.n, c0.jlo, c0.jlo + c0.n, c0.jlo, c0.jlo + c0.n};
-        bool live = rec.touches(sb, 64 * R);  // this wavefront's registers / streams are current
+        bool live = band_near(c0, sb, 64 * R);  // this wavefront's registers / streams are current
         if (live) fwd_streams(x0, y0);
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -1009,7 +1002,6 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                     }
                 }
                 x0 += ct.reb, y0 -= ct.reb;
-                rec.shift(-ct.reb);
                 if (live) {
                     if (ct.reb > 0) {
                         bases_up_inplace<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + sb + 64 * R - 2, lane));
@@ -1023,8 +1015,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 if (live) publish<R, NW>(ed, 0, wv, A), publish<R, NW>(ed, 1, wv, B);
                 lds_barrier();
             }
-            rec.push(ct);
-            const bool act = rec.touches(sb, 64 * R);
+            const bool act = band_near(ct, sb, 64 * R);
             if (act) {
                 if (!live) {  // the band has come back into this wavefront: restart from dead cells
                     A = dead_diag<R>(), B = dead_diag<R>();
@@ -1117,8 +1108,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
             A = dead_diag<R>(), B = dead_diag<R>();
             const bool oddD = D & 1;
             Ctl cur = read_ctl(ctl, D);
-            rec = Recent{cur.jlo, cur.jlo + cur.n, cur.jlo, cur.jlo + cur.n, cur.jlo, cur.jlo + cur.n};
-            live = rec.touches(sb, 64 * R);
+            live = band_near(cur, sb, 64 * R);
             if (live) bwd_streams(x0, y0);
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -1202,7 +1192,6 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                         }
                     }
                     x0 -= reb, y0 += reb;
-                    rec.shift(reb);
                     if (live) {
                         if (reb > 0) {
                             bases_down_inplace<R>(S.X, feed_get<-1>(S.fx, E.X, E.lX, x0 + sb, lane));
@@ -1216,8 +1205,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                     if (live) publish<R, NW>(ed, 0, wv, A), publish<R, NW>(ed, 1, wv, B);
                     lds_barrier();
                 }
-                rec.push(ct);
-                const bool act = rec.touches(sb, 64 * R);
+                const bool act = band_near(ct, sb, 64 * R);
                 if (par) y0 -= 1; else x0 -= 1;  // the frame of dd
                 if (act) {
                     if (!live) {
