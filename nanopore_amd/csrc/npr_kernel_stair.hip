@@ -150,7 +150,9 @@ __device__ __forceinline__ void feed_init(Feed &f, const uint8_t *seq, int len, 
 // base*4 of sequence index `idx` (uniform), which must move monotonically in direction DIR
 template <int DIR>
 __device__ __forceinline__ int feed_get(Feed &f, const uint8_t *seq, int len, int idx, int lane) {
-    int off = DIR * (idx - f.base);
+    // (uni: in k_dp_wide the feed lives in a struct the step lambdas capture, and the compiler no longer sees that
+    // `base` is wave-uniform -- without it the refill test becomes per-lane code with an exec mask)
+    int off = uni(DIR * (idx - f.base));
     if (off >= 64) {  // uniform
         f.cur = f.nxt;
         f.base += DIR * 64;
