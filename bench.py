@@ -47,6 +47,10 @@ def build_workload(name, n_reads, rank):
     elif name == "c2":
         w, W = synth.make_workload(1001 + 7919 * rank, n_reads, 1000, h.transitions, h.emissions), 100
         label = "synthetic 1k reads x 1kb, band 100, blasr_hmm_0 (BASELINE.json configs[1])"
+    elif name == "anchor":
+        w, W = synth.make_workload(1004 + 7919 * rank, n_reads, 8000, h.transitions, h.emissions), 0
+        label = ("synthetic ~8kb reads, the reference's own band: anchors +- diagonalExpansion 10, 14 trimmed columns, "
+                 "splitMatrixBiggerThanThis 3000 (nanopore/analyses/utils.py:587), blasr_hmm_0")
     elif name == "c3":
         w, W = synth.config_c3(h.transitions, h.emissions, n_reads=n_reads)
         label = "synthetic E. coli-sized reference x ~8kb reads, band 200 (BASELINE.json configs[2])"
@@ -78,7 +82,8 @@ def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
     from nanopore_amd.realign import encode
     cores = usable_cpus()
     oh = orc.make_hmm(h.transitions, h.emissions)
-    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
+    # W = 0: the reference's own call parameters (anchors +- 10, trim 14, splitMatrixBiggerThanThis 3000; utils.py:587)
+    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W) if W > 0 else orc.make_params(band_mode=orc.BAND_ANCHOR)
 
     def run(k):
         if w.get("guide_start") is not None:
@@ -116,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3"])
+    ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3", "anchor"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 12288 northstar = two per resident wavefront, so that the work queue evens out the tail; 1000 c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -147,11 +152,12 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from nanopore_amd import realign as R
-    n_reads = args.reads or {"northstar": 12288, "c2": 1000, "c3": 50000}[args.workload]
+    n_reads = args.reads or {"northstar": 12288, "c2": 1000, "c3": 50000, "anchor": 8192}[args.workload]
     h, w, W, label = build_workload(args.workload, n_reads, rank)
     ctx = R.Context(local_rank)
     ctx.set_hmm(h)
-    batch = ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"],
+    params = R.make_params(band_mode=R.BAND_FIXED, fixed_width=W) if W > 0 else R.make_params(band_mode=R.BAND_ANCHOR, max_pairs_per_base=24)
+    batch = ctx.stage_csr(params, w["ref"], w["ref_off"], w["read"],
                           w["read_off"], w["guide_ops"], w["guide_off"], guide_start=w.get("guide_start"))
     st = batch.stats()
     cells = st["cells"]
