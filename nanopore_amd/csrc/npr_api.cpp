@@ -46,6 +46,9 @@ struct npr_ctx {
     // Forward-value scratch (one region per resident wavefront) lives with the context and only grows: a
     // hipMalloc of ~100 GB costs seconds, far more than the DP pass it serves.  Batches on one context run one
     // at a time (include/nprealign.h), so they can share it.
+    // Both arenas point kArenaPad bytes into their allocations and are followed by as much: the register E-step loads
+    // forward rows with a slot shift of up to two and may touch a few cells before / after a region.
+    static constexpr size_t kArenaPad = 1024;
     char *arena_F = nullptr;  // 8 bytes per cell
     size_t arena_cells = 0;
     float *arena_Fx = nullptr;  // E-step only: four more forward planes
@@ -278,8 +281,8 @@ void npr_destroy(npr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_models) (void)hipFree(ctx->d_models);
-    if (ctx->arena_F) (void)hipFree(ctx->arena_F);
-    if (ctx->arena_Fx) (void)hipFree(ctx->arena_Fx);
+    if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
+    if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
     if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -674,9 +677,11 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(grid);
     if (b->scratch_cells > ctx->arena_cells) {
-        if (ctx->arena_F) (void)hipFree(ctx->arena_F);
+        if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
         ctx->arena_F = nullptr, ctx->arena_cells = 0;
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8)) != hipSuccess)
+        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8 + 2 * npr_ctx::kArenaPad)) == hipSuccess)
+            ctx->arena_F += npr_ctx::kArenaPad;
+        if (e != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc of the forward scratch", e);
         ctx->arena_cells = b->scratch_cells;
     }
@@ -981,12 +986,21 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         int first, count, wcap, grid;
         size_t lds;
         bool global_ring;
+        int stair_R;  // > 0: the register-kernel E-step (k_em_stair<R>), else the generic kernel
     };
     std::vector<L> launches;
     int64_t max_grid = 1;
     for (const auto &dl : b->launches) {  // one E-step launch per kernel class of the batch (tasks are grouped by class)
         L l{};
         l.first = dl.first, l.count = dl.count;
+        if (kClassTab[dl.cls].kind == K_STAIR && !std::getenv("NPR_EM_GENERIC")) {
+            // 100 / 149 / 193 VGPRs and 12.5 KiB of LDS bins per wavefront: 12 / 12 / 8 wavefronts per CU
+            l.stair_R = kClassTab[dl.cls].R;
+            l.lds = em_stair_lds_bytes();
+            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * (l.stair_R == 4 ? 8 : 12))));
+            launches.push_back(l);
+            continue;
+        }
         l.wcap = static_cast<int>((std::max<int64_t>(dl.width, 64) + 3) & ~int64_t(3));
         l.lds = generic_lds_bytes(l.wcap) + em_extra_lds_bytes();
         l.global_ring = l.lds > 160 * 1024;  // the bins take 12 KiB of the LDS the ring would otherwise have
@@ -1005,9 +1019,12 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     const size_t fx_cells = static_cast<size_t>(max_grid) * 4 * static_cast<size_t>(b->slot_stride);
     hipError_t e;
     if (fx_cells > ctx->arena_fx_cells) {
-        if (ctx->arena_Fx) (void)hipFree(ctx->arena_Fx);
+        if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
         ctx->arena_Fx = nullptr, ctx->arena_fx_cells = 0;
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_Fx), fx_cells * sizeof(float))) != hipSuccess)
+        char *raw = nullptr;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&raw), fx_cells * sizeof(float) + 2 * npr_ctx::kArenaPad)) == hipSuccess)
+            ctx->arena_Fx = reinterpret_cast<float *>(raw + npr_ctx::kArenaPad);
+        if (e != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc of the forward planes", e);
         ctx->arena_fx_cells = fx_cells;
     }
@@ -1032,7 +1049,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         a.Fx = ctx->arena_Fx;
         a.em_T = d_T.p;
         a.em_E = d_E.p;
-        const int rc = launch_em(a, l.grid, l.lds, l.global_ring, ctx->stream);
+        const int rc = l.stair_R ? launch_em_stair(a, l.stair_R, l.grid, ctx->stream) : launch_em(a, l.grid, l.lds, l.global_ring, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "E-step kernel launch", static_cast<hipError_t>(rc));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));

@@ -85,6 +85,8 @@ size_t em_extra_lds_bytes();
 int launch_compact(const CompactArgs &a, void *stream);
 int launch_stair(const KernelArgs &a, int R, int grid, void *stream);
 int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
+int launch_em_stair(const KernelArgs &a, int R, int grid, void *stream);
+size_t em_stair_lds_bytes();
 size_t wide_lds_bytes(int nw);
 size_t stair_lds_bytes();
 size_t generic_lds_bytes(int wcap);

@@ -162,6 +162,14 @@ __device__ __forceinline__ int feed_get(Feed &f, const uint8_t *seq, int len, in
     return __builtin_amdgcn_readlane(f.cur, off);
 }
 
+// The base a feed would deliver for `idx` (at most one step ahead of its last request), without moving the feed: a
+// later request may be for idx + 1 again (a rebase in between), which a block switch made here would have lost.
+template <int DIR>
+__device__ __forceinline__ int feed_peek(const Feed &f, int idx) {
+    const int off = uni(DIR * (idx - f.base));
+    return off < 64 ? __builtin_amdgcn_readlane(f.cur, off) : __builtin_amdgcn_readlane(f.nxt, off - 64);
+}
+
 typedef const __attribute__((address_space(4))) uint32_t *cptr32;
 
 // Control word of one anti-diagonal (written by build_stair_schedule, npr_api.cpp): where the band sits in the frame,
@@ -221,6 +229,7 @@ __device__ __forceinline__ void emissions(const StepEnv &E, const Bases<R> &bx, 
 
 // A slot outside the band keeps whatever mantissas the arithmetic produced and only gets the dead exponent: every
 // consumer multiplies it by scale2(E_DEAD - eref) = 0, so the mantissas never matter.
+__device__ __forceinline__ bool lanes_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 __device__ __forceinline__ void kill_outside(Cell &c, uint64_t in_band) {
     c.e = __builtin_amdgcn_inverse_ballot_w64(in_band) ? c.e : E_DEAD;
 }
@@ -1305,6 +1314,347 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
     }
 }
 
+// =====================================================================================================================
+// k_em_stair<R>: Baum-Welch E-step on the register kernel (cactus_realign --outputExpectations,
+// summed by cactus_expectationMaximisation at nanopore/analyses/utils.py:509-528 -- 3 trials x 100 iterations over the
+// training alignments, so this pass runs hundreds of times per trained model).  Same frame-based sweep as k_dp_stair;
+//   * the forward sweep stores ALL five states of every cell (the (m, e) pairs as k_dp_stair does, plus a float4
+//     (sx, sy, lx, ly) per slot in a second scratch region);
+//   * the backward sweep keeps the forward cells of the two anti-diagonals BELOW the current one in registers (loaded
+//     one anti-diagonal ahead, with a slot shift that undoes the frame rebases in between, and moved in place by the
+//     backward rebases like everything else) and, after finishing a backward cell, adds the posterior probability of
+//     each of the 15 transitions INTO that cell to 15 per-lane accumulators and the emitted symbols' posterior to
+//     per-lane bins in LDS (no atomics in the loop);
+//   * the wavefront reduces accumulators and bins at the end of the task: one fp64 atomic per count per task.
+// Expected counts agree with the fp64 oracle to <= 2e-5 relative (tests/test_gpu_em.py); the summation order differs
+// from k_dp_generic<EM>, so the two are not bit-identical.
+// =====================================================================================================================
+// lanes whose slot R*lane + r lies in [jlo, jlo + n); jlo may be negative (a band seen from a shifted frame)
+template <int R>
+__device__ __forceinline__ uint64_t cell_mask(int jlo, int n, int r) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    const int lo = max(jlo - r + R - 1, 0) >> SH, hi = max(jlo + n - r + R - 1, 0) >> SH;
+    return hi > lo ? (low_lanes(hi) & ~low_lanes(lo)) : 0ull;
+}
+
+template <int R>
+__device__ __forceinline__ void store_row_x(char *Fx, const Diag<R> &C, const Ctl &ct, int lane) {
+    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Fx + (static_cast<int64_t>(ct.co) - R * mk.l0) * 16, 0, -1, 0x00020000);
+    if (lanes_of(mk.lanes)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[r].sx), fbits(C.c[r].sy), fbits(C.c[r].lx), fbits(C.c[r].ly)}, rs,
+                                                   16 * (R * lane + r), 0, 0);
+    }
+}
+
+// the forward cells of the row `ct` into G, seen from a frame in which slot j is the row's slot j + shift
+template <int R>
+__device__ __forceinline__ void load_full_row(char *F, char *Fx, Diag<R> &G, const Ctl &ct, int shift, int lane) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    uint64_t lanes = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) lanes |= cell_mask<R>(ct.jlo - shift, ct.n, r);
+    const int64_t first = static_cast<int64_t>(ct.co) - R * (ct.jlo >> SH) + shift;  // cell index of this frame's slot 0
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(F + first * 8, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(Fx + first * 16, 0, -1, 0x00020000);
+    if (lanes_of(lanes)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * (R * lane + r), 0, 0);
+            const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rx, 16 * (R * lane + r), 0, 0);
+            G.c[r].m = bitsf(q.x), G.c[r].e = q.y;
+            G.c[r].sx = bitsf(g.x), G.c[r].sy = bitsf(g.y), G.c[r].lx = bitsf(g.z), G.c[r].ly = bitsf(g.w);
+        }
+    }
+}
+
+// per-lane emission bins in LDS: bin b of lane l at float b * 64 + l (byte b * 256 + 4 * l)
+__device__ __forceinline__ float &bin_at(float *lbins, int byte_off) {
+    return *reinterpret_cast<float *>(reinterpret_cast<char *>(lbins) + byte_off);
+}
+
+template <int R>
+__global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lmodel = reinterpret_cast<float *>(smem);
+    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // 8 ints: cell hand-off
+    float *lbins = reinterpret_cast<float *>(lmisc + 8);          // (EM_BINS + 15) rows of 64 lanes
+
+    const int lane = threadIdx.x;
+    char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
+    char *const Fx = reinterpret_cast<char *>(a.Fx) + static_cast<int64_t>(blockIdx.x) * a.slot_stride * 16;
+    const int voff = 8 * R * lane;
+    int jr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
+
+    int t = blockIdx.x;
+    while (t < a.ntasks) {
+        const Task *tp = a.tasks + t;
+        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off);
+        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), flags = uni(tp->flags), model = uni(tp->model);
+        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
+        const int rs = flags & 1, re = (flags >> 1) & 1;
+
+        __syncthreads();
+        {
+            const float *gm = reinterpret_cast<const float *>(a.models + model);
+            for (int i = lane; i < MODEL_FLOATS; i += WAVE) lmodel[i] = gm[i];
+            for (int i = 0; i < EM_BINS; ++i) lbins[i * WAVE + lane] = 0.f;
+        }
+        __syncthreads();
+        StepEnv E;
+        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
+        E.ltab = reinterpret_cast<const char *>(lmodel);
+        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
+        {
+            Trans tr = load_trans(E.mdl->T);
+            tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
+            tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
+            tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
+            tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
+            E.tr = tr;
+        }
+        const Trans &tr = E.tr;
+        const DevModel *mdl = E.mdl;
+
+        // =============================== forward: as k_dp_stair, all five states stored ===============================
+        Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
+        Streams<R> S;
+        const Ctl c0 = read_ctl(ctl, 0);
+        const int j0 = c0.jlo;
+        int x0 = -j0, y0 = j0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            S.X.b[r] = base4(E.X, lX, x0 + jr[r] - 1);
+            S.Y.b[r] = base4(E.Y, lY, y0 - jr[r] - 1);
+        }
+        S.xcap = S.ycap = 16;
+        feed_init<+1>(S.fx, E.X, lX, x0 + 64 * R - 1, lane);
+        feed_init<+1>(S.fy, E.Y, lY, y0, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (jr[r] == j0) {
+                Cell c;
+                c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
+                c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
+                normalise(c, 0);
+                A.c[r] = c;
+            }
+        store_row<R>(F, A, c0, voff), store_row_x<R>(Fx, A, c0, lane);
+        for (int d = 1; d <= D; ++d) {
+            const Ctl ct = read_ctl(ctl, d);
+            if (ct.reb) fwd_rebase<R>(E, ct.reb, A, B, S, x0, y0);
+            if (d & 1) {
+                fwd_x_step<R>(E, B, A, S, x0, ct);
+                store_row<R>(F, B, ct, voff), store_row_x<R>(Fx, B, ct, lane);
+            } else {
+                fwd_y_step<R>(E, A, B, S, y0, ct);
+                store_row<R>(F, A, ct, voff), store_row_x<R>(Fx, A, ct, lane);
+            }
+        }
+        {
+            const int je = lX - x0;
+            const bool oddD = D & 1;
+            float tm = 0.f;
+            int te = E_DEAD;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (jr[r] == je) {
+                    const Cell c = oddD ? B.c[r] : A.c[r];
+                    const float raw = dot5(mdl->end + re * 5, c);
+                    if (raw > 0.f) {
+                        int k;
+                        tm = __builtin_frexpf(raw, &k);
+                        te = c.e + k;
+                    }
+                    reinterpret_cast<float *>(lmisc)[0] = tm;
+                    lmisc[1] = te;
+                }
+        }
+        __syncthreads();
+        const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
+        const int tot_e = uni(lmisc[1]);
+        __syncthreads();
+
+        TaskOut out;
+        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
+        out.status = NPR_OK;
+        const bool alive = tot_m > 0.f;
+        if (!alive) out.status = NPR_ERR_ZERO_PROB;
+
+        // =============================== backward + expected counts ===============================
+        if (alive) {
+            const float inv_tot = 1.0f / tot_m;
+            float acc[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) acc[i] = 0.f;
+            A = dead_diag<R>(), B = dead_diag<R>();
+            // q0..q3: control words of the anti-diagonals d, d-1, d-2, d-3 (n = 0 below the first one)
+            const Ctl none{0u, 0, 0, 0};
+            Ctl q0 = read_ctl(ctl, D), q1 = D >= 1 ? read_ctl(ctl, D - 1) : none, q2 = D >= 2 ? read_ctl(ctl, D - 2) : none,
+                q3 = D >= 3 ? read_ctl(ctl, D - 3) : none;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                S.X.b[r] = base4(E.X, lX, x0 + jr[r]);
+                S.Y.b[r] = base4(E.Y, lY, y0 - jr[r]);
+                if (x0 + jr[r] == lX) {
+                    Cell c;
+                    c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
+                    c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
+                    normalise(c, 0);
+                    if (D & 1) B.c[r] = c; else A.c[r] = c;
+                }
+            }
+            S.xcap = S.ycap = 16;
+            feed_init<-1>(S.fx, E.X, lX, x0 - 1, lane);
+            feed_init<-1>(S.fy, E.Y, lY, y0 - 64 * R, lane);
+            // forward cells of d-1 and d-2 in the frame of d; GN: those of d-3 in the frame of d-1, loaded one ahead
+            Diag<R> G1 = dead_diag<R>(), G2 = dead_diag<R>(), GN = dead_diag<R>();
+            if (D >= 1) load_full_row<R>(F, Fx, G1, q1, q0.reb, lane);
+            if (D >= 2) load_full_row<R>(F, Fx, G2, q2, q1.reb + q0.reb, lane);
+
+            for (int d = D; d >= 1; --d) {
+                // prefetch for the next anti-diagonal: forward cells of d-3 in the frame of d-1
+                if (d >= 3) load_full_row<R>(F, Fx, GN, q3, q2.reb + q1.reb, lane);
+                Diag<R> &io = (d & 1) ? B : A;
+                // ---- expected counts of the transitions into the cells of d ----
+                const Masks<R> mk = band_masks<R>(q0.jlo, q0.n);
+                const int jl1 = q1.jlo - q0.reb, jl2 = q2.jlo - q1.reb - q0.reb;
+                // bases consumed INTO (x, y): X[x-1] = slot j-1 of the X stream, Y[y-1] = slot j+1 of the Y stream
+                Bases<R> eX, eY;
+                {
+                    const int injx = feed_peek<-1>(S.fx, x0 - 1), injy = feed_peek<-1>(S.fy, y0 - 64 * R);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) eX.b[r] = S.X.b[r - 1];
+                    eX.b[0] = dpp_from_below(S.X.b[R - 1], injx);
+#pragma unroll
+                    for (int r = 0; r + 1 < R; ++r) eY.b[r] = S.Y.b[r + 1];
+                    eY.b[R - 1] = dpp_from_above(S.Y.b[0], injy);
+                }
+                const Diag<R> Gs = (d & 1) ? shift_up<R>(G1) : shift_down<R>(G1);  // the d-1 predecessor one slot away
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const Cell c = io.c[r];
+                    const uint64_t here = __ballot(c.e != E_DEAD) & mk.cell[r];
+                    const int ex4 = eX.b[r], ey4 = eY.b[r];
+                    const int lane4 = 4 * lane;
+                    float bM = 0.f, bXs = 0.f, bXl = 0.f, bYs = 0.f, bYl = 0.f;  // this cell's emission posteriors
+                    // (x-1, y-1) on d-2, same slot
+                    if (lanes_of(here & cell_mask<R>(jl2, q2.n, r))) {
+                        const Cell &Fm = G2.c[r];
+                        const int s = min(max(Fm.e + c.e - tot_e, -200), 200);
+                        const float em = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, em) + 5 * ex4 + ey4);
+                        const float w = __builtin_ldexpf(em * c.m * inv_tot, s);
+                        const float t0 = Fm.m * tr.mm * w, t1 = Fm.sx * tr.sxm * w, t2 = Fm.sy * tr.sym * w, t3 = Fm.lx * tr.lxm * w,
+                                    t4 = Fm.ly * tr.lym * w;
+                        acc[0] += t0, acc[1] += t1, acc[2] += t2, acc[3] += t3, acc[4] += t4;
+                        bM = (t0 + t1) + (t2 + t3) + t4;
+                    }
+                    // (x-1, y) on d-1: same slot after an X-step into d, one slot below after a Y-step
+                    if (lanes_of(here & cell_mask<R>((d & 1) ? jl1 : jl1 + 1, q1.n, r))) {
+                        const Cell &Fl = (d & 1) ? G1.c[r] : Gs.c[r];
+                        const int s = min(max(Fl.e + c.e - tot_e, -200), 200);
+                        const float g = __builtin_ldexpf(inv_tot, s);
+                        const float exs = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 20 + ex4);
+                        const float exl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 60 + ex4);
+                        const float ws = exs * c.sx * g, wl = exl * c.lx * g;
+                        const float t0 = Fl.m * tr.msx * ws, t1 = Fl.sx * tr.sxsx * ws, t2 = Fl.sy * tr.sysx * ws;
+                        const float u0 = Fl.m * tr.mlx * wl, u1 = Fl.lx * tr.lxlx * wl;
+                        acc[5] += t0, acc[6] += t1, acc[7] += t2, acc[8] += u0, acc[9] += u1;
+                        bXs = (t0 + t1) + t2, bXl = u0 + u1;
+                    }
+                    // (x, y-1) on d-1: one slot above after an X-step into d, same slot after a Y-step
+                    if (lanes_of(here & cell_mask<R>((d & 1) ? jl1 - 1 : jl1, q1.n, r))) {
+                        const Cell &Fu = (d & 1) ? Gs.c[r] : G1.c[r];
+                        const int s = min(max(Fu.e + c.e - tot_e, -200), 200);
+                        const float g = __builtin_ldexpf(inv_tot, s);
+                        const float eys = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 40 + ey4);
+                        const float eyl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 80 + ey4);
+                        const float ws = eys * c.sy * g, wl = eyl * c.ly * g;
+                        const float t0 = Fu.m * tr.msy * ws, t1 = Fu.sy * tr.sysy * ws, t2 = Fu.sx * tr.sxsy * ws;
+                        const float u0 = Fu.m * tr.mly * wl, u1 = Fu.ly * tr.lyly * wl;
+                        acc[10] += t0, acc[11] += t1, acc[12] += t2, acc[13] += u0, acc[14] += u1;
+                        bYs = (t0 + t1) + t2, bYl = u0 + u1;
+                    }
+                    // the five bins of this cell (disjoint tables): all reads, then all writes -- one LDS round trip
+                    // per cell.  An N base goes to a scratch row (row EM_BINS + 14, overwritten by the final reduction).
+                    if (lanes_of(here)) {
+                        constexpr int TRASH = (EM_BINS + 14) * 256;
+                        const bool nx = ex4 >= 16, ny = ey4 >= 16;
+                        const int aM = ((nx || ny) ? TRASH : ex4 * 256 + ey4 * 64) + lane4;
+                        const int aXs = (nx ? TRASH : 16 * 256 + ex4 * 64) + lane4, aXl = (nx ? TRASH : 20 * 256 + ex4 * 64) + lane4;
+                        const int aYs = (ny ? TRASH : 24 * 256 + ey4 * 64) + lane4, aYl = (ny ? TRASH : 28 * 256 + ey4 * 64) + lane4;
+                        const float v0 = bin_at(lbins, aM), v1 = bin_at(lbins, aXs), v2 = bin_at(lbins, aXl), v3 = bin_at(lbins, aYs),
+                                    v4 = bin_at(lbins, aYl);
+                        bin_at(lbins, aM) = v0 + bM;
+                        bin_at(lbins, aXs) = v1 + bXs;
+                        bin_at(lbins, aXl) = v2 + bXl;
+                        bin_at(lbins, aYs) = v3 + bYs;
+                        bin_at(lbins, aYl) = v4 + bYl;
+                    }
+                }
+                // ---- on to anti-diagonal d-1: undo the rebase made before the forward step into d, then that step ----
+                if (q0.reb) {
+                    bwd_rebase<R>(E, q0.reb, A, B, S, x0, y0);
+                    if (q0.reb > 0) {
+                        diag_down_inplace<R>(G1), diag_down_inplace<R>(G2);
+                    } else {
+                        diag_up_inplace<R>(G1), diag_up_inplace<R>(G2);
+                    }
+                }
+                if ((d - 1) & 1) {
+                    bwd_y_step<R>(E, B, A, S, y0, q1);
+                } else {
+                    bwd_x_step<R>(E, A, B, S, x0, q1);
+                }
+                G1 = G2, G2 = GN;
+                q0 = q1, q1 = q2, q2 = q3, q3 = d >= 4 ? read_ctl(ctl, d - 4) : none;
+            }
+            // total from the backward side
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (jr[r] == j0) {
+                    const Cell cz = A.c[r];
+                    const float raw = dot5(mdl->start + rs * 5, cz);
+                    float bm = 0.f;
+                    int be = E_DEAD;
+                    if (raw > 0.f) {
+                        int k;
+                        bm = __builtin_frexpf(raw, &k);
+                        be = cz.e + k;
+                    }
+                    reinterpret_cast<float *>(lmisc)[2] = bm;
+                    lmisc[3] = be;
+                }
+            __syncthreads();
+            out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
+            out.btot_e = uni(lmisc[3]);
+            // transition accumulators -> LDS rows EM_BINS .. EM_BINS+14, then one lane per row sums 64 values
+#pragma unroll
+            for (int i = 0; i < 15; ++i) lbins[(EM_BINS + i) * WAVE + lane] = acc[i];
+            __syncthreads();
+            if (lane < EM_BINS + 15) {
+                double sum = 0.0;
+                for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
+                if (lane < EM_BINS) {
+                    atomicAdd(a.em_E + model * EM_BINS + lane, sum);
+                } else {
+                    const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
+                    atomicAdd(a.em_T + model * 25 + map[lane - EM_BINS], sum);
+                }
+            }
+            __syncthreads();
+        }
+        if (lane == 0) a.outs[t] = out;
+        int nt = 0;
+        if (lane == 0) nt = atomicAdd(a.queue, 1);
+        t = uni(nt) + static_cast<int>(gridDim.x);
+    }
+}
+
 }  // namespace
 
 size_t stair_lds_bytes() { return sizeof(float) * (MODEL_FLOATS + 8); }
@@ -1328,6 +1678,22 @@ int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
         hipLaunchKernelGGL((k_dp_wide<4, 8>), dim3(grid), dim3(WAVE * 8), lds, s, a);
     else if (R == 4 && NW == 12)
         hipLaunchKernelGGL((k_dp_wide<4, 12>), dim3(grid), dim3(WAVE * 12), lds, s, a);
+    else
+        return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipGetLastError());
+}
+
+size_t em_stair_lds_bytes() { return sizeof(float) * (MODEL_FLOATS + 8 + (EM_BINS + 15) * WAVE); }
+
+int launch_em_stair(const KernelArgs &a, int R, int grid, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = em_stair_lds_bytes();
+    if (R == 1)
+        hipLaunchKernelGGL(k_em_stair<1>, dim3(grid), dim3(WAVE), lds, s, a);
+    else if (R == 2)
+        hipLaunchKernelGGL(k_em_stair<2>, dim3(grid), dim3(WAVE), lds, s, a);
+    else if (R == 4)
+        hipLaunchKernelGGL(k_em_stair<4>, dim3(grid), dim3(WAVE), lds, s, a);
     else
         return static_cast<int>(hipErrorInvalidValue);
     return static_cast<int>(hipGetLastError());
