@@ -1337,35 +1337,68 @@ __device__ __forceinline__ uint64_t cell_mask(int jlo, int n, int r) {
     return hi > lo ? (low_lanes(hi) & ~low_lanes(lo)) : 0ull;
 }
 
+// The four other forward states of a row live in four planes of the second scratch region (plane p of cell i at float
+// p * stride + i, the layout k_dp_generic<EM> uses): a lane's R slots are R consecutive floats of a plane, so every
+// store / load instruction moves one contiguous 256*R-byte run per wavefront -- whole cache lines.  (A float4 per slot
+// wrote each line in R instalments and quadrupled the bytes that reached HBM.)
 template <int R>
-__device__ __forceinline__ void store_row_x(char *Fx, const Diag<R> &C, const Ctl &ct, int lane) {
+__device__ __forceinline__ void plane_store(__amdgpu_buffer_rsrc_t rs, int voff, const float (&v)[R]) {
+    if constexpr (R == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(fbits(v[0]), rs, voff, 0, 0);
+    } else if constexpr (R == 2) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(v[0]), fbits(v[1])}, rs, voff, 0, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(v[0]), fbits(v[1]), fbits(v[2]), fbits(v[3])}, rs, voff, 0, 0);
+    }
+}
+template <int R>
+__device__ __forceinline__ void plane_load(__amdgpu_buffer_rsrc_t rs, int voff, float (&v)[R]) {
+    if constexpr (R == 1) {
+        v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+    } else if constexpr (R == 2) {
+        const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+        v[0] = bitsf(q.x), v[1] = bitsf(q.y);
+    } else {
+        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+        v[0] = bitsf(q.x), v[1] = bitsf(q.y), v[2] = bitsf(q.z), v[3] = bitsf(q.w);
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void store_row_x(char *Fx, int64_t stride, const Diag<R> &C, const Ctl &ct, int lane) {
     const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Fx + (static_cast<int64_t>(ct.co) - R * mk.l0) * 16, 0, -1, 0x00020000);
+    const int64_t first = static_cast<int64_t>(ct.co) - R * mk.l0;
     if (lanes_of(mk.lanes)) {
+        float sx[R], sy[R], lx[R], ly[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[r].sx), fbits(C.c[r].sy), fbits(C.c[r].lx), fbits(C.c[r].ly)}, rs,
-                                                   16 * (R * lane + r), 0, 0);
+        for (int r = 0; r < R; ++r) sx[r] = C.c[r].sx, sy[r] = C.c[r].sy, lx[r] = C.c[r].lx, ly[r] = C.c[r].ly;
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (first) * 4, 0, -1, 0x00020000), 4 * R * lane, sx);
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, sy);
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (2 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, lx);
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (3 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, ly);
     }
 }
 
 // the forward cells of the row `ct` into G, seen from a frame in which slot j is the row's slot j + shift
 template <int R>
-__device__ __forceinline__ void load_full_row(char *F, char *Fx, Diag<R> &G, const Ctl &ct, int shift, int lane) {
+__device__ __forceinline__ void load_full_row(char *F, char *Fx, int64_t stride, Diag<R> &G, const Ctl &ct, int shift, int lane) {
     constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
     uint64_t lanes = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) lanes |= cell_mask<R>(ct.jlo - shift, ct.n, r);
     const int64_t first = static_cast<int64_t>(ct.co) - R * (ct.jlo >> SH) + shift;  // cell index of this frame's slot 0
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(F + first * 8, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(Fx + first * 16, 0, -1, 0x00020000);
     if (lanes_of(lanes)) {
+        float sx[R], sy[R], lx[R], ly[R];
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (first) * 4, 0, -1, 0x00020000), 4 * R * lane, sx);
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, sy);
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (2 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, lx);
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (3 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, ly);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * (R * lane + r), 0, 0);
-            const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rx, 16 * (R * lane + r), 0, 0);
             G.c[r].m = bitsf(q.x), G.c[r].e = q.y;
-            G.c[r].sx = bitsf(g.x), G.c[r].sy = bitsf(g.y), G.c[r].lx = bitsf(g.z), G.c[r].ly = bitsf(g.w);
+            G.c[r].sx = sx[r], G.c[r].sy = sy[r], G.c[r].lx = lx[r], G.c[r].ly = ly[r];
         }
     }
 }
@@ -1373,6 +1406,77 @@ __device__ __forceinline__ void load_full_row(char *F, char *Fx, Diag<R> &G, con
 // per-lane emission bins in LDS: bin b of lane l at float b * 64 + l (byte b * 256 + 4 * l)
 __device__ __forceinline__ float &bin_at(float *lbins, int byte_off) {
     return *reinterpret_cast<float *>(reinterpret_cast<char *>(lbins) + byte_off);
+}
+
+// Expected counts of the transitions into the cells of one anti-diagonal d (`io`: its backward cells; G1 / G2: the
+// forward cells of d-1 / d-2 in the frame of d; eX / eY: the bases consumed into each cell).  ODD: d is odd, i.e. the
+// forward step into d was an X-step.
+template <int R, bool ODD>
+__device__ __forceinline__ void em_cells(const StepEnv &E, const Diag<R> &io, const Diag<R> &G1, const Diag<R> &G2, const Bases<R> &eX,
+                                         const Bases<R> &eY, const Masks<R> &mk, int jl1, int n1, int jl2, int n2, int tot_e,
+                                         float inv_tot, float (&acc)[15], float *lbins, int lane) {
+        const Diag<R> Gs = ODD ? shift_up<R>(G1) : shift_down<R>(G1);  // the d-1 predecessor one slot away
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const Cell c = io.c[r];
+            const uint64_t here = __ballot(c.e != E_DEAD) & mk.cell[r];
+            const int ex4 = eX.b[r], ey4 = eY.b[r];
+            const int lane4 = 4 * lane;
+            float bM = 0.f, bXs = 0.f, bXl = 0.f, bYs = 0.f, bYl = 0.f;  // this cell's emission posteriors
+            // (x-1, y-1) on d-2, same slot
+            if (lanes_of(here & cell_mask<R>(jl2, n2, r))) {
+                const Cell &Fm = G2.c[r];
+                const int s = min(max(Fm.e + c.e - tot_e, -200), 200);
+                const float em = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, em) + 5 * ex4 + ey4);
+                const float w = __builtin_ldexpf(em * c.m * inv_tot, s);
+                const float t0 = Fm.m * E.tr.mm * w, t1 = Fm.sx * E.tr.sxm * w, t2 = Fm.sy * E.tr.sym * w, t3 = Fm.lx * E.tr.lxm * w,
+                            t4 = Fm.ly * E.tr.lym * w;
+                acc[0] += t0, acc[1] += t1, acc[2] += t2, acc[3] += t3, acc[4] += t4;
+                bM = (t0 + t1) + (t2 + t3) + t4;
+            }
+            // (x-1, y) on d-1: same slot after an X-step into d, one slot below after a Y-step
+            if (lanes_of(here & cell_mask<R>(ODD ? jl1 : jl1 + 1, n1, r))) {
+                const Cell &Fl = ODD ? G1.c[r] : Gs.c[r];
+                const int s = min(max(Fl.e + c.e - tot_e, -200), 200);
+                const float g = __builtin_ldexpf(inv_tot, s);
+                const float exs = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 20 + ex4);
+                const float exl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 60 + ex4);
+                const float ws = exs * c.sx * g, wl = exl * c.lx * g;
+                const float t0 = Fl.m * E.tr.msx * ws, t1 = Fl.sx * E.tr.sxsx * ws, t2 = Fl.sy * E.tr.sysx * ws;
+                const float u0 = Fl.m * E.tr.mlx * wl, u1 = Fl.lx * E.tr.lxlx * wl;
+                acc[5] += t0, acc[6] += t1, acc[7] += t2, acc[8] += u0, acc[9] += u1;
+                bXs = (t0 + t1) + t2, bXl = u0 + u1;
+            }
+            // (x, y-1) on d-1: one slot above after an X-step into d, same slot after a Y-step
+            if (lanes_of(here & cell_mask<R>(ODD ? jl1 - 1 : jl1, n1, r))) {
+                const Cell &Fu = ODD ? Gs.c[r] : G1.c[r];
+                const int s = min(max(Fu.e + c.e - tot_e, -200), 200);
+                const float g = __builtin_ldexpf(inv_tot, s);
+                const float eys = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 40 + ey4);
+                const float eyl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 80 + ey4);
+                const float ws = eys * c.sy * g, wl = eyl * c.ly * g;
+                const float t0 = Fu.m * E.tr.msy * ws, t1 = Fu.sy * E.tr.sysy * ws, t2 = Fu.sx * E.tr.sxsy * ws;
+                const float u0 = Fu.m * E.tr.mly * wl, u1 = Fu.ly * E.tr.lyly * wl;
+                acc[10] += t0, acc[11] += t1, acc[12] += t2, acc[13] += u0, acc[14] += u1;
+                bYs = (t0 + t1) + t2, bYl = u0 + u1;
+            }
+            // the five bins of this cell (disjoint tables): all reads, then all writes -- one LDS round trip
+            // per cell.  An N base goes to a scratch row (row EM_BINS + 14, overwritten by the final reduction).
+            if (lanes_of(here)) {
+                constexpr int TRASH = (EM_BINS + 14) * 256;
+                const bool nx = ex4 >= 16, ny = ey4 >= 16;
+                const int aM = ((nx || ny) ? TRASH : ex4 * 256 + ey4 * 64) + lane4;
+                const int aXs = (nx ? TRASH : 16 * 256 + ex4 * 64) + lane4, aXl = (nx ? TRASH : 20 * 256 + ex4 * 64) + lane4;
+                const int aYs = (ny ? TRASH : 24 * 256 + ey4 * 64) + lane4, aYl = (ny ? TRASH : 28 * 256 + ey4 * 64) + lane4;
+                const float v0 = bin_at(lbins, aM), v1 = bin_at(lbins, aXs), v2 = bin_at(lbins, aXl), v3 = bin_at(lbins, aYs),
+                            v4 = bin_at(lbins, aYl);
+                bin_at(lbins, aM) = v0 + bM;
+                bin_at(lbins, aXs) = v1 + bXs;
+                bin_at(lbins, aXl) = v2 + bXl;
+                bin_at(lbins, aYs) = v3 + bYs;
+                bin_at(lbins, aYl) = v4 + bYl;
+            }
+        }
 }
 
 template <int R>
@@ -1410,12 +1514,7 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
         E.ltab = reinterpret_cast<const char *>(lmodel);
         E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
         {
-            Trans tr = load_trans(E.mdl->T);
-            tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
-            tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
-            tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
-            tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
-            E.tr = tr;
+            E.tr = load_trans(E.mdl->T);  // in VGPRs: every count multiplies by one, and the scalar file is short here
         }
         const Trans &tr = E.tr;
         const DevModel *mdl = E.mdl;
@@ -1443,16 +1542,16 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                 normalise(c, 0);
                 A.c[r] = c;
             }
-        store_row<R>(F, A, c0, voff), store_row_x<R>(Fx, A, c0, lane);
+        store_row<R>(F, A, c0, voff), store_row_x<R>(Fx, a.slot_stride, A, c0, lane);
         for (int d = 1; d <= D; ++d) {
             const Ctl ct = read_ctl(ctl, d);
             if (ct.reb) fwd_rebase<R>(E, ct.reb, A, B, S, x0, y0);
             if (d & 1) {
                 fwd_x_step<R>(E, B, A, S, x0, ct);
-                store_row<R>(F, B, ct, voff), store_row_x<R>(Fx, B, ct, lane);
+                store_row<R>(F, B, ct, voff), store_row_x<R>(Fx, a.slot_stride, B, ct, lane);
             } else {
                 fwd_y_step<R>(E, A, B, S, y0, ct);
-                store_row<R>(F, A, ct, voff), store_row_x<R>(Fx, A, ct, lane);
+                store_row<R>(F, A, ct, voff), store_row_x<R>(Fx, a.slot_stride, A, ct, lane);
             }
         }
         {
@@ -1513,13 +1612,12 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
             feed_init<-1>(S.fy, E.Y, lY, y0 - 64 * R, lane);
             // forward cells of d-1 and d-2 in the frame of d; GN: those of d-3 in the frame of d-1, loaded one ahead
             Diag<R> G1 = dead_diag<R>(), G2 = dead_diag<R>(), GN = dead_diag<R>();
-            if (D >= 1) load_full_row<R>(F, Fx, G1, q1, q0.reb, lane);
-            if (D >= 2) load_full_row<R>(F, Fx, G2, q2, q1.reb + q0.reb, lane);
+            if (D >= 1) load_full_row<R>(F, Fx, a.slot_stride, G1, q1, q0.reb, lane);
+            if (D >= 2) load_full_row<R>(F, Fx, a.slot_stride, G2, q2, q1.reb + q0.reb, lane);
 
             for (int d = D; d >= 1; --d) {
                 // prefetch for the next anti-diagonal: forward cells of d-3 in the frame of d-1
-                if (d >= 3) load_full_row<R>(F, Fx, GN, q3, q2.reb + q1.reb, lane);
-                Diag<R> &io = (d & 1) ? B : A;
+                if (d >= 3) load_full_row<R>(F, Fx, a.slot_stride, GN, q3, q2.reb + q1.reb, lane);
                 // ---- expected counts of the transitions into the cells of d ----
                 const Masks<R> mk = band_masks<R>(q0.jlo, q0.n);
                 const int jl1 = q1.jlo - q0.reb, jl2 = q2.jlo - q1.reb - q0.reb;
@@ -1534,67 +1632,10 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                     for (int r = 0; r + 1 < R; ++r) eY.b[r] = S.Y.b[r + 1];
                     eY.b[R - 1] = dpp_from_above(S.Y.b[0], injy);
                 }
-                const Diag<R> Gs = (d & 1) ? shift_up<R>(G1) : shift_down<R>(G1);  // the d-1 predecessor one slot away
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const Cell c = io.c[r];
-                    const uint64_t here = __ballot(c.e != E_DEAD) & mk.cell[r];
-                    const int ex4 = eX.b[r], ey4 = eY.b[r];
-                    const int lane4 = 4 * lane;
-                    float bM = 0.f, bXs = 0.f, bXl = 0.f, bYs = 0.f, bYl = 0.f;  // this cell's emission posteriors
-                    // (x-1, y-1) on d-2, same slot
-                    if (lanes_of(here & cell_mask<R>(jl2, q2.n, r))) {
-                        const Cell &Fm = G2.c[r];
-                        const int s = min(max(Fm.e + c.e - tot_e, -200), 200);
-                        const float em = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, em) + 5 * ex4 + ey4);
-                        const float w = __builtin_ldexpf(em * c.m * inv_tot, s);
-                        const float t0 = Fm.m * tr.mm * w, t1 = Fm.sx * tr.sxm * w, t2 = Fm.sy * tr.sym * w, t3 = Fm.lx * tr.lxm * w,
-                                    t4 = Fm.ly * tr.lym * w;
-                        acc[0] += t0, acc[1] += t1, acc[2] += t2, acc[3] += t3, acc[4] += t4;
-                        bM = (t0 + t1) + (t2 + t3) + t4;
-                    }
-                    // (x-1, y) on d-1: same slot after an X-step into d, one slot below after a Y-step
-                    if (lanes_of(here & cell_mask<R>((d & 1) ? jl1 : jl1 + 1, q1.n, r))) {
-                        const Cell &Fl = (d & 1) ? G1.c[r] : Gs.c[r];
-                        const int s = min(max(Fl.e + c.e - tot_e, -200), 200);
-                        const float g = __builtin_ldexpf(inv_tot, s);
-                        const float exs = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 20 + ex4);
-                        const float exl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 60 + ex4);
-                        const float ws = exs * c.sx * g, wl = exl * c.lx * g;
-                        const float t0 = Fl.m * tr.msx * ws, t1 = Fl.sx * tr.sxsx * ws, t2 = Fl.sy * tr.sysx * ws;
-                        const float u0 = Fl.m * tr.mlx * wl, u1 = Fl.lx * tr.lxlx * wl;
-                        acc[5] += t0, acc[6] += t1, acc[7] += t2, acc[8] += u0, acc[9] += u1;
-                        bXs = (t0 + t1) + t2, bXl = u0 + u1;
-                    }
-                    // (x, y-1) on d-1: one slot above after an X-step into d, same slot after a Y-step
-                    if (lanes_of(here & cell_mask<R>((d & 1) ? jl1 - 1 : jl1, q1.n, r))) {
-                        const Cell &Fu = (d & 1) ? Gs.c[r] : G1.c[r];
-                        const int s = min(max(Fu.e + c.e - tot_e, -200), 200);
-                        const float g = __builtin_ldexpf(inv_tot, s);
-                        const float eys = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 40 + ey4);
-                        const float eyl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 80 + ey4);
-                        const float ws = eys * c.sy * g, wl = eyl * c.ly * g;
-                        const float t0 = Fu.m * tr.msy * ws, t1 = Fu.sy * tr.sysy * ws, t2 = Fu.sx * tr.sxsy * ws;
-                        const float u0 = Fu.m * tr.mly * wl, u1 = Fu.ly * tr.lyly * wl;
-                        acc[10] += t0, acc[11] += t1, acc[12] += t2, acc[13] += u0, acc[14] += u1;
-                        bYs = (t0 + t1) + t2, bYl = u0 + u1;
-                    }
-                    // the five bins of this cell (disjoint tables): all reads, then all writes -- one LDS round trip
-                    // per cell.  An N base goes to a scratch row (row EM_BINS + 14, overwritten by the final reduction).
-                    if (lanes_of(here)) {
-                        constexpr int TRASH = (EM_BINS + 14) * 256;
-                        const bool nx = ex4 >= 16, ny = ey4 >= 16;
-                        const int aM = ((nx || ny) ? TRASH : ex4 * 256 + ey4 * 64) + lane4;
-                        const int aXs = (nx ? TRASH : 16 * 256 + ex4 * 64) + lane4, aXl = (nx ? TRASH : 20 * 256 + ex4 * 64) + lane4;
-                        const int aYs = (ny ? TRASH : 24 * 256 + ey4 * 64) + lane4, aYl = (ny ? TRASH : 28 * 256 + ey4 * 64) + lane4;
-                        const float v0 = bin_at(lbins, aM), v1 = bin_at(lbins, aXs), v2 = bin_at(lbins, aXl), v3 = bin_at(lbins, aYs),
-                                    v4 = bin_at(lbins, aYl);
-                        bin_at(lbins, aM) = v0 + bM;
-                        bin_at(lbins, aXs) = v1 + bXs;
-                        bin_at(lbins, aXl) = v2 + bXl;
-                        bin_at(lbins, aYs) = v3 + bYs;
-                        bin_at(lbins, aYl) = v4 + bYl;
-                    }
+                if (d & 1) {
+                    em_cells<R, true>(E, B, G1, G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
+                } else {
+                    em_cells<R, false>(E, A, G1, G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
                 }
                 // ---- on to anti-diagonal d-1: undo the rebase made before the forward step into d, then that step ----
                 if (q0.reb) {
