@@ -994,10 +994,10 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         L l{};
         l.first = dl.first, l.count = dl.count;
         if (kClassTab[dl.cls].kind == K_STAIR && !std::getenv("NPR_EM_GENERIC")) {
-            // 100 / 149 / 193 VGPRs and 12.5 KiB of LDS bins per wavefront: 12 / 12 / 8 wavefronts per CU
+            // 127 / 161 / 223 VGPRs and 9 KiB of LDS bins per wavefront: 16 / 12 / 8 wavefronts per CU
             l.stair_R = kClassTab[dl.cls].R;
             l.lds = em_stair_lds_bytes();
-            int em_waves = l.stair_R == 4 ? 8 : 12;
+            int em_waves = l.stair_R == 4 ? 8 : (l.stair_R == 2 ? 12 : 16);
             if (const char *w = std::getenv("NPR_EM_WAVES")) em_waves = std::max(1, std::atoi(w));  // bring-up
             l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * em_waves)));
             launches.push_back(l);

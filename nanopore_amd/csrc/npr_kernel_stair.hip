@@ -1461,7 +1461,7 @@ __device__ __forceinline__ void em_cells(const StepEnv &E, const Diag<R> &io, co
                 bYs = (t0 + t1) + t2, bYl = u0 + u1;
             }
             // the five bins of this cell (disjoint tables): all reads, then all writes -- one LDS round trip
-            // per cell.  An N base goes to a scratch row (row EM_BINS + 14, overwritten by the final reduction).
+            // per cell.  An N base goes to a scratch row (row EM_BINS).
             if (lanes_of(here)) {
                 constexpr int TRASH = (EM_BINS + 14) * 256;
                 const bool nx = ex4 >= 16, ny = ey4 >= 16;
@@ -1484,7 +1484,7 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmodel = reinterpret_cast<float *>(smem);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // 8 ints: cell hand-off
-    float *lbins = reinterpret_cast<float *>(lmisc + 8);          // (EM_BINS + 15) rows of 64 lanes
+    float *lbins = reinterpret_cast<float *>(lmisc + 8);          // EM_BINS + 1 rows of 64 lanes (the last: scratch row for N bases)
 
     const int lane = threadIdx.x;
     char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
@@ -1673,19 +1673,23 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
             __syncthreads();
             out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
             out.btot_e = uni(lmisc[3]);
-            // transition accumulators -> LDS rows EM_BINS .. EM_BINS+14, then one lane per row sums 64 values
-#pragma unroll
-            for (int i = 0; i < 15; ++i) lbins[(EM_BINS + i) * WAVE + lane] = acc[i];
+            // emission bins: one lane per bin sums its 64 columns; then the 15 transition accumulators go through the
+            // same rows
             __syncthreads();
-            if (lane < EM_BINS + 15) {
+            if (lane < EM_BINS) {
                 double sum = 0.0;
                 for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
-                if (lane < EM_BINS) {
-                    atomicAdd(a.em_E + model * EM_BINS + lane, sum);
-                } else {
-                    const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
-                    atomicAdd(a.em_T + model * 25 + map[lane - EM_BINS], sum);
-                }
+                atomicAdd(a.em_E + model * EM_BINS + lane, sum);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 15; ++i) lbins[i * WAVE + lane] = acc[i];
+            __syncthreads();
+            if (lane < 15) {
+                double sum = 0.0;
+                for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
+                const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
+                atomicAdd(a.em_T + model * 25 + map[lane], sum);
             }
             __syncthreads();
         }
@@ -1724,7 +1728,7 @@ int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
     return static_cast<int>(hipGetLastError());
 }
 
-size_t em_stair_lds_bytes() { return sizeof(float) * (MODEL_FLOATS + 8 + (EM_BINS + 15) * WAVE); }
+size_t em_stair_lds_bytes() { return sizeof(float) * (MODEL_FLOATS + 8 + (EM_BINS + 1) * WAVE); }
 
 int launch_em_stair(const KernelArgs &a, int R, int grid, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
