@@ -1320,9 +1320,9 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
 // training alignments, so this pass runs hundreds of times per trained model).  Same frame-based sweep as k_dp_stair;
 //   * the forward sweep stores ALL five states of every cell (the (m, e) pairs as k_dp_stair does, plus a float4
 //     (sx, sy, lx, ly) per slot in a second scratch region);
-//   * the backward sweep keeps the forward cells of the two anti-diagonals BELOW the current one in registers (loaded
-//     one anti-diagonal ahead, with a slot shift that undoes the frame rebases in between, and moved in place by the
-//     backward rebases like everything else) and, after finishing a backward cell, adds the posterior probability of
+//   * the backward sweep holds the forward cells of the two anti-diagonals BELOW the current one in registers (loaded
+//     for every anti-diagonal with a slot shift that undoes the frame rebases in between: rows are slot-linear in
+//     memory, so a shifted row is just another base address) and, after finishing a backward cell, adds the posterior probability of
 //     each of the 15 transitions INTO that cell to 15 per-lane accumulators and the emitted symbols' posterior to
 //     per-lane bins in LDS (no atomics in the loop);
 //   * the wavefront reduces accumulators and bins at the end of the task: one fp64 atomic per count per task.
@@ -1610,14 +1610,14 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
             S.xcap = S.ycap = 16;
             feed_init<-1>(S.fx, E.X, lX, x0 - 1, lane);
             feed_init<-1>(S.fy, E.Y, lY, y0 - 64 * R, lane);
-            // forward cells of d-1 and d-2 in the frame of d; GN: those of d-3 in the frame of d-1, loaded one ahead
-            Diag<R> G1 = dead_diag<R>(), G2 = dead_diag<R>(), GN = dead_diag<R>();
+            // forward cells of d-1 and d-2 in the frame of d.  Both are loaded afresh for every anti-diagonal (right after
+            // their last use, so the backward step hides the latency): a row loaded once and then carried along through
+            // the rebases would lose the cells that lie outside one frame but inside the next.
+            Diag<R> G1 = dead_diag<R>(), G2 = dead_diag<R>();
             if (D >= 1) load_full_row<R>(F, Fx, a.slot_stride, G1, q1, q0.reb, lane);
             if (D >= 2) load_full_row<R>(F, Fx, a.slot_stride, G2, q2, q1.reb + q0.reb, lane);
 
             for (int d = D; d >= 1; --d) {
-                // prefetch for the next anti-diagonal: forward cells of d-3 in the frame of d-1
-                if (d >= 3) load_full_row<R>(F, Fx, a.slot_stride, GN, q3, q2.reb + q1.reb, lane);
                 // ---- expected counts of the transitions into the cells of d ----
                 const Masks<R> mk = band_masks<R>(q0.jlo, q0.n);
                 const int jl1 = q1.jlo - q0.reb, jl2 = q2.jlo - q1.reb - q0.reb;
@@ -1638,20 +1638,15 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                     em_cells<R, false>(E, A, G1, G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
                 }
                 // ---- on to anti-diagonal d-1: undo the rebase made before the forward step into d, then that step ----
-                if (q0.reb) {
-                    bwd_rebase<R>(E, q0.reb, A, B, S, x0, y0);
-                    if (q0.reb > 0) {
-                        diag_down_inplace<R>(G1), diag_down_inplace<R>(G2);
-                    } else {
-                        diag_up_inplace<R>(G1), diag_up_inplace<R>(G2);
-                    }
-                }
+                // forward cells for the next anti-diagonal, d-1: those of d-2 and d-3 in ITS frame
+                if (d >= 2) load_full_row<R>(F, Fx, a.slot_stride, G1, q2, q1.reb, lane);
+                if (d >= 3) load_full_row<R>(F, Fx, a.slot_stride, G2, q3, q2.reb + q1.reb, lane);
+                if (q0.reb) bwd_rebase<R>(E, q0.reb, A, B, S, x0, y0);
                 if ((d - 1) & 1) {
                     bwd_y_step<R>(E, B, A, S, y0, q1);
                 } else {
                     bwd_x_step<R>(E, A, B, S, x0, q1);
                 }
-                G1 = G2, G2 = GN;
                 q0 = q1, q1 = q2, q2 = q3, q3 = d >= 4 ? read_ctl(ctl, d - 4) : none;
             }
             // total from the backward side

@@ -29,9 +29,10 @@ def run(ops, W, label):
     sch = R.frame_schedule(R.make_params(band_mode=1, fixed_width=W), lX, lY, ops, 64 if W < 126 else 128, 1 if W < 126 else 2)
     d = np.abs(out["stair"] - out["generic"])
     print("%-28s W %3d: max dT %.4g of %.4g; rebases +%d -%d" % (label, W, d.max(), out["generic"].sum(), (sch["rebase"] > 0).sum(), (sch["rebase"] < 0).sum()))
-for W in (120, 60):
+for W in (50, 124):
     run([(0, 150)], W, "matches only")
-    run([(0, 100), (2, 40), (0, 100)], W, "one 40-base deletion")
-    run([(0, 100), (1, 40), (0, 100)], W, "one 40-base insertion")
-    run([(0, 60), (2, 20), (0, 60), (1, 20), (0, 60)], W, "deletion then insertion")
-    run([(0, 60), (1, 20), (0, 60), (2, 20), (0, 60)], W, "insertion then deletion")
+    run([(0, 100), (2, 60), (0, 100)], W, "one 60-base deletion")
+    run([(0, 100), (1, 60), (0, 100)], W, "one 60-base insertion")
+    run([(0, 60), (2, 45), (0, 60), (1, 50), (0, 60)], W, "deletion then insertion")
+    run([(0, 60), (1, 45), (0, 60), (2, 50), (0, 60)], W, "insertion then deletion")
+    run([(0, 10), (1, 30), (0, 10), (2, 30), (0, 10), (1, 5), (2, 5), (0, 20)], W, "short blocks")
