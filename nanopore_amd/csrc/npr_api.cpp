@@ -987,6 +987,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         size_t lds;
         bool global_ring;
         int stair_R;  // > 0: the register-kernel E-step (k_em_stair<R>), else the generic kernel
+        int wide_NW;  // > 0: stair_R slots per lane on wide_NW wavefronts per task (k_dp_wide<R, NW, EM>)
     };
     std::vector<L> launches;
     int64_t max_grid = 1;
@@ -1000,6 +1001,15 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
             int em_waves = l.stair_R == 4 ? 8 : (l.stair_R == 2 ? 12 : 16);
             if (const char *w = std::getenv("NPR_EM_WAVES")) em_waves = std::max(1, std::atoi(w));  // bring-up
             l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * em_waves)));
+            launches.push_back(l);
+            continue;
+        }
+        if (kClassTab[dl.cls].kind == K_WIDE && kClassTab[dl.cls].R == 2 && !std::getenv("NPR_EM_GENERIC")) {
+            // 157 VGPRs: 3 wavefronts per SIMD, 12 per CU -> 3 / 1 tasks per CU on 4 / 8 wavefronts each
+            l.stair_R = 2, l.wide_NW = kClassTab[dl.cls].NW;
+            const int per_cu = 12 / l.wide_NW;
+            l.lds = em_wide_lds_bytes(l.wide_NW);
+            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * per_cu)));
             launches.push_back(l);
             continue;
         }
@@ -1051,7 +1061,9 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         a.Fx = ctx->arena_Fx;
         a.em_T = d_T.p;
         a.em_E = d_E.p;
-        const int rc = l.stair_R ? launch_em_stair(a, l.stair_R, l.grid, ctx->stream) : launch_em(a, l.grid, l.lds, l.global_ring, ctx->stream);
+        const int rc = l.wide_NW   ? launch_em_wide(a, l.stair_R, l.wide_NW, l.grid, ctx->stream)
+                       : l.stair_R ? launch_em_stair(a, l.stair_R, l.grid, ctx->stream)
+                                   : launch_em(a, l.grid, l.lds, l.global_ring, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "E-step kernel launch", static_cast<hipError_t>(rc));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));

@@ -87,6 +87,8 @@ int launch_stair(const KernelArgs &a, int R, int grid, void *stream);
 int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
 int launch_em_stair(const KernelArgs &a, int R, int grid, void *stream);
 size_t em_stair_lds_bytes();
+int launch_em_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
+size_t em_wide_lds_bytes(int nw);
 size_t wide_lds_bytes(int nw);
 size_t stair_lds_bytes();
 size_t generic_lds_bytes(int wcap);

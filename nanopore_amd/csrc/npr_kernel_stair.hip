@@ -898,18 +898,194 @@ __device__ __forceinline__ bool band_near(const Ctl &ct, int sb, int width) {
     return ct.jlo - 4 < sb + width && ct.jlo + ct.n + 4 > sb;
 }
 
-template <int R, int NW>
-__global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((R == 4 && NW == 8) ? 4 : 1))) k_dp_wide(KernelArgs a) {
+// =====================================================================================================================
+// k_em_stair<R>: Baum-Welch E-step on the register kernel (SURVEY.md 8f next #2; cactus_realign --outputExpectations,
+// summed by cactus_expectationMaximisation at nanopore/analyses/utils.py:509-528 -- 3 trials x 100 iterations over the
+// training alignments, so this pass runs hundreds of times per trained model).  Same frame-based sweep as k_dp_stair;
+//   * the forward sweep stores ALL five states of every cell (the (m, e) pairs as k_dp_stair does, plus a float4
+//     (sx, sy, lx, ly) per slot in a second scratch region);
+//   * the backward sweep holds the forward cells of the two anti-diagonals BELOW the current one in registers (loaded
+//     for every anti-diagonal with a slot shift that undoes the frame rebases in between: rows are slot-linear in
+//     memory, so a shifted row is just another base address) and, after finishing a backward cell, adds the posterior probability of
+//     each of the 15 transitions INTO that cell to 15 per-lane accumulators and the emitted symbols' posterior to
+//     per-lane bins in LDS (no atomics in the loop);
+//   * the wavefront reduces accumulators and bins at the end of the task: one fp64 atomic per count per task.
+// Expected counts agree with the fp64 oracle to <= 2e-5 relative (tests/test_gpu_em.py); the summation order differs
+// from k_dp_generic<EM>, so the two are not bit-identical.
+// =====================================================================================================================
+// lanes whose slot R*lane + r lies in [jlo, jlo + n); jlo may be negative (a band seen from a shifted frame)
+template <int R>
+__device__ __forceinline__ uint64_t cell_mask(int jlo, int n, int r) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    const int lo = max(jlo - r + R - 1, 0) >> SH, hi = max(jlo + n - r + R - 1, 0) >> SH;
+    return hi > lo ? (low_lanes(hi) & ~low_lanes(lo)) : 0ull;
+}
+
+// The four other forward states of a row live in four planes of the second scratch region (plane p of cell i at float
+// p * stride + i, the layout k_dp_generic<EM> uses): a lane's R slots are R consecutive floats of a plane, so every
+// store / load instruction moves one contiguous 256*R-byte run per wavefront -- whole cache lines.  (A float4 per slot
+// wrote each line in R instalments and quadrupled the bytes that reached HBM.)
+template <int R>
+__device__ __forceinline__ void plane_store(__amdgpu_buffer_rsrc_t rs, int voff, const float (&v)[R]) {
+    if constexpr (R == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(fbits(v[0]), rs, voff, 0, 0);
+    } else if constexpr (R == 2) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(v[0]), fbits(v[1])}, rs, voff, 0, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(v[0]), fbits(v[1]), fbits(v[2]), fbits(v[3])}, rs, voff, 0, 0);
+    }
+}
+template <int R>
+__device__ __forceinline__ void plane_load(__amdgpu_buffer_rsrc_t rs, int voff, float (&v)[R]) {
+    if constexpr (R == 1) {
+        v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+    } else if constexpr (R == 2) {
+        const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+        v[0] = bitsf(q.x), v[1] = bitsf(q.y);
+    } else {
+        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+        v[0] = bitsf(q.x), v[1] = bitsf(q.y), v[2] = bitsf(q.z), v[3] = bitsf(q.w);
+    }
+}
+
+// `mk`: the lanes of THIS wavefront that hold band cells; `glane`: the lane's number across the whole frame
+template <int R>
+__device__ __forceinline__ void store_row_x(char *Fx, int64_t stride, const Diag<R> &C, const Ctl &ct, const Masks<R> &mk, int glane) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    const int lane = glane;
+    const int64_t first = static_cast<int64_t>(ct.co) - R * (ct.jlo >> SH);
+    if (lanes_of(mk.lanes)) {
+        float sx[R], sy[R], lx[R], ly[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) sx[r] = C.c[r].sx, sy[r] = C.c[r].sy, lx[r] = C.c[r].lx, ly[r] = C.c[r].ly;
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (first) * 4, 0, -1, 0x00020000), 4 * R * lane, sx);
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, sy);
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (2 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, lx);
+        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (3 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, ly);
+    }
+}
+
+// the forward cells of the row `ct` into G, seen from a frame in which slot j is the row's slot j + shift
+// (sb: first slot of this wavefront in the frame, glane: the lane's number across the whole frame; 0 / lane in k_em_stair)
+template <int R>
+__device__ __forceinline__ void load_full_row(char *F, char *Fx, int64_t stride, Diag<R> &G, const Ctl &ct, int shift, int glane, int sb = 0) {
+    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
+    const int lane = glane;
+    uint64_t lanes = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) lanes |= cell_mask<R>(ct.jlo - shift - sb, ct.n, r);
+    const int64_t first = static_cast<int64_t>(ct.co) - R * (ct.jlo >> SH) + shift;  // cell index of this frame's slot 0
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(F + first * 8, 0, -1, 0x00020000);
+    if (lanes_of(lanes)) {
+        float sx[R], sy[R], lx[R], ly[R];
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (first) * 4, 0, -1, 0x00020000), 4 * R * lane, sx);
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, sy);
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (2 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, lx);
+        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (3 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, ly);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * (R * lane + r), 0, 0);
+            G.c[r].m = bitsf(q.x), G.c[r].e = q.y;
+            G.c[r].sx = sx[r], G.c[r].sy = sy[r], G.c[r].lx = lx[r], G.c[r].ly = ly[r];
+        }
+    }
+}
+
+// per-lane emission bins in LDS: bin b of lane l at float b * 64 + l (byte b * 256 + 4 * l)
+__device__ __forceinline__ float &bin_at(float *lbins, int byte_off) {
+    return *reinterpret_cast<float *>(reinterpret_cast<char *>(lbins) + byte_off);
+}
+
+// Expected counts of the transitions into the cells of one anti-diagonal d (`io`: its backward cells; G1 / G2: the
+// forward cells of d-1 / d-2 in the frame of d, Gs: those of d-1 one slot away -- above after an X-step into d, below
+// after a Y-step; eX / eY: the bases consumed into each cell; jl1 / jl2: first band slot of d-1 / d-2 in this
+// wavefront's slot numbering).  ODD: d is odd, i.e. the
+// forward step into d was an X-step.
+template <int R, bool ODD>
+__device__ __forceinline__ void em_cells(const StepEnv &E, const Diag<R> &io, const Diag<R> &G1, const Diag<R> &Gs, const Diag<R> &G2, const Bases<R> &eX,
+                                         const Bases<R> &eY, const Masks<R> &mk, int jl1, int n1, int jl2, int n2, int tot_e,
+                                         float inv_tot, float (&acc)[15], float *lbins, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const Cell c = io.c[r];
+            const uint64_t here = __ballot(c.e != E_DEAD) & mk.cell[r];
+            const int ex4 = eX.b[r], ey4 = eY.b[r];
+            const int lane4 = 4 * lane;
+            float bM = 0.f, bXs = 0.f, bXl = 0.f, bYs = 0.f, bYl = 0.f;  // this cell's emission posteriors
+            // (x-1, y-1) on d-2, same slot
+            if (lanes_of(here & cell_mask<R>(jl2, n2, r))) {
+                const Cell &Fm = G2.c[r];
+                const int s = min(max(Fm.e + c.e - tot_e, -200), 200);
+                const float em = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, em) + 5 * ex4 + ey4);
+                const float w = __builtin_ldexpf(em * c.m * inv_tot, s);
+                const float t0 = Fm.m * E.tr.mm * w, t1 = Fm.sx * E.tr.sxm * w, t2 = Fm.sy * E.tr.sym * w, t3 = Fm.lx * E.tr.lxm * w,
+                            t4 = Fm.ly * E.tr.lym * w;
+                acc[0] += t0, acc[1] += t1, acc[2] += t2, acc[3] += t3, acc[4] += t4;
+                bM = (t0 + t1) + (t2 + t3) + t4;
+            }
+            // (x-1, y) on d-1: same slot after an X-step into d, one slot below after a Y-step
+            if (lanes_of(here & cell_mask<R>(ODD ? jl1 : jl1 + 1, n1, r))) {
+                const Cell &Fl = ODD ? G1.c[r] : Gs.c[r];
+                const int s = min(max(Fl.e + c.e - tot_e, -200), 200);
+                const float g = __builtin_ldexpf(inv_tot, s);
+                const float exs = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 20 + ex4);
+                const float exl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 60 + ex4);
+                const float ws = exs * c.sx * g, wl = exl * c.lx * g;
+                const float t0 = Fl.m * E.tr.msx * ws, t1 = Fl.sx * E.tr.sxsx * ws, t2 = Fl.sy * E.tr.sysx * ws;
+                const float u0 = Fl.m * E.tr.mlx * wl, u1 = Fl.lx * E.tr.lxlx * wl;
+                acc[5] += t0, acc[6] += t1, acc[7] += t2, acc[8] += u0, acc[9] += u1;
+                bXs = (t0 + t1) + t2, bXl = u0 + u1;
+            }
+            // (x, y-1) on d-1: one slot above after an X-step into d, same slot after a Y-step
+            if (lanes_of(here & cell_mask<R>(ODD ? jl1 - 1 : jl1, n1, r))) {
+                const Cell &Fu = ODD ? Gs.c[r] : G1.c[r];
+                const int s = min(max(Fu.e + c.e - tot_e, -200), 200);
+                const float g = __builtin_ldexpf(inv_tot, s);
+                const float eys = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 40 + ey4);
+                const float eyl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 80 + ey4);
+                const float ws = eys * c.sy * g, wl = eyl * c.ly * g;
+                const float t0 = Fu.m * E.tr.msy * ws, t1 = Fu.sy * E.tr.sysy * ws, t2 = Fu.sx * E.tr.sxsy * ws;
+                const float u0 = Fu.m * E.tr.mly * wl, u1 = Fu.ly * E.tr.lyly * wl;
+                acc[10] += t0, acc[11] += t1, acc[12] += t2, acc[13] += u0, acc[14] += u1;
+                bYs = (t0 + t1) + t2, bYl = u0 + u1;
+            }
+            // the five bins of this cell (disjoint tables): all reads, then all writes -- one LDS round trip
+            // per cell.  An N base goes to a scratch row (row EM_BINS).
+            if (lanes_of(here)) {
+                constexpr int TRASH = (EM_BINS + 14) * 256;
+                const bool nx = ex4 >= 16, ny = ey4 >= 16;
+                const int aM = ((nx || ny) ? TRASH : ex4 * 256 + ey4 * 64) + lane4;
+                const int aXs = (nx ? TRASH : 16 * 256 + ex4 * 64) + lane4, aXl = (nx ? TRASH : 20 * 256 + ex4 * 64) + lane4;
+                const int aYs = (ny ? TRASH : 24 * 256 + ey4 * 64) + lane4, aYl = (ny ? TRASH : 28 * 256 + ey4 * 64) + lane4;
+                const float v0 = bin_at(lbins, aM), v1 = bin_at(lbins, aXs), v2 = bin_at(lbins, aXl), v3 = bin_at(lbins, aYs),
+                            v4 = bin_at(lbins, aYl);
+                bin_at(lbins, aM) = v0 + bM;
+                bin_at(lbins, aXs) = v1 + bXs;
+                bin_at(lbins, aXl) = v2 + bXl;
+                bin_at(lbins, aYs) = v3 + bYs;
+                bin_at(lbins, aYl) = v4 + bYl;
+            }
+        }
+}
+
+// EM: the Baum-Welch E-step variant (k_em_stair's accumulation on this kernel's sweep; the trainer's own band --
+// splitMatrixBiggerThanThis 300, utils.py:511 -- is 256-310 cells wide, just too wide for one wavefront).  Forward
+// cells of the neighbouring anti-diagonals come from memory with a slot shift, the one-slot-away copy too, so nothing
+// but the backward cells crosses wavefronts.
+template <int R, int NW, bool EM = false>
+__global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((!EM && R == 4 && NW == 8) ? 4 : 1))) k_dp_wide(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmodel = reinterpret_cast<float *>(smem);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] pair counter, [5] next task
     const Edges<NW> ed{reinterpret_cast<float *>(lmisc + 8)};
+    float *const lbins = ed.base + Edges<NW>::floats() + (threadIdx.x >> 6) * (EM_BINS + 1) * WAVE;  // EM: this wavefront's bins
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
     const int sb = wv * 64 * R;  // first slot of this wavefront
     char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
     const int voff = 8 * R * (64 * wv + lane);
+    char *const Fx = EM ? reinterpret_cast<char *>(a.Fx) + static_cast<int64_t>(blockIdx.x) * a.slot_stride * 16 : nullptr;
     int jr[R];  // slot numbers across the whole frame
 #pragma unroll
     for (int r = 0; r < R; ++r) jr[r] = sb + R * lane + r;
@@ -934,6 +1110,8 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 c[0] = c[1] = c[2] = c[3] = c[4] = 0.f, c[5] = bitsf(E_DEAD), c[6] = c[7] = 0.f;
             }
             if (threadIdx.x == 0) lmisc[0] = 0, lmisc[1] = E_DEAD, lmisc[2] = 0, lmisc[3] = E_DEAD, lmisc[4] = 0;
+            if constexpr (EM)
+                for (int i = 0; i < EM_BINS; ++i) lbins[i * WAVE + lane] = 0.f;
         }
         __syncthreads();
         StepEnv E;
@@ -997,6 +1175,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
         {
             const LocalBand lb = local_band<R>(c0, sb);
             store_row_w<R>(F, A, c0, band_masks<R>(lb.lo, lb.n), voff);
+            if constexpr (EM) store_row_x<R>(Fx, a.slot_stride, A, c0, band_masks<R>(lb.lo, lb.n), 64 * wv + lane);
             if (live) publish<R, NW>(ed, 0, wv, A);
         }
         __syncthreads();
@@ -1060,6 +1239,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                     }
                 }
                 store_row_w<R>(F, io, ct, mk, voff);
+                if constexpr (EM) store_row_x<R>(Fx, a.slot_stride, io, ct, mk, 64 * wv + lane);
                 publish<R, NW>(ed, par, wv, io);
             }
             live = act;
@@ -1131,65 +1311,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                     if (oddD) B.c[r] = c; else A.c[r] = c;
                 }
             if (live) publish<R, NW>(ed, D & 1, wv, oddD ? B : A);
-            FRow<R> fa, fb;  // forward rows of the even / odd anti-diagonals, loaded one ahead
-#pragma unroll
-            for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
-            // (a wavefront the band does not touch leaves at once: most wavefronts of a wide frame, most of the time)
-            auto load = [&](FRow<R> &f, const Ctl &ct) {
-                if (ct.jlo + ct.n <= sb || ct.jlo >= sb + 64 * R) return;
-                const LocalBand lb = local_band<R>(ct, sb);
-                load_row_w<R>(F, f, ct, band_masks<R>(lb.lo, lb.n), voff);
-            };
-            // posteriors of anti-diagonal dd (frame at x0, y0), slots claimed from the workgroup's LDS counter
-            auto emit = [&](const Diag<R> &Bd, const FRow<R> &f, int dd, const Ctl &ct) {
-                if (ct.jlo + ct.n <= sb || ct.jlo >= sb + 64 * R) return;
-                const LocalBand lb = local_band<R>(ct, sb);
-                const Masks<R> mk = band_masks<R>(lb.lo, lb.n);
-                float p[R];
-                uint64_t hit[R];
-                int total = 0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    p[r] = posterior(f.v[r], f.e[r], Bd.c[r].m, Bd.c[r].e, tot_e, inv_tot);
-                    hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
-                    total += __popcll(hit[r]);
-                }
-                if (dd >= 2 && total) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(lmisc + 4, total);
-                    base = uni(base);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (hit[r]) {
-                            const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
-                            const int slot = base + before;
-                            if (__builtin_amdgcn_inverse_ballot_w64(hit[r]) && slot < sink.cap) {
-                                sink.px[sink.off + slot] = x0 + jr[r] - 1 + sink.xs;
-                                sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
-                                sink.pp[sink.off + slot] = p[r];
-                            }
-                            base += __popcll(hit[r]);
-                        }
-                    }
-                }
-            };
-            Ctl nxt = cur;
-            if (oddD) {
-                load(fb, cur);
-                nxt = read_ctl(ctl, D - 1);
-                load(fa, nxt);
-                emit(B, fb, D, cur);
-            } else {
-                load(fa, cur);
-                if (D >= 1) {
-                    nxt = read_ctl(ctl, D - 1);
-                    load(fb, nxt);
-                }
-                emit(A, fa, D, cur);
-            }
             lds_barrier();
-
             // one backward step into anti-diagonal dd: undoes the rebase `reb` made before the forward step into dd + 1,
             // then that step (an X-step when dd is even)
             auto bwd = [&](int dd, Diag<R> &io, Diag<R> &s1, const Ctl &ct, int reb) {
@@ -1255,6 +1377,133 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 live = act;
             };
 
+            if constexpr (EM) {
+                // ---- expected counts (see k_em_stair); q0, q1, q2: control words of d, d-1, d-2 ----
+                float acc[15];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) acc[i] = 0.f;
+                Diag<R> G1 = dead_diag<R>(), Gs = dead_diag<R>(), G2 = dead_diag<R>();
+                const Ctl none{0u, 0, 0, 0};
+                const int glane = 64 * wv + lane;
+                // forward cells for the counts of anti-diagonal d, in ITS frame: d-1 (and one slot away), d-2
+                auto em_load = [&](int d, const Ctl &q0, const Ctl &q1, const Ctl &q2) {
+                    if (!band_near(q0, sb, 64 * R)) return;
+                    if (d >= 1) {
+                        load_full_row<R>(F, Fx, a.slot_stride, G1, q1, q0.reb, glane, sb);
+                        load_full_row<R>(F, Fx, a.slot_stride, Gs, q1, q0.reb + ((d & 1) ? 1 : -1), glane, sb);
+                    }
+                    if (d >= 2) load_full_row<R>(F, Fx, a.slot_stride, G2, q2, q1.reb + q0.reb, glane, sb);
+                };
+                auto em_acc = [&](int d, const Ctl &q0, const Ctl &q1, const Ctl &q2) {
+                    if (!live) return;
+                    const LocalBand lb = local_band<R>(q0, sb);
+                    const Masks<R> mk = band_masks<R>(lb.lo, lb.n);
+                    const int jl1 = q1.jlo - q0.reb - sb, jl2 = q2.jlo - q1.reb - q0.reb - sb;
+                    Bases<R> eX, eY;  // X[x-1] = slot j-1 of the X stream, Y[y-1] = slot j+1 of the Y stream
+                    const int injx = feed_peek<-1>(S.fx, x0 + sb - 1), injy = feed_peek<-1>(S.fy, y0 - sb - 64 * R);
+#pragma unroll
+                    for (int r = 1; r < R; ++r) eX.b[r] = S.X.b[r - 1];
+                    eX.b[0] = dpp_from_below(S.X.b[R - 1], injx);
+#pragma unroll
+                    for (int r = 0; r + 1 < R; ++r) eY.b[r] = S.Y.b[r + 1];
+                    eY.b[R - 1] = dpp_from_above(S.Y.b[0], injy);
+                    if (d & 1) {
+                        em_cells<R, true>(E, B, G1, Gs, G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
+                    } else {
+                        em_cells<R, false>(E, A, G1, Gs, G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
+                    }
+                };
+                Ctl q0 = cur, q1 = D >= 1 ? read_ctl(ctl, D - 1) : none, q2 = D >= 2 ? read_ctl(ctl, D - 2) : none;
+                em_load(D, q0, q1, q2);
+                for (int d = D; d >= 1; --d) {
+                    em_acc(d, q0, q1, q2);
+                    const int reb = q0.reb;
+                    q0 = q1, q1 = q2, q2 = d >= 3 ? read_ctl(ctl, d - 3) : none;
+                    em_load(d - 1, q0, q1, q2);  // before the step: it hides the latency
+                    if ((d - 1) & 1) {
+                        bwd(d - 1, B, A, q0, reb);
+                    } else {
+                        bwd(d - 1, A, B, q0, reb);
+                    }
+                    lds_barrier();
+                }
+                // this wavefront's bins and accumulators -> the model's global counts
+                __syncthreads();
+                if (lane < EM_BINS) {
+                    double sum = 0.0;
+                    for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
+                    atomicAdd(a.em_E + model * EM_BINS + lane, sum);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 15; ++i) lbins[i * WAVE + lane] = acc[i];
+                __syncthreads();
+                if (lane < 15) {
+                    double sum = 0.0;
+                    for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
+                    const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
+                    atomicAdd(a.em_T + model * 25 + map[lane], sum);
+                }
+                __syncthreads();
+            } else {
+            FRow<R> fa, fb;  // forward rows of the even / odd anti-diagonals, loaded one ahead
+#pragma unroll
+            for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
+            // (a wavefront the band does not touch leaves at once: most wavefronts of a wide frame, most of the time)
+            auto load = [&](FRow<R> &f, const Ctl &ct) {
+                if (ct.jlo + ct.n <= sb || ct.jlo >= sb + 64 * R) return;
+                const LocalBand lb = local_band<R>(ct, sb);
+                load_row_w<R>(F, f, ct, band_masks<R>(lb.lo, lb.n), voff);
+            };
+            // posteriors of anti-diagonal dd (frame at x0, y0), slots claimed from the workgroup's LDS counter
+            auto emit = [&](const Diag<R> &Bd, const FRow<R> &f, int dd, const Ctl &ct) {
+                if (ct.jlo + ct.n <= sb || ct.jlo >= sb + 64 * R) return;
+                const LocalBand lb = local_band<R>(ct, sb);
+                const Masks<R> mk = band_masks<R>(lb.lo, lb.n);
+                float p[R];
+                uint64_t hit[R];
+                int total = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    p[r] = posterior(f.v[r], f.e[r], Bd.c[r].m, Bd.c[r].e, tot_e, inv_tot);
+                    hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
+                    total += __popcll(hit[r]);
+                }
+                if (dd >= 2 && total) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(lmisc + 4, total);
+                    base = uni(base);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (hit[r]) {
+                            const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                            const int slot = base + before;
+                            if (__builtin_amdgcn_inverse_ballot_w64(hit[r]) && slot < sink.cap) {
+                                sink.px[sink.off + slot] = x0 + jr[r] - 1 + sink.xs;
+                                sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
+                                sink.pp[sink.off + slot] = p[r];
+                            }
+                            base += __popcll(hit[r]);
+                        }
+                    }
+                }
+            };
+            Ctl nxt = cur;
+            if (oddD) {
+                load(fb, cur);
+                nxt = read_ctl(ctl, D - 1);
+                load(fa, nxt);
+                emit(B, fb, D, cur);
+            } else {
+                load(fa, cur);
+                if (D >= 1) {
+                    nxt = read_ctl(ctl, D - 1);
+                    load(fb, nxt);
+                }
+                emit(A, fa, D, cur);
+            }
+            
             int d2 = D - 1;
             if (oddD) {
                 const int reb = cur.reb;
@@ -1286,6 +1535,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                 emit(A, fa, d2 - 1, cur);
                 lds_barrier();
             }
+            }
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -1314,170 +1564,6 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
     }
 }
 
-// =====================================================================================================================
-// k_em_stair<R>: Baum-Welch E-step on the register kernel (SURVEY.md 8f next #2; cactus_realign --outputExpectations,
-// summed by cactus_expectationMaximisation at nanopore/analyses/utils.py:509-528 -- 3 trials x 100 iterations over the
-// training alignments, so this pass runs hundreds of times per trained model).  Same frame-based sweep as k_dp_stair;
-//   * the forward sweep stores ALL five states of every cell (the (m, e) pairs as k_dp_stair does, plus a float4
-//     (sx, sy, lx, ly) per slot in a second scratch region);
-//   * the backward sweep holds the forward cells of the two anti-diagonals BELOW the current one in registers (loaded
-//     for every anti-diagonal with a slot shift that undoes the frame rebases in between: rows are slot-linear in
-//     memory, so a shifted row is just another base address) and, after finishing a backward cell, adds the posterior probability of
-//     each of the 15 transitions INTO that cell to 15 per-lane accumulators and the emitted symbols' posterior to
-//     per-lane bins in LDS (no atomics in the loop);
-//   * the wavefront reduces accumulators and bins at the end of the task: one fp64 atomic per count per task.
-// Expected counts agree with the fp64 oracle to <= 2e-5 relative (tests/test_gpu_em.py); the summation order differs
-// from k_dp_generic<EM>, so the two are not bit-identical.
-// =====================================================================================================================
-// lanes whose slot R*lane + r lies in [jlo, jlo + n); jlo may be negative (a band seen from a shifted frame)
-template <int R>
-__device__ __forceinline__ uint64_t cell_mask(int jlo, int n, int r) {
-    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
-    const int lo = max(jlo - r + R - 1, 0) >> SH, hi = max(jlo + n - r + R - 1, 0) >> SH;
-    return hi > lo ? (low_lanes(hi) & ~low_lanes(lo)) : 0ull;
-}
-
-// The four other forward states of a row live in four planes of the second scratch region (plane p of cell i at float
-// p * stride + i, the layout k_dp_generic<EM> uses): a lane's R slots are R consecutive floats of a plane, so every
-// store / load instruction moves one contiguous 256*R-byte run per wavefront -- whole cache lines.  (A float4 per slot
-// wrote each line in R instalments and quadrupled the bytes that reached HBM.)
-template <int R>
-__device__ __forceinline__ void plane_store(__amdgpu_buffer_rsrc_t rs, int voff, const float (&v)[R]) {
-    if constexpr (R == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(fbits(v[0]), rs, voff, 0, 0);
-    } else if constexpr (R == 2) {
-        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(v[0]), fbits(v[1])}, rs, voff, 0, 0);
-    } else {
-        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(v[0]), fbits(v[1]), fbits(v[2]), fbits(v[3])}, rs, voff, 0, 0);
-    }
-}
-template <int R>
-__device__ __forceinline__ void plane_load(__amdgpu_buffer_rsrc_t rs, int voff, float (&v)[R]) {
-    if constexpr (R == 1) {
-        v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
-    } else if constexpr (R == 2) {
-        const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
-        v[0] = bitsf(q.x), v[1] = bitsf(q.y);
-    } else {
-        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-        v[0] = bitsf(q.x), v[1] = bitsf(q.y), v[2] = bitsf(q.z), v[3] = bitsf(q.w);
-    }
-}
-
-template <int R>
-__device__ __forceinline__ void store_row_x(char *Fx, int64_t stride, const Diag<R> &C, const Ctl &ct, int lane) {
-    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
-    const int64_t first = static_cast<int64_t>(ct.co) - R * mk.l0;
-    if (lanes_of(mk.lanes)) {
-        float sx[R], sy[R], lx[R], ly[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) sx[r] = C.c[r].sx, sy[r] = C.c[r].sy, lx[r] = C.c[r].lx, ly[r] = C.c[r].ly;
-        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (first) * 4, 0, -1, 0x00020000), 4 * R * lane, sx);
-        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, sy);
-        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (2 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, lx);
-        plane_store<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (3 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, ly);
-    }
-}
-
-// the forward cells of the row `ct` into G, seen from a frame in which slot j is the row's slot j + shift
-template <int R>
-__device__ __forceinline__ void load_full_row(char *F, char *Fx, int64_t stride, Diag<R> &G, const Ctl &ct, int shift, int lane) {
-    constexpr int SH = R == 1 ? 0 : (R == 2 ? 1 : 2);
-    uint64_t lanes = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) lanes |= cell_mask<R>(ct.jlo - shift, ct.n, r);
-    const int64_t first = static_cast<int64_t>(ct.co) - R * (ct.jlo >> SH) + shift;  // cell index of this frame's slot 0
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(F + first * 8, 0, -1, 0x00020000);
-    if (lanes_of(lanes)) {
-        float sx[R], sy[R], lx[R], ly[R];
-        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (first) * 4, 0, -1, 0x00020000), 4 * R * lane, sx);
-        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, sy);
-        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (2 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, lx);
-        plane_load<R>(__builtin_amdgcn_make_buffer_rsrc(Fx + (3 * stride + first) * 4, 0, -1, 0x00020000), 4 * R * lane, ly);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * (R * lane + r), 0, 0);
-            G.c[r].m = bitsf(q.x), G.c[r].e = q.y;
-            G.c[r].sx = sx[r], G.c[r].sy = sy[r], G.c[r].lx = lx[r], G.c[r].ly = ly[r];
-        }
-    }
-}
-
-// per-lane emission bins in LDS: bin b of lane l at float b * 64 + l (byte b * 256 + 4 * l)
-__device__ __forceinline__ float &bin_at(float *lbins, int byte_off) {
-    return *reinterpret_cast<float *>(reinterpret_cast<char *>(lbins) + byte_off);
-}
-
-// Expected counts of the transitions into the cells of one anti-diagonal d (`io`: its backward cells; G1 / G2: the
-// forward cells of d-1 / d-2 in the frame of d; eX / eY: the bases consumed into each cell).  ODD: d is odd, i.e. the
-// forward step into d was an X-step.
-template <int R, bool ODD>
-__device__ __forceinline__ void em_cells(const StepEnv &E, const Diag<R> &io, const Diag<R> &G1, const Diag<R> &G2, const Bases<R> &eX,
-                                         const Bases<R> &eY, const Masks<R> &mk, int jl1, int n1, int jl2, int n2, int tot_e,
-                                         float inv_tot, float (&acc)[15], float *lbins, int lane) {
-        const Diag<R> Gs = ODD ? shift_up<R>(G1) : shift_down<R>(G1);  // the d-1 predecessor one slot away
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const Cell c = io.c[r];
-            const uint64_t here = __ballot(c.e != E_DEAD) & mk.cell[r];
-            const int ex4 = eX.b[r], ey4 = eY.b[r];
-            const int lane4 = 4 * lane;
-            float bM = 0.f, bXs = 0.f, bXl = 0.f, bYs = 0.f, bYl = 0.f;  // this cell's emission posteriors
-            // (x-1, y-1) on d-2, same slot
-            if (lanes_of(here & cell_mask<R>(jl2, n2, r))) {
-                const Cell &Fm = G2.c[r];
-                const int s = min(max(Fm.e + c.e - tot_e, -200), 200);
-                const float em = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, em) + 5 * ex4 + ey4);
-                const float w = __builtin_ldexpf(em * c.m * inv_tot, s);
-                const float t0 = Fm.m * E.tr.mm * w, t1 = Fm.sx * E.tr.sxm * w, t2 = Fm.sy * E.tr.sym * w, t3 = Fm.lx * E.tr.lxm * w,
-                            t4 = Fm.ly * E.tr.lym * w;
-                acc[0] += t0, acc[1] += t1, acc[2] += t2, acc[3] += t3, acc[4] += t4;
-                bM = (t0 + t1) + (t2 + t3) + t4;
-            }
-            // (x-1, y) on d-1: same slot after an X-step into d, one slot below after a Y-step
-            if (lanes_of(here & cell_mask<R>(ODD ? jl1 : jl1 + 1, n1, r))) {
-                const Cell &Fl = ODD ? G1.c[r] : Gs.c[r];
-                const int s = min(max(Fl.e + c.e - tot_e, -200), 200);
-                const float g = __builtin_ldexpf(inv_tot, s);
-                const float exs = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 20 + ex4);
-                const float exl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ex) + 60 + ex4);
-                const float ws = exs * c.sx * g, wl = exl * c.lx * g;
-                const float t0 = Fl.m * E.tr.msx * ws, t1 = Fl.sx * E.tr.sxsx * ws, t2 = Fl.sy * E.tr.sysx * ws;
-                const float u0 = Fl.m * E.tr.mlx * wl, u1 = Fl.lx * E.tr.lxlx * wl;
-                acc[5] += t0, acc[6] += t1, acc[7] += t2, acc[8] += u0, acc[9] += u1;
-                bXs = (t0 + t1) + t2, bXl = u0 + u1;
-            }
-            // (x, y-1) on d-1: one slot above after an X-step into d, same slot after a Y-step
-            if (lanes_of(here & cell_mask<R>(ODD ? jl1 - 1 : jl1, n1, r))) {
-                const Cell &Fu = ODD ? Gs.c[r] : G1.c[r];
-                const int s = min(max(Fu.e + c.e - tot_e, -200), 200);
-                const float g = __builtin_ldexpf(inv_tot, s);
-                const float eys = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 40 + ey4);
-                const float eyl = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, ey) + 80 + ey4);
-                const float ws = eys * c.sy * g, wl = eyl * c.ly * g;
-                const float t0 = Fu.m * E.tr.msy * ws, t1 = Fu.sy * E.tr.sysy * ws, t2 = Fu.sx * E.tr.sxsy * ws;
-                const float u0 = Fu.m * E.tr.mly * wl, u1 = Fu.ly * E.tr.lyly * wl;
-                acc[10] += t0, acc[11] += t1, acc[12] += t2, acc[13] += u0, acc[14] += u1;
-                bYs = (t0 + t1) + t2, bYl = u0 + u1;
-            }
-            // the five bins of this cell (disjoint tables): all reads, then all writes -- one LDS round trip
-            // per cell.  An N base goes to a scratch row (row EM_BINS).
-            if (lanes_of(here)) {
-                constexpr int TRASH = (EM_BINS + 14) * 256;
-                const bool nx = ex4 >= 16, ny = ey4 >= 16;
-                const int aM = ((nx || ny) ? TRASH : ex4 * 256 + ey4 * 64) + lane4;
-                const int aXs = (nx ? TRASH : 16 * 256 + ex4 * 64) + lane4, aXl = (nx ? TRASH : 20 * 256 + ex4 * 64) + lane4;
-                const int aYs = (ny ? TRASH : 24 * 256 + ey4 * 64) + lane4, aYl = (ny ? TRASH : 28 * 256 + ey4 * 64) + lane4;
-                const float v0 = bin_at(lbins, aM), v1 = bin_at(lbins, aXs), v2 = bin_at(lbins, aXl), v3 = bin_at(lbins, aYs),
-                            v4 = bin_at(lbins, aYl);
-                bin_at(lbins, aM) = v0 + bM;
-                bin_at(lbins, aXs) = v1 + bXs;
-                bin_at(lbins, aXl) = v2 + bXl;
-                bin_at(lbins, aYs) = v3 + bYs;
-                bin_at(lbins, aYl) = v4 + bYl;
-            }
-        }
-}
 
 template <int R>
 __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
@@ -1516,7 +1602,6 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
         {
             E.tr = load_trans(E.mdl->T);  // in VGPRs: every count multiplies by one, and the scalar file is short here
         }
-        const Trans &tr = E.tr;
         const DevModel *mdl = E.mdl;
 
         // =============================== forward: as k_dp_stair, all five states stored ===============================
@@ -1542,16 +1627,16 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                 normalise(c, 0);
                 A.c[r] = c;
             }
-        store_row<R>(F, A, c0, voff), store_row_x<R>(Fx, a.slot_stride, A, c0, lane);
+        store_row<R>(F, A, c0, voff), store_row_x<R>(Fx, a.slot_stride, A, c0, band_masks<R>(c0.jlo, c0.n), lane);
         for (int d = 1; d <= D; ++d) {
             const Ctl ct = read_ctl(ctl, d);
             if (ct.reb) fwd_rebase<R>(E, ct.reb, A, B, S, x0, y0);
             if (d & 1) {
                 fwd_x_step<R>(E, B, A, S, x0, ct);
-                store_row<R>(F, B, ct, voff), store_row_x<R>(Fx, a.slot_stride, B, ct, lane);
+                store_row<R>(F, B, ct, voff), store_row_x<R>(Fx, a.slot_stride, B, ct, band_masks<R>(ct.jlo, ct.n), lane);
             } else {
                 fwd_y_step<R>(E, A, B, S, y0, ct);
-                store_row<R>(F, A, ct, voff), store_row_x<R>(Fx, a.slot_stride, A, ct, lane);
+                store_row<R>(F, A, ct, voff), store_row_x<R>(Fx, a.slot_stride, A, ct, band_masks<R>(ct.jlo, ct.n), lane);
             }
         }
         {
@@ -1633,9 +1718,9 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                     eY.b[R - 1] = dpp_from_above(S.Y.b[0], injy);
                 }
                 if (d & 1) {
-                    em_cells<R, true>(E, B, G1, G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
+                    em_cells<R, true>(E, B, G1, shift_up<R>(G1), G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
                 } else {
-                    em_cells<R, false>(E, A, G1, G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
+                    em_cells<R, false>(E, A, G1, shift_down<R>(G1), G2, eX, eY, mk, jl1, q1.n, jl2, q2.n, tot_e, inv_tot, acc, lbins, lane);
                 }
                 // ---- on to anti-diagonal d-1: undo the rebase made before the forward step into d, then that step ----
                 // forward cells for the next anti-diagonal, d-1: those of d-2 and d-3 in ITS frame
@@ -1718,6 +1803,20 @@ int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
         hipLaunchKernelGGL((k_dp_wide<4, 8>), dim3(grid), dim3(WAVE * 8), lds, s, a);
     else if (R == 4 && NW == 12)
         hipLaunchKernelGGL((k_dp_wide<4, 12>), dim3(grid), dim3(WAVE * 12), lds, s, a);
+    else
+        return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipGetLastError());
+}
+
+size_t em_wide_lds_bytes(int nw) { return wide_lds_bytes(nw) + sizeof(float) * static_cast<size_t>(nw) * (EM_BINS + 1) * WAVE; }
+
+int launch_em_wide(const KernelArgs &a, int R, int NW, int grid, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = em_wide_lds_bytes(NW);
+    if (R == 2 && NW == 4)
+        hipLaunchKernelGGL((k_dp_wide<2, 4, true>), dim3(grid), dim3(WAVE * 4), lds, s, a);
+    else if (R == 2 && NW == 8)
+        hipLaunchKernelGGL((k_dp_wide<2, 8, true>), dim3(grid), dim3(WAVE * 8), lds, s, a);
     else
         return static_cast<int>(hipErrorInvalidValue);
     return static_cast<int>(hipGetLastError());
