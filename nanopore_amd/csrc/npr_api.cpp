@@ -197,7 +197,9 @@ struct npr_batch {
     std::vector<int64_t> ops_off;
     std::vector<int32_t> ops;
     std::vector<int64_t> pair_off;
-    std::vector<Pair> pairs;
+    std::vector<Pair> pairs;             // filled by fetch_pairs(): at finish in the host modes, on demand after the device MEA
+    bool pairs_ready = false;
+    std::vector<int64_t> task_dst;       // prefix of the per-task pair counts
 };
 
 extern "C" {
@@ -792,20 +794,20 @@ int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells
     return kClasses;
 }
 
-int32_t npr_batch_finish(npr_batch *b) {
-    if (!b) return NPR_ERR_INVALID;
+namespace {
+
+// Posterior pairs of every read to the host: one dense D2H, then per read (host threads) its segments' pairs merged
+// and sorted by (x, y).  b->task_dst (prefix of the per-task pair counts) and b->pair_off are already set.
+int32_t fetch_pairs(npr_batch *b) {
     npr_ctx *ctx = b->ctx;
-    if (!b->ran) return fail(ctx, NPR_ERR_STATE, "npr_batch_finish before npr_batch_run");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    StageTimer tm("batch_finish");
+    if (b->pairs_ready) return NPR_OK;
+    StageTimer tm("fetch_pairs");
     const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
-    std::vector<int64_t> dst(ntasks + 1, 0);
+    const std::vector<int64_t> &dst = b->task_dst;
     const int32_t *hx = nullptr, *hy = nullptr;
     const float *hp = nullptr;
-    if (ntasks) {
-        HIP_TRY(ctx, hipMemcpy(b->outs.data(), b->d_outs.p, b->d_outs.bytes(), hipMemcpyDeviceToHost));
-        for (int64_t k = 0; k < ntasks; ++k) dst[k + 1] = dst[k] + std::min(b->outs[k].npairs, b->tasks[k].pair_cap);
-        const int64_t total = dst[ntasks];
+    const int64_t total = ntasks ? dst[ntasks] : 0;
+    if (total) {
         DevBuf<int64_t> d_dst;
         DevBuf<int32_t> d_cx, d_cy;
         DevBuf<float> d_cp;
@@ -814,58 +816,34 @@ int32_t npr_batch_finish(npr_batch *b) {
             (e = d_cy.alloc(total)) != hipSuccess || (e = d_cp.alloc(total)) != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc", e);
         HIP_TRY(ctx, hipMemcpyAsync(d_dst.p, dst.data(), d_dst.bytes(), hipMemcpyHostToDevice, ctx->stream));
-        if (total) {
-            CompactArgs ca{b->d_tasks.p, b->d_outs.p, d_dst.p, static_cast<int32_t>(ntasks), b->d_px.p, b->d_py.p, b->d_pp.p, d_cx.p, d_cy.p, d_cp.p};
-            const int rc = launch_compact(ca, ctx->stream);
-            if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_compact launch", static_cast<hipError_t>(rc));
-            const size_t need = static_cast<size_t>(total) * 12;
-            if (need > ctx->pin_pairs_bytes) {
-                if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
-                ctx->pin_pairs = nullptr, ctx->pin_pairs_bytes = 0;
-                if ((e = hipHostMalloc(&ctx->pin_pairs, need + need / 4, hipHostMallocDefault)) != hipSuccess)
-                    return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipHostMalloc", e);
-                ctx->pin_pairs_bytes = need + need / 4;
-            }
-            int32_t *px_h = static_cast<int32_t *>(ctx->pin_pairs), *py_h = px_h + total;
-            float *pp_h = reinterpret_cast<float *>(py_h + total);
-            HIP_TRY(ctx, hipMemcpyAsync(px_h, d_cx.p, d_cx.bytes(), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(py_h, d_cy.p, d_cy.bytes(), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(pp_h, d_cp.p, d_cp.bytes(), hipMemcpyDeviceToHost, ctx->stream));
-            hx = px_h, hy = py_h, hp = pp_h;
+        CompactArgs ca{b->d_tasks.p, b->d_outs.p, d_dst.p, static_cast<int32_t>(ntasks), b->d_px.p, b->d_py.p, b->d_pp.p, d_cx.p, d_cy.p, d_cp.p};
+        const int rc = launch_compact(ca, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_compact launch", static_cast<hipError_t>(rc));
+        const size_t need = static_cast<size_t>(total) * 12;
+        if (need > ctx->pin_pairs_bytes) {
+            if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
+            ctx->pin_pairs = nullptr, ctx->pin_pairs_bytes = 0;
+            if ((e = hipHostMalloc(&ctx->pin_pairs, need + need / 4, hipHostMallocDefault)) != hipSuccess)
+                return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipHostMalloc", e);
+            ctx->pin_pairs_bytes = need + need / 4;
         }
+        int32_t *px_h = static_cast<int32_t *>(ctx->pin_pairs), *py_h = px_h + total;
+        float *pp_h = reinterpret_cast<float *>(py_h + total);
+        HIP_TRY(ctx, hipMemcpyAsync(px_h, d_cx.p, d_cx.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(py_h, d_cy.p, d_cy.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(pp_h, d_cp.p, d_cp.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        hx = px_h, hy = py_h, hp = pp_h;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-
     tm.lap("compact + D2H");
-    // per read: merge its segments' pairs (sorted by (x,y)), then MEA / rescore
     const int64_t n = b->n_reads;
-    b->results.assign(n, npr_read_result{});
-    b->pair_off.assign(n + 1, 0);
-    for (int64_t i = 0; i < n; ++i) {
-        int64_t c = 0;
-        for (int32_t s = 0; s < b->read_ntasks[i]; ++s) {
-            const int32_t k = b->task_of[b->read_first_task[i] + s];
-            c += dst[k + 1] - dst[k];
-        }
-        b->pair_off[i + 1] = b->pair_off[i] + c;
-    }
     b->pairs.resize(b->pair_off[n]);
-    std::vector<std::vector<int32_t>> per_read_ops(n);
-    const double LN2 = 0.69314718055994530942;
     parallel_for(n, ctx->host_threads, [&](int64_t i) {
-        npr_read_result &r = b->results[i];
-        r.status = b->read_status[i];
-        r.n_segments = b->read_ntasks[i];
-        if (r.status != NPR_OK) return;
+        if (b->read_status[i] != NPR_OK) return;
         Pair *pp = b->pairs.data() + b->pair_off[i];
         int64_t c = 0;
         for (int32_t s = 0; s < b->read_ntasks[i]; ++s) {
             const int32_t k = b->task_of[b->read_first_task[i] + s];
-            const TaskOut &o = b->outs[k];
-            if (o.status != NPR_OK && r.status == NPR_OK) r.status = o.status;
-            r.cells += b->task_cells[k];
-            if (o.tot_m > 0.f) r.loglik += (std::log2(static_cast<double>(o.tot_m)) + o.tot_e) * LN2;
-            if (o.btot_m > 0.f) r.loglik_bwd += (std::log2(static_cast<double>(o.btot_m)) + o.btot_e) * LN2;
             for (int64_t q = dst[k]; q < dst[k + 1]; ++q) pp[c++] = Pair{hx[q], hy[q], hp[q]};
         }
         // order by (x, y).  The pairs of a read number about two per reference base, so when the reference span is
@@ -903,8 +881,159 @@ int32_t npr_batch_finish(npr_batch *b) {
         } else {
             std::sort(pp, pp + c, [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
         }
+    });
+    tm.lap("merge + sort");
+    b->pairs_ready = true;
+    return NPR_OK;
+}
+
+// MEA chain + cigar of every read on the device (npr_mea.hip): only the ops cross PCIe.  Returns 1 when some read
+// needs the host stage instead (a chain reaching back further than the prefix-maximum ring), NPR_OK or an error.
+int32_t device_mea(npr_batch *b) {
+    npr_ctx *ctx = b->ctx;
+    StageTimer tm("device_mea");
+    const int64_t n = b->n_reads, ntasks = static_cast<int64_t>(b->tasks.size());
+    std::vector<int64_t> rx(n + 1, 0), ry(n + 1, 0), rp(n + 1, 0), ot(n + 1, 0), od(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {  // a read that already failed gets empty tables: its pairs are skipped as out of range
+        const bool ok = b->results[i].status == NPR_OK;
+        const int64_t lX = ok ? b->ref_len[i] : 0, lY = ok ? b->read_len[i] : 0, np = ok ? b->pair_off[i + 1] - b->pair_off[i] : 0;
+        rx[i + 1] = rx[i] + lX + 1;
+        ry[i + 1] = ry[i] + lY;
+        rp[i + 1] = rp[i] + np;
+        ot[i + 1] = ot[i] + 3 * std::min({np, lX, lY}) + 2;  // (D, I, M) per chain pair, one trailing (D, I)
+    }
+    int64_t maxw = 64;
+    for (const auto &dl : b->launches) maxw = std::max<int64_t>(maxw, dl.width);
+    int ring = 1024;
+    while (ring < 4 * maxw + 64) ring <<= 1;
+    const int64_t total = rp[n];
+    DevBuf<int64_t> d_off, d_mass, d_od;
+    DevBuf<int32_t> d_cnt, d_start, d_col, d_sorted, d_small, d_tmp, d_dense;
+    hipError_t e;
+    if ((e = d_off.alloc(4 * (n + 1))) != hipSuccess || (e = d_mass.alloc(n)) != hipSuccess || (e = d_od.alloc(n + 1)) != hipSuccess ||
+        (e = d_cnt.alloc(rx[n])) != hipSuccess || (e = d_start.alloc(rx[n])) != hipSuccess || (e = d_col.alloc(ry[n] + 1)) != hipSuccess ||
+        (e = d_sorted.alloc(4 * total + 4)) != hipSuccess || (e = d_small.alloc(4 * n)) != hipSuccess || (e = d_tmp.alloc(2 * ot[n])) != hipSuccess)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the MEA scratch", e);
+    std::vector<int64_t> offs(4 * (n + 1));
+    std::copy(rx.begin(), rx.end(), offs.begin());
+    std::copy(ry.begin(), ry.end(), offs.begin() + (n + 1));
+    std::copy(rp.begin(), rp.end(), offs.begin() + 2 * (n + 1));
+    std::copy(ot.begin(), ot.end(), offs.begin() + 3 * (n + 1));
+    HIP_TRY(ctx, hipMemcpyAsync(d_off.p, offs.data(), d_off.bytes(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_cnt.p, 0, d_cnt.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_col.p, 0, d_col.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_small.p, 0, d_small.bytes(), ctx->stream));
+    MeaArgs a{};
+    a.tasks = b->d_tasks.p, a.outs = b->d_outs.p, a.ntasks = static_cast<int32_t>(ntasks), a.n_reads = static_cast<int32_t>(n);
+    a.px = b->d_px.p, a.py = b->d_py.p, a.pp = b->d_pp.p;
+    a.rx_off = d_off.p, a.ry_off = d_off.p + (n + 1), a.rp_off = d_off.p + 2 * (n + 1), a.ot_off = d_off.p + 3 * (n + 1);
+    a.cnt = d_cnt.p, a.start = d_start.p, a.colsum = d_col.p;
+    a.sx = d_sorted.p, a.sy = d_sorted.p + total + 1, a.sq = d_sorted.p + 2 * (total + 1), a.back = d_sorted.p + 3 * (total + 1);
+    a.best_who = d_small.p, a.read_flag = d_small.p + n, a.n_ops = d_small.p + 2 * n, a.chain_len = d_small.p + 3 * n;
+    a.chain_mass = d_mass.p;
+    a.gap_gamma = b->params.gap_gamma, a.match_gamma = b->params.match_gamma, a.ring = ring;
+    a.ops_tmp = d_tmp.p, a.od_off = d_od.p;
+    int rc = launch_mea_sort(a, ctx->stream);
+    if (rc == 0) rc = launch_mea_chain(a, ctx->stream);
+    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "MEA kernel launch", static_cast<hipError_t>(rc));
+    std::vector<int32_t> small(4 * n);
+    std::vector<int64_t> mass(n);
+    HIP_TRY(ctx, hipMemcpyAsync(small.data(), d_small.p, d_small.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mass.data(), d_mass.p, d_mass.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    tm.lap("sort + chain + trace");
+    const int32_t *flag = small.data() + n, *nops = small.data() + 2 * n, *clen = small.data() + 3 * n;
+    for (int64_t i = 0; i < n; ++i)
+        if (b->results[i].status == NPR_OK && flag[i] == NPR_ERR_CAPACITY) return 1;
+    for (int64_t i = 0; i < n; ++i) {
+        npr_read_result &r = b->results[i];
+        if (r.status == NPR_OK && flag[i] != 0) r.status = flag[i];
+        const int64_t k = r.status == NPR_OK ? nops[i] : 0;
+        od[i + 1] = od[i] + k;
+        r.n_ops = k;
+        r.score = (r.status == NPR_OK && clen[i] > 0) ? static_cast<double>(mass[i]) / (static_cast<double>(clen[i]) * PROB_ONE) : 0.0;
+    }
+    b->ops_off = od;
+    b->ops.assign(2 * od[n], 0);
+    if (od[n]) {
+        if ((e = d_dense.alloc(2 * od[n])) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the ops", e);
+        a.ops_dense = d_dense.p;
+        HIP_TRY(ctx, hipMemcpyAsync(d_od.p, od.data(), d_od.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = launch_mea_gather(a, ctx->stream)) != 0) return fail(ctx, NPR_ERR_HIP, "k_mea_gather launch", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipMemcpyAsync(b->ops.data(), d_dense.p, d_dense.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    tm.lap("gather + D2H of the ops");
+    return NPR_OK;
+}
+
+}  // namespace
+
+int32_t npr_batch_finish(npr_batch *b) {
+    if (!b) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    if (!b->ran) return fail(ctx, NPR_ERR_STATE, "npr_batch_finish before npr_batch_run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    StageTimer tm("batch_finish");
+    const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
+    const int64_t n = b->n_reads;
+    std::vector<int64_t> &dst = b->task_dst;
+    dst.assign(ntasks + 1, 0);
+    if (ntasks) HIP_TRY(ctx, hipMemcpy(b->outs.data(), b->d_outs.p, b->d_outs.bytes(), hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < ntasks; ++k) dst[k + 1] = dst[k] + std::min(b->outs[k].npairs, b->tasks[k].pair_cap);
+    b->results.assign(n, npr_read_result{});
+    b->pair_off.assign(n + 1, 0);
+    b->pairs_ready = false;
+    const double LN2 = 0.69314718055994530942;
+    for (int64_t i = 0; i < n; ++i) {
+        npr_read_result &r = b->results[i];
+        r.status = b->read_status[i];
+        r.n_segments = b->read_ntasks[i];
+        int64_t c = 0;
+        if (r.status == NPR_OK)
+            for (int32_t s = 0; s < b->read_ntasks[i]; ++s) {
+                const int32_t k = b->task_of[b->read_first_task[i] + s];
+                const TaskOut &o = b->outs[k];
+                if (o.status != NPR_OK && r.status == NPR_OK) r.status = o.status;
+                r.cells += b->task_cells[k];
+                if (o.tot_m > 0.f) r.loglik += (std::log2(static_cast<double>(o.tot_m)) + o.tot_e) * LN2;
+                if (o.btot_m > 0.f) r.loglik_bwd += (std::log2(static_cast<double>(o.btot_m)) + o.btot_e) * LN2;
+                c += dst[k + 1] - dst[k];
+            }
         r.n_pairs = c;
+        b->pair_off[i + 1] = b->pair_off[i] + c;
+    }
+    tm.lap("task results");
+    // --- realign mode: chain and cigar on the device, the pairs stay in HBM until npr_batch_pairs asks for them ---
+    if (b->params.mode == NPR_MODE_REALIGN && n > 0 && ntasks > 0 && !std::getenv("NPR_HOST_MEA")) {
+        int64_t scratch = 0;
+        for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 24 * std::min(b->ref_len[i], b->read_len[i]);
+        scratch += 16 * b->pair_off[n];
+        int64_t maxw = 0;
+        for (const auto &dl : b->launches) maxw = std::max<int64_t>(maxw, dl.width);
+        size_t mem_free = 0, mem_total = 0;
+        if (4 * maxw + 64 <= 8192 && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && static_cast<size_t>(scratch) < mem_free / 2) {
+            const int32_t rc = device_mea(b);
+            if (rc < 0) return rc;
+            if (rc == NPR_OK) {
+                tm.lap("device MEA");
+                b->finished = true;
+                return NPR_OK;
+            }
+        }
+    }
+    // --- host stage: all-posteriors and rescore modes need the pairs on the host anyway; realign comes here when the
+    // per-position tables of the device stage would not fit (records chained across a whole contig) ---
+    {
+        const int32_t rc = fetch_pairs(b);
+        if (rc != NPR_OK) return rc;
+    }
+    std::vector<std::vector<int32_t>> per_read_ops(n);
+    parallel_for(n, ctx->host_threads, [&](int64_t i) {
+        npr_read_result &r = b->results[i];
         if (r.status != NPR_OK) return;
+        const Pair *pp = b->pairs.data() + b->pair_off[i];
+        const int64_t c = r.n_pairs;
         const int32_t *g = b->guide_ops.data() + 2 * b->guide_off[i];
         const int64_t ng = b->guide_off[i + 1] - b->guide_off[i];
         if (b->params.mode == NPR_MODE_RESCORE_ORIGINAL) {
@@ -918,7 +1047,7 @@ int32_t npr_batch_finish(npr_batch *b) {
         }
         r.n_ops = static_cast<int64_t>(per_read_ops[i].size() / 2);
     });
-    tm.lap("sort + MEA + cigar");
+    tm.lap("MEA + cigar");
     b->ops_off.assign(n + 1, 0);
     for (int64_t i = 0; i < n; ++i) b->ops_off[i + 1] = b->ops_off[i] + static_cast<int64_t>(per_read_ops[i].size() / 2);
     b->ops.resize(2 * b->ops_off[n]);
@@ -962,6 +1091,10 @@ int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32
     if (!b->finished) return NPR_ERR_STATE;
     std::copy(b->pair_off.begin(), b->pair_off.end(), pair_off);
     if (!x) return NPR_OK;
+    if (!b->pairs_ready) {  // realign mode left them on the device
+        const int32_t rc = fetch_pairs(const_cast<npr_batch *>(b));
+        if (rc != NPR_OK) return rc;
+    }
     const int64_t total = b->pair_off[b->n_reads];
     if (cap < total) return NPR_ERR_CAPACITY;
     for (int64_t r = 0; r < b->n_reads; ++r) {  // internal coordinates are relative to the guide's window

@@ -87,6 +87,33 @@ int launch_stair(const KernelArgs &a, int R, int grid, void *stream);
 int launch_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
 int launch_em_stair(const KernelArgs &a, int R, int grid, void *stream);
 size_t em_stair_lds_bytes();
+// device MEA stage (npr_mea.hip); offsets are per read, prefix sums with n_reads + 1 entries
+struct MeaArgs {
+    const Task *tasks;
+    const TaskOut *outs;
+    int32_t ntasks, n_reads;
+    const int32_t *px, *py;  // posterior pairs as the DP kernels left them (per task at Task::pair_off)
+    const float *pp;
+    const int64_t *rx_off;   // reference positions: lX + 1 entries per read in cnt / start
+    const int64_t *ry_off;   // read positions: lY entries per read in colsum
+    const int64_t *rp_off;   // pairs: the read's slice of sx / sy / sq / back
+    int32_t *cnt, *start, *colsum;
+    int32_t *sx, *sy, *sq, *back;
+    int32_t *best_who;       // last pair of the heaviest chain, -1 if none
+    int32_t *read_flag;      // 0 or an NPR_ERR_* raised by this stage
+    double gap_gamma, match_gamma;
+    int32_t ring;            // entries of the prefix-maximum ring (power of two)
+    int32_t *ops_tmp;        // (op, length) pairs, each read's written backwards from the end of its slice
+    const int64_t *ot_off;
+    int32_t *n_ops, *chain_len;
+    int64_t *chain_mass;
+    int32_t *ops_dense;
+    const int64_t *od_off;
+};
+size_t mea_chain_lds_bytes(int ring);
+int launch_mea_sort(const MeaArgs &a, void *stream);
+int launch_mea_chain(const MeaArgs &a, void *stream);
+int launch_mea_gather(const MeaArgs &a, void *stream);
 int launch_em_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
 size_t em_wide_lds_bytes(int nw);
 size_t wide_lds_bytes(int nw);

@@ -227,7 +227,7 @@ class Context(object):
             for i in range(b.n_reads):
                 d = dict(status=int(res["status"][i]), score=float(res["score"][i]), loglik=float(res["loglik"][i]),
                          loglik_bwd=float(res["loglik_bwd"][i]), cells=int(res["cells"][i]),
-                         n_segments=int(res["n_segments"][i]),
+                         n_segments=int(res["n_segments"][i]), n_pairs=int(res["n_pairs"][i]),
                          ops=[(int(a), int(c)) for a, c in ops[off[i]:off[i + 1]]])
                 if want_pairs:
                     d["x"] = x[poff[i]:poff[i + 1]].copy()

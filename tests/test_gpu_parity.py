@@ -172,6 +172,38 @@ def test_posterior_capacity_overflow_is_reported_and_retried(gpu_ctx):
         assert u["status"] == 0 and u["ops"] == v["ops"] and np.array_equal(u["p"], v["p"])
 
 
+def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
+    """The chain + cigar stage runs on the device in realign mode (npr_mea.hip) and on the host in the other modes,
+    for hand-made pair lists (npr_mea_cigar) and with NPR_HOST_MEA=1: same integers, so same ops and same scores --
+    over gapGamma / matchGamma settings, reads of several segments, N bases, reads without any pair above matchGamma,
+    and with the pairs fetched afterwards."""
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(23)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    cases = [random_pair(rng, int(rng.integers(30, 2500)), indel=0.2, max_indel=40) for _ in range(40)]
+    cases += [random_pair(rng, 1, indel=0.0), random_pair(rng, 3000, indel=0.3, max_indel=150)]
+    cases[1][0][5:40] = 4
+    refs = [bytes(b"ACGTN"[c] for c in X) for X, _, _ in cases]
+    reads = [bytes(b"ACGTN"[c] for c in Y) for _, Y, _ in cases]
+    guides = [g for _, _, g in cases]
+    for kw in (dict(band_mode=1, fixed_width=100), dict(band_mode=1, fixed_width=100, gap_gamma=0.0),
+               dict(band_mode=1, fixed_width=64, gap_gamma=0.9, match_gamma=0.3), dict(band_mode=1, fixed_width=700),
+               dict(band_mode=0, split_threshold=40, constraint_trim=3), dict(band_mode=0, match_gamma=0.95),
+               dict(band_mode=0, gap_gamma=0.2, match_gamma=-0.1)):
+        got = {}
+        for where in ("device", "host"):
+            if where == "host":
+                monkeypatch.setenv("NPR_HOST_MEA", "1")
+            else:
+                monkeypatch.delenv("NPR_HOST_MEA", raising=False)
+            got[where] = gpu_ctx.realign(R.make_params(**kw), refs, reads, guides, want_pairs=(where == "device"))
+        monkeypatch.delenv("NPR_HOST_MEA", raising=False)
+        for u, v in zip(got["device"], got["host"]):
+            assert u["status"] == v["status"] == 0
+            assert u["ops"] == v["ops"] and u["score"] == v["score"] and u["n_pairs"] == v["n_pairs"], kw
+            assert len(u["p"]) == u["n_pairs"]
+
+
 def test_base_dependent_gap_emissions(gpu_ctx):
     """Gap-state emissions that depend on the base (and the flat N emission next to them): every shipped model is
     flat there, so this is the only place the per-base gap tables are exercised."""
