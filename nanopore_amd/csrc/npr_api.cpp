@@ -27,6 +27,10 @@ struct npr_plan {
     Plan plan;
 };
 
+namespace {
+struct MeaScratch;
+}
+
 struct npr_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -57,6 +61,7 @@ struct npr_ctx {
     // the D2H rate and the copy is a GB per batch
     void *pin_pairs = nullptr;
     size_t pin_pairs_bytes = 0;
+    MeaScratch *mea = nullptr;
 };
 
 namespace {
@@ -77,7 +82,27 @@ struct DevBuf {
         count = 0;
     }
     size_t bytes() const { return count * sizeof(T); }
+    // grow-only use (scratch kept from batch to batch): count is the size asked for, cap what is allocated
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap && p) {
+            count = n;
+            return hipSuccess;
+        }
+        const hipError_t e = alloc(n + n / 4 + 1);
+        cap = e == hipSuccess ? count : 0;
+        count = e == hipSuccess ? n : 0;
+        return e;
+    }
     ~DevBuf() { release(); }
+};
+
+// scratch of the device MEA stage (npr_mea.hip), kept by the context: hipMalloc / hipFree of gigabytes per batch
+// cost more than the kernels
+struct MeaScratch {
+    DevBuf<int64_t> off, mass, od;
+    DevBuf<int32_t> cnt, start, col, sorted, small, tmp;
+    DevBuf<uint32_t> dense;
 };
 
 int32_t fail(npr_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuccess) {
@@ -195,7 +220,8 @@ struct npr_batch {
     // results
     std::vector<npr_read_result> results;
     std::vector<int64_t> ops_off;
-    std::vector<int32_t> ops;
+    std::unique_ptr<int32_t[]> ops;      // (op, length) pairs of all reads; not a vector: no zero-fill of 100s of MB
+    int64_t ops_words = 0, ops_cap = 0;
     std::vector<int64_t> pair_off;
     std::vector<Pair> pairs;             // filled by fetch_pairs(): at finish in the host modes, on demand after the device MEA
     bool pairs_ready = false;
@@ -286,6 +312,7 @@ void npr_destroy(npr_ctx *ctx) {
     if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
     if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
     if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
+    delete ctx->mea;
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -904,42 +931,43 @@ int32_t device_mea(npr_batch *b) {
     }
     int64_t maxw = 64;
     for (const auto &dl : b->launches) maxw = std::max<int64_t>(maxw, dl.width);
-    int ring = 1024;
+    int ring = 256;  // read positions the prefix maximum is kept for: several times what one reference position's band spans
     while (ring < 4 * maxw + 64) ring <<= 1;
     const int64_t total = rp[n];
-    DevBuf<int64_t> d_off, d_mass, d_od;
-    DevBuf<int32_t> d_cnt, d_start, d_col, d_sorted, d_small, d_tmp, d_dense;
+    if (!ctx->mea) ctx->mea = new MeaScratch;
+    MeaScratch &m = *ctx->mea;
     hipError_t e;
-    if ((e = d_off.alloc(4 * (n + 1))) != hipSuccess || (e = d_mass.alloc(n)) != hipSuccess || (e = d_od.alloc(n + 1)) != hipSuccess ||
-        (e = d_cnt.alloc(rx[n])) != hipSuccess || (e = d_start.alloc(rx[n])) != hipSuccess || (e = d_col.alloc(ry[n] + 1)) != hipSuccess ||
-        (e = d_sorted.alloc(4 * total + 4)) != hipSuccess || (e = d_small.alloc(4 * n)) != hipSuccess || (e = d_tmp.alloc(2 * ot[n])) != hipSuccess)
+    if ((e = m.off.reserve(4 * (n + 1))) != hipSuccess || (e = m.mass.reserve(n)) != hipSuccess || (e = m.od.reserve(n + 1)) != hipSuccess ||
+        (e = m.cnt.reserve(rx[n])) != hipSuccess || (e = m.start.reserve(rx[n])) != hipSuccess || (e = m.col.reserve(ry[n] + 1)) != hipSuccess ||
+        (e = m.sorted.reserve(4 * total + 4)) != hipSuccess || (e = m.small.reserve(4 * n)) != hipSuccess || (e = m.tmp.reserve(2 * ot[n])) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the MEA scratch", e);
     std::vector<int64_t> offs(4 * (n + 1));
     std::copy(rx.begin(), rx.end(), offs.begin());
     std::copy(ry.begin(), ry.end(), offs.begin() + (n + 1));
     std::copy(rp.begin(), rp.end(), offs.begin() + 2 * (n + 1));
     std::copy(ot.begin(), ot.end(), offs.begin() + 3 * (n + 1));
-    HIP_TRY(ctx, hipMemcpyAsync(d_off.p, offs.data(), d_off.bytes(), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_cnt.p, 0, d_cnt.bytes(), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_col.p, 0, d_col.bytes(), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_small.p, 0, d_small.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(m.off.p, offs.data(), m.off.bytes(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(m.cnt.p, 0, m.cnt.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(m.col.p, 0, m.col.bytes(), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(m.small.p, 0, m.small.bytes(), ctx->stream));
     MeaArgs a{};
     a.tasks = b->d_tasks.p, a.outs = b->d_outs.p, a.ntasks = static_cast<int32_t>(ntasks), a.n_reads = static_cast<int32_t>(n);
     a.px = b->d_px.p, a.py = b->d_py.p, a.pp = b->d_pp.p;
-    a.rx_off = d_off.p, a.ry_off = d_off.p + (n + 1), a.rp_off = d_off.p + 2 * (n + 1), a.ot_off = d_off.p + 3 * (n + 1);
-    a.cnt = d_cnt.p, a.start = d_start.p, a.colsum = d_col.p;
-    a.sx = d_sorted.p, a.sy = d_sorted.p + total + 1, a.sq = d_sorted.p + 2 * (total + 1), a.back = d_sorted.p + 3 * (total + 1);
-    a.best_who = d_small.p, a.read_flag = d_small.p + n, a.n_ops = d_small.p + 2 * n, a.chain_len = d_small.p + 3 * n;
-    a.chain_mass = d_mass.p;
+    a.rx_off = m.off.p, a.ry_off = m.off.p + (n + 1), a.rp_off = m.off.p + 2 * (n + 1), a.ot_off = m.off.p + 3 * (n + 1);
+    a.cnt = m.cnt.p, a.start = m.start.p, a.colsum = m.col.p;
+    a.sx = m.sorted.p, a.sy = m.sorted.p + total + 1, a.sq = m.sorted.p + 2 * (total + 1), a.back = m.sorted.p + 3 * (total + 1);
+    a.best_who = m.small.p, a.read_flag = m.small.p + n, a.n_ops = m.small.p + 2 * n, a.chain_len = m.small.p + 3 * n;
+    a.chain_mass = m.mass.p;
     a.gap_gamma = b->params.gap_gamma, a.match_gamma = b->params.match_gamma, a.ring = ring;
-    a.ops_tmp = d_tmp.p, a.od_off = d_od.p;
+    a.ring_only = std::getenv("NPR_MEA_RING_ONLY") ? 1 : 0;
+    a.ops_tmp = m.tmp.p, a.od_off = m.od.p;
     int rc = launch_mea_sort(a, ctx->stream);
     if (rc == 0) rc = launch_mea_chain(a, ctx->stream);
     if (rc != 0) return fail(ctx, NPR_ERR_HIP, "MEA kernel launch", static_cast<hipError_t>(rc));
     std::vector<int32_t> small(4 * n);
     std::vector<int64_t> mass(n);
-    HIP_TRY(ctx, hipMemcpyAsync(small.data(), d_small.p, d_small.bytes(), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(mass.data(), d_mass.p, d_mass.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(small.data(), m.small.p, m.small.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mass.data(), m.mass.p, m.mass.bytes(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     tm.lap("sort + chain + trace");
     const int32_t *flag = small.data() + n, *nops = small.data() + 2 * n, *clen = small.data() + 3 * n;
@@ -954,14 +982,34 @@ int32_t device_mea(npr_batch *b) {
         r.score = (r.status == NPR_OK && clen[i] > 0) ? static_cast<double>(mass[i]) / (static_cast<double>(clen[i]) * PROB_ONE) : 0.0;
     }
     b->ops_off = od;
-    b->ops.assign(2 * od[n], 0);
+    b->ops_words = 2 * od[n];
+    if (b->ops_words > b->ops_cap) {  // kept when the batch is finished again
+        b->ops.reset(new int32_t[b->ops_words]);
+        b->ops_cap = b->ops_words;
+    }
     if (od[n]) {
-        if ((e = d_dense.alloc(2 * od[n])) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the ops", e);
-        a.ops_dense = d_dense.p;
-        HIP_TRY(ctx, hipMemcpyAsync(d_od.p, od.data(), d_od.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        // one packed word per op (length << 2 | op) through the pinned staging, unpacked by the host threads
+        if ((e = m.dense.reserve(od[n])) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the ops", e);
+        a.ops_dense = m.dense.p;
+        HIP_TRY(ctx, hipMemcpyAsync(m.od.p, od.data(), m.od.bytes(), hipMemcpyHostToDevice, ctx->stream));
         if ((rc = launch_mea_gather(a, ctx->stream)) != 0) return fail(ctx, NPR_ERR_HIP, "k_mea_gather launch", static_cast<hipError_t>(rc));
-        HIP_TRY(ctx, hipMemcpyAsync(b->ops.data(), d_dense.p, d_dense.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        const size_t need = m.dense.bytes();
+        if (need > ctx->pin_pairs_bytes) {
+            if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
+            ctx->pin_pairs = nullptr, ctx->pin_pairs_bytes = 0;
+            if ((e = hipHostMalloc(&ctx->pin_pairs, need + need / 4, hipHostMallocDefault)) != hipSuccess)
+                return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipHostMalloc", e);
+            ctx->pin_pairs_bytes = need + need / 4;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_pairs, m.dense.p, need, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t *src = static_cast<const uint32_t *>(ctx->pin_pairs);
+        int32_t *out = b->ops.get();
+        const int64_t nops_all = od[n], chunk = 1 << 19, nchunks = (nops_all + chunk - 1) / chunk;
+        parallel_for(nchunks, ctx->host_threads, [&](int64_t c) {
+            for (int64_t i = c * chunk, hi = std::min(nops_all, (c + 1) * chunk); i < hi; ++i)
+                out[2 * i] = static_cast<int32_t>(src[i] & 3u), out[2 * i + 1] = static_cast<int32_t>(src[i] >> 2);
+        });
     }
     tm.lap("gather + D2H of the ops");
     return NPR_OK;
@@ -1050,8 +1098,12 @@ int32_t npr_batch_finish(npr_batch *b) {
     tm.lap("MEA + cigar");
     b->ops_off.assign(n + 1, 0);
     for (int64_t i = 0; i < n; ++i) b->ops_off[i + 1] = b->ops_off[i] + static_cast<int64_t>(per_read_ops[i].size() / 2);
-    b->ops.resize(2 * b->ops_off[n]);
-    for (int64_t i = 0; i < n; ++i) std::copy(per_read_ops[i].begin(), per_read_ops[i].end(), b->ops.begin() + 2 * b->ops_off[i]);
+    b->ops_words = 2 * b->ops_off[n];
+    if (b->ops_words > b->ops_cap) {
+        b->ops.reset(new int32_t[b->ops_words]);
+        b->ops_cap = b->ops_words;
+    }
+    for (int64_t i = 0; i < n; ++i) std::copy(per_read_ops[i].begin(), per_read_ops[i].end(), b->ops.get() + 2 * b->ops_off[i]);
     tm.lap("gather ops");
     b->finished = true;
     return NPR_OK;
@@ -1082,7 +1134,7 @@ int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_
     std::copy(b->ops_off.begin(), b->ops_off.end(), ops_off);
     if (!ops) return NPR_OK;
     if (cap_pairs < b->ops_off[b->n_reads]) return NPR_ERR_CAPACITY;
-    std::copy(b->ops.begin(), b->ops.end(), ops);
+    std::copy(b->ops.get(), b->ops.get() + b->ops_words, ops);
     return NPR_OK;
 }
 

@@ -103,11 +103,12 @@ struct MeaArgs {
     int32_t *read_flag;      // 0 or an NPR_ERR_* raised by this stage
     double gap_gamma, match_gamma;
     int32_t ring;            // entries of the prefix-maximum ring (power of two)
+    int32_t ring_only;       // tests: every read through the LDS-ring kernel
     int32_t *ops_tmp;        // (op, length) pairs, each read's written backwards from the end of its slice
     const int64_t *ot_off;
     int32_t *n_ops, *chain_len;
     int64_t *chain_mass;
-    int32_t *ops_dense;
+    uint32_t *ops_dense;     // one word per op: length << 2 | op
     const int64_t *od_off;
 };
 size_t mea_chain_lds_bytes(int ring);

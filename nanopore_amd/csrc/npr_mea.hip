@@ -7,14 +7,16 @@
 //                  add the quantum to its read position's column sum
 //   k_mea_scan     per read: exclusive scan of the counts -> first sorted slot of every reference position
 //   k_mea_scatter  per pair: move to its reference position's group (order inside a group arbitrary)
-//   k_mea_chain    one wavefront per read: groups in reference order; inside a 64-pair chunk the lanes sort their
+//   k_mea_chain_win  one wavefront per read: groups in reference order; inside a 64-pair chunk the lanes sort their
 //                  groups by read position, weigh the pairs (posterior - gapGamma * gap mass of row and column) and
-//                  drop those not above matchGamma; the heaviest chain ending below every read position y lives in
-//                  an LDS ring keyed by y (a monotone prefix maximum: a query is one read, an insert overwrites the
-//                  run of entries the new chain beats, all lanes at once); ties go to the pair that sorts last
-//   k_mea_trace    one lane per read: walk the back pointers from the best chain's last pair, writing the ops
+//                  drop those not above matchGamma; the heaviest chain ending below every read position y is a
+//                  monotone prefix maximum kept in registers for a window of 128 read positions (a query is a
+//                  readlane, an insert one compare-and-select); ties go to the pair that sorts last
+//   k_mea_chain    the same with the prefix maximum in an LDS ring of any length, for the reads whose pairs reach
+//                  back further than the window (none on usual data)
+//   k_mea_trace    one wavefront per read: walk the back pointers from the best chain's last pair, writing the ops
 //                  backwards (run-length merged) into the read's scratch, and sum the chain's posterior mass
-//   k_mea_gather   dense copy of every read's ops for one D2H
+//   k_mea_gather   dense copy of every read's ops, one word each, for one D2H
 #include <hip/hip_runtime.h>
 
 #include "npr_device.h"
@@ -30,6 +32,13 @@ __device__ __forceinline__ int64_t rdlane64(int64_t v, int j) {
     const int lo = __builtin_amdgcn_readlane(static_cast<int>(v), j);
     const int hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), j);
     return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+// the kernel's workgroups are one wavefront: LDS operations of a wavefront complete in issue order, so cross-lane
+// traffic through LDS needs the compiler to keep the order, not a hardware barrier
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ bool beats(int64_t s, int w, int64_t os, int ow) { return s > os || (s == os && w > ow); }
 
@@ -55,25 +64,26 @@ __global__ void __launch_bounds__(256) k_mea_count(MeaArgs a) {
 
 // start[x] = number of pairs of the read on reference positions < x, for x in [0, lX]
 __global__ void __launch_bounds__(256) k_mea_scan(MeaArgs a) {
-    __shared__ int part[256];
-    const int r = blockIdx.x;
+    __shared__ int wsum[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t rx = a.rx_off[r];
     const int n = static_cast<int>(a.rx_off[r + 1] - rx);  // lX + 1 entries (the last count is zero)
-    const int per = (n + 255) / 256, lo = min(n, static_cast<int>(threadIdx.x) * per), hi = min(n, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += a.cnt[rx + i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = static_cast<int>(threadIdx.x) >= o ? part[threadIdx.x - o] : 0;
+    int carry = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        const int v = i < n ? a.cnt[rx + i] : 0;
+        int s = v;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int t = __shfl_up(s, o);
+            if (lane >= o) s += t;
+        }
+        if (lane == WAVE - 1) wsum[wv] = s;
         __syncthreads();
-        part[threadIdx.x] += v;
+        int before = 0, total = 0;
+        for (int k = 0; k < 4; ++k) before += k < wv ? wsum[k] : 0, total += wsum[k];
+        if (i < n) a.start[rx + i] = carry + before + s - v;
+        carry += total;
         __syncthreads();
-    }
-    int run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; ++i) {
-        a.start[rx + i] = run;
-        run += a.cnt[rx + i];
     }
 }
 
@@ -94,7 +104,142 @@ __global__ void __launch_bounds__(256) k_mea_scatter(MeaArgs a) {
     }
 }
 
-// LDS: ring of `ring` (score int64, who int32) entries keyed by read position, then the 64-lane permutation buffers
+constexpr int MEA_RETRY = 1;  // read_flag: the register window was too short for this read, the LDS-ring kernel takes it
+
+// One 64-pair chunk of a read's x-grouped pairs, complete groups only, brought into (x, y) order: the lanes find their
+// rank inside their group (groups are a few pairs), weigh their pair and change places through LDS.
+struct Chunk {
+    int valid;      // pairs taken (0: a group of more than 64 pairs)
+    uint64_t ends;  // last lane of every group, over the valid lanes
+    uint64_t keep;  // lanes whose weight exceeds matchGamma
+    int y, q;       // sorted order from here on
+    int64_t w;
+};
+__device__ __forceinline__ Chunk prep_chunk(const MeaArgs &a, int *sx, int *sy, int *sq, int64_t ry, int base, int n, int lane,
+                                            int64_t floor_w, int64_t *tw, int *ty, int *tq) {
+    Chunk c;
+    const int pos = base + lane;
+    const bool in = pos < n;
+    const int x = in ? sx[pos] : -1, xn = pos + 1 < n ? sx[pos + 1] : -2;
+    int y = in ? sy[pos] : 0, q = in ? sq[pos] : 0;
+    const uint64_t ends = __ballot(in && x != xn);
+    c.valid = ends ? 64 - __builtin_clzll(ends) : 0;
+    c.ends = ends, c.keep = 0, c.y = 0, c.q = 0, c.w = 0;
+    if (!ends) return c;
+    const bool act = lane < c.valid;
+    const uint64_t starts = (ends << 1) | 1ull;
+    const int gfirst = 63 - __builtin_clzll(starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1)));
+    const int gend = act ? lane + __builtin_ctzll(ends >> lane) : lane;
+    const int gsize = gend - gfirst + 1;
+    int rank = 0, rowsum = q;  // rank by read position inside the group, posterior mass of the reference position
+    for (int o = 1; __any(act && o < gsize); ++o) {
+        const int lo = lane - o, hi = lane + o;
+        const int yl = __shfl(y, lo & 63), ql = __shfl(q, lo & 63), yh = __shfl(y, hi & 63), qh = __shfl(q, hi & 63);
+        if (lo >= gfirst) rank += yl < y ? 1 : 0, rowsum += ql;
+        if (hi <= gend) rank += yh < y ? 1 : 0, rowsum += qh;
+    }
+    const int colsum = act ? a.colsum[ry + y] : 0;
+    const int64_t gap = max(P1 - rowsum, int64_t(0)) + max(P1 - colsum, int64_t(0));
+    const int64_t w0 = q - static_cast<int64_t>(floor(a.gap_gamma * static_cast<double>(gap)));
+    wave_sync();
+    if (act) {
+        const int to = gfirst + rank;  // sorted place inside the chunk
+        tw[to] = w0, ty[to] = y, tq[to] = q;
+    }
+    wave_sync();
+    c.w = tw[lane], c.y = ty[lane], c.q = tq[lane];
+    c.keep = __ballot(act && c.w > floor_w);
+    if (act) sy[pos] = c.y, sq[pos] = c.q;  // the trace reads them back
+    return c;
+}
+
+// The heaviest chain ending at or below each read position, for the 128 positions [ybase, ybase + 127], in registers:
+// position k lives in lane k & 63, register (k >> 6) & 1.  Positions above the window all hold `top`.  An insert at
+// position vy raises every held position >= vy the new chain beats -- one compare-and-select per register, no loop:
+// the prefix maximum is monotone.  The window moves up when an insert lands above it (the positions it leaves are
+// forgotten); a query or insert below the window hands the read to the LDS-ring kernel (MEA_RETRY).
+__global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
+    __shared__ int64_t tw[WAVE];
+    __shared__ int ty[WAVE], tq[WAVE];
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;
+    const int64_t rp = a.rp_off[r], ry = a.ry_off[r];
+    const int n = a.read_flag[r] ? 0 : static_cast<int>(a.rp_off[r + 1] - rp);  // (flagged: the scatter was incomplete)
+    if (a.ring_only) {
+        if (lane == 0 && a.read_flag[r] == 0) a.read_flag[r] = MEA_RETRY;
+        return;
+    }
+    int *const sx = a.sx + rp, *const sy = a.sy + rp, *const sq = a.sq + rp, *const back = a.back + rp;
+    const int64_t floor_w = static_cast<int64_t>(floor(a.match_gamma * static_cast<double>(P1)));
+    int ybase = 0;
+    int64_t s0 = 0, s1 = 0, top_s = 0;
+    int w0 = -1, w1 = -1, top_w = -1;
+    int k0 = lane, k1 = lane + 64;  // positions held
+    int flag = 0;
+    for (int base = 0; base < n && !flag;) {
+        const Chunk c = prep_chunk(a, sx, sy, sq, ry, base, n, lane, floor_w, tw, ty, tq);
+        if (!c.valid) {
+            flag = MEA_RETRY;
+            break;
+        }
+        int64_t tot = 0;
+        int bk = -1;
+        uint64_t gm = c.ends & (c.valid == 64 ? ~0ull : ((1ull << c.valid) - 1));
+        int gs = 0;
+        while (gm && !flag) {
+            const int ge = __builtin_ctzll(gm);
+            gm &= gm - 1;
+            const uint64_t mine = c.keep & (ge == 63 ? ~0ull : ((2ull << ge) - 1)) & ~((1ull << gs) - 1);
+            for (uint64_t qm = mine; qm;) {  // heaviest chain over the pairs inserted so far with read position < y
+                const int i = __builtin_ctzll(qm);
+                qm &= qm - 1;
+                const int key = rdlane(c.y, i) - 1;
+                int64_t bs = 0;
+                int bw = -1;
+                if (key >= 0) {
+                    if (key > ybase + 127) {
+                        bs = top_s, bw = top_w;
+                    } else if (key < ybase) {
+                        flag = MEA_RETRY;
+                    } else if (key & 64) {
+                        bs = rdlane64(s1, key & 63), bw = rdlane(w1, key & 63);
+                    } else {
+                        bs = rdlane64(s0, key & 63), bw = rdlane(w0, key & 63);
+                    }
+                }
+                const int64_t t = rdlane64(c.w, i) + bs;
+                if (lane == i) tot = t, bk = bw;
+            }
+            for (uint64_t im = mine; im;) {
+                const int i = __builtin_ctzll(im);
+                im &= im - 1;
+                const int vy = rdlane(c.y, i), vw = base + i;
+                const int64_t vs = rdlane64(tot, i);
+                if (vy > ybase + 127) {  // move the window up: the positions it gains hold the overall maximum
+                    ybase = vy - 127;
+                    if (k0 < ybase) s0 = top_s, w0 = top_w;
+                    if (k1 < ybase) s1 = top_s, w1 = top_w;
+                    k0 = ybase + ((lane - ybase) & 127), k1 = ybase + ((lane + 64 - ybase) & 127);
+                } else if (vy < ybase) {
+                    flag = MEA_RETRY;
+                }
+                if (beats(vs, vw, top_s, top_w)) top_s = vs, top_w = vw;
+                if (k0 >= vy && beats(vs, vw, s0, w0)) s0 = vs, w0 = vw;
+                if (k1 >= vy && beats(vs, vw, s1, w1)) s1 = vs, w1 = vw;
+            }
+            gs = ge + 1;
+        }
+        if ((c.keep >> lane) & 1) back[base + lane] = bk;
+        base += c.valid;
+    }
+    if (lane == 0) {
+        a.best_who[r] = top_w;
+        if (flag) a.read_flag[r] = flag;
+    }
+}
+
+// The general version, for the reads k_mea_chain_win gave up on: the prefix maximum in an LDS ring of `ring` read
+// positions (score int64, who int32); an insert overwrites the run of entries the new chain beats, all lanes at once.
 __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
     extern __shared__ __align__(16) char lds[];
     const int RING = a.ring, MASK = RING - 1;
@@ -103,11 +248,11 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
     int64_t *const tw = reinterpret_cast<int64_t *>(rw + RING);  // weights in sorted lane order
     int *const ty = reinterpret_cast<int *>(tw + WAVE);
     int *const tq = ty + WAVE;
-    int *const tk = tq + WAVE;
     const int lane = threadIdx.x;
     const int r = blockIdx.x;
+    if (a.read_flag[r] != MEA_RETRY) return;
     const int64_t rp = a.rp_off[r], ry = a.ry_off[r];
-    const int n = a.read_flag[r] ? 0 : static_cast<int>(a.rp_off[r + 1] - rp);  // (flagged: the scatter was incomplete)
+    const int n = static_cast<int>(a.rp_off[r + 1] - rp);
     int *const sx = a.sx + rp, *const sy = a.sy + rp, *const sq = a.sq + rp, *const back = a.back + rp;
     const int64_t floor_w = static_cast<int64_t>(floor(a.match_gamma * static_cast<double>(P1)));
     int ytop = -1;  // largest key the ring holds; beyond it the prefix maximum is `top`
@@ -115,40 +260,15 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
     int top_w = -1;
     int flag = 0;
     for (int base = 0; base < n && !flag;) {
-        const int pos = base + lane;
-        const bool in = pos < n;
-        const int x = in ? sx[pos] : -1, xn = pos + 1 < n ? sx[pos + 1] : -2;
-        int y = in ? sy[pos] : 0, q = in ? sq[pos] : 0;
-        const uint64_t ends = __ballot(in && x != xn);  // last lane of every reference position's group
-        if (!ends) {
+        const Chunk c = prep_chunk(a, sx, sy, sq, ry, base, n, lane, floor_w, tw, ty, tq);
+        if (!c.valid) {
             flag = NPR_ERR_CAPACITY;  // more than 64 pairs on one reference position: cannot happen above a 0.01 threshold
             break;
         }
-        const int valid = 64 - __builtin_clzll(ends);
-        const bool act = lane < valid;
-        // group statistics: rank by read position, first lane of the group, posterior mass of the row
-        int rank = 0, before = 0, rowsum = 0;
-        for (int j = 0; j < valid; ++j) {
-            const int xj = rdlane(x, j), yj = rdlane(y, j), qj = rdlane(q, j);
-            const bool same = xj == x;
-            rank += (same && yj < y) ? 1 : 0;
-            before += (same && j < lane) ? 1 : 0;
-            rowsum += same ? qj : 0;
-        }
-        const int colsum = act ? a.colsum[ry + y] : 0;
-        const int64_t gap = max(P1 - rowsum, int64_t(0)) + max(P1 - colsum, int64_t(0));
-        const int64_t w0 = q - static_cast<int64_t>(floor(a.gap_gamma * static_cast<double>(gap)));
-        __syncthreads();
-        if (act) {
-            const int to = lane - before + rank;  // sorted place inside the chunk
-            tw[to] = w0, ty[to] = y, tq[to] = q, tk[to] = w0 > floor_w ? 1 : 0;
-        }
-        __syncthreads();
-        const int64_t w = tw[lane];
-        y = ty[lane], q = tq[lane];
-        const bool keep = act && tk[lane] != 0;
-        if (act) sy[pos] = y, sq[pos] = q;  // (x, y)-sorted from here on: the trace reads them back
-        uint64_t gm = ends & (valid == 64 ? ~0ull : ((1ull << valid) - 1));
+        const int pos = base + lane, y = c.y;
+        const int64_t w = c.w;
+        const bool keep = (c.keep >> lane) & 1;
+        uint64_t gm = c.ends & (c.valid == 64 ? ~0ull : ((1ull << c.valid) - 1));
         int gs = 0;
         while (gm) {
             const int ge = __builtin_ctzll(gm);
@@ -169,7 +289,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
             }
             const int64_t total = w + bs;
             if (mine) back[pos] = bw;
-            __syncthreads();
+            wave_sync();
             uint64_t km = __ballot(mine);
             while (km) {
                 const int i = __builtin_ctzll(km);
@@ -193,22 +313,23 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
                     }
                     if (beats(vs, vw, top_s, top_w)) top_s = vs, top_w = vw;
                 }
-                __syncthreads();
+                wave_sync();
             }
             gs = ge + 1;
         }
         flag = __any(flag) ? NPR_ERR_CAPACITY : 0;
-        base += valid;
+        base += c.valid;
     }
     if (lane == 0) {
         a.best_who[r] = top_w;
-        if (flag && a.read_flag[r] == 0) a.read_flag[r] = flag;
+        a.read_flag[r] = flag;
     }
 }
 
+// One wavefront per read: the chain's pairs are visited in descending sorted order and mostly a few entries apart,
+// so 64 consecutive entries are loaded at once and the back pointers followed from lane to lane; lane 0 writes.
 __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
-    const int r = blockIdx.x * WAVE + threadIdx.x;
-    if (r >= a.n_reads) return;
+    const int r = blockIdx.x, lane = threadIdx.x;
     const int64_t rp = a.rp_off[r];
     const int *sx = a.sx + rp, *sy = a.sy + rp, *sq = a.sq + rp, *back = a.back + rp;
     const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
@@ -221,39 +342,53 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
             hlen += len;
             return;
         }
-        if (hop >= 0 && p > lo) *--p = make_int2(hop, hlen);
+        if (hop >= 0 && p > lo) {
+            --p;
+            if (lane == 0) *p = make_int2(hop, hlen);
+        }
         hop = op, hlen = len;
     };
     int cx = lX, cy = lY, len = 0;
     int64_t mass = 0;
-    if (a.read_flag[r] == 0)
-        for (int i = a.best_who[r]; i >= 0; i = back[i]) {
-            const int x = sx[i], y = sy[i];
+    int i = a.read_flag[r] == 0 ? __builtin_amdgcn_readfirstlane(a.best_who[r]) : -1;
+    while (i >= 0) {
+        const int cb = max(i - (WAVE - 1), 0), idx = min(cb + lane, i);
+        const int vb = back[idx], vx = sx[idx], vy = sy[idx], vq = sq[idx];
+        while (i >= cb) {
+            const int l = i - cb;
+            const int x = rdlane(vx, l), y = rdlane(vy, l);
             emit(NPR_OP_I, cy - y - 1);  // backwards: the pair's M comes last in its (D, I, M) triple
             emit(NPR_OP_D, cx - x - 1);
             emit(NPR_OP_M, 1);
-            cx = x, cy = y, mass += sq[i], ++len;
+            cx = x, cy = y, mass += rdlane(vq, l), ++len;
+            i = rdlane(vb, l);
         }
+    }
     emit(NPR_OP_I, cy);
     emit(NPR_OP_D, cx);
-    if (hop >= 0 && p > lo) *--p = make_int2(hop, hlen);
-    a.n_ops[r] = static_cast<int>(reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r + 1] - p);
-    a.chain_len[r] = len;
-    a.chain_mass[r] = mass;
+    if (hop >= 0 && p > lo) {
+        --p;
+        if (lane == 0) *p = make_int2(hop, hlen);
+    }
+    if (lane == 0) {
+        a.n_ops[r] = static_cast<int>(reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r + 1] - p);
+        a.chain_len[r] = len;
+        a.chain_mass[r] = mass;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_mea_gather(MeaArgs a) {
     for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
         const int n = static_cast<int>(a.od_off[r + 1] - a.od_off[r]);
         const int2 *src = reinterpret_cast<const int2 *>(a.ops_tmp) + a.ot_off[r + 1] - a.n_ops[r];
-        int2 *dst = reinterpret_cast<int2 *>(a.ops_dense) + a.od_off[r];
-        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+        uint32_t *dst = a.ops_dense + a.od_off[r];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = static_cast<uint32_t>(src[i].y) << 2 | static_cast<uint32_t>(src[i].x);
     }
 }
 
 }  // namespace
 
-size_t mea_chain_lds_bytes(int ring) { return static_cast<size_t>(ring) * 12 + WAVE * (8 + 4 + 4 + 4); }
+size_t mea_chain_lds_bytes(int ring) { return static_cast<size_t>(ring) * 12 + WAVE * (8 + 4 + 4); }
 
 int launch_mea_sort(const MeaArgs &a, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -269,8 +404,9 @@ int launch_mea_chain(const MeaArgs &a, void *stream) {
     const size_t lds = mea_chain_lds_bytes(a.ring);
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mea_chain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL(k_mea_chain, dim3(a.n_reads), dim3(WAVE), lds, s, a);
-    hipLaunchKernelGGL(k_mea_trace, dim3((a.n_reads + WAVE - 1) / WAVE), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL(k_mea_chain_win, dim3(a.n_reads), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL(k_mea_chain, dim3(a.n_reads), dim3(WAVE), lds, s, a);  // returns at once unless the read was handed over
+    hipLaunchKernelGGL(k_mea_trace, dim3(a.n_reads), dim3(WAVE), 0, s, a);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -191,16 +191,20 @@ def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
                dict(band_mode=0, split_threshold=40, constraint_trim=3), dict(band_mode=0, match_gamma=0.95),
                dict(band_mode=0, gap_gamma=0.2, match_gamma=-0.1)):
         got = {}
-        for where in ("device", "host"):
+        for where in ("device", "device_ring", "host"):  # device_ring: the general (LDS-ring) chain kernel for every read
+            monkeypatch.delenv("NPR_HOST_MEA", raising=False)
+            monkeypatch.delenv("NPR_MEA_RING_ONLY", raising=False)
             if where == "host":
                 monkeypatch.setenv("NPR_HOST_MEA", "1")
-            else:
-                monkeypatch.delenv("NPR_HOST_MEA", raising=False)
+            elif where == "device_ring":
+                monkeypatch.setenv("NPR_MEA_RING_ONLY", "1")
             got[where] = gpu_ctx.realign(R.make_params(**kw), refs, reads, guides, want_pairs=(where == "device"))
         monkeypatch.delenv("NPR_HOST_MEA", raising=False)
-        for u, v in zip(got["device"], got["host"]):
-            assert u["status"] == v["status"] == 0
+        monkeypatch.delenv("NPR_MEA_RING_ONLY", raising=False)
+        for u, t, v in zip(got["device"], got["device_ring"], got["host"]):
+            assert u["status"] == t["status"] == v["status"] == 0
             assert u["ops"] == v["ops"] and u["score"] == v["score"] and u["n_pairs"] == v["n_pairs"], kw
+            assert t["ops"] == v["ops"] and t["score"] == v["score"], kw
             assert len(u["p"]) == u["n_pairs"]
 
 
