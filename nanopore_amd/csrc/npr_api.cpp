@@ -101,7 +101,7 @@ struct DevBuf {
 // cost more than the kernels
 struct MeaScratch {
     DevBuf<int64_t> off, mass, od;
-    DevBuf<int32_t> cnt, start, col, sorted, small, tmp;
+    DevBuf<int32_t> cnt, start, col, sorted, small, tmp, map;
     DevBuf<uint32_t> dense;
 };
 
@@ -931,14 +931,27 @@ int32_t device_mea(npr_batch *b) {
     }
     int64_t maxw = 64;
     for (const auto &dl : b->launches) maxw = std::max<int64_t>(maxw, dl.width);
-    int ring = 256;  // read positions the prefix maximum is kept for: several times what one reference position's band spans
-    while (ring < 4 * maxw + 64) ring <<= 1;
+    // the LDS-ring kernel (reads the register window gives up on): read positions the prefix maximum is kept for,
+    // several times what one reference position's band spans, as far as the LDS goes; a read that outgrows even that
+    // is reported and the batch takes the host stage
+    int ring = 256;
+    while (ring < 4 * maxw + 64 && ring < 8192) ring <<= 1;
     const int64_t total = rp[n];
     if (!ctx->mea) ctx->mea = new MeaScratch;
     MeaScratch &m = *ctx->mea;
     hipError_t e;
+    // per-position tables of one read in LDS (count + scan + scatter in one kernel) when the longest span fits
+    int64_t span = 0;
+    for (int64_t i = 0; i < n; ++i) span = std::max(span, rx[i + 1] - rx[i]), span = std::max(span, ry[i + 1] - ry[i]);
+    const bool sort_in_lds = 4 * span <= 64 * 1024 && !std::getenv("NPR_MEA_GLOBAL_SORT");
+    const size_t ntask_map = b->task_of.size();
+    if ((e = m.map.reserve(2 * n + ntask_map)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the MEA scratch", e);
+    HIP_TRY(ctx, hipMemcpyAsync(m.map.p, b->read_first_task.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(m.map.p + n, b->read_ntasks.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(m.map.p + 2 * n, b->task_of.data(), sizeof(int32_t) * ntask_map, hipMemcpyHostToDevice, ctx->stream));
     if ((e = m.off.reserve(4 * (n + 1))) != hipSuccess || (e = m.mass.reserve(n)) != hipSuccess || (e = m.od.reserve(n + 1)) != hipSuccess ||
-        (e = m.cnt.reserve(rx[n])) != hipSuccess || (e = m.start.reserve(rx[n])) != hipSuccess || (e = m.col.reserve(ry[n] + 1)) != hipSuccess ||
+        (e = m.cnt.reserve(sort_in_lds ? 1 : rx[n])) != hipSuccess || (e = m.start.reserve(sort_in_lds ? 1 : rx[n])) != hipSuccess ||
+        (e = m.col.reserve(ry[n] + 1)) != hipSuccess ||
         (e = m.sorted.reserve(4 * total + 4)) != hipSuccess || (e = m.small.reserve(4 * n)) != hipSuccess || (e = m.tmp.reserve(2 * ot[n])) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the MEA scratch", e);
     std::vector<int64_t> offs(4 * (n + 1));
@@ -947,8 +960,10 @@ int32_t device_mea(npr_batch *b) {
     std::copy(rp.begin(), rp.end(), offs.begin() + 2 * (n + 1));
     std::copy(ot.begin(), ot.end(), offs.begin() + 3 * (n + 1));
     HIP_TRY(ctx, hipMemcpyAsync(m.off.p, offs.data(), m.off.bytes(), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(m.cnt.p, 0, m.cnt.bytes(), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(m.col.p, 0, m.col.bytes(), ctx->stream));
+    if (!sort_in_lds) {
+        HIP_TRY(ctx, hipMemsetAsync(m.cnt.p, 0, m.cnt.bytes(), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(m.col.p, 0, m.col.bytes(), ctx->stream));
+    }
     HIP_TRY(ctx, hipMemsetAsync(m.small.p, 0, m.small.bytes(), ctx->stream));
     MeaArgs a{};
     a.tasks = b->d_tasks.p, a.outs = b->d_outs.p, a.ntasks = static_cast<int32_t>(ntasks), a.n_reads = static_cast<int32_t>(n);
@@ -960,6 +975,8 @@ int32_t device_mea(npr_batch *b) {
     a.chain_mass = m.mass.p;
     a.gap_gamma = b->params.gap_gamma, a.match_gamma = b->params.match_gamma, a.ring = ring;
     a.ring_only = std::getenv("NPR_MEA_RING_ONLY") ? 1 : 0;
+    a.read_first = m.map.p, a.read_ntasks = m.map.p + n, a.task_of = m.map.p + 2 * n;
+    a.sort_lds_bytes = sort_in_lds ? static_cast<int32_t>(4 * span) : 0;
     a.ops_tmp = m.tmp.p, a.od_off = m.od.p;
     int rc = launch_mea_sort(a, ctx->stream);
     if (rc == 0) rc = launch_mea_chain(a, ctx->stream);
@@ -1057,10 +1074,8 @@ int32_t npr_batch_finish(npr_batch *b) {
         int64_t scratch = 0;
         for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 24 * std::min(b->ref_len[i], b->read_len[i]);
         scratch += 16 * b->pair_off[n];
-        int64_t maxw = 0;
-        for (const auto &dl : b->launches) maxw = std::max<int64_t>(maxw, dl.width);
         size_t mem_free = 0, mem_total = 0;
-        if (4 * maxw + 64 <= 8192 && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && static_cast<size_t>(scratch) < mem_free / 2) {
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && static_cast<size_t>(scratch) < mem_free / 2) {
             const int32_t rc = device_mea(b);
             if (rc < 0) return rc;
             if (rc == NPR_OK) {

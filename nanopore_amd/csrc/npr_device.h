@@ -103,6 +103,8 @@ struct MeaArgs {
     int32_t *read_flag;      // 0 or an NPR_ERR_* raised by this stage
     double gap_gamma, match_gamma;
     int32_t ring;            // entries of the prefix-maximum ring (power of two)
+    const int32_t *read_first, *read_ntasks, *task_of;  // the tasks of a read: task_of[read_first[r] + s]
+    int32_t sort_lds_bytes;  // > 0: k_mea_sort_lds with this much LDS; 0: the three global-memory kernels
     int32_t ring_only;       // tests: every read through the LDS-ring kernel
     int32_t *ops_tmp;        // (op, length) pairs, each read's written backwards from the end of its slice
     const int64_t *ot_off;

@@ -3,6 +3,8 @@
 // one npr_host.cpp's mea_cigar() produces from the same posterior pairs, bit for bit; what changes is where it runs:
 // the pairs (about 12 bytes per reference base and read) stay in HBM and only the run-length encoded ops cross PCIe.
 //
+//   k_mea_sort_lds count + scan + scatter below in one kernel, one workgroup per read with its tables in LDS; used
+//                  when every read's span fits (the three kernels below otherwise: records chained over long spans)
 //   k_mea_count    per pair: quantise the posterior (floor(p * 1e7)), count the pair on its reference position,
 //                  add the quantum to its read position's column sum
 //   k_mea_scan     per read: exclusive scan of the counts -> first sorted slot of every reference position
@@ -26,6 +28,7 @@ namespace {
 
 constexpr int64_t P1 = PROB_ONE;
 constexpr int WAVE = 64;
+constexpr int SORT_THREADS = 512;  // k_mea_sort_lds: its loops wait on memory, so many wavefronts per read
 
 __device__ __forceinline__ int rdlane(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
 __device__ __forceinline__ int64_t rdlane64(int64_t v, int j) {
@@ -104,6 +107,68 @@ __global__ void __launch_bounds__(256) k_mea_scatter(MeaArgs a) {
     }
 }
 
+// count + scan + scatter of one read in LDS (one workgroup per read, its tasks' pairs read three times, from L2 after
+// the first): column sums first, then -- in the same LDS -- the per-position counts, their exclusive scan in place and
+// the scatter with the scanned counts as fill pointers.  For reads whose longer span fits the LDS (4 bytes per base).
+__global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
+    extern __shared__ int h[];
+    __shared__ int wsum[SORT_THREADS / WAVE];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t rx = a.rx_off[r], ry = a.ry_off[r], rp = a.rp_off[r];
+    const int lX = static_cast<int>(a.rx_off[r + 1] - rx) - 1, lY = static_cast<int>(a.ry_off[r + 1] - ry);
+    if (a.rp_off[r + 1] == rp) return;
+    const int ft = a.read_first[r], nt = a.read_ntasks[r];
+    int bad = 0;
+    // the pairs of every task of the read, f(x, y, p-quantum)
+    auto for_pairs = [&](auto f) {
+        for (int s = 0; s < nt; ++s) {
+            const int t = a.task_of[ft + s];
+            const Task &tk = a.tasks[t];
+            const int n = min(a.outs[t].npairs, tk.pair_cap);
+            for (int i = tid; i < n; i += SORT_THREADS) {
+                const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
+                if (x < 0 || x >= lX || y < 0 || y >= lY) {
+                    bad = 1;
+                    continue;
+                }
+                f(x, y, static_cast<int>(floor(static_cast<double>(a.pp[tk.pair_off + i]) * static_cast<double>(P1))));
+            }
+        }
+    };
+    for (int i = tid; i < lY; i += SORT_THREADS) h[i] = 0;
+    __syncthreads();
+    for_pairs([&](int, int y, int q) { atomicAdd(&h[y], q); });
+    __syncthreads();
+    for (int i = tid; i < lY; i += SORT_THREADS) a.colsum[ry + i] = h[i];
+    __syncthreads();
+    for (int i = tid; i <= lX; i += SORT_THREADS) h[i] = 0;
+    __syncthreads();
+    for_pairs([&](int x, int, int) { atomicAdd(&h[x], 1); });
+    __syncthreads();
+    int carry = 0;
+    for (int base = 0; base <= lX; base += SORT_THREADS) {
+        const int i = base + tid;
+        const int v = i <= lX ? h[i] : 0;
+        int sc = v;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int t = __shfl_up(sc, o);
+            if (lane >= o) sc += t;
+        }
+        if (lane == WAVE - 1) wsum[wv] = sc;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int k = 0; k < SORT_THREADS / WAVE; ++k) before += k < wv ? wsum[k] : 0, total += wsum[k];
+        if (i <= lX) h[i] = carry + before + sc - v;
+        carry += total;
+        __syncthreads();
+    }
+    for_pairs([&](int x, int y, int q) {
+        const int64_t pos = rp + atomicAdd(&h[x], 1);
+        a.sx[pos] = x, a.sy[pos] = y, a.sq[pos] = q;
+    });
+    if (bad) a.read_flag[r] = NPR_ERR_INVALID;
+}
+
 constexpr int MEA_RETRY = 1;  // read_flag: the register window was too short for this read, the LDS-ring kernel takes it
 
 // One 64-pair chunk of a read's x-grouped pairs, complete groups only, brought into (x, y) order: the lanes find their
@@ -154,10 +219,14 @@ __device__ __forceinline__ Chunk prep_chunk(const MeaArgs &a, int *sx, int *sy, 
 }
 
 // The heaviest chain ending at or below each read position, for the 128 positions [ybase, ybase + 127], in registers:
-// position k lives in lane k & 63, register (k >> 6) & 1.  Positions above the window all hold `top`.  An insert at
-// position vy raises every held position >= vy the new chain beats -- one compare-and-select per register, no loop:
-// the prefix maximum is monotone.  The window moves up when an insert lands above it (the positions it leaves are
-// forgotten); a query or insert below the window hands the read to the LDS-ring kernel (MEA_RETRY).
+// position k lives in lane k & 63, register (k >> 6) & 1.  Positions above the window all hold `top`.  A chain is one
+// 64-bit key, score << 23 | (last pair + 1): "heavier, ties to the pair that sorts last" is an integer compare (scores
+// are not negative: a chain of negative weight beats nothing, the empty chain included, so it is never inserted).
+// An insert at position vy raises every held position >= vy the new chain beats -- one compare-and-select per
+// register, no loop: the prefix maximum is monotone.  The window moves up when an insert lands above it (the
+// positions it leaves are forgotten); a query or insert below the window hands the read to the LDS-ring kernel
+// (MEA_RETRY), and so do reads too long for the key (scores from 2^40, pairs from 2^23).
+constexpr int WHO_BITS = 23;
 __global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
     __shared__ int64_t tw[WAVE];
     __shared__ int ty[WAVE], tq[WAVE];
@@ -165,17 +234,43 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
     const int r = blockIdx.x;
     const int64_t rp = a.rp_off[r], ry = a.ry_off[r];
     const int n = a.read_flag[r] ? 0 : static_cast<int>(a.rp_off[r + 1] - rp);  // (flagged: the scatter was incomplete)
-    if (a.ring_only) {
+    const int lmin = static_cast<int>(min(a.rx_off[r + 1] - a.rx_off[r] - 1, a.ry_off[r + 1] - ry));
+    if (a.ring_only || n >= (1 << WHO_BITS) - 1 || lmin > 100000) {
         if (lane == 0 && a.read_flag[r] == 0) a.read_flag[r] = MEA_RETRY;
         return;
     }
     int *const sx = a.sx + rp, *const sy = a.sy + rp, *const sq = a.sq + rp, *const back = a.back + rp;
     const int64_t floor_w = static_cast<int64_t>(floor(a.match_gamma * static_cast<double>(P1)));
+    constexpr int64_t WHO_MASK = (int64_t(1) << WHO_BITS) - 1;
     int ybase = 0;
-    int64_t s0 = 0, s1 = 0, top_s = 0;
-    int w0 = -1, w1 = -1, top_w = -1;
+    int64_t p0 = 0, p1 = 0, top = 0;
     int k0 = lane, k1 = lane + 64;  // positions held
     int flag = 0;
+    // heaviest chain over the pairs inserted so far with read position <= key
+    auto query = [&](int key) -> int64_t {
+        if (key < 0) return 0;
+        if (key > ybase + 127) return top;
+        if (key < ybase) {
+            flag = MEA_RETRY;
+            return 0;
+        }
+        return (key & 64) ? rdlane64(p1, key & 63) : rdlane64(p0, key & 63);
+    };
+    auto insert = [&](int vy, int64_t total, int who) {
+        if (total < 0) return;
+        const int64_t v = (total << WHO_BITS) | static_cast<int64_t>(who + 1);
+        if (vy > ybase + 127) {  // move the window up: the positions it gains hold the overall maximum
+            ybase = vy - 127;
+            if (k0 < ybase) p0 = top;
+            if (k1 < ybase) p1 = top;
+            k0 = ybase + ((lane - ybase) & 127), k1 = ybase + ((lane + 64 - ybase) & 127);
+        } else if (vy < ybase) {
+            flag = MEA_RETRY;
+        }
+        top = max(top, v);
+        if (k0 >= vy) p0 = max(p0, v);
+        if (k1 >= vy) p1 = max(p1, v);
+    };
     for (int base = 0; base < n && !flag;) {
         const Chunk c = prep_chunk(a, sx, sy, sq, ry, base, n, lane, floor_w, tw, ty, tq);
         if (!c.valid) {
@@ -186,54 +281,37 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
         int bk = -1;
         uint64_t gm = c.ends & (c.valid == 64 ? ~0ull : ((1ull << c.valid) - 1));
         int gs = 0;
-        while (gm && !flag) {
+        while (gm) {
             const int ge = __builtin_ctzll(gm);
             gm &= gm - 1;
             const uint64_t mine = c.keep & (ge == 63 ? ~0ull : ((2ull << ge) - 1)) & ~((1ull << gs) - 1);
-            for (uint64_t qm = mine; qm;) {  // heaviest chain over the pairs inserted so far with read position < y
+            gs = ge + 1;
+            if (!mine) continue;
+            if (!(mine & (mine - 1))) {  // one pair on this reference position: query and insert in one go
+                const int i = __builtin_ctzll(mine), y = rdlane(c.y, i);
+                const int64_t k = query(y - 1);
+                if (lane == i) bk = static_cast<int>(k & WHO_MASK) - 1;
+                insert(y, rdlane64(c.w, i) + (k >> WHO_BITS), base + i);
+                continue;
+            }
+            for (uint64_t qm = mine; qm;) {  // all queries of the group before its inserts
                 const int i = __builtin_ctzll(qm);
                 qm &= qm - 1;
-                const int key = rdlane(c.y, i) - 1;
-                int64_t bs = 0;
-                int bw = -1;
-                if (key >= 0) {
-                    if (key > ybase + 127) {
-                        bs = top_s, bw = top_w;
-                    } else if (key < ybase) {
-                        flag = MEA_RETRY;
-                    } else if (key & 64) {
-                        bs = rdlane64(s1, key & 63), bw = rdlane(w1, key & 63);
-                    } else {
-                        bs = rdlane64(s0, key & 63), bw = rdlane(w0, key & 63);
-                    }
-                }
-                const int64_t t = rdlane64(c.w, i) + bs;
-                if (lane == i) tot = t, bk = bw;
+                const int64_t k = query(rdlane(c.y, i) - 1);
+                const int64_t t = rdlane64(c.w, i) + (k >> WHO_BITS);
+                if (lane == i) tot = t, bk = static_cast<int>(k & WHO_MASK) - 1;
             }
             for (uint64_t im = mine; im;) {
                 const int i = __builtin_ctzll(im);
                 im &= im - 1;
-                const int vy = rdlane(c.y, i), vw = base + i;
-                const int64_t vs = rdlane64(tot, i);
-                if (vy > ybase + 127) {  // move the window up: the positions it gains hold the overall maximum
-                    ybase = vy - 127;
-                    if (k0 < ybase) s0 = top_s, w0 = top_w;
-                    if (k1 < ybase) s1 = top_s, w1 = top_w;
-                    k0 = ybase + ((lane - ybase) & 127), k1 = ybase + ((lane + 64 - ybase) & 127);
-                } else if (vy < ybase) {
-                    flag = MEA_RETRY;
-                }
-                if (beats(vs, vw, top_s, top_w)) top_s = vs, top_w = vw;
-                if (k0 >= vy && beats(vs, vw, s0, w0)) s0 = vs, w0 = vw;
-                if (k1 >= vy && beats(vs, vw, s1, w1)) s1 = vs, w1 = vw;
+                insert(rdlane(c.y, i), rdlane64(tot, i), base + i);
             }
-            gs = ge + 1;
         }
         if ((c.keep >> lane) & 1) back[base + lane] = bk;
         base += c.valid;
     }
     if (lane == 0) {
-        a.best_who[r] = top_w;
+        a.best_who[r] = static_cast<int>(top & WHO_MASK) - 1;
         if (flag) a.read_flag[r] = flag;
     }
 }
@@ -392,6 +470,12 @@ size_t mea_chain_lds_bytes(int ring) { return static_cast<size_t>(ring) * 12 + W
 
 int launch_mea_sort(const MeaArgs &a, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.sort_lds_bytes > 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mea_sort_lds), hipFuncAttributeMaxDynamicSharedMemorySize, a.sort_lds_bytes);
+        if (e != hipSuccess) return static_cast<int>(e);
+        hipLaunchKernelGGL(k_mea_sort_lds, dim3(a.n_reads), dim3(SORT_THREADS), a.sort_lds_bytes, s, a);
+        return static_cast<int>(hipGetLastError());
+    }
     const int tg = a.ntasks < 8192 ? (a.ntasks > 0 ? a.ntasks : 1) : 8192;
     hipLaunchKernelGGL(k_mea_count, dim3(tg), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_mea_scan, dim3(a.n_reads), dim3(256), 0, s, a);

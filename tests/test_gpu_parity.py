@@ -191,16 +191,19 @@ def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
                dict(band_mode=0, split_threshold=40, constraint_trim=3), dict(band_mode=0, match_gamma=0.95),
                dict(band_mode=0, gap_gamma=0.2, match_gamma=-0.1)):
         got = {}
-        for where in ("device", "device_ring", "host"):  # device_ring: the general (LDS-ring) chain kernel for every read
-            monkeypatch.delenv("NPR_HOST_MEA", raising=False)
-            monkeypatch.delenv("NPR_MEA_RING_ONLY", raising=False)
+        # device_ring: the general (LDS-ring) chain kernel for every read and the global-memory sort kernels (the
+        # variants long spans and far-reaching pairs fall back to)
+        for where in ("device", "device_ring", "host"):
+            for k in ("NPR_HOST_MEA", "NPR_MEA_RING_ONLY", "NPR_MEA_GLOBAL_SORT"):
+                monkeypatch.delenv(k, raising=False)
             if where == "host":
                 monkeypatch.setenv("NPR_HOST_MEA", "1")
             elif where == "device_ring":
                 monkeypatch.setenv("NPR_MEA_RING_ONLY", "1")
+                monkeypatch.setenv("NPR_MEA_GLOBAL_SORT", "1")
             got[where] = gpu_ctx.realign(R.make_params(**kw), refs, reads, guides, want_pairs=(where == "device"))
-        monkeypatch.delenv("NPR_HOST_MEA", raising=False)
-        monkeypatch.delenv("NPR_MEA_RING_ONLY", raising=False)
+        for k in ("NPR_HOST_MEA", "NPR_MEA_RING_ONLY", "NPR_MEA_GLOBAL_SORT"):
+            monkeypatch.delenv(k, raising=False)
         for u, t, v in zip(got["device"], got["device_ring"], got["host"]):
             assert u["status"] == t["status"] == v["status"] == 0
             assert u["ops"] == v["ops"] and u["score"] == v["score"] and u["n_pairs"] == v["n_pairs"], kw
