@@ -16,6 +16,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "npr_device.h"
@@ -69,7 +70,7 @@ namespace {
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
-    size_t count = 0;
+    size_t count = 0, cap = 0;
     hipError_t alloc(size_t n) {
         release();
         count = n;
@@ -77,13 +78,18 @@ struct DevBuf {
         return hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
-        count = 0;
+        count = 0, cap = 0, borrowed = false;
+    }
+    // a view of memory owned elsewhere (the forward scratch arena, idle between the DP launch and the next one)
+    bool borrowed = false;
+    void borrow(T *ptr, size_t n) {
+        release();
+        p = ptr, count = n, borrowed = true;
     }
     size_t bytes() const { return count * sizeof(T); }
     // grow-only use (scratch kept from batch to batch): count is the size asked for, cap what is allocated
-    size_t cap = 0;
     hipError_t reserve(size_t n) {
         if (n <= cap && p) {
             count = n;
@@ -929,13 +935,10 @@ int32_t device_mea(npr_batch *b) {
         rp[i + 1] = rp[i] + np;
         ot[i + 1] = ot[i] + 3 * std::min({np, lX, lY}) + 2;  // (D, I, M) per chain pair, one trailing (D, I)
     }
-    int64_t maxw = 64;
-    for (const auto &dl : b->launches) maxw = std::max<int64_t>(maxw, dl.width);
-    // the LDS-ring kernel (reads the register window gives up on): read positions the prefix maximum is kept for,
-    // several times what one reference position's band spans, as far as the LDS goes; a read that outgrows even that
-    // is reported and the batch takes the host stage
-    int ring = 256;
-    while (ring < 4 * maxw + 64 && ring < 8192) ring <<= 1;
+    // the LDS-ring kernel takes the few reads the register window gives up on: as many read positions as the LDS
+    // holds with one workgroup per CU; a read whose pairs reach back further than that is reported and the batch takes
+    // the host stage
+    const int ring = 8192;
     const int64_t total = rp[n];
     if (!ctx->mea) ctx->mea = new MeaScratch;
     MeaScratch &m = *ctx->mea;
@@ -945,15 +948,33 @@ int32_t device_mea(npr_batch *b) {
     for (int64_t i = 0; i < n; ++i) span = std::max(span, rx[i + 1] - rx[i]), span = std::max(span, ry[i + 1] - ry[i]);
     const bool sort_in_lds = 4 * span <= 64 * 1024 && !std::getenv("NPR_MEA_GLOBAL_SORT");
     const size_t ntask_map = b->task_of.size();
-    if ((e = m.map.reserve(2 * n + ntask_map)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the MEA scratch", e);
+    // The forward scratch of the DP launches is idle now and usually far larger than what this stage needs: carve the
+    // tables out of it (a batch that fills the device's memory leaves nothing to hipMalloc).  Else: grow-only buffers.
+    const size_t n_cnt = sort_in_lds ? 1 : rx[n];
+    {
+        auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+        const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (4 * total + 4)) +
+                            al(4 * 4 * n) + al(4 * 2 * ot[n]) + al(4 * (2 * n + ntask_map)) + al(4 * ot[n]);
+        const bool in_arena = ctx->arena_F && need <= static_cast<size_t>(ctx->arena_cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
+        char *cur = ctx->arena_F;
+        auto take = [&](auto &buf, size_t count) -> hipError_t {
+            using T = std::remove_pointer_t<decltype(buf.p)>;
+            if (!in_arena) return buf.reserve(count);
+            buf.borrow(reinterpret_cast<T *>(cur), count);
+            cur += al(sizeof(T) * count);
+            return hipSuccess;
+        };
+        if ((e = take(m.off, 4 * (n + 1))) != hipSuccess || (e = take(m.mass, n)) != hipSuccess || (e = take(m.od, n + 1)) != hipSuccess ||
+            (e = take(m.cnt, n_cnt)) != hipSuccess || (e = take(m.start, n_cnt)) != hipSuccess || (e = take(m.col, ry[n] + 1)) != hipSuccess ||
+            (e = take(m.sorted, 4 * total + 4)) != hipSuccess || (e = take(m.small, 4 * n)) != hipSuccess || (e = take(m.tmp, 2 * ot[n])) != hipSuccess ||
+            (e = take(m.map, 2 * n + ntask_map)) != hipSuccess || (e = take(m.dense, ot[n])) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;  // no room on the device: the host stage takes the batch
+        }
+    }
     HIP_TRY(ctx, hipMemcpyAsync(m.map.p, b->read_first_task.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(m.map.p + n, b->read_ntasks.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(m.map.p + 2 * n, b->task_of.data(), sizeof(int32_t) * ntask_map, hipMemcpyHostToDevice, ctx->stream));
-    if ((e = m.off.reserve(4 * (n + 1))) != hipSuccess || (e = m.mass.reserve(n)) != hipSuccess || (e = m.od.reserve(n + 1)) != hipSuccess ||
-        (e = m.cnt.reserve(sort_in_lds ? 1 : rx[n])) != hipSuccess || (e = m.start.reserve(sort_in_lds ? 1 : rx[n])) != hipSuccess ||
-        (e = m.col.reserve(ry[n] + 1)) != hipSuccess ||
-        (e = m.sorted.reserve(4 * total + 4)) != hipSuccess || (e = m.small.reserve(4 * n)) != hipSuccess || (e = m.tmp.reserve(2 * ot[n])) != hipSuccess)
-        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the MEA scratch", e);
     std::vector<int64_t> offs(4 * (n + 1));
     std::copy(rx.begin(), rx.end(), offs.begin());
     std::copy(ry.begin(), ry.end(), offs.begin() + (n + 1));
@@ -1006,11 +1027,10 @@ int32_t device_mea(npr_batch *b) {
     }
     if (od[n]) {
         // one packed word per op (length << 2 | op) through the pinned staging, unpacked by the host threads
-        if ((e = m.dense.reserve(od[n])) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc of the ops", e);
-        a.ops_dense = m.dense.p;
+        a.ops_dense = m.dense.p;  // (sized for the bound ot[n] >= od[n])
         HIP_TRY(ctx, hipMemcpyAsync(m.od.p, od.data(), m.od.bytes(), hipMemcpyHostToDevice, ctx->stream));
         if ((rc = launch_mea_gather(a, ctx->stream)) != 0) return fail(ctx, NPR_ERR_HIP, "k_mea_gather launch", static_cast<hipError_t>(rc));
-        const size_t need = m.dense.bytes();
+        const size_t need = sizeof(uint32_t) * static_cast<size_t>(od[n]);
         if (need > ctx->pin_pairs_bytes) {
             if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
             ctx->pin_pairs = nullptr, ctx->pin_pairs_bytes = 0;
@@ -1072,10 +1092,11 @@ int32_t npr_batch_finish(npr_batch *b) {
     // --- realign mode: chain and cigar on the device, the pairs stay in HBM until npr_batch_pairs asks for them ---
     if (b->params.mode == NPR_MODE_REALIGN && n > 0 && ntasks > 0 && !std::getenv("NPR_HOST_MEA")) {
         int64_t scratch = 0;
-        for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 24 * std::min(b->ref_len[i], b->read_len[i]);
+        for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 36 * std::min(b->ref_len[i], b->read_len[i]) + 128;
         scratch += 16 * b->pair_off[n];
         size_t mem_free = 0, mem_total = 0;
-        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && static_cast<size_t>(scratch) < mem_free / 2) {
+        if (static_cast<size_t>(scratch) <= static_cast<size_t>(ctx->arena_cells) * 8 ||
+            (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && static_cast<size_t>(scratch) < mem_free / 2)) {
             const int32_t rc = device_mea(b);
             if (rc < 0) return rc;
             if (rc == NPR_OK) {
