@@ -156,7 +156,10 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
  * resident in HBM.  Blocks until done; kernel_ms (nullable) receives the HIP-event time of the DP launch
  * measured on the context's stream.  May be called repeatedly (benchmarks). */
 int32_t npr_batch_run(npr_batch *b, float *kernel_ms);
-/* Stage 3 (D2H + host): sparse posteriors back, MEA chain / rescore, cigars. */
+/* Stage 3: MEA chain / rescore, cigars.  In NPR_MODE_REALIGN the chain and the cigar are computed on the device from
+ * the posterior pairs where they lie (integer arithmetic: the same ops and scores as the host stage, npr_mea_cigar) and
+ * only the run-length ops come back; the other modes, and batches whose tables do not fit the device, copy the pairs
+ * to the host and chain there. */
 int32_t npr_batch_finish(npr_batch *b);
 void npr_batch_destroy(npr_batch *b);
 
@@ -174,7 +177,8 @@ int32_t npr_batch_results(const npr_batch *b, npr_read_result *out /* [n_reads] 
 int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_t cap_pairs);
 /* sparse posteriors (>= threshold), CSR by read, sorted by (x, y); x is the 0-based reference coordinate in
  * the read's slice, y the 0-based read coordinate: the `refPos readPos prob` TSV of
- * --outputAllPosteriorProbs (marginAlignSnpCaller.py:149). */
+ * --outputAllPosteriorProbs (marginAlignSnpCaller.py:149).  After a device-side npr_batch_finish the pairs are
+ * still in HBM: the first call with x != NULL copies and sorts them (pair_off alone costs nothing). */
 int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32_t *y, float *p, int64_t cap);
 
 /* Baum-Welch E-step over the staged batch with the models currently installed: what
