@@ -551,7 +551,8 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         task_y[k] = seq_bytes;
         seq_bytes += s.ye - s.ys;
     }
-    std::vector<uint8_t> h_seq(seq_bytes);
+    const std::unique_ptr<uint8_t[]> h_seq_buf(new uint8_t[seq_bytes + 1]);
+    uint8_t *const h_seq = h_seq_buf.get();
     parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
@@ -601,16 +602,16 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         cls_width[c] = std::max<int64_t>(cls_width[c], s.max_width);
         cls_cells[c] += s.cells;
     }
-    std::vector<int32_t> h_lo(band_entries), h_n(band_entries);
-    std::vector<uint32_t> h_coff(band_entries);
+    // not vectors: value-initialising gigabytes on one thread took longer than filling them on all of them
+    const std::unique_ptr<int32_t[]> h_lo(new int32_t[band_entries + 1]), h_n(new int32_t[band_entries + 1]);
+    const std::unique_ptr<uint32_t[]> h_coff(new uint32_t[band_entries + 1]), h_ctl(new uint32_t[2 * ctl_entries + 2]);
     std::vector<int64_t> pad_cells(ntasks);
-    std::vector<uint32_t> h_ctl(2 * ctl_entries);
     parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
         const Ref &r = order[rank[k]];
         const Segment &s = plans[r.read].segs[r.seg];
         int64_t stair_cells = 0;
         if (b->tasks[k].ctl_off >= 0)
-            build_stair_schedule(s, kClassTab[cls_of[rank[k]]].R, kClassTab[cls_of[rank[k]]].NW, h_ctl.data() + 2 * b->tasks[k].ctl_off, &stair_cells);
+            build_stair_schedule(s, kClassTab[cls_of[rank[k]]].R, kClassTab[cls_of[rank[k]]].NW, h_ctl.get() + 2 * b->tasks[k].ctl_off, &stair_cells);
         uint64_t off = 0;
         for (int64_t d = 0; d <= s.D(); ++d) {
             h_lo[band_base[k] + d] = s.lo[d];
@@ -723,11 +724,11 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     tm.lap("hipMalloc");
     if (ntasks) {
         HIP_TRY(ctx, hipMemcpy(b->d_tasks.p, b->tasks.data(), b->d_tasks.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_seq.p, h_seq.data(), b->d_seq.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_lo.p, h_lo.data(), b->d_lo.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_n.p, h_n.data(), b->d_n.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.data(), b->d_coff.bytes(), hipMemcpyHostToDevice));
-        if (ctl_entries) HIP_TRY(ctx, hipMemcpy(b->d_ctl.p, h_ctl.data(), b->d_ctl.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_seq.p, h_seq, b->d_seq.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_lo.p, h_lo.get(), b->d_lo.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_n.p, h_n.get(), b->d_n.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.get(), b->d_coff.bytes(), hipMemcpyHostToDevice));
+        if (ctl_entries) HIP_TRY(ctx, hipMemcpy(b->d_ctl.p, h_ctl.get(), b->d_ctl.bytes(), hipMemcpyHostToDevice));
     }
     tm.lap("H2D");
     b->outs.resize(ntasks);
