@@ -3,8 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -S --cuda-device-only tools/pk_step.hip
 // VALU instructions per step in the loop: 90.5 (30 packed) against 116.5 for the same arithmetic on scalars (replace
 // the typedef by a struct of two floats) -- about -18 % issue cycles at the measured 4.8 / 4.07 cycles per packed /
-// plain instruction.  In k_dp_stair itself, packing only the cell update while the state stays scalar gained nothing:
-// the compiler re-paired the operands with 34 moves per step.
+// plain instruction -- on paper.  Built into k_dp_stair<2> (state carried as pairs, all parity tests green) the launch
+// took 151 ms instead of 133 ms: see DESIGN.md 11.
 #include <hip/hip_runtime.h>
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct Tr { float mm, sxm, sym, lxm, lym, msx, sxsx, sysx, msy, sysy, sxsy, mlx, lxlx, mly, lyly; };
