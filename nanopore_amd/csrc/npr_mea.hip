@@ -277,34 +277,24 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
             flag = MEA_RETRY;
             break;
         }
-        int64_t tot = 0;
         int bk = -1;
         uint64_t gm = c.ends & (c.valid == 64 ? ~0ull : ((1ull << c.valid) - 1));
-        int gs = 0;
+        uint64_t below = 0;  // lanes of the groups already done
         while (gm) {
             const int ge = __builtin_ctzll(gm);
             gm &= gm - 1;
-            const uint64_t mine = c.keep & (ge == 63 ? ~0ull : ((2ull << ge) - 1)) & ~((1ull << gs) - 1);
-            gs = ge + 1;
-            if (!mine) continue;
-            if (!(mine & (mine - 1))) {  // one pair on this reference position: query and insert in one go
-                const int i = __builtin_ctzll(mine), y = rdlane(c.y, i);
+            const uint64_t upto = ge == 63 ? ~0ull : ((2ull << ge) - 1);
+            uint64_t mine = c.keep & upto & ~below;
+            below = upto;
+            // The pairs of one reference position must not see each other's chains.  Taken from the highest read
+            // position down, each can query and insert in one go: an insert at y leaves every position below y alone.
+            while (mine) {
+                const int i = 63 - __builtin_clzll(mine);
+                mine ^= 1ull << i;
+                const int y = rdlane(c.y, i);
                 const int64_t k = query(y - 1);
                 if (lane == i) bk = static_cast<int>(k & WHO_MASK) - 1;
                 insert(y, rdlane64(c.w, i) + (k >> WHO_BITS), base + i);
-                continue;
-            }
-            for (uint64_t qm = mine; qm;) {  // all queries of the group before its inserts
-                const int i = __builtin_ctzll(qm);
-                qm &= qm - 1;
-                const int64_t k = query(rdlane(c.y, i) - 1);
-                const int64_t t = rdlane64(c.w, i) + (k >> WHO_BITS);
-                if (lane == i) tot = t, bk = static_cast<int>(k & WHO_MASK) - 1;
-            }
-            for (uint64_t im = mine; im;) {
-                const int i = __builtin_ctzll(im);
-                im &= im - 1;
-                insert(rdlane(c.y, i), rdlane64(tot, i), base + i);
             }
         }
         if ((c.keep >> lane) & 1) back[base + lane] = bk;
