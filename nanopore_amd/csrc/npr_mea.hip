@@ -171,14 +171,16 @@ __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
 
 constexpr int MEA_RETRY = 1;  // read_flag: the register window was too short for this read, the LDS-ring kernel takes it
 
-// One 64-pair chunk of a read's x-grouped pairs, complete groups only, brought into (x, y) order: the lanes find their
-// rank inside their group (groups are a few pairs), weigh their pair and change places through LDS.
+// One 64-pair chunk of a read's x-grouped pairs, complete groups only: the lanes find their rank inside their group
+// (groups are a few pairs), weigh their pair and change places through LDS so that a group runs from its highest read
+// position down (the order the chain kernel wants, see there); sy / sq are rewritten in (x, y) order for the trace.
 struct Chunk {
     int valid;      // pairs taken (0: a group of more than 64 pairs)
     uint64_t ends;  // last lane of every group, over the valid lanes
     uint64_t keep;  // lanes whose weight exceeds matchGamma
-    int y, q;       // sorted order from here on
+    int y, q;       // by reference position, and inside a reference position from the highest read position down
     int64_t w;
+    int who;        // the pair's place in (x, y) order, relative to the chunk: its id (ties go to the larger)
 };
 __device__ __forceinline__ Chunk prep_chunk(const MeaArgs &a, int *sx, int *sy, int *sq, int64_t ry, int base, int n, int lane,
                                             int64_t floor_w, int64_t *tw, int *ty, int *tq) {
@@ -208,13 +210,14 @@ __device__ __forceinline__ Chunk prep_chunk(const MeaArgs &a, int *sx, int *sy, 
     const int64_t w0 = q - static_cast<int64_t>(floor(a.gap_gamma * static_cast<double>(gap)));
     wave_sync();
     if (act) {
-        const int to = gfirst + rank;  // sorted place inside the chunk
+        const int to = gend - rank;
         tw[to] = w0, ty[to] = y, tq[to] = q;
     }
     wave_sync();
     c.w = tw[lane], c.y = ty[lane], c.q = tq[lane];
     c.keep = __ballot(act && c.w > floor_w);
-    if (act) sy[pos] = c.y, sq[pos] = c.q;  // the trace reads them back
+    c.who = gfirst + gend - lane;
+    if (act) sy[base + c.who] = c.y, sq[base + c.who] = c.q;  // the trace reads them back
     return c;
 }
 
@@ -278,26 +281,16 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
             break;
         }
         int bk = -1;
-        uint64_t gm = c.ends & (c.valid == 64 ? ~0ull : ((1ull << c.valid) - 1));
-        uint64_t below = 0;  // lanes of the groups already done
-        while (gm) {
-            const int ge = __builtin_ctzll(gm);
-            gm &= gm - 1;
-            const uint64_t upto = ge == 63 ? ~0ull : ((2ull << ge) - 1);
-            uint64_t mine = c.keep & upto & ~below;
-            below = upto;
-            // The pairs of one reference position must not see each other's chains.  Taken from the highest read
-            // position down, each can query and insert in one go: an insert at y leaves every position below y alone.
-            while (mine) {
-                const int i = 63 - __builtin_clzll(mine);
-                mine ^= 1ull << i;
-                const int y = rdlane(c.y, i);
-                const int64_t k = query(y - 1);
-                if (lane == i) bk = static_cast<int>(k & WHO_MASK) - 1;
-                insert(y, rdlane64(c.w, i) + (k >> WHO_BITS), base + i);
-            }
+        // The pairs of one reference position must not see each other's chains.  Taken from the highest read position
+        // down (the lane order prep_chunk leaves), each can query and insert in one go: an insert at y leaves every
+        // position below y alone.
+        for (uint64_t todo = c.keep; todo; todo &= todo - 1) {
+            const int i = __builtin_ctzll(todo), y = rdlane(c.y, i);
+            const int64_t k = query(y - 1);
+            if (lane == i) bk = static_cast<int>(k & WHO_MASK) - 1;
+            insert(y, rdlane64(c.w, i) + (k >> WHO_BITS), base + rdlane(c.who, i));
         }
-        if ((c.keep >> lane) & 1) back[base + lane] = bk;
+        if ((c.keep >> lane) & 1) back[base + c.who] = bk;
         base += c.valid;
     }
     if (lane == 0) {
@@ -333,7 +326,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
             flag = NPR_ERR_CAPACITY;  // more than 64 pairs on one reference position: cannot happen above a 0.01 threshold
             break;
         }
-        const int pos = base + lane, y = c.y;
+        const int pos = base + c.who, y = c.y;
         const int64_t w = c.w;
         const bool keep = (c.keep >> lane) & 1;
         uint64_t gm = c.ends & (c.valid == 64 ? ~0ull : ((1ull << c.valid) - 1));
@@ -362,7 +355,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
             while (km) {
                 const int i = __builtin_ctzll(km);
                 km &= km - 1;
-                const int vy = rdlane(y, i), vw = base + i;
+                const int vy = rdlane(y, i), vw = base + rdlane(c.who, i);
                 const int64_t vs = rdlane64(total, i);
                 if (vy > ytop) {
                     const int fill = min(vy - ytop - 1, RING);
