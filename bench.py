@@ -151,6 +151,8 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if world > 1:  # the ranks of one node share its host cores: split them instead of oversubscribing each rank's pool
+        os.environ.setdefault("NPR_HOST_THREADS", str(max(1, usable_cpus() // world)))
     from nanopore_amd import realign as R
     n_reads = args.reads or {"northstar": 12288, "c2": 1000, "c3": 50000, "anchor": 8192}[args.workload]
     h, w, W, label = build_workload(args.workload, n_reads, rank)
