@@ -211,6 +211,26 @@ def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
             assert len(u["p"]) == u["n_pairs"]
 
 
+def test_device_mea_long_spans(gpu_ctx, monkeypatch):
+    """Reads longer than the 16 k positions the in-LDS sort holds: the device chain takes its tables through HBM
+    (k_mea_count / k_mea_scan / k_mea_scatter) without being told to; same ops and scores as the host stage."""
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(29)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    cases = [random_pair(rng, n, indel=0.15, max_indel=25) for n in (17000, 300, 21000)]
+    refs = [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases]
+    reads = [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases]
+    guides = [g for _, _, g in cases]
+    P = R.make_params(band_mode=1, fixed_width=80)
+    dev = gpu_ctx.realign(P, refs, reads, guides)
+    monkeypatch.setenv("NPR_HOST_MEA", "1")
+    host = gpu_ctx.realign(P, refs, reads, guides)
+    monkeypatch.delenv("NPR_HOST_MEA", raising=False)
+    for u, v, (X, Y, _) in zip(dev, host, cases):
+        assert u["status"] == v["status"] == 0 and u["ops"] == v["ops"] and u["score"] == v["score"]
+        assert cigar_spans(u["ops"]) == (len(X), len(Y))
+
+
 def test_base_dependent_gap_emissions(gpu_ctx):
     """Gap-state emissions that depend on the base (and the flat N emission next to them): every shipped model is
     flat there, so this is the only place the per-base gap tables are exercised."""
