@@ -251,24 +251,24 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
     int flag = 0;
     // heaviest chain over the pairs inserted so far with read position <= key
     auto query = [&](int key) -> int64_t {
+        if (static_cast<unsigned>(key - ybase) < 128u) return (key & 64) ? rdlane64(p1, key & 63) : rdlane64(p0, key & 63);  // the usual case
         if (key < 0) return 0;
         if (key > ybase + 127) return top;
-        if (key < ybase) {
-            flag = MEA_RETRY;
-            return 0;
-        }
-        return (key & 64) ? rdlane64(p1, key & 63) : rdlane64(p0, key & 63);
+        flag = MEA_RETRY;  // below the window
+        return 0;
     };
     auto insert = [&](int vy, int64_t total, int who) {
         if (total < 0) return;
         const int64_t v = (total << WHO_BITS) | static_cast<int64_t>(who + 1);
-        if (vy > ybase + 127) {  // move the window up: the positions it gains hold the overall maximum
-            ybase = vy - 127;
-            if (k0 < ybase) p0 = top;
-            if (k1 < ybase) p1 = top;
-            k0 = ybase + ((lane - ybase) & 127), k1 = ybase + ((lane + 64 - ybase) & 127);
-        } else if (vy < ybase) {
-            flag = MEA_RETRY;
+        if (static_cast<unsigned>(vy - ybase) >= 128u) {
+            if (vy < ybase) {
+                flag = MEA_RETRY;
+            } else {  // move the window up: the positions it gains hold the overall maximum
+                ybase = vy - 127;
+                if (k0 < ybase) p0 = top;
+                if (k1 < ybase) p1 = top;
+                k0 = ybase + ((lane - ybase) & 127), k1 = ybase + ((lane + 64 - ybase) & 127);
+            }
         }
         top = max(top, v);
         if (k0 >= vy) p0 = max(p0, v);
