@@ -955,7 +955,7 @@ int32_t device_mea(npr_batch *b) {
     {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
         const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (4 * total + 4)) +
-                            al(4 * 4 * n) + al(4 * 2 * ot[n]) + al(4 * (2 * n + ntask_map)) + al(4 * ot[n]);
+                            al(4 * 4 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]);
         const bool in_arena = ctx->arena_F && need <= static_cast<size_t>(ctx->arena_cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
         char *cur = ctx->arena_F;
         auto take = [&](auto &buf, size_t count) -> hipError_t {
@@ -968,7 +968,7 @@ int32_t device_mea(npr_batch *b) {
         if ((e = take(m.off, 4 * (n + 1))) != hipSuccess || (e = take(m.mass, n)) != hipSuccess || (e = take(m.od, n + 1)) != hipSuccess ||
             (e = take(m.cnt, n_cnt)) != hipSuccess || (e = take(m.start, n_cnt)) != hipSuccess || (e = take(m.col, ry[n] + 1)) != hipSuccess ||
             (e = take(m.sorted, 4 * total + 4)) != hipSuccess || (e = take(m.small, 4 * n)) != hipSuccess || (e = take(m.tmp, 2 * ot[n])) != hipSuccess ||
-            (e = take(m.map, 2 * n + ntask_map)) != hipSuccess || (e = take(m.dense, ot[n])) != hipSuccess) {
+            (e = take(m.map, 3 * n + ntask_map)) != hipSuccess || (e = take(m.dense, ot[n])) != hipSuccess) {
             (void)hipGetLastError();
             return 1;  // no room on the device: the host stage takes the batch
         }
@@ -976,6 +976,10 @@ int32_t device_mea(npr_batch *b) {
     HIP_TRY(ctx, hipMemcpyAsync(m.map.p, b->read_first_task.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(m.map.p + n, b->read_ntasks.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(m.map.p + 2 * n, b->task_of.data(), sizeof(int32_t) * ntask_map, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int32_t> order(n);  // longest first: the per-read kernels end together instead of waiting for a late long read
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rp[x + 1] - rp[x] > rp[y + 1] - rp[y]; });
+    HIP_TRY(ctx, hipMemcpyAsync(m.map.p + 2 * n + ntask_map, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     std::vector<int64_t> offs(4 * (n + 1));
     std::copy(rx.begin(), rx.end(), offs.begin());
     std::copy(ry.begin(), ry.end(), offs.begin() + (n + 1));
@@ -997,7 +1001,7 @@ int32_t device_mea(npr_batch *b) {
     a.chain_mass = m.mass.p;
     a.gap_gamma = b->params.gap_gamma, a.match_gamma = b->params.match_gamma, a.ring = ring;
     a.ring_only = std::getenv("NPR_MEA_RING_ONLY") ? 1 : 0;
-    a.read_first = m.map.p, a.read_ntasks = m.map.p + n, a.task_of = m.map.p + 2 * n;
+    a.read_first = m.map.p, a.read_ntasks = m.map.p + n, a.task_of = m.map.p + 2 * n, a.order = m.map.p + 2 * n + ntask_map;
     a.sort_lds_bytes = sort_in_lds ? static_cast<int32_t>(4 * span) : 0;
     a.ops_tmp = m.tmp.p, a.od_off = m.od.p;
     int rc = launch_mea_sort(a, ctx->stream);

@@ -103,6 +103,7 @@ struct MeaArgs {
     int32_t *read_flag;      // 0 or an NPR_ERR_* raised by this stage
     double gap_gamma, match_gamma;
     int32_t ring;            // entries of the prefix-maximum ring (power of two)
+    const int32_t *order;    // reads by decreasing pair count: the per-read kernels take them in this order (no long read last)
     const int32_t *read_first, *read_ntasks, *task_of;  // the tasks of a read: task_of[read_first[r] + s]
     int32_t sort_lds_bytes;  // > 0: k_mea_sort_lds with this much LDS; 0: the three global-memory kernels
     int32_t ring_only;       // tests: every read through the LDS-ring kernel

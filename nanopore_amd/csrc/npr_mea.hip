@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) k_mea_scatter(MeaArgs a) {
 __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
     extern __shared__ int h[];
     __shared__ int wsum[SORT_THREADS / WAVE];
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = a.order[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t rx = a.rx_off[r], ry = a.ry_off[r], rp = a.rp_off[r];
     const int lX = static_cast<int>(a.rx_off[r + 1] - rx) - 1, lY = static_cast<int>(a.ry_off[r + 1] - ry);
     if (a.rp_off[r + 1] == rp) return;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
     __shared__ int64_t tw[WAVE];
     __shared__ int ty[WAVE], tq[WAVE];
     const int lane = threadIdx.x;
-    const int r = blockIdx.x;
+    const int r = a.order[blockIdx.x];
     const int64_t rp = a.rp_off[r], ry = a.ry_off[r];
     const int n = a.read_flag[r] ? 0 : static_cast<int>(a.rp_off[r + 1] - rp);  // (flagged: the scatter was incomplete)
     const int lmin = static_cast<int>(min(a.rx_off[r + 1] - a.rx_off[r] - 1, a.ry_off[r + 1] - ry));
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
 // One wavefront per read: the chain's pairs are visited in descending sorted order and mostly a few entries apart,
 // so 64 consecutive entries are loaded at once and the back pointers followed from lane to lane; lane 0 writes.
 __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
-    const int r = blockIdx.x, lane = threadIdx.x;
+    const int r = a.order[blockIdx.x], lane = threadIdx.x;
     const int64_t rp = a.rp_off[r];
     const int *sx = a.sx + rp, *sy = a.sy + rp, *sq = a.sq + rp, *back = a.back + rp;
     const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
