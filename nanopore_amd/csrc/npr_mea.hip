@@ -28,7 +28,7 @@ namespace {
 
 constexpr int64_t P1 = PROB_ONE;
 constexpr int WAVE = 64;
-constexpr int SORT_THREADS = 512;  // k_mea_sort_lds: its loops wait on memory, so many wavefronts per read
+constexpr int SORT_THREADS = 1024;  // k_mea_sort_lds: its loops wait on memory, so many wavefronts per read
 
 __device__ __forceinline__ int rdlane(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
 __device__ __forceinline__ int64_t rdlane64(int64_t v, int j) {
