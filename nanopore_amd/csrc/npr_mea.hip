@@ -415,14 +415,25 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
     while (i >= 0) {
         const int cb = max(i - (WAVE - 1), 0), idx = min(cb + lane, i);
         const int vb = back[idx], vx = sx[idx], vy = sy[idx], vq = sq[idx];
+        // Runs of diagonal steps (the previous pair of the chain is (x-1, y-1): most steps) are found by all lanes at
+        // once -- pointer jumping over the back pointers inside the chunk, the posterior mass summed along -- so that
+        // the serial walk below takes one step per run, not per pair.
+        const int rel = (vb - cb) & (WAVE - 1);
+        const bool diag = vb >= cb && __shfl(vx, rel) == vx - 1 && __shfl(vy, rel) == vy - 1;
+        int nxt = diag ? rel : lane, val = diag ? vq : 0;  // val: mass of the pairs from this one down to, not including, nxt
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            val += __shfl(val, nxt);
+            nxt = __shfl(nxt, nxt);
+        }
         while (i >= cb) {
-            const int l = i - cb;
-            const int x = rdlane(vx, l), y = rdlane(vy, l);
+            const int l = i - cb, h = rdlane(nxt, l);
+            const int x = rdlane(vx, l), y = rdlane(vy, l), hx = rdlane(vx, h), hy = rdlane(vy, h);
             emit(NPR_OP_I, cy - y - 1);  // backwards: the pair's M comes last in its (D, I, M) triple
             emit(NPR_OP_D, cx - x - 1);
-            emit(NPR_OP_M, 1);
-            cx = x, cy = y, mass += rdlane(vq, l), ++len;
-            i = rdlane(vb, l);
+            emit(NPR_OP_M, x - hx + 1);  // the run's pairs
+            cx = hx, cy = hy, mass += rdlane(val, l) + rdlane(vq, h), len += x - hx + 1;
+            i = rdlane(vb, h);
         }
     }
     emit(NPR_OP_I, cy);
