@@ -66,6 +66,8 @@ extern "C" {
                                        posterior of its M columns */
 #define NPR_MODE_ALL_POSTERIORS 2   /* marginAlignSnpCaller.py:136-146: --outputAllPosteriorProbs; the MEA
                                        cigar is produced as well (stdout of that call) */
+#define NPR_MODE_EXPECTATIONS 3     /* utils.py:509-528: the batch is staged for npr_batch_expectations (the E-step of
+                                       cactus_expectationMaximisation); npr_batch_run / finish behave as NPR_MODE_REALIGN */
 
 #define NPR_MAX_MODELS 8
 
@@ -108,7 +110,9 @@ typedef struct {
     int64_t max_width;      /* widest anti-diagonal (cells) */
     int64_t device_bytes;   /* device memory held by the batch */
     int64_t slots;          /* resident wavefront slots used by the DP launch */
-    int32_t kernel_variant; /* 0 = generic LDS-ring kernel, 1 = register systolic kernel */
+    int32_t kernel_variant; /* kernel that carries most cells: 0 = generic LDS-ring kernel, 1 = register kernel on a frame
+                               that follows the anti-diagonal (k_dp_stair / k_dp_wide), 2 = register kernel on column
+                               stripes (k_dp_tile) */
 } npr_batch_stats;
 
 /* ---- library / context ---- */
@@ -165,10 +169,12 @@ void npr_batch_destroy(npr_batch *b);
 
 int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
 /* Diagnostics: how the batch's DP problems (segments) were spread over the kernel classes.  tasks[c] / cells[c] for
- * class c (either may be NULL), capacity `cap` entries; returns the number of classes (11):
+ * class c (either may be NULL), capacity `cap` entries; returns the number of classes (12):
  *   0-2  register kernel, one wavefront per task, 64 / 128 / 256 slots (k_dp_stair<1|2|4>)
  *   3-6  register kernel, 4 / 8 / 8 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
- *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring */
+ *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring
+ *   11   register kernel on column stripes, any width (k_dp_tile); takes what 3-10 would take unless the batch is staged
+ *        with NPR_MODE_EXPECTATIONS or NPR_NO_TILE=1 is set */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* results, valid after npr_batch_finish */
 int32_t npr_batch_results(const npr_batch *b, npr_read_result *out /* [n_reads] */);
@@ -224,6 +230,12 @@ int32_t npr_plan_segment_band(const npr_plan *pl, int32_t seg, int32_t *lo, int3
  * followed with that frame. */
 int32_t npr_plan_frame_schedule(const npr_plan *pl, int32_t seg, int32_t slots, int32_t slots_per_lane, int32_t *jlo,
                                 int32_t *rebase, uint32_t *row_off, int64_t *cells);
+/* Stripe table of the wide-band kernel (k_dp_tile) for one segment (host logic, for inspection and tests): the lattice
+ * columns 0..lX are cut into stripes of at most 64 * slots_per_lane columns, one wavefront sweeps a stripe anti-diagonal
+ * by anti-diagonal.  stripes5[5 * k ..] = first column, columns, first / last anti-diagonal with band cells in the
+ * stripe, index of its first row in the task's forward scratch (one row per anti-diagonal of a stripe); *rows = rows of
+ * the segment.  Returns the number of stripes (stripes5 == NULL: only that), NPR_ERR_CAPACITY when cap is smaller. */
+int32_t npr_plan_stripes(const npr_plan *pl, int32_t seg, int32_t slots_per_lane, int32_t *stripes5, int32_t cap, int64_t *rows);
 /* MEA chain + cigar from sparse posteriors (stage a5.6).  Returns number of op pairs or NPR_ERR_*. */
 int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y, const float *p, int64_t n,
                       double gap_gamma, double match_gamma, int32_t *ops, int64_t cap_pairs, double *score);

@@ -17,7 +17,7 @@ ERR_INVALID, ERR_ZERO_PROB, ERR_CAPACITY, ERR_MODEL, ERR_NO_DEVICE, ERR_HIP, ERR
     ERR_STATE = -1, -2, -3, -4, -5, -6, -7, -8, -9
 OP_M, OP_I, OP_D = 0, 1, 2
 BAND_ANCHOR, BAND_FIXED = 0, 1
-MODE_REALIGN, MODE_RESCORE_ORIGINAL, MODE_ALL_POSTERIORS = 0, 1, 2
+MODE_REALIGN, MODE_RESCORE_ORIGINAL, MODE_ALL_POSTERIORS, MODE_EXPECTATIONS = 0, 1, 2, 3
 MAX_MODELS = 8
 E_DEAD = -(1 << 28)
 
@@ -84,7 +84,7 @@ EXPORTS = [
     "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_batch_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
-    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
+    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
 ]
 
 _lib = None
@@ -149,6 +149,8 @@ def load():
     L.npr_plan_segment_info.argtypes = [vp, i32, vp]
     L.npr_plan_segment_band.restype = i32
     L.npr_plan_segment_band.argtypes = [vp, i32, vp, vp]
+    L.npr_plan_stripes.restype = i32
+    L.npr_plan_stripes.argtypes = [vp, i32, i32, vp, i32, vp]
     L.npr_mea_cigar.restype = i64
     L.npr_mea_cigar.argtypes = [i64, i64, vp, vp, vp, i64, dbl, dbl, vp, i64, C.POINTER(dbl)]
     L.npr_rescore.restype = i32

@@ -400,7 +400,8 @@ def learnModelFromSamFileTargetFn(target, samFile, readFastqFile, referenceFasta
     options.outputXMLModelFile = outputModel + ".xml"
     unnormalisedOutputModel = outputModel + "_unnormalised"
     if not os.path.exists(unnormalisedOutputModel):
-        batch, sam, _ = stageSamFile(samFile, referenceFastaFile, EM_SPLIT_MATRIX_BIGGER_THAN, ctx=ctx)
+        from .. import realign
+        batch, sam, _ = stageSamFile(samFile, referenceFastaFile, EM_SPLIT_MATRIX_BIGGER_THAN, mode=realign.MODE_EXPECTATIONS, ctx=ctx)
         try:
             em.expectationMaximisationTrials(batch, unnormalisedOutputModel, options,
                                              log=(target.logToMaster if target is not None else None))

@@ -205,6 +205,7 @@ struct npr_batch {
     DevBuf<int32_t> d_lo, d_n;
     DevBuf<uint32_t> d_coff;
     DevBuf<uint32_t> d_ctl;  // register-kernel tasks: frame schedule, two words per anti-diagonal
+    DevBuf<Stripe> d_stripes;  // k_dp_tile tasks: stripe tables
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
@@ -404,17 +405,52 @@ bool build_stair_schedule(const Segment &s, int R, int NW, uint32_t *ctl, int64_
 // lane), the register kernel with NW wavefronts per task (k_dp_wide), the generic kernel with an LDS ring in three
 // width classes, the generic kernel with its ring in HBM.
 namespace {
-enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3 };
+enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4 };
 struct KClass {
     int kind, R, NW;
     int slots() const { return 64 * R * NW; }
 };
-constexpr int kClasses = 11;
+constexpr int kClasses = 12;
 constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STAIR, 4, 1}, {K_WIDE, 2, 4}, {K_WIDE, 2, 8},
                                         {K_WIDE, 4, 8}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
-                                        {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}};
-constexpr int kFirstGeneric = 7, kQueueSlots = 16;
+                                        {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}, {K_TILE, 2, 0}};
+constexpr int kFirstGeneric = 7, kTileClass = 11, kQueueSlots = 16;
 inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE; }
+
+// Stripe table of k_dp_tile for one segment (npr_kernel_tile.hip): the lattice columns 0..lX cut into stripes of 64*R
+// columns; per stripe the first / last anti-diagonal on which the band has cells in it and the index of its first row in
+// the task's scratch (one row per anti-diagonal of a stripe).  out[0] is the header {stripes, rows}.
+void build_stripes(const Segment &s, int R, Stripe *out, int64_t *rows_out) {
+    const int64_t K = 64 * R, lX = s.xe - s.xs, D = s.D();
+    const int64_t S = lX / K + 1;
+    for (int64_t k = 0; k < S; ++k) {
+        Stripe &st = out[1 + k];
+        st = Stripe{};
+        st.X = static_cast<int32_t>(k * K);
+        st.K = static_cast<int32_t>(K);
+        st.df = 1, st.dl = 0;
+    }
+    for (int64_t d = 0; d <= D; ++d) {
+        if (s.n[d] < 1) continue;
+        const int64_t xlo = (d + s.lo[d]) >> 1, xhi = xlo + s.n[d] - 1;
+        for (int64_t k = std::max<int64_t>(xlo / K, 0); k <= std::min(xhi / K, S - 1); ++k) {
+            Stripe &st = out[1 + k];
+            if (st.dl < st.df) st.df = static_cast<int32_t>(d);
+            st.dl = static_cast<int32_t>(d);
+        }
+    }
+    int64_t rows = 0;
+    for (int64_t k = 0; k < S; ++k) {
+        Stripe &st = out[1 + k];
+        st.row0 = static_cast<uint32_t>(rows);
+        if (st.dl >= st.df) rows += st.dl - st.df + 1;
+    }
+    out[0] = Stripe{};
+    out[0].X = static_cast<int32_t>(S);
+    out[0].K = static_cast<int32_t>(rows);
+    if (rows_out) *rows_out = rows;
+}
+inline int64_t stripes_of(const Segment &s, int R) { return (s.xe - s.xs) / (64 * R) + 1; }
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
@@ -522,12 +558,18 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     const bool no_wide = nowide_env && nowide_env[0] == '1';
     const char *cmin_env = std::getenv("NPR_CLASS_MIN");  // bring-up: smallest register class to use
     const int cmin = cmin_env ? std::atoi(cmin_env) : 0;
+    // Bands too wide for one wavefront's frame go to the stripe kernel (k_dp_tile), whatever their shape.  A batch staged
+    // for the E-step (NPR_MODE_EXPECTATIONS) keeps the classes that have an E-step kernel; NPR_NO_TILE=1: A/B runs, tests.
+    const char *notile_env = std::getenv("NPR_NO_TILE");
+    const bool use_tile = !force_generic && !(notile_env && notile_env[0] == '1') && b->params.mode != NPR_MODE_EXPECTATIONS;
     auto class_of = [&](const Segment &s) {
         if (!force_generic)
             for (int c = cmin; c < kFirstGeneric; ++c) {
+                if (use_tile && kClassTab[c].kind == K_WIDE) return kTileClass;
                 if (s.max_width >= kClassTab[c].slots() || (no_wide && kClassTab[c].kind == K_WIDE)) continue;
                 if (build_stair_schedule(s, kClassTab[c].R, kClassTab[c].NW, nullptr, nullptr)) return c;
             }
+        if (use_tile) return kTileClass;
         if (s.max_width <= 512) return kFirstGeneric;
         if (s.max_width <= 1024) return kFirstGeneric + 1;
         return s.max_width <= lds_max_w ? kFirstGeneric + 2 : kFirstGeneric + 3;
@@ -565,7 +607,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     b->tasks.resize(ntasks);
     b->task_cells.resize(ntasks);
     std::vector<int64_t> band_base(ntasks);
-    int64_t ctl_entries = 0;
+    int64_t ctl_entries = 0, stripe_entries = 0;
     int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
     int64_t cls_count[kClasses] = {}, cls_width[kClasses] = {}, cls_cells[kClasses] = {};
     for (int64_t k = 0; k < ntasks; ++k) {
@@ -594,9 +636,14 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         max_width = std::max<int64_t>(max_width, s.max_width);
         const int c = cls_of[rank[k]];
         t.ctl_off = -1;
+        t.tile_off = -1;
         if (is_register_class(c)) {
             t.ctl_off = ctl_entries;
             ctl_entries += s.D() + 1;
+        }
+        if (kClassTab[c].kind == K_TILE) {
+            t.tile_off = stripe_entries;
+            stripe_entries += 1 + stripes_of(s, kClassTab[c].R);
         }
         ++cls_count[c];
         cls_width[c] = std::max<int64_t>(cls_width[c], s.max_width);
@@ -605,6 +652,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     // not vectors: value-initialising gigabytes on one thread took longer than filling them on all of them
     const std::unique_ptr<int32_t[]> h_lo(new int32_t[band_entries + 1]), h_n(new int32_t[band_entries + 1]);
     const std::unique_ptr<uint32_t[]> h_coff(new uint32_t[band_entries + 1]), h_ctl(new uint32_t[2 * ctl_entries + 2]);
+    const std::unique_ptr<Stripe[]> h_stripes(new Stripe[stripe_entries + 1]);
     std::vector<int64_t> pad_cells(ntasks);
     parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
         const Ref &r = order[rank[k]];
@@ -612,6 +660,11 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         int64_t stair_cells = 0;
         if (b->tasks[k].ctl_off >= 0)
             build_stair_schedule(s, kClassTab[cls_of[rank[k]]].R, kClassTab[cls_of[rank[k]]].NW, h_ctl.get() + 2 * b->tasks[k].ctl_off, &stair_cells);
+        if (b->tasks[k].tile_off >= 0) {
+            int64_t rows = 0;
+            build_stripes(s, kClassTab[cls_of[rank[k]]].R, h_stripes.get() + b->tasks[k].tile_off, &rows);
+            stair_cells = tile_scratch_cells(rows, kClassTab[cls_of[rank[k]]].R);
+        }
         uint64_t off = 0;
         for (int64_t d = 0; d <= s.D(); ++d) {
             h_lo[band_base[k] + d] = s.lo[d];
@@ -633,7 +686,8 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     b->slot_stride = (max_pad + 63) & ~int64_t(63);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-    const int64_t fixed = seq_bytes + band_entries * 12 + ctl_entries * 8 + pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
+    const int64_t fixed = seq_bytes + band_entries * 12 + ctl_entries * 8 + stripe_entries * (int64_t)sizeof(Stripe) + pair_total * 12 +
+                          ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
     const int64_t budget = static_cast<int64_t>((free_b + ctx->arena_cells * 8) * 0.9) - fixed;
     int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
@@ -663,6 +717,14 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
             waves_per_cu = (kClassTab[c].R == 2 || nw <= 8) ? 16 / nw : 1;
             L.wcap = 0;
             L.lds = wide_lds_bytes(nw);
+            L.threads = 64 * nw;
+        } else if (kClassTab[c].kind == K_TILE) {
+            // 80 VGPRs: 6 wavefronts per SIMD, 24 per CU, shared by workgroups of NW wavefronts
+            int nw = 8;
+            if (const char *w = std::getenv("NPR_TILE_WAVES")) nw = std::min(8, std::max(1, std::atoi(w)));
+            waves_per_cu = std::max(1, 24 / nw);
+            L.wcap = nw;
+            L.lds = tile_lds_bytes(nw);
             L.threads = 64 * nw;
         } else if (kClassTab[c].kind == K_GENERIC_LDS) {
             // several wavefronts per task: these tasks are big, their forward scratch caps how many can be
@@ -708,6 +770,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         (e = b->d_queue.alloc(kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
         (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
         (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_ctl.alloc(2 * ctl_entries)) != hipSuccess ||
+        (e = b->d_stripes.alloc(stripe_entries)) != hipSuccess ||
         (e = b->d_px.alloc(pair_total)) != hipSuccess ||
         (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
@@ -729,6 +792,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         HIP_TRY(ctx, hipMemcpy(b->d_n.p, h_n.get(), b->d_n.bytes(), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.get(), b->d_coff.bytes(), hipMemcpyHostToDevice));
         if (ctl_entries) HIP_TRY(ctx, hipMemcpy(b->d_ctl.p, h_ctl.get(), b->d_ctl.bytes(), hipMemcpyHostToDevice));
+        if (stripe_entries) HIP_TRY(ctx, hipMemcpy(b->d_stripes.p, h_stripes.get(), b->d_stripes.bytes(), hipMemcpyHostToDevice));
     }
     tm.lap("H2D");
     b->outs.resize(ntasks);
@@ -741,7 +805,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
     {   // report the class that carries most cells
         int64_t best = -1;
         for (const auto &L : b->launches)
-            if (L.cells > best) best = L.cells, b->stats.kernel_variant = is_register_class(L.cls) ? 1 : 0;
+            if (L.cells > best) best = L.cells, b->stats.kernel_variant = kClassTab[L.cls].kind == K_TILE ? 2 : (is_register_class(L.cls) ? 1 : 0);
     }
     b->stats.device_bytes = fixed + b->slot_stride * grid * 8 + ring_floats * 4;
     *out = b.release();
@@ -760,6 +824,7 @@ static KernelArgs make_args(npr_batch *b) {
     a.n = b->d_n.p;
     a.coff = b->d_coff.p;
     a.ctl = b->d_ctl.p;
+    a.stripes = b->d_stripes.p;
     a.F = b->ctx->arena_F;
     a.slot_stride = b->slot_stride;
     a.px = b->d_px.p;
@@ -800,6 +865,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.slot_base = L.slot_base;
         const KClass &kc = kClassTab[L.cls];
         const int rc = kc.kind == K_STAIR  ? launch_stair(a, kc.R, L.grid, s)
+                       : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
                        : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
                                            : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
@@ -1447,6 +1513,24 @@ int32_t npr_plan_frame_schedule(const npr_plan *pl, int32_t seg, int32_t slots, 
     }
     if (cells) *cells = c;
     return NPR_OK;
+}
+
+int32_t npr_plan_stripes(const npr_plan *pl, int32_t seg, int32_t slots_per_lane, int32_t *stripes5, int32_t cap, int64_t *rows) {
+    if (!pl || seg < 0 || seg >= static_cast<int32_t>(pl->plan.segs.size()) || (slots_per_lane != 2 && slots_per_lane != 4)) return NPR_ERR_INVALID;
+    const Segment &s = pl->plan.segs[seg];
+    const int64_t S = stripes_of(s, slots_per_lane);
+    if (!stripes5) return static_cast<int32_t>(S);
+    if (cap < S) return NPR_ERR_CAPACITY;
+    std::vector<Stripe> tab(S + 1);
+    int64_t r = 0;
+    build_stripes(s, slots_per_lane, tab.data(), &r);
+    for (int64_t k = 0; k < S; ++k) {
+        const Stripe &st = tab[1 + k];
+        stripes5[5 * k] = st.X, stripes5[5 * k + 1] = st.K, stripes5[5 * k + 2] = st.df, stripes5[5 * k + 3] = st.dl;
+        stripes5[5 * k + 4] = static_cast<int32_t>(st.row0);
+    }
+    if (rows) *rows = r;
+    return static_cast<int32_t>(S);
 }
 
 int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y, const float *p, int64_t n,

@@ -21,6 +21,18 @@ struct Task {
     int32_t read;      // owning read
     int32_t cells_pad; // padded cell count (scratch use)
     int64_t ctl_off;   // register-kernel tasks: first anti-diagonal entry in d_ctl (pairs of words), else -1
+    int64_t tile_off;  // stripe-kernel tasks: index of the task's header in d_stripes (Stripe units), else -1
+};
+
+// k_dp_tile cuts a task's lattice columns into stripes of at most 64*R columns; one wavefront sweeps a stripe
+// anti-diagonal by anti-diagonal, one row of the forward scratch per anti-diagonal.  A task's table is a header
+// {X = number of stripes, K = rows of the whole task} followed by its stripes in column order.
+struct Stripe {
+    int32_t X;      // first lattice column of the stripe
+    int32_t K;      // lattice columns (a multiple of the slots per lane; the last stripe may reach past lX)
+    int32_t df, dl; // first / last anti-diagonal on which the band has cells in the stripe (dl < df: none)
+    uint32_t row0;  // row index of anti-diagonal df in the task's scratch; anti-diagonal d is row row0 + d - df
+    int32_t pad[3];
 };
 
 struct TaskOut {
@@ -42,6 +54,7 @@ struct KernelArgs {
     const int32_t *lo;
     const int32_t *n;
     const uint32_t *coff;  // per anti-diagonal: offset of its first cell inside the task (cells padded to x4)
+    const Stripe *stripes;  // k_dp_tile: stripe tables (Task::tile_off)
     const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 13 | (rebase + 1) << 26)
     char *F;               // forward match-state scratch: one region of 8*slot_stride bytes per resident wave.  The
                            // register kernel keeps (mantissa, exponent) interleaved per cell; the generic kernel
@@ -114,6 +127,9 @@ struct MeaArgs {
     uint32_t *ops_dense;     // one word per op: length << 2 | op
     const int64_t *od_off;
 };
+int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream);
+size_t tile_lds_bytes(int nw);
+int64_t tile_scratch_cells(int64_t rows, int R);  // forward scratch (8-byte cells) of a task with that many stripe rows
 size_t mea_chain_lds_bytes(int ring);
 int launch_mea_sort(const MeaArgs &a, void *stream);
 int launch_mea_chain(const MeaArgs &a, void *stream);

@@ -1,0 +1,553 @@
+// npr_kernel_tile.hip -- k_dp_tile<R>: the register-resident DP kernel for WIDE bands.
+//
+// Same recurrences and the same per-cell arithmetic (npr_cell.h) as k_dp_stair / k_dp_generic -- cactus_realign's banded
+// five-state forward / backward / posterior pass, SURVEY.md 8a rows a5.3-a5.5, reference call site
+// nanopore/analyses/utils.py:587 -- for the band the reference's own parameters give (anchors +- diagonalExpansion 10,
+// 14 trimmed columns, splitMatrixBiggerThanThis 3000): a chain of unanchored rectangles hundreds to 3000 cells across,
+// joined by 21-cell stripes.  97 % of its cells lie on anti-diagonals wider than one wavefront can hold.
+//
+// A frame that follows the anti-diagonal (k_dp_stair, k_dp_wide) needs the neighbour on BOTH sides, so a band spread
+// over several wavefronts has to synchronise all of them after every anti-diagonal.  In lattice coordinates the
+// dependencies of a cell, (x-1, y), (x, y-1), (x-1, y-1), point one way only.  So here the lattice COLUMNS of a task
+// are cut into stripes of 64*R columns and one wavefront sweeps one stripe:
+//   * slot j of the wavefront is lattice column X + j for the whole life of the stripe; on anti-diagonal d it holds the
+//     cell (X + j, d - X - j).  (x, y-1) is the same slot on d-1, (x-1, y) the slot below on d-1, (x-1, y-1) the slot
+//     below on d-2: one DPP shift per anti-diagonal (the shifted copy of d-1 is kept for the next step, where it is the
+//     shifted d-2), no frame rebases, no reference stream -- a slot's reference base never changes; the read streams
+//     through the wavefront one slot per step;
+//   * the only thing a stripe needs from outside is the last column of the stripe to its left (forward) or the first
+//     column of the stripe to its right (backward): one cell per anti-diagonal.  The producer writes it to the task's
+//     scratch, the consumer stages 16 of them at a time into LDS; a per-wavefront progress word in LDS says how far a
+//     stripe has got.  Wavefronts of a workgroup take the stripes of ONE task round-robin and run as a pipeline, each a
+//     stripe width behind its left neighbour -- no barrier inside the sweep;
+//   * forward match values stream to HBM one fixed-stride row per anti-diagonal of a stripe and stream back one row
+//     ahead of use; the backward sweep keeps its stripe right-aligned in the wavefront (the neighbour's column then
+//     always enters at lane 63) and reads the rows with a lane offset.
+// Any band shape and width goes: what is outside the band is masked per anti-diagonal from the band arrays.
+// Bit-identical to the other kernels and to the fp32 mirror (same cell arithmetic, order of evaluation is irrelevant to
+// a cell's value).
+#include <hip/hip_runtime.h>
+
+#include "npr_cell.h"
+#include "npr_device.h"
+#include "npr_frame.h"
+
+namespace npr {
+
+namespace {
+
+constexpr int TILE_MAX_NW = 8;  // wavefronts per workgroup (launch bound)
+constexpr int TILE_BLOCK = 16;  // neighbour cells staged / published at a time
+constexpr int EDGE_FLOATS = 8;  // one neighbour cell in memory: m, sx, sy, lx, ly, e, -, -
+
+typedef const __attribute__((address_space(4))) int32_t *cptr_i32;
+
+struct UStripe {
+    int X, K, df, dl;
+    uint32_t row0;
+};
+__device__ __forceinline__ UStripe load_stripe(const Stripe *tab, int s) {
+    cptr_i32 p = (cptr_i32)(tab + s);
+    return UStripe{p[0], p[1], p[2], p[3], static_cast<uint32_t>(p[4])};
+}
+
+// the band of anti-diagonal d inside a stripe whose slot 0 is lattice column `origin`, clipped to the slots [c0, c1]
+struct TBand {
+    int jlo, n;
+};
+__device__ __forceinline__ TBand tile_band(int d, int lo, int n, int origin, int c0, int c1) {
+    const int xlo = (d + lo) >> 1;  // lo has the parity of d
+    const int j0 = max(xlo - origin, c0), j1 = min(xlo + n - 1 - origin, c1);
+    return TBand{j1 >= j0 ? j0 : 0, max(j1 - j0 + 1, 0)};
+}
+
+__device__ __forceinline__ int lds_peek(const int *p) { return *reinterpret_cast<const volatile int *>(p); }
+__device__ __forceinline__ void lds_poke(int *p, int v) { *reinterpret_cast<volatile int *>(p) = v; }
+
+// one row per anti-diagonal of a stripe: 64*R cells of 8 bytes, lane l at 8*R*l
+template <int R>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_row_rsrc(char *F, uint32_t row, int lane_shift) {
+    return __builtin_amdgcn_make_buffer_rsrc(F + (static_cast<int64_t>(row) * 64 - lane_shift) * (8 * R), 0, -1, 0x00020000);
+}
+template <int R>
+__device__ __forceinline__ void tile_store_row(char *F, uint32_t row, const Diag<R> &C, const Masks<R> &mk, int voff) {
+    const __amdgpu_buffer_rsrc_t rs = tile_row_rsrc<R>(F, row, 0);
+    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
+        if constexpr (R == 1) {
+            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), C.c[0].e}, rs, voff, 0, 0);
+        } else if constexpr (R == 2) {
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[2].m), C.c[2].e, fbits(C.c[3].m), C.c[3].e}, rs, voff + 16, 0, 0);
+        }
+    }
+}
+// lane_shift: the row was stored by lanes `lane_shift` below the ones that now read it (right-aligned backward stripe)
+template <int R>
+__device__ __forceinline__ void tile_load_row(char *F, uint32_t row, int lane_shift, FRow<R> &f, const Masks<R> &mk, int voff) {
+    const __amdgpu_buffer_rsrc_t rs = tile_row_rsrc<R>(F, row, lane_shift);
+    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
+        if constexpr (R == 1) {
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y;
+        } else if constexpr (R == 2) {
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
+        } else {
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
+            f.v[2] = bitsf(g.x), f.e[2] = g.y, f.v[3] = bitsf(g.z), f.e[3] = g.w;
+        }
+    }
+}
+
+// the neighbour cell of row `row`: 32 bytes at Eb + 32 * row, written by the one lane that holds it
+__device__ __forceinline__ void edge_store(char *Eb, uint32_t row, const Cell &c, uint64_t lane_mask) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Eb + static_cast<int64_t>(row) * (4 * EDGE_FLOATS), 0, -1, 0x00020000);
+    if (__builtin_amdgcn_inverse_ballot_w64(lane_mask)) {
+        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.sy), fbits(c.lx)}, rs, 0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(c.ly), c.e}, rs, 16, 0, 0);
+    }
+}
+// `cnt` neighbour cells starting at row `row` into this wavefront's LDS staging (lane l takes cell l).  The loads bypass
+// the vector L1 (sc1: agent scope): the producer is another wavefront of this workgroup and its stores went through that cache.
+__device__ __forceinline__ void edge_stage(char *Eb, uint32_t row, int cnt, float *stage, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Eb + static_cast<int64_t>(row) * (4 * EDGE_FLOATS), 0, -1, 0x00020000);
+    if (__builtin_amdgcn_inverse_ballot_w64(low_lanes(cnt))) {
+        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 16);
+        const v2i g = __builtin_amdgcn_raw_buffer_load_b64(rs, 32 * lane + 16, 0, 16);
+        *reinterpret_cast<v4i *>(stage + EDGE_FLOATS * lane) = q;
+        *reinterpret_cast<v2i *>(stage + EDGE_FLOATS * lane + 4) = g;
+    }
+}
+__device__ __forceinline__ Cell edge_get(const float *stage, int k) {
+    const float4 q = *reinterpret_cast<const float4 *>(stage + EDGE_FLOATS * k);
+    const float2 g = *reinterpret_cast<const float2 *>(stage + EDGE_FLOATS * k + 4);
+    return Cell{q.x, q.y, q.z, q.w, g.x, fbits(g.y)};
+}
+
+__device__ __forceinline__ Cell dpp_cell_from_below(const Cell &v, const Cell &edge) {
+    Cell o;
+    o.m = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.m), fbits(v.m), 0x138, 0xf, 0xf, false));
+    o.sx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sx), fbits(v.sx), 0x138, 0xf, 0xf, false));
+    o.sy = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sy), fbits(v.sy), 0x138, 0xf, 0xf, false));
+    o.lx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.lx), fbits(v.lx), 0x138, 0xf, 0xf, false));
+    o.ly = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.ly), fbits(v.ly), 0x138, 0xf, 0xf, false));
+    o.e = __builtin_amdgcn_update_dpp(edge.e, v.e, 0x138, 0xf, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ Cell dpp_cell_from_above(const Cell &v, const Cell &edge) {
+    Cell o;
+    o.m = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.m), fbits(v.m), 0x130, 0xf, 0xf, false));
+    o.sx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sx), fbits(v.sx), 0x130, 0xf, 0xf, false));
+    o.sy = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sy), fbits(v.sy), 0x130, 0xf, 0xf, false));
+    o.lx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.lx), fbits(v.lx), 0x130, 0xf, 0xf, false));
+    o.ly = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.ly), fbits(v.ly), 0x130, 0xf, 0xf, false));
+    o.e = __builtin_amdgcn_update_dpp(edge.e, v.e, 0x130, 0xf, 0xf, false);
+    return o;
+}
+
+// One forward anti-diagonal of a stripe.  `io`: d-2 on entry, d on exit; `p1`: d-1; `carry`: the slot-below copy of
+// d-2's top register (made by the step before) on entry, that of d-1 on exit; `edge`: the left stripe's last column on
+// d-1 (every lane holds it, lane 0 uses it).  bx / by: X[x-1]*4 and Y[y-1]*4 of every slot.
+template <int R>
+__device__ __forceinline__ void tile_fwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Cell &carry, const Cell &edge,
+                                              const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
+    const Cell Le = dpp_cell_from_below(p1.c[R - 1], edge);  // (x-1, y) of every lane's register 0
+    Diag<R> o;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
+        Cell c = fwd_cell(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : carry, p1.c[r], em, exs, exl, eys, eyl);
+        kill_outside(c, mk.cell[r]);
+        o.c[r] = c;
+    }
+    io = o;
+    carry = Le;
+}
+// One backward anti-diagonal.  `io`: d+2 -> d; `s1`: d+1; `carry`: the slot-above copy of d+2's register 0 -> that of
+// d+1; `edge`: the right stripe's first column on d+1 (lane 63 uses it).  bx / by: X[x]*4 and Y[y]*4 of every slot.
+template <int R>
+__device__ __forceinline__ void tile_bwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Cell &carry, const Cell &edge,
+                                              const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
+    const Cell Xe = dpp_cell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register
+    Diag<R> o;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
+        Cell c = bwd_cell(E.tr, r + 1 < R ? io.c[r + 1] : carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
+        kill_outside(c, mk.cell[r]);
+        o.c[r] = c;
+    }
+    io = o;
+    carry = Xe;
+}
+
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int R>
+__global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lmodel = reinterpret_cast<float *>(smem);
+    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] pair counter, [5] next task
+    int *prog = lmisc + 8;                                        // [TILE_MAX_NW] rows whose neighbour cells are out
+    constexpr int K = 64 * R;
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
+    const int NW = static_cast<int>(blockDim.x) >> 6;
+    float *const stage = reinterpret_cast<float *>(prog + TILE_MAX_NW) + wv * (TILE_BLOCK * EDGE_FLOATS);
+    char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
+    const int voff = 8 * R * lane;
+    int jr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
+
+    int t = blockIdx.x;
+    while (t < a.ntasks) {
+        const Task *tp = a.tasks + t;
+        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), band_off = uni64(tp->band_off),
+                      pair_off = uni64(tp->pair_off), tile_off = uni64(tp->tile_off);
+        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap),
+                  flags = uni(tp->flags), model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
+        cptr_i32 blo = (cptr_i32)(a.lo + band_off), bn = (cptr_i32)(a.n + band_off);
+        const Stripe *tab = a.stripes + tile_off;
+        const UStripe hd = load_stripe(tab, 0);
+        const int S = hd.X;
+        const uint32_t rows = static_cast<uint32_t>(hd.K);
+        tab += 1;
+        char *const Ef = F + static_cast<int64_t>(rows) * (K * 8);           // neighbour cells of the forward sweep
+        char *const Eb = Ef + static_cast<int64_t>(rows) * (4 * EDGE_FLOATS);  // ... of the backward sweep
+        const int rs = flags & 1, re = (flags >> 1) & 1;
+
+        __syncthreads();
+        {
+            const float *gm = reinterpret_cast<const float *>(a.models + model);
+            for (int i = threadIdx.x; i < MODEL_FLOATS; i += blockDim.x) lmodel[i] = gm[i];
+            if (threadIdx.x == 0) lmisc[0] = 0, lmisc[1] = E_DEAD, lmisc[2] = 0, lmisc[3] = E_DEAD, lmisc[4] = 0;
+            if (threadIdx.x < TILE_MAX_NW) prog[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        StepEnv E;
+        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
+        E.ltab = reinterpret_cast<const char *>(lmodel);
+        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
+        {
+            Trans tr = load_trans(E.mdl->T);
+            if constexpr (R >= NPR_T_SGPR_MIN_R) {
+                tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
+                tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
+                tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
+                tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
+            }
+            E.tr = tr;
+        }
+        const DevModel *mdl = E.mdl;
+
+        // =============================== forward ===============================
+        for (int s = wv; s < S; s += NW) {
+            const UStripe st = load_stripe(tab, s);
+            if (st.dl >= st.df) {
+            // the stripe to the left: its rows, and which wavefront sweeps it
+            int dfL = 1, dlL = 0, wL = 0;
+            uint32_t row0L = 0;
+            if (s > 0) {
+                const UStripe sl = load_stripe(tab, s - 1);
+                dfL = sl.df, dlL = sl.dl, row0L = sl.row0;
+                wL = (s - 1) % NW;
+            }
+            const int lenL = dlL - dfL + 1;
+            Bases<R> bx, by;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bx.b[r] = base4(E.X, lX, st.X + jr[r] - 1);
+                by.b[r] = base4(E.Y, lY, (st.df - 1) - st.X - jr[r] - 1);  // as of anti-diagonal df - 1
+            }
+            Feed fy;
+            feed_init<+1>(fy, E.Y, lY, st.df - st.X - 1, lane);
+            Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
+            Cell carry = dead_cell();
+            const uint64_t out_lane = 1ull << (st.K / R - 1);  // holds the stripe's last column in its top register
+            int blk_lo = 0, blk_hi = 0;                         // staged cells of the left stripe: [blk_lo, blk_hi) past dfL
+            int lo_n = blo[st.df], n_n = bn[st.df];             // band row one ahead
+            {   // (x-1, y-1) of slot 0 on the first anti-diagonal: the left stripe's cell on df - 2
+                const int q0 = st.df - 2 - dfL;
+                if (q0 >= 0 && q0 < lenL) {
+                    const int hi = min(q0 + TILE_BLOCK, lenL);
+                    const int need = static_cast<int>(row0L) + hi;
+                    while (uni(lds_peek(prog + wL)) < need) __builtin_amdgcn_s_sleep(2);
+                    asm volatile("" ::: "memory");
+                    edge_stage(Ef, row0L + q0, hi - q0, stage, lane);
+                    blk_lo = q0, blk_hi = hi;
+                    const Cell c0 = edge_get(stage, 0);
+                    if (lane == 0) carry = c0;
+                }
+            }
+
+            auto step = [&](int d, Diag<R> &io, const Diag<R> &p1) {
+                const int lo_c = lo_n, n_c = n_n;
+                if (d < st.dl) lo_n = blo[d + 1], n_n = bn[d + 1];
+                const TBand tb = tile_band(d, lo_c, n_c, st.X, 0, st.K - 1);
+                const Masks<R> mk = band_masks<R>(tb.jlo, tb.n);
+                Cell edge = dead_cell();
+                const int q = d - 1 - dfL;
+                if (q >= 0 && q < lenL) {  // uniform
+                    if (q >= blk_hi) {
+                        const int hi = min(q + TILE_BLOCK, lenL);
+                        const int need = static_cast<int>(row0L) + hi;
+                        while (uni(lds_peek(prog + wL)) < need) __builtin_amdgcn_s_sleep(2);
+                        asm volatile("" ::: "memory");
+                        edge_stage(Ef, row0L + q, hi - q, stage, lane);
+                        blk_lo = q, blk_hi = hi;
+                    }
+                    edge = edge_get(stage, q - blk_lo);
+                }
+                bases_down<R>(by, feed_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
+                tile_fwd_step<R>(E, io, p1, carry, edge, bx, by, mk);
+                if (d == 0) {  // the start cell (0, 0): slot 0 of the first stripe
+                    if (lane == 0) {
+                        Cell c;
+                        c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
+                        c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
+                        normalise(c, 0);
+                        io.c[0] = c;
+                    }
+                }
+                const uint32_t row = st.row0 + static_cast<uint32_t>(d - st.df);
+                tile_store_row<R>(F, row, io, mk, voff);
+                edge_store(Ef, row, io.c[R - 1], out_lane);
+                const int k = d - st.df;
+                if ((k & (TILE_BLOCK - 1)) == TILE_BLOCK - 1 || d == st.dl) {
+                    wait_vm();
+                    if (lane == 0) lds_poke(prog + wv, static_cast<int>(row) + 1);
+                }
+            };
+            int d = st.df;
+            for (; d + 1 <= st.dl; d += 2) {
+                step(d, B, A);
+                step(d + 1, A, B);
+            }
+            if (d <= st.dl) step(d, B, A);
+            if (s == S - 1) {  // total probability at the end corner (lX, lY), anti-diagonal D = this stripe's last row
+                const bool inB = ((st.dl - st.df) & 1) == 0;
+                const int je = lX - st.X;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (jr[r] == je) {
+                        const Cell c = inB ? B.c[r] : A.c[r];
+                        const float raw = dot5(mdl->end + re * 5, c);
+                        if (raw > 0.f) {
+                            int k;
+                            reinterpret_cast<float *>(lmisc)[0] = __builtin_frexpf(raw, &k);
+                            lmisc[1] = c.e + k;
+                        }
+                    }
+            }
+            }
+        }
+        __syncthreads();
+        const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
+        const int tot_e = uni(lmisc[1]);
+
+        TaskOut out;
+        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
+        out.status = NPR_OK;
+        const bool alive = tot_m > 0.f;
+        if (!alive) out.status = NPR_ERR_ZERO_PROB;
+
+        // =============================== backward + posteriors ===============================
+        if (alive) {
+            const float inv_tot = 1.0f / tot_m;
+            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            if (threadIdx.x < TILE_MAX_NW) prog[threadIdx.x] = 0x7fffffff;  // now: the LOWEST row whose neighbour cell is out
+            __syncthreads();
+            int s_top = S - 1 - ((S - 1 - wv) % NW + NW) % NW;  // the last stripe of this wavefront (s == wv mod NW)
+            for (int s = s_top; s >= 0; s -= NW) {
+                const UStripe st = load_stripe(tab, s);
+                if (st.dl >= st.df) {
+                int dfR = 1, dlR = 0, wR = 0;
+                uint32_t row0R = 0;
+                if (s + 1 < S) {
+                    const UStripe sr = load_stripe(tab, s + 1);
+                    dfR = sr.df, dlR = sr.dl, row0R = sr.row0;
+                    wR = (s + 1) % NW;
+                }
+                const int lenR = dlR - dfR + 1;
+                const int pad = K - st.K;    // the stripe sits in the top slots: slot j is column X0 + j
+                const int X0 = st.X - pad;
+                const int lane_shift = pad / R;
+                Bases<R> bx, by;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    bx.b[r] = base4(E.X, lX, X0 + jr[r]);
+                    by.b[r] = base4(E.Y, lY, (st.dl + 1) - X0 - jr[r]);  // as of anti-diagonal dl + 1
+                }
+                Feed fy;
+                feed_init<-1>(fy, E.Y, lY, st.dl - X0 - (K - 1), lane);
+                Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
+                Cell carry = dead_cell();
+                const uint64_t out_lane = 1ull << lane_shift;  // holds the stripe's first column in its register 0
+                int blk_lo = 0, blk_hi = 0;                     // staged cells of the right stripe: entries (blk_lo, blk_hi] ... see below
+                FRow<R> fa, fb;
+#pragma unroll
+                for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
+                int lo_n = blo[st.dl], n_n = bn[st.dl];
+                // forward row of the first anti-diagonal (the later ones are loaded one step ahead)
+                {
+                    const TBand tb = tile_band(st.dl, lo_n, n_n, X0, pad, K - 1);
+                    tile_load_row<R>(F, st.row0 + static_cast<uint32_t>(st.dl - st.df), lane_shift, fb, band_masks<R>(tb.jlo, tb.n), voff);
+                }
+                blk_lo = lenR, blk_hi = lenR;  // staged: entries [blk_lo, blk_hi) of the right stripe (entry = d' - dfR); empty
+                {   // (x+1, y+1) of the top slot on the first anti-diagonal: the right stripe's cell on dl + 2
+                    const int q0 = st.dl + 2 - dfR;
+                    if (q0 >= 0 && q0 < lenR) {
+                        const int lo = max(q0 - TILE_BLOCK + 1, 0);
+                        const int need = static_cast<int>(row0R) + lo;
+                        while (uni(lds_peek(prog + wR)) > need) __builtin_amdgcn_s_sleep(2);
+                        asm volatile("" ::: "memory");
+                        edge_stage(Eb, row0R + lo, q0 - lo + 1, stage, lane);
+                        blk_lo = lo, blk_hi = q0 + 1;
+                        const Cell c0 = edge_get(stage, q0 - lo);
+                        if (lane == WAVE - 1) carry = c0;
+                    }
+                }
+
+                // f: the forward row of d (loaded a step ago); fnext: where the row of d-1 goes
+                auto step = [&](int d, Diag<R> &io, const Diag<R> &s1, FRow<R> &f, FRow<R> &fnext) {
+                    const int lo_c = lo_n, n_c = n_n;
+                    if (d > st.df) {
+                        lo_n = blo[d - 1], n_n = bn[d - 1];
+                        const TBand tn = tile_band(d - 1, lo_n, n_n, X0, pad, K - 1);
+                        tile_load_row<R>(F, st.row0 + static_cast<uint32_t>(d - 1 - st.df), lane_shift, fnext, band_masks<R>(tn.jlo, tn.n), voff);
+                    }
+                    const TBand tb = tile_band(d, lo_c, n_c, X0, pad, K - 1);
+                    const Masks<R> mk = band_masks<R>(tb.jlo, tb.n);
+                    Cell edge = dead_cell();
+                    const int q = d + 1 - dfR;
+                    if (q >= 0 && q < lenR) {  // uniform
+                        if (q < blk_lo) {
+                            const int lo = max(q - TILE_BLOCK + 1, 0);
+                            const int need = static_cast<int>(row0R) + lo;
+                            while (uni(lds_peek(prog + wR)) > need) __builtin_amdgcn_s_sleep(2);
+                            asm volatile("" ::: "memory");
+                            edge_stage(Eb, row0R + lo, q - lo + 1, stage, lane);
+                            blk_lo = lo, blk_hi = q + 1;
+                        }
+                        edge = edge_get(stage, q - blk_lo);
+                    }
+                    bases_up<R>(by, feed_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
+                    tile_bwd_step<R>(E, io, s1, carry, edge, bx, by, mk);
+                    if (d == D) {  // the end corner (lX, lY)
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (X0 + jr[r] == lX) {
+                                Cell c;
+                                c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
+                                c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
+                                normalise(c, 0);
+                                io.c[r] = c;
+                            }
+                    }
+                    const uint32_t row = st.row0 + static_cast<uint32_t>(d - st.df);
+                    edge_store(Eb, row, io.c[0], out_lane);
+                    // posteriors of this anti-diagonal, slots claimed from the workgroup's LDS counter
+                    {
+                        float p[R];
+                        uint64_t hit[R];
+                        int total = 0;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            p[r] = posterior(f.v[r], f.e[r], io.c[r].m, io.c[r].e, tot_e, inv_tot);
+                            hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
+                            total += __popcll(hit[r]);
+                        }
+                        if (d >= 2 && total) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(lmisc + 4, total);
+                            base = uni(base);
+                            const int y0 = d - X0;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                if (hit[r]) {
+                                    const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                                    const int slot = base + before;
+                                    if (__builtin_amdgcn_inverse_ballot_w64(hit[r]) && slot < sink.cap) {
+                                        sink.px[sink.off + slot] = X0 + jr[r] - 1 + sink.xs;
+                                        sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
+                                        sink.pp[sink.off + slot] = p[r];
+                                    }
+                                    base += __popcll(hit[r]);
+                                }
+                            }
+                        }
+                    }
+                    const int k = st.dl - d;
+                    if ((k & (TILE_BLOCK - 1)) == TILE_BLOCK - 1 || d == st.df) {
+                        wait_vm();
+                        if (lane == 0) lds_poke(prog + wv, static_cast<int>(row));
+                    }
+                };
+                int d = st.dl;
+                for (; d - 1 >= st.df; d -= 2) {
+                    step(d, B, A, fb, fa);
+                    step(d - 1, A, B, fa, fb);
+                }
+                if (d >= st.df) step(d, B, A, fb, fa);
+                if (s == 0) {  // total from the backward side: the lattice point (0, 0) is the stripe's first slot on d = 0
+                    const bool inB = ((st.dl - st.df) & 1) == 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (X0 + jr[r] == 0) {
+                            const Cell cz = inB ? B.c[r] : A.c[r];
+                            const float raw = dot5(mdl->start + rs * 5, cz);
+                            if (raw > 0.f) {
+                                int k;
+                                reinterpret_cast<float *>(lmisc)[2] = __builtin_frexpf(raw, &k);
+                                lmisc[3] = cz.e + k;
+                            }
+                        }
+                }
+                }
+            }
+            __syncthreads();
+            out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
+            out.btot_e = uni(lmisc[3]);
+        }
+        if (threadIdx.x == 0) {
+            const int cnt = lmisc[4];
+            out.npairs = cnt;
+            if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
+            a.outs[t] = out;
+            lmisc[5] = atomicAdd(a.queue, 1);
+        }
+        __syncthreads();
+        t = uni(lmisc[5]) + static_cast<int>(gridDim.x);
+    }
+}
+
+}  // namespace
+
+size_t tile_lds_bytes(int nw) { return sizeof(float) * (MODEL_FLOATS + 8 + TILE_MAX_NW + static_cast<size_t>(nw) * TILE_BLOCK * EDGE_FLOATS); }
+
+// rows of 64*R cells plus one 32-byte neighbour cell per row for each sweep direction
+int64_t tile_scratch_cells(int64_t rows, int R) { return rows * (64 * R + 2 * EDGE_FLOATS / 2); }
+
+int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (NW < 1 || NW > TILE_MAX_NW) return static_cast<int>(hipErrorInvalidValue);
+    const size_t lds = tile_lds_bytes(NW);
+    if (R == 2)
+        hipLaunchKernelGGL(k_dp_tile<2>, dim3(grid), dim3(WAVE * NW), lds, s, a);
+    else if (R == 4)
+        hipLaunchKernelGGL(k_dp_tile<4>, dim3(grid), dim3(WAVE * NW), lds, s, a);
+    else
+        return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace npr

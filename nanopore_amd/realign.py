@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (BAND_ANCHOR, BAND_FIXED, MODE_ALL_POSTERIORS, MODE_REALIGN, MODE_RESCORE_ORIGINAL, NprError,
+from ._lib import (BAND_ANCHOR, BAND_FIXED, MODE_ALL_POSTERIORS, MODE_EXPECTATIONS, MODE_REALIGN, MODE_RESCORE_ORIGINAL, NprError,
                    Params, ptr)
 
 
@@ -326,6 +326,30 @@ def frame_schedule(params, lX, lY, guide, slots, slots_per_lane, segment=0):
         if rc != _lib.OK:
             raise NprError(rc, "npr_plan_frame_schedule")
         return dict(jlo=jlo, rebase=reb, row_off=off, cells=int(cells[0]))
+    finally:
+        L.npr_plan_destroy(h)
+
+
+def stripes(params, lX, lY, guide, slots_per_lane=2, segment=0):
+    """Stripe table of the wide-band kernel for one segment of the plan (host logic, no GPU needed):
+    dict(X, K, df, dl, row0 -- arrays per stripe --, rows) (include/nprealign.h: npr_plan_stripes)."""
+    L = _lib.load()
+    g = np.ascontiguousarray(np.asarray(guide, dtype=np.int32).reshape(-1, 2))
+    h = C.c_void_p()
+    rc = L.npr_plan_create(C.byref(params), lX, lY, ptr(g), len(g), C.byref(h))
+    if rc != _lib.OK:
+        raise NprError(rc, "npr_plan_create")
+    try:
+        S = L.npr_plan_stripes(h, segment, slots_per_lane, None, 0, None)
+        if S < 0:
+            raise NprError(S, "npr_plan_stripes")
+        tab = np.zeros((S, 5), dtype=np.int32)
+        rows = np.zeros(1, dtype=np.int64)
+        rc = L.npr_plan_stripes(h, segment, slots_per_lane, ptr(tab), S, ptr(rows))
+        if rc < 0:
+            raise NprError(rc, "npr_plan_stripes")
+        return dict(X=tab[:, 0].copy(), K=tab[:, 1].copy(), df=tab[:, 2].copy(), dl=tab[:, 3].copy(),
+                    row0=tab[:, 4].copy(), rows=int(rows[0]))
     finally:
         L.npr_plan_destroy(h)
 

@@ -126,6 +126,7 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
     w = synth.make_workload(1007, 48, 3000, T, E, flank=0, length_sigma=0.5, len_min=300, len_max=9000)
     gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
     P = R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)
+    monkeypatch.setenv("NPR_NO_TILE", "1")  # the stripe kernel (tests/test_gpu_tile.py) would take these bands
 
     def run():
         b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])

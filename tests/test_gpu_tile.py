@@ -1,0 +1,94 @@
+"""k_dp_tile (the wide-band register kernel on column stripes, nanopore_amd/csrc/npr_kernel_tile.hip) on the GPU, through
+the C ABI: bit-exact against the oracle's fp32 mirror and within 1e-4 of the fp64 log-space oracle (test_gpu_parity's two
+bars), bit-identical to the kernels it replaces (k_dp_wide / k_dp_generic under NPR_NO_TILE=1), and independent of how many
+wavefronts share a task."""
+import numpy as np
+import pytest
+
+from helpers import MODEL_DIR, load_model_arrays, orc
+from test_gpu_parity import _run_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(buf):
+    from nanopore_amd.realign import encode
+    return encode(bytes(buf))
+
+
+def test_wide_fixed_bands_match_the_oracle(gpu_ctx):
+    """Constant-width bands from just over one wavefront's frame (256 slots) to several stripes: every read against the
+    fp32 mirror (bit-exact) and the fp64 oracle (1e-4)."""
+    rng = np.random.default_rng(31)
+    _run_case(gpu_ctx, rng, 4, 300, 600, dict(band_mode=1, fixed_width=300), indel=0.2, max_indel=20)
+    _run_case(gpu_ctx, rng, 3, 500, 900, dict(band_mode=1, fixed_width=700), indel=0.2, max_indel=30)
+    _run_case(gpu_ctx, rng, 2, 1300, 1600, dict(band_mode=1, fixed_width=2600, max_pairs_per_base=12), indel=0.2, max_indel=30)
+
+
+def test_anchor_bands_match_the_oracle(gpu_ctx):
+    """The reference's band shape: unanchored rectangles joined by narrow stripes, with and without matrix splits
+    (ragged ends start / end in the long-gap states)."""
+    rng = np.random.default_rng(32)
+    _run_case(gpu_ctx, rng, 6, 400, 1500, dict(band_mode=0, diagonal_expansion=10, constraint_trim=14, split_threshold=3000,
+                                              max_pairs_per_base=12), indel=0.3, max_indel=8)
+    _run_case(gpu_ctx, rng, 6, 400, 1500, dict(band_mode=0, diagonal_expansion=10, constraint_trim=14, split_threshold=300,
+                                              max_pairs_per_base=40), indel=0.3, max_indel=8)
+
+
+def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(gpu_ctx, monkeypatch):
+    """Reads from the shipped nanopore model under the reference's call parameters (nanopore/analyses/utils.py:587): the
+    stripe kernel takes every band wider than one wavefront's frame; results are those of k_dp_wide / k_dp_generic bit for
+    bit, whatever the number of wavefronts per task."""
+    from nanopore_amd import realign as R, synth
+    from nanopore_amd.hmm import Hmm
+    T, E, _ = load_model_arrays()
+    w = synth.make_workload(1007, 48, 3000, T, E, flank=0, length_sigma=0.5, len_min=300, len_max=9000)
+    gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
+
+    def run(P):
+        b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
+        tasks, cells = b.class_stats()
+        b.run(), b.finish()
+        out = (b.results(), b.ops(), b.pairs(), tasks, cells, b.stats())
+        b.close()
+        return out
+
+    def same(a, c):
+        assert np.array_equal(a[0]["cells"], c[0]["cells"]) and np.array_equal(a[0]["status"], c[0]["status"])
+        assert np.array_equal(a[0]["loglik"], c[0]["loglik"]) and np.array_equal(a[0]["loglik_bwd"], c[0]["loglik_bwd"])
+        assert np.array_equal(a[0]["score"], c[0]["score"])
+        assert np.array_equal(a[1][0], c[1][0]) and np.array_equal(a[1][1], c[1][1])
+        for k in range(4):
+            assert np.array_equal(a[2][k], c[2][k])
+
+    for P in (R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000),
+              R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=700,
+                            max_pairs_per_base=40)):
+        ref = run(P)
+        res, tasks, cells, st = ref[0], ref[3], ref[4], ref[5]
+        assert (res["status"] == 0).all() and np.abs(res["loglik"] - res["loglik_bwd"]).max() < 1e-2
+        assert tasks[3:11].sum() == 0 and tasks[11] > 0 and cells[11] > 0.9 * cells.sum() and st["kernel_variant"] == 2
+        for nw in ("1", "3", "4"):
+            monkeypatch.setenv("NPR_TILE_WAVES", nw)
+            same(ref, run(P))
+        monkeypatch.delenv("NPR_TILE_WAVES")
+        monkeypatch.setenv("NPR_NO_TILE", "1")
+        old = run(P)
+        monkeypatch.delenv("NPR_NO_TILE")
+        assert old[3][11] == 0 and old[3][3:11].sum() == tasks[11]
+        same(ref, old)
+
+    # two reads against the oracle's fp32 mirror
+    h = orc.make_hmm(T, E)
+    PO = orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)
+    res, (off, ops), (poff, px, py, pp) = run(R.make_params(band_mode=R.BAND_ANCHOR))[:3]
+    order_by_cells = np.argsort(res["cells"])
+    for i in (int(order_by_cells[len(order_by_cells) // 2]), int(order_by_cells[5])):
+        X = _codes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]])
+        Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
+        g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
+        m = orc.realign_read(h, PO, X, Y, g, precision=1)
+        assert m["cells"] == res["cells"][i]
+        assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
+        order = np.lexsort((m["py"], m["px"]))
+        assert np.array_equal(pp[poff[i]:poff[i + 1]], m["pp"].astype(np.float32)[order])
