@@ -206,6 +206,7 @@ struct npr_batch {
     DevBuf<uint32_t> d_coff;
     DevBuf<uint32_t> d_ctl;  // register-kernel tasks: frame schedule, two words per anti-diagonal
     DevBuf<Stripe> d_stripes;  // k_dp_tile tasks: stripe tables
+    DevBuf<int64_t> d_region;  // k_dp_tile: first scratch cell of each resident workgroup
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
@@ -423,31 +424,33 @@ inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE; }
 void build_stripes(const Segment &s, int R, Stripe *out, int64_t *rows_out) {
     const int64_t K = 64 * R, lX = s.xe - s.xs, D = s.D();
     const int64_t S = lX / K + 1;
-    for (int64_t k = 0; k < S; ++k) {
-        Stripe &st = out[1 + k];
-        st = Stripe{};
-        st.X = static_cast<int32_t>(k * K);
-        st.K = static_cast<int32_t>(K);
-        st.df = 1, st.dl = 0;
-    }
+    thread_local std::vector<int32_t> df, dl;
+    df.assign(S, 1), dl.assign(S, 0);
     for (int64_t d = 0; d <= D; ++d) {
         if (s.n[d] < 1) continue;
         const int64_t xlo = (d + s.lo[d]) >> 1, xhi = xlo + s.n[d] - 1;
         for (int64_t k = std::max<int64_t>(xlo / K, 0); k <= std::min(xhi / K, S - 1); ++k) {
-            Stripe &st = out[1 + k];
-            if (st.dl < st.df) st.df = static_cast<int32_t>(d);
-            st.dl = static_cast<int32_t>(d);
+            if (dl[k] < df[k]) df[k] = static_cast<int32_t>(d);
+            dl[k] = static_cast<int32_t>(d);
         }
     }
     int64_t rows = 0;
     for (int64_t k = 0; k < S; ++k) {
-        Stripe &st = out[1 + k];
-        st.row0 = static_cast<uint32_t>(rows);
-        if (st.dl >= st.df) rows += st.dl - st.df + 1;
+        if (out) {
+            Stripe &st = out[1 + k];
+            st = Stripe{};
+            st.X = static_cast<int32_t>(k * K);
+            st.K = static_cast<int32_t>(K);
+            st.df = df[k], st.dl = dl[k];
+            st.row0 = static_cast<uint32_t>(rows);
+        }
+        if (dl[k] >= df[k]) rows += dl[k] - df[k] + 1;
     }
-    out[0] = Stripe{};
-    out[0].X = static_cast<int32_t>(S);
-    out[0].K = static_cast<int32_t>(rows);
+    if (out) {
+        out[0] = Stripe{};
+        out[0].X = static_cast<int32_t>(S);
+        out[0].K = static_cast<int32_t>(rows);
+    }
     if (rows_out) *rows_out = rows;
 }
 inline int64_t stripes_of(const Segment &s, int R) { return (s.xe - s.xs) / (64 * R) + 1; }
@@ -575,9 +578,22 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         return s.max_width <= lds_max_w ? kFirstGeneric + 2 : kFirstGeneric + 3;
     };
     std::vector<int8_t> cls_of(ntasks);
-    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) { cls_of[k] = static_cast<int8_t>(class_of(plans[order[k].read].segs[order[k].seg])); });
+    // k_dp_tile tasks are ordered by the forward scratch they need (one row per anti-diagonal of a stripe: also what a
+    // task costs): a workgroup's region is sized by its FIRST task, every later one from the queue is smaller
+    std::vector<int64_t> tile_need(ntasks, 0);
+    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
+        const Segment &sg = plans[order[k].read].segs[order[k].seg];
+        cls_of[k] = static_cast<int8_t>(class_of(sg));
+        if (kClassTab[cls_of[k]].kind == K_TILE) {
+            int64_t rows = 0;
+            build_stripes(sg, kClassTab[cls_of[k]].R, nullptr, &rows);
+            tile_need[k] = (tile_scratch_cells(rows, kClassTab[cls_of[k]].R) + 63) & ~int64_t(63);
+        }
+    });
     std::stable_sort(rank.begin(), rank.end(), [&](int32_t a, int32_t c) {
-        return cls_of[a] != cls_of[c] ? cls_of[a] < cls_of[c] : order[a].cells > order[c].cells;
+        if (cls_of[a] != cls_of[c]) return cls_of[a] < cls_of[c];
+        if (tile_need[a] != tile_need[c]) return tile_need[a] > tile_need[c];
+        return order[a].cells > order[c].cells;
     });
     b->task_of.assign(ntasks, 0);
     for (int64_t k = 0; k < ntasks; ++k) b->task_of[rank[k]] = static_cast<int32_t>(k);
@@ -660,11 +676,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         int64_t stair_cells = 0;
         if (b->tasks[k].ctl_off >= 0)
             build_stair_schedule(s, kClassTab[cls_of[rank[k]]].R, kClassTab[cls_of[rank[k]]].NW, h_ctl.get() + 2 * b->tasks[k].ctl_off, &stair_cells);
-        if (b->tasks[k].tile_off >= 0) {
-            int64_t rows = 0;
-            build_stripes(s, kClassTab[cls_of[rank[k]]].R, h_stripes.get() + b->tasks[k].tile_off, &rows);
-            stair_cells = tile_scratch_cells(rows, kClassTab[cls_of[rank[k]]].R);
-        }
+        if (b->tasks[k].tile_off >= 0) build_stripes(s, kClassTab[cls_of[rank[k]]].R, h_stripes.get() + b->tasks[k].tile_off, nullptr);
         uint64_t off = 0;
         for (int64_t d = 0; d <= s.D(); ++d) {
             h_lo[band_base[k] + d] = s.lo[d];
@@ -719,8 +731,11 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
             L.lds = wide_lds_bytes(nw);
             L.threads = 64 * nw;
         } else if (kClassTab[c].kind == K_TILE) {
-            // 80 VGPRs: 6 wavefronts per SIMD, 24 per CU, shared by workgroups of NW wavefronts
-            int nw = 8;
+            // 80 VGPRs: 6 wavefronts per SIMD, 24 per CU, shared by workgroups of NW wavefronts.  A read's band offers a
+            // parallelism of about four stripes on average (rectangles of ~1000 columns, each stripe starting 128 + 16..31
+            // anti-diagonals after its left neighbour): measured on 8192 x 8 kb reads in the reference's band, 2 / 3 / 4 / 6 / 8
+            // wavefronts per task give 1.26 / 1.71 / 2.06 / 1.42 / 1.64e11 cells/s (more tasks in flight need more scratch)
+            int nw = 4;
             if (const char *w = std::getenv("NPR_TILE_WAVES")) nw = std::min(8, std::max(1, std::atoi(w)));
             waves_per_cu = std::max(1, 24 / nw);
             L.wcap = nw;
@@ -749,32 +764,60 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
                          (long long)cls_width[c], L.grid, L.threads);
         b->launches.push_back(L);
     }
-    // the launches run concurrently, each on its own scratch regions: the regions of all of them must fit
+    // The launches run concurrently, each on its own scratch regions: the regions of all of them must fit.  The frame /
+    // generic launches take uniform regions of slot_stride cells; the stripe launch one region per workgroup, sized by the
+    // workgroup's first task (its tasks are sorted by need, so everything the queue hands out later is smaller).
+    npr_batch::Launch *tileL = nullptr;
+    for (auto &L : b->launches)
+        if (kClassTab[L.cls].kind == K_TILE) tileL = &L;
+    const int64_t tile_min = tileL ? tile_need[rank[tileL->first]] : 0;
     int64_t sum_grid = 0;
-    for (auto &L : b->launches) sum_grid += L.grid;
+    for (auto &L : b->launches)
+        if (&L != tileL) sum_grid += L.grid;
+    if (tileL && tile_min * 8 > budget) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
+    if (b->slot_stride > 0) fit = (budget - tile_min * 8) / (b->slot_stride * 8);
     if (sum_grid > fit) {
-        if (fit < static_cast<int64_t>(b->launches.size())) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for one forward scratch region per kernel class");
+        const int64_t others = static_cast<int64_t>(b->launches.size()) - (tileL ? 1 : 0);
+        if (fit < others) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for one forward scratch region per kernel class");
         const double shrink = static_cast<double>(fit) / static_cast<double>(sum_grid);
-        for (auto &L : b->launches) L.grid = std::max(1, static_cast<int>(L.grid * shrink));
+        for (auto &L : b->launches)
+            if (&L != tileL) L.grid = std::max(1, static_cast<int>(L.grid * shrink));
     }
     sum_grid = 0;
     for (auto &L : b->launches) {
+        if (&L == tileL) continue;
         L.slot_base = static_cast<int>(sum_grid);
         sum_grid += L.grid;
         if (kClassTab[L.cls].kind == K_GENERIC_GLOBAL) ring_floats = static_cast<int64_t>(L.grid) * 18 * L.wcap;
         max_grid = std::max<int64_t>(max_grid, L.grid);
     }
-    const int64_t grid = ntasks ? sum_grid : 0;
+    std::vector<int64_t> region;  // first scratch cell of each workgroup of the stripe launch
+    int64_t tile_total = 0;
+    if (tileL) {
+        const int64_t room = budget / 8 - sum_grid * b->slot_stride;
+        int g = 0;
+        for (; g < tileL->grid; ++g) {
+            const int64_t need = tile_need[rank[tileL->first + g]];
+            if (g > 0 && tile_total + need > room) break;
+            region.push_back(sum_grid * b->slot_stride + tile_total);
+            tile_total += need;
+        }
+        tileL->grid = std::max(1, g);
+        tileL->slot_base = 0;
+        max_grid = std::max<int64_t>(max_grid, tileL->grid);
+    }
+    const int64_t grid = ntasks ? sum_grid + (tileL ? tileL->grid : 0) : 0;
     hipError_t e;
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
         (e = b->d_queue.alloc(kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
         (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
         (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_ctl.alloc(2 * ctl_entries)) != hipSuccess ||
-        (e = b->d_stripes.alloc(stripe_entries)) != hipSuccess ||
+        (e = b->d_stripes.alloc(stripe_entries)) != hipSuccess || (e = b->d_region.alloc(region.size())) != hipSuccess ||
         (e = b->d_px.alloc(pair_total)) != hipSuccess ||
         (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
-    b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(grid);
+    // (at least one uniform region: npr_batch_dense and the generic E-step run any task there)
+    b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(std::max<int64_t>(sum_grid, ntasks ? 1 : 0)) + static_cast<size_t>(tile_total);
     if (b->scratch_cells > ctx->arena_cells) {
         if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
         ctx->arena_F = nullptr, ctx->arena_cells = 0;
@@ -793,6 +836,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.get(), b->d_coff.bytes(), hipMemcpyHostToDevice));
         if (ctl_entries) HIP_TRY(ctx, hipMemcpy(b->d_ctl.p, h_ctl.get(), b->d_ctl.bytes(), hipMemcpyHostToDevice));
         if (stripe_entries) HIP_TRY(ctx, hipMemcpy(b->d_stripes.p, h_stripes.get(), b->d_stripes.bytes(), hipMemcpyHostToDevice));
+        if (!region.empty()) HIP_TRY(ctx, hipMemcpy(b->d_region.p, region.data(), b->d_region.bytes(), hipMemcpyHostToDevice));
     }
     tm.lap("H2D");
     b->outs.resize(ntasks);
@@ -807,7 +851,7 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
         for (const auto &L : b->launches)
             if (L.cells > best) best = L.cells, b->stats.kernel_variant = kClassTab[L.cls].kind == K_TILE ? 2 : (is_register_class(L.cls) ? 1 : 0);
     }
-    b->stats.device_bytes = fixed + b->slot_stride * grid * 8 + ring_floats * 4;
+    b->stats.device_bytes = fixed + static_cast<int64_t>(b->scratch_cells) * 8 + ring_floats * 4;
     *out = b.release();
     return NPR_OK;
 }
@@ -825,6 +869,7 @@ static KernelArgs make_args(npr_batch *b) {
     a.coff = b->d_coff.p;
     a.ctl = b->d_ctl.p;
     a.stripes = b->d_stripes.p;
+    a.region = b->d_region.p;
     a.F = b->ctx->arena_F;
     a.slot_stride = b->slot_stride;
     a.px = b->d_px.p;
@@ -843,6 +888,11 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     if (b->tasks.empty()) {
         b->ran = true;
         return NPR_OK;
+    }
+    DevBuf<unsigned long long> d_prof;  // NPR_TILE_PROF=1 (bring-up): wait cycles of the stripe kernel's wavefronts
+    if (std::getenv("NPR_TILE_PROF")) {
+        if (d_prof.alloc(8) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_run: hipMalloc");
+        HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, d_prof.bytes(), ctx->stream));
     }
     HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * kQueueSlots, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -863,6 +913,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.queue += L.cls;
         a.wcap = L.wcap;
         a.slot_base = L.slot_base;
+        a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
         const int rc = kc.kind == K_STAIR  ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
@@ -875,6 +926,12 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    if (d_prof.p) {
+        unsigned long long pf[8];
+        HIP_TRY(ctx, hipMemcpy(pf, d_prof.p, sizeof(pf), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[npr tile prof] wavefront cycles: waiting for a neighbour %.3g, for own stores %.3g, at barriers %.3g, total %.3g\n",
+                     (double)pf[0], (double)pf[1], (double)pf[2], (double)pf[3]);
+    }
     b->ran = true;
     b->finished = false;
     return NPR_OK;
@@ -1316,7 +1373,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     size_t ring_floats = 0;
     for (auto &l : launches) {
         // the forward scratch of this batch was sized for the DP launches' grid: stay inside it
-        l.grid = static_cast<int>(std::min<int64_t>(l.grid, b->stats.slots));
+        l.grid = static_cast<int>(std::min<int64_t>(l.grid, std::max<int64_t>(1, static_cast<int64_t>(ctx->arena_cells) / std::max<int64_t>(b->slot_stride, 1))));
         max_grid = std::max<int64_t>(max_grid, l.grid);
         if (l.global_ring) ring_floats = std::max(ring_floats, static_cast<size_t>(l.grid) * 18 * l.wcap);
     }

@@ -55,6 +55,8 @@ struct KernelArgs {
     const int32_t *n;
     const uint32_t *coff;  // per anti-diagonal: offset of its first cell inside the task (cells padded to x4)
     const Stripe *stripes;  // k_dp_tile: stripe tables (Task::tile_off)
+    unsigned long long *prof;  // k_dp_tile, NPR_TILE_PROF=1: wait-cycle counters
+    const int64_t *region;  // k_dp_tile: first scratch cell of each workgroup (regions sized by the workgroup's first task)
     const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 13 | (rebase + 1) << 26)
     char *F;               // forward match-state scratch: one region of 8*slot_stride bytes per resident wave.  The
                            // register kernel keeps (mantissa, exponent) interleaved per cell; the generic kernel

@@ -61,8 +61,10 @@ __device__ __forceinline__ TBand tile_band(int d, int lo, int n, int origin, int
     return TBand{j1 >= j0 ? j0 : 0, max(j1 - j0 + 1, 0)};
 }
 
-__device__ __forceinline__ int lds_peek(const int *p) { return *reinterpret_cast<const volatile int *>(p); }
-__device__ __forceinline__ void lds_poke(int *p, int v) { *reinterpret_cast<volatile int *>(p) = v; }
+// progress words: volatile LDS accesses (the pointer has to say LDS, or the compiler emits flat loads)
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ int lds_peek(const int *p) { return *(const volatile lds_int *)(p); }
+__device__ __forceinline__ void lds_poke(int *p, int v) { *(volatile lds_int *)(p) = v; }
 
 // one row per anti-diagonal of a stripe: 64*R cells of 8 bytes, lane l at 8*R*l
 template <int R>
@@ -189,8 +191,10 @@ __device__ __forceinline__ void tile_bwd_step(const StepEnv &E, Diag<R> &io, con
 
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int R>
-__global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
+// PROF (NPR_TILE_PROF=1, bring-up): cycles every wavefront spends waiting -- for a neighbour's cells, for its own stores
+// before it publishes, at the barriers between the sweeps -- summed into a.prof[0..3] next to its total.
+template <int R, bool PROF>
+__global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves_per_eu(R == 2 ? 6 : 1))) k_dp_tile(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmodel = reinterpret_cast<float *>(smem);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] pair counter, [5] next task
@@ -201,11 +205,15 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
     const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
     const int NW = static_cast<int>(blockDim.x) >> 6;
     float *const stage = reinterpret_cast<float *>(prog + TILE_MAX_NW) + wv * (TILE_BLOCK * EDGE_FLOATS);
-    char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
+    char *const F = a.F + uni64(a.region[blockIdx.x]) * 8;
     const int voff = 8 * R * lane;
     int jr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
+
+    uint64_t pf_spin = 0, pf_vm = 0, pf_bar = 0, pf_t0 = 0, pf_all = 0;
+    auto tick = [&]() -> uint64_t { return PROF ? __builtin_readcyclecounter() : 0; };
+    if constexpr (PROF) pf_t0 = tick();
 
     int t = blockIdx.x;
     while (t < a.ntasks) {
@@ -279,7 +287,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
                 if (q0 >= 0 && q0 < lenL) {
                     const int hi = min(q0 + TILE_BLOCK, lenL);
                     const int need = static_cast<int>(row0L) + hi;
-                    while (uni(lds_peek(prog + wL)) < need) __builtin_amdgcn_s_sleep(2);
+                    { const uint64_t c0 = tick(); while (uni(lds_peek(prog + wL)) < need) __builtin_amdgcn_s_sleep(2); pf_spin += tick() - c0; }
                     asm volatile("" ::: "memory");
                     edge_stage(Ef, row0L + q0, hi - q0, stage, lane);
                     blk_lo = q0, blk_hi = hi;
@@ -299,7 +307,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
                     if (q >= blk_hi) {
                         const int hi = min(q + TILE_BLOCK, lenL);
                         const int need = static_cast<int>(row0L) + hi;
-                        while (uni(lds_peek(prog + wL)) < need) __builtin_amdgcn_s_sleep(2);
+                        { const uint64_t c0 = tick(); while (uni(lds_peek(prog + wL)) < need) __builtin_amdgcn_s_sleep(2); pf_spin += tick() - c0; }
                         asm volatile("" ::: "memory");
                         edge_stage(Ef, row0L + q, hi - q, stage, lane);
                         blk_lo = q, blk_hi = hi;
@@ -322,7 +330,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
                 edge_store(Ef, row, io.c[R - 1], out_lane);
                 const int k = d - st.df;
                 if ((k & (TILE_BLOCK - 1)) == TILE_BLOCK - 1 || d == st.dl) {
-                    wait_vm();
+                    { const uint64_t c0 = tick(); wait_vm(); pf_vm += tick() - c0; }
                     if (lane == 0) lds_poke(prog + wv, static_cast<int>(row) + 1);
                 }
             };
@@ -349,7 +357,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
             }
             }
         }
-        __syncthreads();
+        { const uint64_t c0 = tick(); __syncthreads(); pf_bar += tick() - c0; }
         const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
         const int tot_e = uni(lmisc[1]);
 
@@ -407,7 +415,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
                     if (q0 >= 0 && q0 < lenR) {
                         const int lo = max(q0 - TILE_BLOCK + 1, 0);
                         const int need = static_cast<int>(row0R) + lo;
-                        while (uni(lds_peek(prog + wR)) > need) __builtin_amdgcn_s_sleep(2);
+                        { const uint64_t c0 = tick(); while (uni(lds_peek(prog + wR)) > need) __builtin_amdgcn_s_sleep(2); pf_spin += tick() - c0; }
                         asm volatile("" ::: "memory");
                         edge_stage(Eb, row0R + lo, q0 - lo + 1, stage, lane);
                         blk_lo = lo, blk_hi = q0 + 1;
@@ -432,7 +440,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
                         if (q < blk_lo) {
                             const int lo = max(q - TILE_BLOCK + 1, 0);
                             const int need = static_cast<int>(row0R) + lo;
-                            while (uni(lds_peek(prog + wR)) > need) __builtin_amdgcn_s_sleep(2);
+                            { const uint64_t c0 = tick(); while (uni(lds_peek(prog + wR)) > need) __builtin_amdgcn_s_sleep(2); pf_spin += tick() - c0; }
                             asm volatile("" ::: "memory");
                             edge_stage(Eb, row0R + lo, q - lo + 1, stage, lane);
                             blk_lo = lo, blk_hi = q + 1;
@@ -488,7 +496,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
                     }
                     const int k = st.dl - d;
                     if ((k & (TILE_BLOCK - 1)) == TILE_BLOCK - 1 || d == st.df) {
-                        wait_vm();
+                        { const uint64_t c0 = tick(); wait_vm(); pf_vm += tick() - c0; }
                         if (lane == 0) lds_poke(prog + wv, static_cast<int>(row));
                     }
                 };
@@ -514,7 +522,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
                 }
                 }
             }
-            __syncthreads();
+            { const uint64_t c0 = tick(); __syncthreads(); pf_bar += tick() - c0; }
             out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
             out.btot_e = uni(lmisc[3]);
         }
@@ -527,6 +535,15 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) k_dp_tile(KernelArgs a) {
         }
         __syncthreads();
         t = uni(lmisc[5]) + static_cast<int>(gridDim.x);
+    }
+    if constexpr (PROF) {
+        pf_all = tick() - pf_t0;
+        if (lane == 0) {
+            atomicAdd(a.prof + 0, static_cast<unsigned long long>(pf_spin));
+            atomicAdd(a.prof + 1, static_cast<unsigned long long>(pf_vm));
+            atomicAdd(a.prof + 2, static_cast<unsigned long long>(pf_bar));
+            atomicAdd(a.prof + 3, static_cast<unsigned long long>(pf_all));
+        }
     }
 }
 
@@ -541,10 +558,12 @@ int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (NW < 1 || NW > TILE_MAX_NW) return static_cast<int>(hipErrorInvalidValue);
     const size_t lds = tile_lds_bytes(NW);
-    if (R == 2)
-        hipLaunchKernelGGL(k_dp_tile<2>, dim3(grid), dim3(WAVE * NW), lds, s, a);
+    if (R == 2 && a.prof)
+        hipLaunchKernelGGL((k_dp_tile<2, true>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+    else if (R == 2)
+        hipLaunchKernelGGL((k_dp_tile<2, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
     else if (R == 4)
-        hipLaunchKernelGGL(k_dp_tile<4>, dim3(grid), dim3(WAVE * NW), lds, s, a);
+        hipLaunchKernelGGL((k_dp_tile<4, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
     else
         return static_cast<int>(hipErrorInvalidValue);
     return static_cast<int>(hipGetLastError());

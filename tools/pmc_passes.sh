@@ -1,6 +1,7 @@
 #!/bin/bash
-# tools/pmc_passes.sh OUT n L W -- rocprofv3 PMC passes (one counter group per run) over tools/gpu_pmc_run.py n L W.
-# Writes gpurun_out/pmc_OUT/summary.csv: counter, launches, per-launch mean of the k_dp_stair kernels.
+# tools/pmc_passes.sh OUT n L W -- rocprofv3 PMC passes (one counter group per run) over tools/gpu_pmc_run.py n L W
+# (W = 0: the reference's anchor band).  Writes gpurun_out/pmc_OUT/summary.csv: counter, launches, per-launch mean of the
+# kernels whose name contains $KERNEL (default k_dp_).
 set -u
 OUT=gpurun_out/pmc_$1; shift
 mkdir -p $OUT
@@ -17,7 +18,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$R/$OUT/g*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_dp_stair" in row["Kernel_Name"]:
+        if "${KERNEL:-k_dp_}" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open("$R/$OUT/summary.csv", "w") as o:
     o.write("counter,launches,per_launch_mean\n")
