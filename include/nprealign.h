@@ -82,7 +82,7 @@ typedef struct {
     int32_t constraint_trim;     /* anchors trimmed at both ends of each gapless block (cPecan default 14) */
     int64_t split_threshold;     /* --splitMatrixBiggerThanThis: 3000 realign (utils.py:587), 100 analyses
                                     (alignmentUncertainty.py:41, marginAlignSnpCaller.py:136) */
-    int32_t fixed_width;         /* W for NPR_BAND_FIXED */
+    int32_t fixed_width;         /* W for NPR_BAND_FIXED, >= 2 (narrower: NPR_ERR_INVALID for the read) */
     double gap_gamma;            /* --gapGamma  (abstractMapper.py:25 default 0.5) */
     double match_gamma;          /* --matchGamma (abstractMapper.py:25 default 0.0) */
     double posterior_threshold;  /* 0.01 */
@@ -242,6 +242,11 @@ int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y
 /* mean posterior over the M columns of a cigar (stage a5.7) */
 int32_t npr_rescore(const int32_t *guide_ops, int64_t n_guide_ops, const int32_t *x, const int32_t *y,
                     const float *p, int64_t n, double *score);
+/* SAM CIGAR text of n op lists (CSR as returned by npr_batch_ops): what realignSamFile3TargetFn assigns to aR.cigar
+ * and pysam prints (nanopore/analyses/utils.py:597-605), for a writer that splices 50 k records at once.  String i is
+ * out[str_off[i] .. str_off[i+1]) (no terminator; "*" for an empty list).  out == NULL: only the offsets; returns the
+ * total length, NPR_ERR_CAPACITY when cap is smaller, NPR_ERR_INVALID for an op outside M/I/D.  Threaded. */
+int64_t npr_format_cigars(int64_t n, const int64_t *ops_off, const int32_t *ops, int64_t *str_off, char *out, int64_t cap);
 /* ASCII -> base codes 0..4 (A,C,G,T,N) */
 void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes);
 

@@ -84,7 +84,7 @@ EXPORTS = [
     "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_batch_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
-    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
+    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
 ]
 
 _lib = None
@@ -151,6 +151,8 @@ def load():
     L.npr_plan_segment_band.argtypes = [vp, i32, vp, vp]
     L.npr_plan_stripes.restype = i32
     L.npr_plan_stripes.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.npr_format_cigars.restype = i64
+    L.npr_format_cigars.argtypes = [i64, vp, vp, vp, vp, i64]
     L.npr_mea_cigar.restype = i64
     L.npr_mea_cigar.argtypes = [i64, i64, vp, vp, vp, i64, dbl, dbl, vp, i64, C.POINTER(dbl)]
     L.npr_rescore.restype = i32

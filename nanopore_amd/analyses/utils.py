@@ -317,20 +317,32 @@ def realignRecords(sam, records, refSequences, gapGamma, matchGamma, hmmFile, mo
         constraint_trim=CONSTRAINT_DIAGONAL_TRIM,
         split_threshold=REALIGN_SPLIT_MATRIX_BIGGER_THAN if splitThreshold is None else splitThreshold,
         gap_gamma=gapGamma, match_gamma=matchGamma, mode=realign.MODE_REALIGN if mode is None else mode)
-    reads, guides, ref_index = [], [], []
+    reads, guides, ref_index, starts = [], [], [], []
     for aR in records:
         for op, _ in aR.cigar:
             assert op in (0, 1, 2, 4, 5)
         reads.append(aR.query)
         guides.append(_guideOf(aR))
         ref_index.append(index[sam.getrname(aR.rname)])
-        # the realigner expects the global records chainSamFile produces (utils.py:492-496)
-        refLen = len(refSequences[sam.getrname(aR.rname)])
-        if aR.pos != 0 or aR.aend != refLen:
-            raise RuntimeError("Record %s is not a global alignment of its reference (pos %s, aend %s, reference length "
-                               "%s): chain the SAM file first" % (aR.qname, aR.pos, aR.aend, refLen))
-    return ctx.realign(params, [refSequences[n] for n in names], reads, guides, ref_index=ref_index,
-                       want_pairs=want_pairs)
+        # the window the exonerate cigar names: reference [pos, aend), read [0, len(query)) (utils.py:175-177).  A chained
+        # record is global (pos 0, aend = reference length, utils.py:381-382); a local hit of an un-chained mapper SAM
+        # (AlignmentUncertainty on a base mapper's output) is realigned inside its own window, as cactus_realign does.
+        starts.append((aR.pos, 0))
+    refs = [refSequences[n] for n in names]
+
+    def run(lo, hi):
+        # one batched call; a batch the device cannot hold (NPR_ERR_NOMEM: the reference's per-read jobs have no such
+        # limit) is halved and retried, results concatenated in input order
+        try:
+            return ctx.realign(params, refs, reads[lo:hi], guides[lo:hi], ref_index=ref_index[lo:hi], want_pairs=want_pairs,
+                               guide_start=starts[lo:hi])
+        except realign.NprError as e:
+            if e.code != realign.ERR_NOMEM or hi - lo < 2:
+                raise
+        mid = (lo + hi) // 2
+        return run(lo, mid) + run(mid, hi)
+
+    return run(0, len(records))
 
 
 def realignSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, hmmFile, gapGamma, matchGamma, ctx=None):

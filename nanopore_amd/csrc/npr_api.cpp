@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -159,6 +161,9 @@ int usable_cpus() {
     return n;
 }
 
+// Runs f(0..n-1) on `threads` host threads.  An exception inside a worker (std::bad_alloc from a plan or MEA vector)
+// must not escape the thread -- that would be std::terminate --: it is caught, the remaining items are skipped and the
+// first one is rethrown on the calling thread, where the C ABI turns it into NPR_ERR_NOMEM.
 template <typename F>
 void parallel_for(int64_t n, int threads, F f) {
     threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(threads, n)));
@@ -167,16 +172,26 @@ void parallel_for(int64_t n, int threads, F f) {
         return;
     }
     std::atomic<int64_t> next{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr first;
+    std::mutex mu;
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; ++t)
         pool.emplace_back([&] {
-            for (;;) {
-                const int64_t i = next.fetch_add(1);
-                if (i >= n) break;
-                f(i);
+            try {
+                for (;;) {
+                    const int64_t i = next.fetch_add(1);
+                    if (i >= n || failed.load()) break;
+                    f(i);
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(mu);
+                if (!first) first = std::current_exception();
+                failed = true;
             }
         });
     for (auto &th : pool) th.join();
+    if (first) std::rethrow_exception(first);
 }
 
 }  // namespace
@@ -290,7 +305,9 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
         say("npr_create: hipSetDevice", e);
         return NPR_ERR_NO_DEVICE;
     }
-    std::unique_ptr<npr_ctx> ctx(new (std::nothrow) npr_ctx);
+    // every failure below goes through npr_destroy (streams, events and device memory made so far are released) and the
+    // handle is only handed out once the default model is installed
+    npr_ctx *ctx = new (std::nothrow) npr_ctx;
     if (!ctx) return NPR_ERR_NOMEM;
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount;
@@ -300,17 +317,25 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
         if ((e = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->side_done[i], hipEventDisableTiming)) != hipSuccess) {
             say("npr_create: side stream allocation", e);
+            npr_destroy(ctx);
             return NPR_ERR_HIP;
         }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void **>(&ctx->d_models), sizeof(DevModel) * NPR_MAX_MODELS)) != hipSuccess) {
         say("npr_create: stream/event/model allocation", e);
+        npr_destroy(ctx);
         return NPR_ERR_HIP;
     }
-    *out = ctx.release();
     // slot 0 defaults to the stock model (no --loadHmm)
-    return npr_set_hmm(*out, 0, nullptr, nullptr);
+    const int32_t rc = npr_set_hmm(ctx, 0, nullptr, nullptr);
+    if (rc != NPR_OK) {
+        if (err && errlen) std::snprintf(err, errlen, "npr_create: %s", ctx->last_error.c_str());
+        npr_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return NPR_OK;
 }
 
 void npr_destroy(npr_ctx *ctx) {
@@ -468,11 +493,31 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
                                nullptr, model_slot, out);
 }
 
+static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                                    const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                                    const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                                    const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
+                                    npr_batch **out);
+
+// no exception crosses the C ABI: allocation failures of the host stages come back as NPR_ERR_NOMEM
 int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
                             const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
                             const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
                             const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
                             npr_batch **out) {
+    try {
+        return batch_create_at_impl(ctx, params, n_reads, n_refs, ref, ref_off, ref_index, read, read_off, guide_ops, guide_off,
+                                    guide_start, model_slot, out);
+    } catch (const std::exception &) {
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: out of host memory");
+    }
+}
+
+static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                                    const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                                    const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                                    const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
+                                    npr_batch **out) {
     if (!ctx || !params || !out || n_reads < 0 || n_refs < 0) return NPR_ERR_INVALID;
     if (!ref_index && n_refs != n_reads) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: without ref_index, n_refs must equal n_reads");
     auto ref_of = [&](int64_t i) -> int64_t { return ref_index ? ref_index[i] : i; };
@@ -1182,7 +1227,17 @@ int32_t device_mea(npr_batch *b) {
 
 }  // namespace
 
+static int32_t batch_finish_impl(npr_batch *b);
+
 int32_t npr_batch_finish(npr_batch *b) {
+    try {
+        return batch_finish_impl(b);
+    } catch (const std::exception &) {
+        return fail(b ? b->ctx : nullptr, NPR_ERR_NOMEM, "npr_batch_finish: out of host memory");
+    }
+}
+
+static int32_t batch_finish_impl(npr_batch *b) {
     if (!b) return NPR_ERR_INVALID;
     npr_ctx *ctx = b->ctx;
     if (!b->ran) return fail(ctx, NPR_ERR_STATE, "npr_batch_finish before npr_batch_run");
@@ -1308,7 +1363,12 @@ int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32
     std::copy(b->pair_off.begin(), b->pair_off.end(), pair_off);
     if (!x) return NPR_OK;
     if (!b->pairs_ready) {  // realign mode left them on the device
-        const int32_t rc = fetch_pairs(const_cast<npr_batch *>(b));
+        int32_t rc;
+        try {
+            rc = fetch_pairs(const_cast<npr_batch *>(b));
+        } catch (const std::exception &) {
+            rc = fail(b->ctx, NPR_ERR_NOMEM, "npr_batch_pairs: out of host memory");
+        }
         if (rc != NPR_OK) return rc;
     }
     const int64_t total = b->pair_off[b->n_reads];
@@ -1614,6 +1674,44 @@ int32_t npr_rescore(const int32_t *guide_ops, int64_t n_guide_ops, const int32_t
     std::sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &d) { return a.x != d.x ? a.x < d.x : a.y < d.y; });
     *score = rescore(guide_ops, n_guide_ops, pairs.data(), n);
     return NPR_OK;
+}
+
+int64_t npr_format_cigars(int64_t n, const int64_t *ops_off, const int32_t *ops, int64_t *str_off, char *out, int64_t cap) {
+    if (n < 0 || (n && (!ops_off || !str_off)) || (n && ops_off[n] > 0 && !ops)) return NPR_ERR_INVALID;
+    static const char code[3] = {'M', 'I', 'D'};
+    auto digits = [](int32_t v) { int k = 1; while (v >= 10) v /= 10, ++k; return k; };
+    const int threads = usable_cpus();
+    std::vector<int64_t> len(n);
+    std::atomic<int> bad{0};
+    parallel_for((n + 255) / 256, threads, [&](int64_t c) {
+        for (int64_t i = c * 256, hi = std::min(n, (c + 1) * 256); i < hi; ++i) {
+            int64_t k = 0;
+            for (int64_t q = ops_off[i]; q < ops_off[i + 1]; ++q) {
+                if (ops[2 * q] < 0 || ops[2 * q] > 2 || ops[2 * q + 1] < 0) bad = 1;
+                k += digits(ops[2 * q + 1]) + 1;
+            }
+            len[i] = k ? k : 1;  // an empty cigar is "*"
+        }
+    });
+    if (bad) return NPR_ERR_INVALID;
+    str_off[0] = 0;
+    for (int64_t i = 0; i < n; ++i) str_off[i + 1] = str_off[i] + len[i];
+    if (!out) return str_off[n];
+    if (cap < str_off[n]) return NPR_ERR_CAPACITY;
+    parallel_for((n + 255) / 256, threads, [&](int64_t c) {
+        for (int64_t i = c * 256, hi = std::min(n, (c + 1) * 256); i < hi; ++i) {
+            char *w = out + str_off[i];
+            if (ops_off[i + 1] == ops_off[i]) *w = '*';
+            for (int64_t q = ops_off[i]; q < ops_off[i + 1]; ++q) {
+                int32_t v = ops[2 * q + 1];
+                const int k = digits(v);
+                for (int j = k - 1; j >= 0; --j) w[j] = static_cast<char>('0' + v % 10), v /= 10;
+                w[k] = code[ops[2 * q]];
+                w += k + 1;
+            }
+        }
+    });
+    return str_off[n];
 }
 
 void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes) {

@@ -178,6 +178,9 @@ int32_t build_plan(const npr_params &p, int64_t lX, int64_t lY, const int32_t *o
     if (lX < 0 || lY < 0 || (nops > 0 && !ops)) return NPR_ERR_INVALID;
     if (!guide_is_global(lX, lY, ops, nops)) return NPR_ERR_INVALID;
     if (lX + lY >= (int64_t(1) << 30)) return NPR_ERR_INVALID;
+    // a fixed band narrower than two cells has empty odd anti-diagonals: the lattice falls apart, and the read would only
+    // surface as NPR_ERR_ZERO_PROB after a full GPU launch
+    if (p.band_mode == NPR_BAND_FIXED && p.fixed_width < 2) return NPR_ERR_INVALID;
     if (p.band_mode == NPR_BAND_FIXED) return plan_fixed_width(p, lX, lY, ops, nops, out);
     if (p.band_mode == NPR_BAND_ANCHOR) return plan_from_anchors(p, lX, lY, ops, nops, out);
     return NPR_ERR_INVALID;

@@ -95,6 +95,28 @@ def allReduceExpectations(T, E, ll, device=None, group=None):
             flat[nT + nE:].reshape(np.asarray(ll).shape))
 
 
+def broadcastModel(hmm, device=None, group=None, src=0):
+    """Sharded EM: every rank continues from rank `src`'s model (a random start drawn per rank would make the first
+    E-step sum counts computed under different models).  A no-op outside torch.distributed."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except ImportError:
+        return hmm
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return hmm
+    t = torch.tensor(list(hmm.transitions) + list(hmm.emissions) + [float(hmm.likelihood)], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=src, group=group)
+    v = t.cpu().numpy()
+    nT = len(hmm.transitions)
+    hmm.transitions = [float(x) for x in v[:nT]]
+    hmm.emissions = [float(x) for x in v[nT:-1]]
+    hmm.likelihood = float(v[-1])
+    return hmm
+
+
 def expectationMaximisation(batch, hmm, iterations, trainEmissions=True, slot=0, log=None, reduce_device=None):
     """Runs `iterations` EM iterations on a staged batch whose reads all use model `slot`; updates `hmm` in place.
     Returns the running likelihoods (log-likelihood of the data under the model BEFORE each update).  Under
@@ -137,19 +159,23 @@ def writeXML(path, trialHmms, runningLikelihoods):
         fh.write(minidom.parseString(ET.tostring(root, "utf-8")).toprettyxml(indent="  "))
 
 
-def expectationMaximisationTrials(batch, outputModel, options, startHmm=None, log=None):
+def expectationMaximisationTrials(batch, outputModel, options, startHmm=None, log=None, reduce_device=None):
     """`options.trials` independent EM runs (random starts when options.randomStart), the trial with the highest
-    final likelihood is written to `outputModel`; the XML summary goes to options.outputXMLModelFile."""
+    final likelihood is written to `outputModel`; the XML summary goes to options.outputXMLModelFile.  Under
+    torch.distributed (every rank a shard of the reads) all ranks walk through the same models and pick the same trial:
+    each trial starts from rank 0's model and every likelihood is the sum over the ranks."""
     rng = np.random.default_rng(options.seed)
     trialHmms, running = [], []
     for trial in range(options.trials):
         hmm = Hmm() if startHmm is None else startHmm.copy()
         if options.randomStart or startHmm is None:
             randomise(hmm, rng)
-        rl = expectationMaximisation(batch, hmm, options.iterations, options.trainEmissions, log=log)
+        broadcastModel(hmm, device=reduce_device)
+        rl = expectationMaximisation(batch, hmm, options.iterations, options.trainEmissions, log=log, reduce_device=reduce_device)
         # likelihood of the final parameters
         batch.ctx.set_hmm(hmm)
-        _, _, ll, _ = batch.expectations()
+        T, E, ll, _ = batch.expectations()
+        _, _, ll = allReduceExpectations(T, E, ll, device=reduce_device)
         hmm.likelihood = float(ll[0])
         rl.append(hmm.likelihood)
         trialHmms.append(hmm)

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (BAND_ANCHOR, BAND_FIXED, MODE_ALL_POSTERIORS, MODE_EXPECTATIONS, MODE_REALIGN, MODE_RESCORE_ORIGINAL, NprError,
+from ._lib import (BAND_ANCHOR, BAND_FIXED, ERR_CAPACITY, ERR_NOMEM, MODE_ALL_POSTERIORS, MODE_EXPECTATIONS, MODE_REALIGN, MODE_RESCORE_ORIGINAL, NprError,
                    Params, ptr)
 
 
@@ -352,6 +352,24 @@ def stripes(params, lX, lY, guide, slots_per_lane=2, segment=0):
                     row0=tab[:, 4].copy(), rows=int(rows[0]))
     finally:
         L.npr_plan_destroy(h)
+
+
+def format_cigars(ops_off, ops):
+    """SAM CIGAR text of every op list of a CSR pair as Batch.ops() returns it: (bytes buffer, offsets[n+1])
+    (include/nprealign.h: npr_format_cigars)."""
+    L = _lib.load()
+    ops_off = np.ascontiguousarray(ops_off, dtype=np.int64)
+    ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 2)
+    n = len(ops_off) - 1
+    str_off = np.zeros(n + 1, dtype=np.int64)
+    total = L.npr_format_cigars(n, ptr(ops_off), ptr(ops), ptr(str_off), None, 0)
+    if total < 0:
+        raise NprError(int(total), "npr_format_cigars")
+    buf = np.empty(max(int(total), 1), dtype=np.uint8)
+    rc = L.npr_format_cigars(n, ptr(ops_off), ptr(ops), ptr(str_off), ptr(buf), int(total))
+    if rc < 0:
+        raise NprError(int(rc), "npr_format_cigars")
+    return buf[:int(total)], str_off
 
 
 def mea_cigar(lX, lY, x, y, p, gap_gamma=0.5, match_gamma=0.0):

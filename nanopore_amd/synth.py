@@ -206,6 +206,7 @@ def make_workload(seed, n_reads, read_len, T, E, flank=0, ref_slice_len=None, ge
         slen = ilen + 2 * flank
     ref_off = np.zeros(n_reads + 1, dtype=np.int64)
     np.cumsum(slen, out=ref_off[1:])
+    start = None
     if genome is None:
         ref_codes = rng.integers(0, 4, size=int(ref_off[-1])).astype(np.uint8)
     else:
@@ -254,7 +255,7 @@ def make_workload(seed, n_reads, read_len, T, E, flank=0, ref_slice_len=None, ge
         guide_start = np.stack([np.asarray(lead, dtype=np.int64), np.zeros(n_reads, dtype=np.int64)], axis=1)
     return dict(ref=_ASCII[ref_codes], ref_off=ref_off, read=_ASCII[read_codes], read_off=read_off,
                 guide_ops=guide_ops, guide_off=out_off, lead=lead, interval_len=ilen,
-                true_runs=true_runs, true_off=run_off, guide_start=guide_start)
+                true_runs=true_runs, true_off=run_off, guide_start=guide_start, genome_start=start)
 
 
 # ---- the named configurations of BASELINE.json / BASELINE.md ----
@@ -279,6 +280,61 @@ def config_c3(T, E, n_reads=50000, genome_len=4641652, gc=0.508):
     genome = random_reference(rng, genome_len, gc)
     return make_workload(1002, n_reads, 8000, T, E, flank=400, genome=genome, length_sigma=0.3, len_min=2000,
                          len_max=20000), 200
+
+
+def config_c3_shared(T, E, n_reads=50000, genome_len=4641652, gc=0.508):
+    """configs[2] the way the reference holds it: ONE 4.6 Mb contig (the reference FASTA, argv[1] of cactus_realign) shared
+    by all reads through `ref_index`, every guide carrying the coordinates of its window on the contig -- the exonerate
+    cigar line of nanopore/analyses/utils.py:173-186.  Same reads, same windows, same bands as config_c3."""
+    rng = np.random.default_rng(1002)
+    genome = random_reference(rng, genome_len, gc)
+    w = make_workload(1002, n_reads, 8000, T, E, flank=400, genome=genome, length_sigma=0.3, len_min=2000,
+                      len_max=20000, windowed=True)
+    return shared_contig(w, genome), 200
+
+
+def shared_contig(w, genome):
+    """A workload cut from `genome` with windowed guides, restated against the genome itself: one reference sequence,
+    ref_index = 0 for every read, guide_start = the window's first position on the contig."""
+    n = len(w["read_off"]) - 1
+    out = dict(w)
+    out["ref"] = _ASCII[genome]
+    out["ref_off"] = np.array([0, len(genome)], dtype=np.int64)
+    out["ref_index"] = np.zeros(n, dtype=np.int32)
+    gs = np.zeros((n, 2), dtype=np.int64)
+    gs[:, 0] = w["genome_start"] + w["lead"]
+    out["guide_start"] = gs
+    return out
+
+
+def csr_take(buf, off, idx):
+    """Rows `idx` of a CSR (buf, off): (new buf, new off).  buf may have trailing dimensions."""
+    off = np.asarray(off)
+    k = off[np.asarray(idx) + 1] - off[idx]
+    new_off = np.zeros(len(idx) + 1, dtype=np.int64)
+    np.cumsum(k, out=new_off[1:])
+    src = np.repeat(off[idx] - new_off[:-1], k) + np.arange(int(new_off[-1]))
+    return buf[src], new_off
+
+
+def take_reads(w, idx):
+    """The sub-workload of the reads `idx` (a rank's shard): reads, guides and per-read fields; a shared reference
+    (ref_index present) stays whole, per-read slices are cut out."""
+    idx = np.asarray(idx, dtype=np.int64)
+    out = {}
+    out["read"], out["read_off"] = csr_take(w["read"], w["read_off"], idx)
+    out["guide_ops"], out["guide_off"] = csr_take(w["guide_ops"], w["guide_off"], idx)
+    if w.get("ref_index") is not None:
+        out["ref"], out["ref_off"], out["ref_index"] = w["ref"], w["ref_off"], np.ascontiguousarray(w["ref_index"][idx])
+    else:
+        out["ref"], out["ref_off"] = csr_take(w["ref"], w["ref_off"], idx)
+        out["ref_index"] = None
+    gs = w.get("guide_start")
+    out["guide_start"] = None if gs is None else np.ascontiguousarray(gs[idx])
+    for k in ("lead", "interval_len", "genome_start"):
+        if w.get(k) is not None:
+            out[k] = w[k][idx]
+    return out
 
 
 def config_c5(T, E, n_reads_per_type=10000):

@@ -65,6 +65,64 @@ def _em_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _FakeCtx(object):
+    def set_hmm(self, hmm, slot=0):
+        self.hmm = hmm
+
+
+class _FakeBatch(object):
+    """Stands in for a staged GPU batch: expected counts and likelihood are a deterministic function of the installed
+    model and of the rank's 'reads' (rank-dependent on purpose)."""
+
+    def __init__(self, rank):
+        self.ctx = _FakeCtx()
+        self.rank = rank
+
+    def expectations(self):
+        t = np.asarray(self.ctx.hmm.transitions)
+        e = np.asarray(self.ctx.hmm.emissions)
+        T = np.zeros((8, 25))
+        E = np.zeros((8, 80))
+        T[0] = (t + 0.01) * (1 + self.rank) * np.arange(1, 26)
+        E[0] = (e + 0.01) * (2 + self.rank)
+        ll = np.zeros(8)
+        ll[0] = -100.0 * (1 + self.rank) - float(np.sum(t * t)) * (3 - 2 * self.rank)
+        return T, E, ll, 0.0
+
+
+def _em_trials_worker(rank, world, port, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nanopore_amd import em
+    opt = em.Options()
+    opt.trials, opt.iterations, opt.randomStart, opt.seed = 3, 2, True, None   # seed None: every rank draws its own start
+    opt.outputXMLModelFile = None
+    out = os.path.join(tmp, "model_rank%d.txt" % rank)
+    best, trials, running = em.expectationMaximisationTrials(_FakeBatch(rank), out, opt)
+    q.put((rank, open(out).read(), [h.likelihood for h in trials], running))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sharded_em_trials_choose_the_same_model_on_every_rank(tmp_path):
+    """Every trial starts from rank 0's random model and every likelihood is summed over the ranks, so both ranks walk
+    through identical models and write the same best one (nanopore_amd/em.py: broadcastModel, allReduceExpectations)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_em_trials_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2] and got[0][3] == got[1][3]
+    assert len(set(got[0][2])) == 3   # three different random starts, three different trials
+
+
 @pytest.mark.timeout(120)
 def test_em_expectations_all_reduce():
     """Sharded EM: expected counts and log-likelihoods are summed over ranks (the training loop's one collective)."""

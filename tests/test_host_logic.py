@@ -130,3 +130,14 @@ def test_frame_schedule_long_gap_rebases_every_other_step():
     d = np.arange(seg["D"] + 1)
     inside = (d > 700) & (d < 1100)                                  # anti-diagonals crossing the deletion
     assert (sch["rebase"][inside & (d % 2 == 1)] == 1).mean() > 0.9
+
+
+def test_fixed_band_narrower_than_two_cells_is_rejected():
+    """A fixed band of width 0 or 1 leaves every odd anti-diagonal empty (a disconnected lattice): the plan refuses it
+    instead of letting the read fail on the device with NPR_ERR_ZERO_PROB."""
+    from nanopore_amd import _lib, realign as R
+    for w in (0, 1):
+        with pytest.raises(_lib.NprError) as e:
+            R.plan(R.make_params(band_mode=R.BAND_FIXED, fixed_width=w), 10, 10, [(0, 10)])
+        assert e.value.code == _lib.ERR_INVALID
+    assert len(R.plan(R.make_params(band_mode=R.BAND_FIXED, fixed_width=2), 10, 10, [(0, 10)])) == 1
