@@ -187,6 +187,29 @@ int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_
  * still in HBM: the first call with x != NULL copies and sorts them (pair_off alone costs nothing). */
 int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32_t *y, float *p, int64_t cap);
 
+/* ---- post-alignment statistics on the device ----
+ * The per-read integer reductions the reference's analyses make by walking every aligned pair in Python:
+ * nanopore/analyses/coverage.py:10-95 (ReadAlignmentCoverageCounter), substitutions.py:9-56, indels.py:9-45.
+ * One record of NPR_STATS_WORDS int32 per read:
+ *   [0] matches (same base, reference base in ACGT)   [1] mismatches (both in ACGT, different)   [2] aligned pairs against N
+ *   [3] aligned pairs (M columns)
+ *   [4] read insertions between aligned pairs, [5] their total length; [6] read deletions, [7] their total length
+ *       (coverage.py:36-41 / indels.py:22-25: runs between two consecutive aligned pairs)
+ *   [8] read bases / [9] reference bases the cigar consumes before its first aligned pair, [10] / [11] after its last one
+ *       (what a global alignment adds, coverage.py:42-58)
+ *   [12] reference bases, [13] read bases the cigar consumes; [14] 0 or NPR_ERR_INVALID (cigar runs out of its sequences)
+ *   [15 + 5 * r + q] aligned pairs of reference base r against read base q, A C G T N (substitutions.py:13-19)
+ * npr_batch_align_stats: the alignments npr_batch_finish just produced, where they lie (packed cigars and base codes are
+ * still in HBM after the device MEA stage; otherwise the cigars are uploaded).  npr_align_stats: any alignments, e.g. the
+ * records of a mapper's SAM file: read i = read[read_off[i] ..) against reference sequence ref_index[i] (NULL: i), cigar
+ * i = (op, length) pairs ops[2 * ops_off[i] ..) starting at reference position start[2 * i] and read position
+ * start[2 * i + 1] (start == NULL: 0, 0).  Sequences are ASCII as in npr_batch_create. */
+#define NPR_STATS_WORDS 40
+int32_t npr_batch_align_stats(npr_batch *b, int32_t *stats /* [n_reads][NPR_STATS_WORDS] */);
+int32_t npr_align_stats(npr_ctx *ctx, int64_t n_reads, int64_t n_refs, const uint8_t *ref, const int64_t *ref_off,
+                        const int32_t *ref_index, const uint8_t *read, const int64_t *read_off, const int32_t *ops,
+                        const int64_t *ops_off, const int64_t *start, int32_t *stats /* [n_reads][NPR_STATS_WORDS] */);
+
 /* Baum-Welch E-step over the staged batch with the models currently installed: what
  * `cactus_realign --outputExpectations` produces per alignment and cactus_expectationMaximisation sums over all of
  * them in every EM iteration (nanopore/analyses/utils.py:509-528).  T_exp[slot*25 + from*5 + to] and

@@ -1,0 +1,105 @@
+"""Per-record alignment statistics of a SAM file, reduced on the GPU.
+
+The reference's coverage / substitutions / indels analyses (nanopore/analyses/coverage.py:10-95,
+substitutions.py:9-56, indels.py:9-45) each walk every aligned pair of every record in Python.  Here the records go to
+the device once (`npr_align_stats`, include/nprealign.h: one wavefront per record reduces its cigar and bases to a row of
+integers: matches, mismatches, pairs against N, gaps between aligned pairs, the 5 x 5 substitution counts) and the three
+analyses format their XML / TSV schemas from that table.  Only what the integer table cannot hold -- the individual gap
+lengths indels.xml lists -- is taken from the cigars on the host, vectorised.  No CPU fallback: the device does the counting.
+"""
+import numpy as np
+
+from .. import sam as pysam
+from .utils import clipLengths, getFastaDictionary, getFastqDictionary, samIterator
+
+# columns of the device table (include/nprealign.h: NPR_STATS_WORDS)
+MATCHES, MISMATCHES, AGAINST_N, PAIRS, N_INS, INS_LEN, N_DEL, DEL_LEN, LEAD_READ, LEAD_REF, TRAIL_READ, TRAIL_REF, REF_SPAN, \
+    READ_SPAN, STATUS = range(15)
+SUBST = 15  # 25 counts, reference base major, A C G T N
+
+
+class SamAlignmentStats(object):
+    """The records of a SAM file (those with a reference, utils.samIterator) and their device-reduced statistics."""
+
+    def __init__(self, samFile, referenceFastaFile, readFastqFile, ctx=None):
+        from .utils import _context
+        self.refSequences = getFastaDictionary(referenceFastaFile)
+        self.readSequences = getFastqDictionary(readFastqFile)
+        sam = pysam.Samfile(samFile, "r")
+        records = list(samIterator(sam))
+        self.readNames = [aR.qname for aR in records]
+        self.refNames = [sam.getrname(aR.rname) for aR in records]
+        self.isReverse = np.array([aR.is_reverse for aR in records], dtype=bool)
+        self.pos = np.array([aR.pos for aR in records], dtype=np.int64)
+        self.aend = np.array([aR.aend for aR in records], dtype=np.int64)
+        self.refLength = np.array([len(self.refSequences[r]) for r in self.refNames], dtype=np.int64)
+        self.readLength = np.array([len(self.readSequences[q]) for q in self.readNames], dtype=np.int64)
+        clips = [clipLengths(aR) for aR in records]
+        self.clipBefore = np.array([c[0] for c in clips], dtype=np.int64)
+        self.clipAfter = np.array([c[1] for c in clips], dtype=np.int64)
+        self.cigars = [[(op, ln) for op, ln in aR.cigar if op in (0, 1, 2)] for aR in records]
+        for aR in records:
+            assert all(op in (0, 1, 2, 4, 5) for op, _ in aR.cigar), "unsupported cigar operation in %s" % aR.qname
+        names = sorted(self.refSequences)
+        index = {n: i for i, n in enumerate(names)}
+        n = len(records)
+        if n:
+            ctx = ctx or _context()
+            self.table = ctx.align_stats([self.refSequences[k] for k in names], [aR.query for aR in records], self.cigars,
+                                         ref_index=[index[r] for r in self.refNames], start=[(int(p), 0) for p in self.pos])
+            bad = np.flatnonzero(self.table[:, STATUS] != 0)
+            if len(bad):
+                raise RuntimeError("The cigar of record %s runs past its sequences" % self.readNames[int(bad[0])])
+        else:
+            self.table = np.zeros((0, 40), dtype=np.int32)
+        sam.close()
+        self._gaps = None
+
+    def __len__(self):
+        return len(self.readNames)
+
+    def gapLengths(self):
+        """(insertion lengths, deletion lengths) per record, in alignment order: read / reference bases between two
+        consecutive aligned pairs (indels.py:22-25).  Vectorised over all cigar operations of the file."""
+        if self._gaps is None:
+            n = len(self)
+            ins, dels = [[] for _ in range(n)], [[] for _ in range(n)]
+            counts = np.array([len(c) for c in self.cigars], dtype=np.int64)
+            if counts.sum():
+                ops = np.array([o for c in self.cigars for o in c], dtype=np.int64).reshape(-1, 2)
+                rec = np.repeat(np.arange(n), counts)
+                first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+                is_m = (ops[:, 0] == 0) & (ops[:, 1] > 0)
+                before = np.cumsum(is_m) - is_m                      # aligned blocks before this op, file-wide
+                gap = before - np.repeat(before[first], counts)      # ... within its record: 0 = before the first block
+                blocks = np.bincount(rec, weights=is_m, minlength=n).astype(np.int64)
+                inner = (~is_m) & (gap > 0) & (gap < blocks[rec])
+                for code, out in ((1, ins), (2, dels)):
+                    sel = inner & (ops[:, 0] == code) & (ops[:, 1] > 0)
+                    key = rec[sel] * (int(gap.max()) + 1) + gap[sel]
+                    uniq, inv = np.unique(key, return_inverse=True)
+                    total = np.bincount(inv, weights=ops[sel, 1]).astype(np.int64)
+                    for k, v in zip(uniq // (int(gap.max()) + 1), total):
+                        out[int(k)].append(int(v))
+            self._gaps = (ins, dels)
+        return self._gaps
+
+    def indelTotals(self, globalAlignment):
+        """(number of read insertions, their total length, number of read deletions, their total length) per record.
+        A global alignment also counts what lies before the first and after the last aligned pair: clipped and inserted
+        read bases, and the reference from its first base to its last (coverage.py:42-58)."""
+        t = self.table.astype(np.int64)
+        n_ins, ins_len, n_del, del_len = t[:, N_INS].copy(), t[:, INS_LEN].copy(), t[:, N_DEL].copy(), t[:, DEL_LEN].copy()
+        if globalAlignment:
+            has_pairs = t[:, PAIRS] > 0
+            for extra_read, extra_ref in ((self.clipBefore + t[:, LEAD_READ], self.pos + t[:, LEAD_REF]),
+                                          (self.clipAfter + t[:, TRAIL_READ], self.refLength - self.aend + t[:, TRAIL_REF])):
+                n_ins += (extra_read > 0) & has_pairs
+                ins_len += np.where(has_pairs, extra_read, 0)
+                n_del += (extra_ref > 0) & has_pairs
+                del_len += np.where(has_pairs, extra_ref, 0)
+        return n_ins, ins_len, n_del, del_len
+
+    def substitutionCounts(self):
+        """5 x 5 counts of aligned (reference base, read base), A C G T N, summed over the file."""
+        return self.table[:, SUBST:SUBST + 25].astype(np.int64).sum(axis=0).reshape(5, 5)

@@ -1,170 +1,113 @@
-"""LocalCoverage / GlobalCoverage: per-alignment and aggregate coverage, identity and indel rates
-(nanopore/analyses/coverage.py:10-166), same XML attribute names (consumed by metaAnalyses/coverageSummary.py).
-SURVEY.md 8f next #3: post-realign statistics.  The R plots are presentation and out of scope."""
+"""LocalCoverage / GlobalCoverage: coverage_all.xml, coverage_bestPerRead.xml and their .txt tables.
+
+Schema of nanopore/analyses/coverage.py: one <readAlignmentCoverage> per SAM record (attributes :79-86: refSeqName,
+readSeqName, readLength, readCoverage, referenceCoverage, identity, mismatchesPerReadBase, insertionsPerReadBase,
+deletionsPerReadBase, with the ratios defined at :60-77) under a root that carries the read / reference counts, the
+mapped / unmapped read lengths and min / avg / median / max / distribution of each of the seven quantities (:88-125;
+read by metaAnalyses/coverageSummary.py:67-73).  The counts behind the ratios come from the device table of
+alignmentStats.SamAlignmentStats; the R plot of the reference (:153) is outside this build's scope."""
 import os
 import xml.etree.ElementTree as ET
-from functools import reduce
-from itertools import chain
 
-import numpy
+import numpy as np
 
-from .. import sam as pysam
 from .abstractAnalysis import AbstractAnalysis
+from .alignmentStats import MATCHES, MISMATCHES, SamAlignmentStats
 from .alignmentUncertainty import prettyXml
-from .utils import AlignedPair, getFastaDictionary, getFastqDictionary, samIterator
+
+QUANTITIES = ("readCoverage", "referenceCoverage", "identity", "mismatchesPerReadBase", "deletionsPerReadBase",
+              "insertionsPerReadBase", "readLength")
 
 
-class ReadAlignmentCoverageCounter(object):
-    """Counts coverage from a pairwise alignment.  Global alignment means the entire reference and read
-    sequences, trailing indels included (coverage.py:10-65)."""
-
-    def __init__(self, readSeqName, readSeq, refSeqName, refSeq, alignedRead, globalAlignment=False):
-        self.matches = 0
-        self.mismatches = 0
-        self.ns = 0
-        self.totalReadInsertionLength = 0
-        self.totalReadInsertions = 0
-        self.totalReadDeletionLength = 0
-        self.totalReadDeletions = 0
-        self.readSeqName = readSeqName
-        self.readSeq = readSeq
-        self.refSeqName = refSeqName
-        self.refSeq = refSeq
-        self.globalAlignment = globalAlignment
-        totalReadInsertionLength, totalReadDeletionLength = 0, 0
-        aP = None
-        for aP in AlignedPair.iterator(alignedRead, self.refSeq, self.readSeq):
-            if aP.isMatch():
-                self.matches += 1
-            elif aP.isMismatch():
-                self.mismatches += 1
-            else:
-                self.ns += 1
-            ins = aP.getPrecedingReadInsertionLength(self.globalAlignment)
-            if ins > 0:
-                self.totalReadInsertions += 1
-                totalReadInsertionLength += ins
-            dele = aP.getPrecedingReadDeletionLength(self.globalAlignment)
-            if dele > 0:
-                self.totalReadDeletions += 1
-                totalReadDeletionLength += dele
-        if self.globalAlignment and aP is not None:  # trailing indels (coverage.py:46-61)
-            assert len(self.refSeq) - aP.refPos - 1 >= 0
-            if len(self.refSeq) - aP.refPos - 1 > 0:
-                self.totalReadDeletions += 1
-                self.totalReadDeletionLength += len(self.refSeq) - aP.refPos - 1
-            if alignedRead.is_reverse:
-                if aP.readPos > 0:
-                    self.totalReadInsertions += 1
-                    totalReadInsertionLength += aP.readPos
-            else:
-                assert len(self.readSeq) - aP.readPos - 1 >= 0
-                if len(self.readSeq) - aP.readPos - 1 > 0:
-                    self.totalReadInsertions += 1
-                    totalReadInsertionLength += len(self.readSeq) - aP.readPos - 1
-        assert totalReadInsertionLength <= len(self.readSeq)
-        assert totalReadDeletionLength <= len(self.refSeq)
-        self.totalReadInsertionLength += totalReadInsertionLength
-        self.totalReadDeletionLength += totalReadDeletionLength
-
-    def readCoverage(self):
-        return AbstractAnalysis.formatRatio(self.matches + self.mismatches,
-                                            self.matches + self.mismatches + self.totalReadInsertionLength)
-
-    def referenceCoverage(self):
-        return AbstractAnalysis.formatRatio(self.matches + self.mismatches,
-                                            self.matches + self.mismatches + self.totalReadDeletionLength)
-
-    def identity(self):
-        return AbstractAnalysis.formatRatio(self.matches, self.matches + self.mismatches + self.totalReadInsertionLength)
-
-    def mismatchesPerReadBase(self):
-        return AbstractAnalysis.formatRatio(self.mismatches, self.matches + self.mismatches)
-
-    def deletionsPerReadBase(self):
-        return AbstractAnalysis.formatRatio(self.totalReadDeletions, self.matches + self.mismatches)
-
-    def insertionsPerReadBase(self):
-        return AbstractAnalysis.formatRatio(self.totalReadInsertions, self.matches + self.mismatches)
-
-    def readLength(self):
-        return len(self.readSeq)
-
-    def getXML(self):
-        return ET.Element("readAlignmentCoverage", {
-            "refSeqName": self.refSeqName, "readSeqName": self.readSeqName, "readLength": str(self.readLength()),
-            "readCoverage": str(self.readCoverage()), "referenceCoverage": str(self.referenceCoverage()),
-            "identity": str(self.identity()), "mismatchesPerReadBase": str(self.mismatchesPerReadBase()),
-            "insertionsPerReadBase": str(self.insertionsPerReadBase()),
-            "deletionsPerReadBase": str(self.deletionsPerReadBase())})
+def _ratio(a, b):
+    return AbstractAnalysis.formatRatio(int(a), int(b))
 
 
-def getAggregateCoverageStats(readAlignmentCoverages, tagName, refSequences, readSequences, readsToReadAlignmentCoverages,
-                              typeof):
-    """Aggregate stats across a set of read alignments (coverage.py:97-125)."""
-    if typeof == "coverage_all":
-        mappedReadLengths = list(chain(*[[len(readSequences[i])] * len(readsToReadAlignmentCoverages[i])
-                                         for i in readSequences if i in readsToReadAlignmentCoverages]))
-    else:
-        mappedReadLengths = [len(readSequences[i]) for i in readSequences if i in readsToReadAlignmentCoverages]
-    unmappedReadLengths = [len(readSequences[i]) for i in readSequences if i not in readsToReadAlignmentCoverages]
+def coverageColumns(stats, globalAlignment):
+    """The seven per-record quantities (coverage.py:60-77) as a dict of lists, from the integer table."""
+    m, x = stats.table[:, MATCHES].astype(np.int64), stats.table[:, MISMATCHES].astype(np.int64)
+    n_ins, ins_len, n_del, del_len = stats.indelTotals(globalAlignment)
+    aligned = m + x
+    n = len(stats)
+    return {
+        "readCoverage": [_ratio(aligned[i], aligned[i] + ins_len[i]) for i in range(n)],
+        "referenceCoverage": [_ratio(aligned[i], aligned[i] + del_len[i]) for i in range(n)],
+        "identity": [_ratio(m[i], aligned[i] + ins_len[i]) for i in range(n)],
+        "mismatchesPerReadBase": [_ratio(x[i], aligned[i]) for i in range(n)],
+        "deletionsPerReadBase": [_ratio(n_del[i], aligned[i]) for i in range(n)],
+        "insertionsPerReadBase": [_ratio(n_ins[i], aligned[i]) for i in range(n)],
+        "readLength": [int(v) for v in stats.readLength],
+    }
 
-    def stats(fnStringName):
-        values = [getattr(x, fnStringName)() for x in readAlignmentCoverages]
+
+def aggregateNode(tagName, stats, columns, chosen, perAlignmentLengths):
+    """Root element for the records `chosen` (indices into the table)."""
+    aligned_reads = {}
+    for i in range(len(stats)):
+        aligned_reads.setdefault(stats.readNames[i], 0)
+        aligned_reads[stats.readNames[i]] += 1
+    mapped, unmapped = [], []
+    for name, seq in stats.readSequences.items():
+        if name in aligned_reads:
+            mapped.extend([len(seq)] * (aligned_reads[name] if perAlignmentLengths else 1))
+        else:
+            unmapped.append(len(seq))
+    attrib = {"numberOfReadAlignments": str(len(chosen)), "numberOfReads": str(len(stats.readSequences)),
+              "numberOfReferenceSequences": str(len(stats.refSequences)), "numberOfMappedReads": str(len(mapped)),
+              "mappedReadLengths": " ".join(map(str, mapped)), "numberOfUnmappedReads": str(len(unmapped)),
+              "unmappedReadLengths": " ".join(map(str, unmapped))}
+    for q in QUANTITIES:
+        values = [columns[q][i] for i in chosen]
         ordered = sorted(values)
-        return ordered[0], numpy.average(ordered), numpy.median(ordered), ordered[-1], " ".join(map(str, values))
-
-    attribs = {"numberOfReadAlignments": str(len(readAlignmentCoverages)), "numberOfReads": str(len(readSequences)),
-               "numberOfReferenceSequences": str(len(refSequences)), "numberOfMappedReads": str(len(mappedReadLengths)),
-               "mappedReadLengths": " ".join(map(str, mappedReadLengths)),
-               "numberOfUnmappedReads": str(len(unmappedReadLengths)),
-               "unmappedReadLengths": " ".join(map(str, unmappedReadLengths))}
-    for fnStringName in ("readCoverage", "referenceCoverage", "identity", "mismatchesPerReadBase", "deletionsPerReadBase",
-                         "insertionsPerReadBase", "readLength"):
-        for prefix, value in zip(("min", "avg", "median", "max", "distribution"), stats(fnStringName)):
-            attribs[prefix + fnStringName] = str(value)
-    parentNode = ET.Element(tagName, attribs)
-    for c in readAlignmentCoverages:
-        parentNode.append(c.getXML())
-    return parentNode
+        attrib["min" + q], attrib["max" + q] = str(ordered[0]), str(ordered[-1])
+        attrib["avg" + q], attrib["median" + q] = str(np.average(ordered)), str(np.median(ordered))
+        attrib["distribution" + q] = " ".join(map(str, values))
+    root = ET.Element(tagName, attrib)
+    for i in chosen:
+        ET.SubElement(root, "readAlignmentCoverage", {
+            "refSeqName": stats.refNames[i], "readSeqName": stats.readNames[i], "readLength": str(columns["readLength"][i]),
+            "readCoverage": str(columns["readCoverage"][i]), "referenceCoverage": str(columns["referenceCoverage"][i]),
+            "identity": str(columns["identity"][i]), "mismatchesPerReadBase": str(columns["mismatchesPerReadBase"][i]),
+            "insertionsPerReadBase": str(columns["insertionsPerReadBase"][i]),
+            "deletionsPerReadBase": str(columns["deletionsPerReadBase"][i])})
+    return root
 
 
 class LocalCoverage(AbstractAnalysis):
-    """Calculates coverage, treating alignments as local alignments (coverage.py:127-160)."""
+    """Coverage with every record taken as a local alignment."""
 
-    def run(self, globalAlignment=False):
+    def run(self, globalAlignment=False, ctx=None):
         AbstractAnalysis.run(self)
-        refSequences = getFastaDictionary(self.referenceFastaFile)
-        readSequences = getFastqDictionary(self.readFastqFile)
-        sam = pysam.Samfile(self.samFile, "r")
-        readsToReadCoverages = {}
-        for aR in samIterator(sam):
-            refName = sam.getrname(aR.rname)
-            counter = ReadAlignmentCoverageCounter(aR.qname, readSequences[aR.qname], refName, refSequences[refName], aR,
-                                                   globalAlignment)
-            readsToReadCoverages.setdefault(aR.qname, []).append(counter)
-        sam.close()
-        if readsToReadCoverages:
-            everything = reduce(lambda x, y: x + y, readsToReadCoverages.values())
-            best = [max(x, key=lambda y: y.readCoverage()) for x in readsToReadCoverages.values()]
-            for readCoverages, outputName in ((everything, "coverage_all"), (best, "coverage_bestPerRead")):
-                parentNode = getAggregateCoverageStats(readCoverages, outputName, refSequences, readSequences,
-                                                       readsToReadCoverages, outputName)
-                with open(os.path.join(self.outputDir, outputName + ".xml"), "w") as fh:
-                    fh.write(prettyXml(parentNode))
-                with open(os.path.join(self.outputDir, outputName + ".txt"), "w") as outf:
-                    outf.write("MappedReadLengths " + parentNode.get("mappedReadLengths") + "\n")
-                    outf.write("UnmappedReadLengths " + parentNode.get("unmappedReadLengths") + "\n")
-                    outf.write("ReadCoverage " + parentNode.get("distributionreadCoverage") + "\n")
-                    outf.write("MismatchesPerReadBase " + parentNode.get("distributionmismatchesPerReadBase") + "\n")
-                    outf.write("ReadIdentity " + parentNode.get("distributionidentity") + "\n")
-                    outf.write("InsertionsPerBase " + parentNode.get("distributioninsertionsPerReadBase") + "\n")
-                    outf.write("DeletionsPerBase " + parentNode.get("distributiondeletionsPerReadBase") + "\n")
+        stats = SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
+        if len(stats):
+            columns = coverageColumns(stats, globalAlignment)
+            # the record with the highest read coverage of every read, reads in order of first appearance (:139)
+            best, order = {}, []
+            for i, name in enumerate(stats.readNames):
+                if name not in best:
+                    best[name] = i
+                    order.append(name)
+                elif columns["readCoverage"][i] > columns["readCoverage"][best[name]]:
+                    best[name] = i
+            # coverage_all lists the records read by read, as the reference's dict of per-read lists does
+            by_read = [i for name in order for i in range(len(stats)) if stats.readNames[i] == name] if len(order) < len(stats) \
+                else list(range(len(stats)))
+            for tag, chosen, perAlignment in (("coverage_all", by_read, True), ("coverage_bestPerRead", [best[k] for k in order], False)):
+                node = aggregateNode(tag, stats, columns, chosen, perAlignment)
+                with open(os.path.join(self.outputDir, tag + ".xml"), "w") as fh:
+                    fh.write(prettyXml(node))
+                with open(os.path.join(self.outputDir, tag + ".txt"), "w") as fh:   # one quantity per line, variable length (:143-151)
+                    for label, key in (("MappedReadLengths", "mappedReadLengths"), ("UnmappedReadLengths", "unmappedReadLengths"),
+                                       ("ReadCoverage", "distributionreadCoverage"),
+                                       ("MismatchesPerReadBase", "distributionmismatchesPerReadBase"),
+                                       ("ReadIdentity", "distributionidentity"), ("InsertionsPerBase", "distributioninsertionsPerReadBase"),
+                                       ("DeletionsPerBase", "distributiondeletionsPerReadBase")):
+                        fh.write("%s %s\n" % (label, node.get(key)))
         self.finish()
 
 
 class GlobalCoverage(LocalCoverage):
-    """Coverage treating alignments as global alignments (coverage.py:162-166)."""
+    """Coverage with every record taken as a global alignment: unaligned ends count as indels."""
 
-    def run(self):
-        LocalCoverage.run(self, globalAlignment=True)
+    def run(self, ctx=None):
+        LocalCoverage.run(self, globalAlignment=True, ctx=ctx)

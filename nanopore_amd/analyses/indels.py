@@ -1,100 +1,67 @@
-"""Indels: read insertion / deletion length statistics per alignment and in aggregate
-(nanopore/analyses/indels.py:9-110)."""
+"""Indels: indels.xml and indels.tsv.
+
+Schema of nanopore/analyses/indels.py: one <indels> element per SAM record (:33-45: names, lengths, number / average /
+median / list of read insertion and deletion lengths) under a root <indels> with the concatenated lists and, per
+aggregate distribution, its sorted values (:47-82 -- the reference's loop leaves only the distribution string under the
+bare name, which is what its TSV writer then reads at :96-107); the TSV is those seven lists side by side, ragged
+columns padded with "None".  Gap lengths come from alignmentStats.SamAlignmentStats (the number of insertions / deletions
+per record is cross-checked against the device table)."""
 import os
 import xml.etree.ElementTree as ET
-from functools import reduce
+from itertools import zip_longest
 
-import numpy
+import numpy as np
 
-from .. import sam as pysam
 from .abstractAnalysis import AbstractAnalysis
+from .alignmentStats import N_DEL, N_INS, SamAlignmentStats
 from .alignmentUncertainty import prettyXml
-from .utils import AlignedPair, getFastaDictionary, getFastqDictionary, samIterator
+
+TSV_COLUMNS = ("readInsertionLengths", "readDeletionLengths", "ReadSequenceLengths", "NumberReadInsertions",
+               "NumberReadDeletions", "MedianReadInsertionLengths", "MedianReadDeletionLengths")
 
 
-def _avg(values):
-    return numpy.average(values) if len(values) else float("nan")
+def _text(values):
+    return " ".join(str(v) for v in values)
 
 
-def _median(values):
-    return numpy.median(values) if len(values) else float("nan")
+def recordNode(stats, i, ins, dels):
+    return ET.Element("indels", {
+        "refSeqName": stats.refNames[i], "refSeqLength": str(int(stats.refLength[i])), "readSeqName": stats.readNames[i],
+        "readSeqLength": str(int(stats.readLength[i])), "numberReadInsertions": str(len(ins)), "numberReadDeletions": str(len(dels)),
+        "avgReadInsertionLength": str(np.average(ins) if ins else float("nan")),
+        "avgReadDeletionLength": str(np.average(dels) if dels else float("nan")),
+        "medianReadInsertionLength": str(np.median(ins) if ins else float("nan")),
+        "medianReadDeletionLength": str(np.median(dels) if dels else float("nan")),
+        "readInsertionLengths": _text(ins), "readDeletionLengths": _text(dels)})
 
 
-class IndelCounter(object):
-    def __init__(self, refSeqName, refSeq, readSeqName, readSeq, alignedRead):
-        self.readInsertionLengths = []
-        self.readDeletionLengths = []
-        self.blockLengths = []
-        self.readSeqName = readSeqName
-        self.readSeq = readSeq
-        self.refSeqName = refSeqName
-        self.refSeq = refSeq
-        blockLength = 0
-        for aP in AlignedPair.iterator(alignedRead, self.refSeq, self.readSeq):
-            ins, dele = aP.getPrecedingReadInsertionLength(), aP.getPrecedingReadDeletionLength()
-            if ins > 0:
-                self.readInsertionLengths.append(ins)
-            if dele > 0:
-                self.readDeletionLengths.append(dele)
-            if ins > 0 or dele > 0:
-                assert blockLength > 0
-                self.blockLengths.append(blockLength)
-                blockLength = 1
-            else:
-                blockLength += 1
-
-    def getXML(self):
-        return ET.Element("indels", {
-            "refSeqName": self.refSeqName, "refSeqLength": str(len(self.refSeq)), "readSeqName": self.readSeqName,
-            "readSeqLength": str(len(self.readSeq)), "numberReadInsertions": str(len(self.readInsertionLengths)),
-            "numberReadDeletions": str(len(self.readDeletionLengths)),
-            "avgReadInsertionLength": str(_avg(self.readInsertionLengths)),
-            "avgReadDeletionLength": str(_avg(self.readDeletionLengths)),
-            "medianReadInsertionLength": str(_median(self.readInsertionLengths)),
-            "medianReadDeletionLength": str(_median(self.readDeletionLengths)),
-            "readInsertionLengths": " ".join(str(i) for i in self.readInsertionLengths),
-            "readDeletionLengths": " ".join(str(i) for i in self.readDeletionLengths)})
-
-
-def getAggregateIndelStats(indelCounters):
-    """Aggregate stats across a set of read alignments (indels.py:47-82).  As in the reference, each of the five
-    per-alignment distributions ends up under its bare name holding the sorted distribution string (the min / avg /
-    median / max values are computed and then overwritten there, indels.py:77-78); indels.tsv is built from these."""
-    readInsertionLengths = reduce(lambda x, y: x + y, [ic.readInsertionLengths for ic in indelCounters])
-    readDeletionLengths = reduce(lambda x, y: x + y, [ic.readDeletionLengths for ic in indelCounters])
-    attribs = {"numberOfReadAlignments": str(len(indelCounters)),
-               "readInsertionLengths": " ".join(map(str, readInsertionLengths)),
-               "readDeletionLengths": " ".join(map(str, readDeletionLengths))}
-    for name, distribution in (("ReadSequenceLengths", [len(ic.readSeq) for ic in indelCounters]),
-                               ("NumberReadInsertions", [len(ic.readInsertionLengths) for ic in indelCounters]),
-                               ("NumberReadDeletions", [len(ic.readDeletionLengths) for ic in indelCounters]),
-                               ("MedianReadInsertionLengths", [_median(ic.readInsertionLengths) for ic in indelCounters]),
-                               ("MedianReadDeletionLengths", [_median(ic.readDeletionLengths) for ic in indelCounters])):
-        attribs[name] = " ".join(map(str, sorted(distribution)))
-    parentNode = ET.Element("indels", attribs)
-    for ic in indelCounters:
-        parentNode.append(ic.getXML())
-    return parentNode
+def getAggregateIndelStats(stats):
+    ins, dels = stats.gapLengths()
+    n = len(stats)
+    assert [len(v) for v in ins] == [int(v) for v in stats.table[:, N_INS]] and [len(v) for v in dels] == [int(v) for v in stats.table[:, N_DEL]]
+    attrib = {"numberOfReadAlignments": str(n), "readInsertionLengths": _text(v for per in ins for v in per),
+              "readDeletionLengths": _text(v for per in dels for v in per)}
+    median = lambda v: float(np.median(v)) if v else float("nan")  # noqa: E731
+    for name, values in (("ReadSequenceLengths", [int(v) for v in stats.readLength]), ("NumberReadInsertions", [len(v) for v in ins]),
+                         ("NumberReadDeletions", [len(v) for v in dels]), ("MedianReadInsertionLengths", [median(v) for v in ins]),
+                         ("MedianReadDeletionLengths", [median(v) for v in dels])):
+        attrib[name] = _text(sorted(values))
+    root = ET.Element("indels", attrib)
+    for i in range(n):
+        root.append(recordNode(stats, i, ins[i], dels[i]))
+    return root
 
 
 class Indels(AbstractAnalysis):
-    def run(self):
+    def run(self, ctx=None):
         AbstractAnalysis.run(self)
-        refSequences = getFastaDictionary(self.referenceFastaFile)
-        readSequences = getFastqDictionary(self.readFastqFile)
-        sam = pysam.Samfile(self.samFile, "r")
-        indelCounters = [IndelCounter(sam.getrname(aR.rname), refSequences[sam.getrname(aR.rname)], aR.qname,
-                                      readSequences[aR.qname], aR) for aR in samIterator(sam)]
-        sam.close()
-        if indelCounters:
-            indelXML = getAggregateIndelStats(indelCounters)
+        stats = SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
+        if len(stats):
+            root = getAggregateIndelStats(stats)
             with open(os.path.join(self.outputDir, "indels.xml"), "w") as fh:
-                fh.write(prettyXml(indelXML))
-            var = ["readInsertionLengths", "readDeletionLengths", "ReadSequenceLengths", "NumberReadInsertions",
-                   "NumberReadDeletions", "MedianReadInsertionLengths", "MedianReadDeletionLengths"]
-            columns = [[x] + indelXML.attrib[x].split() for x in var]
-            depth = max(len(c) for c in columns)
-            with open(os.path.join(self.outputDir, "indels.tsv"), "w") as tmp:
-                for i in range(depth):  # transposed, short columns padded with None like Python 2's map(None, ...)
-                    tmp.write("\t".join(str(c[i]) if i < len(c) else "None" for c in columns) + "\n")
+                fh.write(prettyXml(root))
+            columns = [[name] + root.attrib[name].split() for name in TSV_COLUMNS]
+            with open(os.path.join(self.outputDir, "indels.tsv"), "w") as fh:
+                for row in zip_longest(*columns):
+                    fh.write("\t".join(str(v) for v in row) + "\n")
         self.finish()

@@ -20,7 +20,7 @@ from .. import sam as pysam
 from ..hmm import Hmm
 from .abstractAnalysis import AbstractAnalysis
 from .alignmentUncertainty import prettyXml
-from .utils import (ANALYSIS_SPLIT_MATRIX_BIGGER_THAN, AlignedPair, getFastaDictionary, getFastqDictionary,
+from .utils import (ANALYSIS_SPLIT_MATRIX_BIGGER_THAN, alignedPairs, getFastaDictionary, getFastqDictionary,
                     realignRecords, samIterator, trainedModelPath)
 
 bases = "ACGT"
@@ -136,10 +136,10 @@ class MarginAlignSnpCaller(AbstractAnalysis):
         for aR in records:
             refName = sam.getrname(aR.rname)
             pos, code = [], []
-            for aP in AlignedPair.iterator(aR, refSequences[refName], readSequences[aR.qname]):
-                b = aP.getReadBase().upper()
-                pos.append(aP.refPos)
-                code.append(bases.index(b) if b in bases else -1)
+            query = aR.query.upper()
+            for r, q in alignedPairs(aR, len(refSequences[refName])):
+                pos.append(r)
+                code.append(bases.find(query[q]))
             alignedBases.append((refIndex[refName], np.array(pos, dtype=np.int64), np.array(code, dtype=np.int64)))
         node = ET.Element("marginAlignComparison")
         for hmmType in self.hmmTypes:

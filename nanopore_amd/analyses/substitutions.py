@@ -1,71 +1,64 @@
-"""Substitutions: nucleotide substitution matrix over all aligned pairs (nanopore/analyses/substitutions.py:9-82)."""
+"""Substitutions: substitutions.xml and subst.tsv from the 5 x 5 counts of aligned (reference base, read base).
+
+Schema of nanopore/analyses/substitutions.py:34-50 -- root <substitutions matches mismatches identity>, one child per
+reference base A C G T N with the same three attributes, under it one child per read base with its count -- and the
+row-normalised 4 x 4 table of :66-72.  Counts are floats in the reference (its matrix starts as 0.0), hence "12.0".  The
+counting itself is the device table of alignmentStats.SamAlignmentStats summed over the records."""
 import os
 import xml.etree.ElementTree as ET
 
-from .. import sam as pysam
 from .abstractAnalysis import AbstractAnalysis
+from .alignmentStats import SamAlignmentStats
 from .alignmentUncertainty import prettyXml
-from .utils import AlignedPair, getFastaDictionary, getFastqDictionary, samIterator
+
+_BASES = "ACGTN"
 
 
 class SubstitutionMatrix(object):
-    """Nucleotide substitution counts, with a fifth row / column for wildcards (substitutions.py:9-56)."""
+    """25 counts, reference base major; anything outside ACGT is N."""
 
-    def __init__(self):
-        self.matrix = [0.0] * 25
+    def __init__(self, counts=None):
+        self.matrix = [0.0] * 25 if counts is None else [float(v) for v in counts]
 
     @staticmethod
     def _index(base):
-        base = base.upper()
-        return {"A": 0, "C": 1, "G": 2, "T": 3}.get(base, 4)
+        return "ACGT".find(base.upper()) % 5 if base.upper() in "ACGT" else 4
 
     def addAlignedPair(self, refBase, readBase):
-        self.matrix[self._index(refBase) * 5 + self._index(readBase)] += 1
+        self.matrix[5 * self._index(refBase) + self._index(readBase)] += 1
 
     def getCount(self, refBase, readBase):
-        return self.matrix[self._index(refBase) * 5 + self._index(readBase)]
+        return self.matrix[5 * self._index(refBase) + self._index(readBase)]
 
     def getFreqs(self, refBase, bases):
-        freqs = [self.getCount(refBase, b) for b in bases]
-        if sum(freqs) == 0:
-            return [0.0] * len(freqs)
-        return [x / sum(freqs) for x in freqs]
+        row = [self.getCount(refBase, b) for b in bases]
+        total = sum(row)
+        return [v / total for v in row] if total else [0.0] * len(row)
+
+    def _tally(self, refBases):
+        same = sum(self.getCount(b, b) for b in refBases)
+        other = sum(self.getCount(b, q) for b in refBases for q in "ACGT" if q != b)
+        return same, other, (same / (same + other) if same + other else "NaN")
 
     def getXML(self):
-        def _identity(matches, mismatches):
-            if matches + mismatches == 0:
-                return "NaN"
-            return matches / (mismatches + matches)
-        matches = sum(self.getCount(b, b) for b in "ACTG")
-        mismatches = sum(sum(self.getCount(r, q) for q in "ACTG" if q != r) for r in "ACTG")
-        node = ET.Element("substitutions", {"matches": str(matches), "mismatches": str(mismatches),
-                                            "identity": str(_identity(matches, mismatches))})
-        for refBase in "ACGTN":
-            matches = self.getCount(refBase, refBase)
-            mismatches = sum(self.getCount(refBase, q) for q in "ACTG" if q != refBase)
-            baseNode = ET.SubElement(node, refBase, {"matches": str(matches), "mismatches": str(mismatches),
-                                                     "identity": str(_identity(matches, mismatches))})
-            for readBase in "ACGTN":
-                ET.SubElement(baseNode, readBase, {"count": str(self.getCount(refBase, readBase))})
-        return node
+        root = ET.Element("substitutions", dict(zip(("matches", "mismatches", "identity"), map(str, self._tally("ACGT")))))
+        for refBase in _BASES:
+            node = ET.SubElement(root, refBase, dict(zip(("matches", "mismatches", "identity"), map(str, self._tally(refBase)))))
+            for readBase in _BASES:
+                ET.SubElement(node, readBase, {"count": str(self.getCount(refBase, readBase))})
+        return root
 
 
 class Substitutions(AbstractAnalysis):
-    def run(self, kmer=5):
+    def run(self, kmer=5, ctx=None):
         AbstractAnalysis.run(self)
-        refSequences = getFastaDictionary(self.referenceFastaFile)
-        readSequences = getFastqDictionary(self.readFastqFile)
-        sM = SubstitutionMatrix()
-        sam = pysam.Samfile(self.samFile, "r")
-        for aR in samIterator(sam):
-            for aP in AlignedPair.iterator(aR, refSequences[sam.getrname(aR.rname)], readSequences[aR.qname]):
-                sM.addAlignedPair(aP.getRefBase(), aP.getReadBase())
-        sam.close()
+        stats = SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
+        sM = SubstitutionMatrix(stats.substitutionCounts().reshape(-1))
         with open(os.path.join(self.outputDir, "substitutions.xml"), "w") as fh:
             fh.write(prettyXml(sM.getXML()))
-        with open(os.path.join(self.outputDir, "subst.tsv"), "w") as outf:
-            outf.write("A\tC\tG\tT\n")
-            for x in "ACGT":
-                outf.write("{}\t{}\n".format(x, "\t".join(map(str, sM.getFreqs(x, "ACGT")))))
+        with open(os.path.join(self.outputDir, "subst.tsv"), "w") as fh:
+            fh.write("A\tC\tG\tT\n")
+            for refBase in "ACGT":
+                fh.write("%s\t%s\n" % (refBase, "\t".join(str(f) for f in sM.getFreqs(refBase, "ACGT"))))
         self.finish()
         return sM

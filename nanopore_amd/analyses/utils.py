@@ -65,101 +65,68 @@ def samIterator(sam):
             yield aR
 
 
+def clipLengths(alignedRead):
+    """(bases clipped before, bases clipped after) the aligned part of SEQ: hard + soft clips at either end of the cigar."""
+    cigar = alignedRead.cigar or []
+    lead = trail = 0
+    for op, length in cigar:
+        if op not in (4, 5):
+            break
+        lead += length
+    for op, length in reversed(cigar):
+        if op not in (4, 5):
+            break
+        trail += length
+    return lead, trail
+
+
 def getAbsoluteReadOffset(alignedRead, refSeq, readSeq):
-    """Absolute coordinate in the read of the first non-clipped base; negative for reverse strand
-    (utils.py:157-166)."""
-    readOffset = alignedRead.cigar[0][1] if alignedRead.cigar[0][0] == 5 else 0
-    if alignedRead.is_reverse:
-        readOffset = -(len(readSeq) - 1 - readOffset)
-    return readOffset + alignedRead.qstart
+    """Where the first non-clipped base of the record sits in the FASTQ read (utils.py:157-166): the clipped prefix
+    (hard clip, then qstart for the soft clip) on the forward strand; on the reverse strand SEQ runs backwards through
+    the read, so the offset is counted from the read's last base and comes out non-positive."""
+    hard = alignedRead.cigar[0][1] if alignedRead.cigar and alignedRead.cigar[0][0] == 5 else 0
+    if not alignedRead.is_reverse:
+        return hard + alignedRead.qstart
+    return hard + alignedRead.qstart - (len(readSeq) - 1)
 
 
-class AlignedPair(object):
-    """An aligned pair of positions (utils.py:81-155).  readPos is the absolute position in the read sequence of the
-    FASTQ (for reverse-strand records counted from the other end, as the reference does)."""
+def alignedPairs(alignedRead, refLength=None):
+    """(reference position, position in alignedRead.query) of every aligned pair of a SAM record, in order.  Pairs whose
+    reference position lies beyond the reference are dropped, as the reference drops them (utils.py:145-147: an
+    off-by-one of some mappers)."""
+    out = []
+    for q, r in alignedRead.aligned_pairs:
+        if q is None or r is None:
+            continue
+        if refLength is not None and r >= refLength:
+            continue
+        out.append((r, q))
+    return out
 
-    def __init__(self, refPos, refSeq, readPos, isReversed, readSeq, pPair):
-        assert 0 <= refPos < len(refSeq)
-        assert 0 <= readPos < len(readSeq)
-        self.refPos = refPos
-        self.refSeq = refSeq
-        self.readPos = readPos
-        self.isReversed = isReversed
-        self.readSeq = readSeq
-        self.pPair = pPair  # the previous aligned pair
 
-    def isMatch(self):
-        return self.getRefBase().upper() == self.getReadBase().upper() and self.getRefBase().upper() in "ACTG"
-
-    def isMismatch(self):
-        return (self.getRefBase().upper() != self.getReadBase().upper() and self.getRefBase().upper() in "ACTG"
-                and self.getReadBase().upper() in "ACTG")
-
-    def getRefBase(self):
-        return self.refSeq[self.refPos]
-
-    def getReadBase(self):
-        if self.isReversed:
-            return reverseComplement(self.readSeq[self.readPos])
-        return self.readSeq[self.readPos]
-
-    def getSignedReadPos(self):
-        return -self.readPos if self.isReversed else self.readPos
-
-    def getPrecedingReadInsertionLength(self, globalAlignment=False):
-        if self.pPair is None:
-            if globalAlignment:
-                if self.isReversed:
-                    assert len(self.readSeq) - self.readPos - 1 >= 0
-                    return len(self.readSeq) - self.readPos - 1
-                return self.readPos
-            return 0
-        return self._indelLength(self.readPos, self.pPair.readPos)
-
-    def getPrecedingReadDeletionLength(self, globalAlignment=False):
-        if self.pPair is None:
-            if globalAlignment:
-                return self.refPos
-            return 0
-        return self._indelLength(self.refPos, self.pPair.refPos)
-
-    @staticmethod
-    def _indelLength(pos, pPos):
-        length = abs(pPos - pos) - 1
-        assert length >= 0
-        return length
-
-    @staticmethod
-    def iterator(alignedRead, refSeq, readSeq):
-        """Aligned pairs of a SAM record, checked against the sequences (utils.py:136-155)."""
-        readOffset = getAbsoluteReadOffset(alignedRead, refSeq, readSeq)
-        pPair = None
-        assert len(alignedRead.seq) <= len(readSeq)
-        for readPos, refPos in alignedRead.aligned_pairs:
-            if readPos is not None and refPos is not None:
-                assert alignedRead.pos <= refPos < alignedRead.aend
-                if refPos >= len(refSeq):  # the reference masks an off-by-one of some mappers here (utils.py:145-147)
-                    continue
-                aP = AlignedPair(refPos, refSeq, abs(readOffset + readPos), alignedRead.is_reverse, readSeq, pPair)
-                assert aP.getReadBase().upper() == alignedRead.query[readPos].upper()
-                pPair = aP
-                yield aP
+_EXONERATE_OP = {0: "M", 1: "I", 2: "D"}
 
 
 def getExonerateCigarFormatString(alignedRead, sam):
-    """SAM record -> exonerate cigar line, query (read) first, target (reference) second; only M/I/D survive,
-    clips are dropped; input score is the literal 1 (utils.py:168-180)."""
+    """The line cactus_realign reads on stdin (utils.py:168-180):
+        cigar: <read> 0 <aligned read bases> + <reference> <pos> <aend> + 1 <op len>...
+    read first, reference second, both '+' (a reverse-strand SEQ is already reverse-complemented); clips carry no
+    operation; the score field is the literal 1.  The line is parsed back and its match columns counted against the
+    record's aligned pairs, the check the reference makes at :179."""
+    words = []
+    columns = 0
     for op, length in alignedRead.cigar:
-        assert op in (0, 1, 2, 4, 5)
-    letters = {0: "M", 1: "I", 2: "D"}
-    cigarString = " ".join("%s %i" % (letters[op], length) for op, length in alignedRead.cigar if op in letters)
-    complete = "cigar: %s %i %i + %s %i %i + 1 %s" % (
-        alignedRead.qname, 0, alignedRead.qend - alignedRead.qstart, sam.getrname(alignedRead.rname), alignedRead.pos,
-        alignedRead.aend, cigarString)
-    pA = cigarReadFromString(complete)  # validates the line
-    matches = sum(op.length for op in pA.operationList if op.type == PairwiseAlignment.PAIRWISE_MATCH)
-    assert matches == sum(1 for q, r in alignedRead.aligned_pairs if q is not None and r is not None)
-    return complete
+        if op in (4, 5):
+            continue
+        if op not in _EXONERATE_OP:
+            raise AssertionError("cigar operation %s of %s has no exonerate form" % (op, alignedRead.qname))
+        words.append("%s %i" % (_EXONERATE_OP[op], length))
+        columns += length if op == 0 else 0
+    line = "cigar: %s 0 %i + %s %i %i + 1 %s" % (alignedRead.qname, alignedRead.qend - alignedRead.qstart,
+                                                   sam.getrname(alignedRead.rname), alignedRead.pos, alignedRead.aend, " ".join(words))
+    parsed = cigarReadFromString(line)
+    assert sum(o.length for o in parsed.operationList if o.type == PairwiseAlignment.PAIRWISE_MATCH) == columns == len(alignedPairs(alignedRead))
+    return line
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -169,7 +136,7 @@ def getExonerateCigarFormatString(alignedRead, sam):
 def _blockCoordinates(aR, refSeq, readSeq):
     """(first ref pos, first signed read pos, last ref pos, last signed read pos, #aligned pairs)."""
     offset = getAbsoluteReadOffset(aR, refSeq, readSeq)
-    pairs = [(q, r) for q, r in aR.aligned_pairs if q is not None and r is not None and r < len(refSeq)]
+    pairs = [(q, r) for r, q in alignedPairs(aR, len(refSeq))]
     sign = -1 if aR.is_reverse else 1
     signed = lambda q: sign * abs(offset + q)  # noqa: E731
     return pairs[0][1], signed(pairs[0][0]), pairs[-1][1], signed(pairs[-1][0]), len(pairs)

@@ -65,6 +65,9 @@ struct npr_ctx {
     void *pin_pairs = nullptr;
     size_t pin_pairs_bytes = 0;
     MeaScratch *mea = nullptr;
+    // bumped whenever the scratch a finished batch left its device-side cigars in may be overwritten (a DP launch, a
+    // device MEA stage): npr_batch_align_stats uses the resident cigars only while the batch's stamp is current
+    uint64_t scratch_epoch = 1;
 };
 
 namespace {
@@ -249,6 +252,10 @@ struct npr_batch {
     std::vector<Pair> pairs;             // filled by fetch_pairs(): at finish in the host modes, on demand after the device MEA
     bool pairs_ready = false;
     std::vector<int64_t> task_dst;       // prefix of the per-task pair counts
+    // packed cigars left on the device by the device MEA stage (valid while dev_ops_epoch == ctx->scratch_epoch)
+    const uint32_t *dev_ops = nullptr;
+    const int64_t *dev_od = nullptr;
+    uint64_t dev_ops_epoch = 0;
 };
 
 extern "C" {
@@ -929,6 +936,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     if (!b) return NPR_ERR_INVALID;
     npr_ctx *ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ++ctx->scratch_epoch;
     if (kernel_ms) *kernel_ms = 0.f;
     if (b->tasks.empty()) {
         b->ran = true;
@@ -1093,6 +1101,7 @@ int32_t fetch_pairs(npr_batch *b) {
 // needs the host stage instead (a chain reaching back further than the prefix-maximum ring), NPR_OK or an error.
 int32_t device_mea(npr_batch *b) {
     npr_ctx *ctx = b->ctx;
+    ++ctx->scratch_epoch;
     StageTimer tm("device_mea");
     const int64_t n = b->n_reads, ntasks = static_cast<int64_t>(b->tasks.size());
     std::vector<int64_t> rx(n + 1, 0), ry(n + 1, 0), rp(n + 1, 0), ot(n + 1, 0), od(n + 1, 0);
@@ -1222,6 +1231,7 @@ int32_t device_mea(npr_batch *b) {
         });
     }
     tm.lap("gather + D2H of the ops");
+    if (od[n]) b->dev_ops = m.dense.p, b->dev_od = m.od.p, b->dev_ops_epoch = ctx->scratch_epoch;
     return NPR_OK;
 }
 
@@ -1384,6 +1394,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     if (!b || !T_exp || !E_exp || !loglik) return NPR_ERR_INVALID;
     npr_ctx *ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ++ctx->scratch_epoch;
     std::fill(T_exp, T_exp + NPR_MAX_MODELS * 25, 0.0);
     std::fill(E_exp, E_exp + NPR_MAX_MODELS * 80, 0.0);
     std::fill(loglik, loglik + NPR_MAX_MODELS, 0.0);
@@ -1502,6 +1513,133 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     }
     b->ran = false;  // the task outputs now belong to the E-step
     return NPR_OK;
+}
+
+namespace {
+
+// the kernel over n reads whose cigars are either packed on the device already (d_ops / d_off) or given on the host
+int32_t run_align_stats(npr_ctx *ctx, int64_t n, const uint32_t *d_ops, const int64_t *d_off, const std::vector<uint32_t> *h_ops,
+                        const std::vector<int64_t> *h_off, const std::vector<int32_t> &seg_off, const std::vector<StatsSeg> &segs,
+                        const uint8_t *d_seq, int32_t *stats) {
+    if (n >= (int64_t(1) << 31)) return fail(ctx, NPR_ERR_INVALID, "npr_align_stats: too many reads");
+    DevBuf<uint32_t> ops;
+    DevBuf<int64_t> off;
+    DevBuf<int32_t> so, out;
+    DevBuf<StatsSeg> sg;
+    hipError_t e;
+    if (!d_ops) {
+        if ((e = ops.alloc(h_ops->size())) != hipSuccess || (e = off.alloc(h_off->size())) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_align_stats: hipMalloc", e);
+        if (!h_ops->empty()) HIP_TRY(ctx, hipMemcpyAsync(ops.p, h_ops->data(), ops.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(off.p, h_off->data(), off.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        d_ops = ops.p, d_off = off.p;
+    }
+    if ((e = so.alloc(seg_off.size())) != hipSuccess || (e = sg.alloc(segs.size())) != hipSuccess ||
+        (e = out.alloc(static_cast<size_t>(n) * NPR_STATS_WORDS)) != hipSuccess)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_align_stats: hipMalloc", e);
+    HIP_TRY(ctx, hipMemcpyAsync(so.p, seg_off.data(), so.bytes(), hipMemcpyHostToDevice, ctx->stream));
+    if (!segs.empty()) HIP_TRY(ctx, hipMemcpyAsync(sg.p, segs.data(), sg.bytes(), hipMemcpyHostToDevice, ctx->stream));
+    StatsArgs a{static_cast<int32_t>(n), d_off, d_ops, so.p, sg.p, d_seq, out.p};
+    const int rc = launch_align_stats(a, ctx->stream);
+    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_align_stats launch", static_cast<hipError_t>(rc));
+    HIP_TRY(ctx, hipMemcpyAsync(stats, out.p, out.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return NPR_OK;
+}
+
+}  // namespace
+
+int32_t npr_batch_align_stats(npr_batch *b, int32_t *stats) {
+    if (!b || (!stats && b->n_reads)) return NPR_ERR_INVALID;
+    if (!b->finished) return NPR_ERR_STATE;
+    npr_ctx *ctx = b->ctx;
+    try {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const int64_t n = b->n_reads;
+        if (n == 0) return NPR_OK;
+        // the pieces of every read's window whose base codes the batch holds: its tasks' segments
+        std::vector<int32_t> seg_off(n + 1, 0);
+        for (int64_t i = 0; i < n; ++i) seg_off[i + 1] = seg_off[i] + b->read_ntasks[i];
+        std::vector<StatsSeg> segs(seg_off[n]);
+        for (int64_t i = 0; i < n; ++i)
+            for (int32_t s = 0; s < b->read_ntasks[i]; ++s) {
+                const Task &t = b->tasks[b->task_of[b->read_first_task[i] + s]];
+                segs[seg_off[i] + s] = StatsSeg{t.xs, t.xs + t.lX, t.ys, t.ys + t.lY, t.x_off, t.y_off};
+            }
+        int32_t rc;
+        if (b->dev_ops && b->dev_ops_epoch == ctx->scratch_epoch) {
+            rc = run_align_stats(ctx, n, b->dev_ops, b->dev_od, nullptr, nullptr, seg_off, segs, b->d_seq.p, stats);
+        } else {
+            std::vector<uint32_t> packed(b->ops_off[n]);
+            for (int64_t q = 0; q < b->ops_off[n]; ++q)
+                packed[q] = static_cast<uint32_t>(b->ops[2 * q + 1]) << 2 | static_cast<uint32_t>(b->ops[2 * q]);
+            rc = run_align_stats(ctx, n, nullptr, nullptr, &packed, &b->ops_off, seg_off, segs, b->d_seq.p, stats);
+        }
+        if (rc != NPR_OK) return rc;
+        for (int64_t i = 0; i < n; ++i)
+            if (b->results[i].status != NPR_OK) std::fill(stats + i * NPR_STATS_WORDS, stats + (i + 1) * NPR_STATS_WORDS, 0), stats[i * NPR_STATS_WORDS + 14] = b->results[i].status;
+        return NPR_OK;
+    } catch (const std::exception &) {
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_align_stats: out of host memory");
+    }
+}
+
+int32_t npr_align_stats(npr_ctx *ctx, int64_t n, int64_t n_refs, const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                        const uint8_t *read, const int64_t *read_off, const int32_t *ops, const int64_t *ops_off, const int64_t *start,
+                        int32_t *stats) {
+    if (!ctx || n < 0 || n_refs < 0 || (n && (!ref_off || !read_off || !ops_off || !stats))) return NPR_ERR_INVALID;
+    if (!ref_index && n_refs != n) return fail(ctx, NPR_ERR_INVALID, "npr_align_stats: without ref_index, n_refs must equal n_reads");
+    if (n == 0) return NPR_OK;
+    try {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        // every read's window (the reference / read bases its cigar consumes) encoded into one code buffer
+        std::vector<int64_t> woff(n + 1, 0), off(ops_off, ops_off + n + 1);
+        std::vector<int32_t> seg_off(n + 1), bad(n, 0);
+        std::vector<StatsSeg> segs(n);
+        std::vector<int64_t> cx(n), cy(n);
+        parallel_for(n, ctx->host_threads, [&](int64_t i) {
+            int64_t x = 0, y = 0;
+            for (int64_t q = ops_off[i]; q < ops_off[i + 1]; ++q) {
+                const int32_t op = ops[2 * q], len = ops[2 * q + 1];
+                if (op < 0 || op > 2 || len < 0) bad[i] = 1;
+                if (op != NPR_OP_I) x += len;
+                if (op != NPR_OP_D) y += len;
+            }
+            const int64_t k = ref_index ? ref_index[i] : i;
+            const int64_t sx = start ? start[2 * i] : 0, sy = start ? start[2 * i + 1] : 0;
+            if (k < 0 || k >= n_refs || sx < 0 || sy < 0 || sx + x > ref_off[k + 1] - ref_off[k] || sy + y > read_off[i + 1] - read_off[i] ||
+                x >= (int64_t(1) << 30) || y >= (int64_t(1) << 30))
+                bad[i] = 1;
+            cx[i] = bad[i] ? 0 : x, cy[i] = bad[i] ? 0 : y;
+        });
+        for (int64_t i = 0; i < n; ++i) woff[i + 1] = woff[i] + cx[i] + cy[i], seg_off[i] = static_cast<int32_t>(i);
+        seg_off[n] = static_cast<int32_t>(n);
+        const std::unique_ptr<uint8_t[]> codes(new uint8_t[woff[n] + 1]);
+        std::vector<uint32_t> packed(ops_off[n]);
+        parallel_for(n, ctx->host_threads, [&](int64_t i) {
+            const int64_t k = ref_index ? ref_index[i] : i;
+            const int64_t sx = start ? start[2 * i] : 0, sy = start ? start[2 * i + 1] : 0;
+            uint8_t *w = codes.get() + woff[i];
+            if (!bad[i]) {
+                const uint8_t *xs = ref + ref_off[k] + sx, *ys = read + read_off[i] + sy;
+                for (int64_t q = 0; q < cx[i]; ++q) w[q] = encode_base(xs[q]);
+                for (int64_t q = 0; q < cy[i]; ++q) w[cx[i] + q] = encode_base(ys[q]);
+            }
+            segs[i] = StatsSeg{0, static_cast<int32_t>(cx[i]), 0, static_cast<int32_t>(cy[i]), woff[i], woff[i] + cx[i]};
+            for (int64_t q = ops_off[i]; q < ops_off[i + 1]; ++q)
+                packed[q] = bad[i] ? 0u : (static_cast<uint32_t>(ops[2 * q + 1]) << 2 | static_cast<uint32_t>(ops[2 * q]));
+        });
+        DevBuf<uint8_t> d_codes;
+        if (d_codes.alloc(woff[n] + 1) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_align_stats: hipMalloc");
+        HIP_TRY(ctx, hipMemcpyAsync(d_codes.p, codes.get(), woff[n] + 1, hipMemcpyHostToDevice, ctx->stream));
+        const int32_t rc = run_align_stats(ctx, n, nullptr, nullptr, &packed, &off, seg_off, segs, d_codes.p, stats);
+        if (rc != NPR_OK) return rc;
+        for (int64_t i = 0; i < n; ++i)
+            if (bad[i]) std::fill(stats + i * NPR_STATS_WORDS, stats + (i + 1) * NPR_STATS_WORDS, 0), stats[i * NPR_STATS_WORDS + 14] = NPR_ERR_INVALID;
+        return NPR_OK;
+    } catch (const std::exception &) {
+        return fail(ctx, NPR_ERR_NOMEM, "npr_align_stats: out of host memory");
+    }
 }
 
 int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, float *Bm_v, int32_t *Bm_e, int64_t cap) {

@@ -132,6 +132,21 @@ struct MeaArgs {
 int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream);
 size_t tile_lds_bytes(int nw);
 int64_t tile_scratch_cells(int64_t rows, int R);  // forward scratch (8-byte cells) of a task with that many stripe rows
+// k_align_stats (npr_stats.hip): per-read reductions over aligned pairs
+struct StatsSeg {  // a piece of a read's window whose base codes lie in `seq`: reference [xs, xe) at x_off, read [ys, ye) at y_off
+    int32_t xs, xe, ys, ye;
+    int64_t x_off, y_off;
+};
+struct StatsArgs {
+    int32_t n_reads;
+    const int64_t *ops_off;  // [n_reads + 1]
+    const uint32_t *ops;     // one word per cigar op: length << 2 | op
+    const int32_t *seg_off;  // [n_reads + 1]
+    const StatsSeg *segs;
+    const uint8_t *seq;      // base codes 0..4
+    int32_t *out;            // [n_reads][NPR_STATS_WORDS]
+};
+int launch_align_stats(const StatsArgs &a, void *stream);
 size_t mea_chain_lds_bytes(int ring);
 int launch_mea_sort(const MeaArgs &a, void *stream);
 int launch_mea_chain(const MeaArgs &a, void *stream);

@@ -1,0 +1,133 @@
+// npr_stats.hip -- k_align_stats: the per-read integer reductions of the reference's post-alignment analyses, on the
+// device, from alignments that already lie there.
+//
+// nanopore/analyses/coverage.py:10-95 (ReadAlignmentCoverageCounter: matches, mismatches, aligned pairs against N, number
+// and total length of read insertions / deletions, with the leading / trailing indels a global alignment adds),
+// substitutions.py:9-56 (5 x 5 substitution counts over aligned pairs) and indels.py:9-45 (insertion / deletion counts)
+// walk every aligned pair of every SAM record in Python.  All of it is integer work over (cigar, reference bases, read
+// bases): one wavefront per read walks the run-length cigar 64 ops at a time -- lanes scan the op extents into start
+// coordinates, the M columns of the chunk are dealt out evenly over the lanes (a binary search in the chunk's prefix sums),
+// each lane compares its column's two bases, ballots count matches / mismatches, 25 LDS counters take the substitution
+// matrix -- while the gaps between aligned pairs are classified in a scalar loop over the chunk's ops.
+// Input is what npr_batch_finish leaves on the device (packed ops from k_mea_gather, base codes of the tasks' segments)
+// or, for any other SAM file, the same uploaded by npr_align_stats.  Counts are exact integers: the tests compare them
+// with an independent CPU counter.
+#include <hip/hip_runtime.h>
+
+#include "npr_device.h"
+
+namespace npr {
+namespace {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const int o = __shfl_up(s, d, WAVE);
+        if (lane >= d) s += o;
+    }
+    total = __shfl(s, WAVE - 1, WAVE);
+    return s - v;
+}
+
+__global__ void __launch_bounds__(WAVE) k_align_stats(StatsArgs a) {
+    __shared__ int sx[WAVE], sy[WAVE], sm[WAVE + 1];
+    __shared__ int sub[25];
+    const int lane = threadIdx.x;
+    for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+        const int64_t o0 = a.ops_off[r];
+        const int nops = static_cast<int>(a.ops_off[r + 1] - o0);
+        const int nseg = a.seg_off[r + 1] - a.seg_off[r];
+        if (lane < 25) sub[lane] = 0;
+        const StatsSeg *segs = a.segs + a.seg_off[r];
+        __syncthreads();
+        int x = 0, y = 0;                    // window coordinates of the next op
+        int matches = 0, mismatches = 0, ns = 0, pairs = 0;
+        int seen_m = 0, pend_i = 0, pend_d = 0;  // gap since the last aligned pair
+        int n_ins = 0, ins_len = 0, n_del = 0, del_len = 0, lead_i = 0, lead_d = 0;
+        for (int base = 0; base < nops; base += WAVE) {
+            const int cnt = min(WAVE, nops - base);
+            const uint32_t w = lane < cnt ? a.ops[o0 + base + lane] : 0u;
+            const int op = static_cast<int>(w & 3u), len = static_cast<int>(w >> 2);
+            int tx, ty, tm;
+            const int ex = wave_excl_scan(op != NPR_OP_I ? len : 0, lane, tx);
+            const int ey = wave_excl_scan(op != NPR_OP_D ? len : 0, lane, ty);
+            const int em = wave_excl_scan(op == NPR_OP_M ? len : 0, lane, tm);
+            sx[lane] = x + ex, sy[lane] = y + ey, sm[lane] = em;
+            if (lane == 0) sm[WAVE] = tm;
+            // gaps between aligned pairs: scalar walk over the chunk's ops
+            for (int i = 0; i < cnt; ++i) {
+                const uint32_t wi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), i));
+                const int oi = static_cast<int>(wi & 3u), li = static_cast<int>(wi >> 2);
+                if (li == 0) continue;
+                if (oi == NPR_OP_M) {
+                    if (seen_m) {
+                        n_ins += pend_i > 0, ins_len += pend_i, n_del += pend_d > 0, del_len += pend_d;
+                    } else {
+                        lead_i = pend_i, lead_d = pend_d;
+                    }
+                    seen_m = 1, pend_i = 0, pend_d = 0;
+                } else if (oi == NPR_OP_I) {
+                    pend_i += li;
+                } else {
+                    pend_d += li;
+                }
+            }
+            __syncthreads();
+            // the chunk's M columns, dealt out over the lanes
+            for (int t = 0; t < tm; t += WAVE) {
+                const int c = t + lane;
+                int hit = 0, rb = 4, qb = 4;
+                if (c < tm) {
+                    int lo = 0, hi = cnt - 1;  // last op whose exclusive M prefix is <= c
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (sm[mid] <= c) lo = mid; else hi = mid - 1;
+                    }
+                    const int xx = sx[lo] + (c - sm[lo]), yy = sy[lo] + (c - sm[lo]);
+                    for (int s = 0; s < nseg; ++s) {
+                        const StatsSeg &g = segs[s];
+                        if (xx >= g.xs && xx < g.xe && yy >= g.ys && yy < g.ye) {
+                            rb = a.seq[g.x_off + (xx - g.xs)];
+                            qb = a.seq[g.y_off + (yy - g.ys)];
+                            hit = 1;
+                            break;
+                        }
+                    }
+                    if (!hit) rb = qb = 4;  // an aligned pair outside every uploaded piece counts against N
+                    atomicAdd(&sub[min(rb, 4) * 5 + min(qb, 4)], 1);
+                }
+                const bool in = c < tm;
+                matches += __popcll(__ballot(in && rb < 4 && rb == qb));
+                mismatches += __popcll(__ballot(in && rb < 4 && qb < 4 && rb != qb));
+                pairs += __popcll(__ballot(in));
+            }
+            x += tx, y += ty;
+            __syncthreads();
+        }
+        ns = pairs - matches - mismatches;
+        int32_t *out = a.out + static_cast<int64_t>(r) * NPR_STATS_WORDS;
+        if (lane == 0) {
+            out[0] = matches, out[1] = mismatches, out[2] = ns, out[3] = pairs;
+            out[4] = n_ins, out[5] = ins_len, out[6] = n_del, out[7] = del_len;
+            out[8] = seen_m ? lead_i : pend_i, out[9] = seen_m ? lead_d : pend_d;   // before the first aligned pair
+            out[10] = seen_m ? pend_i : 0, out[11] = seen_m ? pend_d : 0;           // after the last one
+            out[12] = x, out[13] = y;                                               // reference / read bases the cigar consumes
+            out[14] = 0;
+        }
+        if (lane < 25) out[15 + lane] = sub[lane];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int launch_align_stats(const StatsArgs &a, void *stream) {
+    const int grid = a.n_reads < 16384 ? (a.n_reads > 0 ? a.n_reads : 1) : 16384;
+    hipLaunchKernelGGL(k_align_stats, dim3(grid), dim3(WAVE), 0, static_cast<hipStream_t>(stream), a);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace npr

@@ -125,6 +125,15 @@ class Batch(object):
             raise NprError(rc, "npr_batch_pairs")
         return off, x, y, p
 
+    def align_stats(self):
+        """Per-read reductions over the aligned pairs of the cigars finish() produced, computed where they lie
+        (include/nprealign.h: npr_batch_align_stats): int32 array [n_reads, STATS_WORDS]."""
+        out = np.zeros((self.n_reads, _lib.STATS_WORDS), dtype=np.int32)
+        rc = self._L.npr_batch_align_stats(self._h, ptr(out))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_align_stats", self.ctx.last_error())
+        return out
+
     def expectations(self):
         """Baum-Welch E-step with the installed models: (T_exp[slots,25], E_exp[slots,80], loglik[slots], kernel ms)."""
         T = np.zeros((_lib.MAX_MODELS, 25))
@@ -213,6 +222,23 @@ class Context(object):
         ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
         gs = None if guide_start is None else np.ascontiguousarray(guide_start, dtype=np.int64).reshape(-1, 2)
         return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms, ri, gs)
+
+    def align_stats(self, refs, reads, cigars, ref_index=None, start=None):
+        """Per-read reductions over the aligned pairs of arbitrary alignments (a mapper's SAM records) on the device
+        (include/nprealign.h: npr_align_stats).  refs / reads: ASCII sequences; cigars: [(op, len)] lists with ops M/I/D
+        (0/1/2); start[i] = (first reference position, first read position) of cigar i.  int32 [n, STATS_WORDS]."""
+        ref, ref_off = _csr(refs)
+        read, read_off = _csr(reads)
+        ops, ops_off = _csr_ops(cigars)
+        n = len(read_off) - 1
+        ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.int64).reshape(-1, 2)
+        out = np.zeros((n, _lib.STATS_WORDS), dtype=np.int32)
+        rc = self._L.npr_align_stats(self._h, n, len(ref_off) - 1, ptr(ref), ptr(ref_off), ptr(ri), ptr(read), ptr(read_off),
+                                     ptr(ops), ptr(ops_off), ptr(st), ptr(out))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_align_stats", self.last_error())
+        return out
 
     def _realign_once(self, params, refs, reads, guides, model_slot, want_pairs, ref_index, guide_start=None):
         b = self.stage(params, refs, reads, guides, model_slot, ref_index, guide_start)
