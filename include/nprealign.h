@@ -225,6 +225,11 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
 int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, float *Bm_v,
                         int32_t *Bm_e, int64_t cap);
 
+/* Test aid: npr_batch_create expands band rows, frame schedules, stripe tables and row offsets on the device; this
+ * recomputes every task of the batch with the host planner (the npr_plan_* functions below, the ones the tests pin
+ * against the oracle) and compares entry by entry.  Returns the number of tasks that differ (0 = identical) or NPR_ERR_*. */
+int64_t npr_batch_plan_check(npr_batch *b);
+
 /* One call = create + run + finish + copy-out + destroy, for callers that do not need staging. */
 int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
                           const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,

@@ -23,6 +23,7 @@
 
 #include "npr_device.h"
 #include "npr_internal.h"
+#include "npr_sched.h"
 
 using namespace npr;
 
@@ -64,6 +65,9 @@ struct npr_ctx {
     // the D2H rate and the copy is a GB per batch
     void *pin_pairs = nullptr;
     size_t pin_pairs_bytes = 0;
+    // pinned host staging of npr_batch_create (plan points + sequence windows), grow-only
+    void *pin_stage = nullptr;
+    size_t pin_stage_bytes = 0;
     MeaScratch *mea = nullptr;
     // bumped whenever the scratch a finished batch left its device-side cigars in may be overwritten (a DP launch, a
     // device MEA stage): npr_batch_align_stats uses the resident cigars only while the batch's stamp is current
@@ -224,6 +228,7 @@ struct npr_batch {
     DevBuf<uint32_t> d_coff;
     DevBuf<uint32_t> d_ctl;  // register-kernel tasks: frame schedule, two words per anti-diagonal
     DevBuf<Stripe> d_stripes;  // k_dp_tile tasks: stripe tables
+    DevBuf<PlanSeg> d_pseg;    // the segments as the device planner sees them (read order)
     DevBuf<int64_t> d_region;  // k_dp_tile: first scratch cell of each resident workgroup
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     DevBuf<int32_t> d_px, d_py;
@@ -352,6 +357,7 @@ void npr_destroy(npr_ctx *ctx) {
     if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
     if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
     if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
+    if (ctx->pin_stage) (void)hipHostFree(ctx->pin_stage);
     delete ctx->mea;
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -399,37 +405,8 @@ int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double 
 namespace {
 
 bool build_stair_schedule(const Segment &s, int R, int NW, uint32_t *ctl, int64_t *cells) {
-    const int64_t C = 64 * R * NW, D = s.D(), span = 2 * (C - 1);
-    if (s.n.empty() || s.n[0] != 1 || s.max_width >= C) return false;
-    const int64_t j0 = (C - 1) / 2;
-    int64_t flo = s.lo[0] - 2 * j0;  // x-y of slot 0
-    uint64_t off = 0;
-    for (int64_t d = 0; d <= D; ++d) {
-        const int64_t lo = s.lo[d], n = s.n[d], hi = lo + 2 * (n - 1);
-        if (n < 1) return false;
-        int reb = 0;
-        if (d > 0) {
-            if (d & 1) {  // X-step; the next one is a Y-step
-                const int64_t f = flo + 1;
-                if (hi > f + span || (d < D && s.lo[d + 1] + 2 * (int64_t(s.n[d + 1]) - 1) > f - 1 + span)) reb = 1;
-                flo = f + 2 * reb;
-            } else {
-                const int64_t f = flo - 1;
-                if (lo < f || (d < D && s.lo[d + 1] < f + 1)) reb = -1;
-                flo = f + 2 * reb;
-            }
-            if (lo < flo || hi > flo + span) return false;
-        }
-        const int64_t jlo = (lo - flo) / 2;
-        const int64_t l0 = jlo / R, l1 = (jlo + n + R - 1) / R;
-        if (ctl) {
-            ctl[2 * d] = static_cast<uint32_t>(off);
-            ctl[2 * d + 1] = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26);
-        }
-        off += static_cast<uint64_t>(R * (l1 - l0));
-    }
-    if (cells) *cells = static_cast<int64_t>(off);
-    return off < (uint64_t(1) << 32);
+    if (s.n.empty()) return false;
+    return stair_schedule(s.lo.data(), s.n.data(), s.D(), s.max_width, R, NW, ctl, cells);
 }
 
 }  // namespace
@@ -454,34 +431,15 @@ inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE; }
 // columns; per stripe the first / last anti-diagonal on which the band has cells in it and the index of its first row in
 // the task's scratch (one row per anti-diagonal of a stripe).  out[0] is the header {stripes, rows}.
 void build_stripes(const Segment &s, int R, Stripe *out, int64_t *rows_out) {
-    const int64_t K = 64 * R, lX = s.xe - s.xs, D = s.D();
-    const int64_t S = lX / K + 1;
-    thread_local std::vector<int32_t> df, dl;
-    df.assign(S, 1), dl.assign(S, 0);
-    for (int64_t d = 0; d <= D; ++d) {
-        if (s.n[d] < 1) continue;
-        const int64_t xlo = (d + s.lo[d]) >> 1, xhi = xlo + s.n[d] - 1;
-        for (int64_t k = std::max<int64_t>(xlo / K, 0); k <= std::min(xhi / K, S - 1); ++k) {
-            if (dl[k] < df[k]) df[k] = static_cast<int32_t>(d);
-            dl[k] = static_cast<int32_t>(d);
-        }
-    }
-    int64_t rows = 0;
-    for (int64_t k = 0; k < S; ++k) {
-        if (out) {
-            Stripe &st = out[1 + k];
-            st = Stripe{};
-            st.X = static_cast<int32_t>(k * K);
-            st.K = static_cast<int32_t>(K);
-            st.df = df[k], st.dl = dl[k];
-            st.row0 = static_cast<uint32_t>(rows);
-        }
-        if (dl[k] >= df[k]) rows += dl[k] - df[k] + 1;
-    }
+    const int64_t S = (s.xe - s.xs) / (64 * R) + 1;
+    int64_t rows;
     if (out) {
-        out[0] = Stripe{};
-        out[0].X = static_cast<int32_t>(S);
-        out[0].K = static_cast<int32_t>(rows);
+        rows = stripe_ranges(s.lo.data(), s.n.data(), s.D(), s.xe - s.xs, R, &out[1].df, &out[1].dl, static_cast<int>(sizeof(Stripe) / sizeof(int32_t)));
+        stripe_fill(out, s.xe - s.xs, R);
+    } else {
+        thread_local std::vector<int32_t> df, dl;
+        df.resize(S), dl.resize(S);
+        rows = stripe_ranges(s.lo.data(), s.n.data(), s.D(), s.xe - s.xs, R, df.data(), dl.data(), 1);
     }
     if (rows_out) *rows_out = rows;
 }
@@ -498,6 +456,20 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
                          const int64_t *guide_off, const int32_t *model_slot, npr_batch **out) {
     return npr_batch_create_at(ctx, params, n_reads, n_refs, ref, ref_off, ref_index, read, read_off, guide_ops, guide_off,
                                nullptr, model_slot, out);
+}
+
+// Row offsets of the generic kernel (rows padded to 4 cells), made on the device from the band rows the first time a
+// generic launch needs them: batches whose tasks all go to the register kernels never pay for them.
+static int32_t ensure_coff(npr_batch *b) {
+    npr_ctx *ctx = b->ctx;
+    if (b->d_coff.p || b->d_lo.count == 0) return NPR_OK;
+    const hipError_t e = b->d_coff.alloc(b->d_lo.count);
+    if (e != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "generic row offsets: hipMalloc", e);
+    CoffArgs ca{static_cast<int32_t>(b->d_pseg.count), b->d_pseg.p, b->d_n.p, b->d_coff.p};
+    const int rc = launch_plan_coff(ca, ctx->stream);
+    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_plan_coff launch", static_cast<hipError_t>(rc));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return NPR_OK;
 }
 
 static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
@@ -546,212 +518,285 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     if (n_reads) b->guide_ops.assign(guide_ops, guide_ops + 2 * guide_off[n_reads]);
 
     StageTimer tm("batch_create");
-    // 1. plan every read (host threads; the analogue of the reference's one-job-per-read fan-out)
-    std::vector<Plan> plans(n_reads);
-    parallel_for(n_reads, ctx->host_threads, [&](int64_t i) {
-        const int64_t k = ref_of(i);
-        if (k < 0 || k >= n_refs) {
-            b->ref_len[i] = b->read_len[i] = 0;
-            b->read_status[i] = NPR_ERR_INVALID;
-            return;
-        }
-        int64_t lX = ref_off[k + 1] - ref_off[k], lY = read_off[i + 1] - read_off[i];
-        int32_t rc = NPR_OK;
-        if (guide_start) {  // the window the guide covers
-            const int64_t gx = guide_start[2 * i], gy = guide_start[2 * i + 1];
-            int64_t sx = 0, sy = 0;
-            for (int64_t q = guide_off[i]; q < guide_off[i + 1]; ++q) {
-                const int32_t op = guide_ops[2 * q], len = guide_ops[2 * q + 1];
-                if (len < 0) rc = NPR_ERR_INVALID;
-                if (op == NPR_OP_M || op == NPR_OP_D) sx += len;
-                if (op == NPR_OP_M || op == NPR_OP_I) sy += len;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ++ctx->scratch_epoch;
+    hipError_t e;
+    // 1. Host, O(cigar operations) per read: the guide's window, validation, matrix splits and the plan points of every
+    // segment (npr_host.cpp plan_points).  Worker threads take chunks of reads and append to their chunk's plan.
+    constexpr int64_t kChunk = 32;
+    const int64_t nchunks = (n_reads + kChunk - 1) / kChunk;
+    std::vector<PointPlan> chunk_plan(nchunks);
+    parallel_for(nchunks, ctx->host_threads, [&](int64_t c) {
+        PointPlan &pp = chunk_plan[c];
+        for (int64_t i = c * kChunk, hi = std::min(n_reads, (c + 1) * kChunk); i < hi; ++i) {
+            const int64_t k = ref_of(i);
+            if (k < 0 || k >= n_refs) {
+                b->ref_len[i] = b->read_len[i] = 0;
+                b->read_status[i] = NPR_ERR_INVALID;
+                continue;
             }
-            if (gx < 0 || gy < 0 || gx + sx > lX || gy + sy > lY) rc = NPR_ERR_INVALID;
-            b->gstart[2 * i] = gx, b->gstart[2 * i + 1] = gy;
-            lX = sx, lY = sy;
+            int64_t lX = ref_off[k + 1] - ref_off[k], lY = read_off[i + 1] - read_off[i];
+            int32_t rc = NPR_OK;
+            if (guide_start) {  // the window the guide covers
+                const int64_t gx = guide_start[2 * i], gy = guide_start[2 * i + 1];
+                int64_t sx = 0, sy = 0;
+                for (int64_t q = guide_off[i]; q < guide_off[i + 1]; ++q) {
+                    const int32_t op = guide_ops[2 * q], len = guide_ops[2 * q + 1];
+                    if (len < 0) rc = NPR_ERR_INVALID;
+                    if (op == NPR_OP_M || op == NPR_OP_D) sx += len;
+                    if (op == NPR_OP_M || op == NPR_OP_I) sy += len;
+                }
+                if (gx < 0 || gy < 0 || gx + sx > lX || gy + sy > lY) rc = NPR_ERR_INVALID;
+                b->gstart[2 * i] = gx, b->gstart[2 * i + 1] = gy;
+                lX = sx, lY = sy;
+            }
+            b->ref_len[i] = lX;
+            b->read_len[i] = lY;
+            const int32_t slot = model_slot ? model_slot[i] : 0;
+            if (slot < 0 || slot >= NPR_MAX_MODELS || !ctx->model_set[slot]) rc = NPR_ERR_MODEL;
+            const size_t seg0 = pp.segs.size(), pt0 = pp.points.size();
+            if (rc == NPR_OK) rc = plan_points(b->params, lX, lY, guide_ops + 2 * guide_off[i], guide_off[i + 1] - guide_off[i], pp);
+            if (rc != NPR_OK) {
+                pp.segs.resize(seg0), pp.points.resize(pt0);
+                b->ref_len[i] = b->read_len[i] = 0;
+            }
+            for (size_t q = seg0; q < pp.segs.size(); ++q) pp.segs[q].owner = i;
+            b->read_ntasks[i] = static_cast<int32_t>(pp.segs.size() - seg0);
+            b->read_status[i] = rc;
         }
-        b->ref_len[i] = lX;
-        b->read_len[i] = lY;
-        const int32_t slot = model_slot ? model_slot[i] : 0;
-        if (slot < 0 || slot >= NPR_MAX_MODELS || !ctx->model_set[slot]) rc = NPR_ERR_MODEL;
-        if (rc != NPR_OK) b->ref_len[i] = b->read_len[i] = 0;
-        if (rc == NPR_OK) rc = build_plan(b->params, lX, lY, guide_ops + 2 * guide_off[i], guide_off[i + 1] - guide_off[i], plans[i]);
-        if (rc == NPR_OK) {
-            for (const Segment &s : plans[i].segs)
-                if (s.max_width > (1 << 22)) rc = NPR_ERR_BAND_TOO_WIDE;
-        }
-        if (rc != NPR_OK) plans[i].segs.clear();
-        b->read_status[i] = rc;
     });
+    tm.lap("plan points");
 
-    tm.lap("plan");
-    // 2. flatten into tasks, longest first
-    struct Ref {
-        int64_t read;
-        int32_t seg;
-        int64_t cells;
-    };
-    std::vector<Ref> order;
-    int64_t seq_bytes = 0, band_entries = 0;
-    for (int64_t i = 0; i < n_reads; ++i) {
-        b->read_first_task[i] = static_cast<int32_t>(order.size());
-        b->read_ntasks[i] = static_cast<int32_t>(plans[i].segs.size());
-        for (size_t s = 0; s < plans[i].segs.size(); ++s) order.push_back({i, static_cast<int32_t>(s), plans[i].segs[s].cells});
+    // 2. flatten: segments in read order, their points and band rows at prefix offsets
+    std::vector<int64_t> chunk_seg0(nchunks + 1, 0), chunk_pt0(nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        chunk_seg0[c + 1] = chunk_seg0[c] + static_cast<int64_t>(chunk_plan[c].segs.size());
+        chunk_pt0[c + 1] = chunk_pt0[c] + static_cast<int64_t>(chunk_plan[c].points.size());
     }
-    const int64_t ntasks = static_cast<int64_t>(order.size());
+    const int64_t ntasks = chunk_seg0[nchunks], npoints = chunk_pt0[nchunks];
     if (ntasks >= (int64_t(1) << 31)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: too many tasks");
-    std::vector<int32_t> rank(ntasks);
-    std::iota(rank.begin(), rank.end(), 0);
-    // kernel class of a segment: the register kernel takes staircase bands of at most 256 cells per
-    // anti-diagonal; wider ones go to the generic kernel (LDS ring while it fits, global ring beyond)
+    {
+        int64_t first = 0;
+        for (int64_t i = 0; i < n_reads; ++i) b->read_first_task[i] = static_cast<int32_t>(first), first += b->read_ntasks[i];
+    }
+    // the read's windows as they stand in the caller's buffers (ASCII), reference part then read part, encoded on the device
+    std::vector<int64_t> win_off(n_reads + 1, 0);
+    for (int64_t i = 0; i < n_reads; ++i) win_off[i + 1] = win_off[i] + (b->read_ntasks[i] ? b->ref_len[i] + b->read_len[i] : 0);
+    const int64_t seq_bytes = win_off[n_reads];
+    std::vector<SegPlan> seg(ntasks);  // flat, read order
+    std::vector<PlanSeg> pseg(ntasks);
+    int64_t band_entries = 0;
+    for (int64_t c = 0; c < nchunks; ++c)
+        for (size_t q = 0; q < chunk_plan[c].segs.size(); ++q) {
+            const int64_t k = chunk_seg0[c] + static_cast<int64_t>(q);
+            seg[k] = chunk_plan[c].segs[q];
+            PlanSeg &ps = pseg[k];
+            ps.point_first = chunk_pt0[c] + seg[k].point_first;
+            ps.band_off = band_entries;
+            ps.pieces = seg[k].pieces;
+            ps.lX = static_cast<int32_t>(seg[k].xe - seg[k].xs), ps.lY = static_cast<int32_t>(seg[k].ye - seg[k].ys), ps.pad = 0;
+            band_entries += static_cast<int64_t>(ps.lX) + ps.lY + 1;
+        }
+    // pinned staging (kept by the context): plan points, then the sequence windows
+    const size_t stage_pts = (static_cast<size_t>(npoints) * sizeof(PlanPoint) + 255) & ~size_t(255);
+    const size_t stage_need = stage_pts + static_cast<size_t>(seq_bytes) + 256;
+    if (stage_need > ctx->pin_stage_bytes) {
+        if (ctx->pin_stage) (void)hipHostFree(ctx->pin_stage);
+        ctx->pin_stage = nullptr, ctx->pin_stage_bytes = 0;
+        if ((e = hipHostMalloc(&ctx->pin_stage, stage_need + stage_need / 4, hipHostMallocDefault)) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipHostMalloc", e);
+        ctx->pin_stage_bytes = stage_need + stage_need / 4;
+    }
+    PlanPoint *const h_points = static_cast<PlanPoint *>(ctx->pin_stage);
+    uint8_t *const h_seq = static_cast<uint8_t *>(ctx->pin_stage) + stage_pts;
+    parallel_for(nchunks, ctx->host_threads, [&](int64_t c) {
+        if (!chunk_plan[c].points.empty())
+            std::memcpy(h_points + chunk_pt0[c], chunk_plan[c].points.data(), chunk_plan[c].points.size() * sizeof(PlanPoint));
+        for (int64_t i = c * kChunk, hi = std::min(n_reads, (c + 1) * kChunk); i < hi; ++i) {
+            if (!b->read_ntasks[i]) continue;
+            std::memcpy(h_seq + win_off[i], ref + ref_off[ref_of(i)] + b->gstart[2 * i], static_cast<size_t>(b->ref_len[i]));
+            std::memcpy(h_seq + win_off[i] + b->ref_len[i], read + read_off[i] + b->gstart[2 * i + 1], static_cast<size_t>(b->read_len[i]));
+        }
+    });
+    chunk_plan.clear();
+    tm.lap("flatten + stage");
+
+    // 3. device: band rows of every anti-diagonal, per-segment summaries
+    DevBuf<PlanPoint> d_points;
+    DevBuf<SegSummary> d_summary;
+    if ((e = d_points.alloc(npoints)) != hipSuccess || (e = b->d_pseg.alloc(ntasks)) != hipSuccess || (e = d_summary.alloc(ntasks)) != hipSuccess ||
+        (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes + 16)) != hipSuccess)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    std::vector<SegSummary> summary(ntasks);
+    if (ntasks) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_points.p, h_points, d_points.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_pseg.p, pseg.data(), b->d_pseg.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        PlanArgs pa{static_cast<int32_t>(ntasks), b->params.band_mode == NPR_BAND_FIXED ? 1 : 0,
+                    b->params.band_mode == NPR_BAND_FIXED ? b->params.fixed_width / 2 : b->params.diagonal_expansion,
+                    d_points.p, b->d_pseg.p, b->d_lo.p, b->d_n.p, d_summary.p};
+        int rc = launch_plan_bands(pa, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_plan_bands launch", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipMemcpyAsync(summary.data(), d_summary.p, d_summary.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        // the sequences travel and are encoded while the host looks at the summaries
+        if (seq_bytes) {
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_seq.p, h_seq, static_cast<size_t>(seq_bytes), hipMemcpyHostToDevice, ctx->side[0]));
+            if ((rc = launch_encode(b->d_seq.p, seq_bytes, ctx->side[0])) != 0) return fail(ctx, NPR_ERR_HIP, "k_encode launch", static_cast<hipError_t>(rc));
+            HIP_TRY(ctx, hipEventRecord(ctx->side_done[0], ctx->side[0]));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    tm.lap("device band rows");
+    for (int64_t k = 0; k < ntasks; ++k)
+        if (summary[k].max_width > (1 << 22) || summary[k].cells >= (int64_t(1) << 40)) b->read_status[seg[k].owner] = NPR_ERR_BAND_TOO_WIDE;
+    // (a read refused here keeps its tasks -- they are cheap to run and its status says the results do not count)
+
+    // 4. kernel classes.  The register kernels on a frame that follows the anti-diagonal take bands whose frame schedule
+    // exists, tried from the smallest frame up (on the device: the schedule is sequential per segment); bands too wide for
+    // one wavefront's frame go to the stripe kernel (k_dp_tile), whatever their shape.  A batch staged for the E-step
+    // (NPR_MODE_EXPECTATIONS) keeps the classes that have an E-step kernel.
     const char *force = std::getenv("NPR_KERNEL");  // "generic": no register kernel (A/B runs, tests)
     const bool force_generic = force && std::strcmp(force, "generic") == 0;
     const int lds_max_w = generic_max_wcap();
-    // the LDS ring is sized by the widest band of a launch and decides how many workgroups share a CU, so the
-    // LDS-ring tasks are launched in three width classes
     const char *nowide_env = std::getenv("NPR_NO_WIDE");  // "1": no multi-wavefront register kernel (A/B runs, tests)
     const bool no_wide = nowide_env && nowide_env[0] == '1';
     const char *cmin_env = std::getenv("NPR_CLASS_MIN");  // bring-up: smallest register class to use
     const int cmin = cmin_env ? std::atoi(cmin_env) : 0;
-    // Bands too wide for one wavefront's frame go to the stripe kernel (k_dp_tile), whatever their shape.  A batch staged
-    // for the E-step (NPR_MODE_EXPECTATIONS) keeps the classes that have an E-step kernel; NPR_NO_TILE=1: A/B runs, tests.
-    const char *notile_env = std::getenv("NPR_NO_TILE");
+    const char *notile_env = std::getenv("NPR_NO_TILE");  // "1": no stripe kernel (A/B runs, tests)
     const bool use_tile = !force_generic && !(notile_env && notile_env[0] == '1') && b->params.mode != NPR_MODE_EXPECTATIONS;
-    auto class_of = [&](const Segment &s) {
-        if (!force_generic)
-            for (int c = cmin; c < kFirstGeneric; ++c) {
-                if (use_tile && kClassTab[c].kind == K_WIDE) return kTileClass;
-                if (s.max_width >= kClassTab[c].slots() || (no_wide && kClassTab[c].kind == K_WIDE)) continue;
-                if (build_stair_schedule(s, kClassTab[c].R, kClassTab[c].NW, nullptr, nullptr)) return c;
-            }
-        if (use_tile) return kTileClass;
-        if (s.max_width <= 512) return kFirstGeneric;
-        if (s.max_width <= 1024) return kFirstGeneric + 1;
-        return s.max_width <= lds_max_w ? kFirstGeneric + 2 : kFirstGeneric + 3;
-    };
+    std::vector<uint32_t> cand(ntasks, 0);
+    std::vector<int64_t> sched_off(ntasks, -1);
+    int64_t ctl_entries = 0;
+    for (int64_t k = 0; k < ntasks; ++k) {
+        if (force_generic) break;
+        for (int c = cmin; c < kSchedClasses; ++c) {
+            if (kClassTab[c].kind == K_WIDE && (use_tile || no_wide)) continue;
+            if (summary[k].max_width < kClassTab[c].slots()) cand[k] |= 1u << c;
+        }
+        if (cand[k]) sched_off[k] = ctl_entries, ctl_entries += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
+    }
+    std::vector<int32_t> sched_cls(ntasks, -1);
+    std::vector<int64_t> sched_cells(ntasks, 0);
+    if ((e = b->d_ctl.alloc(2 * ctl_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    if (ctl_entries) {
+        DevBuf<uint32_t> d_cand;
+        DevBuf<int64_t> d_off, d_cells;
+        DevBuf<int32_t> d_cls;
+        if ((e = d_cand.alloc(ntasks)) != hipSuccess || (e = d_off.alloc(ntasks)) != hipSuccess || (e = d_cells.alloc(ntasks)) != hipSuccess ||
+            (e = d_cls.alloc(ntasks)) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+        HIP_TRY(ctx, hipMemcpyAsync(d_cand.p, cand.data(), d_cand.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_off.p, sched_off.data(), d_off.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        SchedArgs sa{static_cast<int32_t>(ntasks), b->d_pseg.p, d_summary.p, b->d_lo.p, b->d_n.p, d_off.p, d_cand.p, b->d_ctl.p, d_cls.p, d_cells.p};
+        const int rc = launch_plan_sched(sa, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_plan_sched launch", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipMemcpyAsync(sched_cls.data(), d_cls.p, d_cls.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(sched_cells.data(), d_cells.p, d_cells.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    tm.lap("device frame schedules");
     std::vector<int8_t> cls_of(ntasks);
+    std::vector<int32_t> tile_list;
+    std::vector<int64_t> tile_off_of(ntasks, -1), tile_offs;
+    int64_t stripe_entries = 0;
+    bool any_generic = false;
+    for (int64_t k = 0; k < ntasks; ++k) {
+        int c = sched_cls[k];
+        if (c < 0) {
+            const int64_t w = summary[k].max_width;
+            c = use_tile ? kTileClass : (w <= 512 ? kFirstGeneric : (w <= 1024 ? kFirstGeneric + 1 : (w <= lds_max_w ? kFirstGeneric + 2 : kFirstGeneric + 3)));
+        }
+        cls_of[k] = static_cast<int8_t>(c);
+        if (kClassTab[c].kind == K_TILE) {
+            tile_list.push_back(static_cast<int32_t>(k));
+            tile_off_of[k] = stripe_entries;
+            tile_offs.push_back(stripe_entries);
+            stripe_entries += 1 + pseg[k].lX / (64 * kClassTab[c].R) + 1;
+        }
+        any_generic |= kClassTab[c].kind == K_GENERIC_LDS || kClassTab[c].kind == K_GENERIC_GLOBAL;
+    }
     // k_dp_tile tasks are ordered by the forward scratch they need (one row per anti-diagonal of a stripe: also what a
     // task costs): a workgroup's region is sized by its FIRST task, every later one from the queue is smaller
     std::vector<int64_t> tile_need(ntasks, 0);
-    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
-        const Segment &sg = plans[order[k].read].segs[order[k].seg];
-        cls_of[k] = static_cast<int8_t>(class_of(sg));
-        if (kClassTab[cls_of[k]].kind == K_TILE) {
-            int64_t rows = 0;
-            build_stripes(sg, kClassTab[cls_of[k]].R, nullptr, &rows);
-            tile_need[k] = (tile_scratch_cells(rows, kClassTab[cls_of[k]].R) + 63) & ~int64_t(63);
-        }
-    });
+    if ((e = b->d_stripes.alloc(stripe_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    if (!tile_list.empty()) {
+        DevBuf<int32_t> d_list;
+        DevBuf<int64_t> d_toff, d_rows;
+        const size_t nt = tile_list.size();
+        if ((e = d_list.alloc(nt)) != hipSuccess || (e = d_toff.alloc(nt)) != hipSuccess || (e = d_rows.alloc(nt)) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+        HIP_TRY(ctx, hipMemcpyAsync(d_list.p, tile_list.data(), d_list.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_toff.p, tile_offs.data(), d_toff.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        StripeArgs ta{static_cast<int32_t>(nt), kClassTab[kTileClass].R, d_list.p, b->d_pseg.p, d_summary.p, b->d_lo.p, b->d_n.p, d_toff.p, b->d_stripes.p, d_rows.p};
+        const int rc = launch_plan_stripes(ta, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_plan_stripes launch", static_cast<hipError_t>(rc));
+        std::vector<int64_t> rows(nt);
+        HIP_TRY(ctx, hipMemcpyAsync(rows.data(), d_rows.p, d_rows.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t q = 0; q < nt; ++q) tile_need[tile_list[q]] = (tile_scratch_cells(rows[q], kClassTab[kTileClass].R) + 63) & ~int64_t(63);
+    }
+    if (any_generic) {
+        const int32_t rc = ensure_coff(b.get());
+        if (rc != NPR_OK) return rc;
+    }
+    tm.lap("device stripe tables");
+
+    // 5. tasks, grouped by class, the costliest first
+    std::vector<int32_t> rank(ntasks);
+    std::iota(rank.begin(), rank.end(), 0);
     std::stable_sort(rank.begin(), rank.end(), [&](int32_t a, int32_t c) {
         if (cls_of[a] != cls_of[c]) return cls_of[a] < cls_of[c];
         if (tile_need[a] != tile_need[c]) return tile_need[a] > tile_need[c];
-        return order[a].cells > order[c].cells;
+        return summary[a].cells > summary[c].cells;
     });
     b->task_of.assign(ntasks, 0);
     for (int64_t k = 0; k < ntasks; ++k) b->task_of[rank[k]] = static_cast<int32_t>(k);
-
-    // sequences: per task, only the part of the reference and of the read its segment spans
-    std::vector<int64_t> task_x(ntasks), task_y(ntasks);
-    seq_bytes = 0;
-    for (int64_t k = 0; k < ntasks; ++k) {
-        const Ref &r = order[rank[k]];
-        const Segment &s = plans[r.read].segs[r.seg];
-        task_x[k] = seq_bytes;
-        seq_bytes += s.xe - s.xs;
-        task_y[k] = seq_bytes;
-        seq_bytes += s.ye - s.ys;
-    }
-    const std::unique_ptr<uint8_t[]> h_seq_buf(new uint8_t[seq_bytes + 1]);
-    uint8_t *const h_seq = h_seq_buf.get();
-    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
-        const Ref &r = order[rank[k]];
-        const Segment &s = plans[r.read].segs[r.seg];
-        const uint8_t *xsrc = ref + ref_off[ref_of(r.read)] + b->gstart[2 * r.read] + s.xs;
-        const uint8_t *ysrc = read + read_off[r.read] + b->gstart[2 * r.read + 1] + s.ys;
-        for (int64_t q = 0; q < s.xe - s.xs; ++q) h_seq[task_x[k] + q] = encode_base(xsrc[q]);
-        for (int64_t q = 0; q < s.ye - s.ys; ++q) h_seq[task_y[k] + q] = encode_base(ysrc[q]);
-    });
-
     b->tasks.resize(ntasks);
     b->task_cells.resize(ntasks);
-    std::vector<int64_t> band_base(ntasks);
-    int64_t ctl_entries = 0, stripe_entries = 0;
     int64_t pair_total = 0, max_pad = 0, max_width = 0, total_cells = 0;
     int64_t cls_count[kClasses] = {}, cls_width[kClasses] = {}, cls_cells[kClasses] = {};
     for (int64_t k = 0; k < ntasks; ++k) {
-        const Ref &r = order[rank[k]];
-        const Segment &s = plans[r.read].segs[r.seg];
-        band_base[k] = band_entries;
-        band_entries += s.D() + 1;
+        const int32_t g = rank[k];
+        const SegPlan &s = seg[g];
+        const int64_t i = s.owner;
         Task &t = b->tasks[k];
-        t.x_off = task_x[k];
-        t.y_off = task_y[k];
-        t.band_off = band_base[k];
-        t.lX = static_cast<int32_t>(s.xe - s.xs);
-        t.lY = static_cast<int32_t>(s.ye - s.ys);
-        t.D = static_cast<int32_t>(s.D());
+        t.x_off = win_off[i] + s.xs;
+        t.y_off = win_off[i] + b->ref_len[i] + s.ys;
+        t.band_off = pseg[g].band_off;
+        t.lX = pseg[g].lX;
+        t.lY = pseg[g].lY;
+        t.D = t.lX + t.lY;
         t.flags = (s.ragged_start ? 1 : 0) | (s.ragged_end ? 2 : 0);
-        t.model = model_slot ? model_slot[r.read] : 0;
+        t.model = model_slot ? model_slot[i] : 0;
         t.xs = static_cast<int32_t>(s.xs);
         t.ys = static_cast<int32_t>(s.ys);
-        t.read = static_cast<int32_t>(r.read);
-        const int64_t cap = std::min<int64_t>(s.cells, static_cast<int64_t>(b->params.max_pairs_per_base) * std::min(t.lX, t.lY) + 64);
+        t.read = static_cast<int32_t>(i);
+        const int64_t cells = summary[g].cells;
+        const int64_t cap = std::min<int64_t>(cells, static_cast<int64_t>(b->params.max_pairs_per_base) * std::min(t.lX, t.lY) + 64);
         t.pair_cap = static_cast<int32_t>(std::min<int64_t>(cap, INT32_MAX));
         t.pair_off = pair_total;
         pair_total += t.pair_cap;
-        b->task_cells[k] = s.cells;
-        total_cells += s.cells;
-        max_width = std::max<int64_t>(max_width, s.max_width);
-        const int c = cls_of[rank[k]];
-        t.ctl_off = -1;
-        t.tile_off = -1;
-        if (is_register_class(c)) {
-            t.ctl_off = ctl_entries;
-            ctl_entries += s.D() + 1;
-        }
-        if (kClassTab[c].kind == K_TILE) {
-            t.tile_off = stripe_entries;
-            stripe_entries += 1 + stripes_of(s, kClassTab[c].R);
-        }
+        b->task_cells[k] = cells;
+        total_cells += cells;
+        max_width = std::max<int64_t>(max_width, summary[g].max_width);
+        const int c = cls_of[g];
+        t.ctl_off = is_register_class(c) ? sched_off[g] : -1;
+        t.tile_off = tile_off_of[g];
+        const int64_t pad = std::max(summary[g].generic_cells, is_register_class(c) ? sched_cells[g] : 0);  // either kernel may run the task
+        if (pad >= (int64_t(1) << 32)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: segment too large");
+        t.cells_pad = static_cast<int32_t>(std::min<int64_t>(pad, INT32_MAX));
+        max_pad = std::max(max_pad, pad);
         ++cls_count[c];
-        cls_width[c] = std::max<int64_t>(cls_width[c], s.max_width);
-        cls_cells[c] += s.cells;
+        cls_width[c] = std::max<int64_t>(cls_width[c], summary[g].max_width);
+        cls_cells[c] += cells;
     }
-    // not vectors: value-initialising gigabytes on one thread took longer than filling them on all of them
-    const std::unique_ptr<int32_t[]> h_lo(new int32_t[band_entries + 1]), h_n(new int32_t[band_entries + 1]);
-    const std::unique_ptr<uint32_t[]> h_coff(new uint32_t[band_entries + 1]), h_ctl(new uint32_t[2 * ctl_entries + 2]);
-    const std::unique_ptr<Stripe[]> h_stripes(new Stripe[stripe_entries + 1]);
-    std::vector<int64_t> pad_cells(ntasks);
-    parallel_for(ntasks, ctx->host_threads, [&](int64_t k) {
-        const Ref &r = order[rank[k]];
-        const Segment &s = plans[r.read].segs[r.seg];
-        int64_t stair_cells = 0;
-        if (b->tasks[k].ctl_off >= 0)
-            build_stair_schedule(s, kClassTab[cls_of[rank[k]]].R, kClassTab[cls_of[rank[k]]].NW, h_ctl.get() + 2 * b->tasks[k].ctl_off, &stair_cells);
-        if (b->tasks[k].tile_off >= 0) build_stripes(s, kClassTab[cls_of[rank[k]]].R, h_stripes.get() + b->tasks[k].tile_off, nullptr);
-        uint64_t off = 0;
-        for (int64_t d = 0; d <= s.D(); ++d) {
-            h_lo[band_base[k] + d] = s.lo[d];
-            h_n[band_base[k] + d] = s.n[d];
-            h_coff[band_base[k] + d] = static_cast<uint32_t>(off);
-            off += (static_cast<uint64_t>(s.n[d]) + 3) & ~uint64_t(3);  // 16-byte aligned rows
-        }
-        pad_cells[k] = std::max(static_cast<int64_t>(off), stair_cells);  // either kernel may run the task
-    });
-    for (int64_t k = 0; k < ntasks; ++k) {
-        if (pad_cells[k] >= (int64_t(1) << 32)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: segment too large");
-        b->tasks[k].cells_pad = static_cast<int32_t>(std::min<int64_t>(pad_cells[k], INT32_MAX));
-        max_pad = std::max(max_pad, pad_cells[k]);
-    }
-
-    tm.lap("flatten + encode + band arrays");
-    // 3. device buffers
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (seq_bytes) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[0], 0));
+    tm.lap("tasks");
+    // 6. launch geometry and the remaining device buffers
     b->slot_stride = (max_pad + 63) & ~int64_t(63);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-    const int64_t fixed = seq_bytes + band_entries * 12 + ctl_entries * 8 + stripe_entries * (int64_t)sizeof(Stripe) + pair_total * 12 +
-                          ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut));
+    // (sequences, band rows, control words and stripe tables are allocated already)
+    const int64_t fixed = pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut)) + (any_generic ? 0 : band_entries * 4);
     const int64_t budget = static_cast<int64_t>((free_b + ctx->arena_cells * 8) * 0.9) - fixed;
     int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
@@ -859,12 +904,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         max_grid = std::max<int64_t>(max_grid, tileL->grid);
     }
     const int64_t grid = ntasks ? sum_grid + (tileL ? tileL->grid : 0) : 0;
-    hipError_t e;
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
-        (e = b->d_queue.alloc(kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes)) != hipSuccess ||
-        (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess ||
-        (e = b->d_coff.alloc(band_entries)) != hipSuccess || (e = b->d_ctl.alloc(2 * ctl_entries)) != hipSuccess ||
-        (e = b->d_stripes.alloc(stripe_entries)) != hipSuccess || (e = b->d_region.alloc(region.size())) != hipSuccess ||
+        (e = b->d_queue.alloc(kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess ||
+        (e = b->d_region.alloc(region.size())) != hipSuccess ||
         (e = b->d_px.alloc(pair_total)) != hipSuccess ||
         (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
@@ -881,14 +923,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     }
     tm.lap("hipMalloc");
     if (ntasks) {
-        HIP_TRY(ctx, hipMemcpy(b->d_tasks.p, b->tasks.data(), b->d_tasks.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_seq.p, h_seq, b->d_seq.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_lo.p, h_lo.get(), b->d_lo.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_n.p, h_n.get(), b->d_n.bytes(), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(b->d_coff.p, h_coff.get(), b->d_coff.bytes(), hipMemcpyHostToDevice));
-        if (ctl_entries) HIP_TRY(ctx, hipMemcpy(b->d_ctl.p, h_ctl.get(), b->d_ctl.bytes(), hipMemcpyHostToDevice));
-        if (stripe_entries) HIP_TRY(ctx, hipMemcpy(b->d_stripes.p, h_stripes.get(), b->d_stripes.bytes(), hipMemcpyHostToDevice));
-        if (!region.empty()) HIP_TRY(ctx, hipMemcpy(b->d_region.p, region.data(), b->d_region.bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_tasks.p, b->tasks.data(), b->d_tasks.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        if (!region.empty()) HIP_TRY(ctx, hipMemcpyAsync(b->d_region.p, region.data(), b->d_region.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the sequences are in place too: the stream waited for their copy)
     }
     tm.lap("H2D");
     b->outs.resize(ntasks);
@@ -1401,6 +1438,10 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     if (kernel_ms) *kernel_ms = 0.f;
     const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
     if (!ntasks) return NPR_OK;
+    {
+        const int32_t rc = ensure_coff(b);  // classes without a register E-step take the generic kernel
+        if (rc != NPR_OK) return rc;
+    }
     // launch geometry: everything goes through the generic kernel (LDS ring while the band fits, global ring beyond)
     struct L {
         int first, count, wcap, grid;
@@ -1642,11 +1683,102 @@ int32_t npr_align_stats(npr_ctx *ctx, int64_t n, int64_t n_refs, const uint8_t *
     }
 }
 
+int64_t npr_batch_plan_check(npr_batch *b) {
+    if (!b) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    try {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        {
+            const int32_t rc = ensure_coff(b);
+            if (rc != NPR_OK) return rc;
+        }
+        const int64_t n = b->n_reads;
+        int64_t mismatches = 0;
+        std::vector<int32_t> lo, nn;
+        std::vector<uint32_t> co, ctl, want_ctl;
+        std::vector<Stripe> st, want_st;
+        for (int64_t i = 0; i < n; ++i) {
+            if (b->read_status[i] != NPR_OK && b->read_ntasks[i] == 0) continue;
+            Plan plan;
+            const int32_t rc = build_plan(b->params, b->ref_len[i], b->read_len[i], b->guide_ops.data() + 2 * b->guide_off[i],
+                                          b->guide_off[i + 1] - b->guide_off[i], plan);
+            if (rc != NPR_OK || static_cast<int32_t>(plan.segs.size()) != b->read_ntasks[i]) {
+                ++mismatches;
+                continue;
+            }
+            for (int32_t s = 0; s < b->read_ntasks[i]; ++s) {
+                const int32_t k = b->task_of[b->read_first_task[i] + s];
+                const Task &t = b->tasks[k];
+                const Segment &sg = plan.segs[s];
+                bool ok = t.D == sg.D() && t.xs == sg.xs && t.ys == sg.ys && t.lX == sg.xe - sg.xs && t.lY == sg.ye - sg.ys &&
+                          t.flags == ((sg.ragged_start ? 1 : 0) | (sg.ragged_end ? 2 : 0)) && b->task_cells[k] == sg.cells;
+                if (ok) {
+                    const size_t rows = static_cast<size_t>(t.D) + 1;
+                    lo.resize(rows), nn.resize(rows), co.resize(rows);
+                    HIP_TRY(ctx, hipMemcpy(lo.data(), b->d_lo.p + t.band_off, rows * 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(ctx, hipMemcpy(nn.data(), b->d_n.p + t.band_off, rows * 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(ctx, hipMemcpy(co.data(), b->d_coff.p + t.band_off, rows * 4, hipMemcpyDeviceToHost));
+                    uint64_t off = 0;
+                    for (size_t d = 0; d < rows && ok; ++d) {
+                        ok = lo[d] == sg.lo[d] && nn[d] == sg.n[d] && co[d] == static_cast<uint32_t>(off);
+                        if (!ok && std::getenv("NPR_TIMING"))
+                            std::fprintf(stderr, "[npr plan check] row %zu: device lo %d n %d coff %u | host lo %d n %d coff %u\n", d, lo[d], nn[d], co[d], sg.lo[d],
+                                         sg.n[d], static_cast<uint32_t>(off));
+                        off += (static_cast<uint64_t>(sg.n[d]) + 3) & ~uint64_t(3);
+                    }
+                    if (ok && t.ctl_off >= 0) {
+                        int cls = -1;  // the class the task was sorted into
+                        for (const auto &L : b->launches)
+                            if (k >= L.first && k < L.first + L.count) cls = L.cls;
+                        ctl.resize(2 * rows), want_ctl.assign(2 * rows, 0);
+                        HIP_TRY(ctx, hipMemcpy(ctl.data(), b->d_ctl.p + 2 * t.ctl_off, rows * 8, hipMemcpyDeviceToHost));
+                        int64_t cells = 0;
+                        ok = cls >= 0 && is_register_class(cls) && build_stair_schedule(sg, kClassTab[cls].R, kClassTab[cls].NW, want_ctl.data(), &cells) &&
+                             ctl == want_ctl;
+                        if (!ok && std::getenv("NPR_TIMING")) {
+                            size_t q = 0;
+                            while (q < 2 * rows && ctl[q] == want_ctl[q]) ++q;
+                            std::fprintf(stderr, "[npr plan check] class %d, control word %zu of %zu: device %08x host %08x\n", cls, q, 2 * rows,
+                                         q < 2 * rows ? ctl[q] : 0u, q < 2 * rows ? want_ctl[q] : 0u);
+                        }
+                    }
+                    if (ok && t.tile_off >= 0) {
+                        const int R = kClassTab[kTileClass].R;
+                        const size_t S = static_cast<size_t>(stripes_of(sg, R)) + 1;
+                        st.resize(S), want_st.assign(S, Stripe{});
+                        HIP_TRY(ctx, hipMemcpy(st.data(), b->d_stripes.p + t.tile_off, S * sizeof(Stripe), hipMemcpyDeviceToHost));
+                        build_stripes(sg, R, want_st.data(), nullptr);
+                        ok = std::memcmp(st.data(), want_st.data(), S * sizeof(Stripe)) == 0;
+                        if (!ok && std::getenv("NPR_TIMING"))
+                            for (size_t q = 0; q < S; ++q)
+                                if (std::memcmp(&st[q], &want_st[q], sizeof(Stripe)) != 0) {
+                                    std::fprintf(stderr, "[npr plan check] stripe entry %zu of %zu: device X %d K %d df %d dl %d row0 %u | host X %d K %d df %d dl %d row0 %u\n", q, S,
+                                                 st[q].X, st[q].K, st[q].df, st[q].dl, st[q].row0, want_st[q].X, want_st[q].K, want_st[q].df, want_st[q].dl, want_st[q].row0);
+                                    break;
+                                }
+                    }
+                }
+                if (!ok && mismatches < 4 && std::getenv("NPR_TIMING"))
+                    std::fprintf(stderr, "[npr plan check] read %lld segment %d differs (D %d, widest band row n/a, ctl %lld, stripes %lld)\n", (long long)i, s,
+                                 t.D, (long long)t.ctl_off, (long long)t.tile_off);
+                mismatches += ok ? 0 : 1;
+            }
+        }
+        return mismatches;
+    } catch (const std::exception &) {
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_plan_check: out of host memory");
+    }
+}
+
 int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, float *Bm_v, int32_t *Bm_e, int64_t cap) {
     if (!b || read_index < 0 || read_index >= b->n_reads || !Fm_v || !Fm_e || !Bm_v || !Bm_e) return NPR_ERR_INVALID;
     npr_ctx *ctx = b->ctx;
     if (b->read_status[read_index] != NPR_OK) return b->read_status[read_index];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const int32_t rc = ensure_coff(b);  // the dense dump runs the generic kernel
+        if (rc != NPR_OK) return rc;
+    }
     int64_t written = 0;
     DevBuf<float> d_Bv;
     DevBuf<int32_t> d_Be;

@@ -3,6 +3,7 @@
 #include <cstdint>
 
 #include "npr_internal.h"
+#include "npr_band.h"
 
 namespace npr {
 
@@ -132,6 +133,65 @@ struct MeaArgs {
 int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream);
 size_t tile_lds_bytes(int nw);
 int64_t tile_scratch_cells(int64_t rows, int R);  // forward scratch (8-byte cells) of a task with that many stripe rows
+// ---- device planner (npr_plan.hip): band rows, frame schedules, stripe tables and generic row offsets of a batch,
+// expanded on the device from the segments' plan points (npr_band.h) ----
+struct PlanSeg {
+    int64_t point_first;  // first of the segment's pieces + 1 points
+    int64_t band_off;     // first entry of its rows in lo / n (/ coff)
+    int32_t pieces, lX, lY, pad;
+};
+struct SegSummary {
+    int64_t cells;          // in-band lattice cells
+    int64_t generic_cells;  // scratch cells of the generic kernel (rows padded to 4)
+    int32_t max_width;
+    int32_t bad;            // anti-diagonals without cells
+    int32_t rough;          // anti-diagonals on which a band edge does not move by exactly one cell
+    int32_t pad;
+};
+// the register classes with a frame schedule: (slots per lane, wavefronts) of kernel classes 0..6
+constexpr int kSchedClasses = 7;
+constexpr int kSchedR[kSchedClasses] = {1, 2, 4, 2, 2, 4, 4};
+constexpr int kSchedNW[kSchedClasses] = {1, 1, 1, 4, 8, 8, 12};
+struct PlanArgs {
+    int32_t n_segs, fixed_mode, width;
+    const PlanPoint *points;
+    const PlanSeg *segs;
+    int32_t *lo, *n;
+    SegSummary *summary;
+};
+struct SchedArgs {
+    int32_t n_segs;
+    const PlanSeg *segs;
+    const SegSummary *summary;
+    const int32_t *lo, *n;
+    const int64_t *ctl_off;    // per segment: first entry of its control words (pairs), -1: no candidate class
+    const uint32_t *cand;      // per segment: bit c set = class c may take it
+    uint32_t *ctl;
+    int32_t *cls;              // out: the first candidate class whose frame can follow the band, -1: none
+    int64_t *cells;            // out: forward scratch cells of that schedule
+};
+struct StripeArgs {
+    int32_t count, R;
+    const int32_t *seg_index;  // the segments that go to k_dp_tile
+    const PlanSeg *segs;
+    const SegSummary *summary;
+    const int32_t *lo, *n;
+    const int64_t *tile_off;   // per listed segment: its header in `stripes`
+    Stripe *stripes;
+    int64_t *rows;             // out, per listed segment
+};
+struct CoffArgs {
+    int32_t n_segs;
+    const PlanSeg *segs;
+    const int32_t *n;
+    uint32_t *coff;
+};
+int launch_plan_bands(const PlanArgs &a, void *stream);
+int launch_plan_sched(const SchedArgs &a, void *stream);
+int launch_plan_stripes(const StripeArgs &a, void *stream);
+int launch_plan_coff(const CoffArgs &a, void *stream);
+int launch_encode(uint8_t *seq, int64_t n, void *stream);
+
 // k_align_stats (npr_stats.hip): per-read reductions over aligned pairs
 struct StatsSeg {  // a piece of a read's window whose base codes lie in `seq`: reference [xs, xe) at x_off, read [ys, ye) at y_off
     int32_t xs, xe, ys, ye;

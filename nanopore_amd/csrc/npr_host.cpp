@@ -51,54 +51,67 @@ void finish_segment(Segment &s) {
     }
 }
 
-// Band of a segment from its chain of lattice points pts[0]=(0,0) ... pts.back()=(lX,lY) (segment-local,
-// non-decreasing in both coordinates).  Between two consecutive points the band on anti-diagonal d is the
-// cut of the rectangle they span, widened by `expansion` in x-y units; adjacent anchors on one diagonal
-// therefore give a stripe of half-width `expansion` (+1 on odd steps).
-void fill_band(Segment &s, const std::vector<LatticePoint> &pts, int64_t expansion) {
-    const int64_t lX = s.xe - s.xs, lY = s.ye - s.ys, D = lX + lY;
-    s.lo.assign(D + 1, 0);
-    s.n.assign(D + 1, 0);
-    const size_t last = pts.size() - 1;
-    for (size_t k = 0; k < std::max<size_t>(last, 1); ++k) {
-        const LatticePoint a = pts[k], b = pts[std::min(k + 1, last)];
-        const int64_t d0 = a.x + a.y;
-        const int64_t d1 = (k + 1 >= last) ? D : (b.x + b.y - 1);  // the final interval owns its end diagonal
-        for (int64_t d = d0; d <= d1; ++d) {
-            int64_t lo = std::max(2 * a.x - d, d - 2 * b.y) - expansion;
-            int64_t hi = std::min(2 * b.x - d, d - 2 * a.y) + expansion;
-            lo = std::max({lo, -d, d - 2 * lY});
-            hi = std::min({hi, d, 2 * lX - d});
-            if ((lo ^ d) & 1) ++lo;
-            if ((hi ^ d) & 1) --hi;
-            s.lo[d] = static_cast<int32_t>(lo);
-            s.n[d] = static_cast<int32_t>((hi - lo) / 2 + 1);
-        }
-    }
-    finish_segment(s);
+PlanPoint point(int64_t x, int64_t y, bool diag = false) {
+    return PlanPoint{static_cast<int32_t>(x), static_cast<uint32_t>(y) | (diag ? 0x80000000u : 0u)};
 }
 
-void close_segment(Plan &plan, LatticePoint origin, LatticePoint corner, int ragged_start, int ragged_end,
-                   std::vector<LatticePoint> &pts, int64_t expansion) {
-    Segment s;
-    s.xs = origin.x, s.ys = origin.y, s.xe = corner.x, s.ye = corner.y;
+// closes the segment whose points (absolute coordinates) were collected in `pts`: origin .. corner
+void close_segment(PointPlan &plan, int64_t ox, int64_t oy, int64_t cx, int64_t cy, int ragged_start, int ragged_end,
+                   std::vector<PlanPoint> &pts) {
+    SegPlan s;
+    s.xs = ox, s.ys = oy, s.xe = cx, s.ye = cy;
     s.ragged_start = ragged_start, s.ragged_end = ragged_end;
-    for (auto &p : pts) p.x -= origin.x, p.y -= origin.y;
-    fill_band(s, pts, expansion);
-    plan.segs.push_back(std::move(s));
+    s.point_first = static_cast<int64_t>(plan.points.size());
+    if (pts.size() < 2) pts.push_back(pts.back());  // a segment has at least one piece
+    for (const PlanPoint &p : pts) plan.points.push_back(point(p.x - ox, p.yy() - oy, p.diag()));
+    s.pieces = static_cast<int32_t>(pts.size() - 1);
+    plan.segs.push_back(s);
 }
 
-int32_t plan_from_anchors(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, Plan &plan) {
+// a5.1: anchors = M columns of the guide, `trim` columns dropped at both ends of each gapless block; the pair of 0-based
+// bases (x, y) is the lattice point (x + 1, y + 1).  The anchors of one block are a run on one diagonal.
+// a5.2: the matrix is cut wherever the unanchored rectangle between two consecutive points is larger than N * N cells; each
+// side keeps at most N (or half the gap) of it and the cut ends are "ragged".
+int32_t points_from_anchors(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, PointPlan &plan) {
     const int64_t trim = p.constraint_trim, N = p.split_threshold;
-    // a5.1: anchors = M columns of the guide, `trim` columns dropped at both ends of each gapless block.
-    // The pair of 0-based bases (x,y) is the lattice point (x+1,y+1).
-    std::vector<LatticePoint> chain;
-    chain.push_back({0, 0});
+    std::vector<PlanPoint> pts{point(0, 0)};
+    int64_t ox = 0, oy = 0;      // origin of the current segment
+    int64_t ax = 0, ay = 0;      // the last chain point
+    int ragged = 0;
+    // link the chain point (ax, ay) to (bx, by): an unanchored rectangle
+    auto gap = [&](int64_t bx, int64_t by) {
+        const int64_t gx = bx - ax, gy = by - ay;
+        if (gx * gy > N * N) {
+            const int64_t hx = std::min(gx / 2, N), hy = std::min(gy / 2, N);
+            const int64_t sx = ax + hx, sy = ay + hy, rx = bx - hx, ry = by - hy;
+            if (!(pts.back().x == sx && pts.back().yy() == sy)) pts.push_back(point(sx, sy));
+            close_segment(plan, ox, oy, sx, sy, ragged, 1, pts);
+            ox = rx, oy = ry, ragged = 1;
+            pts.assign(1, point(rx, ry));
+            if (!(bx == rx && by == ry)) pts.push_back(point(bx, by));
+        } else {
+            pts.push_back(point(bx, by));
+        }
+        ax = bx, ay = by;
+    };
     int64_t x = 0, y = 0;
     for (int64_t i = 0; i < nops; ++i) {
         const int64_t len = ops[2 * i + 1];
         if (ops[2 * i] == NPR_OP_M) {
-            for (int64_t t = trim; t + trim < len; ++t) chain.push_back({x + t + 1, y + t + 1});
+            const int64_t m = len - 2 * trim;  // anchors of this block: (x + trim + 1 + t, y + trim + 1 + t), t = 0 .. m-1
+            if (m > 0) {
+                const int64_t fx = x + trim + 1, fy = y + trim + 1;
+                gap(fx, fy);
+                if (m > 1) {
+                    if (N >= 1) {  // unit steps along the diagonal: 1 x 1 rectangles, never cut
+                        pts.back() = point(fx, fy, true);
+                        pts.push_back(point(fx + m - 1, fy + m - 1));
+                        ax = fx + m - 1, ay = fy + m - 1;
+                    } else {       // splitMatrixBiggerThanThis = 0 cuts between any two points
+                        for (int64_t t = 1; t < m; ++t) gap(fx + t, fy + t);
+                    }
+                }
+            }
             x += len, y += len;
         } else if (ops[2 * i] == NPR_OP_I) {
             y += len;
@@ -106,84 +119,68 @@ int32_t plan_from_anchors(const npr_params &p, int64_t lX, int64_t lY, const int
             x += len;
         }
     }
-    const LatticePoint corner{lX, lY};
-    if (!(chain.back() == corner)) chain.push_back(corner);
-
-    // a5.2: cut the matrix wherever the unanchored rectangle between two consecutive points is larger than
-    // N*N cells; each side keeps at most N (or half the gap) of it and the cut ends are "ragged".
-    std::vector<LatticePoint> pts{chain[0]};
-    LatticePoint origin = chain[0];
-    int ragged = 0;
-    for (size_t i = 0; i + 1 < chain.size(); ++i) {
-        const LatticePoint a = chain[i], b = chain[i + 1];
-        const int64_t gx = b.x - a.x, gy = b.y - a.y;
-        if (gx * gy > N * N) {
-            const int64_t hx = std::min(gx / 2, N), hy = std::min(gy / 2, N);
-            const LatticePoint stop{a.x + hx, a.y + hy}, resume{b.x - hx, b.y - hy};
-            if (!(pts.back() == stop)) pts.push_back(stop);
-            close_segment(plan, origin, stop, ragged, 1, pts, p.diagonal_expansion);
-            origin = resume;
-            ragged = 1;
-            pts.assign(1, resume);
-            if (!(b == resume)) pts.push_back(b);
-        } else {
-            pts.push_back(b);
-        }
-    }
-    close_segment(plan, origin, corner, ragged, 0, pts, p.diagonal_expansion);
+    if (!(ax == lX && ay == lY)) gap(lX, lY);
+    close_segment(plan, ox, oy, lX, lY, ragged, 0, pts);
     return NPR_OK;
 }
 
-// Fixed-width band: on every anti-diagonal the cells whose x-y is within W/2 of where the guide path
-// crosses it (a match step jumps over one diagonal; that diagonal takes the step's own x-y).
-int32_t plan_fixed_width(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, Plan &plan) {
-    Segment s;
+// Fixed-width band: one piece per operation of the guide (band_row centres the band on the guide path).
+int32_t points_fixed_width(int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, PointPlan &plan) {
+    SegPlan s;
     s.xe = lX, s.ye = lY;
-    const int64_t D = lX + lY, half = p.fixed_width / 2;
-    std::vector<int64_t> centre(D + 1, 0);
+    s.point_first = static_cast<int64_t>(plan.points.size());
     int64_t x = 0, y = 0;
+    plan.points.push_back(point(0, 0));
     for (int64_t i = 0; i < nops; ++i) {
-        const int32_t op = ops[2 * i];
-        for (int64_t t = ops[2 * i + 1]; t > 0; --t) {
-            if (op == NPR_OP_M) {
-                centre[x + y + 1] = x - y;
-                ++x, ++y;
-            } else if (op == NPR_OP_D) {
-                ++x;
-            } else {
-                ++y;
-            }
-            centre[x + y] = x - y;
-        }
+        const int64_t len = ops[2 * i + 1];
+        if (ops[2 * i] != NPR_OP_I) x += len;
+        if (ops[2 * i] != NPR_OP_D) y += len;
+        plan.points.push_back(point(x, y));
     }
-    s.lo.resize(D + 1);
-    s.n.resize(D + 1);
-    for (int64_t d = 0; d <= D; ++d) {
-        int64_t lo = std::max({centre[d] - half, -d, d - 2 * lY});
-        int64_t hi = std::min({centre[d] + half, d, 2 * lX - d});
-        if ((lo ^ d) & 1) ++lo;
-        if ((hi ^ d) & 1) --hi;
-        s.lo[d] = static_cast<int32_t>(lo);
-        s.n[d] = static_cast<int32_t>((hi - lo) / 2 + 1);
-    }
-    finish_segment(s);
-    plan.segs.push_back(std::move(s));
+    if (nops == 0) plan.points.push_back(point(0, 0));
+    s.pieces = static_cast<int32_t>(plan.points.size() - s.point_first - 1);
+    plan.segs.push_back(s);
     return NPR_OK;
 }
 
 }  // namespace
 
-int32_t build_plan(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, Plan &out) {
-    out.segs.clear();
+int32_t plan_points(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, PointPlan &out) {
     if (lX < 0 || lY < 0 || (nops > 0 && !ops)) return NPR_ERR_INVALID;
     if (!guide_is_global(lX, lY, ops, nops)) return NPR_ERR_INVALID;
     if (lX + lY >= (int64_t(1) << 30)) return NPR_ERR_INVALID;
     // a fixed band narrower than two cells has empty odd anti-diagonals: the lattice falls apart, and the read would only
     // surface as NPR_ERR_ZERO_PROB after a full GPU launch
     if (p.band_mode == NPR_BAND_FIXED && p.fixed_width < 2) return NPR_ERR_INVALID;
-    if (p.band_mode == NPR_BAND_FIXED) return plan_fixed_width(p, lX, lY, ops, nops, out);
-    if (p.band_mode == NPR_BAND_ANCHOR) return plan_from_anchors(p, lX, lY, ops, nops, out);
+    if (p.band_mode == NPR_BAND_FIXED) return points_fixed_width(lX, lY, ops, nops, out);
+    if (p.band_mode == NPR_BAND_ANCHOR) return points_from_anchors(p, lX, lY, ops, nops, out);
     return NPR_ERR_INVALID;
+}
+
+int32_t build_plan(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, Plan &out) {
+    out.segs.clear();
+    PointPlan pp;
+    const int32_t rc = plan_points(p, lX, lY, ops, nops, pp);
+    if (rc != NPR_OK) return rc;
+    const int32_t fixed = p.band_mode == NPR_BAND_FIXED;
+    const int32_t width = fixed ? p.fixed_width / 2 : p.diagonal_expansion;
+    for (const SegPlan &sp : pp.segs) {
+        Segment s;
+        s.xs = sp.xs, s.ys = sp.ys, s.xe = sp.xe, s.ye = sp.ye;
+        s.ragged_start = sp.ragged_start, s.ragged_end = sp.ragged_end;
+        const int32_t slX = static_cast<int32_t>(sp.xe - sp.xs), slY = static_cast<int32_t>(sp.ye - sp.ys), D = slX + slY;
+        const PlanPoint *P = pp.points.data() + sp.point_first;
+        s.lo.resize(D + 1), s.n.resize(D + 1);
+        int32_t k = 0;
+        for (int32_t d = 0; d <= D; ++d) {
+            while (k + 1 < sp.pieces && P[k + 1].d0() <= d) ++k;
+            const BandRow r = band_row_of_piece(fixed, width, slX, slY, P[k], P[k + 1], d);
+            s.lo[d] = r.lo, s.n[d] = r.n;
+        }
+        finish_segment(s);
+        out.segs.push_back(std::move(s));
+    }
+    return NPR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "nprealign.h"
+#include "npr_band.h"
 
 namespace npr {
 
@@ -27,6 +28,22 @@ struct Segment {
 struct Plan {
     std::vector<Segment> segs;
 };
+
+// The O(#cigar ops) half of stages a5.1-a5.2: the segments of a read (matrix splits) and, per segment, the chain of lattice
+// points whose pieces define its band (npr_band.h).  The band rows themselves are expanded per anti-diagonal -- by
+// build_plan on the host, by npr_plan.hip on the device.
+struct SegPlan {
+    int64_t xs = 0, ys = 0, xe = 0, ye = 0;
+    int32_t ragged_start = 0, ragged_end = 0;
+    int64_t point_first = 0;  // first point of the segment in PointPlan::points (pieces + 1 of them)
+    int32_t pieces = 0;
+    int64_t owner = 0;        // the read it belongs to (set by the caller that plans many reads into one PointPlan)
+};
+struct PointPlan {
+    std::vector<SegPlan> segs;
+    std::vector<PlanPoint> points;
+};
+int32_t plan_points(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, PointPlan &out);
 
 // stages a5.1-a5.2: anchors from the guide, band, split.  Returns NPR_OK / NPR_ERR_INVALID.
 int32_t build_plan(const npr_params &p, int64_t lX, int64_t lY, const int32_t *ops, int64_t nops, Plan &out);

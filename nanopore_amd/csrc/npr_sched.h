@@ -1,0 +1,122 @@
+// npr_sched.h -- per-anti-diagonal schedules derived from a segment's band rows, written once for the host and the device:
+// the frame schedule of the register kernels on a frame that follows the anti-diagonal (k_dp_stair / k_dp_wide: control
+// words) and the stripe table of k_dp_tile.  The host runs them for the npr_plan_* entry points and the tests, the device
+// (npr_plan.hip) when a batch is staged.
+#pragma once
+#include <cstdint>
+
+#include "npr_band.h"
+#include "npr_device.h"
+
+namespace npr {
+
+// Frame schedule (see npr_kernel_stair.hip).  The wavefront(s) hold a frame of C = 64*R*NW slots of the current
+// anti-diagonal, slot j = lattice point (x0 + j, y0 - j); the frame takes an X-step (x0 += 1) into every odd anti-diagonal
+// and a Y-step (y0 += 1) into every even one, so its first x-y, flo, just alternates.  The band (first x-y `lo`, n cells)
+// must stay inside the frame; when it drifts to an edge the frame is REBASED by one slot (flo +- 2) between two
+// anti-diagonals.  A rebase towards higher x-y may only precede an X-step and one towards lower x-y a Y-step (the kernel
+// re-injects the base that left the wavefront at the step before), so the decision looks one anti-diagonal ahead.  Control
+// words per anti-diagonal: row offset in the forward scratch (cells), and jlo | n << 13 | (rebase + 1) << 26.  Returns false
+// when the band cannot be followed; `ctl` and `cells` may be null.
+struct StairState {
+    int32_t flo;   // x-y of slot 0 of the current frame
+    uint32_t off;  // scratch cells of the rows so far (a schedule that needs 2^32 or more is refused)
+};
+NPR_HD inline bool stair_begin(StairState &st, int32_t lo0, int32_t n0, int32_t max_width, int R, int NW) {
+    const int32_t C = 64 * R * NW;
+    if (n0 != 1 || max_width >= C) return false;
+    st.flo = lo0 - 2 * ((C - 1) / 2);
+    st.off = 0;
+    return true;
+}
+// one anti-diagonal: its band (lo, n), the next one's (lo_nx, n_nx; ignored when d == D) -> its two control words.
+// R is 1, 2 or 4: rshift = log2 R (the device walks this loop on one lane; no divisions).
+NPR_HD inline bool stair_step(StairState &st, int32_t d, int32_t D, int32_t lo, int32_t n, int32_t lo_nx, int32_t n_nx, int rshift, int32_t C,
+                              uint32_t &w0, uint32_t &w1) {
+    const int32_t span = 2 * (C - 1), R = 1 << rshift;
+    const int32_t hi = lo + 2 * (n - 1);
+    if (n < 1) return false;
+    int32_t reb = 0;
+    if (d > 0) {
+        if (d & 1) {  // X-step; the next one is a Y-step
+            const int32_t f = st.flo + 1;
+            if (hi > f + span || (d < D && lo_nx + 2 * (n_nx - 1) > f - 1 + span)) reb = 1;
+            st.flo = f + 2 * reb;
+        } else {
+            const int32_t f = st.flo - 1;
+            if (lo < f || (d < D && lo_nx < f + 1)) reb = -1;
+            st.flo = f + 2 * reb;
+        }
+        if (lo < st.flo || hi > st.flo + span) return false;
+    }
+    const int32_t jlo = (lo - st.flo) >> 1;  // lo >= flo, same parity
+    const int32_t l0 = jlo >> rshift, l1 = (jlo + n + R - 1) >> rshift;
+    w0 = st.off;
+    w1 = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26);
+    const uint32_t row = static_cast<uint32_t>(l1 - l0) << rshift;
+    if (st.off + row < st.off) return false;  // 2^32 cells
+    st.off += row;
+    return true;
+}
+NPR_HD inline int stair_rshift(int R) { return R == 1 ? 0 : (R == 2 ? 1 : 2); }
+NPR_HD inline bool stair_schedule(const int32_t *lo_, const int32_t *n_, int64_t D, int32_t max_width, int R, int NW, uint32_t *ctl,
+                                  int64_t *cells) {
+    StairState st;
+    if (D < 0 || !stair_begin(st, lo_[0], n_[0], max_width, R, NW)) return false;
+    const int rshift = stair_rshift(R);
+    const int32_t C = 64 * R * NW, Di = static_cast<int32_t>(D);
+    for (int32_t d = 0; d <= Di; ++d) {
+        uint32_t w0, w1;
+        if (!stair_step(st, d, Di, lo_[d], n_[d], d < Di ? lo_[d + 1] : 0, d < Di ? n_[d + 1] : 0, rshift, C, w0, w1)) return false;
+        if (ctl) ctl[2 * d] = w0, ctl[2 * d + 1] = w1;
+    }
+    if (cells) *cells = static_cast<int64_t>(st.off);
+    return true;
+}
+
+// Stripe table of k_dp_tile (npr_kernel_tile.hip): the lattice columns 0..lX cut into stripes of 64*R columns; per stripe
+// the first / last anti-diagonal on which the band has cells in it and the index of its first row in the task's scratch
+// (one row per anti-diagonal of a stripe).  stripe_ranges finds df / dl of the S = lX / (64 R) + 1 stripes (arrays with a
+// stride, so that the device can write straight into the table) and returns the rows; stripe_fill completes the table
+// (out[0] is the header {stripes, rows}).
+NPR_HD inline int64_t stripe_ranges(const int32_t *lo_, const int32_t *n_, int64_t D, int64_t lX, int R, int32_t *df, int32_t *dl, int stride) {
+    const int64_t K = 64 * R;
+    const int64_t S = lX / K + 1;
+    for (int64_t k = 0; k < S; ++k) df[k * stride] = 1, dl[k * stride] = 0;
+    for (int64_t d = 0; d <= D; ++d) {
+        if (n_[d] < 1) continue;
+        const int64_t xlo = (d + lo_[d]) >> 1, xhi = xlo + n_[d] - 1;
+        int64_t k0 = xlo / K, k1 = xhi / K;
+        if (k0 < 0) k0 = 0;
+        if (k1 > S - 1) k1 = S - 1;
+        for (int64_t k = k0; k <= k1; ++k) {
+            if (dl[k * stride] < df[k * stride]) df[k * stride] = static_cast<int32_t>(d);
+            dl[k * stride] = static_cast<int32_t>(d);
+        }
+    }
+    int64_t rows = 0;
+    for (int64_t k = 0; k < S; ++k)
+        if (dl[k * stride] >= df[k * stride]) rows += dl[k * stride] - df[k * stride] + 1;
+    return rows;
+}
+// out[1 + k].df / .dl already hold the ranges
+NPR_HD inline void stripe_fill(Stripe *out, int64_t lX, int R) {
+    const int64_t K = 64 * R;
+    const int64_t S = lX / K + 1;
+    int64_t rows = 0;
+    for (int64_t k = 0; k < S; ++k) {
+        Stripe &st = out[1 + k];
+        st.X = static_cast<int32_t>(k * K);
+        st.K = static_cast<int32_t>(K);
+        st.row0 = static_cast<uint32_t>(rows);
+        st.pad[0] = st.pad[1] = st.pad[2] = 0;
+        if (st.dl >= st.df) rows += st.dl - st.df + 1;
+    }
+    out[0].X = static_cast<int32_t>(S);
+    out[0].K = static_cast<int32_t>(rows);
+    out[0].df = out[0].dl = 0;
+    out[0].row0 = 0;
+    out[0].pad[0] = out[0].pad[1] = out[0].pad[2] = 0;
+}
+
+}  // namespace npr

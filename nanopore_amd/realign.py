@@ -125,6 +125,14 @@ class Batch(object):
             raise NprError(rc, "npr_batch_pairs")
         return off, x, y, p
 
+    def plan_check(self):
+        """Tasks whose device-made band rows / schedules / stripe tables differ from the host planner's (test aid;
+        include/nprealign.h: npr_batch_plan_check)."""
+        rc = self._L.npr_batch_plan_check(self._h)
+        if rc < 0:
+            raise NprError(int(rc), "npr_batch_plan_check", self.ctx.last_error())
+        return int(rc)
+
     def align_stats(self):
         """Per-read reductions over the aligned pairs of the cigars finish() produced, computed where they lie
         (include/nprealign.h: npr_batch_align_stats): int32 array [n_reads, STATS_WORDS]."""

@@ -193,3 +193,41 @@ def test_margin_align_snp_caller_recovers_held_out_snps(tmp_path, gpu_ctx):
     low = [k for k in kids if k.tag == "marginAlignMaxExpectedSnpCalls_trained_0" and k.attrib["coverage"] == "10"]
     assert len(low) == 3 and all(int(k.attrib["totalSampledReads"]) < 40 for k in low)
     gpu_ctx.set_hmm(__import__("nanopore_amd.hmm", fromlist=["Hmm"]).Hmm.loadHmm(utils.trainedModelPath("blasr_hmm_0.txt")))
+
+
+def test_alignment_uncertainty_on_a_local_soft_clipped_record(tmp_path, gpu_ctx):
+    """A base mapper's SAM holds LOCAL hits (pos > 0, soft clips, aend short of the reference).  The reference passes
+    aR.pos / aR.aend in the exonerate cigar and cactus_realign rescoring works inside that window
+    (utils.py:175-177, alignmentUncertainty.py:41); so does realignRecords: same score as the oracle on the cut-out
+    window, posterior coordinates absolute."""
+    from nanopore_amd import realign as R
+    from nanopore_amd import sam as pysam
+    from nanopore_amd.analyses.alignmentUncertainty import AlignmentUncertainty
+    from nanopore_amd.analyses.utils import ANALYSIS_SPLIT_MATRIX_BIGGER_THAN, realignRecords, trainedModelPath
+    fq, fa, reads, refs = _slice_inputs(tmp_path, mild=True)
+    (rname, ref), read = next(iter(refs.items())), reads["read_1"]
+    # the read was made from ref[500:5500]; a local hit: 7 read bases soft-clipped in front, 5 behind, gap-free guide
+    n = min(len(read) - 12, 3000)
+    rec = ["read_1", 0, rname, 500 + 7 + 1, 60, "7S%dM%dS" % (n, len(read) - 7 - n), "*", 0, 0, read, "*"]
+    samp = tmp_path / "local.sam"
+    samp.write_text("@SQ\tSN:%s\tLN:%d\n" % (rname, len(ref)) + "\t".join(str(v) for v in rec) + "\n")
+    adir = tmp_path / "au"
+    adir.mkdir()
+    an = AlignmentUncertainty(fq, "fake_readtype", fa, str(samp), str(adir))
+    an.run(ctx=gpu_ctx)
+    an.cleanup()
+    root = ET.parse(str(adir / "alignmentUncertainty.xml")).getroot()
+    X = np.array(["ACGT".index(c) for c in ref[507:507 + n]], dtype=np.uint8)
+    Y = np.array(["ACGT".index(c) for c in read[7:7 + n]], dtype=np.uint8)
+    P2 = orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=100,
+                         mode=orc.MODE_RESCORE_ORIGINAL)
+    want = orc.realign_read(oracle_hmm(), P2, X, Y, [(0, n)], precision=0)
+    assert float(root.attrib["averagePosteriorMatchProbabilitesPerRead"]) == pytest.approx(want["score"], abs=1e-5)
+    assert int(root.attrib["alignedPairsInCigar"]) == n
+    # realign mode on the same record: posteriors come back in contig / query coordinates
+    sam = pysam.Samfile(str(samp), "r")
+    records = list(sam)
+    out = realignRecords(sam, records, refs, 0.5, 0.0, trainedModelPath("blasr_hmm_0.txt"), mode=R.MODE_ALL_POSTERIORS,
+                         splitThreshold=ANALYSIS_SPLIT_MATRIX_BIGGER_THAN, ctx=gpu_ctx, want_pairs=True)
+    assert out[0]["status"] == 0 and out[0]["x"].min() >= 507 and out[0]["x"].max() < 507 + n and out[0]["y"].max() < n
+    assert cigar_spans(out[0]["ops"]) == (n, n)
