@@ -210,6 +210,15 @@ int32_t npr_align_stats(npr_ctx *ctx, int64_t n_reads, int64_t n_refs, const uin
                         const int32_t *ref_index, const uint8_t *read, const int64_t *read_off, const int32_t *ops,
                         const int64_t *ops_off, const int64_t *start, int32_t *stats /* [n_reads][NPR_STATS_WORDS] */);
 
+/* Expected base counts per reference position from the posterior pairs of a finished batch, on the device (SURVEY.md 8f
+ * next #4): what marginAlignSnpCaller.py:150-155 collates from the --outputAllPosteriorProbs files, one text line at a time:
+ * every pair (refPos, readPos, p) of a selected read adds p to expect[(first row of its reference + refPos) * 4 + base] for
+ * the read's base at readPos (A C G T; other bases add nothing) and sets seen[...].  use[i] != 0 selects read i (NULL: all) --
+ * the caller's coverage sampling; the reference table is n_refs sequences of ref_len[k] positions, rows in that order.
+ * fp64 atomics: sums agree with a sequential sum to rounding. */
+int32_t npr_batch_base_expectations(npr_batch *b, const uint8_t *use, int64_t n_refs, const int64_t *ref_len, double *expect,
+                                    uint8_t *seen);
+
 /* Baum-Welch E-step over the staged batch with the models currently installed: what
  * `cactus_realign --outputExpectations` produces per alignment and cactus_expectationMaximisation sums over all of
  * them in every EM iteration (nanopore/analyses/utils.py:509-528).  T_exp[slot*25 + from*5 + to] and
@@ -270,6 +279,13 @@ int64_t npr_mea_cigar(int64_t lX, int64_t lY, const int32_t *x, const int32_t *y
 /* mean posterior over the M columns of a cigar (stage a5.7) */
 int32_t npr_rescore(const int32_t *guide_ops, int64_t n_guide_ops, const int32_t *x, const int32_t *y,
                     const float *p, int64_t n, double *score);
+/* Chaining of local hits (stage before the realigner, nanopore/analyses/utils.py:388-426 chainFn): hit k spans reference
+ * [ref_start, ref_end] and signed read positions [read_start, read_end] (last aligned pair inclusive, reverse-strand
+ * positions negated as AlignedPair.getSignedReadPos does), scores `score` (aligned pairs).  Writes the indices of the
+ * highest-scoring co-linear chain, in chain order, to chain[0 .. return value); same chain as the reference's quadratic
+ * scan, ties included, found with a sort and a windowed scan.  Host code. */
+int64_t npr_chain_hits(int64_t n, const int64_t *ref_start, const int64_t *read_start, const int64_t *ref_end,
+                       const int64_t *read_end, const uint8_t *reverse, const int64_t *score, int64_t max_gap, int64_t *chain);
 /* SAM CIGAR text of n op lists (CSR as returned by npr_batch_ops): what realignSamFile3TargetFn assigns to aR.cigar
  * and pysam prints (nanopore/analyses/utils.py:597-605), for a writer that splices 50 k records at once.  String i is
  * out[str_off[i] .. str_off[i+1]) (no terminator; "*" for an empty list).  out == NULL: only the offsets; returns the

@@ -83,10 +83,10 @@ EXPORTS = [
     "npr_abi_version", "npr_strerror", "npr_create", "npr_destroy", "npr_last_error", "npr_set_hmm",
     "npr_batch_create", "npr_batch_create_at", "npr_batch_run", "npr_batch_finish", "npr_batch_destroy", "npr_batch_get_stats", "npr_batch_class_stats",
     "npr_batch_results", "npr_batch_ops", "npr_batch_pairs", "npr_batch_dense", "npr_batch_expectations",
-    "npr_batch_align_stats", "npr_align_stats", "npr_batch_plan_check",
+    "npr_batch_align_stats", "npr_align_stats", "npr_batch_plan_check", "npr_batch_base_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
-    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
+    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_chain_hits", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
 ]
 
 _lib = None
@@ -137,6 +137,8 @@ def load():
     L.npr_batch_pairs.argtypes = [vp, vp, vp, vp, vp, i64]
     L.npr_batch_expectations.restype = i32
     L.npr_batch_expectations.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.npr_batch_base_expectations.restype = i32
+    L.npr_batch_base_expectations.argtypes = [vp, vp, i64, vp, vp, vp]
     L.npr_batch_plan_check.restype = i64
     L.npr_batch_plan_check.argtypes = [vp]
     L.npr_batch_align_stats.restype = i32
@@ -159,6 +161,8 @@ def load():
     L.npr_plan_segment_band.argtypes = [vp, i32, vp, vp]
     L.npr_plan_stripes.restype = i32
     L.npr_plan_stripes.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.npr_chain_hits.restype = i64
+    L.npr_chain_hits.argtypes = [i64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.npr_format_cigars.restype = i64
     L.npr_format_cigars.argtypes = [i64, vp, vp, vp, vp, i64]
     L.npr_mea_cigar.restype = i64

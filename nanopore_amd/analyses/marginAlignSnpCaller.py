@@ -143,25 +143,31 @@ class MarginAlignSnpCaller(AbstractAnalysis):
             alignedBases.append((refIndex[refName], np.array(pos, dtype=np.int64), np.array(code, dtype=np.int64)))
         node = ET.Element("marginAlignComparison")
         for hmmType in self.hmmTypes:
-            # one batched GPU call per hmm type: all posterior match probabilities of every read (:135-146)
-            results = realignRecords(sam, records, refSequences, 0.5, 0.0, hmmFiles[hmmType], mode=realign.MODE_ALL_POSTERIORS,
-                                     splitThreshold=ANALYSIS_SPLIT_MATRIX_BIGGER_THAN, ctx=ctx, want_pairs=True)
-            posteriors = []
-            for aR, r in zip(records, results):
-                if r["status"] != 0:
-                    raise RuntimeError("Posterior computation failed for %s: status %d" % (aR.qname, r["status"]))
-                q = aR.query.upper()
-                code = np.array([bases.index(q[y]) if q[y] in bases else -1 for y in r["y"]], dtype=np.int64)
-                posteriors.append((r["x"].astype(np.int64), code, r["p"].astype(np.float64)))
+            # one batched GPU call per hmm type: all posterior match probabilities of every read (:135-146).  The pairs
+            # stay in HBM: each coverage sample below scatter-adds them per reference position on the device
+            # (npr_batch_base_expectations) instead of parsing a `refPos readPos prob` file per read (:149-155).
+            from .utils import _context, _loadHmmInto, stageSamFile
+            ctx = ctx or _context()
+            _loadHmmInto(ctx, hmmFiles[hmmType])
+            batch, stagedSam, _ = stageSamFile(self.samFile, self.referenceFastaFile, ANALYSIS_SPLIT_MATRIX_BIGGER_THAN,
+                                               mode=realign.MODE_ALL_POSTERIORS, ctx=ctx, maxPairsPerBase=48)
+            stagedSam.close()
+            batch.run()
+            batch.finish()
+            status = batch.results()["status"]
+            for aR, st in zip(records, status):
+                if st != 0:
+                    raise RuntimeError("Posterior computation failed for %s: status %d" % (aR.qname, st))
+            refLengths = [len(refSequences[n]) for n in refNames]
+            refRows = np.concatenate([[0], np.cumsum(refLengths)])
             for coverage in self.coverages:
                 for replicate in range(3 if coverage < 1000000 else 1):
                     order = list(range(len(records)))
                     rng.shuffle(order)  # :91
-                    expectations = [np.zeros((len(refSequences[n]), 4)) for n in refNames]
                     frequencies = [np.zeros((len(refSequences[n]), 4)) for n in refNames]
-                    seenE = [np.zeros(len(refSequences[n]), dtype=bool) for n in refNames]
                     seenF = [np.zeros(len(refSequences[n]), dtype=bool) for n in refNames]
                     totalSampledReads = totalAlignedPairs = totalReadLength = 0
+                    sampled = np.zeros(len(records), dtype=np.uint8)
                     for i in order:
                         if totalReadLength / totalReferenceLength >= coverage:  # :94
                             break
@@ -173,10 +179,10 @@ class MarginAlignSnpCaller(AbstractAnalysis):
                         seenF[k][pos] = True
                         ok = code >= 0
                         np.add.at(frequencies[k], (pos[ok], code[ok]), 1.0)
-                        x, c, p = posteriors[i]
-                        seenE[k][x] = True
-                        ok = c >= 0
-                        np.add.at(expectations[k], (x[ok], c[ok]), p[ok])
+                        sampled[i] = 1
+                    allE, allSeen = batch.base_expectations(refLengths, use=sampled)
+                    expectations = [allE[refRows[k]:refRows[k + 1]] for k in range(len(refNames))]
+                    seenE = [allSeen[refRows[k]:refRows[k + 1]] for k in range(len(refNames))]
                     totalHeldOut = len(snpSet)
                     totalNotHeldOut = totalReferenceLength - totalHeldOut
                     callSets = [SnpCalls(totalHeldOut) for _ in range(4)]
@@ -220,6 +226,7 @@ class MarginAlignSnpCaller(AbstractAnalysis):
                             "optimumProbThreshold": str(float(pIndex) / 100.0), "totalNoCalls": str(snpCalls.notCalled),
                             "recallByProbability": " ".join(map(str, recall)),
                             "precisionByProbability": " ".join(map(str, precision))})
+            batch.close()
         sam.close()
         with open(os.path.join(self.outputDir, "marginaliseConsensus.xml"), "w") as fh:
             fh.write(prettyXml(node))

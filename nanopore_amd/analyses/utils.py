@@ -143,29 +143,24 @@ def _blockCoordinates(aR, refSeq, readSeq):
 
 
 def chainFn(alignedReads, refSeq, readSeq, scoreFn=None, maxGap=200):
-    """Highest-scoring co-linear chain of local alignments on one strand; score = number of aligned pairs;
-    two blocks chain when the second starts after the first ends in both sequences and the summed gap is at
-    most maxGap (utils.py:388-426; quadratic, like the reference)."""
-    coords = {id(aR): _blockCoordinates(aR, refSeq, readSeq) for aR in alignedReads}
-    own = {id(aR): (scoreFn(aR, refSeq, readSeq) if scoreFn else coords[id(aR)][4]) for aR in alignedReads}
-    best = dict(own)
-    back = {}
-    order = sorted(alignedReads, key=lambda aR: coords[id(aR)][0])
-    for i, aR in enumerate(order):
-        rStart, qStart, _, _, _ = coords[id(aR)]
-        for aR2 in order[:i]:
-            _, _, rEnd2, qEnd2, _ = coords[id(aR2)]
-            if (rStart > rEnd2 and qStart > qEnd2 and aR.is_reverse == aR2.is_reverse
-                    and rStart - rEnd2 + qStart - qEnd2 <= maxGap and own[id(aR)] + best[id(aR2)] > best[id(aR)]):
-                best[id(aR)] = own[id(aR)] + best[id(aR2)]
-                back[id(aR)] = aR2
-    aR = sorted(order, key=lambda a: best[id(a)])[-1]
-    chain = [aR]
-    while id(aR) in back:
-        aR = back[id(aR)]
-        chain.append(aR)
-    chain.reverse()
-    return chain
+    """Highest-scoring co-linear chain of local alignments on one strand; score = number of aligned pairs; two blocks
+    chain when the second starts after the first ends in both sequences and the summed gap is at most maxGap
+    (utils.py:388-426).  The scan itself is native (include/nprealign.h: npr_chain_hits -- sort + windowed scan instead of
+    the reference's all-pairs loop, same chain, ties included)."""
+    import numpy as np
+    from .. import _lib
+    alignedReads = list(alignedReads)
+    coords = [_blockCoordinates(aR, refSeq, readSeq) for aR in alignedReads]
+    n = len(alignedReads)
+    col = lambda k: np.ascontiguousarray([c[k] for c in coords], dtype=np.int64)  # noqa: E731
+    score = np.ascontiguousarray([scoreFn(aR, refSeq, readSeq) for aR in alignedReads] if scoreFn else [c[4] for c in coords], dtype=np.int64)
+    reverse = np.ascontiguousarray([1 if aR.is_reverse else 0 for aR in alignedReads], dtype=np.uint8)
+    chain = np.zeros(max(n, 1), dtype=np.int64)
+    k = _lib.load().npr_chain_hits(n, _lib.ptr(col(0)), _lib.ptr(col(1)), _lib.ptr(col(2)), _lib.ptr(col(3)), _lib.ptr(reverse), _lib.ptr(score),
+                                   maxGap, _lib.ptr(chain))
+    if k < 0:
+        raise _lib.NprError(int(k), "npr_chain_hits")
+    return [alignedReads[int(i)] for i in chain[:k]]
 
 
 def mergeChainedAlignedReads(chainedAlignedReads, refSequence, readSequence):
@@ -338,7 +333,7 @@ def realignSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, hm
 EM_SPLIT_MATRIX_BIGGER_THAN = 300  # options.optionsToRealign, utils.py:511
 
 
-def stageSamFile(samFile, referenceFastaFile, splitThreshold, gapGamma=0.5, matchGamma=0.0, mode=None, ctx=None):
+def stageSamFile(samFile, referenceFastaFile, splitThreshold, gapGamma=0.5, matchGamma=0.0, mode=None, ctx=None, maxPairsPerBase=0):
     """Stages every record of a chained SAM file on the GPU (band planning + upload); returns (batch, sam, records)."""
     from .. import realign
     ctx = ctx or _context()
@@ -350,9 +345,9 @@ def stageSamFile(samFile, referenceFastaFile, splitThreshold, gapGamma=0.5, matc
     params = realign.make_params(band_mode=realign.BAND_ANCHOR, diagonal_expansion=REALIGN_DIAGONAL_EXPANSION,
                                  constraint_trim=CONSTRAINT_DIAGONAL_TRIM, split_threshold=splitThreshold,
                                  gap_gamma=gapGamma, match_gamma=matchGamma,
-                                 mode=realign.MODE_REALIGN if mode is None else mode)
+                                 mode=realign.MODE_REALIGN if mode is None else mode, max_pairs_per_base=maxPairsPerBase)
     batch = ctx.stage(params, [refSequences[n] for n in names], [aR.query for aR in records], [_guideOf(aR) for aR in records],
-                      ref_index=[index[sam.getrname(aR.rname)] for aR in records])
+                      ref_index=[index[sam.getrname(aR.rname)] for aR in records], guide_start=[(aR.pos, 0) for aR in records])
     return batch, sam, records
 
 

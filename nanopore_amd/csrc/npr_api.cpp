@@ -210,6 +210,7 @@ struct npr_batch {
     // host copies needed by finish()
     std::vector<int64_t> ref_len, read_len;  // spans of the guide's window
     std::vector<int64_t> gstart;             // per read: first reference / read position of the window
+    std::vector<int32_t> ref_id;             // per read: its reference sequence
     std::vector<int32_t> guide_ops;
     std::vector<int64_t> guide_off;
     std::vector<int32_t> read_status;    // planning status per read
@@ -512,6 +513,8 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     b->read_len.resize(n_reads);
     b->read_status.assign(n_reads, NPR_OK);
     b->gstart.assign(2 * n_reads, 0);
+    b->ref_id.resize(n_reads);
+    for (int64_t i = 0; i < n_reads; ++i) b->ref_id[i] = static_cast<int32_t>(ref_of(i));
     b->read_first_task.assign(n_reads, 0);
     b->read_ntasks.assign(n_reads, 0);
     b->guide_off.assign(guide_off, guide_off + (n_reads ? n_reads + 1 : 0));
@@ -1767,6 +1770,54 @@ int64_t npr_batch_plan_check(npr_batch *b) {
         return mismatches;
     } catch (const std::exception &) {
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_plan_check: out of host memory");
+    }
+}
+
+int32_t npr_batch_base_expectations(npr_batch *b, const uint8_t *use, int64_t n_refs, const int64_t *ref_len, double *expect, uint8_t *seen) {
+    if (!b || n_refs < 0 || (n_refs && !ref_len) || !expect || !seen) return NPR_ERR_INVALID;
+    if (!b->finished) return NPR_ERR_STATE;
+    npr_ctx *ctx = b->ctx;
+    try {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        std::vector<int64_t> base(n_refs + 1, 0);
+        for (int64_t k = 0; k < n_refs; ++k) {
+            if (ref_len[k] < 0) return NPR_ERR_INVALID;
+            base[k + 1] = base[k] + ref_len[k];
+        }
+        const int64_t rows = base[n_refs], n = b->n_reads, ntasks = static_cast<int64_t>(b->tasks.size());
+        std::fill(expect, expect + 4 * rows, 0.0);
+        std::fill(seen, seen + rows, uint8_t(0));
+        if (!ntasks || !rows) return NPR_OK;
+        std::vector<int64_t> target(n, 0);
+        std::vector<uint8_t> mask(n, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t k = b->ref_id[i];
+            const bool ok = b->results[i].status == NPR_OK && (!use || use[i]) && k >= 0 && k < n_refs &&
+                            b->gstart[2 * i] + b->ref_len[i] <= ref_len[k];
+            if (use && use[i] && !ok && b->results[i].status == NPR_OK) return fail(ctx, NPR_ERR_INVALID, "npr_batch_base_expectations: a read's window does not fit its reference");
+            mask[i] = ok ? 1 : 0;
+            target[i] = ok ? base[k] + b->gstart[2 * i] : 0;
+        }
+        DevBuf<double> d_e;
+        DevBuf<uint8_t> d_seen, d_use;
+        DevBuf<int64_t> d_target;
+        hipError_t e;
+        if ((e = d_e.alloc(4 * rows)) != hipSuccess || (e = d_seen.alloc(rows)) != hipSuccess || (e = d_use.alloc(n)) != hipSuccess ||
+            (e = d_target.alloc(n)) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_base_expectations: hipMalloc", e);
+        HIP_TRY(ctx, hipMemsetAsync(d_e.p, 0, d_e.bytes(), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_seen.p, 0, d_seen.bytes(), ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_use.p, mask.data(), d_use.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_target.p, target.data(), d_target.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        ExpectArgs a{b->d_tasks.p, b->d_outs.p, static_cast<int32_t>(ntasks), b->d_px.p, b->d_py.p, b->d_pp.p, b->d_seq.p, d_use.p, d_target.p, d_e.p, d_seen.p};
+        const int rc = launch_base_expectations(a, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_base_expectations launch", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipMemcpyAsync(expect, d_e.p, d_e.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(seen, d_seen.p, d_seen.bytes(), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return NPR_OK;
+    } catch (const std::exception &) {
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_base_expectations: out of host memory");
     }
 }
 

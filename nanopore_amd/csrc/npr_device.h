@@ -207,6 +207,19 @@ struct StatsArgs {
     int32_t *out;            // [n_reads][NPR_STATS_WORDS]
 };
 int launch_align_stats(const StatsArgs &a, void *stream);
+struct ExpectArgs {
+    const Task *tasks;
+    const TaskOut *outs;
+    int32_t ntasks;
+    const int32_t *px, *py;
+    const float *pp;
+    const uint8_t *seq;
+    const uint8_t *use;     // per read: 0 = skip (NULL: all reads)
+    const int64_t *target;  // per read: table row of reference position 0 of its window
+    double *expect;         // [positions][4]
+    uint8_t *seen;          // [positions]
+};
+int launch_base_expectations(const ExpectArgs &a, void *stream);
 size_t mea_chain_lds_bytes(int ring);
 int launch_mea_sort(const MeaArgs &a, void *stream);
 int launch_mea_chain(const MeaArgs &a, void *stream);

@@ -122,7 +122,33 @@ __global__ void __launch_bounds__(WAVE) k_align_stats(StatsArgs a) {
     }
 }
 
+// Expected base counts per reference position (nanopore/analyses/marginAlignSnpCaller.py:150-155): every
+// posterior pair (x, y, p) of a selected read adds p to the count of the read's base y at reference position x.  The pairs
+// are where the DP kernels left them; a workgroup takes a task, its threads the task's pairs; fp64 atomics into a table of
+// 4 counts per reference position, plus a byte that says the position was seen at all.
+__global__ void __launch_bounds__(256) k_base_expectations(ExpectArgs a) {
+    for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
+        const Task &tk = a.tasks[t];
+        const int r = tk.read;
+        if (a.use && !a.use[r]) continue;
+        const int n = min(a.outs[t].npairs, tk.pair_cap);
+        const int64_t target = a.target[r];  // table row of the window's first reference position
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
+            const int code = a.seq[tk.y_off + (y - tk.ys)];
+            a.seen[target + x] = 1;
+            if (code < 4) atomicAdd(a.expect + 4 * (target + x) + code, static_cast<double>(a.pp[tk.pair_off + i]));
+        }
+    }
+}
+
 }  // namespace
+
+int launch_base_expectations(const ExpectArgs &a, void *stream) {
+    const int grid = a.ntasks < 8192 ? (a.ntasks > 0 ? a.ntasks : 1) : 8192;
+    hipLaunchKernelGGL(k_base_expectations, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return static_cast<int>(hipGetLastError());
+}
 
 int launch_align_stats(const StatsArgs &a, void *stream) {
     const int grid = a.n_reads < 16384 ? (a.n_reads > 0 ? a.n_reads : 1) : 16384;

@@ -125,6 +125,19 @@ class Batch(object):
             raise NprError(rc, "npr_batch_pairs")
         return off, x, y, p
 
+    def base_expectations(self, ref_lengths, use=None):
+        """Posterior-weighted base counts per reference position of the (selected) reads, scattered on the device
+        (include/nprealign.h: npr_batch_base_expectations): (expect[sum(ref_lengths), 4], seen[sum(ref_lengths)])."""
+        ref_lengths = np.ascontiguousarray(ref_lengths, dtype=np.int64)
+        rows = int(ref_lengths.sum())
+        expect = np.zeros((rows, 4), dtype=np.float64)
+        seen = np.zeros(rows, dtype=np.uint8)
+        u = None if use is None else np.ascontiguousarray(use, dtype=np.uint8)
+        rc = self._L.npr_batch_base_expectations(self._h, ptr(u), len(ref_lengths), ptr(ref_lengths), ptr(expect), ptr(seen))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_base_expectations", self.ctx.last_error())
+        return expect, seen.astype(bool)
+
     def plan_check(self):
         """Tasks whose device-made band rows / schedules / stripe tables differ from the host planner's (test aid;
         include/nprealign.h: npr_batch_plan_check)."""

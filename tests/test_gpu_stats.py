@@ -224,3 +224,38 @@ def test_statistics_of_a_realigned_batch_where_it_lies(gpu_ctx, monkeypatch):
             read = bytes(w["read"][w["read_off"][i]:w["read_off"][i + 1]]).decode()
             want = _count_by_hand(ref, read, [(int(a), int(c)) for a, c in ops[off[i]:off[i + 1]]], 0, 0)
             assert np.array_equal(tables[0][i].astype(np.int64), want), i
+
+
+def test_posterior_scatter_add_on_the_device_equals_numpy(gpu_ctx):
+    """npr_batch_base_expectations (marginAlignSnpCaller.py:150-155 on the device) against np.add.at over the same pairs,
+    with a read selection, shared references and windows that start inside the reference."""
+    from helpers import MODEL_DIR, load_model_arrays
+    from nanopore_amd import realign as R, synth
+    from nanopore_amd.hmm import Hmm
+    T, E, _ = load_model_arrays()
+    gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
+    w, W = synth.config_c3_shared(T, E, n_reads=96, genome_len=60000)
+    reads = w["read"].copy()
+    reads[::37] = ord("N")                                       # bases outside ACGT add nothing
+    P = R.make_params(band_mode=R.BAND_ANCHOR, split_threshold=100, mode=R.MODE_ALL_POSTERIORS, max_pairs_per_base=48)
+    b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], reads, w["read_off"], w["guide_ops"], w["guide_off"], ref_index=w["ref_index"],
+                          guide_start=w["guide_start"])
+    b.run(), b.finish()
+    assert (b.results()["status"] == 0).all()
+    poff, px, py, pp = b.pairs()
+    rng = np.random.default_rng(5)
+    for use in (None, (rng.random(96) < 0.5).astype(np.uint8), np.zeros(96, dtype=np.uint8)):
+        got, seen = b.base_expectations([60000], use=use)
+        want = np.zeros((60000, 4))
+        wseen = np.zeros(60000, dtype=bool)
+        for i in range(96):
+            if use is not None and not use[i]:
+                continue
+            x, y, p = px[poff[i]:poff[i + 1]].astype(np.int64), py[poff[i]:poff[i + 1]].astype(np.int64), pp[poff[i]:poff[i + 1]].astype(np.float64)
+            code = np.array([b"ACGT".find(bytes([c])) for c in reads[w["read_off"][i] + y]])
+            wseen[x] = True
+            ok = code >= 0
+            np.add.at(want, (x[ok], code[ok]), p[ok])
+        assert np.array_equal(seen, wseen)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, want.max()) * 50 and (got.sum() > 0) == (want.sum() > 0)
+    b.close()
