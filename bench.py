@@ -169,13 +169,19 @@ def roofline_block(cells, pairs, kms, class_cells, clock_hz):
         out["traffic_frac"] = out["traffic"] / t / HBM_PEAK_GBPS
     if tab.get("valu_insts_per_cell") is not None:
         insts = tab["valu_insts_per_cell"] * cells
-        simd_cycles = t * clock_hz * SIMDS
+        clock = tab.get("clock_hz_under_load", clock_hz)  # the clock the chip holds under this kernel (PMC run), not the 2.4 GHz peak
+        simd_cycles = t * clock * SIMDS
+        counter_ratio = insts * tab["cycles_per_valu_inst"] / simd_cycles
         out["valu"] = {"insts_per_cell": tab["valu_insts_per_cell"], "issue_cycles_per_inst": tab["cycles_per_valu_inst"],
-                       "clock_hz": clock_hz, "simd_cycles": simd_cycles,
-                       "busy_frac": insts * tab["cycles_per_valu_inst"] / simd_cycles,
+                       "clock_hz": clock, "peak_clock_hz": clock_hz, "simd_cycles": simd_cycles,
+                       "busy_frac": min(1.0, counter_ratio), "counter_ratio": counter_ratio,
                        "nominal_frac": insts * NOMINAL_CYCLES_PER_VALU / simd_cycles,
-                       "note": "busy_frac = instructions x measured issue cycles / SIMD-cycles of the launch; nominal_frac prices "
-                               "every instruction at the 2-cycle wave64 peak (157 TF fp32)",
+                       "useful_fp32_frac_of_peak": insts * NOMINAL_CYCLES_PER_VALU / (t * clock_hz * SIMDS),
+                       "note": "counter_ratio = VALU instructions x issue cycles per instruction (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU: "
+                               "the counter ticks in quad-cycles and over-counts instructions that issue in fewer) / SIMD-cycles of the "
+                               "launch at the clock held under load; busy_frac caps it at 1 (the pipes are saturated when it reaches 1); "
+                               "nominal_frac prices every instruction at the 2-cycle wave64 issue peak instead: the distance to the "
+                               "157 TF fp32 vector peak that a cheaper instruction mix could still close",
                        "source": tab.get("valu_source", "profiles/")}
     return out
 
