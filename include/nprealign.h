@@ -291,6 +291,11 @@ int64_t npr_chain_hits(int64_t n, const int64_t *ref_start, const int64_t *read_
  * out[str_off[i] .. str_off[i+1]) (no terminator; "*" for an empty list).  out == NULL: only the offsets; returns the
  * total length, NPR_ERR_CAPACITY when cap is smaller, NPR_ERR_INVALID for an op outside M/I/D.  Threaded. */
 int64_t npr_format_cigars(int64_t n, const int64_t *ops_off, const int32_t *ops, int64_t *str_off, char *out, int64_t cap);
+/* The same from packed cigars, one 32-bit word per operation (length << 2 | op -- the form the ranks of a sharded job send
+ * to rank 0, nanopore_amd/dist.py): list i = words[word_off[i] .. word_off[i] + n_ops[i]), the lists in any order and
+ * anywhere in `words`, so the gathered payloads need no merge copy before the SAM is written. */
+int64_t npr_format_cigars_packed(int64_t n, const int64_t *word_off, const int64_t *n_ops, const uint32_t *words, int64_t *str_off,
+                                 char *out, int64_t cap);
 /* ASCII -> base codes 0..4 (A,C,G,T,N) */
 void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes);
 

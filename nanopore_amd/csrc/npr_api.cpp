@@ -72,6 +72,20 @@ struct npr_ctx {
     // bumped whenever the scratch a finished batch left its device-side cigars in may be overwritten (a DP launch, a
     // device MEA stage): npr_batch_align_stats uses the resident cigars only while the batch's stamp is current
     uint64_t scratch_epoch = 1;
+    // Device buffers of destroyed batches, kept for the next batch (DevBuf::alloc_from): hipMalloc / hipFree of the
+    // gigabyte-sized band, control-word and pair arrays cost more than the kernels that fill them (0.1 s per batch of
+    // 50 k reads), and a pipeline stages batch after batch of the same shape.
+    struct Cached {
+        void *p;
+        size_t bytes;
+    };
+    std::vector<Cached> cache;
+    size_t cache_bytes = 0;
+    void cache_flush() {
+        for (const Cached &c : cache) (void)hipFree(c.p);
+        cache.clear();
+        cache_bytes = 0;
+    }
 };
 
 namespace {
@@ -87,9 +101,16 @@ struct DevBuf {
         return hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
     }
     void release() {
-        if (p && !borrowed) (void)hipFree(p);
+        if (p && !borrowed) {
+            if (owner && owner->cache.size() < 48) {
+                owner->cache.push_back(npr_ctx::Cached{p, held});
+                owner->cache_bytes += held;
+            } else {
+                (void)hipFree(p);
+            }
+        }
         p = nullptr;
-        count = 0, cap = 0, borrowed = false;
+        count = 0, cap = 0, borrowed = false, owner = nullptr, held = 0;
     }
     // a view of memory owned elsewhere (the forward scratch arena, idle between the DP launch and the next one)
     bool borrowed = false;
@@ -98,6 +119,35 @@ struct DevBuf {
         p = ptr, count = n, borrowed = true;
     }
     size_t bytes() const { return count * sizeof(T); }
+    // a buffer from the context's cache of released ones (the smallest that fits without wasting more than half), else a
+    // fresh one; it goes back to the cache when released
+    npr_ctx *owner = nullptr;
+    size_t held = 0;
+    hipError_t alloc_from(npr_ctx *ctx, size_t n) {
+        release();
+        count = n;
+        if (n == 0) return hipSuccess;
+        const size_t need = n * sizeof(T);
+        if (need < (size_t(1) << 20)) return hipMalloc(reinterpret_cast<void **>(&p), need);  // small ones are cheap
+        int best = -1;
+        for (size_t i = 0; i < ctx->cache.size(); ++i)
+            if (ctx->cache[i].bytes >= need && ctx->cache[i].bytes <= 2 * need && (best < 0 || ctx->cache[i].bytes < ctx->cache[best].bytes)) best = static_cast<int>(i);
+        if (best >= 0) {
+            p = static_cast<T *>(ctx->cache[best].p), held = ctx->cache[best].bytes, owner = ctx;
+            ctx->cache_bytes -= held;
+            ctx->cache.erase(ctx->cache.begin() + best);
+            return hipSuccess;
+        }
+        const size_t take = need + need / 8;  // a little headroom: the next batch of the same shape differs by a few percent
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), take);
+        if (e != hipSuccess && !ctx->cache.empty()) {
+            (void)hipGetLastError();
+            ctx->cache_flush();
+            e = hipMalloc(reinterpret_cast<void **>(&p), take);
+        }
+        if (e == hipSuccess) held = take, owner = ctx;
+        return e;
+    }
     // grow-only use (scratch kept from batch to batch): count is the size asked for, cap what is allocated
     hipError_t reserve(size_t n) {
         if (n <= cap && p) {
@@ -354,6 +404,7 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
 void npr_destroy(npr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    ctx->cache_flush();
     if (ctx->d_models) (void)hipFree(ctx->d_models);
     if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
     if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
@@ -464,7 +515,7 @@ int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads
 static int32_t ensure_coff(npr_batch *b) {
     npr_ctx *ctx = b->ctx;
     if (b->d_coff.p || b->d_lo.count == 0) return NPR_OK;
-    const hipError_t e = b->d_coff.alloc(b->d_lo.count);
+    const hipError_t e = b->d_coff.alloc_from(ctx, b->d_lo.count);
     if (e != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "generic row offsets: hipMalloc", e);
     CoffArgs ca{static_cast<int32_t>(b->d_pseg.count), b->d_pseg.p, b->d_n.p, b->d_coff.p};
     const int rc = launch_plan_coff(ca, ctx->stream);
@@ -627,8 +678,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // 3. device: band rows of every anti-diagonal, per-segment summaries
     DevBuf<PlanPoint> d_points;
     DevBuf<SegSummary> d_summary;
-    if ((e = d_points.alloc(npoints)) != hipSuccess || (e = b->d_pseg.alloc(ntasks)) != hipSuccess || (e = d_summary.alloc(ntasks)) != hipSuccess ||
-        (e = b->d_lo.alloc(band_entries)) != hipSuccess || (e = b->d_n.alloc(band_entries)) != hipSuccess || (e = b->d_seq.alloc(seq_bytes + 16)) != hipSuccess)
+    if ((e = d_points.alloc_from(ctx, npoints)) != hipSuccess || (e = b->d_pseg.alloc(ntasks)) != hipSuccess || (e = d_summary.alloc(ntasks)) != hipSuccess ||
+        (e = b->d_lo.alloc_from(ctx, band_entries)) != hipSuccess || (e = b->d_n.alloc_from(ctx, band_entries)) != hipSuccess ||
+        (e = b->d_seq.alloc_from(ctx, seq_bytes + 16)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     std::vector<SegSummary> summary(ntasks);
     if (ntasks) {
@@ -679,7 +731,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     }
     std::vector<int32_t> sched_cls(ntasks, -1);
     std::vector<int64_t> sched_cells(ntasks, 0);
-    if ((e = b->d_ctl.alloc(2 * ctl_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    if ((e = b->d_ctl.alloc_from(ctx, 2 * ctl_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     if (ctl_entries) {
         DevBuf<uint32_t> d_cand;
         DevBuf<int64_t> d_off, d_cells;
@@ -720,7 +772,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // k_dp_tile tasks are ordered by the forward scratch they need (one row per anti-diagonal of a stripe: also what a
     // task costs): a workgroup's region is sized by its FIRST task, every later one from the queue is smaller
     std::vector<int64_t> tile_need(ntasks, 0);
-    if ((e = b->d_stripes.alloc(stripe_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    if ((e = b->d_stripes.alloc_from(ctx, stripe_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     if (!tile_list.empty()) {
         DevBuf<int32_t> d_list;
         DevBuf<int64_t> d_toff, d_rows;
@@ -800,7 +852,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
     // (sequences, band rows, control words and stripe tables are allocated already)
     const int64_t fixed = pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut)) + (any_generic ? 0 : band_entries * 4);
-    const int64_t budget = static_cast<int64_t>((free_b + ctx->arena_cells * 8) * 0.9) - fixed;
+    const int64_t budget = static_cast<int64_t>((free_b + ctx->cache_bytes + ctx->arena_cells * 8) * 0.9) - fixed;
     int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
         fit = budget / (b->slot_stride * 8);
@@ -910,16 +962,21 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
         (e = b->d_queue.alloc(kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess ||
         (e = b->d_region.alloc(region.size())) != hipSuccess ||
-        (e = b->d_px.alloc(pair_total)) != hipSuccess ||
-        (e = b->d_py.alloc(pair_total)) != hipSuccess || (e = b->d_pp.alloc(pair_total)) != hipSuccess)
+        (e = b->d_px.alloc_from(ctx, pair_total)) != hipSuccess ||
+        (e = b->d_py.alloc_from(ctx, pair_total)) != hipSuccess || (e = b->d_pp.alloc_from(ctx, pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     // (at least one uniform region: npr_batch_dense and the generic E-step run any task there)
     b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(std::max<int64_t>(sum_grid, ntasks ? 1 : 0)) + static_cast<size_t>(tile_total);
     if (b->scratch_cells > ctx->arena_cells) {
         if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
         ctx->arena_F = nullptr, ctx->arena_cells = 0;
-        if ((e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8 + 2 * npr_ctx::kArenaPad)) == hipSuccess)
-            ctx->arena_F += npr_ctx::kArenaPad;
+        e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8 + 2 * npr_ctx::kArenaPad);
+        if (e != hipSuccess && !ctx->cache.empty()) {  // the buffers kept from earlier batches are in the way
+            (void)hipGetLastError();
+            ctx->cache_flush();
+            e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8 + 2 * npr_ctx::kArenaPad);
+        }
+        if (e == hipSuccess) ctx->arena_F += npr_ctx::kArenaPad;
         if (e != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc of the forward scratch", e);
         ctx->arena_cells = b->scratch_cells;
@@ -1062,8 +1119,8 @@ int32_t fetch_pairs(npr_batch *b) {
         DevBuf<int32_t> d_cx, d_cy;
         DevBuf<float> d_cp;
         hipError_t e;
-        if ((e = d_dst.alloc(ntasks + 1)) != hipSuccess || (e = d_cx.alloc(total)) != hipSuccess ||
-            (e = d_cy.alloc(total)) != hipSuccess || (e = d_cp.alloc(total)) != hipSuccess)
+        if ((e = d_dst.alloc(ntasks + 1)) != hipSuccess || (e = d_cx.alloc_from(ctx, total)) != hipSuccess ||
+            (e = d_cy.alloc_from(ctx, total)) != hipSuccess || (e = d_cp.alloc_from(ctx, total)) != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc", e);
         HIP_TRY(ctx, hipMemcpyAsync(d_dst.p, dst.data(), d_dst.bytes(), hipMemcpyHostToDevice, ctx->stream));
         CompactArgs ca{b->d_tasks.p, b->d_outs.p, d_dst.p, static_cast<int32_t>(ntasks), b->d_px.p, b->d_py.p, b->d_pp.p, d_cx.p, d_cy.p, d_cp.p};
@@ -1997,19 +2054,24 @@ int32_t npr_rescore(const int32_t *guide_ops, int64_t n_guide_ops, const int32_t
     return NPR_OK;
 }
 
-int64_t npr_format_cigars(int64_t n, const int64_t *ops_off, const int32_t *ops, int64_t *str_off, char *out, int64_t cap) {
-    if (n < 0 || (n && (!ops_off || !str_off)) || (n && ops_off[n] > 0 && !ops)) return NPR_ERR_INVALID;
+}  // extern "C"
+
+namespace {
+// cigar text of n op lists; op q of list i is get(i, q) -> (code, length)
+template <typename Count, typename Get>
+int64_t format_cigars(int64_t n, Count count, Get get, int64_t *str_off, char *out, int64_t cap) {
     static const char code[3] = {'M', 'I', 'D'};
-    auto digits = [](int32_t v) { int k = 1; while (v >= 10) v /= 10, ++k; return k; };
+    auto digits = [](int64_t v) { int k = 1; while (v >= 10) v /= 10, ++k; return k; };
     const int threads = usable_cpus();
     std::vector<int64_t> len(n);
     std::atomic<int> bad{0};
     parallel_for((n + 255) / 256, threads, [&](int64_t c) {
         for (int64_t i = c * 256, hi = std::min(n, (c + 1) * 256); i < hi; ++i) {
             int64_t k = 0;
-            for (int64_t q = ops_off[i]; q < ops_off[i + 1]; ++q) {
-                if (ops[2 * q] < 0 || ops[2 * q] > 2 || ops[2 * q + 1] < 0) bad = 1;
-                k += digits(ops[2 * q + 1]) + 1;
+            for (int64_t q = 0, m = count(i); q < m; ++q) {
+                const std::pair<int32_t, int64_t> o = get(i, q);
+                if (o.first < 0 || o.first > 2 || o.second < 0) bad = 1;
+                k += digits(o.second) + 1;
             }
             len[i] = k ? k : 1;  // an empty cigar is "*"
         }
@@ -2022,17 +2084,47 @@ int64_t npr_format_cigars(int64_t n, const int64_t *ops_off, const int32_t *ops,
     parallel_for((n + 255) / 256, threads, [&](int64_t c) {
         for (int64_t i = c * 256, hi = std::min(n, (c + 1) * 256); i < hi; ++i) {
             char *w = out + str_off[i];
-            if (ops_off[i + 1] == ops_off[i]) *w = '*';
-            for (int64_t q = ops_off[i]; q < ops_off[i + 1]; ++q) {
-                int32_t v = ops[2 * q + 1];
+            const int64_t m = count(i);
+            if (m == 0) *w = '*';
+            for (int64_t q = 0; q < m; ++q) {
+                const std::pair<int32_t, int64_t> o = get(i, q);
+                int64_t v = o.second;
                 const int k = digits(v);
                 for (int j = k - 1; j >= 0; --j) w[j] = static_cast<char>('0' + v % 10), v /= 10;
-                w[k] = code[ops[2 * q]];
+                w[k] = code[o.first];
                 w += k + 1;
             }
         }
     });
     return str_off[n];
+}
+}  // namespace
+
+extern "C" {
+
+int64_t npr_format_cigars(int64_t n, const int64_t *ops_off, const int32_t *ops, int64_t *str_off, char *out, int64_t cap) {
+    if (n < 0 || (n && (!ops_off || !str_off)) || (n && ops_off[n] > 0 && !ops)) return NPR_ERR_INVALID;
+    try {
+        return format_cigars(n, [&](int64_t i) { return ops_off[i + 1] - ops_off[i]; },
+                             [&](int64_t i, int64_t q) { return std::pair<int32_t, int64_t>(ops[2 * (ops_off[i] + q)], ops[2 * (ops_off[i] + q) + 1]); }, str_off, out, cap);
+    } catch (const std::exception &) {
+        return NPR_ERR_NOMEM;
+    }
+}
+
+int64_t npr_format_cigars_packed(int64_t n, const int64_t *word_off, const int64_t *n_ops, const uint32_t *words, int64_t *str_off, char *out,
+                                 int64_t cap) {
+    if (n < 0 || (n && (!word_off || !n_ops || !str_off || !words))) return NPR_ERR_INVALID;
+    try {
+        return format_cigars(n, [&](int64_t i) { return n_ops[i]; },
+                             [&](int64_t i, int64_t q) {
+                                 const uint32_t w = words[word_off[i] + q];
+                                 return std::pair<int32_t, int64_t>(static_cast<int32_t>(w & 3u), static_cast<int64_t>(w >> 2));
+                             },
+                             str_off, out, cap);
+    } catch (const std::exception &) {
+        return NPR_ERR_NOMEM;
+    }
 }
 
 void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes) {

@@ -80,62 +80,83 @@ __global__ void __launch_bounds__(BAND_THREADS) k_plan_bands(PlanArgs a) {
     }
 }
 
-// One wavefront per segment.  The schedule is a sequential scan (every rebase depends on all steps before it), so one lane
-// walks it -- but through LDS: the lanes load 64 band rows at a time and write the 64 finished control-word pairs back
-// together, and the walking lane never touches memory (a lane per segment streaming its own rows took 47 ms for the
-// default bench batch; this takes a few).
+// The schedule is a sequential scan per segment (every rebase depends on all steps before it), so the parallelism is ACROSS
+// segments: a wavefront takes 16 of them and 16 of its lanes walk them in lockstep.  What a walking lane needs -- its own
+// segment's band rows, one after the other -- is the worst pattern for memory, so the rows go through LDS: for every tile
+// of 31 anti-diagonals all 64 lanes load the 32 rows (31 + the one looked ahead) of two segments per instruction, eight
+// independent instructions per tile; the finished control words go back the same way, coalesced.  Few walking lanes per
+// wavefront on purpose: the walk is a chain of dependent integer operations, what hides its latency is the number of
+// wavefronts, not their width.  (One lane per segment straight from memory: 47 ms for the 12288 reads of the default bench;
+// one wavefront per segment on the scalar unit: 40 ms -- a CU issues one scalar instruction per cycle whatever its
+// occupancy; 64 segments per wavefront: 28 ms.)
+constexpr int SCHED_TILE = 31, SCHED_SEGS = 16;
 __global__ void __launch_bounds__(64) k_plan_sched(SchedArgs a) {
-    __shared__ int t_lo[65], t_n[65];
-    __shared__ uint32_t t_w[128];
-    __shared__ int t_ok;
-    __shared__ unsigned int t_off;
-    __shared__ int t_flo;
+    __shared__ int t_lo[SCHED_SEGS][SCHED_TILE + 2], t_n[SCHED_SEGS][SCHED_TILE + 2];  // (row stride 33: conflict-free walks)
+    __shared__ uint32_t t_w0[SCHED_SEGS][SCHED_TILE + 2], t_w1[SCHED_SEGS][SCHED_TILE + 2];
     const int lane = threadIdx.x;
-    for (int g = blockIdx.x; g < a.n_segs; g += gridDim.x) {
-        const PlanSeg sg = a.segs[g];
+    const int half = lane >> 5, row = lane & 31;
+    for (int g0 = blockIdx.x * SCHED_SEGS; g0 < a.n_segs; g0 += gridDim.x * SCHED_SEGS) {
+        const int g = g0 + lane;
+        const bool have = lane < SCHED_SEGS && g < a.n_segs;
+        PlanSeg sg{};
+        if (have) sg = a.segs[g];
+        const int64_t ctl_off = have ? a.ctl_off[g] : -1;
+        const uint32_t cand = (have && ctl_off >= 0 && a.summary[g].bad == 0) ? a.cand[g] : 0u;
+        const int max_width = have ? a.summary[g].max_width : 0;
+        const int D = sg.lX + sg.lY;
         int cls = -1;
-        int64_t cells = 0;
-        if (a.ctl_off[g] >= 0 && a.summary[g].bad == 0) {
-            const int32_t *lo = a.lo + sg.band_off, *n = a.n + sg.band_off;
-            uint32_t *ctl = a.ctl + 2 * a.ctl_off[g];
-            const int D = sg.lX + sg.lY;
-            for (int c = 0; c < kSchedClasses && cls < 0; ++c) {
-                if (!((a.cand[g] >> c) & 1u)) continue;
-                const int R = kSchedR[c], NW = kSchedNW[c], rshift = stair_rshift(R), C = 64 * R * NW;
-                __syncthreads();
-                if (lane == 0) {
-                    StairState st;
-                    t_ok = stair_begin(st, lo[0], n[0], a.summary[g].max_width, R, NW) ? 1 : 0;
-                    t_flo = st.flo, t_off = st.off;
+        uint32_t cells = 0;
+        for (int c = 0; c < kSchedClasses; ++c) {
+            const bool active = cls < 0 && ((cand >> c) & 1u);
+            if (!__any(active)) continue;
+            const int R = kSchedR[c], NW = kSchedNW[c], rshift = stair_rshift(R), C = 64 * R * NW;
+            StairState st{0, 0};
+            int ok = 0;
+            if (active) ok = stair_begin(st, a.lo[sg.band_off], a.n[sg.band_off], max_width, R, NW) ? 1 : 0;
+            int Dmax = active ? D : -1;
+#pragma unroll
+            for (int k = 32; k > 0; k >>= 1) Dmax = max(Dmax, __shfl_xor(Dmax, k, 64));
+            for (int base = 0; base <= Dmax; base += SCHED_TILE) {
+                if (!__any(ok && base <= D)) break;
+                // rows base .. base + 31 of the walking segments into LDS: two segments per instruction
+#pragma unroll
+                for (int q = 0; q < SCHED_SEGS / 2; ++q) {
+                    const int s2 = 2 * q + half;
+                    const int walking = __shfl(ok && base <= D, s2, 64);
+                    const int64_t off = __shfl(sg.band_off, s2, 64);
+                    const int Ds = __shfl(D, s2, 64);
+                    if (walking && base + row <= Ds) {
+                        t_lo[s2][row] = a.lo[off + base + row];
+                        t_n[s2][row] = a.n[off + base + row];
+                    }
                 }
                 __syncthreads();
-                for (int base = 0; base <= D && t_ok; base += 64) {
-                    const int cnt = min(64, D + 1 - base);
-                    if (lane < cnt) t_lo[lane] = lo[base + lane], t_n[lane] = n[base + lane];
-                    if (lane == 0 && base + cnt <= D) t_lo[cnt] = lo[base + cnt], t_n[cnt] = n[base + cnt];
-                    __syncthreads();
-                    if (lane == 0) {
-                        StairState st{t_flo, t_off};
-                        int ok = 1;
-                        for (int i = 0; i < cnt && ok; ++i) {
-                            uint32_t w0 = 0, w1 = 0;
-                            ok = stair_step(st, base + i, D, t_lo[i], t_n[i], t_lo[i + 1], t_n[i + 1], rshift, C, w0, w1) ? 1 : 0;
-                            t_w[2 * i] = w0, t_w[2 * i + 1] = w1;
-                        }
-                        t_ok = ok, t_flo = st.flo, t_off = st.off;
+                const bool walk = ok && base <= D;
+                if (walk) {
+                    const int cnt = min(SCHED_TILE, D + 1 - base);
+                    for (int i = 0; i < cnt && ok; ++i) {
+                        uint32_t w0 = 0, w1 = 0;
+                        ok = stair_step(st, base + i, D, t_lo[lane][i], t_n[lane][i], t_lo[lane][i + 1], t_n[lane][i + 1], rshift, C, w0, w1) ? 1 : 0;
+                        t_w0[lane][i] = w0, t_w1[lane][i] = w1;
                     }
-                    __syncthreads();
-                    if (t_ok && lane < cnt) {
-                        ctl[2 * (base + lane)] = t_w[2 * lane];
-                        ctl[2 * (base + lane) + 1] = t_w[2 * lane + 1];
-                    }
-                    __syncthreads();
                 }
-                if (t_ok) cls = c, cells = static_cast<int64_t>(t_off);
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < SCHED_SEGS / 2; ++q) {
+                    const int s2 = 2 * q + half;
+                    const int done = __shfl(walk && ok, s2, 64);  // (a segment that failed in this tile is retried in the next class)
+                    const int64_t off = __shfl(ctl_off, s2, 64);
+                    const int Ds = __shfl(D, s2, 64);
+                    if (done && row < SCHED_TILE && base + row <= Ds) {
+                        uint2 *dst = reinterpret_cast<uint2 *>(a.ctl + 2 * (off + base + row));
+                        *dst = make_uint2(t_w0[s2][row], t_w1[s2][row]);
+                    }
+                }
+                __syncthreads();
             }
+            if (active && ok) cls = c, cells = st.off;
         }
-        if (lane == 0) a.cls[g] = cls, a.cells[g] = cls >= 0 ? cells : 0;
-        __syncthreads();
+        if (have) a.cls[g] = cls, a.cells[g] = cls >= 0 ? static_cast<int64_t>(cells) : 0;
     }
 }
 
@@ -243,7 +264,7 @@ int launch_plan_bands(const PlanArgs &a, void *stream) {
     return static_cast<int>(hipGetLastError());
 }
 int launch_plan_sched(const SchedArgs &a, void *stream) {
-    const int grid = a.n_segs < 65536 ? (a.n_segs > 0 ? a.n_segs : 1) : 65536;
+    const int grid = (a.n_segs + SCHED_SEGS - 1) / SCHED_SEGS > 0 ? (a.n_segs + SCHED_SEGS - 1) / SCHED_SEGS : 1;
     hipLaunchKernelGGL(k_plan_sched, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return static_cast<int>(hipGetLastError());
 }

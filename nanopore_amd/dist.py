@@ -82,6 +82,49 @@ def gather_to_root(payload, device=None, group=None, chunk_bytes=64 << 20):
     return out
 
 
+def index_packed_in_input_order(payloads, n_total):
+    """Rank 0: the gathered payloads indexed in input (SAM) order WITHOUT moving the cigars: (status[n], score[n], n_ops[n],
+    word_off[n], words) where read i's packed cigar (one uint32 per op, length << 2 | op) is
+    words[word_off[i] .. word_off[i] + n_ops[i]).  Work is per read, not per cigar operation."""
+    status = np.zeros(n_total, dtype=np.int64)
+    score = np.zeros(n_total, dtype=np.float64)
+    nops = np.zeros(n_total, dtype=np.int64)
+    word_off = np.zeros(n_total, dtype=np.int64)
+    seen = np.zeros(n_total, dtype=bool)
+    parts, base = [], 0
+    for p in payloads:
+        buf = np.ascontiguousarray(p, dtype=np.uint8)
+        n, total = (int(v) for v in buf[:16].view(np.int64))
+        rec = buf[16:16 + n * _REC.itemsize].view(_REC)
+        words = buf[16 + n * _REC.itemsize:16 + n * _REC.itemsize + total * 4].view(np.uint32)
+        idx = rec["idx"]
+        if seen[idx].any():
+            raise ValueError("a read was realigned by two ranks")
+        seen[idx] = True
+        status[idx], score[idx], nops[idx] = rec["status"], rec["score"], rec["nops"]
+        start = np.zeros(n, dtype=np.int64)
+        np.cumsum(rec["nops"][:-1], out=start[1:])
+        word_off[idx] = base + start
+        parts.append(words)
+        base += total
+    if not seen.all():
+        raise ValueError("%d reads came back from no rank" % int((~seen).sum()))
+    words = parts[0] if len(parts) == 1 else (np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32))
+    return status, score, nops, word_off, words
+
+
+def unpack_ops(nops, word_off, words):
+    """(ops_off[n+1], ops[(op, length)]) in input order from the packed form (tests, small jobs)."""
+    off = np.zeros(len(nops) + 1, dtype=np.int64)
+    np.cumsum(nops, out=off[1:])
+    src = np.repeat(np.asarray(word_off) - off[:-1], nops) + np.arange(int(off[-1]))
+    w = np.asarray(words)[src]
+    ops = np.empty((len(w), 2), dtype=np.int32)
+    ops[:, 0] = w & np.uint32(3)
+    ops[:, 1] = w >> np.uint32(2)
+    return off, ops
+
+
 def merge_csr_in_input_order(payloads, n_total):
     """Rank 0: every rank's payload unpacked into ONE result set in input (SAM) order (utils.py:597 zips by order):
     (status[n], score[n], ops_off[n+1], ops[(op, length)]).  Vectorised: no Python loop over reads."""

@@ -19,7 +19,9 @@ from . import synth
 
 def realign_shard(ctx, params, w, idx, model_slot=None):
     """Stage + run + finish for the reads `idx` of workload `w`.  Returns (results, ops_off, ops, timings)."""
-    sub = synth.take_reads(w, idx)
+    n = len(w["read_off"]) - 1
+    whole = len(idx) == n and (n == 0 or (idx[0] == 0 and idx[-1] == n - 1))  # one rank: its shard is the set itself
+    sub = w if whole else synth.take_reads(w, idx)
     t0 = time.perf_counter()
     b = ctx.stage_csr(params, sub["ref"], sub["ref_off"], sub["read"], sub["read_off"], sub["guide_ops"], sub["guide_off"],
                       model_slot=None if model_slot is None else np.ascontiguousarray(np.asarray(model_slot)[idx], dtype=np.int32),
@@ -37,12 +39,13 @@ def realign_shard(ctx, params, w, idx, model_slot=None):
     return res, off, ops, dict(stage_s=t1 - t0, run_s=t2 - t1, finish_s=t3 - t2, kernel_ms=kms)
 
 
-def write_sam(path, w, ops_off, ops, ref_names=None):
+def write_sam(path, w, nops, word_off, words, ref_names=None):
     """The realigned SAM: one record per read in input order, CIGAR = the realigner's ops (what
-    realignSamFile3TargetFn splices in, utils.py:597-605), POS = where the guide's window starts on the reference."""
+    realignSamFile3TargetFn splices in, utils.py:597-605), POS = where the guide's window starts on the reference.
+    The cigars come packed (dist.index_packed_in_input_order) and are formatted natively."""
     from . import realign
     n = len(w["read_off"]) - 1
-    cig, coff = realign.format_cigars(ops_off, ops)
+    cig, coff = realign.format_cigars_packed(word_off, nops, words)
     cig = cig.tobytes()
     read = np.ascontiguousarray(w["read"]).tobytes()
     ro = w["read_off"]
@@ -69,7 +72,7 @@ def write_sam(path, w, ops_off, ops, ref_names=None):
             fh.write(b"\n".join(lines) + b"\n")
 
 
-def write_summary_xml(path, status, score, ops_off, cells=None):
+def write_summary_xml(path, status, score, nops, cells=None):
     """Summary of the job for rank 0's report (the reference's per-experiment XMLs are built from exactly these per-read
     scalars, e.g. alignmentUncertainty.py:59-64)."""
     ok = np.asarray(status) == 0
@@ -77,7 +80,7 @@ def write_summary_xml(path, status, score, ops_off, cells=None):
     root.set("reads", str(len(status)))
     root.set("failedReads", str(int((~ok).sum())))
     root.set("averagePosteriorMatchProbabilityPerRead", repr(float(np.mean(np.asarray(score)[ok])) if ok.any() else float("nan")))
-    root.set("cigarOps", str(int(ops_off[-1])))
+    root.set("cigarOps", str(int(np.sum(nops))))
     if cells is not None:
         root.set("cells", str(int(cells)))
     ET.ElementTree(root).write(path)
@@ -85,8 +88,9 @@ def write_summary_xml(path, status, score, ops_off, cells=None):
 
 def run_job(ctx, params, w, out_dir=None, work=None, model_slot=None, device=None, group=None):
     """The whole job on this rank (collective: every rank of the process group calls it).  Without torch.distributed
-    initialised it is the one-GPU job.  Returns on rank 0 a dict with the merged results (status, score, ops_off, ops),
-    the output paths and the stage timings of this rank; on other ranks the timings only."""
+    initialised it is the one-GPU job.  Returns on rank 0 a dict with the results in input order (status, score and the
+    packed cigars n_ops / word_off / words -- dist.unpack_ops turns them into (op, length) pairs), the output paths and
+    the stage timings of this rank; on other ranks the timings only."""
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if multi else 1
@@ -106,15 +110,15 @@ def run_job(ctx, params, w, out_dir=None, work=None, model_slot=None, device=Non
     if rank != 0:
         return dict(timings=tm)
     t0 = time.perf_counter()
-    status, score, moff, mops = npd.merge_csr_in_input_order(got, n)
+    status, score, nops, word_off, words = npd.index_packed_in_input_order(got, n)
     tm["merge_s"] = time.perf_counter() - t0
-    out = dict(status=status, score=score, ops_off=moff, ops=mops, timings=tm)
+    out = dict(status=status, score=score, n_ops=nops, word_off=word_off, words=words, timings=tm)
     if out_dir is not None:
         t0 = time.perf_counter()
         os.makedirs(out_dir, exist_ok=True)
         out["sam"] = os.path.join(out_dir, "realigned.sam")
         out["xml"] = os.path.join(out_dir, "summary.xml")
-        write_sam(out["sam"], w, moff, mops)
-        write_summary_xml(out["xml"], status, score, moff)
+        write_sam(out["sam"], w, nops, word_off, words)
+        write_summary_xml(out["xml"], status, score, nops)
         tm["write_s"] = time.perf_counter() - t0
     return out

@@ -419,6 +419,25 @@ def format_cigars(ops_off, ops):
     return buf[:int(total)], str_off
 
 
+def format_cigars_packed(word_off, n_ops, words):
+    """SAM CIGAR text from packed cigars (one uint32 per op, length << 2 | op), list i at words[word_off[i] .. + n_ops[i]):
+    (bytes buffer, offsets[n+1]) (include/nprealign.h: npr_format_cigars_packed)."""
+    L = _lib.load()
+    word_off = np.ascontiguousarray(word_off, dtype=np.int64)
+    n_ops = np.ascontiguousarray(n_ops, dtype=np.int64)
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    n = len(n_ops)
+    str_off = np.zeros(n + 1, dtype=np.int64)
+    total = L.npr_format_cigars_packed(n, ptr(word_off), ptr(n_ops), ptr(words), ptr(str_off), None, 0)
+    if total < 0:
+        raise NprError(int(total), "npr_format_cigars_packed")
+    buf = np.empty(max(int(total), 1), dtype=np.uint8)
+    rc = L.npr_format_cigars_packed(n, ptr(word_off), ptr(n_ops), ptr(words), ptr(str_off), ptr(buf), int(total))
+    if rc < 0:
+        raise NprError(int(rc), "npr_format_cigars_packed")
+    return buf[:int(total)], str_off
+
+
 def mea_cigar(lX, lY, x, y, p, gap_gamma=0.5, match_gamma=0.0):
     L = _lib.load()
     x = np.ascontiguousarray(x, dtype=np.int32)

@@ -193,7 +193,7 @@ def _rank_main(rank, world, port, n_reads, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     os.environ["NPR_HOST_THREADS"] = "4"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from nanopore_amd import job, realign as R, synth
+    from nanopore_amd import dist as npd, job, realign as R, synth
     from nanopore_amd.hmm import Hmm
     T, E, _ = load_model_arrays()
     w, W = synth.config_c3_shared(T, E, n_reads=n_reads, genome_len=400000)
@@ -201,7 +201,8 @@ def _rank_main(rank, world, port, n_reads, out_dir):
     ctx.set_hmm(Hmm.loadHmm(os.path.join(MODEL_DIR, "blasr_hmm_0.txt")))
     out = job.run_job(ctx, R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w, out_dir=out_dir if rank == 0 else None, device="cpu")
     if rank == 0:
-        np.savez(os.path.join(out_dir, "merged.npz"), status=out["status"], score=out["score"], ops_off=out["ops_off"], ops=out["ops"])
+        off, ops = npd.unpack_ops(out["n_ops"], out["word_off"], out["words"])
+        np.savez(os.path.join(out_dir, "merged.npz"), status=out["status"], score=out["score"], ops_off=off, ops=ops)
     else:
         assert set(out) == {"timings"}
     dist.barrier()
@@ -219,6 +220,7 @@ def test_two_ranks_shard_one_read_set_and_match_the_single_rank_job(gpu_ctx, tmp
     _set_models(gpu_ctx)
     one = job.run_job(gpu_ctx, R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w, out_dir=str(tmp_path / "one"))
     assert (one["status"] == 0).all() and one["timings"]["cells"] > 1e9
+    one["ops_off"], one["ops"] = npd.unpack_ops(one["n_ops"], one["word_off"], one["words"])
     # the shards partition the set and balance the work
     work = w["read_off"][1:] - w["read_off"][:-1]
     s0, s1 = npd.shard_indices(work, 2, 0), npd.shard_indices(work, 2, 1)
