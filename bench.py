@@ -17,8 +17,9 @@ collective (weak scaling); one chunked RCCL gather of the packed results to rank
 `--workload c3` is the STRONG-scaling job of BASELINE.json configs[2] / configs[3]: ONE set of 50 k reads (~8 kb, one
 shared 4.6 Mb contig) sharded over the ranks as the reference shards one SAM file over jobTree jobs
 (utils.py:565-570); a step is the whole job from host buffers: stage (band planning + upload) + run + finish on every
-rank, the chunked gather to rank 0, the merge into input order and the realigned SAM + summary XML written by rank 0
-(utils.py:591-609).  value = cells of the whole set / that time; reads_per_s likewise.
+rank, every rank's block of the realigned SAM formatted and written at its offset of the one output file, the per-read
+scalars gathered to rank 0 and the summary XML written there (utils.py:591-609).  value = cells of the whole set / that
+time; reads_per_s likewise.
 
 Rank 0 prints ONE JSON line.
 """
@@ -421,7 +422,7 @@ def strong_c3(args, ctx, rank, world, dist, coll_dev, sync, allreduce):
     h, w, W = c3_workload(n_reads, rank, dist)
     ctx.set_hmm(h)
     params = make_params(W)
-    out_dir = tempfile.mkdtemp(prefix="npr_bench_c3_") if rank == 0 else None
+    out_dir = os.path.join(tempfile.gettempdir(), "npr_bench_c3_out_%d" % os.getuid())  # one file, written by all ranks
     last = None
     for _ in range(args.warmup):
         last = job.run_job(ctx, params, w, out_dir=out_dir, device=coll_dev)
@@ -461,13 +462,13 @@ def strong_c3(args, ctx, rank, world, dist, coll_dev, sync, allreduce):
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[2]/[3]: one set of %d synthetic ~8kb reads on one shared 4.6 Mb contig "
-                               "(ref_index, windowed guides), band 200, blasr_hmm_0, sharded over the ranks by "
-                               "dist.shard_indices (length-sorted, dealt round-robin)" % n_reads,
+                               "(ref_index, windowed guides), band 200, blasr_hmm_0, sharded over the ranks into contiguous "
+                               "ranges balanced by read length (dist.shard_ranges)" % n_reads,
                    "reads": n_reads, "band": W, "cells": total_cells, "parallelism": "one read set sharded x%d" % world},
         "reads_per_s": n_reads * args.steps / elapsed,
         "ok_reads": ok,
-        "step": "per rank: npr_batch_create (plan + pack + H2D) + npr_batch_run + npr_batch_finish; chunked gather to rank 0 "
-                "(RCCL); rank 0: merge into input order + realigned SAM (%d bytes) + summary XML" % sam_bytes,
+        "step": "per rank: npr_batch_create (plan + pack + H2D) + npr_batch_run + npr_batch_finish + its block of the realigned SAM "
+                "(%d bytes in all) formatted and written at its offset; per-read scalars gathered to rank 0 (RCCL); rank 0: summary XML" % sam_bytes,
         "rank0_stage_seconds": mean,
         "dp_sweep_only_rank0": {"value": cells_rank / (kms * 1e-3), "unit": "cells/s", "ms": kms},
     }

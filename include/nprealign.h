@@ -181,6 +181,9 @@ int32_t npr_batch_results(const npr_batch *b, npr_read_result *out /* [n_reads] 
 /* output cigars, CSR: ops_off[n_reads+1] (in op pairs), ops[2*ops_off[n_reads]].  Pass ops == NULL to get
  * only the offsets (two-pass sizing). */
 int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_t cap_pairs);
+/* the same cigars, one 32-bit word per operation: length << 2 | op (the form the device MEA stage produces and a sharded
+ * job ships between ranks); words[ops_off[n_reads]].  Pass words == NULL for the offsets only. */
+int32_t npr_batch_ops_packed(const npr_batch *b, int64_t *ops_off, uint32_t *words, int64_t cap_words);
 /* sparse posteriors (>= threshold), CSR by read, sorted by (x, y); x is the 0-based reference coordinate in
  * the read's slice, y the 0-based read coordinate: the `refPos readPos prob` TSV of
  * --outputAllPosteriorProbs (marginAlignSnpCaller.py:149).  After a device-side npr_batch_finish the pairs are

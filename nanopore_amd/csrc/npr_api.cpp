@@ -304,6 +304,11 @@ struct npr_batch {
     std::vector<int64_t> ops_off;
     std::unique_ptr<int32_t[]> ops;      // (op, length) pairs of all reads; not a vector: no zero-fill of 100s of MB
     int64_t ops_words = 0, ops_cap = 0;
+    // the same cigars as one 32-bit word per op (length << 2 | op): how the device MEA stage hands them over.  Either
+    // form is made from the other the first time it is asked for.
+    std::unique_ptr<uint32_t[]> packed;
+    int64_t packed_cap = 0;
+    bool have_pairs_form = false, have_packed_form = false;
     std::vector<int64_t> pair_off;
     std::vector<Pair> pairs;             // filled by fetch_pairs(): at finish in the host modes, on demand after the device MEA
     bool pairs_ready = false;
@@ -1300,12 +1305,13 @@ int32_t device_mea(npr_batch *b) {
     }
     b->ops_off = od;
     b->ops_words = 2 * od[n];
-    if (b->ops_words > b->ops_cap) {  // kept when the batch is finished again
-        b->ops.reset(new int32_t[b->ops_words]);
-        b->ops_cap = b->ops_words;
+    b->have_pairs_form = false, b->have_packed_form = true;
+    if (od[n] > b->packed_cap) {  // kept when the batch is finished again
+        b->packed.reset(new uint32_t[od[n]]);
+        b->packed_cap = od[n];
     }
     if (od[n]) {
-        // one packed word per op (length << 2 | op) through the pinned staging, unpacked by the host threads
+        // one packed word per op (length << 2 | op) through the pinned staging; (op, length) pairs are made on demand
         a.ops_dense = m.dense.p;  // (sized for the bound ot[n] >= od[n])
         HIP_TRY(ctx, hipMemcpyAsync(m.od.p, od.data(), m.od.bytes(), hipMemcpyHostToDevice, ctx->stream));
         if ((rc = launch_mea_gather(a, ctx->stream)) != 0) return fail(ctx, NPR_ERR_HIP, "k_mea_gather launch", static_cast<hipError_t>(rc));
@@ -1320,11 +1326,10 @@ int32_t device_mea(npr_batch *b) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_pairs, m.dense.p, need, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t *src = static_cast<const uint32_t *>(ctx->pin_pairs);
-        int32_t *out = b->ops.get();
-        const int64_t nops_all = od[n], chunk = 1 << 19, nchunks = (nops_all + chunk - 1) / chunk;
+        uint32_t *out = b->packed.get();
+        const int64_t nops_all = od[n], chunk = 1 << 20, nchunks = (nops_all + chunk - 1) / chunk;
         parallel_for(nchunks, ctx->host_threads, [&](int64_t c) {
-            for (int64_t i = c * chunk, hi = std::min(nops_all, (c + 1) * chunk); i < hi; ++i)
-                out[2 * i] = static_cast<int32_t>(src[i] & 3u), out[2 * i + 1] = static_cast<int32_t>(src[i] >> 2);
+            std::memcpy(out + c * chunk, src + c * chunk, sizeof(uint32_t) * static_cast<size_t>(std::min(nops_all, (c + 1) * chunk) - c * chunk));
         });
     }
     tm.lap("gather + D2H of the ops");
@@ -1430,6 +1435,7 @@ static int32_t batch_finish_impl(npr_batch *b) {
         b->ops_cap = b->ops_words;
     }
     for (int64_t i = 0; i < n; ++i) std::copy(per_read_ops[i].begin(), per_read_ops[i].end(), b->ops.get() + 2 * b->ops_off[i]);
+    b->have_pairs_form = true, b->have_packed_form = false;
     tm.lap("gather ops");
     b->finished = true;
     return NPR_OK;
@@ -1454,13 +1460,61 @@ int32_t npr_batch_results(const npr_batch *b, npr_read_result *out) {
     return NPR_OK;
 }
 
+static void ensure_pairs_form(npr_batch *b) {
+    if (b->have_pairs_form) return;
+    const int64_t total = b->ops_off[b->n_reads];
+    if (2 * total > b->ops_cap) b->ops.reset(new int32_t[2 * total]), b->ops_cap = 2 * total;
+    const uint32_t *src = b->packed.get();
+    int32_t *out = b->ops.get();
+    const int64_t chunk = 1 << 19, nchunks = (total + chunk - 1) / chunk;
+    parallel_for(nchunks, b->ctx->host_threads, [&](int64_t c) {
+        for (int64_t i = c * chunk, hi = std::min(total, (c + 1) * chunk); i < hi; ++i)
+            out[2 * i] = static_cast<int32_t>(src[i] & 3u), out[2 * i + 1] = static_cast<int32_t>(src[i] >> 2);
+    });
+    b->have_pairs_form = true;
+}
+static void ensure_packed_form(npr_batch *b) {
+    if (b->have_packed_form) return;
+    const int64_t total = b->ops_off[b->n_reads];
+    if (total > b->packed_cap) b->packed.reset(new uint32_t[total]), b->packed_cap = total;
+    const int32_t *src = b->ops.get();
+    uint32_t *out = b->packed.get();
+    const int64_t chunk = 1 << 19, nchunks = (total + chunk - 1) / chunk;
+    parallel_for(nchunks, b->ctx->host_threads, [&](int64_t c) {
+        for (int64_t i = c * chunk, hi = std::min(total, (c + 1) * chunk); i < hi; ++i)
+            out[i] = static_cast<uint32_t>(src[2 * i + 1]) << 2 | static_cast<uint32_t>(src[2 * i]);
+    });
+    b->have_packed_form = true;
+}
+
 int32_t npr_batch_ops(const npr_batch *b, int64_t *ops_off, int32_t *ops, int64_t cap_pairs) {
     if (!b || !ops_off) return NPR_ERR_INVALID;
     if (!b->finished) return NPR_ERR_STATE;
     std::copy(b->ops_off.begin(), b->ops_off.end(), ops_off);
     if (!ops) return NPR_OK;
     if (cap_pairs < b->ops_off[b->n_reads]) return NPR_ERR_CAPACITY;
+    try {
+        ensure_pairs_form(const_cast<npr_batch *>(b));
+    } catch (const std::exception &) {
+        return fail(b->ctx, NPR_ERR_NOMEM, "npr_batch_ops: out of host memory");
+    }
     std::copy(b->ops.get(), b->ops.get() + b->ops_words, ops);
+    return NPR_OK;
+}
+
+int32_t npr_batch_ops_packed(const npr_batch *b, int64_t *ops_off, uint32_t *words, int64_t cap_words) {
+    if (!b || !ops_off) return NPR_ERR_INVALID;
+    if (!b->finished) return NPR_ERR_STATE;
+    std::copy(b->ops_off.begin(), b->ops_off.end(), ops_off);
+    if (!words) return NPR_OK;
+    const int64_t total = b->ops_off[b->n_reads];
+    if (cap_words < total) return NPR_ERR_CAPACITY;
+    try {
+        ensure_packed_form(const_cast<npr_batch *>(b));
+    } catch (const std::exception &) {
+        return fail(b->ctx, NPR_ERR_NOMEM, "npr_batch_ops_packed: out of host memory");
+    }
+    std::copy(b->packed.get(), b->packed.get() + total, words);
     return NPR_OK;
 }
 
@@ -1671,9 +1725,8 @@ int32_t npr_batch_align_stats(npr_batch *b, int32_t *stats) {
         if (b->dev_ops && b->dev_ops_epoch == ctx->scratch_epoch) {
             rc = run_align_stats(ctx, n, b->dev_ops, b->dev_od, nullptr, nullptr, seg_off, segs, b->d_seq.p, stats);
         } else {
-            std::vector<uint32_t> packed(b->ops_off[n]);
-            for (int64_t q = 0; q < b->ops_off[n]; ++q)
-                packed[q] = static_cast<uint32_t>(b->ops[2 * q + 1]) << 2 | static_cast<uint32_t>(b->ops[2 * q]);
+            ensure_packed_form(b);
+            std::vector<uint32_t> packed(b->packed.get(), b->packed.get() + b->ops_off[n]);
             rc = run_align_stats(ctx, n, nullptr, nullptr, &packed, &b->ops_off, seg_off, segs, b->d_seq.p, stats);
         }
         if (rc != NPR_OK) return rc;

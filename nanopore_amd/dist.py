@@ -17,6 +17,18 @@ def shard_indices(work, world_size, rank):
     return np.sort(order[rank::world_size])
 
 
+def shard_ranges(work, world_size):
+    """Contiguous shards balanced by work: bounds[r] .. bounds[r + 1] are rank r's reads (input order kept inside and
+    across ranks, so every rank can write its own block of the output file).  The prefix sum of the work is cut at
+    multiples of total / world_size."""
+    work = np.asarray(work, dtype=np.float64)
+    n = len(work)
+    cum = np.concatenate([[0.0], np.cumsum(work)])
+    cuts = cum[-1] * np.arange(1, world_size) / world_size
+    inner = np.searchsorted(cum, cuts, side="left")
+    return np.concatenate([[0], np.minimum(inner, n), [n]]).astype(np.int64)
+
+
 _REC = np.dtype([("idx", np.int64), ("status", np.int64), ("score", np.float64), ("nops", np.int64)])
 
 

@@ -1,11 +1,11 @@
 """The whole realignment job on one read set, sharded over the ranks of a node.
 
 The reference's job is: one jobTree job per record of ONE SAM file (nanopore/analyses/utils.py:565-570), the temp cigar
-files gathered in input order and spliced into a copy of the input SAM (utils.py:591-609).  Here: every rank takes its
-shard of the reads (`dist.shard_indices`: length-sorted, dealt round-robin), stages / realigns / closes it on its GPU with
-no data-path collective, one chunked gather (RCCL under backend nccl) brings the packed cigars and scores to rank 0, which
-restores the input order and writes the realigned SAM and a summary XML.  Used by `bench.py --workload c3` (strong
-scaling, BASELINE.json configs[3]) and by the two-rank GPU test.
+files gathered in input order and spliced into a copy of the input SAM (utils.py:591-609).  Here: every rank takes a
+contiguous range of the reads (`dist.shard_ranges`: balanced by read length), stages / realigns / closes it on its GPU
+and writes the SAM records of its range at its own offset of the output file -- no data-path collective in either
+direction --; one small gather (RCCL under backend nccl) brings the per-read scalars to rank 0 for the summary XML.  Used
+by `bench.py --workload c3` (strong scaling, BASELINE.json configs[3]) and by the two-rank GPU test.
 """
 import os
 import time
@@ -17,14 +17,13 @@ from . import dist as npd
 from . import synth
 
 
-def realign_shard(ctx, params, w, idx, model_slot=None):
-    """Stage + run + finish for the reads `idx` of workload `w`.  Returns (results, ops_off, ops, timings)."""
+def realign_shard(ctx, params, w, lo, hi, model_slot=None):
+    """Stage + run + finish for the reads lo .. hi of workload `w`.  Returns (results, ops_off, packed cigar words, timings)."""
     n = len(w["read_off"]) - 1
-    whole = len(idx) == n and (n == 0 or (idx[0] == 0 and idx[-1] == n - 1))  # one rank: its shard is the set itself
-    sub = w if whole else synth.take_reads(w, idx)
+    sub = w if (lo == 0 and hi == n) else synth.take_reads(w, np.arange(lo, hi))
     t0 = time.perf_counter()
     b = ctx.stage_csr(params, sub["ref"], sub["ref_off"], sub["read"], sub["read_off"], sub["guide_ops"], sub["guide_off"],
-                      model_slot=None if model_slot is None else np.ascontiguousarray(np.asarray(model_slot)[idx], dtype=np.int32),
+                      model_slot=None if model_slot is None else np.ascontiguousarray(np.asarray(model_slot)[lo:hi], dtype=np.int32),
                       ref_index=sub.get("ref_index"), guide_start=sub.get("guide_start"))
     t1 = time.perf_counter()
     try:
@@ -33,43 +32,43 @@ def realign_shard(ctx, params, w, idx, model_slot=None):
         b.finish()
         t3 = time.perf_counter()
         res = b.results()
-        off, ops = b.ops()
+        off, words = b.ops_packed()
     finally:
         b.close()
-    return res, off, ops, dict(stage_s=t1 - t0, run_s=t2 - t1, finish_s=t3 - t2, kernel_ms=kms)
+    return res, off, words, dict(stage_s=t1 - t0, run_s=t2 - t1, finish_s=t3 - t2, kernel_ms=kms)
 
 
-def write_sam(path, w, nops, word_off, words, ref_names=None):
-    """The realigned SAM: one record per read in input order, CIGAR = the realigner's ops (what
-    realignSamFile3TargetFn splices in, utils.py:597-605), POS = where the guide's window starts on the reference.
-    The cigars come packed (dist.index_packed_in_input_order) and are formatted natively."""
-    from . import realign
-    n = len(w["read_off"]) - 1
-    cig, coff = realign.format_cigars_packed(word_off, nops, words)
-    cig = cig.tobytes()
-    read = np.ascontiguousarray(w["read"]).tobytes()
-    ro = w["read_off"]
-    ri = w.get("ref_index")
-    gs = w.get("guide_start")
+def sam_header(w, ref_names=None):
     n_refs = len(w["ref_off"]) - 1
     if ref_names is None:
         ref_names = ["ref_%d" % k for k in range(n_refs)]
-    with open(path, "wb") as fh:
-        fh.write(b"@HD\tVN:1.0\tSO:unsorted\n")
-        for k in range(n_refs):
-            fh.write(("@SQ\tSN:%s\tLN:%d\n" % (ref_names[k], int(w["ref_off"][k + 1] - w["ref_off"][k]))).encode())
-        rn = [s.encode() for s in ref_names]
-        lines = []
-        for i in range(n):
-            k = int(ri[i]) if ri is not None else i
-            pos = (int(gs[i][0]) if gs is not None else 0) + 1
-            lines.append(b"\t".join((b"read_%d" % i, b"0", rn[k], b"%d" % pos, b"255", cig[coff[i]:coff[i + 1]], b"*\t0\t0",
-                                     read[ro[i]:ro[i + 1]], b"*")))
-            if len(lines) >= 4096:
-                fh.write(b"\n".join(lines) + b"\n")
-                lines = []
-        if lines:
-            fh.write(b"\n".join(lines) + b"\n")
+    head = [b"@HD\tVN:1.0\tSO:unsorted\n"]
+    for k in range(n_refs):
+        head.append(("@SQ\tSN:%s\tLN:%d\n" % (ref_names[k], int(w["ref_off"][k + 1] - w["ref_off"][k]))).encode())
+    return b"".join(head), ref_names
+
+
+def sam_block(w, lo, hi, ops_off, words, ref_names):
+    """The SAM records of reads lo .. hi as one bytes object: CIGAR = the realigner's ops (what realignSamFile3TargetFn
+    splices in, utils.py:597-605), POS = where the guide's window starts on the reference.  The cigars come packed and are
+    formatted natively (npr_format_cigars_packed)."""
+    from . import realign
+    nops = np.asarray(ops_off[1:]) - np.asarray(ops_off[:-1])
+    cig, coff = realign.format_cigars_packed(ops_off[:-1], nops, words)
+    cig = cig.tobytes()
+    ro = w["read_off"]
+    read = np.ascontiguousarray(w["read"][ro[lo]:ro[hi]]).tobytes()
+    r0 = int(ro[lo])
+    ri = w.get("ref_index")
+    gs = w.get("guide_start")
+    rn = [s.encode() for s in ref_names]
+    lines = []
+    for k, i in enumerate(range(lo, hi)):
+        ref = int(ri[i]) if ri is not None else i
+        pos = (int(gs[i][0]) if gs is not None else 0) + 1
+        lines.append(b"\t".join((b"read_%d" % i, b"0", rn[ref], b"%d" % pos, b"255", cig[coff[k]:coff[k + 1]], b"*\t0\t0",
+                                 read[ro[i] - r0:ro[i + 1] - r0], b"*")))
+    return b"\n".join(lines) + (b"\n" if lines else b"")
 
 
 def write_summary_xml(path, status, score, nops, cells=None):
@@ -87,38 +86,69 @@ def write_summary_xml(path, status, score, nops, cells=None):
 
 
 def run_job(ctx, params, w, out_dir=None, work=None, model_slot=None, device=None, group=None):
-    """The whole job on this rank (collective: every rank of the process group calls it).  Without torch.distributed
-    initialised it is the one-GPU job.  Returns on rank 0 a dict with the results in input order (status, score and the
-    packed cigars n_ops / word_off / words -- dist.unpack_ops turns them into (op, length) pairs), the output paths and
-    the stage timings of this rank; on other ranks the timings only."""
+    """The whole job on this rank (collective: every rank of the process group calls it; without torch.distributed
+    initialised it is the one-GPU job).
+
+    Reads shard into CONTIGUOUS ranges balanced by work (dist.shard_ranges), so the output needs no data-path collective
+    either: every rank formats the SAM records of its own range and writes them at its own offset of the one output file
+    (an all_gather of the block sizes gives the offsets; the reference's single writer, utils.py:591-609, would serialise
+    half a gigabyte of text behind eight GPUs).  Only the per-read scalars -- status, score, number of cigar operations --
+    are gathered to rank 0, for the summary XML.  Returns on rank 0 a dict with those scalars in input order, the output
+    paths and this rank's stage timings; on other ranks the timings only."""
+    import torch
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
+    dev = torch.device("cpu") if device is None else torch.device(device)
     n = len(w["read_off"]) - 1
     if work is None:
         work = np.asarray(w["read_off"][1:]) - np.asarray(w["read_off"][:-1])
-    mine = npd.shard_indices(work, world, rank)
-    res, off, ops, tm = realign_shard(ctx, params, w, mine, model_slot)
+    bounds = npd.shard_ranges(work, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    res, off, words, tm = realign_shard(ctx, params, w, lo, hi, model_slot)
     tm["cells"] = int(res["cells"].sum())
+    out = dict(timings=tm)
+    if out_dir is not None:
+        t0 = time.perf_counter()
+        sam_path = os.path.join(out_dir, "realigned.sam")
+        header, ref_names = sam_header(w)
+        block = sam_block(w, lo, hi, off, words, ref_names)
+        tm["format_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sizes = [len(block)]
+        if multi:
+            t = torch.tensor([len(block)], dtype=torch.int64, device=dev)
+            got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(got, t, group=group)
+            sizes = [int(g.item()) for g in got]
+        if rank == 0:
+            os.makedirs(out_dir, exist_ok=True)
+            with open(sam_path, "wb") as fh:
+                fh.write(header)
+                fh.truncate(len(header) + sum(sizes))
+        if multi:
+            dist.barrier(group=group)
+        fd = os.open(sam_path, os.O_WRONLY)
+        try:
+            os.pwrite(fd, block, len(header) + sum(sizes[:rank]))
+        finally:
+            os.close(fd)
+        tm["write_s"] = time.perf_counter() - t0
+        out["sam"] = sam_path
+    # the one gather: per-read scalars for the summary
     t0 = time.perf_counter()
+    mine = np.stack([res["status"].astype(np.float64), res["score"].astype(np.float64), (off[1:] - off[:-1]).astype(np.float64)], axis=1)
     if multi:
-        got = npd.gather_to_root(npd.pack_results(mine, res["status"], res["score"], off, ops), device=device, group=group)
-    else:
-        got = [npd.pack_results(mine, res["status"], res["score"], off, ops)]
+        got = npd.gather_to_root(mine.reshape(-1).view(np.uint8), device=device, group=group)
+        if rank == 0:
+            mine = np.concatenate([g.view(np.float64).reshape(-1, 3) for g in got])
+        dist.barrier(group=group)  # every rank's block is on disk when rank 0 returns
     tm["gather_s"] = time.perf_counter() - t0
     if rank != 0:
         return dict(timings=tm)
-    t0 = time.perf_counter()
-    status, score, nops, word_off, words = npd.index_packed_in_input_order(got, n)
-    tm["merge_s"] = time.perf_counter() - t0
-    out = dict(status=status, score=score, n_ops=nops, word_off=word_off, words=words, timings=tm)
+    out["status"], out["score"], out["n_ops"] = mine[:, 0].astype(np.int64), mine[:, 1], mine[:, 2].astype(np.int64)
     if out_dir is not None:
-        t0 = time.perf_counter()
-        os.makedirs(out_dir, exist_ok=True)
-        out["sam"] = os.path.join(out_dir, "realigned.sam")
         out["xml"] = os.path.join(out_dir, "summary.xml")
-        write_sam(out["sam"], w, nops, word_off, words)
-        write_summary_xml(out["xml"], status, score, nops)
-        tm["write_s"] = time.perf_counter() - t0
+        write_summary_xml(out["xml"], out["status"], out["score"], out["n_ops"])
     return out

@@ -110,6 +110,18 @@ class Batch(object):
             raise NprError(rc, "npr_batch_ops")
         return off, ops
 
+    def ops_packed(self):
+        """Output cigars, one uint32 per op (length << 2 | op): (offsets[n+1], words)."""
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        rc = self._L.npr_batch_ops_packed(self._h, ptr(off), None, 0)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_ops_packed", self.ctx.last_error())
+        words = np.zeros(max(int(off[-1]), 1), dtype=np.uint32)
+        rc = self._L.npr_batch_ops_packed(self._h, ptr(off), ptr(words), int(off[-1]))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_ops_packed", self.ctx.last_error())
+        return off, words[:int(off[-1])]
+
     def pairs(self):
         """-> (pair_off[n+1], x, y, p) sparse posterior match probabilities sorted by (x, y)."""
         off = np.zeros(self.n_reads + 1, dtype=np.int64)

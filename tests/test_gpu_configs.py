@@ -3,8 +3,9 @@
               fp64 log-space oracle);
   configs[2]  50 000 reads ~8 kb on ONE shared 4.6 Mb contig (ref_index, guides with window coordinates), band 200:
               size-independent properties over all reads, a 32-read sample bit-exact vs the mirror / 1e-4 vs fp64;
-  configs[3]  the same kind of set sharded over TWO ranks (one GPU shared, gloo collectives): shard_indices, the real
-              stage / run / finish on each rank, chunked gather, merge, SAM + XML -- identical to the one-rank job;
+  configs[3]  the same kind of set sharded over TWO ranks (one GPU shared, gloo collectives): contiguous shards, the real
+              stage / run / finish on each rank, each rank's block of the SAM written in place, scalars gathered for the
+              XML -- byte-identical to the one-rank job;
   configs[4]  3 x 1 000 reads of 10-50 kb with per-read-type model slots (hmm_0 / hmm_20 / hmm_40).
 PARITY UNPINNED: the oracle is this build's restatement of cactus_realign (absent from the reference snapshot)."""
 import os
@@ -199,10 +200,9 @@ def _rank_main(rank, world, port, n_reads, out_dir):
     w, W = synth.config_c3_shared(T, E, n_reads=n_reads, genome_len=400000)
     ctx = R.Context(0)
     ctx.set_hmm(Hmm.loadHmm(os.path.join(MODEL_DIR, "blasr_hmm_0.txt")))
-    out = job.run_job(ctx, R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w, out_dir=out_dir if rank == 0 else None, device="cpu")
+    out = job.run_job(ctx, R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w, out_dir=out_dir, device="cpu")
     if rank == 0:
-        off, ops = npd.unpack_ops(out["n_ops"], out["word_off"], out["words"])
-        np.savez(os.path.join(out_dir, "merged.npz"), status=out["status"], score=out["score"], ops_off=off, ops=ops)
+        np.savez(os.path.join(out_dir, "merged.npz"), status=out["status"], score=out["score"], n_ops=out["n_ops"])
     else:
         assert set(out) == {"timings"}
     dist.barrier()
@@ -220,26 +220,31 @@ def test_two_ranks_shard_one_read_set_and_match_the_single_rank_job(gpu_ctx, tmp
     _set_models(gpu_ctx)
     one = job.run_job(gpu_ctx, R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w, out_dir=str(tmp_path / "one"))
     assert (one["status"] == 0).all() and one["timings"]["cells"] > 1e9
-    one["ops_off"], one["ops"] = npd.unpack_ops(one["n_ops"], one["word_off"], one["words"])
-    # the shards partition the set and balance the work
+    # the shards are contiguous, partition the set and balance the work
     work = w["read_off"][1:] - w["read_off"][:-1]
-    s0, s1 = npd.shard_indices(work, 2, 0), npd.shard_indices(work, 2, 1)
-    assert np.array_equal(np.sort(np.concatenate([s0, s1])), np.arange(n_reads))
-    assert abs(int(work[s0].sum()) - int(work[s1].sum())) < 0.02 * work.sum()
+    bounds = npd.shard_ranges(work, 2)
+    assert bounds[0] == 0 and bounds[2] == n_reads and 0 < bounds[1] < n_reads
+    assert abs(int(work[:bounds[1]].sum()) - int(work[bounds[1]:].sum())) < 0.02 * work.sum()
     two_dir = str(tmp_path / "two")
     os.makedirs(two_dir)
     mp.spawn(_rank_main, args=(2, _free_port(), n_reads, two_dir), nprocs=2, join=True)
     z = np.load(os.path.join(two_dir, "merged.npz"))
-    for k in ("status", "score", "ops_off", "ops"):
+    for k in ("status", "score", "n_ops"):
         assert np.array_equal(z[k], one[k]), k
     sam1 = open(one["sam"], "rb").read()
     sam2 = open(os.path.join(two_dir, "realigned.sam"), "rb").read()
     assert sam1 == sam2 and sam1.count(b"\n") == n_reads + 2
     assert open(one["xml"], "rb").read() == open(os.path.join(two_dir, "summary.xml"), "rb").read()
-    # the SAM is the input order with the realigner's cigars: spot-check records against the merged ops
+    # the SAM is the input order with the realigner's cigars: spot-check records against a direct realignment
+    b = gpu_ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"],
+                          w["guide_off"], ref_index=w["ref_index"], guide_start=w["guide_start"])
+    b.run(), b.finish()
+    off, ops = b.ops()
+    b.close()
     lines = sam1.split(b"\n")[2:]
-    for i in (0, 1, n_reads // 2, n_reads - 1):
+    for i in (0, 1, int(bounds[1]) - 1, int(bounds[1]), n_reads - 1):
         f = lines[i].split(b"\t")
         assert f[0] == b"read_%d" % i and int(f[3]) == int(w["guide_start"][i][0]) + 1
-        cig = b"".join(b"%d%s" % (ln, b"MID"[op:op + 1]) for op, ln in one["ops"][one["ops_off"][i]:one["ops_off"][i + 1]])
+        cig = b"".join(b"%d%s" % (ln, b"MID"[op:op + 1]) for op, ln in ops[off[i]:off[i + 1]])
         assert f[5] == cig and f[9] == bytes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
+        assert one["n_ops"][i] == off[i + 1] - off[i]
