@@ -44,6 +44,21 @@ __device__ __forceinline__ void normalise(Cell &c, int eref) {
     c.e = vmax > 0.0f ? eref + (bits >> 23) - 126 : E_DEAD;
 }
 
+// Which anti-diagonals renormalise: d = 0, 1 (mod 4).  On d = 2, 3 (mod 4) a cell keeps the reference exponent of
+// its predecessors and whatever mantissas the recurrence produced.  Every predecessor chain (steps of 1 or 2
+// anti-diagonals, either sweep direction) meets a renormalising anti-diagonal after at most two such cells, so the
+// mantissas stay far inside fp32's range (each step costs at most one transition, one emission and one
+// exponent spread), and half of the renormalisations -- 12 of the ~55 VALU instructions of a cell -- are not issued.
+// (Skipping every second anti-diagonal instead would not do: match moves step by two, so the even anti-diagonals
+// would never renormalise along a run of matches.)  The CPU mirror follows the same rule.
+__host__ __device__ constexpr bool norm_diag(int d) { return (d & 2) == 0; }
+
+template <bool NORM>
+__device__ __forceinline__ void settle(Cell &c, int eref) {
+    if constexpr (NORM) normalise(c, eref);
+    else c.e = eref;
+}
+
 // transition probabilities held in registers (wave-uniform)
 struct Trans {
     float mm, sxm, sym, lxm, lym;  // -> match
@@ -64,6 +79,7 @@ __device__ __forceinline__ Trans load_trans(const float *T) {
 }
 
 // forward: L = (x-1,y), M = (x-1,y-1), U = (x,y-1); em/exs/exl/eys/eyl the emissions of the bases consumed
+template <bool NORM = true>
 __device__ __forceinline__ Cell fwd_cell(const Trans &t, const Cell &L, const Cell &M, const Cell &U, float em,
                                          float exs, float exl, float eys, float eyl) {
     const int eref = max(L.e, max(M.e, U.e));
@@ -90,11 +106,12 @@ __device__ __forceinline__ Cell fwd_cell(const Trans &t, const Cell &L, const Ce
     a = t.mly * U.m;
     a = __builtin_fmaf(t.lyly, U.ly, a);
     c.ly = (fU * eyl) * a;
-    normalise(c, eref);
+    settle<NORM>(c, eref);
     return c;
 }
 
 // backward: Ms = (x+1,y+1), Xs = (x+1,y), Ys = (x,y+1); emissions of the bases those moves consume
+template <bool NORM = true>
 __device__ __forceinline__ Cell bwd_cell(const Trans &t, const Cell &Ms, const Cell &Xs, const Cell &Ys, float em,
                                          float exs, float exl, float eys, float eyl) {
     const int eref = max(Ms.e, max(Xs.e, Ys.e));
@@ -126,7 +143,21 @@ __device__ __forceinline__ Cell bwd_cell(const Trans &t, const Cell &Ms, const C
     b = t.lym * am;
     b = __builtin_fmaf(t.lyly, aly, b);
     c.ly = b;
-    normalise(c, eref);
+    settle<NORM>(c, eref);
+    return c;
+}
+
+// the rule evaluated at run time (wave-uniform `norm`): same bits as the static versions
+__device__ __forceinline__ Cell fwd_cell_dyn(bool norm, const Trans &t, const Cell &L, const Cell &M, const Cell &U, float em,
+                                             float exs, float exl, float eys, float eyl) {
+    Cell c = fwd_cell<false>(t, L, M, U, em, exs, exl, eys, eyl);
+    if (norm) normalise(c, c.e);
+    return c;
+}
+__device__ __forceinline__ Cell bwd_cell_dyn(bool norm, const Trans &t, const Cell &Ms, const Cell &Xs, const Cell &Ys, float em,
+                                             float exs, float exl, float eys, float eyl) {
+    Cell c = bwd_cell<false>(t, Ms, Xs, Ys, em, exs, exl, eys, eyl);
+    if (norm) normalise(c, c.e);
     return c;
 }
 

@@ -212,6 +212,22 @@ __device__ __forceinline__ void kill_outside(Cell &c, uint64_t in_band) {
     c.e = __builtin_amdgcn_inverse_ballot_w64(in_band) ? c.e : E_DEAD;
 }
 
+// The end of a step: renormalise the new cells if this anti-diagonal does (wave-uniform `norm` = norm_diag(d),
+// npr_cell.h -- one branch on the scalar unit around 12 instructions per cell) and mark the slots outside the band dead.
+template <int R>
+__device__ __forceinline__ void settle_diag(bool norm, Diag<R> &o, const Masks<R> &mk) {
+    if (norm) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            normalise(o.c[r], o.c[r].e);
+            kill_outside(o.c[r], mk.cell[r]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) kill_outside(o.c[r], mk.cell[r]);
+    }
+}
+
 // In-place moves of the whole register state by one slot (frame rebase).  Written as inline assembly on tied
 // operands: expressed in C++ the moved values are new SSA values, and the compiler pays for the join with the
 // not-moved path by copying the state on the hot path.  s_nop: a DPP read of a VGPR written by the previous VALU
@@ -313,38 +329,40 @@ __device__ __forceinline__ void bwd_rebase(const StepEnv &E, int r, Diag<R> &A, 
 }
 
 // One forward anti-diagonal.  `io` holds anti-diagonal d-2 on entry and d on exit; `p1` holds d-1.  S.X / S.Y hold
-// X[x-1]*4 and Y[y-1]*4 of every slot.
+// X[x-1]*4 and Y[y-1]*4 of every slot.  norm = norm_diag(d) of the anti-diagonal being computed.
 template <int R>
-__device__ __forceinline__ void fwd_x_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &x0, const Ctl &ct) {
+__device__ __forceinline__ void fwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &x0, const Ctl &ct) {
     const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
     S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     x0 += 1;
     bases_up<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
     const Diag<R> U = shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
+    Diag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-        Cell c = fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
-        kill_outside(c, mk.cell[r]);
-        io.c[r] = c;
+        o.c[r] = fwd_cell<false>(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
     }
+    settle_diag<R>(norm, o, mk);
+    io = o;
 }
 template <int R>
-__device__ __forceinline__ void fwd_y_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &y0, const Ctl &ct) {
+__device__ __forceinline__ void fwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &y0, const Ctl &ct) {
     const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     y0 += 1;
     bases_down<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
     const Diag<R> L = shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
+    Diag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-        Cell c = fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
-        kill_outside(c, mk.cell[r]);
-        io.c[r] = c;
+        o.c[r] = fwd_cell<false>(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
     }
+    settle_diag<R>(norm, o, mk);
+    io = o;
 }
 
 // Forward rows in HBM: a row holds the lanes [l0, l1) that carry band cells, 8R bytes per lane -- per slot the pair
@@ -445,37 +463,39 @@ __device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, 
 // One backward anti-diagonal d.  `io` holds anti-diagonal d+2 on entry and d on exit; `s1` holds d+1.  S.X / S.Y hold
 // X[x]*4 and Y[y]*4 of every slot.  The X variant undoes the X-step into d+1 (d even), the Y variant a Y-step.
 template <int R>
-__device__ __forceinline__ void bwd_x_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &x0, const Ctl &ct) {
+__device__ __forceinline__ void bwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &x0, const Ctl &ct) {
     const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
     S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     x0 -= 1;
     // x decreased by one in every slot: X[x] moves up a slot, slot 0 takes X[x0]
     bases_down<R>(S.X, feed_get<-1>(S.fx, E.X, E.lX, x0, E.lane));
     const Diag<R> Ys = shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
+    Diag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-        Cell c = bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
-        kill_outside(c, mk.cell[r]);
-        io.c[r] = c;
+        o.c[r] = bwd_cell<false>(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
     }
+    settle_diag<R>(norm, o, mk);
+    io = o;
 }
 template <int R>
-__device__ __forceinline__ void bwd_y_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &y0, const Ctl &ct) {
+__device__ __forceinline__ void bwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &y0, const Ctl &ct) {
     const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     y0 -= 1;
     bases_up<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
     const Diag<R> Xs = shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
+    Diag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-        Cell c = bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
-        kill_outside(c, mk.cell[r]);
-        io.c[r] = c;
+        o.c[r] = bwd_cell<false>(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
     }
+    settle_diag<R>(norm, o, mk);
+    io = o;
 }
 
 }  // namespace

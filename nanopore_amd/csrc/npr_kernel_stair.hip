@@ -118,17 +118,17 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             Ctl cur = nx;
             nx = read_ctl(ctl, d + 1);  // one ahead
             if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-            fwd_x_step<R>(E, B, A, S, x0, cur);
+            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, cur);
             store_row<R>(F, B, cur, voff);
             cur = nx;
             if (d + 2 <= D) nx = read_ctl(ctl, d + 2);
             if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-            fwd_y_step<R>(E, A, B, S, y0, cur);
+            fwd_y_step<R>(norm_diag(d + 1), E, A, B, S, y0, cur);
             store_row<R>(F, A, cur, voff);
         }
         if (d <= D) {  // D odd: one more X-step, into B
             if (nx.reb) fwd_rebase<R>(E, nx.reb, A, B, S, x0, y0);
-            fwd_x_step<R>(E, B, A, S, x0, nx);
+            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, nx);
             store_row<R>(F, B, nx, voff);
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     load_row<R>(F, fb, nxt, voff);
                 }
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(E, A, B, S, x0, cur);
+                bwd_x_step<R>(norm_diag(d2), E, A, B, S, x0, cur);
                 emit_pairs<R>(sink, A, fa, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
                 d2 -= 1;
             }
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 nxt = read_ctl(ctl, d2 - 1);
                 load_row<R>(F, fa, nxt, voff);  // for the step after this one
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_y_step<R>(E, B, A, S, y0, cur);
+                bwd_y_step<R>(norm_diag(d2), E, B, A, S, y0, cur);
                 emit_pairs<R>(sink, B, fb, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
                 reb = cur.reb;
                 cur = nxt;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     load_row<R>(F, fb, nxt, voff);
                 }
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(E, A, B, S, x0, cur);
+                bwd_x_step<R>(norm_diag(d2 - 1), E, A, B, S, x0, cur);
                 emit_pairs<R>(sink, A, fa, d2 - 1, x0, y0, cur, tot_e, inv_tot, jr, cnt);
             }
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                     for (int r = 0; r < R; ++r) {
                         float em, exs, exl, eys, eyl;
                         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-                        Cell c = fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
+                        Cell c = fwd_cell_dyn(norm_diag(d), E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
                         kill_outside(c, mk.cell[r]);
                         io.c[r] = c;
                     }
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                     for (int r = 0; r < R; ++r) {
                         float em, exs, exl, eys, eyl;
                         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-                        Cell c = fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
+                        Cell c = fwd_cell_dyn(norm_diag(d), E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
                         kill_outside(c, mk.cell[r]);
                         io.c[r] = c;
                     }
@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                         for (int r = 0; r < R; ++r) {
                             float em, exs, exl, eys, eyl;
                             emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-                            Cell c = bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
+                            Cell c = bwd_cell_dyn(norm_diag(dd), E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
                             kill_outside(c, mk.cell[r]);
                             io.c[r] = c;
                         }
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(WAVE *NW) __attribute__((amdgpu_waves_per_eu((
                         for (int r = 0; r < R; ++r) {
                             float em, exs, exl, eys, eyl;
                             emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
-                            Cell c = bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
+                            Cell c = bwd_cell_dyn(norm_diag(dd), E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
                             kill_outside(c, mk.cell[r]);
                             io.c[r] = c;
                         }
@@ -1168,10 +1168,10 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
             const Ctl ct = read_ctl(ctl, d);
             if (ct.reb) fwd_rebase<R>(E, ct.reb, A, B, S, x0, y0);
             if (d & 1) {
-                fwd_x_step<R>(E, B, A, S, x0, ct);
+                fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, ct);
                 store_row<R>(F, B, ct, voff), store_row_x<R>(Fx, a.slot_stride, B, ct, band_masks<R>(ct.jlo, ct.n), lane);
             } else {
-                fwd_y_step<R>(E, A, B, S, y0, ct);
+                fwd_y_step<R>(norm_diag(d), E, A, B, S, y0, ct);
                 store_row<R>(F, A, ct, voff), store_row_x<R>(Fx, a.slot_stride, A, ct, band_masks<R>(ct.jlo, ct.n), lane);
             }
         }
@@ -1264,9 +1264,9 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                 if (d >= 3) load_full_row<R>(F, Fx, a.slot_stride, G2, q3, q2.reb + q1.reb, lane);
                 if (q0.reb) bwd_rebase<R>(E, q0.reb, A, B, S, x0, y0);
                 if ((d - 1) & 1) {
-                    bwd_y_step<R>(E, B, A, S, y0, q1);
+                    bwd_y_step<R>(norm_diag(d - 1), E, B, A, S, y0, q1);
                 } else {
-                    bwd_x_step<R>(E, A, B, S, x0, q1);
+                    bwd_x_step<R>(norm_diag(d - 1), E, A, B, S, x0, q1);
                 }
                 q0 = q1, q1 = q2, q2 = q3, q3 = d >= 4 ? read_ctl(ctl, d - 4) : none;
             }

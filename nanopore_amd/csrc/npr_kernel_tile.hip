@@ -155,7 +155,7 @@ __device__ __forceinline__ Cell dpp_cell_from_above(const Cell &v, const Cell &e
 // d-2's top register (made by the step before) on entry, that of d-1 on exit; `edge`: the left stripe's last column on
 // d-1 (every lane holds it, lane 0 uses it).  bx / by: X[x-1]*4 and Y[y-1]*4 of every slot.
 template <int R>
-__device__ __forceinline__ void tile_fwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Cell &carry, const Cell &edge,
+__device__ __forceinline__ void tile_fwd_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Cell &carry, const Cell &edge,
                                               const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
     const Cell Le = dpp_cell_from_below(p1.c[R - 1], edge);  // (x-1, y) of every lane's register 0
     Diag<R> o;
@@ -163,17 +163,16 @@ __device__ __forceinline__ void tile_fwd_step(const StepEnv &E, Diag<R> &io, con
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
-        Cell c = fwd_cell(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : carry, p1.c[r], em, exs, exl, eys, eyl);
-        kill_outside(c, mk.cell[r]);
-        o.c[r] = c;
+        o.c[r] = fwd_cell<false>(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : carry, p1.c[r], em, exs, exl, eys, eyl);
     }
+    settle_diag<R>(norm, o, mk);  // norm = norm_diag(d)
     io = o;
     carry = Le;
 }
 // One backward anti-diagonal.  `io`: d+2 -> d; `s1`: d+1; `carry`: the slot-above copy of d+2's register 0 -> that of
 // d+1; `edge`: the right stripe's first column on d+1 (lane 63 uses it).  bx / by: X[x]*4 and Y[y]*4 of every slot.
 template <int R>
-__device__ __forceinline__ void tile_bwd_step(const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Cell &carry, const Cell &edge,
+__device__ __forceinline__ void tile_bwd_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Cell &carry, const Cell &edge,
                                               const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
     const Cell Xe = dpp_cell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register
     Diag<R> o;
@@ -181,10 +180,9 @@ __device__ __forceinline__ void tile_bwd_step(const StepEnv &E, Diag<R> &io, con
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
-        Cell c = bwd_cell(E.tr, r + 1 < R ? io.c[r + 1] : carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
-        kill_outside(c, mk.cell[r]);
-        o.c[r] = c;
+        o.c[r] = bwd_cell<false>(E.tr, r + 1 < R ? io.c[r + 1] : carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
     }
+    settle_diag<R>(norm, o, mk);
     io = o;
     carry = Xe;
 }
@@ -315,7 +313,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                     edge = edge_get(stage, q - blk_lo);
                 }
                 bases_down<R>(by, feed_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
-                tile_fwd_step<R>(E, io, p1, carry, edge, bx, by, mk);
+                tile_fwd_step<R>(norm_diag(d), E, io, p1, carry, edge, bx, by, mk);
                 if (d == 0) {  // the start cell (0, 0): slot 0 of the first stripe
                     if (lane == 0) {
                         Cell c;
@@ -448,7 +446,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                         edge = edge_get(stage, q - blk_lo);
                     }
                     bases_up<R>(by, feed_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
-                    tile_bwd_step<R>(E, io, s1, carry, edge, bx, by, mk);
+                    tile_bwd_step<R>(norm_diag(d), E, io, s1, carry, edge, bx, by, mk);
                     if (d == D) {  // the end corner (lX, lY)
 #pragma unroll
                         for (int r = 0; r < R; ++r)

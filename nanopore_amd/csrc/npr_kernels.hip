@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(512) k_dp_generic(KernelArgs a) {
                         const Cell U = jU >= 0 ? ring.get(s1, jU) : dead_cell();
                         const Cell M = jM >= 0 ? ring.get(s2, jM) : dead_cell();
                         const int cx = x > 0 ? X[x - 1] : 4, cy = y > 0 ? Y[y - 1] : 4;
-                        c = fwd_cell(tr, L, M, U, mdl->em[cx * 5 + cy], mdl->ex[5 + cx], mdl->ex[15 + cx],
+                        c = fwd_cell_dyn(norm_diag(d), tr, L, M, U, mdl->em[cx * 5 + cy], mdl->ex[5 + cx], mdl->ex[15 + cx],
                                      mdl->ey[10 + cy], mdl->ey[20 + cy]);
                     }
                 }
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(512) k_dp_generic(KernelArgs a) {
                             const Cell Ys = jY >= 0 ? ring.get(s1, jY) : dead_cell();
                             const Cell Ms = jM >= 0 ? ring.get(s2, jM) : dead_cell();
                             const int cx = x < lX ? X[x] : 4, cy = y < lY ? Y[y] : 4;
-                            c = bwd_cell(tr, Ms, Xs, Ys, mdl->em[cx * 5 + cy], mdl->ex[5 + cx], mdl->ex[15 + cx],
+                            c = bwd_cell_dyn(norm_diag(d), tr, Ms, Xs, Ys, mdl->em[cx * 5 + cy], mdl->ex[5 + cx], mdl->ex[15 + cx],
                                          mdl->ey[10 + cy], mdl->ey[20 + cy]);
                         }
                         if (x >= 1 && y >= 1 && !EM) {

@@ -95,8 +95,16 @@ static inline void normalise(cell32 *c, int32_t eref) {
 
 static const cell32 DEAD = {{0.f, 0.f, 0.f, 0.f, 0.f}, E_DEAD};
 
+/* Which anti-diagonals renormalise (npr_cell.h norm_diag): d = 0, 1 (mod 4).  On the others a cell keeps the
+ * reference exponent of its predecessors and the mantissas the recurrence produced. */
+static inline int norm_diag(int64_t d) { return (d & 2) == 0; }
+static inline void settle(cell32 *c, int32_t eref, int norm) {
+    if (norm) normalise(c, eref);
+    else c->e = eref;
+}
+
 static inline void fwd_cell(cell32 *c, const model32 *m, const cell32 *L, const cell32 *M, const cell32 *U, int cx,
-                            int cy) {
+                            int cy, int norm) {
     const int32_t eref = imax(L->e, imax(M->e, U->e));
     const float fL = scale2(L->e - eref), fM = scale2(M->e - eref), fU = scale2(U->e - eref);
     const float(*T)[5] = m->T;
@@ -121,12 +129,12 @@ static inline void fwd_cell(cell32 *c, const model32 *m, const cell32 *L, const 
     a = T[0][4] * U->v[0];
     a = fmaf(T[4][4], U->v[4], a);
     c->v[4] = (fU * m->ey[4][cy]) * a;
-    normalise(c, eref);
+    settle(c, eref, norm);
 }
 
 /* Ms = (x+1,y+1), Xs = (x+1,y), Ys = (x,y+1); cx = X[x], cy = Y[y] (the bases those moves consume) */
 static inline void bwd_cell(cell32 *c, const model32 *m, const cell32 *Ms, const cell32 *Xs, const cell32 *Ys, int cx,
-                            int cy) {
+                            int cy, int norm) {
     const int32_t eref = imax(Ms->e, imax(Xs->e, Ys->e));
     const float fM = scale2(Ms->e - eref), fX = scale2(Xs->e - eref), fY = scale2(Ys->e - eref);
     const float(*T)[5] = m->T;
@@ -156,7 +164,7 @@ static inline void bwd_cell(cell32 *c, const model32 *m, const cell32 *Ms, const
     b = T[4][0] * am;
     b = fmaf(T[4][4], aly, b);
     c->v[4] = b;
-    normalise(c, eref);
+    settle(c, eref, norm);
 }
 
 static inline float dot5(const float *w, const float *v) {
@@ -219,7 +227,7 @@ int32_t orc_fb_f32(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
                 const int64_t iL = (x > 0) ? cidx(lo, n, off, D, d - 1, xmy - 1) : -1;
                 const int64_t iU = (y > 0) ? cidx(lo, n, off, D, d - 1, xmy + 1) : -1;
                 fwd_cell(c, &m, iL >= 0 ? F + iL : &DEAD, iM >= 0 ? F + iM : &DEAD, iU >= 0 ? F + iU : &DEAD,
-                         x > 0 ? X[x - 1] : 4, y > 0 ? Y[y - 1] : 4);
+                         x > 0 ? X[x - 1] : 4, y > 0 ? Y[y - 1] : 4, norm_diag(d));
             }
         }
     float tm = 0.f;
@@ -257,7 +265,7 @@ int32_t orc_fb_f32(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
                     const int64_t jX = (x < lX) ? cidx(lo, n, off, D, d + 1, xmy + 1) : -1;
                     const int64_t jY = (y < lY) ? cidx(lo, n, off, D, d + 1, xmy - 1) : -1;
                     bwd_cell(c, &m, jM >= 0 ? B + jM : &DEAD, jX >= 0 ? B + jX : &DEAD, jY >= 0 ? B + jY : &DEAD,
-                             x < lX ? X[x] : 4, y < lY ? Y[y] : 4);
+                             x < lX ? X[x] : 4, y < lY ? Y[y] : 4, norm_diag(d));
                 }
             }
         if (btot_m) {
