@@ -90,6 +90,20 @@ struct npr_ctx {
 
 namespace {
 
+// NPR_POISON=<byte>: every device buffer is filled with that byte when it is handed out (and the forward scratch before
+// every batch), so that a kernel reading memory nobody wrote gives the same wrong answer on every box instead of
+// depending on what the previous owner of the memory left there.  Test / bring-up switch.
+int poison_byte() {
+    const char *e = std::getenv("NPR_POISON");
+    return e && e[0] ? static_cast<int>(std::strtol(e, nullptr, 0)) & 0xff : -1;
+}
+void poison(void *p, size_t bytes) {
+    if (poison_byte() >= 0 && p && bytes) {
+        (void)hipMemset(p, poison_byte(), bytes);
+        (void)hipDeviceSynchronize();
+    }
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -98,7 +112,9 @@ struct DevBuf {
         release();
         count = n;
         if (n == 0) return hipSuccess;
-        return hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        if (e == hipSuccess) poison(p, n * sizeof(T));
+        return e;
     }
     void release() {
         if (p && !borrowed) {
@@ -128,7 +144,11 @@ struct DevBuf {
         count = n;
         if (n == 0) return hipSuccess;
         const size_t need = n * sizeof(T);
-        if (need < (size_t(1) << 20)) return hipMalloc(reinterpret_cast<void **>(&p), need);  // small ones are cheap
+        if (need < (size_t(1) << 20)) {  // small ones are cheap
+            const hipError_t e0 = hipMalloc(reinterpret_cast<void **>(&p), need);
+            if (e0 == hipSuccess) poison(p, need);
+            return e0;
+        }
         int best = -1;
         for (size_t i = 0; i < ctx->cache.size(); ++i)
             if (ctx->cache[i].bytes >= need && ctx->cache[i].bytes <= 2 * need && (best < 0 || ctx->cache[i].bytes < ctx->cache[best].bytes)) best = static_cast<int>(i);
@@ -136,6 +156,7 @@ struct DevBuf {
             p = static_cast<T *>(ctx->cache[best].p), held = ctx->cache[best].bytes, owner = ctx;
             ctx->cache_bytes -= held;
             ctx->cache.erase(ctx->cache.begin() + best);
+            poison(p, held);
             return hipSuccess;
         }
         const size_t take = need + need / 8;  // a little headroom: the next batch of the same shape differs by a few percent
@@ -145,7 +166,7 @@ struct DevBuf {
             ctx->cache_flush();
             e = hipMalloc(reinterpret_cast<void **>(&p), take);
         }
-        if (e == hipSuccess) held = take, owner = ctx;
+        if (e == hipSuccess) held = take, owner = ctx, poison(p, take);
         return e;
     }
     // grow-only use (scratch kept from batch to batch): count is the size asked for, cap what is allocated
@@ -730,7 +751,8 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         if (force_generic) break;
         for (int c = cmin; c < kSchedClasses; ++c) {
             if (kClassTab[c].kind == K_WIDE && (use_tile || no_wide)) continue;
-            if (summary[k].max_width < kClassTab[c].slots()) cand[k] |= 1u << c;
+            if (kClassTab[c].kind == K_STAIR && !stair_fits(static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1, kClassTab[c].slots())) continue;
+            if (summary[k].max_width <= stair_max_width(kClassTab[c].R, kClassTab[c].NW)) cand[k] |= 1u << c;
         }
         if (cand[k]) sched_off[k] = ctl_entries, ctl_entries += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
     }
@@ -986,6 +1008,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc of the forward scratch", e);
         ctx->arena_cells = b->scratch_cells;
     }
+    poison(ctx->arena_F, ctx->arena_cells * 8);
     tm.lap("hipMalloc");
     if (ntasks) {
         HIP_TRY(ctx, hipMemcpyAsync(b->d_tasks.p, b->tasks.data(), b->d_tasks.bytes(), hipMemcpyHostToDevice, ctx->stream));
@@ -1237,6 +1260,10 @@ int32_t device_mea(npr_batch *b) {
                             al(4 * 4 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]);
         const bool in_arena = ctx->arena_F && need <= static_cast<size_t>(ctx->arena_cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
         char *cur = ctx->arena_F;
+        if (in_arena && poison_byte() >= 0) {  // the DP launches are done (their streams feed this one): the tables start from poison
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            poison(ctx->arena_F, need);
+        }
         auto take = [&](auto &buf, size_t count) -> hipError_t {
             using T = std::remove_pointer_t<decltype(buf.p)>;
             if (!in_arena) return buf.reserve(count);
@@ -2053,8 +2080,16 @@ int32_t npr_plan_frame_schedule(const npr_plan *pl, int32_t seg, int32_t slots, 
     std::vector<uint32_t> ctl(2 * (s.D() + 1));
     int64_t c = 0;
     if (!build_stair_schedule(s, slots_per_lane, slots / (64 * slots_per_lane), ctl.data(), &c)) return NPR_ERR_BAND_TOO_WIDE;
+    const bool packed = stair_packed(slots_per_lane, slots / (64 * slots_per_lane));  // npr_sched.h: the words come ready to use
     for (int64_t d = 0; d <= s.D(); ++d) {
         const uint32_t w = ctl[2 * d + 1];
+        if (packed) {
+            const uint32_t lo0 = w & 127u, lo1 = (w >> 7) & 127u;
+            if (row_off) row_off[d] = (((ctl[2 * d] - row_bias<2>()) >> 3) + 2u * lo1) & ((1u << 29) - 1u);  // the byte offset wrapped for rows before lane lo1
+            if (jlo) jlo[d] = static_cast<int32_t>(lo0 + lo1);
+            if (rebase) rebase[d] = static_cast<int32_t>((w >> 28) & 3u) - 1;
+            continue;
+        }
         if (row_off) row_off[d] = ctl[2 * d];
         if (jlo) jlo[d] = static_cast<int32_t>(w & 8191u);
         if (rebase) rebase[d] = static_cast<int32_t>((w >> 26) & 3u) - 1;

@@ -187,6 +187,12 @@ struct CoffArgs {
     uint32_t *coff;
 };
 int launch_plan_bands(const PlanArgs &a, void *stream);
+// k_dp_stair addresses a row of a task's forward scratch as (descriptor of the task's region - row_bias) + a 32-bit byte
+// offset of where lane 0 of the row would land; the bias keeps that offset non-negative for rows whose first lane is not
+// lane 0 (8 * R * 63 bytes at most).  A task therefore needs 8 * cells + bias < 2^32: see stair_fits().
+template <int R>
+NPR_HD constexpr uint32_t row_bias() { return R == 4 ? 2048u : 1024u; }
+NPR_HD constexpr bool stair_fits(int64_t rows, int slots) { return rows * slots < (int64_t(1) << 29) - 512; }
 int launch_plan_sched(const SchedArgs &a, void *stream);
 int launch_plan_stripes(const StripeArgs &a, void *stream);
 int launch_plan_coff(const CoffArgs &a, void *stream);

@@ -184,6 +184,61 @@ __device__ __forceinline__ Masks<R> band_masks(int jlo, int n) {
     return m;
 }
 
+// What k_dp_stair needs to know about one anti-diagonal, ready to use: the lane masks of the band, the byte offset of
+// the row in the task's forward scratch (where lane 0 would land, biased by row_bias so that it is never negative: the
+// byte offset added to every lane's own) and the rebase that leads into it.  For R = 2 -- the north-star class
+// -- the control words hold exactly that (npr_sched.h, stair_packed): four bit-field extracts and two s_bfm_b64 instead
+// of the ~40 scalar instructions that (jlo, n, co) took.  The other classes build the same from their control words.
+template <int R>
+struct RowCtl {
+    Masks<R> mk;
+    uint32_t soff;
+    int reb;
+    int jlo;
+};
+// lanes [lo, lo + w): s_bfm_b64 takes the low six bits of both operands (w <= 63; lo = 64 comes with w = 0), so the
+// bit fields of the control word need no masking -- one shift per field and this
+__device__ __forceinline__ uint64_t lane_run(uint32_t lo, uint32_t w) {
+    uint64_t m;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(w), "s"(lo));
+    return m;
+}
+template <int R>
+__device__ __forceinline__ RowCtl<R> read_row_ctl(cptr32 ctl, int d) {
+    RowCtl<R> c;
+    if constexpr (R == 2) {
+        const uint32_t so = ctl[2 * d], w = ctl[2 * d + 1];
+        c.mk.cell[0] = lane_run(w, w >> 14);
+        c.mk.cell[1] = lane_run(w >> 7, w >> 21);
+        c.mk.lanes = c.mk.cell[0] | c.mk.cell[1];
+        c.mk.l0 = static_cast<int>((w >> 7) & 127u);
+        c.soff = so;
+        c.reb = static_cast<int>((w >> 28) & 3u) - 1;
+        c.jlo = static_cast<int>((w & 127u) + ((w >> 7) & 127u));
+    } else {
+        const Ctl t = read_ctl(ctl, d);
+        c.mk = band_masks<R>(t.jlo, t.n);
+        c.soff = ((t.co - static_cast<uint32_t>(R * c.mk.l0)) << 3) + row_bias<R>();
+        c.reb = t.reb;
+        c.jlo = t.jlo;
+    }
+    return c;
+}
+// a packed control word (one-wavefront R = 2 tasks) in the terms of the other kernels (k_em_stair<2>)
+__device__ __forceinline__ Ctl read_ctl_packed(cptr32 ctl, int d) {
+    const uint32_t so = ctl[2 * d], w = ctl[2 * d + 1];
+    const uint32_t lo0 = w & 127u, lo1 = (w >> 7) & 127u;
+    return Ctl{(((so - row_bias<2>()) >> 3) + 2u * lo1) & ((1u << 29) - 1u), static_cast<int>(lo0 + lo1), static_cast<int>(((w >> 14) & 127u) + ((w >> 21) & 127u)),
+               static_cast<int>((w >> 28) & 3u) - 1};
+}
+
+// control word of a one-wavefront task of class R
+template <int R>
+__device__ __forceinline__ Ctl read_ctl_one(cptr32 ctl, int d) {
+    if constexpr (R == 2) return read_ctl_packed(ctl, d);
+    else return read_ctl(ctl, d);
+}
+
 // Everything wave-uniform a step needs.
 struct StepEnv {
     const DevModel *mdl;
@@ -331,8 +386,7 @@ __device__ __forceinline__ void bwd_rebase(const StepEnv &E, int r, Diag<R> &A, 
 // One forward anti-diagonal.  `io` holds anti-diagonal d-2 on entry and d on exit; `p1` holds d-1.  S.X / S.Y hold
 // X[x-1]*4 and Y[y-1]*4 of every slot.  norm = norm_diag(d) of the anti-diagonal being computed.
 template <int R>
-__device__ __forceinline__ void fwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &x0, const Ctl &ct) {
-    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+__device__ __forceinline__ void fwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &x0, const Masks<R> &mk) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     x0 += 1;
     bases_up<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
@@ -348,8 +402,7 @@ __device__ __forceinline__ void fwd_x_step(bool norm, const StepEnv &E, Diag<R> 
     io = o;
 }
 template <int R>
-__device__ __forceinline__ void fwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &y0, const Ctl &ct) {
-    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+__device__ __forceinline__ void fwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &y0, const Masks<R> &mk) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     y0 += 1;
     bases_down<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
@@ -393,6 +446,30 @@ __device__ __forceinline__ void store_row(char *F, const Diag<R> &C, const Ctl &
     }
 }
 
+// ... and with the descriptor of the task's scratch made once (base = F - row_bias) and the row's offset ready-made in
+// the control word: one vector add per row instead of seven scalar instructions.  (The offset goes into the VECTOR
+// offset, not the instruction's scalar offset: with the row offset in a short-lived SGPR as soffset, the next scalar
+// instruction reused that register and about one launch in a hundred read rows from a wrong address when another kernel
+// kept the memory pipeline busy -- tools/stress_tile.py; operands in VGPRs are read before the wavefront moves on.)
+template <int R>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t task_rsrc(char *F) {
+    return __builtin_amdgcn_make_buffer_rsrc(F - static_cast<int64_t>(row_bias<R>()), 0, -1, 0x00020000);
+}
+template <int R>
+__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t rs, const Diag<R> &C, const RowCtl<R> &ct, int voff) {
+    if (__builtin_amdgcn_inverse_ballot_w64(ct.mk.lanes)) {
+        const int vo = voff + static_cast<int>(ct.soff);
+        if constexpr (R == 1) {
+            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), C.c[0].e}, rs, vo, 0, 0);
+        } else if constexpr (R == 2) {
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, vo, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[2].m), C.c[2].e, fbits(C.c[3].m), C.c[3].e}, rs, vo + 16, 0, 0);
+        }
+    }
+}
+
 template <int R>
 struct FRow {  // forward match values of one anti-diagonal
     float v[R];
@@ -420,6 +497,25 @@ __device__ __forceinline__ void load_row(char *F, FRow<R> &f, const Ctl &ct, int
     }
 }
 
+template <int R>
+__device__ __forceinline__ void load_row(__amdgpu_buffer_rsrc_t rs, FRow<R> &f, const RowCtl<R> &ct, int voff) {
+    if (__builtin_amdgcn_inverse_ballot_w64(ct.mk.lanes)) {
+        const int vo = voff + static_cast<int>(ct.soff);
+        if constexpr (R == 1) {
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y;
+        } else if constexpr (R == 2) {
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
+        } else {
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, 0, 0);
+            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
+            f.v[2] = bitsf(g.x), f.e[2] = g.y, f.v[3] = bitsf(g.z), f.e[3] = g.w;
+        }
+    }
+}
+
 struct PairSink {
     int32_t *px, *py;
     float *pp;
@@ -432,8 +528,7 @@ struct PairSink {
 // d = 0 is the start cell, whose match state holds the start probability)
 template <int R>
 __device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, const FRow<R> &f, int d, int x0, int y0,
-                                           const Ctl &ct, int tot_e, float inv_tot, const int (&jr)[R], int &cnt) {
-    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+                                           const Masks<R> &mk, int tot_e, float inv_tot, const int (&jr)[R], int &cnt) {
     float p[R];
     uint64_t hit[R], any = 0;
 #pragma unroll
@@ -463,8 +558,7 @@ __device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, 
 // One backward anti-diagonal d.  `io` holds anti-diagonal d+2 on entry and d on exit; `s1` holds d+1.  S.X / S.Y hold
 // X[x]*4 and Y[y]*4 of every slot.  The X variant undoes the X-step into d+1 (d even), the Y variant a Y-step.
 template <int R>
-__device__ __forceinline__ void bwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &x0, const Ctl &ct) {
-    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+__device__ __forceinline__ void bwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &x0, const Masks<R> &mk) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     x0 -= 1;
     // x decreased by one in every slot: X[x] moves up a slot, slot 0 takes X[x0]
@@ -481,8 +575,7 @@ __device__ __forceinline__ void bwd_x_step(bool norm, const StepEnv &E, Diag<R> 
     io = o;
 }
 template <int R>
-__device__ __forceinline__ void bwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &y0, const Ctl &ct) {
-    const Masks<R> mk = band_masks<R>(ct.jlo, ct.n);
+__device__ __forceinline__ void bwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &y0, const Masks<R> &mk) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     y0 -= 1;
     bases_up<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
@@ -497,6 +590,19 @@ __device__ __forceinline__ void bwd_y_step(bool norm, const StepEnv &E, Diag<R> 
     settle_diag<R>(norm, o, mk);
     io = o;
 }
+
+// the same with the masks built from a control word (k_em_stair)
+#define NPR_CTL_STEP(name)                                                                                                     \
+    template <int R>                                                                                                           \
+    __device__ __forceinline__ void name(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &o, Streams<R> &S, int &c0, \
+                                         const Ctl &ct) {                                                                      \
+        name<R>(norm, E, io, o, S, c0, band_masks<R>(ct.jlo, ct.n));                                                           \
+    }
+NPR_CTL_STEP(fwd_x_step)
+NPR_CTL_STEP(fwd_y_step)
+NPR_CTL_STEP(bwd_x_step)
+NPR_CTL_STEP(bwd_y_step)
+#undef NPR_CTL_STEP
 
 }  // namespace
 

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                   flags = uni(tp->flags), model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
         // control words through the scalar cache: the array is never written by the kernel
         cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
+        const __amdgpu_buffer_rsrc_t frs = task_rsrc<R>(F);
         const int rs = flags & 1, re = (flags >> 1) & 1;
 
         __syncthreads();
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         // A holds the even anti-diagonals, B the odd ones; X-steps lead into odd anti-diagonals, Y-steps into even ones.
         Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
         Streams<R> S;  // X[x-1]*4 and Y[y-1]*4 of every slot
-        const Ctl c0 = read_ctl(ctl, 0);
+        const RowCtl<R> c0 = read_row_ctl<R>(ctl, 0);
         const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
         int x0 = -j0, y0 = j0;  // lattice point of slot 0
 #pragma unroll
@@ -110,26 +111,26 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 normalise(c, 0);
                 A.c[r] = c;
             }
-        store_row<R>(F, A, c0, voff);
-        Ctl nx = c0;
-        if (D >= 1) nx = read_ctl(ctl, 1);
+        store_row<R>(frs, A, c0, voff);
+        RowCtl<R> nx = c0;
+        if (D >= 1) nx = read_row_ctl<R>(ctl, 1);
         int d = 1;
         for (; d + 1 <= D; d += 2) {
-            Ctl cur = nx;
-            nx = read_ctl(ctl, d + 1);  // one ahead
+            RowCtl<R> cur = nx;
+            nx = read_row_ctl<R>(ctl, d + 1);  // one ahead
             if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, cur);
-            store_row<R>(F, B, cur, voff);
+            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, cur.mk);
+            store_row<R>(frs, B, cur, voff);
             cur = nx;
-            if (d + 2 <= D) nx = read_ctl(ctl, d + 2);
+            if (d + 2 <= D) nx = read_row_ctl<R>(ctl, d + 2);
             if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-            fwd_y_step<R>(norm_diag(d + 1), E, A, B, S, y0, cur);
-            store_row<R>(F, A, cur, voff);
+            fwd_y_step<R>(norm_diag(d + 1), E, A, B, S, y0, cur.mk);
+            store_row<R>(frs, A, cur, voff);
         }
         if (d <= D) {  // D odd: one more X-step, into B
             if (nx.reb) fwd_rebase<R>(E, nx.reb, A, B, S, x0, y0);
-            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, nx);
-            store_row<R>(F, B, nx, voff);
+            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, nx.mk);
+            store_row<R>(frs, B, nx, voff);
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
         {
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             // loaded one anti-diagonal ahead.  S now holds X[x]*4 and Y[y]*4 of every slot.
             A = dead_diag<R>(), B = dead_diag<R>();
             const bool oddD = D & 1;
-            Ctl cur = read_ctl(ctl, D);
+            RowCtl<R> cur = read_row_ctl<R>(ctl, D);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 S.X.b[r] = base4(E.X, lX, x0 + jr[r]);
@@ -191,19 +192,19 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             FRow<R> fa, fb;
 #pragma unroll
             for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
-            Ctl nxt = cur;
+            RowCtl<R> nxt = cur;
             if (oddD) {
-                load_row<R>(F, fb, cur, voff);
-                nxt = read_ctl(ctl, D - 1);
-                load_row<R>(F, fa, nxt, voff);
-                emit_pairs<R>(sink, B, fb, D, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                load_row<R>(frs, fb, cur, voff);
+                nxt = read_row_ctl<R>(ctl, D - 1);
+                load_row<R>(frs, fa, nxt, voff);
+                emit_pairs<R>(sink, B, fb, D, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
             } else {
-                load_row<R>(F, fa, cur, voff);
+                load_row<R>(frs, fa, cur, voff);
                 if (D >= 1) {
-                    nxt = read_ctl(ctl, D - 1);
-                    load_row<R>(F, fb, nxt, voff);
+                    nxt = read_row_ctl<R>(ctl, D - 1);
+                    load_row<R>(frs, fb, nxt, voff);
                 }
-                emit_pairs<R>(sink, A, fa, D, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                emit_pairs<R>(sink, A, fa, D, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
             }
             // `cur` is the control word of the anti-diagonal above the one computed next: its rebase is undone first
             int d2 = D - 1;
@@ -211,31 +212,31 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 const int reb = cur.reb;
                 cur = nxt;
                 if (d2 >= 1) {
-                    nxt = read_ctl(ctl, d2 - 1);
-                    load_row<R>(F, fb, nxt, voff);
+                    nxt = read_row_ctl<R>(ctl, d2 - 1);
+                    load_row<R>(frs, fb, nxt, voff);
                 }
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(norm_diag(d2), E, A, B, S, x0, cur);
-                emit_pairs<R>(sink, A, fa, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                bwd_x_step<R>(norm_diag(d2), E, A, B, S, x0, cur.mk);
+                emit_pairs<R>(sink, A, fa, d2, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
                 d2 -= 1;
             }
             for (; d2 >= 1; d2 -= 2) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
                 int reb = cur.reb;
                 cur = nxt;
-                nxt = read_ctl(ctl, d2 - 1);
-                load_row<R>(F, fa, nxt, voff);  // for the step after this one
+                nxt = read_row_ctl<R>(ctl, d2 - 1);
+                load_row<R>(frs, fa, nxt, voff);  // for the step after this one
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_y_step<R>(norm_diag(d2), E, B, A, S, y0, cur);
-                emit_pairs<R>(sink, B, fb, d2, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                bwd_y_step<R>(norm_diag(d2), E, B, A, S, y0, cur.mk);
+                emit_pairs<R>(sink, B, fb, d2, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
                 reb = cur.reb;
                 cur = nxt;
                 if (d2 >= 2) {
-                    nxt = read_ctl(ctl, d2 - 2);
-                    load_row<R>(F, fb, nxt, voff);
+                    nxt = read_row_ctl<R>(ctl, d2 - 2);
+                    load_row<R>(frs, fb, nxt, voff);
                 }
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(norm_diag(d2 - 1), E, A, B, S, x0, cur);
-                emit_pairs<R>(sink, A, fa, d2 - 1, x0, y0, cur, tot_e, inv_tot, jr, cnt);
+                bwd_x_step<R>(norm_diag(d2 - 1), E, A, B, S, x0, cur.mk);
+                emit_pairs<R>(sink, A, fa, d2 - 1, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
             }
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll
@@ -1143,7 +1144,7 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
         // =============================== forward: as k_dp_stair, all five states stored ===============================
         Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
         Streams<R> S;
-        const Ctl c0 = read_ctl(ctl, 0);
+        const Ctl c0 = read_ctl_one<R>(ctl, 0);
         const int j0 = c0.jlo;
         int x0 = -j0, y0 = j0;
 #pragma unroll
@@ -1165,7 +1166,7 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
             }
         store_row<R>(F, A, c0, voff), store_row_x<R>(Fx, a.slot_stride, A, c0, band_masks<R>(c0.jlo, c0.n), lane);
         for (int d = 1; d <= D; ++d) {
-            const Ctl ct = read_ctl(ctl, d);
+            const Ctl ct = read_ctl_one<R>(ctl, d);
             if (ct.reb) fwd_rebase<R>(E, ct.reb, A, B, S, x0, y0);
             if (d & 1) {
                 fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, ct);
@@ -1214,8 +1215,8 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
             A = dead_diag<R>(), B = dead_diag<R>();
             // q0..q3: control words of the anti-diagonals d, d-1, d-2, d-3 (n = 0 below the first one)
             const Ctl none{0u, 0, 0, 0};
-            Ctl q0 = read_ctl(ctl, D), q1 = D >= 1 ? read_ctl(ctl, D - 1) : none, q2 = D >= 2 ? read_ctl(ctl, D - 2) : none,
-                q3 = D >= 3 ? read_ctl(ctl, D - 3) : none;
+            Ctl q0 = read_ctl_one<R>(ctl, D), q1 = D >= 1 ? read_ctl_one<R>(ctl, D - 1) : none, q2 = D >= 2 ? read_ctl_one<R>(ctl, D - 2) : none,
+                q3 = D >= 3 ? read_ctl_one<R>(ctl, D - 3) : none;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 S.X.b[r] = base4(E.X, lX, x0 + jr[r]);
@@ -1268,7 +1269,7 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                 } else {
                     bwd_x_step<R>(norm_diag(d - 1), E, A, B, S, x0, q1);
                 }
-                q0 = q1, q1 = q2, q2 = q3, q3 = d >= 4 ? read_ctl(ctl, d - 4) : none;
+                q0 = q1, q1 = q2, q2 = q3, q3 = d >= 4 ? read_ctl_one<R>(ctl, d - 4) : none;
             }
             // total from the backward side
 #pragma unroll

@@ -39,6 +39,12 @@ namespace {
 constexpr int TILE_MAX_NW = 8;  // wavefronts per workgroup (launch bound)
 constexpr int TILE_BLOCK = 16;  // neighbour cells staged / published at a time
 constexpr int EDGE_FLOATS = 8;  // one neighbour cell in memory: m, sx, sy, lx, ly, e, -, -
+#ifndef NPR_EDGE_ST_AUX
+#define NPR_EDGE_ST_AUX 0
+#endif
+#ifndef NPR_EDGE_LD_AUX
+#define NPR_EDGE_LD_AUX 16
+#endif
 
 typedef const __attribute__((address_space(4))) int32_t *cptr_i32;
 
@@ -109,8 +115,8 @@ __device__ __forceinline__ void tile_load_row(char *F, uint32_t row, int lane_sh
 __device__ __forceinline__ void edge_store(char *Eb, uint32_t row, const Cell &c, uint64_t lane_mask) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Eb + static_cast<int64_t>(row) * (4 * EDGE_FLOATS), 0, -1, 0x00020000);
     if (__builtin_amdgcn_inverse_ballot_w64(lane_mask)) {
-        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.sy), fbits(c.lx)}, rs, 0, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(c.ly), c.e}, rs, 16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.sy), fbits(c.lx)}, rs, 0, 0, NPR_EDGE_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(c.ly), c.e}, rs, 16, 0, NPR_EDGE_ST_AUX);
     }
 }
 // `cnt` neighbour cells starting at row `row` into this wavefront's LDS staging (lane l takes cell l).  The loads bypass
@@ -118,8 +124,8 @@ __device__ __forceinline__ void edge_store(char *Eb, uint32_t row, const Cell &c
 __device__ __forceinline__ void edge_stage(char *Eb, uint32_t row, int cnt, float *stage, int lane) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Eb + static_cast<int64_t>(row) * (4 * EDGE_FLOATS), 0, -1, 0x00020000);
     if (__builtin_amdgcn_inverse_ballot_w64(low_lanes(cnt))) {
-        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, 16);
-        const v2i g = __builtin_amdgcn_raw_buffer_load_b64(rs, 32 * lane + 16, 0, 16);
+        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * lane, 0, NPR_EDGE_LD_AUX);
+        const v2i g = __builtin_amdgcn_raw_buffer_load_b64(rs, 32 * lane + 16, 0, NPR_EDGE_LD_AUX);
         *reinterpret_cast<v4i *>(stage + EDGE_FLOATS * lane) = q;
         *reinterpret_cast<v2i *>(stage + EDGE_FLOATS * lane + 4) = g;
     }

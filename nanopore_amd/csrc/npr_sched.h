@@ -18,13 +18,24 @@ namespace npr {
 // re-injects the base that left the wavefront at the step before), so the decision looks one anti-diagonal ahead.  Control
 // words per anti-diagonal: row offset in the forward scratch (cells), and jlo | n << 13 | (rebase + 1) << 26.  Returns false
 // when the band cannot be followed; `ctl` and `cells` may be null.
+//
+// The one-wavefront class with two slots per lane (k_dp_stair<2>, the north-star class) gets its words READY TO USE
+// instead (stair_packed): the scalar unit is shared by a CU's four SIMDs and issues about one instruction per cycle
+// (tools/issue_mix), and deriving two lane masks and a row address from (jlo, n, offset) took ~40 of the ~80 scalar
+// instructions of a step.  Word 0: byte offset of where lane 0 of the row would land in the task's scratch, biased by
+// row_bias (added to the lanes' own offsets in the row's buffer instruction).  Word 1: lo0 | lo1 << 7 | w0 << 14 | w1 << 21 |
+// (rebase + 1) << 28 -- slot r of the lanes [lo_r, lo_r + w_r) is inside the band (w_r <= 63: the class takes bands of at
+// most 126 cells).  jlo = lo0 + lo1, n = w0 + w1.
 struct StairState {
     int32_t flo;   // x-y of slot 0 of the current frame
     uint32_t off;  // scratch cells of the rows so far (a schedule that needs 2^32 or more is refused)
 };
+NPR_HD inline bool stair_packed(int R, int NW) { return R == 2 && NW == 1; }
+// widest band a class takes
+NPR_HD inline int32_t stair_max_width(int R, int NW) { return 64 * R * NW - 1 - (stair_packed(R, NW) ? 1 : 0); }
 NPR_HD inline bool stair_begin(StairState &st, int32_t lo0, int32_t n0, int32_t max_width, int R, int NW) {
     const int32_t C = 64 * R * NW;
-    if (n0 != 1 || max_width >= C) return false;
+    if (n0 != 1 || max_width > stair_max_width(R, NW)) return false;
     st.flo = lo0 - 2 * ((C - 1) / 2);
     st.off = 0;
     return true;
@@ -51,10 +62,19 @@ NPR_HD inline bool stair_step(StairState &st, int32_t d, int32_t D, int32_t lo, 
     }
     const int32_t jlo = (lo - st.flo) >> 1;  // lo >= flo, same parity
     const int32_t l0 = jlo >> rshift, l1 = (jlo + n + R - 1) >> rshift;
-    w0 = st.off;
-    w1 = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26);
     const uint32_t row = static_cast<uint32_t>(l1 - l0) << rshift;
-    if (st.off + row < st.off) return false;  // 2^32 cells
+    if (rshift == 1 && C == 128) {  // stair_packed
+        const uint32_t lo0 = static_cast<uint32_t>(jlo + 1) >> 1, lo1 = static_cast<uint32_t>(jlo) >> 1;
+        const uint32_t hi0 = static_cast<uint32_t>(jlo + n + 1) >> 1, hi1 = static_cast<uint32_t>(jlo + n) >> 1;
+        if (hi0 - lo0 > 63u || hi1 - lo1 > 63u) return false;
+        if (st.off + row >= (1u << 29) - 512u) return false;  // the row offsets are 32-bit byte offsets (stair_fits)
+        w0 = ((st.off - 2u * lo1) << 3) + row_bias<2>();
+        w1 = lo0 | (lo1 << 7) | ((hi0 - lo0) << 14) | ((hi1 - lo1) << 21) | (static_cast<uint32_t>(reb + 1) << 28);
+    } else {
+        if (st.off + row < st.off) return false;  // 2^32 cells
+        w0 = st.off;
+        w1 = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26);
+    }
     st.off += row;
     return true;
 }

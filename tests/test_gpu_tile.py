@@ -92,3 +92,37 @@ def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(
         assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
         order = np.lexsort((m["py"], m["px"]))
         assert np.array_equal(pp[poff[i]:poff[i + 1]], m["pp"].astype(np.float32)[order])
+
+
+def test_repeated_launches_on_poisoned_scratch_give_identical_pairs(gpu_ctx, monkeypatch):
+    """Every launch finds its scratch and its buffers filled with a poison byte (NPR_POISON) instead of what the previous,
+    identical launch left there, several kernel classes run side by side, and every result must equal the first one's: a
+    kernel that reads a row before it is written, or from a wrong address, shows up here instead of once in a hundred
+    launches on one box in three.  (This caught the row offset of k_dp_stair held in a short-lived SGPR as the buffer
+    instruction's scalar offset: tools/stress_tile.py)"""
+    from nanopore_amd import realign as R, synth
+    from nanopore_amd.hmm import Hmm
+    T, E, _ = load_model_arrays()
+    gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
+    monkeypatch.setenv("NPR_POISON", "0x3f")
+    cases = ((synth.make_workload(1007, 48, 3000, T, E, flank=0, length_sigma=0.5, len_min=300, len_max=9000),
+              R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000), 120),
+             (synth.make_workload(1008, 256, 1500, T, E, flank=0, length_sigma=0.4, len_min=200, len_max=5000),
+              R.make_params(band_mode=R.BAND_FIXED, fixed_width=100), 60),
+             (synth.make_workload(1009, 96, 2000, T, E, flank=0, length_sigma=0.4, len_min=200, len_max=5000),
+              R.make_params(band_mode=R.BAND_FIXED, fixed_width=300), 60))
+    for w, P, reps in cases:
+        first = None
+        for rep in range(reps):
+            b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
+            b.run(), b.finish()
+            out = (b.results(), b.pairs(), b.ops())
+            b.close()
+            if first is None:
+                first = out
+                assert (out[0]["status"] == 0).all()
+                continue
+            for key in ("status", "loglik", "loglik_bwd", "score"):
+                assert np.array_equal(out[0][key], first[0][key]), (rep, key)
+            assert all(np.array_equal(a, c) for a, c in zip(out[1], first[1])), rep
+            assert all(np.array_equal(a, c) for a, c in zip(out[2], first[2])), rep
