@@ -300,6 +300,7 @@ struct npr_batch {
     DevBuf<uint32_t> d_coff;
     DevBuf<uint32_t> d_ctl;  // register-kernel tasks: frame schedule, two words per anti-diagonal
     DevBuf<Stripe> d_stripes;  // k_dp_tile tasks: stripe tables
+    DevBuf<uint32_t> d_rowmask;  // ... and the packed lane masks of every row of every stripe (tile_row_word)
     DevBuf<PlanSeg> d_pseg;    // the segments as the device planner sees them (read order)
     DevBuf<int64_t> d_region;  // k_dp_tile: first scratch cell of each resident workgroup
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
@@ -798,7 +799,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     }
     // k_dp_tile tasks are ordered by the forward scratch they need (one row per anti-diagonal of a stripe: also what a
     // task costs): a workgroup's region is sized by its FIRST task, every later one from the queue is smaller
-    std::vector<int64_t> tile_need(ntasks, 0);
+    std::vector<int64_t> tile_need(ntasks, 0), rowmask_off_of(ntasks, -1);
     if ((e = b->d_stripes.alloc_from(ctx, stripe_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     if (!tile_list.empty()) {
         DevBuf<int32_t> d_list;
@@ -815,6 +816,18 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         HIP_TRY(ctx, hipMemcpyAsync(rows.data(), d_rows.p, d_rows.bytes(), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (size_t q = 0; q < nt; ++q) tile_need[tile_list[q]] = (tile_scratch_cells(rows[q], kClassTab[kTileClass].R) + 63) & ~int64_t(63);
+        // the lane masks of all those rows, one word each
+        std::vector<int64_t> moff(nt);
+        int64_t mask_rows = 0;
+        for (size_t q = 0; q < nt; ++q) moff[q] = mask_rows, rowmask_off_of[tile_list[q]] = mask_rows, mask_rows += rows[q];
+        DevBuf<int64_t> d_moff;
+        if ((e = d_moff.alloc(nt)) != hipSuccess || (e = b->d_rowmask.alloc_from(ctx, mask_rows)) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+        HIP_TRY(ctx, hipMemcpyAsync(d_moff.p, moff.data(), d_moff.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        RowMaskArgs ma{static_cast<int32_t>(nt), d_list.p, b->d_pseg.p, b->d_lo.p, b->d_n.p, d_toff.p, b->d_stripes.p, d_moff.p, b->d_rowmask.p};
+        const int rc2 = launch_plan_rowmask(ma, ctx->stream);
+        if (rc2 != 0) return fail(ctx, NPR_ERR_HIP, "k_plan_rowmask launch", static_cast<hipError_t>(rc2));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // d_list / d_toff / d_moff go out of scope
     }
     if (any_generic) {
         const int32_t rc = ensure_coff(b.get());
@@ -863,6 +876,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         const int c = cls_of[g];
         t.ctl_off = is_register_class(c) ? sched_off[g] : -1;
         t.tile_off = tile_off_of[g];
+        t.rowmask_off = rowmask_off_of[g];
         const int64_t pad = std::max(summary[g].generic_cells, is_register_class(c) ? sched_cells[g] : 0);  // either kernel may run the task
         if (pad >= (int64_t(1) << 32)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: segment too large");
         t.cells_pad = static_cast<int32_t>(std::min<int64_t>(pad, INT32_MAX));
@@ -1046,6 +1060,7 @@ static KernelArgs make_args(npr_batch *b) {
     a.coff = b->d_coff.p;
     a.ctl = b->d_ctl.p;
     a.stripes = b->d_stripes.p;
+    a.rowmask = b->d_rowmask.p;
     a.region = b->d_region.p;
     a.F = b->ctx->arena_F;
     a.slot_stride = b->slot_stride;
@@ -1889,6 +1904,16 @@ int64_t npr_batch_plan_check(npr_batch *b) {
                         HIP_TRY(ctx, hipMemcpy(st.data(), b->d_stripes.p + t.tile_off, S * sizeof(Stripe), hipMemcpyDeviceToHost));
                         build_stripes(sg, R, want_st.data(), nullptr);
                         ok = std::memcmp(st.data(), want_st.data(), S * sizeof(Stripe)) == 0;
+                        if (ok && R == 2) {  // the packed lane masks of every row
+                            const size_t nrows = static_cast<size_t>(want_st[0].K);
+                            std::vector<uint32_t> rm(nrows), want_rm(nrows, 0);
+                            if (nrows) HIP_TRY(ctx, hipMemcpy(rm.data(), b->d_rowmask.p + t.rowmask_off, nrows * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                            for (size_t q = 1; q < S; ++q)
+                                for (int32_t d = want_st[q].df; d <= want_st[q].dl; ++d)
+                                    want_rm[want_st[q].row0 + static_cast<uint32_t>(d - want_st[q].df)] = tile_row_word(d, sg.lo[d], sg.n[d], want_st[q].X);
+                            ok = rm == want_rm;
+                            if (!ok && std::getenv("NPR_TIMING")) std::fprintf(stderr, "[npr plan check] row masks differ (%zu rows)\n", nrows);
+                        }
                         if (!ok && std::getenv("NPR_TIMING"))
                             for (size_t q = 0; q < S; ++q)
                                 if (std::memcmp(&st[q], &want_st[q], sizeof(Stripe)) != 0) {

@@ -23,6 +23,7 @@ struct Task {
     int32_t cells_pad; // padded cell count (scratch use)
     int64_t ctl_off;   // register-kernel tasks: first anti-diagonal entry in d_ctl (pairs of words), else -1
     int64_t tile_off;  // stripe-kernel tasks: index of the task's header in d_stripes (Stripe units), else -1
+    int64_t rowmask_off;  // stripe-kernel tasks: first row of the task in d_rowmask (one word per row of a stripe), else -1
 };
 
 // k_dp_tile cuts a task's lattice columns into stripes of at most 64*R columns; one wavefront sweeps a stripe
@@ -56,6 +57,7 @@ struct KernelArgs {
     const int32_t *n;
     const uint32_t *coff;  // per anti-diagonal: offset of its first cell inside the task (cells padded to x4)
     const Stripe *stripes;  // k_dp_tile: stripe tables (Task::tile_off)
+    const uint32_t *rowmask;  // k_dp_tile: lane masks of every row, packed (npr_sched.h tile_row_word; Task::rowmask_off)
     unsigned long long *prof;  // k_dp_tile, NPR_TILE_PROF=1: wait-cycle counters
     const int64_t *region;  // k_dp_tile: first scratch cell of each workgroup (regions sized by the workgroup's first task)
     const uint32_t *ctl;   // register kernel: two control words per anti-diagonal (row offset; jlo | n << 13 | (rebase + 1) << 26)
@@ -193,6 +195,17 @@ int launch_plan_bands(const PlanArgs &a, void *stream);
 template <int R>
 NPR_HD constexpr uint32_t row_bias() { return R == 4 ? 2048u : 1024u; }
 NPR_HD constexpr bool stair_fits(int64_t rows, int slots) { return rows * slots < (int64_t(1) << 29) - 512; }
+struct RowMaskArgs {
+    int32_t count;              // stripe-kernel tasks
+    const int32_t *seg_index;   // their segments
+    const PlanSeg *segs;
+    const int32_t *lo, *n;
+    const int64_t *tile_off;    // per task: header of its stripe table
+    const Stripe *stripes;
+    const int64_t *mask_off;    // per task: first row in `out`
+    uint32_t *out;
+};
+int launch_plan_rowmask(const RowMaskArgs &a, void *stream);
 int launch_plan_sched(const SchedArgs &a, void *stream);
 int launch_plan_stripes(const StripeArgs &a, void *stream);
 int launch_plan_coff(const CoffArgs &a, void *stream);

@@ -57,14 +57,15 @@ __device__ __forceinline__ UStripe load_stripe(const Stripe *tab, int s) {
     return UStripe{p[0], p[1], p[2], p[3], static_cast<uint32_t>(p[4])};
 }
 
-// the band of anti-diagonal d inside a stripe whose slot 0 is lattice column `origin`, clipped to the slots [c0, c1]
-struct TBand {
-    int jlo, n;
-};
-__device__ __forceinline__ TBand tile_band(int d, int lo, int n, int origin, int c0, int c1) {
-    const int xlo = (d + lo) >> 1;  // lo has the parity of d
-    const int j0 = max(xlo - origin, c0), j1 = min(xlo + n - 1 - origin, c1);
-    return TBand{j1 >= j0 ? j0 : 0, max(j1 - j0 + 1, 0)};
+// lane masks of a row from its packed word (npr_sched.h tile_row_word): mask_r = (~0 << lo_r) & (~0 >> sh_r), six-bit
+// fields -- the 64-bit shifts take six bits of their count, so the fields need no masking
+__device__ __forceinline__ Masks<2> row_masks(uint32_t w) {
+    Masks<2> m;
+    m.cell[0] = (~0ull << (w & 63u)) & (~0ull >> ((w >> 6) & 63u));
+    m.cell[1] = (~0ull << ((w >> 12) & 63u)) & (~0ull >> ((w >> 18) & 63u));
+    m.lanes = m.cell[0] | m.cell[1];
+    m.l0 = 0;
+    return m;
 }
 
 // progress words: volatile LDS accesses (the pointer has to say LDS, or the compiler emits flat loads)
@@ -72,51 +73,33 @@ typedef __attribute__((address_space(3))) int lds_int;
 __device__ __forceinline__ int lds_peek(const int *p) { return *(const volatile lds_int *)(p); }
 __device__ __forceinline__ void lds_poke(int *p, int v) { *(volatile lds_int *)(p) = v; }
 
-// one row per anti-diagonal of a stripe: 64*R cells of 8 bytes, lane l at 8*R*l
+// One row per anti-diagonal of a stripe: 64*R cells of 8 bytes, lane l at 8*R*l.  The descriptor is the stripe's (its
+// first row); `vo` = this lane's byte offset in the row + 8 * 64 * R * (row - first row), in a VGPR: nothing per row on the
+// scalar unit, and no scalar offset operand (npr_frame.h store_row explains why).
 template <int R>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_row_rsrc(char *F, uint32_t row, int lane_shift) {
-    return __builtin_amdgcn_make_buffer_rsrc(F + (static_cast<int64_t>(row) * 64 - lane_shift) * (8 * R), 0, -1, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stripe_rsrc(char *base, uint32_t row0, int row_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base + static_cast<int64_t>(row0) * row_bytes, 0, -1, 0x00020000);
 }
 template <int R>
-__device__ __forceinline__ void tile_store_row(char *F, uint32_t row, const Diag<R> &C, const Masks<R> &mk, int voff) {
-    const __amdgpu_buffer_rsrc_t rs = tile_row_rsrc<R>(F, row, 0);
-    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
-        if constexpr (R == 1) {
-            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), C.c[0].e}, rs, voff, 0, 0);
-        } else if constexpr (R == 2) {
-            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, voff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[2].m), C.c[2].e, fbits(C.c[3].m), C.c[3].e}, rs, voff + 16, 0, 0);
-        }
-    }
+__device__ __forceinline__ void tile_store_row(__amdgpu_buffer_rsrc_t rs, int vo, const Diag<R> &C, const Masks<R> &mk) {
+    static_assert(R == 2, "k_dp_tile: two slots per lane");
+    if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes))
+        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), C.c[0].e, fbits(C.c[1].m), C.c[1].e}, rs, vo, 0, 0);
 }
-// lane_shift: the row was stored by lanes `lane_shift` below the ones that now read it (right-aligned backward stripe)
 template <int R>
-__device__ __forceinline__ void tile_load_row(char *F, uint32_t row, int lane_shift, FRow<R> &f, const Masks<R> &mk, int voff) {
-    const __amdgpu_buffer_rsrc_t rs = tile_row_rsrc<R>(F, row, lane_shift);
+__device__ __forceinline__ void tile_load_row(__amdgpu_buffer_rsrc_t rs, int vo, FRow<R> &f, const Masks<R> &mk) {
     if (__builtin_amdgcn_inverse_ballot_w64(mk.lanes)) {
-        if constexpr (R == 1) {
-            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
-            f.v[0] = bitsf(q.x), f.e[0] = q.y;
-        } else if constexpr (R == 2) {
-            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
-        } else {
-            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-            const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, 0, 0);
-            f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
-            f.v[2] = bitsf(g.x), f.e[2] = g.y, f.v[3] = bitsf(g.z), f.e[3] = g.w;
-        }
+        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+        f.v[0] = bitsf(q.x), f.e[0] = q.y, f.v[1] = bitsf(q.z), f.e[1] = q.w;
     }
 }
 
-// the neighbour cell of row `row`: 32 bytes at Eb + 32 * row, written by the one lane that holds it
-__device__ __forceinline__ void edge_store(char *Eb, uint32_t row, const Cell &c, uint64_t lane_mask) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Eb + static_cast<int64_t>(row) * (4 * EDGE_FLOATS), 0, -1, 0x00020000);
+// the neighbour cell of a row: 32 bytes at (stripe's first) + 32 * (row - first row), written by the one lane that holds it
+__device__ __forceinline__ void edge_store(__amdgpu_buffer_rsrc_t rs, int k, const Cell &c, uint64_t lane_mask) {
     if (__builtin_amdgcn_inverse_ballot_w64(lane_mask)) {
-        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.sy), fbits(c.lx)}, rs, 0, 0, NPR_EDGE_ST_AUX);
-        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(c.ly), c.e}, rs, 16, 0, NPR_EDGE_ST_AUX);
+        const int vo = 4 * EDGE_FLOATS * k;
+        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.sy), fbits(c.lx)}, rs, vo, 0, NPR_EDGE_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(c.ly), c.e}, rs, vo + 16, 0, NPR_EDGE_ST_AUX);
     }
 }
 // `cnt` neighbour cells starting at row `row` into this wavefront's LDS staging (lane l takes cell l).  The loads bypass
@@ -222,11 +205,11 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
     int t = blockIdx.x;
     while (t < a.ntasks) {
         const Task *tp = a.tasks + t;
-        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), band_off = uni64(tp->band_off),
-                      pair_off = uni64(tp->pair_off), tile_off = uni64(tp->tile_off);
+        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), pair_off = uni64(tp->pair_off),
+                      tile_off = uni64(tp->tile_off), rowmask_off = uni64(tp->rowmask_off);
         const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap),
                   flags = uni(tp->flags), model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
-        cptr_i32 blo = (cptr_i32)(a.lo + band_off), bn = (cptr_i32)(a.n + band_off);
+        cptr32 rowmask = (cptr32)(a.rowmask + rowmask_off);  // one packed word per row, through the scalar cache
         const Stripe *tab = a.stripes + tile_off;
         const UStripe hd = load_stripe(tab, 0);
         const int S = hd.X;
@@ -285,7 +268,9 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
             Cell carry = dead_cell();
             const uint64_t out_lane = 1ull << (st.K / R - 1);  // holds the stripe's last column in its top register
             int blk_lo = 0, blk_hi = 0;                         // staged cells of the left stripe: [blk_lo, blk_hi) past dfL
-            int lo_n = blo[st.df], n_n = bn[st.df];             // band row one ahead
+            cptr32 rm = rowmask + st.row0;
+            uint32_t w_n = rm[0];                               // mask word one row ahead
+            const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc<R>(F, st.row0, K * 8), rsE = stripe_rsrc<R>(Ef, st.row0, 4 * EDGE_FLOATS);
             {   // (x-1, y-1) of slot 0 on the first anti-diagonal: the left stripe's cell on df - 2
                 const int q0 = st.df - 2 - dfL;
                 if (q0 >= 0 && q0 < lenL) {
@@ -301,10 +286,9 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
             }
 
             auto step = [&](int d, Diag<R> &io, const Diag<R> &p1) {
-                const int lo_c = lo_n, n_c = n_n;
-                if (d < st.dl) lo_n = blo[d + 1], n_n = bn[d + 1];
-                const TBand tb = tile_band(d, lo_c, n_c, st.X, 0, st.K - 1);
-                const Masks<R> mk = band_masks<R>(tb.jlo, tb.n);
+                const int k = d - st.df;
+                const Masks<R> mk = row_masks(w_n);
+                if (d < st.dl) w_n = rm[static_cast<uint32_t>(k + 1)];
                 Cell edge = dead_cell();
                 const int q = d - 1 - dfL;
                 if (q >= 0 && q < lenL) {  // uniform
@@ -329,13 +313,11 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                         io.c[0] = c;
                     }
                 }
-                const uint32_t row = st.row0 + static_cast<uint32_t>(d - st.df);
-                tile_store_row<R>(F, row, io, mk, voff);
-                edge_store(Ef, row, io.c[R - 1], out_lane);
-                const int k = d - st.df;
+                tile_store_row<R>(rsF, voff + k * (K * 8), io, mk);
+                edge_store(rsE, k, io.c[R - 1], out_lane);
                 if ((k & (TILE_BLOCK - 1)) == TILE_BLOCK - 1 || d == st.dl) {
                     { const uint64_t c0 = tick(); wait_vm(); pf_vm += tick() - c0; }
-                    if (lane == 0) lds_poke(prog + wv, static_cast<int>(row) + 1);
+                    if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k + 1);
                 }
             };
             int d = st.df;
@@ -389,9 +371,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                     wR = (s + 1) % NW;
                 }
                 const int lenR = dlR - dfR + 1;
-                const int pad = K - st.K;    // the stripe sits in the top slots: slot j is column X0 + j
-                const int X0 = st.X - pad;
-                const int lane_shift = pad / R;
+                const int X0 = st.X;  // every stripe is 64*R columns wide (npr_sched.h stripe_fill): slot j is column X0 + j
                 Bases<R> bx, by;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -402,17 +382,16 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                 feed_init<-1>(fy, E.Y, lY, st.dl - X0 - (K - 1), lane);
                 Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
                 Cell carry = dead_cell();
-                const uint64_t out_lane = 1ull << lane_shift;  // holds the stripe's first column in its register 0
+                const uint64_t out_lane = 1ull;  // lane 0 holds the stripe's first column in its register 0
                 int blk_lo = 0, blk_hi = 0;                     // staged cells of the right stripe: entries (blk_lo, blk_hi] ... see below
                 FRow<R> fa, fb;
 #pragma unroll
                 for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
-                int lo_n = blo[st.dl], n_n = bn[st.dl];
-                // forward row of the first anti-diagonal (the later ones are loaded one step ahead)
-                {
-                    const TBand tb = tile_band(st.dl, lo_n, n_n, X0, pad, K - 1);
-                    tile_load_row<R>(F, st.row0 + static_cast<uint32_t>(st.dl - st.df), lane_shift, fb, band_masks<R>(tb.jlo, tb.n), voff);
-                }
+                cptr32 rm = rowmask + st.row0;
+                const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc<R>(F, st.row0, K * 8), rsE = stripe_rsrc<R>(Eb, st.row0, 4 * EDGE_FLOATS);
+                // forward row of the first anti-diagonal (the later ones are loaded one step ahead, with their masks)
+                Masks<R> mk_n = row_masks(rm[static_cast<uint32_t>(st.dl - st.df)]);
+                tile_load_row<R>(rsF, voff + (st.dl - st.df) * (K * 8), fb, mk_n);
                 blk_lo = lenR, blk_hi = lenR;  // staged: entries [blk_lo, blk_hi) of the right stripe (entry = d' - dfR); empty
                 {   // (x+1, y+1) of the top slot on the first anti-diagonal: the right stripe's cell on dl + 2
                     const int q0 = st.dl + 2 - dfR;
@@ -430,14 +409,12 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
 
                 // f: the forward row of d (loaded a step ago); fnext: where the row of d-1 goes
                 auto step = [&](int d, Diag<R> &io, const Diag<R> &s1, FRow<R> &f, FRow<R> &fnext) {
-                    const int lo_c = lo_n, n_c = n_n;
+                    const int k = d - st.df;
+                    const Masks<R> mk = mk_n;
                     if (d > st.df) {
-                        lo_n = blo[d - 1], n_n = bn[d - 1];
-                        const TBand tn = tile_band(d - 1, lo_n, n_n, X0, pad, K - 1);
-                        tile_load_row<R>(F, st.row0 + static_cast<uint32_t>(d - 1 - st.df), lane_shift, fnext, band_masks<R>(tn.jlo, tn.n), voff);
+                        mk_n = row_masks(rm[static_cast<uint32_t>(k - 1)]);
+                        tile_load_row<R>(rsF, voff + (k - 1) * (K * 8), fnext, mk_n);
                     }
-                    const TBand tb = tile_band(d, lo_c, n_c, X0, pad, K - 1);
-                    const Masks<R> mk = band_masks<R>(tb.jlo, tb.n);
                     Cell edge = dead_cell();
                     const int q = d + 1 - dfR;
                     if (q >= 0 && q < lenR) {  // uniform
@@ -464,8 +441,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                                 io.c[r] = c;
                             }
                     }
-                    const uint32_t row = st.row0 + static_cast<uint32_t>(d - st.df);
-                    edge_store(Eb, row, io.c[0], out_lane);
+                    edge_store(rsE, k, io.c[0], out_lane);
                     // posteriors of this anti-diagonal, slots claimed from the workgroup's LDS counter
                     {
                         float p[R];
@@ -498,10 +474,9 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                             }
                         }
                     }
-                    const int k = st.dl - d;
-                    if ((k & (TILE_BLOCK - 1)) == TILE_BLOCK - 1 || d == st.df) {
+                    if (((st.dl - d) & (TILE_BLOCK - 1)) == TILE_BLOCK - 1 || d == st.df) {
                         { const uint64_t c0 = tick(); wait_vm(); pf_vm += tick() - c0; }
-                        if (lane == 0) lds_poke(prog + wv, static_cast<int>(row));
+                        if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k);
                     }
                 };
                 int d = st.dl;
@@ -566,8 +541,6 @@ int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream) {
         hipLaunchKernelGGL((k_dp_tile<2, true>), dim3(grid), dim3(WAVE * NW), lds, s, a);
     else if (R == 2)
         hipLaunchKernelGGL((k_dp_tile<2, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
-    else if (R == 4)
-        hipLaunchKernelGGL((k_dp_tile<4, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
     else
         return static_cast<int>(hipErrorInvalidValue);
     return static_cast<int>(hipGetLastError());

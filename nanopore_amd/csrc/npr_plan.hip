@@ -236,6 +236,23 @@ __global__ void __launch_bounds__(64) k_plan_coff(CoffArgs a) {
     }
 }
 
+// The packed lane masks of every row of every stripe of the k_dp_tile tasks (npr_sched.h tile_row_word): one workgroup
+// per task, its wavefronts take the stripes round-robin, a lane per row.
+__global__ void __launch_bounds__(256) k_plan_rowmask(RowMaskArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = blockIdx.x; i < a.count; i += gridDim.x) {
+        const PlanSeg sg = a.segs[a.seg_index[i]];
+        const int32_t *lo = a.lo + sg.band_off, *n = a.n + sg.band_off;
+        const Stripe *tab = a.stripes + a.tile_off[i];
+        uint32_t *out = a.out + a.mask_off[i];
+        const int S = tab[0].X;
+        for (int s = wv; s < S; s += 4) {
+            const Stripe st = tab[1 + s];
+            for (int d = st.df + lane; d <= st.dl; d += 64) out[st.row0 + static_cast<uint32_t>(d - st.df)] = tile_row_word(d, lo[d], n[d], st.X);
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t code_of(uint32_t c) {
     c &= 0xdfu;  // upper case
     return c == 'A' ? 0u : (c == 'C' ? 1u : (c == 'G' ? 2u : (c == 'T' ? 3u : 4u)));
@@ -271,6 +288,11 @@ int launch_plan_sched(const SchedArgs &a, void *stream) {
 int launch_plan_stripes(const StripeArgs &a, void *stream) {
     const int grid = a.count < 65536 ? (a.count > 0 ? a.count : 1) : 65536;
     hipLaunchKernelGGL(k_plan_stripes, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return static_cast<int>(hipGetLastError());
+}
+int launch_plan_rowmask(const RowMaskArgs &a, void *stream) {
+    if (a.count <= 0) return 0;
+    hipLaunchKernelGGL(k_plan_rowmask, dim3(a.count < 65536 ? a.count : 65536), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return static_cast<int>(hipGetLastError());
 }
 int launch_plan_coff(const CoffArgs &a, void *stream) {

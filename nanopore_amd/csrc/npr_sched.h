@@ -119,6 +119,26 @@ NPR_HD inline int64_t stripe_ranges(const int32_t *lo_, const int32_t *n_, int64
         if (dl[k * stride] >= df[k * stride]) rows += dl[k * stride] - df[k * stride] + 1;
     return rows;
 }
+// What k_dp_tile<2> needs to know about one row (anti-diagonal d of a stripe whose first lattice column is X), ready to
+// use: which lanes hold a band cell in their slot 0 / slot 1 (slot j = column X + j, two slots per lane).  As for
+// k_dp_stair<2> (stair_packed above) the scalar unit is the scarce resource: clipping the band to the stripe and building
+// the two masks from (lo, n) took ~35 scalar instructions per step.  Word: lo0 | sh0 << 6 | lo1 << 12 | sh1 << 18 with
+// mask_r = (~0 << lo_r) & (~0 >> sh_r), every field 0..63 (s_lshl_b64 / s_lshr_b64 take six bits of the count); an
+// empty run is lo = 1, sh = 63.
+NPR_HD inline uint32_t tile_row_word(int32_t d, int32_t lo, int32_t n, int32_t X) {
+    const int32_t xlo = (d + lo) >> 1;  // lo has the parity of d
+    const int32_t j0 = xlo - X > 0 ? xlo - X : 0, j1 = xlo + n - 1 - X < 127 ? xlo + n - 1 - X : 127;
+    uint32_t w = 0;
+    for (int r = 0; r < 2; ++r) {
+        int32_t a = 1, b = 1;  // lanes [a, b)
+        if (j1 >= j0) a = (j0 - r + 1) >> 1, b = (j1 + 1 - r + 1) >> 1;
+        uint32_t f = 1u | (63u << 6);
+        if (b > a) f = static_cast<uint32_t>(a) | (static_cast<uint32_t>(64 - b) << 6);
+        w |= f << (12 * r);
+    }
+    return w;
+}
+
 // out[1 + k].df / .dl already hold the ranges
 NPR_HD inline void stripe_fill(Stripe *out, int64_t lX, int R) {
     const int64_t K = 64 * R;
