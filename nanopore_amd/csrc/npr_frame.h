@@ -204,10 +204,10 @@ __device__ __forceinline__ uint64_t lane_run(uint32_t lo, uint32_t w) {
     return m;
 }
 template <int R>
-__device__ __forceinline__ RowCtl<R> read_row_ctl(cptr32 ctl, int d) {
+__device__ __forceinline__ RowCtl<R> read_row_ctl_at(cptr32 e) {  // e: the anti-diagonal's two control words
     RowCtl<R> c;
     if constexpr (R == 2) {
-        const uint32_t so = ctl[2 * d], w = ctl[2 * d + 1];
+        const uint32_t so = e[0], w = e[1];
         c.mk.cell[0] = lane_run(w, w >> 14);
         c.mk.cell[1] = lane_run(w >> 7, w >> 21);
         c.mk.lanes = c.mk.cell[0] | c.mk.cell[1];
@@ -216,7 +216,7 @@ __device__ __forceinline__ RowCtl<R> read_row_ctl(cptr32 ctl, int d) {
         c.reb = static_cast<int>((w >> 28) & 3u) - 1;
         c.jlo = static_cast<int>((w & 127u) + ((w >> 7) & 127u));
     } else {
-        const Ctl t = read_ctl(ctl, d);
+        const Ctl t = read_ctl(e, 0);
         c.mk = band_masks<R>(t.jlo, t.n);
         c.soff = ((t.co - static_cast<uint32_t>(R * c.mk.l0)) << 3) + row_bias<R>();
         c.reb = t.reb;
@@ -224,6 +224,8 @@ __device__ __forceinline__ RowCtl<R> read_row_ctl(cptr32 ctl, int d) {
     }
     return c;
 }
+template <int R>
+__device__ __forceinline__ RowCtl<R> read_row_ctl(cptr32 ctl, int d) { return read_row_ctl_at<R>(ctl + 2 * static_cast<int64_t>(d)); }
 // a packed control word (one-wavefront R = 2 tasks) in the terms of the other kernels (k_em_stair<2>)
 __device__ __forceinline__ Ctl read_ctl_packed(cptr32 ctl, int d) {
     const uint32_t so = ctl[2 * d], w = ctl[2 * d + 1];
@@ -267,20 +269,18 @@ __device__ __forceinline__ void kill_outside(Cell &c, uint64_t in_band) {
     c.e = __builtin_amdgcn_inverse_ballot_w64(in_band) ? c.e : E_DEAD;
 }
 
-// The end of a step: renormalise the new cells if this anti-diagonal does (wave-uniform `norm` = norm_diag(d),
+// The end of a step: renormalise the new cells if this anti-diagonal, d, does (wave-uniform: norm_diag(d),
 // npr_cell.h -- one branch on the scalar unit around 12 instructions per cell) and mark the slots outside the band dead.
 template <int R>
-__device__ __forceinline__ void settle_diag(bool norm, Diag<R> &o, const Masks<R> &mk) {
-    if (norm) {
+__device__ __forceinline__ void settle_diag(int d, Diag<R> &o, const Masks<R> &mk) {
+    // (one `if`, no `else`: with both arms the compiler lays the arms out one after the other behind a 64-bit flag and
+    // spends six scalar instructions and two branches on it)
+    if (norm_diag(d)) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            normalise(o.c[r], o.c[r].e);
-            kill_outside(o.c[r], mk.cell[r]);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) kill_outside(o.c[r], mk.cell[r]);
+        for (int r = 0; r < R; ++r) normalise(o.c[r], o.c[r].e);
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) kill_outside(o.c[r], mk.cell[r]);
 }
 
 // In-place moves of the whole register state by one slot (frame rebase).  Written as inline assembly on tied
@@ -384,9 +384,9 @@ __device__ __forceinline__ void bwd_rebase(const StepEnv &E, int r, Diag<R> &A, 
 }
 
 // One forward anti-diagonal.  `io` holds anti-diagonal d-2 on entry and d on exit; `p1` holds d-1.  S.X / S.Y hold
-// X[x-1]*4 and Y[y-1]*4 of every slot.  norm = norm_diag(d) of the anti-diagonal being computed.
+// X[x-1]*4 and Y[y-1]*4 of every slot.  d: the anti-diagonal being computed (norm_diag(d) says whether it renormalises).
 template <int R>
-__device__ __forceinline__ void fwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &x0, const Masks<R> &mk) {
+__device__ __forceinline__ void fwd_x_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &x0, const Masks<R> &mk) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     x0 += 1;
     bases_up<R>(S.X, feed_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
@@ -398,11 +398,11 @@ __device__ __forceinline__ void fwd_x_step(bool norm, const StepEnv &E, Diag<R> 
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
         o.c[r] = fwd_cell<false>(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
     }
-    settle_diag<R>(norm, o, mk);
+    settle_diag<R>(d, o, mk);
     io = o;
 }
 template <int R>
-__device__ __forceinline__ void fwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &y0, const Masks<R> &mk) {
+__device__ __forceinline__ void fwd_y_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Streams<R> &S, int &y0, const Masks<R> &mk) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     y0 += 1;
     bases_down<R>(S.Y, feed_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
@@ -414,7 +414,7 @@ __device__ __forceinline__ void fwd_y_step(bool norm, const StepEnv &E, Diag<R> 
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
         o.c[r] = fwd_cell<false>(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
     }
-    settle_diag<R>(norm, o, mk);
+    settle_diag<R>(d, o, mk);
     io = o;
 }
 
@@ -558,7 +558,7 @@ __device__ __forceinline__ void emit_pairs(const PairSink &S, const Diag<R> &B, 
 // One backward anti-diagonal d.  `io` holds anti-diagonal d+2 on entry and d on exit; `s1` holds d+1.  S.X / S.Y hold
 // X[x]*4 and Y[y]*4 of every slot.  The X variant undoes the X-step into d+1 (d even), the Y variant a Y-step.
 template <int R>
-__device__ __forceinline__ void bwd_x_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &x0, const Masks<R> &mk) {
+__device__ __forceinline__ void bwd_x_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &x0, const Masks<R> &mk) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     x0 -= 1;
     // x decreased by one in every slot: X[x] moves up a slot, slot 0 takes X[x0]
@@ -571,11 +571,11 @@ __device__ __forceinline__ void bwd_x_step(bool norm, const StepEnv &E, Diag<R> 
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
         o.c[r] = bwd_cell<false>(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
     }
-    settle_diag<R>(norm, o, mk);
+    settle_diag<R>(d, o, mk);
     io = o;
 }
 template <int R>
-__device__ __forceinline__ void bwd_y_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &y0, const Masks<R> &mk) {
+__device__ __forceinline__ void bwd_y_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Streams<R> &S, int &y0, const Masks<R> &mk) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     y0 -= 1;
     bases_up<R>(S.Y, feed_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
@@ -587,16 +587,16 @@ __device__ __forceinline__ void bwd_y_step(bool norm, const StepEnv &E, Diag<R> 
         emissions<R>(E, S.X, S.Y, r, em, exs, exl, eys, eyl);
         o.c[r] = bwd_cell<false>(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
     }
-    settle_diag<R>(norm, o, mk);
+    settle_diag<R>(d, o, mk);
     io = o;
 }
 
 // the same with the masks built from a control word (k_em_stair)
 #define NPR_CTL_STEP(name)                                                                                                     \
     template <int R>                                                                                                           \
-    __device__ __forceinline__ void name(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &o, Streams<R> &S, int &c0, \
+    __device__ __forceinline__ void name(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &o, Streams<R> &S, int &c0, \
                                          const Ctl &ct) {                                                                      \
-        name<R>(norm, E, io, o, S, c0, band_masks<R>(ct.jlo, ct.n));                                                           \
+        name<R>(d, E, io, o, S, c0, band_masks<R>(ct.jlo, ct.n));                                                           \
     }
 NPR_CTL_STEP(fwd_x_step)
 NPR_CTL_STEP(fwd_y_step)

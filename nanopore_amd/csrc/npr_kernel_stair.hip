@@ -115,21 +115,22 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         RowCtl<R> nx = c0;
         if (D >= 1) nx = read_row_ctl<R>(ctl, 1);
         int d = 1;
-        for (; d + 1 <= D; d += 2) {
+        cptr32 cp = ctl + 2;  // the control words of d, walked by pointer: two scalar adds per pair of anti-diagonals
+        for (; d + 1 <= D; d += 2, cp += 4) {
             RowCtl<R> cur = nx;
-            nx = read_row_ctl<R>(ctl, d + 1);  // one ahead
+            nx = read_row_ctl_at<R>(cp + 2);  // one ahead
             if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, cur.mk);
+            fwd_x_step<R>(d, E, B, A, S, x0, cur.mk);
             store_row<R>(frs, B, cur, voff);
             cur = nx;
-            if (d + 2 <= D) nx = read_row_ctl<R>(ctl, d + 2);
+            if (d + 2 <= D) nx = read_row_ctl_at<R>(cp + 4);
             if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-            fwd_y_step<R>(norm_diag(d + 1), E, A, B, S, y0, cur.mk);
+            fwd_y_step<R>(d + 1, E, A, B, S, y0, cur.mk);
             store_row<R>(frs, A, cur, voff);
         }
         if (d <= D) {  // D odd: one more X-step, into B
             if (nx.reb) fwd_rebase<R>(E, nx.reb, A, B, S, x0, y0);
-            fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, nx.mk);
+            fwd_x_step<R>(d, E, B, A, S, x0, nx.mk);
             store_row<R>(frs, B, nx, voff);
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
@@ -216,26 +217,27 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     load_row<R>(frs, fb, nxt, voff);
                 }
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(norm_diag(d2), E, A, B, S, x0, cur.mk);
+                bwd_x_step<R>(d2, E, A, B, S, x0, cur.mk);
                 emit_pairs<R>(sink, A, fa, d2, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
                 d2 -= 1;
             }
-            for (; d2 >= 1; d2 -= 2) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
+            cptr32 cq = ctl + 2 * static_cast<int64_t>(d2 - 2);  // the control words of d2 - 2 (read only while d2 >= 2)
+            for (; d2 >= 1; d2 -= 2, cq -= 4) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
                 int reb = cur.reb;
                 cur = nxt;
-                nxt = read_row_ctl<R>(ctl, d2 - 1);
+                nxt = read_row_ctl_at<R>(cq + 2);
                 load_row<R>(frs, fa, nxt, voff);  // for the step after this one
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_y_step<R>(norm_diag(d2), E, B, A, S, y0, cur.mk);
+                bwd_y_step<R>(d2, E, B, A, S, y0, cur.mk);
                 emit_pairs<R>(sink, B, fb, d2, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
                 reb = cur.reb;
                 cur = nxt;
                 if (d2 >= 2) {
-                    nxt = read_row_ctl<R>(ctl, d2 - 2);
+                    nxt = read_row_ctl_at<R>(cq);
                     load_row<R>(frs, fb, nxt, voff);
                 }
                 if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(norm_diag(d2 - 1), E, A, B, S, x0, cur.mk);
+                bwd_x_step<R>(d2 - 1, E, A, B, S, x0, cur.mk);
                 emit_pairs<R>(sink, A, fa, d2 - 1, x0, y0, cur.mk, tot_e, inv_tot, jr, cnt);
             }
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
@@ -1169,10 +1171,10 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
             const Ctl ct = read_ctl_one<R>(ctl, d);
             if (ct.reb) fwd_rebase<R>(E, ct.reb, A, B, S, x0, y0);
             if (d & 1) {
-                fwd_x_step<R>(norm_diag(d), E, B, A, S, x0, ct);
+                fwd_x_step<R>(d, E, B, A, S, x0, ct);
                 store_row<R>(F, B, ct, voff), store_row_x<R>(Fx, a.slot_stride, B, ct, band_masks<R>(ct.jlo, ct.n), lane);
             } else {
-                fwd_y_step<R>(norm_diag(d), E, A, B, S, y0, ct);
+                fwd_y_step<R>(d, E, A, B, S, y0, ct);
                 store_row<R>(F, A, ct, voff), store_row_x<R>(Fx, a.slot_stride, A, ct, band_masks<R>(ct.jlo, ct.n), lane);
             }
         }
@@ -1265,9 +1267,9 @@ __global__ void __launch_bounds__(WAVE) k_em_stair(KernelArgs a) {
                 if (d >= 3) load_full_row<R>(F, Fx, a.slot_stride, G2, q3, q2.reb + q1.reb, lane);
                 if (q0.reb) bwd_rebase<R>(E, q0.reb, A, B, S, x0, y0);
                 if ((d - 1) & 1) {
-                    bwd_y_step<R>(norm_diag(d - 1), E, B, A, S, y0, q1);
+                    bwd_y_step<R>(d - 1, E, B, A, S, y0, q1);
                 } else {
-                    bwd_x_step<R>(norm_diag(d - 1), E, A, B, S, x0, q1);
+                    bwd_x_step<R>(d - 1, E, A, B, S, x0, q1);
                 }
                 q0 = q1, q1 = q2, q2 = q3, q3 = d >= 4 ? read_ctl_one<R>(ctl, d - 4) : none;
             }

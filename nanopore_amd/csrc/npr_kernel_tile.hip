@@ -144,7 +144,7 @@ __device__ __forceinline__ Cell dpp_cell_from_above(const Cell &v, const Cell &e
 // d-2's top register (made by the step before) on entry, that of d-1 on exit; `edge`: the left stripe's last column on
 // d-1 (every lane holds it, lane 0 uses it).  bx / by: X[x-1]*4 and Y[y-1]*4 of every slot.
 template <int R>
-__device__ __forceinline__ void tile_fwd_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Cell &carry, const Cell &edge,
+__device__ __forceinline__ void tile_fwd_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Cell &carry, const Cell &edge,
                                               const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
     const Cell Le = dpp_cell_from_below(p1.c[R - 1], edge);  // (x-1, y) of every lane's register 0
     Diag<R> o;
@@ -154,14 +154,14 @@ __device__ __forceinline__ void tile_fwd_step(bool norm, const StepEnv &E, Diag<
         emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
         o.c[r] = fwd_cell<false>(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : carry, p1.c[r], em, exs, exl, eys, eyl);
     }
-    settle_diag<R>(norm, o, mk);  // norm = norm_diag(d)
+    settle_diag<R>(d, o, mk);
     io = o;
     carry = Le;
 }
 // One backward anti-diagonal.  `io`: d+2 -> d; `s1`: d+1; `carry`: the slot-above copy of d+2's register 0 -> that of
 // d+1; `edge`: the right stripe's first column on d+1 (lane 63 uses it).  bx / by: X[x]*4 and Y[y]*4 of every slot.
 template <int R>
-__device__ __forceinline__ void tile_bwd_step(bool norm, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Cell &carry, const Cell &edge,
+__device__ __forceinline__ void tile_bwd_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Cell &carry, const Cell &edge,
                                               const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
     const Cell Xe = dpp_cell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register
     Diag<R> o;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void tile_bwd_step(bool norm, const StepEnv &E, Diag<
         emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
         o.c[r] = bwd_cell<false>(E.tr, r + 1 < R ? io.c[r + 1] : carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
     }
-    settle_diag<R>(norm, o, mk);
+    settle_diag<R>(d, o, mk);
     io = o;
     carry = Xe;
 }
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
             Cell carry = dead_cell();
             const uint64_t out_lane = 1ull << (st.K / R - 1);  // holds the stripe's last column in its top register
             int blk_lo = 0, blk_hi = 0;                         // staged cells of the left stripe: [blk_lo, blk_hi) past dfL
-            cptr32 rm = rowmask + st.row0;
+            cptr32 rm = rowmask + st.row0;                      // walked by pointer: the word of the row in hand
             uint32_t w_n = rm[0];                               // mask word one row ahead
             const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc<R>(F, st.row0, K * 8), rsE = stripe_rsrc<R>(Ef, st.row0, 4 * EDGE_FLOATS);
             {   // (x-1, y-1) of slot 0 on the first anti-diagonal: the left stripe's cell on df - 2
@@ -288,10 +288,11 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
             auto step = [&](int d, Diag<R> &io, const Diag<R> &p1) {
                 const int k = d - st.df;
                 const Masks<R> mk = row_masks(w_n);
-                if (d < st.dl) w_n = rm[static_cast<uint32_t>(k + 1)];
+                if (d < st.dl) w_n = rm[1];
+                rm += 1;
                 Cell edge = dead_cell();
                 const int q = d - 1 - dfL;
-                if (q >= 0 && q < lenL) {  // uniform
+                if (static_cast<unsigned>(q) < static_cast<unsigned>(lenL)) {  // uniform; 0 <= q < lenL (lenL >= 0)
                     if (q >= blk_hi) {
                         const int hi = min(q + TILE_BLOCK, lenL);
                         const int need = static_cast<int>(row0L) + hi;
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                     edge = edge_get(stage, q - blk_lo);
                 }
                 bases_down<R>(by, feed_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
-                tile_fwd_step<R>(norm_diag(d), E, io, p1, carry, edge, bx, by, mk);
+                tile_fwd_step<R>(d, E, io, p1, carry, edge, bx, by, mk);
                 if (d == 0) {  // the start cell (0, 0): slot 0 of the first stripe
                     if (lane == 0) {
                         Cell c;
@@ -387,10 +388,10 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                 FRow<R> fa, fb;
 #pragma unroll
                 for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f, fa.e[r] = fb.e[r] = E_DEAD;
-                cptr32 rm = rowmask + st.row0;
+                cptr32 rm = rowmask + st.row0 + static_cast<uint32_t>(st.dl - st.df);  // walked by pointer: the word of the row in hand
                 const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc<R>(F, st.row0, K * 8), rsE = stripe_rsrc<R>(Eb, st.row0, 4 * EDGE_FLOATS);
                 // forward row of the first anti-diagonal (the later ones are loaded one step ahead, with their masks)
-                Masks<R> mk_n = row_masks(rm[static_cast<uint32_t>(st.dl - st.df)]);
+                Masks<R> mk_n = row_masks(rm[0]);
                 tile_load_row<R>(rsF, voff + (st.dl - st.df) * (K * 8), fb, mk_n);
                 blk_lo = lenR, blk_hi = lenR;  // staged: entries [blk_lo, blk_hi) of the right stripe (entry = d' - dfR); empty
                 {   // (x+1, y+1) of the top slot on the first anti-diagonal: the right stripe's cell on dl + 2
@@ -412,12 +413,13 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                     const int k = d - st.df;
                     const Masks<R> mk = mk_n;
                     if (d > st.df) {
-                        mk_n = row_masks(rm[static_cast<uint32_t>(k - 1)]);
+                        rm -= 1;
+                        mk_n = row_masks(rm[0]);
                         tile_load_row<R>(rsF, voff + (k - 1) * (K * 8), fnext, mk_n);
                     }
                     Cell edge = dead_cell();
                     const int q = d + 1 - dfR;
-                    if (q >= 0 && q < lenR) {  // uniform
+                    if (static_cast<unsigned>(q) < static_cast<unsigned>(lenR)) {  // uniform; 0 <= q < lenR (lenR >= 0)
                         if (q < blk_lo) {
                             const int lo = max(q - TILE_BLOCK + 1, 0);
                             const int need = static_cast<int>(row0R) + lo;
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                         edge = edge_get(stage, q - blk_lo);
                     }
                     bases_up<R>(by, feed_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
-                    tile_bwd_step<R>(norm_diag(d), E, io, s1, carry, edge, bx, by, mk);
+                    tile_bwd_step<R>(d, E, io, s1, carry, edge, bx, by, mk);
                     if (d == D) {  // the end corner (lX, lY)
 #pragma unroll
                         for (int r = 0; r < R; ++r)
