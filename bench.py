@@ -178,11 +178,16 @@ def roofline_block(cells, pairs, kms, class_cells, clock_hz):
                        "busy_frac": min(1.0, counter_ratio), "counter_ratio": counter_ratio,
                        "nominal_frac": insts * NOMINAL_CYCLES_PER_VALU / simd_cycles,
                        "useful_fp32_frac_of_peak": insts * NOMINAL_CYCLES_PER_VALU / (t * clock_hz * SIMDS),
+                       "simd_cycles_per_valu_inst": simd_cycles / insts,
+                       "salu_insts_per_cell": tab.get("salu_insts_per_cell"),
                        "note": "counter_ratio = VALU instructions x issue cycles per instruction (4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU: "
                                "the counter ticks in quad-cycles and over-counts instructions that issue in fewer) / SIMD-cycles of the "
                                "launch at the clock held under load; busy_frac caps it at 1 (the pipes are saturated when it reaches 1); "
                                "nominal_frac prices every instruction at the 2-cycle wave64 issue peak instead: the distance to the "
-                               "157 TF fp32 vector peak that a cheaper instruction mix could still close",
+                               "157 TF fp32 vector peak that a cheaper instruction mix could still close; "
+                               "simd_cycles_per_valu_inst = SIMD-cycles of this launch per VALU instruction (what an instruction "
+                               "costs all told); salu_insts_per_cell: scalar instructions, which share the CU's one scalar unit and "
+                               "the SIMDs' issue slots (tools/issue_mix.hip)",
                        "source": tab.get("valu_source", "profiles/")}
     return out
 
