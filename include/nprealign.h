@@ -299,6 +299,18 @@ int64_t npr_format_cigars(int64_t n, const int64_t *ops_off, const int32_t *ops,
  * anywhere in `words`, so the gathered payloads need no merge copy before the SAM is written. */
 int64_t npr_format_cigars_packed(int64_t n, const int64_t *word_off, const int64_t *n_ops, const uint32_t *words, int64_t *str_off,
                                  char *out, int64_t cap);
+/* The realigned SAM records themselves, as text: what realignSamFile3TargetFn's writer puts out for every record after
+ * assigning the new cigar (nanopore/analyses/utils.py:591-609; pysam's AlignmentFile.write there), for a job that writes
+ * 50 k records per rank at once.  Record i = QNAME \t FLAG \t RNAME \t POS \t MAPQ \t CIGAR \t * \t 0 \t 0 \t SEQ \t * \n with
+ * QNAME = qnames[qname_off[i] .. qname_off[i+1]), RNAME = entry ref_index[i] of the rnames list, POS = pos[i] (1-based, as
+ * printed), FLAG = flag[i] (NULL: 0), MAPQ = mapq[i] (NULL: 255), CIGAR = the packed list i as in npr_format_cigars_packed
+ * ("*" when empty), SEQ = seq[seq_off[i] .. seq_off[i+1]).  Record i lands at out[rec_off[i] .. rec_off[i+1]).  out == NULL:
+ * only the offsets; returns the total length, NPR_ERR_CAPACITY when cap is smaller, NPR_ERR_INVALID for a negative
+ * number or an op outside M/I/D.  Threaded host code. */
+int64_t npr_format_sam_records(int64_t n, const char *qnames, const int64_t *qname_off, const int32_t *flag, const char *rnames,
+                               const int64_t *rname_off, const int32_t *ref_index, const int64_t *pos, const int32_t *mapq,
+                               const int64_t *word_off, const int64_t *n_ops, const uint32_t *words, const char *seq, const int64_t *seq_off,
+                               int64_t *rec_off, char *out, int64_t cap);
 /* ASCII -> base codes 0..4 (A,C,G,T,N) */
 void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes);
 

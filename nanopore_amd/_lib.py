@@ -86,7 +86,7 @@ EXPORTS = [
     "npr_batch_align_stats", "npr_align_stats", "npr_batch_plan_check", "npr_batch_base_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
-    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_format_cigars_packed", "npr_chain_hits", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
+    "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_format_cigars_packed", "npr_format_sam_records", "npr_chain_hits", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
 ]
 
 _lib = None
@@ -165,6 +165,8 @@ def load():
     L.npr_plan_stripes.argtypes = [vp, i32, i32, vp, i32, vp]
     L.npr_format_cigars_packed.restype = i64
     L.npr_format_cigars_packed.argtypes = [i64, vp, vp, vp, vp, vp, i64]
+    L.npr_format_sam_records.restype = i64
+    L.npr_format_sam_records.argtypes = [i64] + [vp] * 15 + [i64]
     L.npr_chain_hits.restype = i64
     L.npr_chain_hits.argtypes = [i64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.npr_format_cigars.restype = i64

@@ -49,26 +49,22 @@ def sam_header(w, ref_names=None):
 
 
 def sam_block(w, lo, hi, ops_off, words, ref_names):
-    """The SAM records of reads lo .. hi as one bytes object: CIGAR = the realigner's ops (what realignSamFile3TargetFn
-    splices in, utils.py:597-605), POS = where the guide's window starts on the reference.  The cigars come packed and are
-    formatted natively (npr_format_cigars_packed)."""
+    """The SAM records of reads lo .. hi as one bytes-like object: CIGAR = the realigner's ops (what realignSamFile3TargetFn
+    splices in, utils.py:597-605), POS = where the guide's window starts on the reference.  The cigars come packed from the
+    device and the records are formatted natively (npr_format_sam_records): at 50 k records per rank a Python loop over
+    the records took longer than the DP."""
     from . import realign
+    n = hi - lo
     nops = np.asarray(ops_off[1:]) - np.asarray(ops_off[:-1])
-    cig, coff = realign.format_cigars_packed(ops_off[:-1], nops, words)
-    cig = cig.tobytes()
-    ro = w["read_off"]
-    read = np.ascontiguousarray(w["read"][ro[lo]:ro[hi]]).tobytes()
-    r0 = int(ro[lo])
+    ro = np.asarray(w["read_off"], dtype=np.int64)
     ri = w.get("ref_index")
     gs = w.get("guide_start")
-    rn = [s.encode() for s in ref_names]
-    lines = []
-    for k, i in enumerate(range(lo, hi)):
-        ref = int(ri[i]) if ri is not None else i
-        pos = (int(gs[i][0]) if gs is not None else 0) + 1
-        lines.append(b"\t".join((b"read_%d" % i, b"0", rn[ref], b"%d" % pos, b"255", cig[coff[k]:coff[k + 1]], b"*\t0\t0",
-                                 read[ro[i] - r0:ro[i + 1] - r0], b"*")))
-    return b"\n".join(lines) + (b"\n" if lines else b"")
+    ref_index = np.asarray(ri[lo:hi], dtype=np.int32) if ri is not None else np.arange(lo, hi, dtype=np.int32)
+    pos = (np.asarray(gs, dtype=np.int64)[lo:hi, 0] if gs is not None else np.zeros(n, dtype=np.int64)) + 1
+    qnames = [b"read_%d" % i for i in range(lo, hi)]
+    buf, _ = realign.format_sam_records(qnames, [s.encode() for s in ref_names], ref_index, pos, ops_off[:-1], nops, words,
+                                        w["read"][ro[lo]:ro[hi]], ro[lo:hi + 1] - ro[lo])
+    return memoryview(buf)
 
 
 def write_summary_xml(path, status, score, nops, cells=None):

@@ -450,6 +450,44 @@ def format_cigars_packed(word_off, n_ops, words):
     return buf[:int(total)], str_off
 
 
+def _ragged(items):
+    """list of bytes -> (uint8 array, int64 offsets[n+1])"""
+    off = np.zeros(len(items) + 1, dtype=np.int64)
+    if len(items):
+        np.cumsum(np.fromiter(map(len, items), dtype=np.int64, count=len(items)), out=off[1:])
+    return np.frombuffer(b"".join(items) or b"\0", dtype=np.uint8), off
+
+
+def format_sam_records(qnames, ref_names, ref_index, pos, word_off, n_ops, words, seq, seq_off, flag=None, mapq=None):
+    """The realigned SAM records as one uint8 array + offsets[n+1] (include/nprealign.h: npr_format_sam_records).  qnames /
+    ref_names: lists of bytes; pos 1-based; cigars packed as for format_cigars_packed; seq: uint8 array of read bases with
+    CSR offsets seq_off (relative to seq[0])."""
+    L = _lib.load()
+    n = len(qnames)
+    qn, qoff = _ragged(qnames)
+    rn, roff = _ragged(ref_names)
+    ref_index = np.ascontiguousarray(ref_index, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    word_off = np.ascontiguousarray(word_off, dtype=np.int64)
+    n_ops = np.ascontiguousarray(n_ops, dtype=np.int64)
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+    flag = None if flag is None else np.ascontiguousarray(flag, dtype=np.int32)
+    mapq = None if mapq is None else np.ascontiguousarray(mapq, dtype=np.int32)
+    rec_off = np.zeros(n + 1, dtype=np.int64)
+    args = [n, ptr(qn), ptr(qoff), None if flag is None else ptr(flag), ptr(rn), ptr(roff), ptr(ref_index), ptr(pos),
+            None if mapq is None else ptr(mapq), ptr(word_off), ptr(n_ops), ptr(words), ptr(seq), ptr(seq_off), ptr(rec_off)]
+    total = L.npr_format_sam_records(*args, None, 0)
+    if total < 0:
+        raise NprError(int(total), "npr_format_sam_records")
+    buf = np.empty(max(int(total), 1), dtype=np.uint8)
+    rc = L.npr_format_sam_records(*args, ptr(buf), int(total))
+    if rc < 0:
+        raise NprError(int(rc), "npr_format_sam_records")
+    return buf[:int(total)], rec_off
+
+
 def mea_cigar(lX, lY, x, y, p, gap_gamma=0.5, match_gamma=0.0):
     L = _lib.load()
     x = np.ascontiguousarray(x, dtype=np.int32)

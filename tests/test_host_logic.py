@@ -141,3 +141,47 @@ def test_fixed_band_narrower_than_two_cells_is_rejected():
             R.plan(R.make_params(band_mode=R.BAND_FIXED, fixed_width=w), 10, 10, [(0, 10)])
         assert e.value.code == _lib.ERR_INVALID
     assert len(R.plan(R.make_params(band_mode=R.BAND_FIXED, fixed_width=2), 10, 10, [(0, 10)])) == 1
+
+
+def test_sam_records_are_formatted_natively_like_the_python_writer():
+    """npr_format_sam_records against a record-by-record rendering of the same fields (the eleven mandatory SAM columns
+    as realignSamFile3TargetFn's writer prints them, nanopore/analyses/utils.py:591-609): empty cigar, shared reference
+    names, default and explicit FLAG / MAPQ, error codes."""
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(5)
+    n = 300
+    ref_names = [b"chr_%d" % k for k in range(7)]
+    ref_index = rng.integers(0, 7, n).astype(np.int32)
+    pos = rng.integers(1, 10 ** 7, n)
+    pos[:3] = (1, 9, 10)
+    lens = rng.integers(0, 400, n)
+    lens[5] = 0
+    seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), int(seq_off[-1]))
+    nops = rng.integers(0, 30, n)
+    nops[7] = 0
+    word_off = np.concatenate([[0], np.cumsum(nops)])[:-1].astype(np.int64) + 3  # the lists may start anywhere
+    words = ((rng.integers(1, 5000, int(nops.sum()) + 3) << 2) | rng.integers(0, 3, int(nops.sum()) + 3)).astype(np.uint32)
+    qnames = [b"read/%d_%s" % (i, b"x" * int(rng.integers(0, 9))) for i in range(n)]
+    flag = rng.choice([0, 16, 256, 2048], n).astype(np.int32)
+    mapq = rng.integers(0, 256, n).astype(np.int32)
+
+    def render(i, f, q):
+        cig = b"".join(b"%d%s" % (int(wd) >> 2, b"MID"[int(wd) & 3:(int(wd) & 3) + 1]) for wd in words[word_off[i]:word_off[i] + nops[i]]) or b"*"
+        return b"\t".join((qnames[i], b"%d" % f, ref_names[ref_index[i]], b"%d" % pos[i], b"%d" % q, cig, b"*", b"0", b"0",
+                           seq[seq_off[i]:seq_off[i + 1]].tobytes(), b"*")) + b"\n"
+
+    buf, off = R.format_sam_records(qnames, ref_names, ref_index, pos, word_off, nops, words, seq, seq_off)
+    assert buf.tobytes() == b"".join(render(i, 0, 255) for i in range(n))
+    assert all(buf[off[i]:off[i + 1]].tobytes() == render(i, 0, 255) for i in (0, 5, 7, n - 1))
+    buf2, _ = R.format_sam_records(qnames, ref_names, ref_index, pos, word_off, nops, words, seq, seq_off, flag=flag, mapq=mapq)
+    assert buf2.tobytes() == b"".join(render(i, int(flag[i]), int(mapq[i])) for i in range(n))
+    empty, eoff = R.format_sam_records([], ref_names, [], [], [], [], words, seq, [0])
+    assert len(empty) == 0 and list(eoff) == [0]
+    bad = words.copy()
+    bad[int(word_off[20])] |= 3
+    if nops[20]:
+        with pytest.raises(R.NprError):
+            R.format_sam_records(qnames, ref_names, ref_index, pos, word_off, nops, bad, seq, seq_off)
+    with pytest.raises(R.NprError):
+        R.format_sam_records(qnames, ref_names, ref_index, -pos, word_off, nops, words, seq, seq_off)
