@@ -240,7 +240,7 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
 /* Test aid: npr_batch_create expands band rows, frame schedules, stripe tables and row offsets on the device; this
  * recomputes every task of the batch with the host planner (the npr_plan_* functions below, the ones the tests pin
  * against the oracle) and compares entry by entry.  Returns the number of tasks that differ (0 = identical) or NPR_ERR_*. */
-int64_t npr_batch_plan_check(npr_batch *b);
+int64_t npr_batch_plan_check(npr_batch *b, const int32_t *guide_ops /* as given to npr_batch_create: a batch keeps no copy */);
 
 /* One call = create + run + finish + copy-out + destroy, for callers that do not need staging. */
 int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,

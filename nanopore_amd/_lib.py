@@ -142,7 +142,7 @@ def load():
     L.npr_batch_base_expectations.restype = i32
     L.npr_batch_base_expectations.argtypes = [vp, vp, i64, vp, vp, vp]
     L.npr_batch_plan_check.restype = i64
-    L.npr_batch_plan_check.argtypes = [vp]
+    L.npr_batch_plan_check.argtypes = [vp, vp]
     L.npr_batch_align_stats.restype = i32
     L.npr_batch_align_stats.argtypes = [vp, vp]
     L.npr_align_stats.restype = i32

@@ -118,7 +118,7 @@ struct DevBuf {
     }
     void release() {
         if (p && !borrowed) {
-            if (owner && owner->cache.size() < 48) {
+            if (owner && owner->cache.size() < 160) {
                 owner->cache.push_back(npr_ctx::Cached{p, held});
                 owner->cache_bytes += held;
             } else {
@@ -144,14 +144,14 @@ struct DevBuf {
         count = n;
         if (n == 0) return hipSuccess;
         const size_t need = n * sizeof(T);
-        if (need < (size_t(1) << 20)) {  // small ones are cheap
-            const hipError_t e0 = hipMalloc(reinterpret_cast<void **>(&p), need);
-            if (e0 == hipSuccess) poison(p, need);
-            return e0;
-        }
+        // small ones come in 256 KiB pieces and any cached piece up to 1 MiB serves them: a batch makes a dozen tables of a few
+        // words per task, and hipFree of each (synchronous) cost 2-3 ms when the batch was staged
+        constexpr size_t kSmall = size_t(1) << 20, kPiece = size_t(256) << 10;
         int best = -1;
         for (size_t i = 0; i < ctx->cache.size(); ++i)
-            if (ctx->cache[i].bytes >= need && ctx->cache[i].bytes <= 2 * need && (best < 0 || ctx->cache[i].bytes < ctx->cache[best].bytes)) best = static_cast<int>(i);
+            if (ctx->cache[i].bytes >= need && (ctx->cache[i].bytes <= 2 * need || ctx->cache[i].bytes <= kSmall) &&
+                (best < 0 || ctx->cache[i].bytes < ctx->cache[best].bytes))
+                best = static_cast<int>(i);
         if (best >= 0) {
             p = static_cast<T *>(ctx->cache[best].p), held = ctx->cache[best].bytes, owner = ctx;
             ctx->cache_bytes -= held;
@@ -159,7 +159,7 @@ struct DevBuf {
             poison(p, held);
             return hipSuccess;
         }
-        const size_t take = need + need / 8;  // a little headroom: the next batch of the same shape differs by a few percent
+        const size_t take = need < kSmall ? (need + kPiece - 1) / kPiece * kPiece : need + need / 8;  // a little headroom: the next batch of the same shape differs by a few percent
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), take);
         if (e != hipSuccess && !ctx->cache.empty()) {
             (void)hipGetLastError();
@@ -596,7 +596,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     b->read_first_task.assign(n_reads, 0);
     b->read_ntasks.assign(n_reads, 0);
     b->guide_off.assign(guide_off, guide_off + (n_reads ? n_reads + 1 : 0));
-    if (n_reads) b->guide_ops.assign(guide_ops, guide_ops + 2 * guide_off[n_reads]);
+    // the guides themselves are needed again only where the result IS the guide (--rescoreOriginalAlignment); copying
+    // them for every realign batch cost 35 ms of a north-star batch's 80 (240 MB, one thread, first touch)
+    if (n_reads && b->params.mode == NPR_MODE_RESCORE_ORIGINAL) b->guide_ops.assign(guide_ops, guide_ops + 2 * guide_off[n_reads]);
 
     StageTimer tm("batch_create");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -705,7 +707,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // 3. device: band rows of every anti-diagonal, per-segment summaries
     DevBuf<PlanPoint> d_points;
     DevBuf<SegSummary> d_summary;
-    if ((e = d_points.alloc_from(ctx, npoints)) != hipSuccess || (e = b->d_pseg.alloc(ntasks)) != hipSuccess || (e = d_summary.alloc(ntasks)) != hipSuccess ||
+    if ((e = d_points.alloc_from(ctx, npoints)) != hipSuccess || (e = b->d_pseg.alloc_from(ctx, ntasks)) != hipSuccess || (e = d_summary.alloc_from(ctx, ntasks)) != hipSuccess ||
         (e = b->d_lo.alloc_from(ctx, band_entries)) != hipSuccess || (e = b->d_n.alloc_from(ctx, band_entries)) != hipSuccess ||
         (e = b->d_seq.alloc_from(ctx, seq_bytes + 16)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
@@ -764,8 +766,8 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         DevBuf<uint32_t> d_cand;
         DevBuf<int64_t> d_off, d_cells;
         DevBuf<int32_t> d_cls;
-        if ((e = d_cand.alloc(ntasks)) != hipSuccess || (e = d_off.alloc(ntasks)) != hipSuccess || (e = d_cells.alloc(ntasks)) != hipSuccess ||
-            (e = d_cls.alloc(ntasks)) != hipSuccess)
+        if ((e = d_cand.alloc_from(ctx, ntasks)) != hipSuccess || (e = d_off.alloc_from(ctx, ntasks)) != hipSuccess || (e = d_cells.alloc_from(ctx, ntasks)) != hipSuccess ||
+            (e = d_cls.alloc_from(ctx, ntasks)) != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
         HIP_TRY(ctx, hipMemcpyAsync(d_cand.p, cand.data(), d_cand.bytes(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_off.p, sched_off.data(), d_off.bytes(), hipMemcpyHostToDevice, ctx->stream));
@@ -805,7 +807,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         DevBuf<int32_t> d_list;
         DevBuf<int64_t> d_toff, d_rows;
         const size_t nt = tile_list.size();
-        if ((e = d_list.alloc(nt)) != hipSuccess || (e = d_toff.alloc(nt)) != hipSuccess || (e = d_rows.alloc(nt)) != hipSuccess)
+        if ((e = d_list.alloc_from(ctx, nt)) != hipSuccess || (e = d_toff.alloc_from(ctx, nt)) != hipSuccess || (e = d_rows.alloc_from(ctx, nt)) != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
         HIP_TRY(ctx, hipMemcpyAsync(d_list.p, tile_list.data(), d_list.bytes(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_toff.p, tile_offs.data(), d_toff.bytes(), hipMemcpyHostToDevice, ctx->stream));
@@ -821,7 +823,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         int64_t mask_rows = 0;
         for (size_t q = 0; q < nt; ++q) moff[q] = mask_rows, rowmask_off_of[tile_list[q]] = mask_rows, mask_rows += rows[q];
         DevBuf<int64_t> d_moff;
-        if ((e = d_moff.alloc(nt)) != hipSuccess || (e = b->d_rowmask.alloc_from(ctx, mask_rows)) != hipSuccess)
+        if ((e = d_moff.alloc_from(ctx, nt)) != hipSuccess || (e = b->d_rowmask.alloc_from(ctx, mask_rows)) != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
         HIP_TRY(ctx, hipMemcpyAsync(d_moff.p, moff.data(), d_moff.bytes(), hipMemcpyHostToDevice, ctx->stream));
         RowMaskArgs ma{static_cast<int32_t>(nt), d_list.p, b->d_pseg.p, b->d_lo.p, b->d_n.p, d_toff.p, b->d_stripes.p, d_moff.p, b->d_rowmask.p};
@@ -1000,9 +1002,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         max_grid = std::max<int64_t>(max_grid, tileL->grid);
     }
     const int64_t grid = ntasks ? sum_grid + (tileL ? tileL->grid : 0) : 0;
-    if ((e = b->d_tasks.alloc(ntasks)) != hipSuccess || (e = b->d_outs.alloc(ntasks)) != hipSuccess ||
-        (e = b->d_queue.alloc(kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc(ring_floats)) != hipSuccess ||
-        (e = b->d_region.alloc(region.size())) != hipSuccess ||
+    if ((e = b->d_tasks.alloc_from(ctx, ntasks)) != hipSuccess || (e = b->d_outs.alloc_from(ctx, ntasks)) != hipSuccess ||
+        (e = b->d_queue.alloc_from(ctx, kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc_from(ctx, ring_floats)) != hipSuccess ||
+        (e = b->d_region.alloc_from(ctx, region.size())) != hipSuccess ||
         (e = b->d_px.alloc_from(ctx, pair_total)) != hipSuccess ||
         (e = b->d_py.alloc_from(ctx, pair_total)) != hipSuccess || (e = b->d_pp.alloc_from(ctx, pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
@@ -1162,7 +1164,7 @@ int32_t fetch_pairs(npr_batch *b) {
         DevBuf<int32_t> d_cx, d_cy;
         DevBuf<float> d_cp;
         hipError_t e;
-        if ((e = d_dst.alloc(ntasks + 1)) != hipSuccess || (e = d_cx.alloc_from(ctx, total)) != hipSuccess ||
+        if ((e = d_dst.alloc_from(ctx, ntasks + 1)) != hipSuccess || (e = d_cx.alloc_from(ctx, total)) != hipSuccess ||
             (e = d_cy.alloc_from(ctx, total)) != hipSuccess || (e = d_cp.alloc_from(ctx, total)) != hipSuccess)
             return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc", e);
         HIP_TRY(ctx, hipMemcpyAsync(d_dst.p, dst.data(), d_dst.bytes(), hipMemcpyHostToDevice, ctx->stream));
@@ -1455,9 +1457,9 @@ static int32_t batch_finish_impl(npr_batch *b) {
         if (r.status != NPR_OK) return;
         const Pair *pp = b->pairs.data() + b->pair_off[i];
         const int64_t c = r.n_pairs;
-        const int32_t *g = b->guide_ops.data() + 2 * b->guide_off[i];
-        const int64_t ng = b->guide_off[i + 1] - b->guide_off[i];
         if (b->params.mode == NPR_MODE_RESCORE_ORIGINAL) {
+            const int32_t *g = b->guide_ops.data() + 2 * b->guide_off[i];
+            const int64_t ng = b->guide_off[i + 1] - b->guide_off[i];
             // --rescoreOriginalAlignment: ops verbatim (alignmentUncertainty.py:51-52), new score
             for (int64_t q = 0; q < ng; ++q)
                 if (g[2 * q + 1] > 0) per_read_ops[i].insert(per_read_ops[i].end(), {g[2 * q], g[2 * q + 1]});
@@ -1838,8 +1840,8 @@ int32_t npr_align_stats(npr_ctx *ctx, int64_t n, int64_t n_refs, const uint8_t *
     }
 }
 
-int64_t npr_batch_plan_check(npr_batch *b) {
-    if (!b) return NPR_ERR_INVALID;
+int64_t npr_batch_plan_check(npr_batch *b, const int32_t *guide_ops) {
+    if (!b || (b->n_reads && b->guide_off[b->n_reads] && !guide_ops)) return NPR_ERR_INVALID;
     npr_ctx *ctx = b->ctx;
     try {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1855,7 +1857,7 @@ int64_t npr_batch_plan_check(npr_batch *b) {
         for (int64_t i = 0; i < n; ++i) {
             if (b->read_status[i] != NPR_OK && b->read_ntasks[i] == 0) continue;
             Plan plan;
-            const int32_t rc = build_plan(b->params, b->ref_len[i], b->read_len[i], b->guide_ops.data() + 2 * b->guide_off[i],
+            const int32_t rc = build_plan(b->params, b->ref_len[i], b->read_len[i], guide_ops + 2 * b->guide_off[i],
                                           b->guide_off[i + 1] - b->guide_off[i], plan);
             if (rc != NPR_OK || static_cast<int32_t>(plan.segs.size()) != b->read_ntasks[i]) {
                 ++mismatches;

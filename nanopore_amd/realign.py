@@ -153,7 +153,7 @@ class Batch(object):
     def plan_check(self):
         """Tasks whose device-made band rows / schedules / stripe tables differ from the host planner's (test aid;
         include/nprealign.h: npr_batch_plan_check)."""
-        rc = self._L.npr_batch_plan_check(self._h)
+        rc = self._L.npr_batch_plan_check(self._h, ptr(self._keep[4]))
         if rc < 0:
             raise NprError(int(rc), "npr_batch_plan_check", self.ctx.last_error())
         return int(rc)
