@@ -89,7 +89,10 @@ __global__ void __launch_bounds__(BAND_THREADS) k_plan_bands(PlanArgs a) {
 // wavefronts, not their width.  (One lane per segment straight from memory: 47 ms for the 12288 reads of the default bench;
 // one wavefront per segment on the scalar unit: 40 ms -- a CU issues one scalar instruction per cycle whatever its
 // occupancy; 64 segments per wavefront: 28 ms.)
-constexpr int SCHED_TILE = 31, SCHED_SEGS = 16;
+#ifndef NPR_SCHED_SEGS
+#define NPR_SCHED_SEGS 8  // segments per wavefront: 16 left the chip with less than one wavefront per SIMD on 12 k segments (46 -> 42 ms staging)
+#endif
+constexpr int SCHED_TILE = 31, SCHED_SEGS = NPR_SCHED_SEGS;
 __global__ void __launch_bounds__(64) k_plan_sched(SchedArgs a) {
     __shared__ int t_lo[SCHED_SEGS][SCHED_TILE + 2], t_n[SCHED_SEGS][SCHED_TILE + 2];  // (row stride 33: conflict-free walks)
     __shared__ uint32_t t_w0[SCHED_SEGS][SCHED_TILE + 2], t_w1[SCHED_SEGS][SCHED_TILE + 2];
@@ -134,10 +137,13 @@ __global__ void __launch_bounds__(64) k_plan_sched(SchedArgs a) {
                 const bool walk = ok && base <= D;
                 if (walk) {
                     const int cnt = min(SCHED_TILE, D + 1 - base);
+                    int lo_c = t_lo[lane][0], n_c = t_n[lane][0];  // the row in hand stays in registers: two LDS reads per step, not four
                     for (int i = 0; i < cnt && ok; ++i) {
+                        const int lo_x = t_lo[lane][i + 1], n_x = t_n[lane][i + 1];
                         uint32_t w0 = 0, w1 = 0;
-                        ok = stair_step(st, base + i, D, t_lo[lane][i], t_n[lane][i], t_lo[lane][i + 1], t_n[lane][i + 1], rshift, C, w0, w1) ? 1 : 0;
+                        ok = stair_step(st, base + i, D, lo_c, n_c, lo_x, n_x, rshift, C, w0, w1) ? 1 : 0;
                         t_w0[lane][i] = w0, t_w1[lane][i] = w1;
+                        lo_c = lo_x, n_c = n_x;
                     }
                 }
                 __syncthreads();

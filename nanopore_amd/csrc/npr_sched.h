@@ -44,21 +44,25 @@ NPR_HD inline bool stair_begin(StairState &st, int32_t lo0, int32_t n0, int32_t 
 // R is 1, 2 or 4: rshift = log2 R (the device walks this loop on one lane; no divisions).
 NPR_HD inline bool stair_step(StairState &st, int32_t d, int32_t D, int32_t lo, int32_t n, int32_t lo_nx, int32_t n_nx, int rshift, int32_t C,
                               uint32_t &w0, uint32_t &w1) {
+    // Written without data-dependent branches (bitwise logic and selects; only d's parity and the class are tested, which are
+    // the same for all the segments a wavefront walks): on the device every lane walks its own segment, and the nested
+    // ifs of the first version compiled to twenty exec-mask branches per step -- 1500 cycles per anti-diagonal.
     const int32_t span = 2 * (C - 1), R = 1 << rshift;
-    const int32_t hi = lo + 2 * (n - 1);
-    if (n < 1) return false;
+    const int32_t hi = lo + 2 * (n - 1), hi_nx = lo_nx + 2 * (n_nx - 1);
+    int ok = n >= 1;
     int32_t reb = 0;
     if (d > 0) {
+        const int next = d < D;
         if (d & 1) {  // X-step; the next one is a Y-step
             const int32_t f = st.flo + 1;
-            if (hi > f + span || (d < D && lo_nx + 2 * (n_nx - 1) > f - 1 + span)) reb = 1;
+            reb = (hi > f + span) | (next & (hi_nx > f - 1 + span));
             st.flo = f + 2 * reb;
         } else {
             const int32_t f = st.flo - 1;
-            if (lo < f || (d < D && lo_nx < f + 1)) reb = -1;
+            reb = -((lo < f) | (next & (lo_nx < f + 1)));
             st.flo = f + 2 * reb;
         }
-        if (lo < st.flo || hi > st.flo + span) return false;
+        ok &= (lo >= st.flo) & (hi <= st.flo + span);
     }
     const int32_t jlo = (lo - st.flo) >> 1;  // lo >= flo, same parity
     const int32_t l0 = jlo >> rshift, l1 = (jlo + n + R - 1) >> rshift;
@@ -66,17 +70,17 @@ NPR_HD inline bool stair_step(StairState &st, int32_t d, int32_t D, int32_t lo, 
     if (rshift == 1 && C == 128) {  // stair_packed
         const uint32_t lo0 = static_cast<uint32_t>(jlo + 1) >> 1, lo1 = static_cast<uint32_t>(jlo) >> 1;
         const uint32_t hi0 = static_cast<uint32_t>(jlo + n + 1) >> 1, hi1 = static_cast<uint32_t>(jlo + n) >> 1;
-        if (hi0 - lo0 > 63u || hi1 - lo1 > 63u) return false;
-        if (st.off + row >= (1u << 29) - 512u) return false;  // the row offsets are 32-bit byte offsets (stair_fits)
+        ok &= (hi0 - lo0 <= 63u) & (hi1 - lo1 <= 63u);
+        ok &= st.off + row < (1u << 29) - 512u;  // the row offsets are 32-bit byte offsets (stair_fits)
         w0 = ((st.off - 2u * lo1) << 3) + row_bias<2>();
         w1 = lo0 | (lo1 << 7) | ((hi0 - lo0) << 14) | ((hi1 - lo1) << 21) | (static_cast<uint32_t>(reb + 1) << 28);
     } else {
-        if (st.off + row < st.off) return false;  // 2^32 cells
+        ok &= st.off + row >= st.off;  // 2^32 cells
         w0 = st.off;
         w1 = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26);
     }
     st.off += row;
-    return true;
+    return ok != 0;
 }
 NPR_HD inline int stair_rshift(int R) { return R == 1 ? 0 : (R == 2 ? 1 : 2); }
 NPR_HD inline bool stair_schedule(const int32_t *lo_, const int32_t *n_, int64_t D, int32_t max_width, int R, int NW, uint32_t *ctl,
