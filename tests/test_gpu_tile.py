@@ -110,11 +110,22 @@ def test_repeated_launches_on_poisoned_scratch_give_identical_pairs(gpu_ctx, mon
              (synth.make_workload(1008, 256, 1500, T, E, flank=0, length_sigma=0.4, len_min=200, len_max=5000),
               R.make_params(band_mode=R.BAND_FIXED, fixed_width=100), 60),
              (synth.make_workload(1009, 96, 2000, T, E, flank=0, length_sigma=0.4, len_min=200, len_max=5000),
-              R.make_params(band_mode=R.BAND_FIXED, fixed_width=300), 60))
+              R.make_params(band_mode=R.BAND_FIXED, fixed_width=300), 60),
+             # band 200: the north-star class (k_dp_stair<2>, packed control words), next to a few narrow and wide stragglers
+             (synth.make_workload(1010, 192, 2500, T, E, flank=0, length_sigma=0.6, len_min=100, len_max=8000),
+              R.make_params(band_mode=R.BAND_FIXED, fixed_width=200), 80),
+             # ... and the same class launched side by side with others: anchors +- 60 with 3 trimmed columns give bands of
+             # 64-126 cells for most reads of this workload (class 1), wider ones where the indels cluster (class 2), one narrow
+             (synth.make_workload(1011, 128, 3000, T, E, flank=0, length_sigma=0.5, len_min=300, len_max=9000),
+              R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=60, constraint_trim=3, split_threshold=3000), 120))
+    seen_classes = set()
     for w, P, reps in cases:
         first = None
         for rep in range(reps):
             b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
+            if rep == 0:
+                tasks, _ = b.class_stats()
+                seen_classes.add(tuple(int(c) for c in np.nonzero(tasks)[0]))
             b.run(), b.finish()
             out = (b.results(), b.pairs(), b.ops())
             b.close()
@@ -126,3 +137,5 @@ def test_repeated_launches_on_poisoned_scratch_give_identical_pairs(gpu_ctx, mon
                 assert np.array_equal(out[0][key], first[0][key]), (rep, key)
             assert all(np.array_equal(a, c) for a, c in zip(out[1], first[1])), rep
             assert all(np.array_equal(a, c) for a, c in zip(out[2], first[2])), rep
+    # the north-star class (1) ran alone and next to other classes
+    assert (1,) in seen_classes and any(1 in c and len(c) > 1 for c in seen_classes), seen_classes
