@@ -150,7 +150,7 @@ __device__ __forceinline__ int feed_peek(const Feed &f, int idx) {
 
 typedef const __attribute__((address_space(4))) uint32_t *cptr32;
 
-// Control word of one anti-diagonal (written by build_stair_schedule, npr_api.cpp): where the band sits in the frame,
+// Control word of one anti-diagonal (stair_step, npr_sched.h; made by k_plan_sched when a batch is staged): where the band sits in the frame,
 // which step brought the frame here, and where the row starts in the forward scratch.
 struct Ctl {
     uint32_t co;  // scratch offset (cells) of the first stored lane of the row
@@ -344,7 +344,7 @@ __device__ __forceinline__ void bases_down_inplace(Bases<R> &s, int inject) {
 
 // Base streams of one sweep plus what a rebase needs to run them backwards by one slot: the base that left the
 // wavefront at the last step of each kind (a rebase towards higher x-y only ever follows a Y-step, one towards lower
-// x-y an X-step: build_stair_schedule).
+// x-y an X-step: stair_step, npr_sched.h).
 template <int R>
 struct Streams {
     Bases<R> X, Y;

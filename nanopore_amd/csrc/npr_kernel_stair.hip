@@ -12,7 +12,7 @@
 //     anti-diagonal and a Y-step (y0 += 1) into every even one, so the (x-1, y-1) predecessor always sits in the same
 //     slot, the loop body is straight-line code and nothing but the one crossing neighbour ever moves.  The band floats
 //     inside the frame (first slot jlo, n cells), selected by wave-uniform lane masks built on the scalar unit; when it
-//     drifts to a frame edge the host-made schedule (build_stair_schedule in npr_api.cpp) asks for a REBASE: the whole
+//     drifts to a frame edge the frame schedule (stair_step in npr_sched.h, run by k_plan_sched at staging) asks for a REBASE: the whole
 //     register state moves one slot, in place (about one anti-diagonal in twenty on noisy reads; every other one
 //     inside a long gap);
 //   * of the R neighbours on d-1 only ONE per state crosses a lane boundary: a single DPP wave_shl:1 / wave_shr:1;
