@@ -746,7 +746,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     const char *cmin_env = std::getenv("NPR_CLASS_MIN");  // bring-up: smallest register class to use
     const int cmin = cmin_env ? std::atoi(cmin_env) : 0;
     const char *notile_env = std::getenv("NPR_NO_TILE");  // "1": no stripe kernel (A/B runs, tests)
-    const bool use_tile = !force_generic && !(notile_env && notile_env[0] == '1') && b->params.mode != NPR_MODE_EXPECTATIONS;
+    const bool use_tile = !force_generic && !(notile_env && notile_env[0] == '1');  // (E-step batches too: k_em_tile)
     std::vector<uint32_t> cand(ntasks, 0);
     std::vector<int64_t> sched_off(ntasks, -1);
     int64_t ctl_entries = 0;
@@ -1607,6 +1607,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         bool global_ring;
         int stair_R;  // > 0: the register-kernel E-step (k_em_stair<R>), else the generic kernel
         int wide_NW;  // > 0: stair_R slots per lane on wide_NW wavefronts per task (k_dp_wide<R, NW, EM>)
+        bool tile;    // the stripe-kernel E-step (k_em_tile<stair_R>): scratch regions per workgroup, as in the DP launch
     };
     std::vector<L> launches;
     int64_t max_grid = 1;
@@ -1620,6 +1621,15 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
             int em_waves = l.stair_R == 4 ? 8 : (l.stair_R == 2 ? 12 : 16);
             if (const char *w = std::getenv("NPR_EM_WAVES")) em_waves = std::max(1, std::atoi(w));  // bring-up
             l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * em_waves)));
+            launches.push_back(l);
+            continue;
+        }
+        if (kClassTab[dl.cls].kind == K_TILE && kClassTab[dl.cls].R == 2 && !std::getenv("NPR_EM_GENERIC")) {
+            // 164 VGPRs: 3 wavefronts per SIMD, 12 per CU -> 3 workgroups of 4; the workgroups keep the scratch regions the DP
+            // launch gave them (region i is sized for task i, and everything the queue hands out later is smaller)
+            l.stair_R = 2, l.tile = true;
+            l.lds = em_tile_lds_bytes(em_tile_waves());
+            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(l.count, dl.grid), static_cast<int64_t>(ctx->cu_count) * (12 / em_tile_waves()))));
             launches.push_back(l);
             continue;
         }
@@ -1641,13 +1651,16 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         launches.push_back(l);
     }
     size_t ring_floats = 0;
+    bool any_tile = false;
     for (auto &l : launches) {
+        any_tile |= l.tile;
         // the forward scratch of this batch was sized for the DP launches' grid: stay inside it
-        l.grid = static_cast<int>(std::min<int64_t>(l.grid, std::max<int64_t>(1, static_cast<int64_t>(ctx->arena_cells) / std::max<int64_t>(b->slot_stride, 1))));
+        if (!l.tile) l.grid = static_cast<int>(std::min<int64_t>(l.grid, std::max<int64_t>(1, static_cast<int64_t>(ctx->arena_cells) / std::max<int64_t>(b->slot_stride, 1))));
         max_grid = std::max<int64_t>(max_grid, l.grid);
         if (l.global_ring) ring_floats = std::max(ring_floats, static_cast<size_t>(l.grid) * 18 * l.wcap);
     }
-    const size_t fx_cells = static_cast<size_t>(max_grid) * 4 * static_cast<size_t>(b->slot_stride);
+    size_t fx_cells = static_cast<size_t>(max_grid) * 4 * static_cast<size_t>(b->slot_stride);
+    if (any_tile) fx_cells = std::max(fx_cells, 4 * b->scratch_cells);  // the stripe kernel's planes mirror its regions of the forward scratch
     hipError_t e;
     if (fx_cells > ctx->arena_fx_cells) {
         if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
@@ -1680,7 +1693,8 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         a.Fx = ctx->arena_Fx;
         a.em_T = d_T.p;
         a.em_E = d_E.p;
-        const int rc = l.wide_NW   ? launch_em_wide(a, l.stair_R, l.wide_NW, l.grid, ctx->stream)
+        const int rc = l.tile      ? launch_em_tile(a, l.stair_R, l.grid, ctx->stream)
+                       : l.wide_NW ? launch_em_wide(a, l.stair_R, l.wide_NW, l.grid, ctx->stream)
                        : l.stair_R ? launch_em_stair(a, l.stair_R, l.grid, ctx->stream)
                                    : launch_em(a, l.grid, l.lds, l.global_ring, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "E-step kernel launch", static_cast<hipError_t>(rc));

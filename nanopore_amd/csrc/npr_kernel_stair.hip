@@ -591,7 +591,7 @@ __device__ __forceinline__ void em_cells(const StepEnv &E, const Diag<R> &io, co
             // the five bins of this cell (disjoint tables): all reads, then all writes -- one LDS round trip
             // per cell.  An N base goes to a scratch row (row EM_BINS).
             if (lanes_of(here)) {
-                constexpr int TRASH = (EM_BINS + 14) * 256;
+                constexpr int TRASH = EM_BINS * 256;  // the scratch row: the last of the EM_BINS + 1 rows a wavefront has
                 const bool nx = ex4 >= 16, ny = ey4 >= 16;
                 const int aM = ((nx || ny) ? TRASH : ex4 * 256 + ey4 * 64) + lane4;
                 const int aXs = (nx ? TRASH : 16 * 256 + ex4 * 64) + lane4, aXl = (nx ? TRASH : 20 * 256 + ex4 * 64) + lane4;
