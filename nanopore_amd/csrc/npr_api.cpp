@@ -303,6 +303,7 @@ struct npr_batch {
     DevBuf<uint32_t> d_rowmask;  // ... and the packed lane masks of every row of every stripe (tile_row_word)
     DevBuf<PlanSeg> d_pseg;    // the segments as the device planner sees them (read order)
     DevBuf<int64_t> d_region;  // k_dp_tile: first scratch cell of each resident workgroup
+    std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
@@ -996,6 +997,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             if (g > 0 && tile_total + need > room) break;
             region.push_back(sum_grid * b->slot_stride + tile_total);
             tile_total += need;
+            b->region_end.push_back(sum_grid * b->slot_stride + tile_total);
         }
         tileL->grid = std::max(1, g);
         tileL->slot_base = 0;
@@ -1659,18 +1661,38 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         max_grid = std::max<int64_t>(max_grid, l.grid);
         if (l.global_ring) ring_floats = std::max(ring_floats, static_cast<size_t>(l.grid) * 18 * l.wcap);
     }
-    size_t fx_cells = static_cast<size_t>(max_grid) * 4 * static_cast<size_t>(b->slot_stride);
-    if (any_tile) fx_cells = std::max(fx_cells, 4 * b->scratch_cells);  // the stripe kernel's planes mirror its regions of the forward scratch
+    // The planes of the other four states: 16 bytes per cell of forward scratch in use.  The stripe kernel's mirror its regions
+    // of the forward scratch, but only those of the workgroups the E-step launches (far fewer than the DP launch had): when
+    // the device has no room for them, fewer workgroups yet.
     hipError_t e;
-    if (fx_cells > ctx->arena_fx_cells) {
+    for (;;) {
+        max_grid = 1;
+        for (const auto &l : launches)
+            if (!l.tile) max_grid = std::max<int64_t>(max_grid, l.grid);
+        size_t fx_cells = static_cast<size_t>(max_grid) * 4 * static_cast<size_t>(b->slot_stride);
+        for (const auto &l : launches)
+            if (l.tile && !b->region_end.empty())
+                fx_cells = std::max(fx_cells, 4 * static_cast<size_t>(b->region_end[std::min<size_t>(static_cast<size_t>(l.grid), b->region_end.size()) - 1]));
+        if (fx_cells <= ctx->arena_fx_cells) break;
         if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
         ctx->arena_Fx = nullptr, ctx->arena_fx_cells = 0;
         char *raw = nullptr;
-        if ((e = hipMalloc(reinterpret_cast<void **>(&raw), fx_cells * sizeof(float) + 2 * npr_ctx::kArenaPad)) == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void **>(&raw), fx_cells * sizeof(float) + 2 * npr_ctx::kArenaPad);
+        if (e != hipSuccess && !ctx->cache.empty()) {  // the buffers kept from closed batches are in the way
+            (void)hipGetLastError();
+            ctx->cache_flush();
+            e = hipMalloc(reinterpret_cast<void **>(&raw), fx_cells * sizeof(float) + 2 * npr_ctx::kArenaPad);
+        }
+        if (e == hipSuccess) {
             ctx->arena_Fx = reinterpret_cast<float *>(raw + npr_ctx::kArenaPad);
-        if (e != hipSuccess)
-            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc of the forward planes", e);
-        ctx->arena_fx_cells = fx_cells;
+            ctx->arena_fx_cells = fx_cells;
+            break;
+        }
+        (void)hipGetLastError();
+        bool shrunk = false;
+        for (auto &l : launches)
+            if (l.grid > 1) l.grid = (l.grid + 1) / 2, shrunk = true;
+        if (!shrunk) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc of the forward planes", e);
     }
     DevBuf<float> ring;
     DevBuf<double> d_T, d_E;
