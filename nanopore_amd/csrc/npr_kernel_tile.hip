@@ -21,8 +21,11 @@
 //     stripe has got.  Wavefronts of a workgroup take the stripes of ONE task round-robin and run as a pipeline, each a
 //     stripe width behind its left neighbour -- no barrier inside the sweep;
 //   * forward match values stream to HBM one fixed-stride row per anti-diagonal of a stripe and stream back one row
-//     ahead of use; the backward sweep keeps its stripe right-aligned in the wavefront (the neighbour's column then
-//     always enters at lane 63) and reads the rows with a lane offset.
+//     ahead of use (every stripe is 64*R columns wide -- the last one may reach past lX --, so the right neighbour's
+//     column always enters at lane 63 and a row is read by the lanes that wrote it);
+//   * which lanes of a row hold band cells is read from a table the planner made (one packed word per row, k_plan_rowmask),
+//     rows and neighbour cells are addressed by one buffer descriptor per stripe plus a vector offset: next to nothing
+//     per step on the scalar unit, which the CU's four SIMDs share.
 // Any band shape and width goes: what is outside the band is masked per anti-diagonal from the band arrays.
 // Bit-identical to the other kernels and to the fp32 mirror (same cell arithmetic, order of evaluation is irrelevant to
 // a cell's value).
