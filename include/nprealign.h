@@ -173,8 +173,8 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
  *   0-2  register kernel, one wavefront per task, 64 / 128 / 256 slots (k_dp_stair<1|2|4>)
  *   3-6  register kernel, 4 / 8 / 8 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
  *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring
- *   11   register kernel on column stripes, any width (k_dp_tile); takes what 3-10 would take unless the batch is staged
- *        with NPR_MODE_EXPECTATIONS or NPR_NO_TILE=1 is set */
+ *   11   register kernel on column stripes, any width (k_dp_tile; k_em_tile for npr_batch_expectations); takes what 3-10
+ *        would take unless NPR_NO_TILE=1 is set */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* results, valid after npr_batch_finish */
 int32_t npr_batch_results(const npr_batch *b, npr_read_result *out /* [n_reads] */);
