@@ -314,6 +314,68 @@ int64_t npr_format_sam_records(int64_t n, const char *qnames, const int64_t *qna
 /* ASCII -> base codes 0..4 (A,C,G,T,N) */
 void npr_encode_bases(const uint8_t *ascii, int64_t n, uint8_t *codes);
 
+/* ---- bulk text ingest / splice: the file side of realignSamFile2TargetFn / realignSamFile3TargetFn ----
+ * The reference walks the SAM file record by record in Python (pysam iterator + samIterator, nanopore/analyses/utils.py:287-293,
+ * :563-570), builds one exonerate cigar per record (utils.py:168-180), and afterwards copies every record to the output with
+ * only its CIGAR replaced (utils.py:591-609).  At 50 k records of 8 kb that loop is longer than the DP; these entry points do
+ * the same over the whole text of the file (the caller maps or reads it), threaded, so that the records of a rank's shard go
+ * from file bytes to the C ABI's batch arrays -- and the realigned cigars back into file bytes -- without a Python object
+ * per record.  Host code; no GPU needed. */
+
+/* Alignment lines of a SAM text: *header_end = offset of the first byte after the @-header lines; returns the number of
+ * alignment lines (non-empty lines after the header).  span[2 * i], span[2 * i + 1] = [start, end) of line i without its
+ * "\n" / "\r\n"; span == NULL: only count.  NPR_ERR_CAPACITY when cap (lines) is smaller. */
+int64_t npr_sam_index(const char *text, int64_t len, int64_t *header_end, int64_t *span, int64_t cap);
+
+/* Fields of n alignment lines (span as from npr_sam_index, possibly a sub-range: a rank's shard).  fields[i * NPR_SAM_COLS + c]:
+ *   0 end of QNAME (it starts at span[2 * i])      1, 2  RNAME [start, end)       3, 4  CIGAR [start, end)
+ *   5, 6 SEQ [start, end)                          7 FLAG     8 POS - 1 (0-based, pysam's aR.pos)     9 MAPQ
+ *   10 tid = index of RNAME in the given name table (the @SQ order), -1 for "*" or a name not in it: samIterator drops
+ *      those records (utils.py:287-293)
+ *   11, 12 [start, end) of the aligned part of SEQ in the text (soft clips cut off: aR.query, the sequence handed to
+ *      cactus_realign, utils.py:570); empty for SEQ "*"
+ *   13 operations M / I / D of the cigar (the guide: clips carry no operation, utils.py:173)
+ *   14 reference bases the cigar consumes (aR.aend - aR.pos)
+ *   15 NPR_OK, or NPR_ERR_INVALID: fewer than 11 columns, a malformed number or cigar, or an operation outside M I D S H
+ *      (the reference asserts `op in (0, 1, 2, 4, 5)`, utils.py:171)
+ * rnames / rname_off: the n_refs reference names, CSR.  Threaded. */
+#define NPR_SAM_COLS 16
+int32_t npr_sam_parse(const char *text, const int64_t *span, int64_t n, const char *rnames, const int64_t *rname_off, int64_t n_refs,
+                      int64_t *fields);
+/* The guides of n parsed lines as the batch entry points take them: (op, length) pairs of the M / I / D operations of line i
+ * at guide_ops[2 * guide_off[i] ..), guide_off = exclusive prefix sum of fields column 13 (made by the caller, n + 1 entries).
+ * Lines whose column 15 is not NPR_OK are skipped. */
+int32_t npr_sam_guides(const char *text, const int64_t *fields, int64_t n, const int64_t *guide_off, int32_t *guide_ops);
+/* Output records: line i of the input with its CIGAR field replaced by the packed cigar i (one 32-bit word per operation,
+ * length << 2 | op, list i = words[word_off[i] .. word_off[i] + n_ops[i]); "*" when empty), every other byte copied --
+ * QNAME, FLAG, RNAME, POS, MAPQ, the mate fields, SEQ, QUAL and the tags exactly as the mapper wrote them, which is what
+ * realignSamFile3TargetFn's `aR.cigar = ...; outputSam.write(aR)` produces (utils.py:597-605).  Each record ends in "\n".
+ * Record i lands at out[rec_off[i] .. rec_off[i + 1]); out == NULL: only the offsets.  Returns the total length,
+ * NPR_ERR_CAPACITY when cap is smaller, NPR_ERR_INVALID for an operation outside M / I / D.  Threaded. */
+int64_t npr_sam_splice(const char *text, const int64_t *span, const int64_t *fields, int64_t n, const int64_t *word_off,
+                       const int64_t *n_ops, const uint32_t *words, int64_t *rec_off, char *out, int64_t cap);
+
+/* FASTA text (getFastaDictionary, utils.py:233-238): returns the number of records; rec[4 * k ..] = [start, end) of the
+ * record's name (first word of the header line) and [start, end) of its sequence lines in the text, seq_len[k] = bases
+ * (line ends and blanks not counted).  rec == NULL: only count.  NPR_ERR_CAPACITY when cap (records) is smaller. */
+int64_t npr_fasta_index(const char *text, int64_t len, int64_t *rec, int64_t *seq_len, int64_t cap);
+/* ... and the sequences themselves, contiguous: record k at out[seq_off[k] .. seq_off[k + 1]) (seq_off = prefix sum of
+ * seq_len), line ends and blanks removed -- the reference table npr_batch_create takes.  Threaded over records. */
+int32_t npr_fasta_pack(const char *text, const int64_t *rec, int64_t n, const int64_t *seq_off, uint8_t *out);
+/* FASTQ text (getFastqDictionary, utils.py:240-245), four-line records: rec[4 * k ..] = [start, end) of the name (first
+ * word after '@') and [start, end) of the sequence line.  rec == NULL: only count.  NPR_ERR_INVALID for a record that does
+ * not start with '@' or whose third line does not start with '+'. */
+int64_t npr_fastq_index(const char *text, int64_t len, int64_t *rec, int64_t cap);
+
+/* npr_batch_create_at for reads that are NOT contiguous in memory: read i = read[read_begin[i] .. read_end[i]) -- e.g. the
+ * aligned part of each record's SEQ inside the mapped SAM text (columns 11, 12 of npr_sam_parse), so the sequences go from
+ * the file's bytes to the pinned staging buffer in one copy.  Everything else as npr_batch_create_at. */
+int32_t npr_batch_create_spans(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                               const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                               const uint8_t *read, const int64_t *read_begin, const int64_t *read_end,
+                               const int32_t *guide_ops, const int64_t *guide_off, const int64_t *guide_start,
+                               const int32_t *model_slot, npr_batch **out);
+
 #ifdef __cplusplus
 }
 #endif

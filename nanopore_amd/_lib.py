@@ -87,6 +87,8 @@ EXPORTS = [
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
     "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_format_cigars_packed", "npr_format_sam_records", "npr_chain_hits", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
+    "npr_sam_index", "npr_sam_parse", "npr_sam_guides", "npr_sam_splice", "npr_fasta_index", "npr_fasta_pack", "npr_fastq_index",
+    "npr_batch_create_spans",
 ]
 
 _lib = None
@@ -177,6 +179,22 @@ def load():
     L.npr_rescore.argtypes = [vp, i64, vp, vp, vp, i64, C.POINTER(dbl)]
     L.npr_encode_bases.restype = None
     L.npr_encode_bases.argtypes = [vp, i64, vp]
+    L.npr_sam_index.restype = i64
+    L.npr_sam_index.argtypes = [vp, i64, C.POINTER(i64), vp, i64]
+    L.npr_sam_parse.restype = i32
+    L.npr_sam_parse.argtypes = [vp, vp, i64, vp, vp, i64, vp]
+    L.npr_sam_guides.restype = i32
+    L.npr_sam_guides.argtypes = [vp, vp, i64, vp, vp]
+    L.npr_sam_splice.restype = i64
+    L.npr_sam_splice.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64]
+    L.npr_fasta_index.restype = i64
+    L.npr_fasta_index.argtypes = [vp, i64, vp, vp, i64]
+    L.npr_fasta_pack.restype = i32
+    L.npr_fasta_pack.argtypes = [vp, vp, i64, vp, vp]
+    L.npr_fastq_index.restype = i64
+    L.npr_fastq_index.argtypes = [vp, i64, vp, i64]
+    L.npr_batch_create_spans.restype = i32
+    L.npr_batch_create_spans.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     _lib = L
     return L
 

@@ -18,6 +18,38 @@ MATCHES, MISMATCHES, AGAINST_N, PAIRS, N_INS, INS_LEN, N_DEL, DEL_LEN, LEAD_READ
 SUBST = 15  # 25 counts, reference base major, A C G T N
 
 
+class _Lengths(object):
+    """Names -> sequence lengths with the dict surface the analyses use on refSequences / readSequences (len(), items()
+    yielding something with a len()): what a job-sized read set needs instead of 30 k Python strings of 30 kb."""
+
+    class _Sized(object):
+        __slots__ = ("n",)
+
+        def __init__(self, n):
+            self.n = int(n)
+
+        def __len__(self):
+            return self.n
+
+    def __init__(self, names, lengths):
+        self._len = {}
+        for name, n in zip(names, lengths):
+            assert name not in self._len, "Duplicate sequence name %s" % name
+            self._len[name] = int(n)
+
+    def __len__(self):
+        return len(self._len)
+
+    def __contains__(self, name):
+        return name in self._len
+
+    def length(self, name):
+        return self._len[name]
+
+    def items(self):
+        return ((k, _Lengths._Sized(v)) for k, v in self._len.items())
+
+
 class SamAlignmentStats(object):
     """The records of a SAM file (those with a reference, utils.samIterator) and their device-reduced statistics."""
 
@@ -54,6 +86,44 @@ class SamAlignmentStats(object):
             self.table = np.zeros((0, 40), dtype=np.int32)
         sam.close()
         self._gaps = None
+
+    @classmethod
+    def fromRealignedSam(cls, samFile, referenceFastaFile, readFastqFile, table):
+        """The same object for the output of a realignment job, from the table the job already reduced on the device where
+        the alignments lay (job.realign_sam_file(..., want_stats=True): npr_batch_align_stats per chunk) -- no second pass over
+        the aligned pairs, and no Python object per record: names, positions and lengths come from the native scanners
+        (nanopore_amd/ingest.py).  Row i of `table` belongs to record i of `samFile` (the records with a reference, in order).
+        The individual gap lengths (indels.xml) are not available in this form."""
+        from .. import ingest
+        self = cls.__new__(cls)
+        sam = ingest.SamText(samFile)
+        f = sam.parse()
+        kept = np.nonzero(f[:, ingest.F_TID] >= 0)[0]
+        f = f[kept]
+        if len(f) != len(table):
+            raise ValueError("%d records with a reference in %s, %d rows of statistics" % (len(f), samFile, len(table)))
+        fasta = ingest.FastaTable(referenceFastaFile)
+        qnames, qtext, qspan = ingest.fastq_table(readFastqFile)
+        self.refSequences = _Lengths(fasta.names, fasta.off[1:] - fasta.off[:-1])
+        self.readSequences = _Lengths(qnames, qspan[:, 1] - qspan[:, 0])
+        starts = sam.span[kept, 0]
+        self.readNames = [sam.field_bytes(int(a), int(b)).decode() for a, b in zip(starts, f[:, ingest.F_QNAME_END])]
+        self.refNames = [sam.references[int(t)] for t in f[:, ingest.F_TID]]
+        self.isReverse = (f[:, ingest.F_FLAG] & 0x10) != 0
+        self.pos = f[:, ingest.F_POS].copy()
+        self.aend = self.pos + f[:, ingest.F_REF_SPAN]
+        self.refLength = np.array([self.refSequences.length(r) for r in self.refNames], dtype=np.int64)
+        self.readLength = np.array([self.readSequences.length(q) for q in self.readNames], dtype=np.int64)
+        # clips of the record as it stands in the file: SEQ outside the aligned part
+        self.clipBefore = f[:, ingest.F_QUERY_LO] - f[:, ingest.F_SEQ_LO]
+        self.clipAfter = f[:, ingest.F_SEQ_HI] - f[:, ingest.F_QUERY_HI]
+        self.cigars = None
+        self.table = np.ascontiguousarray(table, dtype=np.int32)
+        bad = np.flatnonzero(self.table[:, STATUS] != 0)
+        if len(bad):
+            raise RuntimeError("The cigar of record %s runs past its sequences" % self.readNames[int(bad[0])])
+        self._gaps = None
+        return self
 
     def __len__(self):
         return len(self.readNames)

@@ -76,9 +76,11 @@ def aggregateNode(tagName, stats, columns, chosen, perAlignmentLengths):
 class LocalCoverage(AbstractAnalysis):
     """Coverage with every record taken as a local alignment."""
 
-    def run(self, globalAlignment=False, ctx=None):
+    def run(self, globalAlignment=False, ctx=None, stats=None):
+        """`stats`: a SamAlignmentStats made elsewhere (SamAlignmentStats.fromRealignedSam: the table a realignment job reduced
+        on the device); default: the records of self.samFile are counted now."""
         AbstractAnalysis.run(self)
-        stats = SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
+        stats = stats or SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
         if len(stats):
             columns = coverageColumns(stats, globalAlignment)
             # the record with the highest read coverage of every read, reads in order of first appearance (:139)
@@ -109,5 +111,5 @@ class LocalCoverage(AbstractAnalysis):
 class GlobalCoverage(LocalCoverage):
     """Coverage with every record taken as a global alignment: unaligned ends count as indels."""
 
-    def run(self, ctx=None):
-        LocalCoverage.run(self, globalAlignment=True, ctx=ctx)
+    def run(self, ctx=None, stats=None):
+        LocalCoverage.run(self, globalAlignment=True, ctx=ctx, stats=stats)

@@ -50,9 +50,9 @@ class SubstitutionMatrix(object):
 
 
 class Substitutions(AbstractAnalysis):
-    def run(self, kmer=5, ctx=None):
+    def run(self, kmer=5, ctx=None, stats=None):
         AbstractAnalysis.run(self)
-        stats = SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
+        stats = stats or SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
         sM = SubstitutionMatrix(stats.substitutionCounts().reshape(-1))
         with open(os.path.join(self.outputDir, "substitutions.xml"), "w") as fh:
             fh.write(prettyXml(sM.getXML()))

@@ -12,6 +12,8 @@ device `realignSamFile` raises.
 import os
 import sys
 
+import numpy as np
+
 from .. import bioio
 from .. import sam as pysam  # attribute-compatible subset
 from ..bioio import (PairwiseAlignment, cigarRead, cigarReadFromString, fastaRead, fastaWrite, fastqRead,
@@ -307,18 +309,46 @@ def realignRecords(sam, records, refSequences, gapGamma, matchGamma, hmmFile, mo
     return run(0, len(records))
 
 
-def realignSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, hmmFile, gapGamma, matchGamma, ctx=None):
-    """realignSamFile2TargetFn + realignCigarTargetFn + realignSamFile3TargetFn (utils.py:557-609) as one
-    batched GPU call: output SAM == input SAM with only each record's CIGAR replaced, same order, header
-    copied (utils.py:596-605)."""
+def realignSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, hmmFile, gapGamma, matchGamma, ctx=None, group=None):
+    """realignSamFile2TargetFn + realignCigarTargetFn + realignSamFile3TargetFn (utils.py:557-609): output SAM == input SAM
+    with only each record's CIGAR replaced, same order, header copied (utils.py:596-605).
+
+    The whole file goes through `nanopore_amd.job.realign_sam_file`: the text is mapped and parsed natively (no Python
+    object per record), the records shard over the ranks of an initialised torch.distributed process group (collective
+    call; one rank otherwise), every rank keeps two batches in flight on its GPU and writes its own block of the output.
+    `readFastqFile` is accepted for the reference's signature: like realignSamFile2TargetFn, which loads the FASTQ and then
+    hands cactus_realign aR.query (utils.py:561, :570), the realignment reads its sequences from the SAM records.
+    Returns the per-record results (structured array, input order) on rank 0, None on the other ranks."""
+    from .. import job
+    if ctx is not None:  # a caller's context joins the pool of its GPU, so its models / scratch are reused
+        pool = job._ctx_pool.setdefault(ctx.device, [])
+        if ctx not in pool:
+            pool.insert(0, ctx)
+    out = job.realign_sam_file(samFile, outputSamFile, referenceFastaFile, hmm=hmmFile, gapGamma=gapGamma, matchGamma=matchGamma,
+                               group=group, gpu=None if ctx is None else ctx.device)
+    if "results" not in out:
+        return None
+    results = out["results"]
+    failed = np.nonzero(results["status"] != 0)[0]
+    if len(failed):
+        # the reference's system() raises on a non-zero exit of cactus_realign and the job tree reports failed jobs
+        # (pipeline.py:209-210), leaving no output SAM; a batch finds out after the fact
+        if os.path.exists(outputSamFile):
+            os.unlink(outputSamFile)
+        raise RuntimeError("Realignment failed for %d record(s), first: record %d, status %d" % (len(failed), int(failed[0]), int(results["status"][failed[0]])))
+    return results
+
+
+def realignSamFileByRecord(samFile, outputSamFile, readFastqFile, referenceFastaFile, hmmFile, gapGamma, matchGamma, ctx=None):
+    """The same through the record-at-a-time host mirror (Samfile iterator, one AlignedRead per record, realignRecords, one
+    write per record): the shape of the reference's own loop, kept as the small-input path of the analyses that hold
+    AlignedRead objects anyway and as the cross-check of the bulk path (tests/test_gpu_job.py: byte-identical output)."""
     refSequences = getFastaDictionary(referenceFastaFile)
     sam = pysam.Samfile(samFile, "r")
     records = list(samIterator(sam))
     results = realignRecords(sam, records, refSequences, gapGamma, matchGamma, hmmFile, ctx=ctx)
     failed = [(aR.qname, r["status"]) for aR, r in zip(records, results) if r["status"] != 0]
     if failed:
-        # the reference's system() raises on a non-zero exit of cactus_realign and the job tree reports failed
-        # jobs (pipeline.py:209-210); a batch does the same after the fact
         raise RuntimeError("Realignment failed for %d record(s), first: %s" % (len(failed), failed[0]))
     out = pysam.Samfile(outputSamFile, "wh", template=sam)
     for aR, r in zip(records, results):

@@ -24,6 +24,7 @@
 #include "npr_device.h"
 #include "npr_internal.h"
 #include "npr_sched.h"
+#include "npr_threads.h"
 
 using namespace npr;
 
@@ -33,7 +34,28 @@ struct npr_plan {
 
 namespace {
 struct MeaScratch;
-}
+
+// Forward-value scratch of ONE device (one region per resident wavefront), shared by every context on that device and only
+// growing: a hipMalloc of ~100 GB costs seconds, far more than the DP pass it serves, and a pipelined job keeps two
+// batches in flight on two contexts of the same GPU (nanopore_amd/job.py) -- their DP launches each fill the chip and so
+// run one after the other anyway, and one arena instead of two is the difference between fitting the device and not
+// (config 3: ~130-250 GB).  `mu` is held by whatever launches kernels that read or write the arena (the DP pass, the device
+// MEA stage whose tables are carved out of it, the E-step, the dense dump) until they have finished, and while it is
+// regrown.  `epoch` is bumped whenever its contents may have been overwritten: a finished batch may use the packed cigars
+// the MEA stage left there only while its stamp is current.
+// The arena points kArenaPad bytes into its allocation and is followed by as much: the register E-step loads forward rows
+// with a slot shift of up to two and may touch a few cells before / after a region.
+struct DeviceArena {
+    static constexpr size_t kPad = 1024;
+    std::mutex mu;
+    char *F = nullptr;  // 8 bytes per cell
+    size_t cells = 0;
+    uint64_t epoch = 1;
+    int users = 0;
+};
+constexpr int kMaxDevices = 64;
+DeviceArena g_arena[kMaxDevices];
+}  // namespace
 
 struct npr_ctx {
     int device = -1;
@@ -51,15 +73,9 @@ struct npr_ctx {
     DevModel *d_models = nullptr;
     std::string last_error;
     int host_threads = 1;
-    // Forward-value scratch (one region per resident wavefront) lives with the context and only grows: a
-    // hipMalloc of ~100 GB costs seconds, far more than the DP pass it serves.  Batches on one context run one
-    // at a time (include/nprealign.h), so they can share it.
-    // Both arenas point kArenaPad bytes into their allocations and are followed by as much: the register E-step loads
-    // forward rows with a slot shift of up to two and may touch a few cells before / after a region.
-    static constexpr size_t kArenaPad = 1024;
-    char *arena_F = nullptr;  // 8 bytes per cell
-    size_t arena_cells = 0;
-    float *arena_Fx = nullptr;  // E-step only: four more forward planes
+    DeviceArena *arena = nullptr;  // the device's forward scratch (shared with the other contexts on this device)
+    static constexpr size_t kArenaPad = DeviceArena::kPad;
+    float *arena_Fx = nullptr;  // E-step only: four more forward planes (per context)
     size_t arena_fx_cells = 0;
     // pinned host staging for the posterior triples of npr_batch_finish (grow-only): a pageable destination halves
     // the D2H rate and the copy is a GB per batch
@@ -69,9 +85,6 @@ struct npr_ctx {
     void *pin_stage = nullptr;
     size_t pin_stage_bytes = 0;
     MeaScratch *mea = nullptr;
-    // bumped whenever the scratch a finished batch left its device-side cigars in may be overwritten (a DP launch, a
-    // device MEA stage): npr_batch_align_stats uses the resident cigars only while the batch's stamp is current
-    uint64_t scratch_epoch = 1;
     // Device buffers of destroyed batches, kept for the next batch (DevBuf::alloc_from): hipMalloc / hipFree of the
     // gigabyte-sized band, control-word and pair arrays cost more than the kernels that fill them (0.1 s per batch of
     // 50 k reads), and a pipeline stages batch after batch of the same shape.
@@ -222,56 +235,6 @@ struct StageTimer {
     }
 };
 
-// CPUs this process may actually use: the hardware count capped by the cgroup CPU quota (a container on a 256-core
-// host is often limited to a few cores; running 256 threads inside such a quota is slower than running 16)
-int usable_cpus() {
-    int n = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
-    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char quota[32] = {0};
-        long long period = 0;
-        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
-            const long long q = std::atoll(quota);
-            if (q > 0) n = std::min<int>(n, static_cast<int>(std::max<long long>(1, (q + period - 1) / period)));
-        }
-        std::fclose(f);
-    }
-    if (const char *e = std::getenv("NPR_HOST_THREADS")) n = std::max(1, std::atoi(e));
-    return n;
-}
-
-// Runs f(0..n-1) on `threads` host threads.  An exception inside a worker (std::bad_alloc from a plan or MEA vector)
-// must not escape the thread -- that would be std::terminate --: it is caught, the remaining items are skipped and the
-// first one is rethrown on the calling thread, where the C ABI turns it into NPR_ERR_NOMEM.
-template <typename F>
-void parallel_for(int64_t n, int threads, F f) {
-    threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(threads, n)));
-    if (threads == 1) {
-        for (int64_t i = 0; i < n; ++i) f(i);
-        return;
-    }
-    std::atomic<int64_t> next{0};
-    std::atomic<bool> failed{false};
-    std::exception_ptr first;
-    std::mutex mu;
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; ++t)
-        pool.emplace_back([&] {
-            try {
-                for (;;) {
-                    const int64_t i = next.fetch_add(1);
-                    if (i >= n || failed.load()) break;
-                    f(i);
-                }
-            } catch (...) {
-                std::lock_guard<std::mutex> lock(mu);
-                if (!first) first = std::current_exception();
-                failed = true;
-            }
-        });
-    for (auto &th : pool) th.join();
-    if (first) std::rethrow_exception(first);
-}
-
 }  // namespace
 
 struct npr_batch {
@@ -336,7 +299,7 @@ struct npr_batch {
     std::vector<Pair> pairs;             // filled by fetch_pairs(): at finish in the host modes, on demand after the device MEA
     bool pairs_ready = false;
     std::vector<int64_t> task_dst;       // prefix of the per-task pair counts
-    // packed cigars left on the device by the device MEA stage (valid while dev_ops_epoch == ctx->scratch_epoch)
+    // packed cigars left on the device by the device MEA stage (valid while dev_ops_epoch == the arena's epoch)
     const uint32_t *dev_ops = nullptr;
     const int64_t *dev_od = nullptr;
     uint64_t dev_ops_epoch = 0;
@@ -377,7 +340,7 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
         say("npr_create: no HIP device visible", e);
         return NPR_ERR_NO_DEVICE;
     }
-    if (device_id >= count) {
+    if (device_id >= count || device_id >= kMaxDevices) {
         say("npr_create: device index out of range", hipSuccess);
         return NPR_ERR_NO_DEVICE;
     }
@@ -401,6 +364,11 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
     npr_ctx *ctx = new (std::nothrow) npr_ctx;
     if (!ctx) return NPR_ERR_NOMEM;
     ctx->device = device_id;
+    ctx->arena = &g_arena[device_id];
+    {
+        std::lock_guard<std::mutex> lock(ctx->arena->mu);
+        ++ctx->arena->users;
+    }
     ctx->cu_count = prop.multiProcessorCount;
     ctx->total_mem = prop.totalGlobalMem;
     ctx->host_threads = usable_cpus();
@@ -434,7 +402,13 @@ void npr_destroy(npr_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     ctx->cache_flush();
     if (ctx->d_models) (void)hipFree(ctx->d_models);
-    if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
+    if (ctx->arena) {  // the last context on the device takes the shared scratch with it
+        std::lock_guard<std::mutex> lock(ctx->arena->mu);
+        if (--ctx->arena->users == 0) {
+            if (ctx->arena->F) (void)hipFree(ctx->arena->F - DeviceArena::kPad);
+            ctx->arena->F = nullptr, ctx->arena->cells = 0, ++ctx->arena->epoch;
+        }
+    }
     if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
     if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
     if (ctx->pin_stage) (void)hipHostFree(ctx->pin_stage);
@@ -554,7 +528,7 @@ static int32_t ensure_coff(npr_batch *b) {
 
 static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
                                     const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
-                                    const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                                    const uint8_t *read, const int64_t *read_begin, const int64_t *read_end, const int32_t *guide_ops,
                                     const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
                                     npr_batch **out);
 
@@ -565,7 +539,20 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
                             const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
                             npr_batch **out) {
     try {
-        return batch_create_at_impl(ctx, params, n_reads, n_refs, ref, ref_off, ref_index, read, read_off, guide_ops, guide_off,
+        return batch_create_at_impl(ctx, params, n_reads, n_refs, ref, ref_off, ref_index, read, read_off, read_off ? read_off + 1 : nullptr, guide_ops,
+                                    guide_off, guide_start, model_slot, out);
+    } catch (const std::exception &) {
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: out of host memory");
+    }
+}
+
+int32_t npr_batch_create_spans(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
+                               const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
+                               const uint8_t *read, const int64_t *read_begin, const int64_t *read_end,
+                               const int32_t *guide_ops, const int64_t *guide_off, const int64_t *guide_start,
+                               const int32_t *model_slot, npr_batch **out) {
+    try {
+        return batch_create_at_impl(ctx, params, n_reads, n_refs, ref, ref_off, ref_index, read, read_begin, read_end, guide_ops, guide_off,
                                     guide_start, model_slot, out);
     } catch (const std::exception &) {
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: out of host memory");
@@ -574,17 +561,30 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
 
 static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
                                     const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
-                                    const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,
+                                    const uint8_t *read, const int64_t *read_begin, const int64_t *read_end, const int32_t *guide_ops,
                                     const int64_t *guide_off, const int64_t *guide_start, const int32_t *model_slot,
                                     npr_batch **out) {
     if (!ctx || !params || !out || n_reads < 0 || n_refs < 0) return NPR_ERR_INVALID;
     if (!ref_index && n_refs != n_reads) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: without ref_index, n_refs must equal n_reads");
     auto ref_of = [&](int64_t i) -> int64_t { return ref_index ? ref_index[i] : i; };
-    if (n_reads > 0 && (!ref_off || !read_off || !guide_off)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: null offsets");
+    if (n_reads > 0 && (!ref_off || !read_begin || !read_end || !guide_off)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: null offsets");
     *out = nullptr;
     std::unique_ptr<npr_batch> b(new (std::nothrow) npr_batch);
     if (!b) return NPR_ERR_NOMEM;
     b->ctx = ctx;
+    // Every error return below may leave copies and planner kernels queued on the context's streams that read or write
+    // buffers of this batch (and the context's pinned staging): released buffers go to the context's cache, not to hipFree
+    // (which would synchronise), so nothing may still be in flight when they do.  Declared after `b`: runs before its
+    // destructor.
+    struct DrainOnError {
+        npr_ctx *c;
+        bool armed = true;
+        ~DrainOnError() {
+            if (!armed) return;
+            (void)hipStreamSynchronize(c->side[0]);
+            (void)hipStreamSynchronize(c->stream);
+        }
+    } drain{ctx};
     b->params = *params;
     if (b->params.max_pairs_per_base <= 0) b->params.max_pairs_per_base = 6;
     b->n_reads = n_reads;
@@ -603,7 +603,6 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
 
     StageTimer tm("batch_create");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ++ctx->scratch_epoch;
     hipError_t e;
     // 1. Host, O(cigar operations) per read: the guide's window, validation, matrix splits and the plan points of every
     // segment (npr_host.cpp plan_points).  Worker threads take chunks of reads and append to their chunk's plan.
@@ -619,8 +618,8 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
                 b->read_status[i] = NPR_ERR_INVALID;
                 continue;
             }
-            int64_t lX = ref_off[k + 1] - ref_off[k], lY = read_off[i + 1] - read_off[i];
-            int32_t rc = NPR_OK;
+            int64_t lX = ref_off[k + 1] - ref_off[k], lY = read_end[i] - read_begin[i];
+            int32_t rc = lY < 0 ? NPR_ERR_INVALID : NPR_OK;
             if (guide_start) {  // the window the guide covers
                 const int64_t gx = guide_start[2 * i], gy = guide_start[2 * i + 1];
                 int64_t sx = 0, sy = 0;
@@ -699,7 +698,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         for (int64_t i = c * kChunk, hi = std::min(n_reads, (c + 1) * kChunk); i < hi; ++i) {
             if (!b->read_ntasks[i]) continue;
             std::memcpy(h_seq + win_off[i], ref + ref_off[ref_of(i)] + b->gstart[2 * i], static_cast<size_t>(b->ref_len[i]));
-            std::memcpy(h_seq + win_off[i] + b->ref_len[i], read + read_off[i] + b->gstart[2 * i + 1], static_cast<size_t>(b->read_len[i]));
+            std::memcpy(h_seq + win_off[i] + b->ref_len[i], read + read_begin[i] + b->gstart[2 * i + 1], static_cast<size_t>(b->read_len[i]));
         }
     });
     chunk_plan.clear();
@@ -896,7 +895,12 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
     // (sequences, band rows, control words and stripe tables are allocated already)
     const int64_t fixed = pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut)) + (any_generic ? 0 : band_entries * 4);
-    const int64_t budget = static_cast<int64_t>((free_b + ctx->cache_bytes + ctx->arena_cells * 8) * 0.9) - fixed;
+    size_t arena_now;
+    {
+        std::lock_guard<std::mutex> lock(ctx->arena->mu);
+        arena_now = ctx->arena->cells;
+    }
+    const int64_t budget = static_cast<int64_t>((free_b + ctx->cache_bytes + arena_now * 8) * 0.9) - fixed;
     int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
         fit = budget / (b->slot_stride * 8);
@@ -1012,21 +1016,27 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     // (at least one uniform region: npr_batch_dense and the generic E-step run any task there)
     b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(std::max<int64_t>(sum_grid, ntasks ? 1 : 0)) + static_cast<size_t>(tile_total);
-    if (b->scratch_cells > ctx->arena_cells) {
-        if (ctx->arena_F) (void)hipFree(ctx->arena_F - npr_ctx::kArenaPad);
-        ctx->arena_F = nullptr, ctx->arena_cells = 0;
-        e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8 + 2 * npr_ctx::kArenaPad);
-        if (e != hipSuccess && !ctx->cache.empty()) {  // the buffers kept from earlier batches are in the way
-            (void)hipGetLastError();
-            ctx->cache_flush();
-            e = hipMalloc(reinterpret_cast<void **>(&ctx->arena_F), b->scratch_cells * 8 + 2 * npr_ctx::kArenaPad);
+    {   // (waits for whatever another context's batch is running in the arena)
+        DeviceArena &ar = *ctx->arena;
+        std::lock_guard<std::mutex> lock(ar.mu);
+        if (b->scratch_cells > ar.cells) {
+            if (ar.F) (void)hipFree(ar.F - DeviceArena::kPad);
+            ar.F = nullptr, ar.cells = 0, ++ar.epoch;
+            e = hipMalloc(reinterpret_cast<void **>(&ar.F), b->scratch_cells * 8 + 2 * DeviceArena::kPad);
+            if (e != hipSuccess && !ctx->cache.empty()) {  // the buffers kept from earlier batches are in the way
+                (void)hipGetLastError();
+                ctx->cache_flush();
+                e = hipMalloc(reinterpret_cast<void **>(&ar.F), b->scratch_cells * 8 + 2 * DeviceArena::kPad);
+            }
+            if (e != hipSuccess) {
+                ar.F = nullptr;
+                return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc of the forward scratch", e);
+            }
+            ar.F += DeviceArena::kPad;
+            ar.cells = b->scratch_cells;
         }
-        if (e == hipSuccess) ctx->arena_F += npr_ctx::kArenaPad;
-        if (e != hipSuccess)
-            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc of the forward scratch", e);
-        ctx->arena_cells = b->scratch_cells;
+        if (poison_byte() >= 0) poison(ar.F, ar.cells * 8), ++ar.epoch;
     }
-    poison(ctx->arena_F, ctx->arena_cells * 8);
     tm.lap("hipMalloc");
     if (ntasks) {
         HIP_TRY(ctx, hipMemcpyAsync(b->d_tasks.p, b->tasks.data(), b->d_tasks.bytes(), hipMemcpyHostToDevice, ctx->stream));
@@ -1047,6 +1057,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             if (L.cells > best) best = L.cells, b->stats.kernel_variant = kClassTab[L.cls].kind == K_TILE ? 2 : (is_register_class(L.cls) ? 1 : 0);
     }
     b->stats.device_bytes = fixed + static_cast<int64_t>(b->scratch_cells) * 8 + ring_floats * 4;
+    drain.armed = false;
     *out = b.release();
     return NPR_OK;
 }
@@ -1066,7 +1077,7 @@ static KernelArgs make_args(npr_batch *b) {
     a.stripes = b->d_stripes.p;
     a.rowmask = b->d_rowmask.p;
     a.region = b->d_region.p;
-    a.F = b->ctx->arena_F;
+    a.F = b->ctx->arena->F;  // (the caller holds the arena's mutex)
     a.slot_stride = b->slot_stride;
     a.px = b->d_px.p;
     a.py = b->d_py.p;
@@ -1080,12 +1091,13 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     if (!b) return NPR_ERR_INVALID;
     npr_ctx *ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ++ctx->scratch_epoch;
     if (kernel_ms) *kernel_ms = 0.f;
     if (b->tasks.empty()) {
         b->ran = true;
         return NPR_OK;
     }
+    std::lock_guard<std::mutex> arena_lock(ctx->arena->mu);  // until the DP pass has finished
+    ++ctx->arena->epoch;
     DevBuf<unsigned long long> d_prof;  // NPR_TILE_PROF=1 (bring-up): wait cycles of the stripe kernel's wavefronts
     if (std::getenv("NPR_TILE_PROF")) {
         if (d_prof.alloc(8) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_run: hipMalloc");
@@ -1245,7 +1257,8 @@ int32_t fetch_pairs(npr_batch *b) {
 // needs the host stage instead (a chain reaching back further than the prefix-maximum ring), NPR_OK or an error.
 int32_t device_mea(npr_batch *b) {
     npr_ctx *ctx = b->ctx;
-    ++ctx->scratch_epoch;
+    std::lock_guard<std::mutex> arena_lock(ctx->arena->mu);  // the tables are carved out of the arena when they fit
+    ++ctx->arena->epoch;
     StageTimer tm("device_mea");
     const int64_t n = b->n_reads, ntasks = static_cast<int64_t>(b->tasks.size());
     std::vector<int64_t> rx(n + 1, 0), ry(n + 1, 0), rp(n + 1, 0), ot(n + 1, 0), od(n + 1, 0);
@@ -1277,11 +1290,11 @@ int32_t device_mea(npr_batch *b) {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
         const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (4 * total + 4)) +
                             al(4 * 4 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]);
-        const bool in_arena = ctx->arena_F && need <= static_cast<size_t>(ctx->arena_cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
-        char *cur = ctx->arena_F;
+        const bool in_arena = ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
+        char *cur = ctx->arena->F;
         if (in_arena && poison_byte() >= 0) {  // the DP launches are done (their streams feed this one): the tables start from poison
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            poison(ctx->arena_F, need);
+            poison(ctx->arena->F, need);
         }
         auto take = [&](auto &buf, size_t count) -> hipError_t {
             using T = std::remove_pointer_t<decltype(buf.p)>;
@@ -1379,7 +1392,7 @@ int32_t device_mea(npr_batch *b) {
         });
     }
     tm.lap("gather + D2H of the ops");
-    if (od[n]) b->dev_ops = m.dense.p, b->dev_od = m.od.p, b->dev_ops_epoch = ctx->scratch_epoch;
+    if (od[n]) b->dev_ops = m.dense.p, b->dev_od = m.od.p, b->dev_ops_epoch = ctx->arena->epoch;
     return NPR_OK;
 }
 
@@ -1436,7 +1449,12 @@ static int32_t batch_finish_impl(npr_batch *b) {
         for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 36 * std::min(b->ref_len[i], b->read_len[i]) + 128;
         scratch += 16 * b->pair_off[n];
         size_t mem_free = 0, mem_total = 0;
-        if (static_cast<size_t>(scratch) <= static_cast<size_t>(ctx->arena_cells) * 8 ||
+        size_t arena_bytes;
+        {
+            std::lock_guard<std::mutex> lock(ctx->arena->mu);
+            arena_bytes = ctx->arena->cells * 8;
+        }
+        if (static_cast<size_t>(scratch) <= arena_bytes ||
             (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && static_cast<size_t>(scratch) < mem_free / 2)) {
             const int32_t rc = device_mea(b);
             if (rc < 0) return rc;
@@ -1591,7 +1609,8 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     if (!b || !T_exp || !E_exp || !loglik) return NPR_ERR_INVALID;
     npr_ctx *ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ++ctx->scratch_epoch;
+    std::lock_guard<std::mutex> arena_lock(ctx->arena->mu);  // the E-step keeps its forward rows in the arena
+    ++ctx->arena->epoch;
     std::fill(T_exp, T_exp + NPR_MAX_MODELS * 25, 0.0);
     std::fill(E_exp, E_exp + NPR_MAX_MODELS * 80, 0.0);
     std::fill(loglik, loglik + NPR_MAX_MODELS, 0.0);
@@ -1657,7 +1676,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     for (auto &l : launches) {
         any_tile |= l.tile;
         // the forward scratch of this batch was sized for the DP launches' grid: stay inside it
-        if (!l.tile) l.grid = static_cast<int>(std::min<int64_t>(l.grid, std::max<int64_t>(1, static_cast<int64_t>(ctx->arena_cells) / std::max<int64_t>(b->slot_stride, 1))));
+        if (!l.tile) l.grid = static_cast<int>(std::min<int64_t>(l.grid, std::max<int64_t>(1, static_cast<int64_t>(ctx->arena->cells) / std::max<int64_t>(b->slot_stride, 1))));
         max_grid = std::max<int64_t>(max_grid, l.grid);
         if (l.global_ring) ring_floats = std::max(ring_floats, static_cast<size_t>(l.grid) * 18 * l.wcap);
     }
@@ -1802,9 +1821,12 @@ int32_t npr_batch_align_stats(npr_batch *b, int32_t *stats) {
                 segs[seg_off[i] + s] = StatsSeg{t.xs, t.xs + t.lX, t.ys, t.ys + t.lY, t.x_off, t.y_off};
             }
         int32_t rc;
-        if (b->dev_ops && b->dev_ops_epoch == ctx->scratch_epoch) {
+        std::unique_lock<std::mutex> arena_lock(ctx->arena->mu);  // the resident cigars lie in the arena
+        if (b->dev_ops && b->dev_ops_epoch == ctx->arena->epoch) {
             rc = run_align_stats(ctx, n, b->dev_ops, b->dev_od, nullptr, nullptr, seg_off, segs, b->d_seq.p, stats);
+            arena_lock.unlock();
         } else {
+            arena_lock.unlock();
             ensure_packed_form(b);
             std::vector<uint32_t> packed(b->packed.get(), b->packed.get() + b->ops_off[n]);
             rc = run_align_stats(ctx, n, nullptr, nullptr, &packed, &b->ops_off, seg_off, segs, b->d_seq.p, stats);
@@ -2030,6 +2052,8 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
         const int32_t rc = ensure_coff(b);  // the dense dump runs the generic kernel
         if (rc != NPR_OK) return rc;
     }
+    std::lock_guard<std::mutex> arena_lock(ctx->arena->mu);  // the dump runs the read in region 0 of the arena
+    ++ctx->arena->epoch;
     int64_t written = 0;
     DevBuf<float> d_Bv;
     DevBuf<int32_t> d_Be;
@@ -2069,8 +2093,8 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
         std::vector<float> fv(t.cells_pad), bv(t.cells_pad);
         std::vector<int32_t> fe(t.cells_pad), be(t.cells_pad);
         // slot 0 of the generic layout: mantissa plane, then exponent plane
-        HIP_TRY(ctx, hipMemcpy(fv.data(), ctx->arena_F, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(fe.data(), ctx->arena_F + sizeof(float) * b->slot_stride, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fv.data(), ctx->arena->F, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fe.data(), ctx->arena->F + sizeof(float) * b->slot_stride, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(bv.data(), d_Bv.p, sizeof(float) * t.cells_pad, hipMemcpyDeviceToHost));
         HIP_TRY(ctx, hipMemcpy(be.data(), d_Be.p, sizeof(int32_t) * t.cells_pad, hipMemcpyDeviceToHost));
         for (int32_t d = 0; d <= t.D; ++d)

@@ -1,30 +1,193 @@
-"""The whole realignment job on one read set, sharded over the ranks of a node.
+"""The whole realignment job on one read set: files (or resident arrays) in, realigned SAM out, sharded over the ranks of a
+node and pipelined on every rank.
 
 The reference's job is: one jobTree job per record of ONE SAM file (nanopore/analyses/utils.py:565-570), the temp cigar
-files gathered in input order and spliced into a copy of the input SAM (utils.py:591-609).  Here: every rank takes a
-contiguous range of the reads (`dist.shard_ranges`: balanced by read length), stages / realigns / closes it on its GPU
-and writes the SAM records of its range at its own offset of the output file -- no data-path collective in either
-direction --; one small gather (RCCL under backend nccl) brings the per-read scalars to rank 0 for the summary XML.  Used
-by `bench.py --workload c3` (strong scaling, BASELINE.json configs[3]) and by the two-rank GPU test.
+files gathered in input order and spliced into a copy of the input SAM (utils.py:591-609).  Here:
+
+* every rank takes a CONTIGUOUS range of the records, balanced by record length (`dist.shard_ranges`), so the output needs no
+  data-path collective: a rank writes the records of its range at its own offset of the one output file (an all_gather of
+  the block sizes gives the offsets); one small gather (RCCL under backend nccl) brings the per-read results to rank 0 for
+  the summary;
+* a rank cuts its range into chunks of about `CHUNK_BASES` read bases and keeps TWO in flight: two worker threads, each
+  with its own realigner context (stream, scratch arena) on the rank's GPU, take the chunks alternately -- stage (plan +
+  H2D + device planner), DP, finish (MEA chain + cigar on the device), splice / format of the chunk's SAM records -- so the
+  host phases of one chunk run under the DP sweep of the other (ctypes releases the GIL inside the C ABI); the main
+  thread writes the finished blocks in order while the workers go on.
+
+`realign_sam_file` is what `analyses.utils.realignSamFile` (the plugin surface: AbstractMapper.realignSamFile,
+realignSamFileTargetFn) runs; `run_job` is the same pipeline over resident synthetic arrays (`bench.py --workload c3`).
 """
 import os
+import queue
+import threading
 import time
 import xml.etree.ElementTree as ET
 
 import numpy as np
 
+from . import _lib
 from . import dist as npd
-from . import synth
+
+CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", 100_000_000))  # ~12 k reads of 8 kb: two per resident wavefront
+WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 2))
 
 
-def realign_shard(ctx, params, w, lo, hi, model_slot=None):
-    """Stage + run + finish for the reads lo .. hi of workload `w`.  Returns (results, ops_off, packed cigar words, timings)."""
-    n = len(w["read_off"]) - 1
-    sub = w if (lo == 0 and hi == n) else synth.take_reads(w, np.arange(lo, hi))
+# ---------------------------------------------------------------------------------------------------------
+# record sources: what a set of reads looks like to the pipeline
+# ---------------------------------------------------------------------------------------------------------
+
+class ArraySource(object):
+    """Reads, guides and references as flat arrays (the C ABI's batch arguments), plus a formatter for the output records
+    of a range.  read i = text[read_begin[i] : read_end[i]]."""
+
+    def __init__(self, ref, ref_off, text, read_begin, read_end, guide_ops, guide_off, ref_index=None, guide_start=None,
+                 model_slot=None):
+        self.ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        self.ref_off = np.ascontiguousarray(ref_off, dtype=np.int64)
+        self.text = text
+        self.read_begin = np.ascontiguousarray(read_begin, dtype=np.int64)
+        self.read_end = np.ascontiguousarray(read_end, dtype=np.int64)
+        self.guide_ops = np.ascontiguousarray(guide_ops, dtype=np.int32).reshape(-1, 2)
+        self.guide_off = np.ascontiguousarray(guide_off, dtype=np.int64)
+        self.ref_index = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
+        self.guide_start = None if guide_start is None else np.ascontiguousarray(guide_start, dtype=np.int64).reshape(-1, 2)
+        self.model_slot = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
+        self.n = len(self.read_begin)
+        if self.ref_index is None and len(self.ref_off) - 1 != self.n:
+            raise ValueError("without ref_index there must be one reference slice per read")
+
+    def lengths(self):
+        return self.read_end - self.read_begin
+
+    def stage(self, ctx, params, lo, hi):
+        sl = slice(lo, hi)
+        if self.ref_index is None:  # per-read slices: the range's own part of the reference table
+            ref, ref_off, ri = self.ref, self.ref_off[lo:hi + 1], None
+        else:
+            ref, ref_off, ri = self.ref, self.ref_off, self.ref_index[sl]
+        return ctx.stage_spans(params, ref, ref_off, self.text, self.read_begin[sl], self.read_end[sl], self.guide_ops,
+                               self.guide_off[lo:hi + 1], model_slot=None if self.model_slot is None else self.model_slot[sl],
+                               ref_index=ri, guide_start=None if self.guide_start is None else self.guide_start[sl])
+
+    def format_block(self, lo, hi, ops_off, words):
+        raise NotImplementedError
+
+
+class SynthSource(ArraySource):
+    """A synthetic workload dict (nanopore_amd.synth): records are made up from the arrays (QNAME read_<i>, POS = where the
+    guide's window starts), formatted natively (npr_format_sam_records)."""
+
+    def __init__(self, w, model_slot=None, ref_names=None):
+        ro = np.asarray(w["read_off"], dtype=np.int64)
+        ArraySource.__init__(self, w["ref"], w["ref_off"], np.ascontiguousarray(w["read"], dtype=np.uint8), ro[:-1], ro[1:], w["guide_ops"],
+                             w["guide_off"], ref_index=w.get("ref_index"), guide_start=w.get("guide_start"), model_slot=model_slot)
+        n_refs = len(self.ref_off) - 1
+        self.ref_names = ref_names or ["ref_%d" % k for k in range(n_refs)]
+        head = [b"@HD\tVN:1.0\tSO:unsorted\n"]
+        for k in range(n_refs):
+            head.append(("@SQ\tSN:%s\tLN:%d\n" % (self.ref_names[k], int(self.ref_off[k + 1] - self.ref_off[k]))).encode())
+        self.header = b"".join(head)
+
+    def format_block(self, lo, hi, ops_off, words):
+        from . import realign
+        n = hi - lo
+        nops = np.asarray(ops_off[1:]) - np.asarray(ops_off[:-1])
+        ref_index = self.ref_index[lo:hi] if self.ref_index is not None else np.arange(lo, hi, dtype=np.int32)
+        pos = (self.guide_start[lo:hi, 0] if self.guide_start is not None else np.zeros(n, dtype=np.int64)) + 1
+        qnames = [b"read_%d" % i for i in range(lo, hi)]
+        a = int(self.read_begin[lo]) if n else 0
+        b = int(self.read_end[hi - 1]) if n else 0
+        seq_off = np.concatenate([self.read_begin[lo:hi] - a, [b - a]]).astype(np.int64)
+        buf, _ = realign.format_sam_records(qnames, [s.encode() for s in self.ref_names], ref_index, pos, ops_off[:-1], nops, words,
+                                            self.text[a:b], seq_off)
+        return buf
+
+
+class SamSource(ArraySource):
+    """The records of a mapped SAM text (nanopore_amd.ingest.SamText) against a FASTA table: the realigner sees aR.query
+    (the aligned part of SEQ, utils.py:570) where it lies in the file's bytes, the guide = the record's M / I / D operations
+    starting at (aR.pos, 0) (the exonerate line's coordinates, utils.py:173-177); an output record is the input record with
+    its CIGAR field replaced (utils.py:597-605)."""
+
+    def __init__(self, sam, fasta, span, fields, model_slot=None):
+        from . import ingest as ing
+        self.sam = sam
+        self.span = np.ascontiguousarray(span, dtype=np.int64)
+        self.fields = np.ascontiguousarray(fields, dtype=np.int64)
+        guide_off, guide_ops = sam.guides(self.fields)
+        tid_to_ref = np.array([fasta.index.get(name, -1) for name in sam.references] + [-1], dtype=np.int32)
+        ref_index = tid_to_ref[self.fields[:, ing.F_TID]]
+        if len(ref_index) and (ref_index < 0).any():
+            k = int(np.nonzero(ref_index < 0)[0][0])
+            raise KeyError(sam.references[int(self.fields[k, ing.F_TID])])  # refSequences[sam.getrname(aR.rname)] (utils.py:570)
+        gs = np.zeros((len(self.fields), 2), dtype=np.int64)
+        gs[:, 0] = self.fields[:, ing.F_POS]
+        ArraySource.__init__(self, fasta.seq, fasta.off, sam.text, self.fields[:, ing.F_QUERY_LO], self.fields[:, ing.F_QUERY_HI], guide_ops,
+                             guide_off, ref_index=ref_index, guide_start=gs, model_slot=model_slot)
+        self.header = sam.header
+
+    def format_block(self, lo, hi, ops_off, words):
+        nops = np.asarray(ops_off[1:]) - np.asarray(ops_off[:-1])
+        return self.sam.splice(self.span[lo:hi], self.fields[lo:hi], ops_off[:-1], nops, words)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the per-rank pipeline
+# ---------------------------------------------------------------------------------------------------------
+
+_ctx_pool = {}
+
+
+def contexts(device, count):
+    """`count` realigner contexts on one GPU, kept for the life of the process (a context owns a stream and a scratch arena
+    whose allocation costs more than a small job)."""
+    from . import realign
+    pool = _ctx_pool.setdefault(device, [])
+    pool[:] = [c for c in pool if getattr(c, "_h", None)]  # (a caller may have closed one it lent)
+    while len(pool) < count:
+        pool.append(realign.Context(device))
+    return pool[:count]
+
+
+def close_contexts():
+    for pool in _ctx_pool.values():
+        for c in pool:
+            c.close()
+    _ctx_pool.clear()
+
+
+def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
+    """[lo, hi) cut into chunks of about chunk_bases read bases (equal shares of the bases), at least `workers` of them when
+    the range can keep as many batches busy (a chunk below ~4 k reads leaves most wavefront slots of a DP launch idle)."""
+    chunk_bases = chunk_bases or CHUNK_BASES
+    workers = workers or WORKERS
+    n = hi - lo
+    if n <= 0:
+        return []
+    total = float(np.sum(lengths[lo:hi]))
+    k = max(1, int(round(total / chunk_bases)))
+    if k < workers and n >= 4096 * workers:
+        k = workers
+    k = min(k, n)
+    cuts = lo + npd.shard_ranges(lengths[lo:hi], k)
+    return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+def _realign_range(ctx, src, params, lo, hi, want_stats, tm):
+    """stage + run + finish of records lo .. hi on one context.  A range the device cannot hold (NPR_ERR_NOMEM: the
+    reference's per-read jobs have no such limit) is halved and retried.  -> (results, ops_off, words, stats or None)"""
+    from . import realign
     t0 = time.perf_counter()
-    b = ctx.stage_csr(params, sub["ref"], sub["ref_off"], sub["read"], sub["read_off"], sub["guide_ops"], sub["guide_off"],
-                      model_slot=None if model_slot is None else np.ascontiguousarray(np.asarray(model_slot)[lo:hi], dtype=np.int32),
-                      ref_index=sub.get("ref_index"), guide_start=sub.get("guide_start"))
+    try:
+        b = src.stage(ctx, params, lo, hi)
+    except realign.NprError as e:
+        if e.code != realign.ERR_NOMEM or hi - lo < 2:
+            raise
+        mid = (lo + hi) // 2
+        r1, o1, w1, s1 = _realign_range(ctx, src, params, lo, mid, want_stats, tm)
+        r2, o2, w2, s2 = _realign_range(ctx, src, params, mid, hi, want_stats, tm)
+        return (np.concatenate([r1, r2]), np.concatenate([o1, o1[-1] + o2[1:]]), np.concatenate([w1, w2]),
+                None if s1 is None else np.concatenate([s1, s2]))
     t1 = time.perf_counter()
     try:
         kms = b.run()
@@ -33,38 +196,104 @@ def realign_shard(ctx, params, w, lo, hi, model_slot=None):
         t3 = time.perf_counter()
         res = b.results()
         off, words = b.ops_packed()
+        stats = b.align_stats() if want_stats else None
+        st = b.stats()
     finally:
         b.close()
-    return res, off, words, dict(stage_s=t1 - t0, run_s=t2 - t1, finish_s=t3 - t2, kernel_ms=kms)
+    t4 = time.perf_counter()
+    tm["stage_s"] += t1 - t0
+    tm["run_s"] += t2 - t1
+    tm["finish_s"] += t3 - t2
+    tm["fetch_s"] += t4 - t3
+    tm["kernel_ms"] += kms
+    tm["cells"] += int(st["cells"])
+    return res, off, words, stats
 
 
-def sam_header(w, ref_names=None):
-    n_refs = len(w["ref_off"]) - 1
-    if ref_names is None:
-        ref_names = ["ref_%d" % k for k in range(n_refs)]
-    head = [b"@HD\tVN:1.0\tSO:unsorted\n"]
-    for k in range(n_refs):
-        head.append(("@SQ\tSN:%s\tLN:%d\n" % (ref_names[k], int(w["ref_off"][k + 1] - w["ref_off"][k]))).encode())
-    return b"".join(head), ref_names
+def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=None):
+    """Records lo .. hi of `src` through the contexts `ctxs` (one worker thread each), chunks handed to `sink(block)` in
+    record order as they complete.  Returns (results[hi - lo], n_ops[hi - lo], stats or None, timings)."""
+    chunks = chunk_bounds(src.lengths(), lo, hi, chunk_bases, len(ctxs))
+    tms = [dict(stage_s=0.0, run_s=0.0, finish_s=0.0, fetch_s=0.0, format_s=0.0, kernel_ms=0.0, cells=0) for _ in ctxs]
+    done = queue.Queue()
+    stop = threading.Event()
 
+    def worker(j):
+        try:
+            for k in range(j, len(chunks), len(ctxs)):
+                if stop.is_set():
+                    return
+                a, b = chunks[k]
+                res, off, words, stats = _realign_range(ctxs[j], src, params, a, b, want_stats, tms[j])
+                t0 = time.perf_counter()
+                block = src.format_block(a, b, off, words)
+                tms[j]["format_s"] += time.perf_counter() - t0
+                done.put((k, block, res, off[1:] - off[:-1], stats))
+        except BaseException as e:  # handed to the caller's thread
+            done.put((-1, e, None, None, None))
 
-def sam_block(w, lo, hi, ops_off, words, ref_names):
-    """The SAM records of reads lo .. hi as one bytes-like object: CIGAR = the realigner's ops (what realignSamFile3TargetFn
-    splices in, utils.py:597-605), POS = where the guide's window starts on the reference.  The cigars come packed from the
-    device and the records are formatted natively (npr_format_sam_records): at 50 k records per rank a Python loop over
-    the records took longer than the DP."""
-    from . import realign
+    threads = [threading.Thread(target=worker, args=(j,), daemon=True) for j in range(min(len(ctxs), max(len(chunks), 1)))]
+    for t in threads:
+        t.start()
+    ready, parts, nxt, sink_s = {}, [], 0, 0.0
+    try:
+        while nxt < len(chunks):
+            k, block, res, nops, stats = done.get()
+            if k < 0:
+                raise block
+            ready[k] = (block, res, nops, stats)
+            while nxt in ready:
+                block, res, nops, stats = ready.pop(nxt)
+                t0 = time.perf_counter()
+                sink(block)
+                sink_s += time.perf_counter() - t0
+                parts.append((res, nops, stats))
+                nxt += 1
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
     n = hi - lo
-    nops = np.asarray(ops_off[1:]) - np.asarray(ops_off[:-1])
-    ro = np.asarray(w["read_off"], dtype=np.int64)
-    ri = w.get("ref_index")
-    gs = w.get("guide_start")
-    ref_index = np.asarray(ri[lo:hi], dtype=np.int32) if ri is not None else np.arange(lo, hi, dtype=np.int32)
-    pos = (np.asarray(gs, dtype=np.int64)[lo:hi, 0] if gs is not None else np.zeros(n, dtype=np.int64)) + 1
-    qnames = [b"read_%d" % i for i in range(lo, hi)]
-    buf, _ = realign.format_sam_records(qnames, [s.encode() for s in ref_names], ref_index, pos, ops_off[:-1], nops, words,
-                                        w["read"][ro[lo]:ro[hi]], ro[lo:hi + 1] - ro[lo])
-    return memoryview(buf)
+    results = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, dtype=_lib.RESULT_DTYPE)
+    n_ops = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, dtype=np.int64)
+    stats = np.concatenate([p[2] for p in parts]) if (parts and want_stats) else (np.zeros((0, _lib.STATS_WORDS), dtype=np.int32) if want_stats else None)
+    assert len(results) == n
+    tm = {key: sum(t[key] for t in tms) for key in tms[0]}
+    tm["sink_s"] = sink_s
+    tm["chunks"] = len(chunks)
+    tm["workers"] = len(threads)
+    return results, n_ops, stats, tm
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the job: shard, pipeline, write, gather
+# ---------------------------------------------------------------------------------------------------------
+
+def _dist_state(group):
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized()
+    if not multi:
+        return None, 1, 0
+    return dist, dist.get_world_size(group), dist.get_rank(group)
+
+
+def _collective_device(dist, group, gpu):
+    """Where the tensors of the job's two small collectives live: on the rank's GPU under nccl (= RCCL), on the host else."""
+    import torch
+    if dist is not None and str(dist.get_backend(group)) == "nccl":
+        return torch.device("cuda", gpu)
+    return torch.device("cpu")
+
+
+def default_gpu():
+    """The GPU of this rank: LOCAL_RANK when torch.distributed runs one process per GPU, else device 0."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() > 1:
+        try:
+            return int(os.environ.get("LOCAL_RANK", torch.cuda.current_device()))
+        except ValueError:
+            return torch.cuda.current_device()
+    return 0
 
 
 def write_summary_xml(path, status, score, nops, cells=None):
@@ -81,70 +310,164 @@ def write_summary_xml(path, status, score, nops, cells=None):
     ET.ElementTree(root).write(path)
 
 
-def run_job(ctx, params, w, out_dir=None, work=None, model_slot=None, device=None, group=None):
-    """The whole job on this rank (collective: every rank of the process group calls it; without torch.distributed
-    initialised it is the one-GPU job).
+def run_source(src, params, bounds, out_path, ctxs=None, gpu=None, group=None, want_stats=False, chunk_bases=None, workers=None,
+               coll_device=None):
+    """The job on this rank (collective: every rank of the process group calls it; without torch.distributed initialised it
+    is the one-GPU job).  `src` holds this rank's view of the records, `bounds[r] .. bounds[r + 1]` the range of rank r in
+    `src`'s numbering.  Output: `out_path` = src.header + every rank's block in rank order.
 
-    Reads shard into CONTIGUOUS ranges balanced by work (dist.shard_ranges), so the output needs no data-path collective
-    either: every rank formats the SAM records of its own range and writes them at its own offset of the one output file
-    (an all_gather of the block sizes gives the offsets; the reference's single writer, utils.py:591-609, would serialise
-    half a gigabyte of text behind eight GPUs).  Only the per-read scalars -- status, score, number of cigar operations --
-    are gathered to rank 0, for the summary XML.  Returns on rank 0 a dict with those scalars in input order, the output
-    paths and this rank's stage timings; on other ranks the timings only."""
+    One rank: blocks are written as they complete, under the DP of the chunks behind them.  Several ranks: a rank's offset
+    is known once the ranks before it know their sizes, so rank 0 writes as it goes and the others keep their blocks (a
+    rank's share of the text: tens of MB) and write them after the all_gather of the sizes.  Only the per-read results are
+    gathered to rank 0 (RCCL over xGMI under backend nccl).  Returns a dict: on rank 0 `results` (structured array in input order),
+    `n_ops`, `stats` (if asked for), `timings`; on the others `timings` only."""
     import torch
-    import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized()
-    world = dist.get_world_size(group) if multi else 1
-    rank = dist.get_rank(group) if multi else 0
-    dev = torch.device("cpu") if device is None else torch.device(device)
-    n = len(w["read_off"]) - 1
-    if work is None:
-        work = np.asarray(w["read_off"][1:]) - np.asarray(w["read_off"][:-1])
-    bounds = npd.shard_ranges(work, world)
+    dist, world, rank = _dist_state(group)
+    gpu = default_gpu() if gpu is None else gpu
+    dev = torch.device(coll_device) if coll_device is not None else _collective_device(dist, group, gpu)
+    ctxs = ctxs or contexts(gpu, workers or WORKERS)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    res, off, words, tm = realign_shard(ctx, params, w, lo, hi, model_slot)
-    tm["cells"] = int(res["cells"].sum())
-    out = dict(timings=tm)
-    if out_dir is not None:
+    header = src.header
+    t_begin = time.perf_counter()
+    fd = None
+    kept = []
+    state = dict(off=len(header))
+    if out_path is not None and rank == 0:
+        fd = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.pwrite(fd, header, 0)
+
+    def sink(block):
+        if out_path is None:
+            return
+        if rank == 0:
+            os.pwrite(fd, memoryview(block), state["off"])
+            state["off"] += len(block)
+        else:
+            kept.append(block)
+
+    try:
+        results, n_ops, stats, tm = run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=want_stats, chunk_bases=chunk_bases)
         t0 = time.perf_counter()
-        sam_path = os.path.join(out_dir, "realigned.sam")
-        header, ref_names = sam_header(w)
-        block = sam_block(w, lo, hi, off, words, ref_names)
-        tm["format_s"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        sizes = [len(block)]
-        if multi:
-            t = torch.tensor([len(block)], dtype=torch.int64, device=dev)
+        if out_path is not None and dist is not None:
+            mine = state["off"] - len(header) if rank == 0 else sum(len(b) for b in kept)
+            t = torch.tensor([mine], dtype=torch.int64, device=dev)
             got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(got, t, group=group)
             sizes = [int(g.item()) for g in got]
-        if rank == 0:
-            os.makedirs(out_dir, exist_ok=True)
-            with open(sam_path, "wb") as fh:
-                fh.write(header)
-                fh.truncate(len(header) + sum(sizes))
-        if multi:
-            dist.barrier(group=group)
-        fd = os.open(sam_path, os.O_WRONLY)
-        try:
-            os.pwrite(fd, block, len(header) + sum(sizes[:rank]))
-        finally:
+            if rank != 0:
+                fd = os.open(out_path, os.O_WRONLY)  # rank 0 created it before its first chunk; this is after everyone's last
+                at = len(header) + sum(sizes[:rank])
+                for b in kept:
+                    os.pwrite(fd, memoryview(b), at)
+                    at += len(b)
+        tm["write_tail_s"] = time.perf_counter() - t0
+    finally:
+        if fd is not None:
             os.close(fd)
-        tm["write_s"] = time.perf_counter() - t0
-        out["sam"] = sam_path
-    # the one gather: per-read scalars for the summary
+    out = dict(timings=tm)
+    # the one gather: per-read results for the summary
     t0 = time.perf_counter()
-    mine = np.stack([res["status"].astype(np.float64), res["score"].astype(np.float64), (off[1:] - off[:-1]).astype(np.float64)], axis=1)
-    if multi:
-        got = npd.gather_to_root(mine.reshape(-1).view(np.uint8), device=device, group=group)
+    if dist is not None:
+        payload = [results.view(np.uint8).reshape(-1), n_ops.astype(np.int64).view(np.uint8)]
+        if want_stats:
+            payload.append(np.ascontiguousarray(stats).view(np.uint8).reshape(-1))
+        head = np.array([len(results)], dtype=np.int64).view(np.uint8)
+        got = npd.gather_to_root(np.concatenate([head] + payload), device=dev, group=group)
         if rank == 0:
-            mine = np.concatenate([g.view(np.float64).reshape(-1, 3) for g in got])
+            rs, ns, ss = [], [], []
+            for g in got:
+                k = int(g[:8].view(np.int64)[0])
+                a = 8
+                rs.append(g[a:a + k * _lib.RESULT_DTYPE.itemsize].view(_lib.RESULT_DTYPE))
+                a += k * _lib.RESULT_DTYPE.itemsize
+                ns.append(g[a:a + 8 * k].view(np.int64))
+                a += 8 * k
+                if want_stats:
+                    ss.append(g[a:a + 4 * _lib.STATS_WORDS * k].view(np.int32).reshape(k, _lib.STATS_WORDS))
+            results, n_ops = np.concatenate(rs), np.concatenate(ns)
+            stats = np.concatenate(ss) if want_stats else None
         dist.barrier(group=group)  # every rank's block is on disk when rank 0 returns
     tm["gather_s"] = time.perf_counter() - t0
+    tm["wall_s"] = time.perf_counter() - t_begin
+    if rank == 0:
+        out.update(results=results, n_ops=n_ops, stats=stats, sam=out_path)
+    return out
+
+
+def realign_sam_file(samFile, outputSamFile, referenceFastaFile, hmm=None, gapGamma=0.5, matchGamma=0.0, params=None, group=None,
+                     gpu=None, want_stats=False, model_slot=0, chunk_bases=None, workers=None, coll_device=None, set_models=True):
+    """Files -> file: every record of `samFile` that has a reference realigned against `referenceFastaFile`, written to
+    `outputSamFile` with only its CIGAR replaced, same order, header copied (realignSamFile2TargetFn + realignCigarTargetFn +
+    realignSamFile3TargetFn, utils.py:557-609).  Under an initialised torch.distributed process group the records shard over
+    the ranks (collective call).  `hmm`: a nanopore_amd.hmm.Hmm, a model file path, or None for the stock model;
+    `params`: npr_params overriding the reference's call parameters (anchors +- 10, trim 14, split 3000) -- the bench's
+    fixed-band configs.  Returns run_source's dict, plus `records` = the number of records kept (rank 0)."""
+    from . import ingest, realign
+    from .hmm import Hmm
+    dist, world, rank = _dist_state(group)
+    gpu = default_gpu() if gpu is None else gpu
+    t0 = time.perf_counter()
+    sam = ingest.SamText(samFile)
+    fasta = ingest.FastaTable(referenceFastaFile)
+    t1 = time.perf_counter()
+    bounds = npd.shard_ranges(sam.line_lengths(), world)  # a record's length in the file ~ its read's length
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    fields = sam.parse(lo, hi)
+    span = sam.span[lo:hi]
+    keep = fields[:, ingest.F_TID] >= 0  # samIterator: records without a reference are not realigned and not written (utils.py:287-293)
+    if not keep.all():
+        fields, span = fields[keep], span[keep]
+    bad = np.nonzero(fields[:, ingest.F_STATUS] != 0)[0]
+    if len(bad):
+        k = int(bad[0])
+        raise AssertionError("SAM record %r: malformed, or a cigar operation outside M I D S H (utils.py:171)"
+                             % sam.field_bytes(int(span[k, 0]), int(fields[k, ingest.F_QNAME_END])).decode(errors="replace"))
+    src = SamSource(sam, fasta, span, fields, model_slot=None if not model_slot else np.full(len(fields), model_slot, dtype=np.int32))
+    t2 = time.perf_counter()
+    ctxs = contexts(gpu, workers or WORKERS)
+    if set_models:
+        model = Hmm.loadHmm(hmm) if isinstance(hmm, str) else hmm
+        for c in ctxs:
+            c.set_hmm(model, slot=model_slot)
+    if params is None:
+        params = realign.make_params(band_mode=realign.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000,
+                                     gap_gamma=gapGamma, match_gamma=matchGamma, mode=realign.MODE_REALIGN)
+    local = np.array([0] * (rank + 1) + [len(fields)] * (world - rank), dtype=np.int64)  # src holds this rank's records only
+    out = run_source(src, params, local, outputSamFile, ctxs=ctxs, gpu=gpu, group=group, want_stats=want_stats, chunk_bases=chunk_bases,
+                     coll_device=coll_device)
+    out["timings"].update(index_s=t1 - t0, parse_s=t2 - t1)
+    out["timings"]["wall_s"] += t2 - t0
+    if rank == 0:
+        out["records"] = len(out["results"])
+    return out
+
+
+def run_job(ctx, params, w, out_dir=None, work=None, model_slot=None, device=None, group=None, chunk_bases=None, workers=None):
+    """The job over a resident synthetic workload dict (nanopore_amd.synth): `bench.py --workload c3` and the two-rank test.
+    `ctx` is the first of the rank's contexts (more are made on its GPU as the pipeline needs them).  Returns on rank 0 a dict
+    with status / score / n_ops in input order, the output paths and the rank's timings; on other ranks the timings only."""
+    dist, world, rank = _dist_state(group)
+    src = SynthSource(w, model_slot=model_slot)
+    if work is None:
+        work = src.lengths()
+    bounds = npd.shard_ranges(work, world)
+    workers = workers or WORKERS
+    ctxs = [ctx] + [c for c in contexts(ctx.device, workers) if c is not ctx][:workers - 1]
+    for c in ctxs[1:]:  # the extra contexts run the same models
+        c.copy_models_from(ctx)
+    sam_path = None
+    if out_dir is not None:
+        if rank == 0:
+            os.makedirs(out_dir, exist_ok=True)
+        if dist is not None:
+            dist.barrier(group=group)
+        sam_path = os.path.join(out_dir, "realigned.sam")
+    out = run_source(src, params, bounds, sam_path, ctxs=ctxs, gpu=ctx.device, group=group, chunk_bases=chunk_bases, coll_device=device)
     if rank != 0:
-        return dict(timings=tm)
-    out["status"], out["score"], out["n_ops"] = mine[:, 0].astype(np.int64), mine[:, 1], mine[:, 2].astype(np.int64)
+        return out
+    res = out["results"]
+    out["status"], out["score"] = res["status"].astype(np.int64), res["score"].astype(np.float64)
     if out_dir is not None:
         out["xml"] = os.path.join(out_dir, "summary.xml")
-        write_summary_xml(out["xml"], out["status"], out["score"], out["n_ops"])
+        write_summary_xml(out["xml"], out["status"], out["score"], out["n_ops"], cells=int(res["cells"].sum()))
     return out

@@ -50,16 +50,22 @@ class Batch(object):
     """A staged batch: inputs resident in HBM after construction."""
 
     def __init__(self, ctx, params, ref, ref_off, read, read_off, guide_ops, guide_off, model_slot=None,
-                 ref_index=None, guide_start=None):
+                 ref_index=None, guide_start=None, read_end=None):
         self._L = _lib.load()
         self.ctx = ctx
-        self.n_reads = len(read_off) - 1
         n_refs = len(ref_off) - 1
-        self._keep = (ref, ref_off, read, read_off, guide_ops, guide_off, model_slot, ref_index, guide_start)
+        self._keep = (ref, ref_off, read, read_off, guide_ops, guide_off, model_slot, ref_index, guide_start, read_end)
         h = C.c_void_p()
-        rc = self._L.npr_batch_create_at(ctx._h, C.byref(params), self.n_reads, n_refs, ptr(ref), ptr(ref_off),
-                                         ptr(ref_index), ptr(read), ptr(read_off), ptr(guide_ops), ptr(guide_off),
-                                         ptr(guide_start), ptr(model_slot), C.byref(h))
+        if read_end is not None:  # reads scattered in `read` (the SEQ fields of a mapped SAM text): read_off = their starts
+            self.n_reads = len(read_off)
+            rc = self._L.npr_batch_create_spans(ctx._h, C.byref(params), self.n_reads, n_refs, ptr(ref), ptr(ref_off),
+                                                ptr(ref_index), ptr(read), ptr(read_off), ptr(read_end), ptr(guide_ops), ptr(guide_off),
+                                                ptr(guide_start), ptr(model_slot), C.byref(h))
+        else:
+            self.n_reads = len(read_off) - 1
+            rc = self._L.npr_batch_create_at(ctx._h, C.byref(params), self.n_reads, n_refs, ptr(ref), ptr(ref_off),
+                                             ptr(ref_index), ptr(read), ptr(read_off), ptr(guide_ops), ptr(guide_off),
+                                             ptr(guide_start), ptr(model_slot), C.byref(h))
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_create", ctx.last_error())
         self._h = h
@@ -212,6 +218,18 @@ class Context(object):
             raise NprError(rc, "npr_create", err.value.decode(errors="replace"))
         self._h = h
         self.device = device
+        self._models = {}  # slot -> (T, E) or None, as installed: what another context on the same GPU copies
+
+    def copy_models_from(self, other):
+        """Installs the models `other` holds (a second context of a pipelined job runs the same ones)."""
+        for slot, m in other._models.items():
+            self._set(slot, m)
+
+    def _set(self, slot, m):
+        rc = self._L.npr_set_hmm(self._h, slot, None, None) if m is None else self._L.npr_set_hmm(self._h, slot, ptr(m[0]), ptr(m[1]))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_set_hmm", self.last_error())
+        self._models[slot] = m
 
     def last_error(self):
         return self._L.npr_last_error(self._h).decode(errors="replace")
@@ -220,15 +238,12 @@ class Context(object):
         """hmm: object with .transitions (25) and .emissions (80) (nanopore_amd.hmm.Hmm), or None for
         the stock model used when the reference passes no --loadHmm."""
         if hmm is None:
-            rc = self._L.npr_set_hmm(self._h, slot, None, None)
-        else:
-            T = np.ascontiguousarray(hmm.transitions, dtype=np.float64)
-            E = np.ascontiguousarray(hmm.emissions, dtype=np.float64)
-            if T.size != 25 or E.size != 80:
-                raise ValueError("HMM must have 25 transitions and 80 emissions")
-            rc = self._L.npr_set_hmm(self._h, slot, ptr(T), ptr(E))
-        if rc != _lib.OK:
-            raise NprError(rc, "npr_set_hmm", self.last_error())
+            return self._set(slot, None)
+        T = np.ascontiguousarray(hmm.transitions, dtype=np.float64)
+        E = np.ascontiguousarray(hmm.emissions, dtype=np.float64)
+        if T.size != 25 or E.size != 80:
+            raise ValueError("HMM must have 25 transitions and 80 emissions")
+        self._set(slot, (T, E))
 
     def stage(self, params, refs, reads, guides, model_slot=None, ref_index=None, guide_start=None):
         """refs/reads: lists of ASCII sequences (str/bytes); guides: list of [(op,len),...].
@@ -255,6 +270,17 @@ class Context(object):
         ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
         gs = None if guide_start is None else np.ascontiguousarray(guide_start, dtype=np.int64).reshape(-1, 2)
         return Batch(self, params, ref, ref_off, read, read_off, guide_ops, guide_off, ms, ri, gs)
+
+    def stage_spans(self, params, ref, ref_off, text, read_begin, read_end, guide_ops, guide_off, model_slot=None,
+                    ref_index=None, guide_start=None):
+        """Stages reads that lie scattered in `text` (uint8): read i = text[read_begin[i] : read_end[i]]
+        (include/nprealign.h: npr_batch_create_spans).  guide_off may be a slice of a longer CSR: its values index guide_ops."""
+        ms = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
+        ri = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
+        gs = None if guide_start is None else np.ascontiguousarray(guide_start, dtype=np.int64).reshape(-1, 2)
+        return Batch(self, params, ref, np.ascontiguousarray(ref_off, dtype=np.int64), text,
+                     np.ascontiguousarray(read_begin, dtype=np.int64), np.ascontiguousarray(guide_ops, dtype=np.int32).reshape(-1, 2),
+                     np.ascontiguousarray(guide_off, dtype=np.int64), ms, ri, gs, read_end=np.ascontiguousarray(read_end, dtype=np.int64))
 
     def align_stats(self, refs, reads, cigars, ref_index=None, start=None):
         """Per-read reductions over the aligned pairs of arbitrary alignments (a mapper's SAM records) on the device

@@ -343,3 +343,55 @@ def config_c5(T, E, n_reads_per_type=10000):
     w = make_workload(1005, 3 * n_reads_per_type, 30000, T, E, flank=400, uniform_len=(10000, 50000))
     slot = np.repeat(np.arange(3, dtype=np.int32), n_reads_per_type)
     return w, 200, slot
+
+
+# ---- a workload as the files the pipeline's entry points take ----
+
+def write_fasta(path, names, ref, ref_off, width=100):
+    """FASTA with `width` bases per line (what fastaWrite emits), vectorised: a 4.6 Mb contig is one reshape."""
+    with open(path, "wb") as fh:
+        for k, name in enumerate(names):
+            seq = np.ascontiguousarray(ref[ref_off[k]:ref_off[k + 1]], dtype=np.uint8)
+            fh.write(b">" + name.encode() + b"\n")
+            full = len(seq) // width * width
+            if full:
+                body = np.empty((full // width, width + 1), dtype=np.uint8)
+                body[:, :width] = seq[:full].reshape(-1, width)
+                body[:, width] = 10
+                fh.write(body.tobytes())
+            if len(seq) > full:
+                fh.write(seq[full:].tobytes() + b"\n")
+
+
+def write_workload_files(w, sam_path, fasta_path, fastq_path=None, ref_names=None, read_names=None):
+    """A workload dict as SAM + FASTA (+ FASTQ): one record per read with FLAG 0, POS = where the guide starts on its
+    reference (1-based), CIGAR = the guide, SEQ = the read -- a mapper's (or chainSamFile's) output for these reads.  The
+    records are formatted natively (npr_format_sam_records).  Returns (ref_names, read_names)."""
+    from . import realign
+    n = len(w["read_off"]) - 1
+    n_refs = len(w["ref_off"]) - 1
+    ref_names = ref_names or ["ref_%d" % k for k in range(n_refs)]
+    read_names = read_names or ["read_%d" % i for i in range(n)]
+    write_fasta(fasta_path, ref_names, w["ref"], w["ref_off"])
+    g = np.asarray(w["guide_ops"], dtype=np.int64).reshape(-1, 2)
+    words = ((g[:, 1] << 2) | g[:, 0]).astype(np.uint32)
+    goff = np.asarray(w["guide_off"], dtype=np.int64)
+    ri = w.get("ref_index")
+    ref_index = np.asarray(ri, dtype=np.int32) if ri is not None else np.arange(n, dtype=np.int32)
+    gs = w.get("guide_start")
+    pos = (np.asarray(gs, dtype=np.int64)[:, 0] if gs is not None else np.zeros(n, dtype=np.int64)) + 1
+    buf, _ = realign.format_sam_records([s.encode() for s in read_names], [s.encode() for s in ref_names], ref_index, pos, goff[:-1],
+                                        goff[1:] - goff[:-1], words, np.ascontiguousarray(w["read"], dtype=np.uint8),
+                                        np.asarray(w["read_off"], dtype=np.int64))
+    with open(sam_path, "wb") as fh:
+        fh.write(b"@HD\tVN:1.0\tSO:unsorted\n")
+        for k in range(n_refs):
+            fh.write(("@SQ\tSN:%s\tLN:%d\n" % (ref_names[k], int(w["ref_off"][k + 1] - w["ref_off"][k]))).encode())
+        fh.write(memoryview(buf))
+    if fastq_path is not None:
+        ro = np.asarray(w["read_off"], dtype=np.int64)
+        with open(fastq_path, "wb") as fh:
+            for i in range(n):
+                s = np.ascontiguousarray(w["read"][ro[i]:ro[i + 1]], dtype=np.uint8).tobytes()
+                fh.write(b"@" + read_names[i].encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+    return ref_names, read_names

@@ -100,8 +100,34 @@ def lib(native=False):
         L.orc_realign_batch.restype = C.c_int32
         L.orc_realign_batch.argtypes = [C.POINTER(Hmm), C.POINTER(Params), C.c_int32, C.c_int64] + [
             C.c_void_p] * 13 + [C.c_int32]
+        L.orc_set_logadd_kind.argtypes = [C.c_int32]
+        L.orc_set_logadd_kind.restype = None
+        L.orc_get_logadd_kind.restype = C.c_int32
+        L.orc_logadd.restype = C.c_double
+        L.orc_logadd.argtypes = [C.c_double, C.c_double]
         _libs[native] = L
     return _libs[native]
+
+
+LOGADD_EXACT, LOGADD_APPROX = 0, 1
+
+
+class logadd_kind(object):
+    """with logadd_kind(LOGADD_APPROX): ... -- the fp64 passes use cPecan's piecewise-cubic log-add [RECALLED, SURVEY.md
+    Appendix A] inside the block (both builds of the library), the exact one again afterwards."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        for native in (False, True):
+            if native in _libs or not native:
+                lib(native).orc_set_logadd_kind(self.kind)
+        return self
+
+    def __exit__(self, *exc):
+        for L in _libs.values():
+            L.orc_set_logadd_kind(LOGADD_EXACT)
 
 
 def _p(a):

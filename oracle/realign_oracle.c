@@ -287,11 +287,37 @@ static void model64_init(model64 *m, const orc_hmm *h) {
     m->lEnd[1][4] = m->lT[4][4];
 }
 
+/* log(e^a + e^b).  Two kinds (orc_set_logadd_kind):
+ *   0  exact: max + log1p(exp(-|a - b|)) -- the normative arithmetic of this oracle;
+ *   1  cPecan's: max + lookup(|a - b|) with the probcons-style four-piece cubic fit of log(1 + e^-t)... written there as
+ *      min + lookup(max - min), lookup(t) ~ log(1 + e^t) on [0, 7.5], and just max beyond 7.5.  [RECALLED, SURVEY.md
+ *      Appendix A: cactus / cPecan are absent from the snapshot, so the coefficients below are from memory of the public
+ *      probcons source (ScoreType.h LOOKUP) that cPecan's pairwiseAligner.c copies; tests/test_oracle.py checks that they
+ *      do approximate log(1 + e^t) to ~1e-4, which is all that is claimed.]  Used only to MEASURE how far the reference's
+ *      own approximation could move a posterior or a cigar; never the checker of a parity test. */
+static int g_logadd_kind = 0;
+void orc_set_logadd_kind(int32_t kind) { g_logadd_kind = kind; }
+int32_t orc_get_logadd_kind(void) { return g_logadd_kind; }
+
+static inline double logadd_lookup(double t) { /* t = max - min in [0, 7.5] */
+    if (t <= 1.00) return ((-0.009350833524763 * t + 0.130659527668286) * t + 0.498799810682272) * t + 0.693203116424741;
+    if (t <= 2.50) return ((-0.014532321752540 * t + 0.139942324101744) * t + 0.495635523139337) * t + 0.692140569840976;
+    if (t <= 4.50) return ((-0.004605031767994 * t + 0.063427417320019) * t + 0.695956496475118) * t + 0.514272634594009;
+    return ((-0.000458661602210 * t + 0.009695946122598) * t + 0.930734667215156) * t + 0.168037164329057;
+}
+
+double orc_logadd(double a, double b); /* exported for the tests */
+
 static inline double logadd(double a, double b) {
     if (a == NEG_INF) return b;
     if (b == NEG_INF) return a;
+    if (g_logadd_kind == 1) {
+        const double lo = a < b ? a : b, hi = a < b ? b : a;
+        return hi - lo >= 7.5 ? hi : lo + logadd_lookup(hi - lo);
+    }
     return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
 }
+double orc_logadd(double a, double b) { return logadd(a, b); }
 
 /* Per-thread scratch that only grows: the forward array of a 10 kb x band-200 read is 160 MB, and a fresh
  * malloc/free of that per read turns the multi-threaded baseline into a page-fault benchmark. */

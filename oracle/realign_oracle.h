@@ -163,6 +163,12 @@ int32_t orc_realign_batch(const orc_hmm *h, const orc_params *p, int32_t precisi
                           int64_t *out_nops, double *out_score, double *out_ll, int64_t *out_cells,
                           int32_t *out_status, int32_t threads);
 
+/* log-add used by the fp64 passes: 0 exact (normative), 1 cPecan's piecewise-cubic approximation [RECALLED]: a global
+ * switch for measuring what the reference's own approximation could move; set it back to 0 afterwards. */
+void orc_set_logadd_kind(int32_t kind);
+int32_t orc_get_logadd_kind(void);
+double orc_logadd(double a, double b);
+
 int32_t orc_version(void);
 
 #ifdef __cplusplus

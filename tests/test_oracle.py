@@ -5,10 +5,12 @@ by (1) an independent unbanded probability-space numpy forward/backward written 
 (helpers.full_matrix_reference), (2) invariants the algorithm must satisfy, (3) the committed golden
 fixtures (test_golden.py).
 """
+import os
+
 import numpy as np
 import pytest
 
-from helpers import cigar_spans, full_matrix_reference, load_model_arrays, oracle_hmm, orc, random_pair
+from helpers import ROOT, cigar_spans, full_matrix_reference, load_model_arrays, oracle_hmm, orc, random_pair
 
 LN2 = np.log(2.0)
 
@@ -244,3 +246,74 @@ def test_expectations_match_independent_numpy():
     assert r["total_ll"] == pytest.approx(np.log(tot), abs=1e-10)
     # every path has one transition per alignment column
     assert max(len(X), len(Y)) <= r["T"].sum() <= len(X) + len(Y)
+
+
+def test_approximate_logadd_mode_is_a_measuring_stick_not_the_norm():
+    """cPecan adds log-probabilities with a piecewise-cubic lookup [RECALLED].  The
+    oracle offers it as a switch so that the distance "exact vs the reference's own approximation" can be put next to
+    "GPU vs exact" (tools/logadd_risk.py).  Here: the recalled coefficients do approximate
+    log(1 + e^t) (to 3e-4 on [0, 7.5], "max" beyond), the switch changes results by about that much and no more, and it
+    switches back."""
+    import math
+    L = orc.lib()
+    assert L.orc_get_logadd_kind() == orc.LOGADD_EXACT
+    rng = np.random.default_rng(12)
+    X, Y, g = random_pair(rng, 300)
+    h = oracle_hmm()
+    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=60)
+    exact = orc.realign_read(h, P, X, Y, g, precision=0)
+    with orc.logadd_kind(orc.LOGADD_APPROX):
+        assert L.orc_get_logadd_kind() == orc.LOGADD_APPROX
+        worst = max(abs(L.orc_logadd(0.0, -t) - math.log1p(math.exp(-t))) for t in np.linspace(0.0, 7.49, 3000))
+        assert 1e-5 < worst < 3e-4
+        assert L.orc_logadd(-3.0, -11.0) == -3.0 and L.orc_logadd(float("-inf"), -2.0) == -2.0
+        approx = orc.realign_read(h, P, X, Y, g, precision=0)
+    assert L.orc_get_logadd_kind() == orc.LOGADD_EXACT
+    assert orc.realign_read(h, P, X, Y, g, precision=0)["total_ll"] == exact["total_ll"]
+    assert approx["total_ll"] != exact["total_ll"] and abs(approx["total_ll"] - exact["total_ll"]) < 3e-4 * 600
+    de = {(int(a), int(b)): float(c) for a, b, c in zip(exact["px"], exact["py"], exact["pp"])}
+    da = {(int(a), int(b)): float(c) for a, b, c in zip(approx["px"], approx["py"], approx["pp"])}
+    diff = max(abs(de.get(k, 0.01) - da.get(k, 0.01)) for k in set(de) | set(da))
+    assert 1e-6 < diff < 0.2   # two orders of magnitude more than fp32-vs-fp64 (1e-6, test_fp32_mirror_*), far from garbage
+
+
+def test_oracle_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """the oracle is the project's C code that every parity claim rests on; its own tests run once
+    with -fsanitize=address,undefined (a subprocess: the sanitizer runtime has to be loaded before Python)."""
+    import shutil
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(orc.__file__))
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.exists(asan):
+        pytest.skip("no libasan in this toolchain")
+    work = tmp_path / "oracle"
+    shutil.copytree(here, str(work), ignore=shutil.ignore_patterns("*.so", "__pycache__", "_ref"))
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           "-std=gnu11", "-fPIC", "-fopenmp", "-ffp-contract=off", "-shared", "-o", str(work / "liboracle.so"),
+                           str(work / "realign_oracle.c"), str(work / "realign_oracle_f32.c"), "-lm"])
+    shutil.copy(str(work / "liboracle.so"), str(work / "liboracle_native.so"))
+    for so in ("liboracle.so", "liboracle_native.so"):   # newer than the sources: oracle.build() keeps them
+        os.utime(str(work / so))
+    script = (
+        "import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"  # the sanitized copy wins
+        "import numpy as np\n"
+        "from oracle import oracle as orc\n"
+        "assert os.path.dirname(orc.__file__) == %r\n"
+        "from helpers import oracle_hmm, random_pair\n"
+        "rng = np.random.default_rng(3)\n"
+        "h = oracle_hmm()\n"
+        "for n, P in ((40, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=20)), (300, orc.make_params(band_mode=orc.BAND_ANCHOR, constraint_trim=3, split_threshold=40)),\n"
+        "             (200, orc.make_params(band_mode=orc.BAND_ANCHOR, mode=orc.MODE_RESCORE_ORIGINAL, split_threshold=100)), (0, orc.make_params())):\n"
+        "    X, Y, g = random_pair(rng, n) if n else (np.zeros(0, np.uint8), np.zeros(0, np.uint8), [])\n"
+        "    for prec in (0, 1):\n"
+        "        r = orc.realign_read(h, P, X, Y, g, precision=prec)\n"
+        "        assert r['status'] in (0, -1), r['status']\n"
+        "    for seg in (orc.plan(len(X), len(Y), g, P) if n else []):\n"
+        "        e = orc.expectations(h, X[seg['xs']:seg['xe']], Y[seg['ys']:seg['ye']], seg['lo'], seg['n'], seg['ragged_start'], seg['ragged_end'])\n"
+        "        assert e['rc'] == 0\n"
+        "print('SANITIZED OK')\n") % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path), str(work))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "SANITIZED OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
