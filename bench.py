@@ -16,10 +16,16 @@ collective (weak scaling); one chunked RCCL gather of the packed results to rank
 
 `--workload c3` is the STRONG-scaling job of BASELINE.json configs[2] / configs[3]: ONE set of 50 k reads (~8 kb, one
 shared 4.6 Mb contig) sharded over the ranks as the reference shards one SAM file over jobTree jobs
-(utils.py:565-570); a step is the whole job from host buffers: stage (band planning + upload) + run + finish on every
-rank, every rank's block of the realigned SAM formatted and written at its offset of the one output file, the per-read
-scalars gathered to rank 0 and the summary XML written there (utils.py:591-609).  value = cells of the whole set / that
-time; reads_per_s likewise.
+(utils.py:565-570); a step is the whole job FILES -> FILE (nanopore_amd/job.py::realign_sam_file, what
+analyses.utils.realignSamFile runs): every rank maps the SAM + FASTA, parses the records of its contiguous shard natively,
+keeps two batches in flight (stage = band planning + upload, DP, finish = MEA chain + cigar) and writes its block of the
+realigned SAM at its offset of the one output file; the per-read results are gathered to rank 0 (RCCL) inside the timed
+region (utils.py:557-609).  `--resident-arrays` runs the same pipeline from arrays already in host memory (round 2's job).
+value = cells of the whole set / that time; reads_per_s likewise.  The default run (any N) carries this job as an `also`
+entry, so that a --gpus 1/2/4/8 series measures the strong-scaling target next to the weak-scaling headline.
+
+`--workload em` is the Baum-Welch E-step (npr_batch_expectations: what the trainer runs 3 x 100 times per model,
+utils.py:509-523) over one resident batch in the trainer's own band (anchors, splitMatrixBiggerThanThis 300, utils.py:511).
 
 Rank 0 prints ONE JSON line.
 """
@@ -40,12 +46,15 @@ DECLARED_BYTES_PER_CELL = 40.0  # all five fp32 states stored + re
                                 # state for the backward sweep, so its algorithmic traffic is the next two constants.
 BYTES_PER_CELL = 16.0       # (mantissa, exponent) of the match state: 8 B stored by the forward sweep + 8 B reloaded
 BYTES_PER_PAIR = 12.0       # one sparse posterior triple (x, y, p) written per pair >= 0.01
+EM_BYTES_PER_CELL = 48.0    # E-step: all five forward states kept for the backward sweep (8 B match pair + 16 B of the
+                            # other four), stored once and reloaded once
 SIMDS = 256 * 4             # 256 CUs x 4 SIMDs
 NOMINAL_CYCLES_PER_VALU = 2.0  # one wave64 VALU instruction per 2 cycles per SIMD: the 157 TF fp32 vector peak
 
 # kernel class (npr_batch_class_stats) -> kernel name in profiles/kernel_table.json
 CLASS_KERNEL = {0: "k_dp_stair<1>", 1: "k_dp_stair<2>", 2: "k_dp_stair<4>", 3: "k_dp_wide", 4: "k_dp_wide", 5: "k_dp_wide",
                 6: "k_dp_wide", 7: "k_dp_generic", 8: "k_dp_generic", 9: "k_dp_generic", 10: "k_dp_generic", 11: "k_dp_tile<2>"}
+EM_CLASS_KERNEL = {0: "k_em_stair<1>", 1: "k_em_stair<2>", 2: "k_em_stair<4>", 11: "k_em_tile<2>"}
 
 
 def load_model(name="blasr_hmm_0.txt"):
@@ -103,9 +112,21 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(h, w, W, cells_per_read, budget_s=9.0):
     """The build's fp64 log-space CPU oracle (kind "port": the reference binary cactus_realign is absent from
-    the snapshot) timed on this host's cores over a bounded sample of the same workload."""
+    the snapshot) timed on this host's cores over bounded samples of the same workload, in the three
+    configurations SURVEY.md 8(d) names: one thread, the reference's 4 workers (/root/reference/Makefile:1: jobTree
+    --maxThreads=4), and every core the cgroup grants.  `value` is the all-cores figure."""
     from oracle import oracle as orc
     from nanopore_amd.realign import encode
     cores = usable_cpus()
@@ -113,7 +134,7 @@ def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
     # W = 0: the reference's own call parameters (anchors +- 10, trim 14, splitMatrixBiggerThanThis 3000; utils.py:587)
     P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W) if W > 0 else orc.make_params(band_mode=orc.BAND_ANCHOR)
 
-    def run(k):
+    def run(k, threads):
         if w.get("guide_start") is not None:
             # the oracle takes the guide's window of every slice (what npr_batch_create_at does on its side)
             lead, ilen = w["guide_start"][:k, 0], w["interval_len"][:k]
@@ -126,23 +147,32 @@ def cpu_baseline(h, w, W, cells_per_read, budget_s=15.0):
         t0 = time.time()
         r = orc.realign_batch(oh, P, X, x_off, Y, w["read_off"][:k + 1],
                               w["guide_ops"][:w["guide_off"][k]], w["guide_off"][:k + 1], precision=0,
-                              threads=cores, native=True)
+                              threads=threads, native=True)
         return r, time.time() - t0
 
-    # pilot (one read per core) to size the timed sample for ~budget_s of wall time
+    # pilot (one read per core) to size the timed samples for ~budget_s of wall time each
     n = len(cells_per_read)
+    mean_cells = max(float(np.mean(cells_per_read)), 1.0)
     k0 = min(n, cores)
-    r, dt = run(k0)
-    rate = float(r["cells"].sum()) / max(dt, 1e-3)
-    k = int(min(n, max(k0, round(rate * budget_s / max(float(np.mean(cells_per_read)), 1.0)))))
-    if k > k0:
-        r, dt = run(k)
-    cells = int(r["cells"].sum())
-    return {"value": cells / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+    r, dt = run(k0, cores)
+    rate_all = float(r["cells"].sum()) / max(dt, 1e-3)
+    variants, keep = [], None
+    for threads in sorted({1, min(4, cores), cores}):
+        guess = rate_all * threads / cores
+        k = int(min(n, max(threads, round(guess * budget_s / mean_cells))))
+        r, dt = run(k, threads)
+        cells = int(r["cells"].sum())
+        variants.append({"threads": threads, "value": cells / dt, "unit": "cells/s", "cells_per_s_per_core": cells / dt / threads,
+                         "reads": k, "cells": cells, "seconds": dt})
+        if threads == cores:
+            keep = (r, k, cells, dt)
+    r, k, cells, dt = keep
+    return {"value": cells / dt, "unit": "cells/s", "cores": cores, "kind": "port", "cpu": cpu_model(), "variants": variants,
             "sample": "first %d reads of the same batch (%d cells), fp64 log-space oracle (this build's own restatement of "
                       "cactus_realign: the reference binary is absent, parity unpinned), OpenMP over reads on %d threads "
-                      "(os.cpu_count() %d, capped by the cgroup CPU quota), gcc -O3 -march=native, %.1f s"
-                      % (k, cells, cores, os.cpu_count() or 1, dt)}, r
+                      "(os.cpu_count() %d, capped by the cgroup CPU quota) of a %s, gcc -O3 -march=native, %.1f s; `variants`: "
+                      "the same on 1 thread, on the reference's 4 workers (/root/reference/Makefile:1) and on all granted cores"
+                      % (k, cells, cores, os.cpu_count() or 1, cpu_model(), dt)}, r
 
 
 def roofline_block(cells, pairs, kms, class_cells, clock_hz):
@@ -255,11 +285,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3", "anchor"])
+    ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3", "anchor", "em"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (resident workloads; default 12288 northstar = two per resident "
-                    "wavefront, 1000 c2, 8192 anchor) or in the whole set (c3; default 50000)")
+                    "wavefront, 1000 c2, 8192 anchor, 6144 em) or in the whole set (c3; default 50000)")
+    ap.add_argument("--resident-arrays", action="store_true", help="c3: the job from arrays in host memory instead of from files")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary line (the reference's own band) of the default run")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary lines of the default run (the reference's own band; the "
+                    "files -> file strong-scaling job of configs[2]/[3])")
     args = ap.parse_args()
 
     import torch
@@ -302,20 +334,30 @@ def main():
         dist.all_reduce(t, op=op)
         return [float(v) for v in t.tolist()]
 
-    from nanopore_amd import realign as R
+    from nanopore_amd import job, realign as R
     ctx = R.Context(local_rank)
+    job._ctx_pool.setdefault(local_rank, []).insert(0, ctx)  # the job's pipeline uses this context and one more on the same GPU
+    env = dict(args=args, ctx=ctx, rank=rank, world=world, dist=dist, coll_dev=coll_dev, sync=sync, allreduce=allreduce, gpu=local_rank)
     if args.workload == "c3":
-        out = strong_c3(args, ctx, rank, world, dist, coll_dev, sync, allreduce)
+        out = c3_job(env, args.reads or 50000, args.steps, args.warmup, from_files=not args.resident_arrays)
+    elif args.workload == "em":
+        out = em_step(env)
     else:
-        out = resident(args, ctx, rank, world, dist, coll_dev, sync, allreduce)
+        out = resident(env)
+        if args.workload == "northstar" and not args.no_also:
+            # collective: the strong-scaling job of configs[2]/[3], files -> file, at this N
+            entry = c3_job(env, 50000, 2, 1, from_files=True)
+            if rank == 0:
+                out.setdefault("also", []).append(entry)
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
+    job.close_contexts()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def resident(args, ctx, rank, world, dist, coll_dev, sync, allreduce):
+def resident(env):
+    args, ctx, rank, world, dist, coll_dev, sync, allreduce = (env[k] for k in ("args", "ctx", "rank", "world", "dist", "coll_dev", "sync", "allreduce"))
     n_reads = args.reads or {"northstar": 12288, "c2": 1000, "anchor": 8192}[args.workload]
     h, w, W, label = build_workload(args.workload, n_reads, rank)
     ctx.set_hmm(h)
@@ -400,42 +442,56 @@ def resident(args, ctx, rank, world, dist, coll_dev, sync, allreduce):
     return out
 
 
-def c3_workload(n_reads, rank, dist):
-    """The one read set of configs[2]: generated by rank 0, handed to the other ranks of the node through a file."""
+def c3_inputs(n_reads, rank, dist, from_files):
+    """The one read set of configs[2], made by rank 0.  from_files: written as SAM (one local record per read, POS = where
+    its window starts on the contig) + FASTA (the 4.6 Mb contig) for every rank to map; else handed to the other ranks as
+    arrays through an .npz."""
     from nanopore_amd import synth
     h = load_model()
-    path = os.path.join(tempfile.gettempdir(), "npr_bench_c3_%d_%d.npz" % (n_reads, os.getuid()))
+    tmp = os.path.join(tempfile.gettempdir(), "npr_bench_c3_%d_%d" % (n_reads, os.getuid()))
+    sam, fa, npz = (os.path.join(tmp, k) for k in ("reads.sam", "contig.fa", "arrays.npz"))
     keys = ("ref", "ref_off", "ref_index", "read", "read_off", "guide_ops", "guide_off", "guide_start", "interval_len")
+    w = None
     if rank == 0:
+        os.makedirs(tmp, exist_ok=True)
         w, W = synth.config_c3_shared(h.transitions, h.emissions, n_reads=n_reads)
-        if dist is not None:
-            np.savez(path, **{k: w[k] for k in keys})
+        if from_files:
+            synth.write_workload_files(w, sam, fa, ref_names=["ecoli_like_contig"])
+        elif dist is not None:
+            np.savez(npz, **{k: w[k] for k in keys})
     if dist is not None:
         dist.barrier()
-        if rank != 0:
-            z = np.load(path)
+        if rank != 0 and not from_files:
+            z = np.load(npz)
             w = {k: z[k] for k in keys}
         dist.barrier()
-        if rank == 0:
-            os.unlink(path)
-    return h, w, 200
+    return h, w, 200, tmp, sam, fa
 
 
-def strong_c3(args, ctx, rank, world, dist, coll_dev, sync, allreduce):
+def c3_job(env, n_reads, steps, warmup, from_files):
+    import shutil
     from nanopore_amd import job
-    n_reads = args.reads or 50000
-    h, w, W = c3_workload(n_reads, rank, dist)
-    ctx.set_hmm(h)
+    ctx, rank, world, dist, coll_dev, sync, allreduce, gpu = (env[k] for k in ("ctx", "rank", "world", "dist", "coll_dev", "sync", "allreduce", "gpu"))
+    h, w, W, tmp, sam, fa = c3_inputs(n_reads, rank, dist, from_files)
+    ctxs = job.contexts(gpu, job.WORKERS)
+    for c in ctxs:
+        c.set_hmm(h)
     params = make_params(W)
-    out_dir = os.path.join(tempfile.gettempdir(), "npr_bench_c3_out_%d" % os.getuid())  # one file, written by all ranks
+    out_sam = os.path.join(tmp, "realigned.sam")  # one file, written by all ranks
+
+    def one():
+        if from_files:
+            return job.realign_sam_file(sam, out_sam, fa, params=params, gpu=gpu, set_models=False, coll_device=coll_dev)
+        return job.run_job(ctx, params, w, out_dir=tmp, device=coll_dev)
+
     last = None
-    for _ in range(args.warmup):
-        last = job.run_job(ctx, params, w, out_dir=out_dir, device=coll_dev)
+    for _ in range(warmup):
+        last = one()
     sync()
     t0 = time.perf_counter()
     tms = []
-    for _ in range(args.steps):
-        last = job.run_job(ctx, params, w, out_dir=out_dir, device=coll_dev)
+    for _ in range(steps):
+        last = one()
         tms.append(last["timings"])
     sync()
     elapsed = time.perf_counter() - t0
@@ -448,35 +504,142 @@ def strong_c3(args, ctx, rank, world, dist, coll_dev, sync, allreduce):
     if rank != 0:
         return None
     mean = {k: float(np.mean([t[k] for t in tms])) for k in tms[0] if k != "cells"}
-    sam_bytes = os.path.getsize(last["sam"])
-    ok = int((last["status"] == 0).sum())
-    import shutil
-    shutil.rmtree(out_dir, ignore_errors=True)
+    sam_bytes = os.path.getsize(out_sam)
+    res = last["results"]
+    ok = int((res["status"] == 0).sum())
+    in_bytes = (os.path.getsize(sam) + os.path.getsize(fa)) if from_files else 0
+    shutil.rmtree(tmp, ignore_errors=True)
     kms = mean["kernel_ms"]
+    wall = elapsed / steps
     return {
-        "metric": "DP cells/sec (banded pair-HMM realign: forward + backward + posterior per cell), whole job from host buffers",
-        "value": total_cells * args.steps / elapsed,
+        "metric": "DP cells/sec (banded pair-HMM realign: forward + backward + posterior per cell), whole job %s" % ("files -> file" if from_files else "from host arrays"),
+        "value": total_cells * steps / elapsed,
         "unit": "cells/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": wall * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[2]/[3]: one set of %d synthetic ~8kb reads on one shared 4.6 Mb contig "
-                               "(ref_index, windowed guides), band 200, blasr_hmm_0, sharded over the ranks into contiguous "
-                               "ranges balanced by read length (dist.shard_ranges)" % n_reads,
-                   "reads": n_reads, "band": W, "cells": total_cells, "parallelism": "one read set sharded x%d" % world},
-        "reads_per_s": n_reads * args.steps / elapsed,
+                               "(local records, POS = window start), band 200, blasr_hmm_0, sharded over the ranks into contiguous "
+                               "ranges balanced by record length (dist.shard_ranges)" % n_reads,
+                   "reads": n_reads, "band": W, "cells": total_cells, "parallelism": "one read set sharded x%d, two batches in flight per rank" % world,
+                   "input_bytes": in_bytes, "output_bytes": sam_bytes},
+        "reads_per_s": n_reads * steps / elapsed,
         "ok_reads": ok,
-        "step": "per rank: npr_batch_create (plan + pack + H2D) + npr_batch_run + npr_batch_finish + its block of the realigned SAM "
-                "(%d bytes in all) formatted and written at its offset; per-read scalars gathered to rank 0 (RCCL); rank 0: summary XML" % sam_bytes,
-        "rank0_stage_seconds": mean,
+        "step": ("per rank: map SAM + FASTA, parse its shard (native), then chunks of ~12 k reads through two contexts on its GPU (stage = plan + pack + "
+                 "H2D + device planner | DP | finish = MEA chain + cigar | splice of the records' bytes), blocks written at the rank's offset of the one "
+                 "output; per-read results gathered to rank 0 (RCCL) inside the timed region") if from_files else
+                "per rank: the same pipeline over arrays resident in host memory, records formatted natively",
+        "rank0_phase_seconds": mean,
+        "dp_share_of_wall": (kms * 1e-3) / wall,
         "dp_sweep_only_rank0": {"value": cells_rank / (kms * 1e-3), "unit": "cells/s", "ms": kms},
+        "note": "phase seconds are sums over the rank's two worker threads (they overlap each other); dp_share_of_wall = HIP-event time of the "
+                "DP launches / wall time of a step",
     }
+
+
+def em_step(env):
+    """Baum-Welch E-step over one resident batch in the trainer's band: a step = npr_batch_expectations (forward with all five
+    states kept, backward with the expected transition / emission counts accumulated, one reduction per model slot)."""
+    args, ctx, rank, world, dist, sync, allreduce = (env[k] for k in ("args", "ctx", "rank", "world", "dist", "sync", "allreduce"))
+    from nanopore_amd import realign as R, synth
+    h = load_model()
+    n_reads = args.reads or 6144
+    w = synth.make_workload(1006 + 7919 * rank, n_reads, 4000, h.transitions, h.emissions, flank=0)
+    ctx.set_hmm(h)
+    P = R.make_params(band_mode=R.BAND_ANCHOR, split_threshold=300, mode=R.MODE_EXPECTATIONS)  # options.optionsToRealign, utils.py:511
+    b = ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
+    st = b.stats()
+    _, class_cells = b.class_stats()
+    for _ in range(args.warmup):
+        b.expectations()
+    sync()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(args.steps):
+        T, E, ll, ms = b.expectations()
+        kms.append(ms)
+    sync()
+    elapsed = time.perf_counter() - t0
+    cells = st["cells"]
+    if dist is not None:
+        elapsed = allreduce([elapsed], dist.ReduceOp.MAX)[0]
+        total_cells = int(allreduce([cells], dist.ReduceOp.SUM)[0])
+    else:
+        total_cells = cells
+    if rank != 0:
+        b.close()
+        return None
+    kms = float(np.mean(kms))
+    dom = int(np.argmax(class_cells))
+    achieved = EM_BYTES_PER_CELL * cells / (kms * 1e-3) / 1e9
+    tab = kernel_table().get(EM_CLASS_KERNEL.get(dom, ""), {})
+    out = {
+        "metric": "DP cells/sec (Baum-Welch E-step: forward + backward + expected counts per cell)",
+        "value": total_cells * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "synthetic ~4kb reads in the trainer's band (anchors +- 10, trim 14, splitMatrixBiggerThanThis 300: "
+                               "nanopore/analyses/utils.py:511), blasr_hmm_0", "reads_per_gpu": n_reads, "cells_per_gpu": int(cells),
+                   "tasks": int(st["n_tasks"]), "class_cells": {EM_CLASS_KERNEL.get(c, CLASS_KERNEL.get(c, str(c))): int(v) for c, v in enumerate(class_cells) if v}},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": (tab["hbm_bytes_per_cell"] * cells / 1e9) if tab.get("hbm_bytes_per_cell") else None,
+                     "kernel": EM_CLASS_KERNEL.get(dom, "k_dp_generic<EM>"), "kernel_ms": kms,
+                     "kernel_share_of_cells": float(class_cells[dom]) / max(float(np.sum(class_cells)), 1.0),
+                     "algorithmic_bytes": "%g B/cell: the five forward states of every cell (match mantissa + exponent 8 B, the other four 16 B) "
+                                          "stored by the forward sweep and reloaded by the backward sweep" % EM_BYTES_PER_CELL,
+                     "note": "kernel_ms = HIP-event time of ALL E-step launches of the batch (one per kernel class, concurrent)"},
+        "loglik": float(ll[0]),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = em_cpu_baseline(h, w, P)
+    b.close()
+    return out
+
+
+def em_cpu_baseline(h, w, P, budget_s=12.0):
+    """orc_expectations_f64 (the fp64 E-step of the oracle: kind "port") over the first reads of the batch, one process
+    per core (the oracle's E-step entry point is per segment; there is no OpenMP batch form)."""
+    import multiprocessing as mp
+    cores = usable_cpus()
+    n = len(w["read_off"]) - 1
+    k = min(n, 4 * cores)
+    global _EM_JOB
+    _EM_JOB = (h.transitions, h.emissions, w)  # inherited by the forked workers: no pickling of the batch per task
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_em_cpu_one, range(cores), chunksize=1)  # (warm: library load, first touch)
+        t0 = time.time()
+        parts = pool.map(_em_cpu_one, range(k), chunksize=1)
+        dt = time.time() - t0
+    cells = int(sum(parts))
+    return {"value": cells / dt, "unit": "cells/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "first %d reads of the same batch (%d cells): plan (anchors, split 300) + orc_expectations_f64 per segment, fp64 log space, "
+                      "%d worker processes, %.1f s" % (k, cells, cores, dt)}
+
+
+_EM_JOB = None
+
+
+def _em_cpu_one(i):
+    from oracle import oracle as orc
+    from nanopore_amd.realign import encode
+    T, E, w = _EM_JOB
+    oh = orc.make_hmm(T, E)
+    P = orc.make_params(band_mode=orc.BAND_ANCHOR, split_threshold=300)
+    X = encode(bytes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]]))
+    Y = encode(bytes(w["read"][w["read_off"][i]:w["read_off"][i + 1]]))
+    g = w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]
+    cells = 0
+    for seg in orc.plan(len(X), len(Y), g, P):
+        r = orc.expectations(oh, X[seg["xs"]:seg["xe"]], Y[seg["ys"]:seg["ye"]], seg["lo"], seg["n"], seg["ragged_start"], seg["ragged_end"])
+        assert r["rc"] == 0
+        cells += seg["cells"]
+    return cells
 
 
 if __name__ == "__main__":

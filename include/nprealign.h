@@ -289,6 +289,15 @@ int32_t npr_rescore(const int32_t *guide_ops, int64_t n_guide_ops, const int32_t
  * scan, ties included, found with a sort and a windowed scan.  Host code. */
 int64_t npr_chain_hits(int64_t n, const int64_t *ref_start, const int64_t *read_start, const int64_t *ref_end,
                        const int64_t *read_end, const uint8_t *reverse, const int64_t *score, int64_t max_gap, int64_t *chain);
+/* The global alignment a chain stands for (mergeChainedAlignedReads, nanopore/analyses/utils.py:295-386): block k = a local
+ * alignment whose first aligned pair is at reference position ref_pos[k] and position read_pos[k] of SEQ (its leading hard +
+ * soft clips; the same on either strand), M / I / D operations ops[2 * ops_off[k] ..).  Unaligned reference / read bases
+ * between, before and after the blocks become D / I operations, neighbours of one kind are merged; the result spans
+ * ref_len x read_len (the asserts of utils.py:381-382).  Returns the number of (op, length) pairs written to out_ops,
+ * NPR_ERR_INVALID when the blocks are out of order, overlap or run past the sequences (the reference's asserts),
+ * NPR_ERR_CAPACITY when cap_pairs is too small (ops + 2 per block + 2 always suffices).  Host code. */
+int64_t npr_chain_merge(int64_t n_blocks, const int64_t *ref_pos, const int64_t *read_pos, const int64_t *ops_off, const int32_t *ops,
+                        int64_t ref_len, int64_t read_len, int32_t *out_ops, int64_t cap_pairs);
 /* SAM CIGAR text of n op lists (CSR as returned by npr_batch_ops): what realignSamFile3TargetFn assigns to aR.cigar
  * and pysam prints (nanopore/analyses/utils.py:597-605), for a writer that splices 50 k records at once.  String i is
  * out[str_off[i] .. str_off[i+1]) (no terminator; "*" for an empty list).  out == NULL: only the offsets; returns the

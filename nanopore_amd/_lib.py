@@ -88,7 +88,7 @@ EXPORTS = [
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
     "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_format_cigars_packed", "npr_format_sam_records", "npr_chain_hits", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
     "npr_sam_index", "npr_sam_parse", "npr_sam_guides", "npr_sam_splice", "npr_fasta_index", "npr_fasta_pack", "npr_fastq_index",
-    "npr_batch_create_spans",
+    "npr_batch_create_spans", "npr_chain_merge",
 ]
 
 _lib = None
@@ -171,6 +171,8 @@ def load():
     L.npr_format_sam_records.argtypes = [i64] + [vp] * 15 + [i64]
     L.npr_chain_hits.restype = i64
     L.npr_chain_hits.argtypes = [i64, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.npr_chain_merge.restype = i64
+    L.npr_chain_merge.argtypes = [i64, vp, vp, vp, vp, i64, i64, vp, i64]
     L.npr_format_cigars.restype = i64
     L.npr_format_cigars.argtypes = [i64, vp, vp, vp, vp, i64]
     L.npr_mea_cigar.restype = i64

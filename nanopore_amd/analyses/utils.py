@@ -166,60 +166,34 @@ def chainFn(alignedReads, refSeq, readSeq, scoreFn=None, maxGap=200):
 
 
 def mergeChainedAlignedReads(chainedAlignedReads, refSequence, readSequence):
-    """One GLOBAL record for a chain: pos 0, SEQ = whole read (reverse-complemented for the minus strand),
-    cigar spanning the entire reference and the entire read with explicit D / I between and around the
-    blocks (utils.py:295-386; asserts :381-382)."""
-    first = chainedAlignedReads[0]
-    cAR = pysam.AlignedRead()
-    cAR.qname = first.qname
-    cAR.rname = first.rname
-    cAR.pos = 0
-    cAR.flag = 0x10 if first.is_reverse else 0
-    cAR.seq = reverseComplement(readSequence) if first.is_reverse else readSequence
-    cigarList = []
-    pPos = 0
-    pQPos = -(len(readSequence) - 1) if first.is_reverse else 0
-    for aR in chainedAlignedReads:
-        assert aR.is_reverse == first.is_reverse
-        assert aR.pos >= pPos
-        if aR.pos > pPos:
-            cigarList.append((2, aR.pos - pPos))
-            pPos = aR.pos
-        qPos = getAbsoluteReadOffset(aR, refSequence, readSequence)
-        assert qPos >= pQPos
-        if qPos > pQPos:
-            cigarList.append((1, qPos - pQPos))
-            pQPos = qPos
-        for op, length in aR.cigar:
-            assert op in (0, 1, 2, 4, 5)
-            if op in (0, 1, 2):
-                cigarList.append((op, length))
-            if op in (0, 2):
-                pPos += length
-            if op in (0, 1):
-                pQPos += length
-    assert pPos <= len(refSequence)
-    if pPos < len(refSequence):
-        cigarList.append((2, len(refSequence) - pPos))
-    if first.is_reverse:
-        assert pQPos <= 1
-        if pQPos < 1:
-            cigarList.append((1, 1 - pQPos))
-    else:
-        assert pQPos <= len(readSequence)
-        if pQPos < len(readSequence):
-            cigarList.append((1, len(readSequence) - pQPos))
-    # merge neighbours of the same type so that the record is a canonical cigar
-    merged = []
-    for op, length in cigarList:
-        if merged and merged[-1][0] == op:
-            merged[-1] = (op, merged[-1][1] + length)
-        else:
-            merged.append((op, length))
-    assert sum(n for op, n in merged if op in (0, 2)) == len(refSequence)
-    assert sum(n for op, n in merged if op in (0, 1)) == len(readSequence)
-    cAR.cigar = merged
-    return cAR
+    """The chain's blocks as ONE global record: pos 0, SEQ = the whole read in the strand's orientation, cigar over the entire
+    reference and the entire read (utils.py:295-386; spans asserted at :381-382).  The cigar is made natively from the
+    blocks' coordinates (include/nprealign.h: npr_chain_merge): what lies between, before and after the blocks becomes
+    explicit D / I operations; blocks out of chain order or overlapping are an AssertionError, as in the reference."""
+    from .. import _lib
+    blocks = list(chainedAlignedReads)
+    head = blocks[0]
+    if any(aR.is_reverse != head.is_reverse for aR in blocks):
+        raise AssertionError("blocks of one chain lie on both strands (%s)" % head.qname)
+    guides = [_guideOf(aR) for aR in blocks]
+    ref_pos = np.array([aR.pos for aR in blocks], dtype=np.int64)
+    read_pos = np.array([clipLengths(aR)[0] for aR in blocks], dtype=np.int64)  # first aligned base in SEQ orientation, either strand
+    ops_off = np.zeros(len(blocks) + 1, dtype=np.int64)
+    np.cumsum([len(g) for g in guides], out=ops_off[1:])
+    ops = np.array([o for g in guides for o in g], dtype=np.int32).reshape(-1, 2)
+    out = np.zeros((int(ops_off[-1]) + 2 * len(blocks) + 2, 2), dtype=np.int32)
+    k = _lib.load().npr_chain_merge(len(blocks), _lib.ptr(ref_pos), _lib.ptr(read_pos), _lib.ptr(ops_off), _lib.ptr(ops), len(refSequence),
+                                    len(readSequence), _lib.ptr(out), len(out))
+    if k == _lib.ERR_INVALID:
+        raise AssertionError("chain of %s is not co-linear inside its sequences" % head.qname)
+    if k < 0:
+        raise _lib.NprError(int(k), "npr_chain_merge")
+    merged = pysam.AlignedRead()
+    merged.qname, merged.rname, merged.pos = head.qname, head.rname, 0
+    merged.flag = 0x10 if head.is_reverse else 0
+    merged.seq = reverseComplement(readSequence) if head.is_reverse else readSequence
+    merged.cigar = [(int(op), int(n)) for op, n in out[:k]]
+    return merged
 
 
 def chainSamFile(samFile, outputSamFile, readFastqFile, referenceFastaFile, chainFn=chainFn):

@@ -1629,12 +1629,17 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         int stair_R;  // > 0: the register-kernel E-step (k_em_stair<R>), else the generic kernel
         int wide_NW;  // > 0: stair_R slots per lane on wide_NW wavefronts per task (k_dp_wide<R, NW, EM>)
         bool tile;    // the stripe-kernel E-step (k_em_tile<stair_R>): scratch regions per workgroup, as in the DP launch
+        int slot_base;    // first uniform forward-scratch region: the one its class had in the DP launch (the classes run concurrently)
+        int dp_grid;      // ... and how many of them that launch owned
+        int64_t cells;
+        size_t fx_off, ring_off;  // where its planes of the other four states / its HBM ring start (floats)
     };
     std::vector<L> launches;
     int64_t max_grid = 1;
     for (const auto &dl : b->launches) {  // one E-step launch per kernel class of the batch (tasks are grouped by class)
         L l{};
         l.first = dl.first, l.count = dl.count;
+        l.slot_base = dl.slot_base, l.dp_grid = dl.grid, l.cells = dl.cells;
         if (kClassTab[dl.cls].kind == K_STAIR && !std::getenv("NPR_EM_GENERIC")) {
             // 127 / 161 / 223 VGPRs and 9 KiB of LDS bins per wavefront: 16 / 12 / 8 wavefronts per CU
             l.stair_R = kClassTab[dl.cls].R;
@@ -1671,27 +1676,34 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * waves)));
         launches.push_back(l);
     }
-    size_t ring_floats = 0;
-    bool any_tile = false;
-    for (auto &l : launches) {
-        any_tile |= l.tile;
-        // the forward scratch of this batch was sized for the DP launches' grid: stay inside it
-        if (!l.tile) l.grid = static_cast<int>(std::min<int64_t>(l.grid, std::max<int64_t>(1, static_cast<int64_t>(ctx->arena->cells) / std::max<int64_t>(b->slot_stride, 1))));
-        max_grid = std::max<int64_t>(max_grid, l.grid);
-        if (l.global_ring) ring_floats = std::max(ring_floats, static_cast<size_t>(l.grid) * 18 * l.wcap);
-    }
+    // The launches run concurrently, like the DP launches of npr_batch_run (serialised, a batch in the trainer's band spent
+    // 63 ms where its longest class takes 38: profiles/r03_em_*): each class keeps the forward-scratch regions its DP launch
+    // owned (so at most that many workgroups) and gets its own planes and ring.
+    for (auto &l : launches)
+        if (!l.tile) l.grid = std::max(1, std::min(l.grid, l.dp_grid));
+    (void)max_grid;
     // The planes of the other four states: 16 bytes per cell of forward scratch in use.  The stripe kernel's mirror its regions
     // of the forward scratch, but only those of the workgroups the E-step launches (far fewer than the DP launch had): when
     // the device has no room for them, fewer workgroups yet.
     hipError_t e;
+    size_t ring_floats = 0;
     for (;;) {
-        max_grid = 1;
-        for (const auto &l : launches)
-            if (!l.tile) max_grid = std::max<int64_t>(max_grid, l.grid);
-        size_t fx_cells = static_cast<size_t>(max_grid) * 4 * static_cast<size_t>(b->slot_stride);
-        for (const auto &l : launches)
-            if (l.tile && !b->region_end.empty())
+        // uniform classes: planes packed one class after the other; the stripe class: a mirror of its scratch regions, which
+        // lie behind all uniform regions of the arena (so behind the packed planes too)
+        size_t fx_cells = 0;
+        ring_floats = 0;
+        for (auto &l : launches) {
+            if (l.tile) continue;
+            l.fx_off = fx_cells;
+            fx_cells += static_cast<size_t>(l.grid) * 4 * static_cast<size_t>(b->slot_stride);
+            l.ring_off = ring_floats;
+            if (l.global_ring) ring_floats += static_cast<size_t>(l.grid) * 18 * l.wcap;
+        }
+        for (auto &l : launches)
+            if (l.tile && !b->region_end.empty()) {
+                l.fx_off = 0;
                 fx_cells = std::max(fx_cells, 4 * static_cast<size_t>(b->region_end[std::min<size_t>(static_cast<size_t>(l.grid), b->region_end.size()) - 1]));
+            }
         if (fx_cells <= ctx->arena_fx_cells) break;
         if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
         ctx->arena_Fx = nullptr, ctx->arena_fx_cells = 0;
@@ -1722,24 +1734,38 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     HIP_TRY(ctx, hipMemsetAsync(d_E.p, 0, d_E.bytes(), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * kQueueSlots, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    int qi = 0;
-    for (const auto &l : launches) {
+    // all classes at once, the smallest first, each on its own stream; the main stream waits for all of them, so
+    // ev0 -> ev1 brackets the whole E-step
+    std::vector<const L *> order;
+    for (const auto &l : launches) order.push_back(&l);
+    std::stable_sort(order.begin(), order.end(), [](const L *x, const L *y) { return x->cells < y->cells; });
+    const bool serial = std::getenv("NPR_EM_SERIAL") != nullptr;  // A/B switch: one launch after the other, as before round 3
+    for (size_t i = 0; i < order.size(); ++i) {
+        const L &l = *order[i];
+        const bool last = serial || i + 1 == order.size();
+        hipStream_t st = last ? ctx->stream : ctx->side[i % npr_ctx::kSideStreams];
+        if (!last) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev0, 0));
         KernelArgs a = make_args(b);
         a.tasks += l.first;
         a.outs += l.first;
         a.ntasks = l.count;
-        a.queue += qi++;  // at most kClasses launches, kQueueSlots counters
+        a.queue += static_cast<int>(i);  // at most kClasses launches, kQueueSlots counters
         a.wcap = l.wcap;
-        a.ring = ring.p;
-        a.Fx = ctx->arena_Fx;
+        a.slot_base = l.slot_base;
+        a.ring = ring.p ? ring.p + l.ring_off : nullptr;
+        // stair / wide / generic kernels index their planes by workgroup from a.Fx; the stripe kernel by its scratch region
+        a.Fx = ctx->arena_Fx + l.fx_off;
         a.em_T = d_T.p;
         a.em_E = d_E.p;
-        const int rc = l.tile      ? launch_em_tile(a, l.stair_R, l.grid, ctx->stream)
-                       : l.wide_NW ? launch_em_wide(a, l.stair_R, l.wide_NW, l.grid, ctx->stream)
-                       : l.stair_R ? launch_em_stair(a, l.stair_R, l.grid, ctx->stream)
-                                   : launch_em(a, l.grid, l.lds, l.global_ring, ctx->stream);
+        const int rc = l.tile      ? launch_em_tile(a, l.stair_R, l.grid, st)
+                       : l.wide_NW ? launch_em_wide(a, l.stair_R, l.wide_NW, l.grid, st)
+                       : l.stair_R ? launch_em_stair(a, l.stair_R, l.grid, st)
+                                   : launch_em(a, l.grid, l.lds, l.global_ring, st);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "E-step kernel launch", static_cast<hipError_t>(rc));
+        if (!last) HIP_TRY(ctx, hipEventRecord(ctx->side_done[i % npr_ctx::kSideStreams], st));
     }
+    if (!serial)
+        for (size_t i = 0; i + 1 < order.size(); ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done[i % npr_ctx::kSideStreams], 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));

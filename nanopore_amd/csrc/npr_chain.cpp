@@ -49,3 +49,47 @@ extern "C" int64_t npr_chain_hits(int64_t n, const int64_t *ref_start, const int
     std::reverse(chain, chain + len);
     return len;
 }
+
+// The global alignment a chain of local hits stands for (mergeChainedAlignedReads, nanopore/analyses/utils.py:295-386, with
+// the spans it asserts at :381-382): block k is a local alignment whose first aligned pair sits at reference position
+// ref_pos[k] and at position read_pos[k] of the record's SEQ orientation (its leading hard + soft clips -- the same number
+// on either strand, since a reverse-strand SEQ is the reverse complement of the read and the merged record's SEQ is too),
+// with the M / I / D operations ops[2 * ops_off[k] ..).  Between consecutive blocks, before the first and after the last,
+// the unaligned reference bases become one D and the unaligned read bases one I (in that order); neighbours of the same
+// kind are merged into one operation.  The blocks must be in chain order and must not overlap (NPR_ERR_INVALID: the
+// reference's asserts :344, :350, :366-375), and the result spans exactly ref_len x read_len.
+extern "C" int64_t npr_chain_merge(int64_t n_blocks, const int64_t *ref_pos, const int64_t *read_pos, const int64_t *ops_off,
+                                   const int32_t *ops, int64_t ref_len, int64_t read_len, int32_t *out_ops, int64_t cap_pairs) {
+    if (n_blocks < 0 || ref_len < 0 || read_len < 0 || (n_blocks && (!ref_pos || !read_pos || !ops_off)) || cap_pairs < 0 || (cap_pairs && !out_ops))
+        return NPR_ERR_INVALID;
+    int64_t n = 0, x = 0, y = 0;  // operations written; reference / read bases consumed
+    bool overflow = false;
+    auto put = [&](int32_t op, int64_t len) {
+        if (len <= 0) return;
+        if (n > 0 && out_ops[2 * (n - 1)] == op && !overflow) {
+            out_ops[2 * (n - 1) + 1] += static_cast<int32_t>(len);
+            return;
+        }
+        if (n >= cap_pairs) {
+            overflow = true;
+            return;
+        }
+        out_ops[2 * n] = op, out_ops[2 * n + 1] = static_cast<int32_t>(len), ++n;
+    };
+    for (int64_t k = 0; k < n_blocks; ++k) {
+        if (ref_pos[k] < x || read_pos[k] < y) return NPR_ERR_INVALID;  // out of order or overlapping its predecessor
+        put(NPR_OP_D, ref_pos[k] - x), x = ref_pos[k];
+        put(NPR_OP_I, read_pos[k] - y), y = read_pos[k];
+        for (int64_t q = ops_off[k]; q < ops_off[k + 1]; ++q) {
+            const int32_t op = ops[2 * q], len = ops[2 * q + 1];
+            if (op < 0 || op > 2 || len < 0) return NPR_ERR_INVALID;
+            put(op, len);
+            if (op != NPR_OP_I) x += len;
+            if (op != NPR_OP_D) y += len;
+        }
+    }
+    if (x > ref_len || y > read_len) return NPR_ERR_INVALID;
+    put(NPR_OP_D, ref_len - x);
+    put(NPR_OP_I, read_len - y);
+    return overflow ? NPR_ERR_CAPACITY : n;
+}

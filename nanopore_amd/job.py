@@ -69,6 +69,25 @@ class ArraySource(object):
                                self.guide_off[lo:hi + 1], model_slot=None if self.model_slot is None else self.model_slot[sl],
                                ref_index=ri, guide_start=None if self.guide_start is None else self.guide_start[sl])
 
+    def stage_records(self, ctx, params, idx):
+        """The records `idx` (any subset, in that order) as one batch: the few reads of a chunk that have to run again."""
+        idx = np.asarray(idx, dtype=np.int64)
+        k = self.guide_off[idx + 1] - self.guide_off[idx]
+        goff = np.zeros(len(idx) + 1, dtype=np.int64)
+        np.cumsum(k, out=goff[1:])
+        gops = self.guide_ops[np.repeat(self.guide_off[idx] - goff[:-1], k) + np.arange(int(goff[-1]))]
+        if self.ref_index is None:  # per-read slices: a private table of the subset's slices, read where they lie
+            ri = np.arange(len(idx), dtype=np.int32)
+            lens = self.ref_off[idx + 1] - self.ref_off[idx]
+            ref_off = np.zeros(len(idx) + 1, dtype=np.int64)
+            np.cumsum(lens, out=ref_off[1:])
+            ref = self.ref[np.repeat(self.ref_off[idx] - ref_off[:-1], lens) + np.arange(int(ref_off[-1]))]
+        else:
+            ref, ref_off, ri = self.ref, self.ref_off, self.ref_index[idx]
+        return ctx.stage_spans(params, ref, ref_off, self.text, self.read_begin[idx], self.read_end[idx], gops, goff,
+                               model_slot=None if self.model_slot is None else self.model_slot[idx], ref_index=ri,
+                               guide_start=None if self.guide_start is None else self.guide_start[idx])
+
     def format_block(self, lo, hi, ops_off, words):
         raise NotImplementedError
 
@@ -173,22 +192,7 @@ def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
-def _realign_range(ctx, src, params, lo, hi, want_stats, tm):
-    """stage + run + finish of records lo .. hi on one context.  A range the device cannot hold (NPR_ERR_NOMEM: the
-    reference's per-read jobs have no such limit) is halved and retried.  -> (results, ops_off, words, stats or None)"""
-    from . import realign
-    t0 = time.perf_counter()
-    try:
-        b = src.stage(ctx, params, lo, hi)
-    except realign.NprError as e:
-        if e.code != realign.ERR_NOMEM or hi - lo < 2:
-            raise
-        mid = (lo + hi) // 2
-        r1, o1, w1, s1 = _realign_range(ctx, src, params, lo, mid, want_stats, tm)
-        r2, o2, w2, s2 = _realign_range(ctx, src, params, mid, hi, want_stats, tm)
-        return (np.concatenate([r1, r2]), np.concatenate([o1, o1[-1] + o2[1:]]), np.concatenate([w1, w2]),
-                None if s1 is None else np.concatenate([s1, s2]))
-    t1 = time.perf_counter()
+def _finish_batch(b, want_stats, tm, t0, t1):
     try:
         kms = b.run()
         t2 = time.perf_counter()
@@ -206,7 +210,52 @@ def _realign_range(ctx, src, params, lo, hi, want_stats, tm):
     tm["finish_s"] += t3 - t2
     tm["fetch_s"] += t4 - t3
     tm["kernel_ms"] += kms
-    tm["cells"] += int(st["cells"])
+    return res, off, words, stats, int(st["cells"])
+
+
+def _realign_range(ctx, src, params, lo, hi, want_stats, tm):
+    """stage + run + finish of records lo .. hi on one context.  A range the device cannot hold (NPR_ERR_NOMEM: the
+    reference's per-read jobs have no such limit) is halved and retried; reads whose sparse posterior list overflowed its
+    capacity (NPR_ERR_CAPACITY: a diffuse model can put up to 1 / threshold pairs on a base) run again with a four times
+    larger `max_pairs_per_base` until they fit, as Context.realign does.  -> (results, ops_off, words, stats or None)"""
+    from . import realign
+    t0 = time.perf_counter()
+    try:
+        b = src.stage(ctx, params, lo, hi)
+    except realign.NprError as e:
+        if e.code != realign.ERR_NOMEM or hi - lo < 2:
+            raise
+        mid = (lo + hi) // 2
+        r1, o1, w1, s1 = _realign_range(ctx, src, params, lo, mid, want_stats, tm)
+        r2, o2, w2, s2 = _realign_range(ctx, src, params, mid, hi, want_stats, tm)
+        return (np.concatenate([r1, r2]), np.concatenate([o1, o1[-1] + o2[1:]]), np.concatenate([w1, w2]),
+                None if s1 is None else np.concatenate([s1, s2]))
+    res, off, words, stats, cells = _finish_batch(b, want_stats, tm, t0, time.perf_counter())
+    tm["cells"] += cells
+    per_base = params.max_pairs_per_base if params.max_pairs_per_base > 0 else 6
+    limit = int(1.0 / max(params.posterior_threshold, 1e-6)) + 1
+    while per_base < limit:
+        again = np.nonzero(res["status"] == realign.ERR_CAPACITY)[0]
+        if not len(again):
+            break
+        per_base = min(4 * per_base, limit)
+        p2 = realign.Params.from_buffer_copy(params)
+        p2.max_pairs_per_base = per_base
+        t0 = time.perf_counter()
+        b = src.stage_records(ctx, p2, lo + again)
+        r2, o2, w2, s2, _ = _finish_batch(b, want_stats, tm, t0, time.perf_counter())
+        res[again] = r2
+        if want_stats:
+            stats[again] = s2
+        pieces, prev = [], 0
+        for k, i in enumerate(again):  # (a handful of reads: the loop is over them, not over the chunk)
+            pieces += [words[off[prev]:off[i]], w2[o2[k]:o2[k + 1]]]
+            prev = i + 1
+        pieces.append(words[off[prev]:])
+        words = np.concatenate(pieces)
+        nops = off[1:] - off[:-1]
+        nops[again] = o2[1:] - o2[:-1]
+        off = np.concatenate([[0], np.cumsum(nops)]).astype(np.int64)
     return res, off, words, stats
 
 

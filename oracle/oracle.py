@@ -121,8 +121,7 @@ class logadd_kind(object):
 
     def __enter__(self):
         for native in (False, True):
-            if native in _libs or not native:
-                lib(native).orc_set_logadd_kind(self.kind)
+            lib(native).orc_set_logadd_kind(self.kind)
         return self
 
     def __exit__(self, *exc):

@@ -59,3 +59,59 @@ def test_degenerate_inputs():
     assert _native([5], [7], [9], [11], [0], [5], 200) == [0]
     # equal chains: the end that sorts last wins, the predecessor that sorts first wins
     assert _native([0, 0, 10], [0, 0, 10], [4, 4, 14], [4, 4, 14], [0, 0, 0], [5, 5, 5], 200) == [0, 2]
+
+
+def _columns(blocks, ref_len, read_len):
+    """Independent restatement of the merge: one letter per alignment column."""
+    cols, x, y = [], 0, 0
+    for (rp, qp, ops) in blocks:
+        cols += "D" * (rp - x) + "I" * (qp - y)
+        x, y = rp, qp
+        for op, n in ops:
+            cols += "MID"[op] * n
+            x += n if op != 1 else 0
+            y += n if op != 2 else 0
+    cols += "D" * (ref_len - x) + "I" * (read_len - y)
+    return cols
+
+
+def test_chain_merge_spells_out_the_gaps_between_blocks():
+    """npr_chain_merge (mergeChainedAlignedReads, utils.py:295-386): the global cigar of a chain == the blocks' columns with
+    D / I filled in between, before and after; spans == (reference length, read length) (the asserts of :381-382); blocks out
+    of order, overlapping or past the sequences are refused as the reference's asserts refuse them."""
+    from nanopore_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(8)
+
+    def merge(blocks, ref_len, read_len, cap=None):
+        rp = np.array([b[0] for b in blocks], dtype=np.int64)
+        qp = np.array([b[1] for b in blocks], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum([len(b[2]) for b in blocks])]).astype(np.int64)
+        ops = np.array([o for b in blocks for o in b[2]], dtype=np.int32).reshape(-1, 2)
+        out = np.zeros(((int(off[-1]) + 2 * len(blocks) + 2) if cap is None else cap, 2), dtype=np.int32)
+        k = L.npr_chain_merge(len(blocks), _lib.ptr(rp), _lib.ptr(qp), _lib.ptr(off), _lib.ptr(ops), ref_len, read_len, _lib.ptr(out), len(out))
+        return k, [(int(a), int(b)) for a, b in out[:max(k, 0)]]
+
+    for _ in range(200):
+        blocks, x, y = [], 0, 0
+        for _ in range(int(rng.integers(1, 6))):
+            x += int(rng.integers(0, 30))
+            y += int(rng.integers(0, 30))
+            ops = [(int(rng.integers(0, 3)), int(rng.integers(1, 20))) for _ in range(int(rng.integers(1, 8)))]
+            blocks.append((x, y, ops))
+            x += sum(n for op, n in ops if op != 1)
+            y += sum(n for op, n in ops if op != 2)
+        ref_len, read_len = x + int(rng.integers(0, 25)), y + int(rng.integers(0, 25))
+        k, got = merge(blocks, ref_len, read_len)
+        assert k == len(got) > 0
+        want = _columns(blocks, ref_len, read_len)
+        assert "".join("MID"[op] * n for op, n in got) == "".join(want)
+        assert all(a[0] != b[0] for a, b in zip(got, got[1:])) and all(n > 0 for _, n in got)   # canonical: merged, no empty ops
+        assert sum(n for op, n in got if op != 1) == ref_len and sum(n for op, n in got if op != 2) == read_len
+    ok = [(5, 2, [(0, 10)]), (20, 14, [(0, 5)])]
+    assert merge(ok, 30, 20)[0] > 0
+    assert merge(ok[::-1], 30, 20)[0] == _lib.ERR_INVALID                          # out of chain order
+    assert merge([(5, 2, [(0, 10)]), (14, 14, [(0, 5)])], 30, 20)[0] == _lib.ERR_INVALID   # overlap on the reference
+    assert merge(ok, 24, 20)[0] == _lib.ERR_INVALID                                # runs past the reference
+    assert merge(ok, 30, 20, cap=2)[0] == _lib.ERR_CAPACITY
+    assert merge([], 7, 3) == (2, [(2, 7), (1, 3)])                                # no block: everything unaligned

@@ -114,3 +114,69 @@ def test_failures_exit_non_zero(tmp_path):
     for stdin in ("cigar: nobody 0 5 + ref0 0 5 + 1 M 5\n", "cigar: read0 0 5 + ref0 0 7 + 1 M 5\n", "not a cigar\n"):
         p = subprocess.run([EXE, fa, rd, "--diagonalExpansion=10"], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert p.returncode != 0 and p.stderr
+
+
+def test_exonerate_lines_of_chained_records_through_the_executable(tmp_path, gpu_ctx):
+    """SURVEY.md 8a row a3 on the GPU path: real chained records -- a forward read inside its reference (leading / trailing
+    D), a reverse-strand read, a read with unaligned bases at both ends (leading / trailing I) -- go through
+    getExonerateCigarFormatString (utils.py:168-180), the line is piped into the cactus_realign executable exactly as
+    realignCigarTargetFn does (utils.py:576-589: reference and aR.query as FASTA files, the cigar on stdin), and the cigar
+    that comes back is the one realignRecords gives for the same records."""
+    from nanopore_amd import bioio, sam as pysam
+    from nanopore_amd.analyses import utils
+    from seed_mapper import revcomp, write_local_hits_sam
+    rng = np.random.default_rng(99)
+    dna = lambda n: "".join("ACGT"[c] for c in rng.integers(0, 4, size=n))  # noqa: E731
+
+    def noisy(seq):
+        X = np.array(["ACGT".index(c) for c in seq], dtype=np.uint8)
+        out, x = [], 0
+        while x < len(X):
+            r = rng.random()
+            if r < 0.02:
+                x += int(rng.integers(1, 3))
+            elif r < 0.04:
+                out.extend(rng.integers(0, 4, size=int(rng.integers(1, 3))).tolist())
+            else:
+                out.append(int(X[x]) if rng.random() > 0.05 else int(rng.integers(0, 4)))
+                x += 1
+        return "".join("ACGT"[c] for c in out)
+
+    refs = {"refA": dna(2400), "refB": dna(1800)}
+    reads = {"fwd_inside": noisy(refs["refA"][400:1900]),                       # leading and trailing D
+             "rev_strand": revcomp(noisy(refs["refB"][200:1500])),             # FLAG 16
+             "ragged_ends": dna(60) + noisy(refs["refA"][0:1200]) + dna(45)}   # leading and trailing I (the read overhangs)
+    fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq")
+    with open(fa, "w") as fh:
+        for k, v in refs.items():
+            bioio.fastaWrite(fh, k, v)
+    with open(fq, "w") as fh:
+        for k, v in reads.items():
+            fh.write("@%s\n%s\n+\n%s\n" % (k, v, "I" * len(v)))
+    hits, chained = str(tmp_path / "hits.sam"), str(tmp_path / "chained.sam")
+    assert write_local_hits_sam(hits, refs, reads, k=12, min_len=16, both_strands=True) >= 9
+    utils.chainSamFile(hits, chained, fq, fa)
+    sam = pysam.Samfile(chained, "r")
+    records = list(utils.samIterator(sam))
+    assert sorted(aR.qname for aR in records) == sorted(reads)
+    by_name = {aR.qname: aR for aR in records}
+    assert by_name["rev_strand"].is_reverse and not by_name["fwd_inside"].is_reverse
+    assert by_name["fwd_inside"].cigar[0][0] == 2 and by_name["fwd_inside"].cigar[0][1] >= 380    # the reference before the read: a leading D
+    assert {op for op, _ in by_name["fwd_inside"].cigar[-2:]} <= {1, 2}                            # ... and what the chain left unaligned behind it
+    assert 1 in {op for op, _ in by_name["ragged_ends"].cigar[:2]} and by_name["ragged_ends"].cigar[-1][0] == 1  # overhanging read: I at both ends
+    hmm = os.path.join(MODEL_DIR, "blasr_hmm_0.txt")
+    want = utils.realignRecords(sam, records, utils.getFastaDictionary(fa), 0.5, 0.0, hmm, ctx=gpu_ctx)
+    for aR, w in zip(records, want):
+        line = utils.getExonerateCigarFormatString(aR, sam)
+        assert line.startswith("cigar: %s 0 %d + %s 0 %d + 1 " % (aR.qname, len(aR.query), sam.getrname(aR.rname), len(refs[sam.getrname(aR.rname)])))
+        # realignCigarTargetFn's temp files: the whole reference sequence, and aR.query under the read's name
+        tref, tread = str(tmp_path / "ref_one.fa"), str(tmp_path / "read_one.fa")
+        bioio.fastaWrite(tref, sam.getrname(aR.rname), refs[sam.getrname(aR.rname)])
+        bioio.fastaWrite(tread, aR.qname, aR.query)
+        out = _run("echo %s | %s %s %s --diagonalExpansion=10 --splitMatrixBiggerThanThis=3000 %s --gapGamma=%s --matchGamma=%s" % (
+            line, EXE, tref, tread, bioio.nameValue("loadHmm", hmm), 0.5, 0.0), "")
+        assert len(out) == 1                                                    # utils.py:588-589
+        pA = bioio.cigarReadFromString(out[0])
+        assert w["status"] == 0 and [(o.type, o.length) for o in pA.operationList] == w["ops"]
+        assert pA.score == pytest.approx(w["score"], abs=1e-6)
+        assert w["ops"] != [(op, n) for op, n in aR.cigar]                     # the realigner moved something
