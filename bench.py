@@ -503,7 +503,11 @@ def c3_job(env, n_reads, steps, warmup, from_files):
         total_cells = cells_rank
     if rank != 0:
         return None
-    mean = {k: float(np.mean([t[k] for t in tms])) for k in tms[0] if k != "cells"}
+    mean = {k: float(np.mean([t[k] for t in tms])) for k in tms[0] if k not in ("cells", "trace")}
+    if tms[-1].get("trace"):  # NPR_JOB_TRACE=1: the last step's phases per worker, seconds from the step's first event
+        base = min(ev[2] for ev in tms[-1]["trace"])
+        for ev in sorted(tms[-1]["trace"], key=lambda e: e[2]):
+            sys.stderr.write("[job trace] worker %d %-7s %8.1f .. %8.1f ms\n" % (ev[0], ev[1], (ev[2] - base) * 1e3, (ev[3] - base) * 1e3))
     sam_bytes = os.path.getsize(out_sam)
     res = last["results"]
     ok = int((res["status"] == 0).sum())

@@ -218,7 +218,8 @@ int32_t npr_align_stats(npr_ctx *ctx, int64_t n_reads, int64_t n_refs, const uin
  * every pair (refPos, readPos, p) of a selected read adds p to expect[(first row of its reference + refPos) * 4 + base] for
  * the read's base at readPos (A C G T; other bases add nothing) and sets seen[...].  use[i] != 0 selects read i (NULL: all) --
  * the caller's coverage sampling; the reference table is n_refs sequences of ref_len[k] positions, rows in that order.
- * fp64 atomics: sums agree with a sequential sum to rounding. */
+ * Accumulated in 64-bit fixed point (units of 2^-40): a sum is the exact sum of its fp32 terms whatever the order, so the
+ * table is the same from run to run and equals a sequential double-precision sum of the same pairs. */
 int32_t npr_batch_base_expectations(npr_batch *b, const uint8_t *use, int64_t n_refs, const int64_t *ref_len, double *expect,
                                     uint8_t *seen);
 
@@ -313,7 +314,7 @@ int64_t npr_format_cigars_packed(int64_t n, const int64_t *word_off, const int64
  * 50 k records per rank at once.  Record i = QNAME \t FLAG \t RNAME \t POS \t MAPQ \t CIGAR \t * \t 0 \t 0 \t SEQ \t * \n with
  * QNAME = qnames[qname_off[i] .. qname_off[i+1]), RNAME = entry ref_index[i] of the rnames list, POS = pos[i] (1-based, as
  * printed), FLAG = flag[i] (NULL: 0), MAPQ = mapq[i] (NULL: 255), CIGAR = the packed list i as in npr_format_cigars_packed
- * ("*" when empty), SEQ = seq[seq_off[i] .. seq_off[i+1]).  Record i lands at out[rec_off[i] .. rec_off[i+1]).  out == NULL:
+ * ("*" when empty), SEQ = seq[seq_off[i] .. seq_off[i+1]) ("*" when empty).  Record i lands at out[rec_off[i] .. rec_off[i+1]).  out == NULL:
  * only the offsets; returns the total length, NPR_ERR_CAPACITY when cap is smaller, NPR_ERR_INVALID for a negative
  * number or an op outside M/I/D.  Threaded host code. */
 int64_t npr_format_sam_records(int64_t n, const char *qnames, const int64_t *qname_off, const int32_t *flag, const char *rnames,

@@ -49,7 +49,7 @@ struct DeviceArena {
     static constexpr size_t kPad = 1024;
     std::mutex mu;
     char *F = nullptr;  // 8 bytes per cell
-    size_t cells = 0;
+    std::atomic<size_t> cells{0};  // (read without the mutex where only its size matters: staging must not wait for a DP pass)
     uint64_t epoch = 1;
     int users = 0;
 };
@@ -791,6 +791,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             c = use_tile ? kTileClass : (w <= 512 ? kFirstGeneric : (w <= 1024 ? kFirstGeneric + 1 : (w <= lds_max_w ? kFirstGeneric + 2 : kFirstGeneric + 3)));
         }
         cls_of[k] = static_cast<int8_t>(c);
+        // the stripe kernels address a stripe's rows (1 KiB each) with a 32-bit byte offset behind one descriptor: a stripe of
+        // 2^21 rows or more would wrap.  No stripe has more rows than its task has anti-diagonals.
+        if (kClassTab[c].kind == K_TILE && static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1 >= (int64_t(1) << 21))
+            b->read_status[seg[k].owner] = NPR_ERR_BAND_TOO_WIDE;
         if (kClassTab[c].kind == K_TILE) {
             tile_list.push_back(static_cast<int32_t>(k));
             tile_off_of[k] = stripe_entries;
@@ -895,11 +899,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
     // (sequences, band rows, control words and stripe tables are allocated already)
     const int64_t fixed = pair_total * 12 + ntasks * (int64_t)(sizeof(Task) + sizeof(TaskOut)) + (any_generic ? 0 : band_entries * 4);
-    size_t arena_now;
-    {
-        std::lock_guard<std::mutex> lock(ctx->arena->mu);
-        arena_now = ctx->arena->cells;
-    }
+    const size_t arena_now = ctx->arena->cells.load();
     const int64_t budget = static_cast<int64_t>((free_b + ctx->cache_bytes + arena_now * 8) * 0.9) - fixed;
     int64_t fit = INT32_MAX;
     if (b->slot_stride > 0) {
@@ -1016,7 +1016,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     // (at least one uniform region: npr_batch_dense and the generic E-step run any task there)
     b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(std::max<int64_t>(sum_grid, ntasks ? 1 : 0)) + static_cast<size_t>(tile_total);
-    {   // (waits for whatever another context's batch is running in the arena)
+    // The arena only grows, so a batch that fits what is there now goes on without the mutex -- staging the next batch must
+    // not wait for the DP pass of the current one, which holds it.  Growing it (or poisoning it) waits for whatever another
+    // context's batch is running there.
+    if (b->scratch_cells > ctx->arena->cells.load() || poison_byte() >= 0) {
         DeviceArena &ar = *ctx->arena;
         std::lock_guard<std::mutex> lock(ar.mu);
         if (b->scratch_cells > ar.cells) {
@@ -1449,11 +1452,7 @@ static int32_t batch_finish_impl(npr_batch *b) {
         for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 36 * std::min(b->ref_len[i], b->read_len[i]) + 128;
         scratch += 16 * b->pair_off[n];
         size_t mem_free = 0, mem_total = 0;
-        size_t arena_bytes;
-        {
-            std::lock_guard<std::mutex> lock(ctx->arena->mu);
-            arena_bytes = ctx->arena->cells * 8;
-        }
+        const size_t arena_bytes = ctx->arena->cells.load() * 8;
         if (static_cast<size_t>(scratch) <= arena_bytes ||
             (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && static_cast<size_t>(scratch) < mem_free / 2)) {
             const int32_t rc = device_mea(b);
@@ -2046,7 +2045,7 @@ int32_t npr_batch_base_expectations(npr_batch *b, const uint8_t *use, int64_t n_
             mask[i] = ok ? 1 : 0;
             target[i] = ok ? base[k] + b->gstart[2 * i] : 0;
         }
-        DevBuf<double> d_e;
+        DevBuf<unsigned long long> d_e;  // fixed-point sums (npr_stats.hip): exact, hence the same from run to run
         DevBuf<uint8_t> d_seen, d_use;
         DevBuf<int64_t> d_target;
         hipError_t e;
@@ -2060,9 +2059,15 @@ int32_t npr_batch_base_expectations(npr_batch *b, const uint8_t *use, int64_t n_
         ExpectArgs a{b->d_tasks.p, b->d_outs.p, static_cast<int32_t>(ntasks), b->d_px.p, b->d_py.p, b->d_pp.p, b->d_seq.p, d_use.p, d_target.p, d_e.p, d_seen.p};
         const int rc = launch_base_expectations(a, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_base_expectations launch", static_cast<hipError_t>(rc));
+        static_assert(sizeof(unsigned long long) == sizeof(double), "the caller's table doubles as the staging of the fixed-point sums");
         HIP_TRY(ctx, hipMemcpyAsync(expect, d_e.p, d_e.bytes(), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(seen, d_seen.p, d_seen.bytes(), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i < 4 * rows; ++i) {
+            unsigned long long fixed;
+            std::memcpy(&fixed, expect + i, sizeof(fixed));
+            expect[i] = static_cast<double>(fixed) / static_cast<double>(EXPECT_FIXED_ONE);
+        }
         return NPR_OK;
     } catch (const std::exception &) {
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_base_expectations: out of host memory");
@@ -2341,7 +2346,7 @@ int64_t npr_format_sam_records(int64_t n, const char *qnames, const int64_t *qna
                 if (n_ops[i] < 0 || pos[i] < 0 || (flag && flag[i] < 0) || (mapq && mapq[i] < 0) || ref_index[i] < 0) bad = 1;
                 const int64_t r = ref_index[i] < 0 ? 0 : ref_index[i];
                 len[i] = (qname_off[i + 1] - qname_off[i]) + digits(flag ? flag[i] : 0) + (rname_off[r + 1] - rname_off[r]) + digits(pos[i]) +
-                         digits(mapq ? mapq[i] : 255) + (k ? k : 1) + (seq_off[i + 1] - seq_off[i]) + 10 + 5;
+                         digits(mapq ? mapq[i] : 255) + (k ? k : 1) + std::max<int64_t>(seq_off[i + 1] - seq_off[i], 1) + 10 + 5;
             }
         });
         if (bad) return NPR_ERR_INVALID;
@@ -2372,6 +2377,7 @@ int64_t npr_format_sam_records(int64_t n, const char *qnames, const int64_t *qna
                     *w++ = code[cw & 3u];
                 }
                 std::memcpy(w, "\t*\t0\t0\t", 7), w += 7;
+                if (sl == 0) *w++ = '*';  // an empty SEQ is "*" in SAM
                 std::memcpy(w, seq + seq_off[i], static_cast<size_t>(sl)), w += sl;
                 std::memcpy(w, "\t*\n", 3), w += 3;
             }

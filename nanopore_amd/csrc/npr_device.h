@@ -226,6 +226,7 @@ struct StatsArgs {
     int32_t *out;            // [n_reads][NPR_STATS_WORDS]
 };
 int launch_align_stats(const StatsArgs &a, void *stream);
+constexpr float EXPECT_FIXED_ONE = 1099511627776.0f;  // 2^40
 struct ExpectArgs {
     const Task *tasks;
     const TaskOut *outs;
@@ -235,7 +236,7 @@ struct ExpectArgs {
     const uint8_t *seq;
     const uint8_t *use;     // per read: 0 = skip (NULL: all reads)
     const int64_t *target;  // per read: table row of reference position 0 of its window
-    double *expect;         // [positions][4]
+    unsigned long long *expect;  // [positions][4], fixed point: units of 1 / EXPECT_FIXED_ONE
     uint8_t *seen;          // [positions]
 };
 int launch_base_expectations(const ExpectArgs &a, void *stream);

@@ -124,8 +124,10 @@ __global__ void __launch_bounds__(WAVE) k_align_stats(StatsArgs a) {
 
 // Expected base counts per reference position (nanopore/analyses/marginAlignSnpCaller.py:150-155): every
 // posterior pair (x, y, p) of a selected read adds p to the count of the read's base y at reference position x.  The pairs
-// are where the DP kernels left them; a workgroup takes a task, its threads the task's pairs; fp64 atomics into a table of
-// 4 counts per reference position, plus a byte that says the position was seen at all.
+// are where the DP kernels left them; a workgroup takes a task, its threads the task's pairs; 64-bit integer atomics into a
+// table of 4 counts per reference position in fixed point (p * 2^40: exact for an fp32 p >= 2^-17, so a sum is the exact sum
+// of its terms whatever order the atomics land in -- the same bits from run to run, which fp64 atomics did not give),
+// plus a byte that says the position was seen at all.
 __global__ void __launch_bounds__(256) k_base_expectations(ExpectArgs a) {
     for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
         const Task &tk = a.tasks[t];
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256) k_base_expectations(ExpectArgs a) {
             const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
             const int code = a.seq[tk.y_off + (y - tk.ys)];
             a.seen[target + x] = 1;
-            if (code < 4) atomicAdd(a.expect + 4 * (target + x) + code, static_cast<double>(a.pp[tk.pair_off + i]));
+            if (code < 4) atomicAdd(a.expect + 4 * (target + x) + code, __float2ull_rz(a.pp[tk.pair_off + i] * EXPECT_FIXED_ONE));
         }
     }
 }

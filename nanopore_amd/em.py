@@ -73,6 +73,35 @@ def normalise(hmm, T_exp, E_exp, trainEmissions=True):
     return hmm
 
 
+def _collectiveDevice(device, group):
+    """Where a collective's tensor has to live: the caller's choice, else the rank's GPU under backend nccl (= RCCL, which
+    takes device tensors only), else the host."""
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return torch.device(device)
+    if str(dist.get_backend(group)) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _isRankZero(group=None):
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return True
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
+
+
+def _barrier(group=None):
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier(group=group)
+
+
 def allReduceExpectations(T, E, ll, device=None, group=None):
     """Sharded EM (one process per GPU, each with its own reads): the per-rank expected counts and log-likelihoods
     are summed over the ranks -- the one collective the training loop needs, 25 + 80 + 1 doubles per model slot per
@@ -85,9 +114,7 @@ def allReduceExpectations(T, E, ll, device=None, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return T, E, ll
     flat = np.concatenate([np.asarray(T).reshape(-1), np.asarray(E).reshape(-1), np.asarray(ll).reshape(-1)])
-    t = torch.from_numpy(flat.copy())
-    if device is not None:
-        t = t.to(device)
+    t = torch.from_numpy(flat.copy()).to(_collectiveDevice(device, group))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     flat = t.cpu().numpy()
     nT, nE = np.asarray(T).size, np.asarray(E).size
@@ -105,9 +132,7 @@ def broadcastModel(hmm, device=None, group=None, src=0):
         return hmm
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return hmm
-    t = torch.tensor(list(hmm.transitions) + list(hmm.emissions) + [float(hmm.likelihood)], dtype=torch.float64)
-    if device is not None:
-        t = t.to(device)
+    t = torch.tensor(list(hmm.transitions) + list(hmm.emissions) + [float(hmm.likelihood)], dtype=torch.float64).to(_collectiveDevice(device, group))
     dist.broadcast(t, src=src, group=group)
     v = t.cpu().numpy()
     nT = len(hmm.transitions)
@@ -163,7 +188,8 @@ def expectationMaximisationTrials(batch, outputModel, options, startHmm=None, lo
     """`options.trials` independent EM runs (random starts when options.randomStart), the trial with the highest
     final likelihood is written to `outputModel`; the XML summary goes to options.outputXMLModelFile.  Under
     torch.distributed (every rank a shard of the reads) all ranks walk through the same models and pick the same trial:
-    each trial starts from rank 0's model and every likelihood is the sum over the ranks."""
+    each trial starts from rank 0's model and every likelihood is the sum over the ranks; the files (model, trial models,
+    XML) are written by rank 0 alone, and every rank returns once they exist."""
     rng = np.random.default_rng(options.seed)
     trialHmms, running = [], []
     for trial in range(options.trials):
@@ -180,10 +206,12 @@ def expectationMaximisationTrials(batch, outputModel, options, startHmm=None, lo
         rl.append(hmm.likelihood)
         trialHmms.append(hmm)
         running.append(rl)
-        if options.outputTrialHmms:
+        if options.outputTrialHmms and _isRankZero():
             hmm.write("%s_%d" % (outputModel, trial))
     best = max(trialHmms, key=lambda h: h.likelihood)
-    best.write(outputModel)
-    if options.outputXMLModelFile:
-        writeXML(options.outputXMLModelFile, trialHmms, running)
+    if _isRankZero():  # one writer: the ranks hold identical models, and a shared filesystem has one file per path
+        best.write(outputModel)
+        if options.outputXMLModelFile:
+            writeXML(options.outputXMLModelFile, trialHmms, running)
+    _barrier()
     return best, trialHmms, running

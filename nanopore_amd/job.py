@@ -30,6 +30,7 @@ from . import dist as npd
 
 CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", 100_000_000))  # ~12 k reads of 8 kb: two per resident wavefront
 WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 2))
+TRACE = os.environ.get("NPR_JOB_TRACE") is not None  # timings["trace"]: (phase, start, end) per chunk, seconds (tools/job_trace.py)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -205,6 +206,8 @@ def _finish_batch(b, want_stats, tm, t0, t1):
     finally:
         b.close()
     t4 = time.perf_counter()
+    if TRACE:
+        tm["trace"] += [("stage", t0, t1), ("run", t1, t2), ("finish", t2, t3), ("fetch", t3, t4)]
     tm["stage_s"] += t1 - t0
     tm["run_s"] += t2 - t1
     tm["finish_s"] += t3 - t2
@@ -263,7 +266,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     """Records lo .. hi of `src` through the contexts `ctxs` (one worker thread each), chunks handed to `sink(block)` in
     record order as they complete.  Returns (results[hi - lo], n_ops[hi - lo], stats or None, timings)."""
     chunks = chunk_bounds(src.lengths(), lo, hi, chunk_bases, len(ctxs))
-    tms = [dict(stage_s=0.0, run_s=0.0, finish_s=0.0, fetch_s=0.0, format_s=0.0, kernel_ms=0.0, cells=0) for _ in ctxs]
+    tms = [dict(stage_s=0.0, run_s=0.0, finish_s=0.0, fetch_s=0.0, format_s=0.0, kernel_ms=0.0, cells=0, trace=[]) for _ in ctxs]
     done = queue.Queue()
     stop = threading.Event()
 
@@ -277,6 +280,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 t0 = time.perf_counter()
                 block = src.format_block(a, b, off, words)
                 tms[j]["format_s"] += time.perf_counter() - t0
+                if TRACE:
+                    tms[j]["trace"].append(("format", t0, time.perf_counter()))
                 done.put((k, block, res, off[1:] - off[:-1], stats))
         except BaseException as e:  # handed to the caller's thread
             done.put((-1, e, None, None, None))
@@ -307,7 +312,9 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     n_ops = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, dtype=np.int64)
     stats = np.concatenate([p[2] for p in parts]) if (parts and want_stats) else (np.zeros((0, _lib.STATS_WORDS), dtype=np.int32) if want_stats else None)
     assert len(results) == n
-    tm = {key: sum(t[key] for t in tms) for key in tms[0]}
+    tm = {key: sum(t[key] for t in tms) for key in tms[0] if key != "trace"}
+    if TRACE:
+        tm["trace"] = [(j,) + ev for j, t in enumerate(tms) for ev in t["trace"]]
     tm["sink_s"] = sink_s
     tm["chunks"] = len(chunks)
     tm["workers"] = len(threads)

@@ -98,8 +98,11 @@ def _em_trials_worker(rank, world, port, tmp, q):
     opt = em.Options()
     opt.trials, opt.iterations, opt.randomStart, opt.seed = 3, 2, True, None   # seed None: every rank draws its own start
     opt.outputXMLModelFile = None
-    out = os.path.join(tmp, "model_rank%d.txt" % rank)
+    out = os.path.join(tmp, "model.txt")   # ONE path, as on a shared filesystem: rank 0 writes it, every rank returns once it exists
     best, trials, running = em.expectationMaximisationTrials(_FakeBatch(rank), out, opt)
+    own = os.path.join(tmp, "own_%d.txt" % rank)
+    best.write(own)
+    assert open(out).read() == open(own).read()   # the file is the model THIS rank chose too
     q.put((rank, open(out).read(), [h.likelihood for h in trials], running))
     dist.barrier()
     dist.destroy_process_group()
