@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnprealign.so")
+LIB_PATH = os.environ.get("NPR_LIB") or os.path.join(_HERE, "libnprealign.so")  # NPR_LIB: a variant build (bring-up, tools/variant_bench.py)
 
 OK = 0
 ERR_INVALID, ERR_ZERO_PROB, ERR_CAPACITY, ERR_MODEL, ERR_NO_DEVICE, ERR_HIP, ERR_BAND_TOO_WIDE, ERR_NOMEM, \

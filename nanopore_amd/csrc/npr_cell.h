@@ -51,7 +51,10 @@ __device__ __forceinline__ void normalise(Cell &c, int eref) {
 // exponent spread), and half of the renormalisations -- 12 of the ~55 VALU instructions of a cell -- are not issued.
 // (Skipping every second anti-diagonal instead would not do: match moves step by two, so the even anti-diagonals
 // would never renormalise along a run of matches.)  The CPU mirror follows the same rule.
-__host__ __device__ constexpr bool norm_diag(int d) { return (d & 2) == 0; }
+#ifndef NPR_NORM_MASK
+#define NPR_NORM_MASK 2
+#endif
+__host__ __device__ constexpr bool norm_diag(int d) { return (d & NPR_NORM_MASK) == 0; }
 
 template <bool NORM>
 __device__ __forceinline__ void settle(Cell &c, int eref) {
@@ -94,14 +97,18 @@ __device__ __forceinline__ Cell fwd_cell(const Trans &t, const Cell &L, const Ce
     c.m = (fM * em) * a;
     a = t.msx * L.m;
     a = __builtin_fmaf(t.sxsx, L.sx, a);
+#ifndef NPR_NO_SHORT_SWITCH
     a = __builtin_fmaf(t.sysx, L.sy, a);
+#endif
     c.sx = (fL * exs) * a;
     a = t.mlx * L.m;
     a = __builtin_fmaf(t.lxlx, L.lx, a);
     c.lx = (fL * exl) * a;
     a = t.msy * U.m;
     a = __builtin_fmaf(t.sysy, U.sy, a);
+#ifndef NPR_NO_SHORT_SWITCH
     a = __builtin_fmaf(t.sxsy, U.sx, a);
+#endif
     c.sy = (fU * eys) * a;
     a = t.mly * U.m;
     a = __builtin_fmaf(t.lyly, U.ly, a);
@@ -131,11 +138,15 @@ __device__ __forceinline__ Cell bwd_cell(const Trans &t, const Cell &Ms, const C
     c.m = b;
     b = t.sxm * am;
     b = __builtin_fmaf(t.sxsx, asx, b);
+#ifndef NPR_NO_SHORT_SWITCH
     b = __builtin_fmaf(t.sxsy, asy, b);
+#endif
     c.sx = b;
     b = t.sym * am;
     b = __builtin_fmaf(t.sysy, asy, b);
+#ifndef NPR_NO_SHORT_SWITCH
     b = __builtin_fmaf(t.sysx, asx, b);
+#endif
     c.sy = b;
     b = t.lxm * am;
     b = __builtin_fmaf(t.lxlx, alx, b);

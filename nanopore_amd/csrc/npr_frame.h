@@ -255,7 +255,11 @@ template <int R>
 __device__ __forceinline__ void emissions(const StepEnv &E, const Bases<R> &bx, const Bases<R> &by, int r, float &em,
                                           float &exs, float &exl, float &eys, float &eyl) {
     constexpr int OFF_EM = offsetof(DevModel, em), OFF_EX = offsetof(DevModel, ex), OFF_EY = offsetof(DevModel, ey);
+#ifdef NPR_EMIDX_MAD24
+    em = *reinterpret_cast<const float *>(E.ltab + OFF_EM + (__umul24(static_cast<unsigned>(bx.b[r]), 5u) + static_cast<unsigned>(by.b[r])));
+#else
     em = *reinterpret_cast<const float *>(E.ltab + OFF_EM + 5 * bx.b[r] + by.b[r]);
+#endif
     exs = *reinterpret_cast<const float *>(E.ltab + OFF_EX + 20 + bx.b[r]);
     exl = *reinterpret_cast<const float *>(E.ltab + OFF_EX + 60 + bx.b[r]);
     eys = *reinterpret_cast<const float *>(E.ltab + OFF_EY + 40 + by.b[r]);

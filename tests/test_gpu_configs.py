@@ -77,7 +77,15 @@ def test_config2_every_read_against_the_oracle(gpu_ctx):
     assert np.allclose(res["loglik"], m32["total_ll"], rtol=1e-12, atol=1e-9)
     assert np.allclose(res["loglik"], m64["total_ll"], rtol=2e-6)
     assert np.abs(res["score"] - m64["score"]).max() < 1e-4
-    assert same64 >= 995  # exact-tie placements may differ between fp32 and fp64
+    # fp32 (device = mirror, bit for bit) against the fp64 oracle: exact-tie placements may differ.  The
+    # count is printed (pytest -s / the captured output of a failure); for scale: the reference's own piecewise log-add, if
+    # recalled right, moves 262 of these 1000 cigars against exact arithmetic (tools/logadd_risk.py)
+    ties = [i for i in range(1000) if not np.array_equal(ops[off[i]:off[i + 1]], m64["ops"][i])]
+    print("configs[1]: %d/1000 cigars identical to the fp64 oracle's; differing reads: %s" % (same64, ties))
+    for i in ties:  # a tie moves an indel along a repeat: same spans, same number of aligned pairs +- a handful, scores within 1e-4
+        a, b_ = ops[off[i]:off[i + 1]], m64["ops"][i]
+        assert abs(int(a[a[:, 0] == 0, 1].sum()) - int(b_[b_[:, 0] == 0, 1].sum())) <= 8
+    assert same64 >= 995
 
 
 def test_config3_shared_contig_50k_reads(gpu_ctx):

@@ -11,6 +11,7 @@ ctx = R.Context(0); ctx.set_hmm(h)
 P = R.make_params(band_mode=1, fixed_width=W) if W > 0 else R.make_params(band_mode=0, split_threshold=300)  # the trainer's own options (utils.py:511)
 b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
 st = b.stats()
+print('class cells', [int(v) for v in b.class_stats()[1]], flush=True)
 ms = min(b.run() for _ in range(2))
 t0=time.time(); T,E,ll,kms = b.expectations(); t1=time.time()
 T,E,ll,kms2 = b.expectations()

@@ -10,5 +10,6 @@ ctx = R.Context(0); ctx.set_hmm(h)
 P = R.make_params(band_mode=1, fixed_width=W) if W > 0 else R.make_params(band_mode=0, max_pairs_per_base=24)  # W = 0: the reference's own band
 b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
 st = b.stats()
+print('class cells', [int(v) for v in b.class_stats()[1]], flush=True)
 ms = [b.run() for _ in range(2)]
 print('cells', st['cells'], 'ms', ms, flush=True)
