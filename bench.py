@@ -477,12 +477,19 @@ def c3_job(env, n_reads, steps, warmup, from_files):
     for c in ctxs:
         c.set_hmm(h)
     params = make_params(W)
-    out_sam = os.path.join(tmp, "realigned.sam")  # one file, written by all ranks
+    step_no = [0]
+    out_sam = None
 
     def one():
+        # a fresh output path per step, as a job has: truncating the previous step's 0.6 GB of page cache is not part of it
+        nonlocal out_sam
+        step_no[0] += 1
         if from_files:
+            out_sam = os.path.join(tmp, "realigned_%d.sam" % step_no[0])  # one file, written by all ranks
             return job.realign_sam_file(sam, out_sam, fa, params=params, gpu=gpu, set_models=False, coll_device=coll_dev)
-        return job.run_job(ctx, params, w, out_dir=tmp, device=coll_dev)
+        out_dir = os.path.join(tmp, "out_%d" % step_no[0])
+        out_sam = os.path.join(out_dir, "realigned.sam")
+        return job.run_job(ctx, params, w, out_dir=out_dir, device=coll_dev)
 
     last = None
     for _ in range(warmup):

@@ -8,11 +8,13 @@ files gathered in input order and spliced into a copy of the input SAM (utils.py
   data-path collective: a rank writes the records of its range at its own offset of the one output file (an all_gather of
   the block sizes gives the offsets); one small gather (RCCL under backend nccl) brings the per-read results to rank 0 for
   the summary;
-* a rank cuts its range into chunks of about `CHUNK_BASES` read bases and keeps TWO in flight: two worker threads, each
-  with its own realigner context (stream, scratch arena) on the rank's GPU, take the chunks alternately -- stage (plan +
-  H2D + device planner), DP, finish (MEA chain + cigar on the device), splice / format of the chunk's SAM records -- so the
-  host phases of one chunk run under the DP sweep of the other (ctypes releases the GIL inside the C ABI); the main
-  thread writes the finished blocks in order while the workers go on.
+* a rank cuts its range into chunks of about `CHUNK_BASES` read bases and keeps `WORKERS` (3) of them in flight: worker
+  threads, each with its own realigner context (stream, staging buffers) on the rank's GPU, take the chunks in turn --
+  stage (plan + H2D + device planner), DP, finish (MEA chain + cigar on the device), splice / format of the chunk's SAM
+  records -- so the host phases of one chunk, and the staging of the next, run under the DP sweep of a third (ctypes
+  releases the GIL inside the C ABI; the contexts of a device share its forward scratch, whose mutex lets one DP pass or
+  one MEA stage run at a time -- each fills the chip anyway); the main thread writes the finished blocks in order while
+  the workers go on.
 
 `realign_sam_file` is what `analyses.utils.realignSamFile` (the plugin surface: AbstractMapper.realignSamFile,
 realignSamFileTargetFn) runs; `run_job` is the same pipeline over resident synthetic arrays (`bench.py --workload c3`).
@@ -29,7 +31,7 @@ from . import _lib
 from . import dist as npd
 
 CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", 100_000_000))  # ~12 k reads of 8 kb: two per resident wavefront
-WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 2))
+WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 3))  # batches in flight: one in its DP, one being finished / written, one being staged
 TRACE = os.environ.get("NPR_JOB_TRACE") is not None  # timings["trace"]: (phase, start, end) per chunk, seconds (tools/job_trace.py)
 
 
