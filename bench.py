@@ -511,10 +511,10 @@ def c3_job(env, n_reads, steps, warmup, from_files):
     if rank != 0:
         return None
     mean = {k: float(np.mean([t[k] for t in tms])) for k in tms[0] if k not in ("cells", "trace")}
-    if tms[-1].get("trace"):  # NPR_JOB_TRACE=1: the last step's phases per worker, seconds from the step's first event
-        base = min(ev[2] for ev in tms[-1]["trace"])
-        for ev in sorted(tms[-1]["trace"], key=lambda e: e[2]):
-            sys.stderr.write("[job trace] worker %d %-7s %8.1f .. %8.1f ms\n" % (ev[0], ev[1], (ev[2] - base) * 1e3, (ev[3] - base) * 1e3))
+    if tms[-1].get("trace"):  # NPR_JOB_TRACE=1: the last step's phases, milliseconds from the step's first event
+        base = min(ev[1] for ev in tms[-1]["trace"])
+        for ev in sorted(tms[-1]["trace"], key=lambda e: e[1]):
+            sys.stderr.write("[job trace] %-7s %8.1f .. %8.1f ms\n" % (ev[0], (ev[1] - base) * 1e3, (ev[2] - base) * 1e3))
     sam_bytes = os.path.getsize(out_sam)
     res = last["results"]
     ok = int((res["status"] == 0).sum())
@@ -538,19 +538,19 @@ def c3_job(env, n_reads, steps, warmup, from_files):
         "config": {"workload": "BASELINE.json configs[2]/[3]: one set of %d synthetic ~8kb reads on one shared 4.6 Mb contig "
                                "(local records, POS = window start), band 200, blasr_hmm_0, sharded over the ranks into contiguous "
                                "ranges balanced by record length (dist.shard_ranges)" % n_reads,
-                   "reads": n_reads, "band": W, "cells": total_cells, "parallelism": "one read set sharded x%d, two batches in flight per rank" % world,
+                   "reads": n_reads, "band": W, "cells": total_cells, "parallelism": "one read set sharded x%d, %d batches in flight per rank" % (world, job.WORKERS),
                    "input_bytes": in_bytes, "output_bytes": sam_bytes},
         "reads_per_s": n_reads * steps / elapsed,
         "ok_reads": ok,
-        "step": ("per rank: map SAM + FASTA, parse its shard (native), then chunks of ~12 k reads through two contexts on its GPU (stage = plan + pack + "
-                 "H2D + device planner | DP | finish = MEA chain + cigar | splice of the records' bytes), blocks written at the rank's offset of the one "
-                 "output; per-read results gathered to rank 0 (RCCL) inside the timed region") if from_files else
+        "step": ("per rank: map SAM + FASTA, parse its shard (native), then chunks of ~12 k reads as a pipeline on its GPU (stage = plan + pack + "
+                 "H2D + device planner | DP | finish = MEA chain + cigar | fetch + splice of the records' bytes: one thread per phase), blocks written at "
+                 "the rank's offset of the one output; per-read results gathered to rank 0 (RCCL) inside the timed region") if from_files else
                 "per rank: the same pipeline over arrays resident in host memory, records formatted natively",
         "rank0_phase_seconds": mean,
         "dp_share_of_wall": (kms * 1e-3) / wall,
         "dp_sweep_only_rank0": {"value": cells_rank / (kms * 1e-3), "unit": "cells/s", "ms": kms},
-        "note": "phase seconds are sums over the rank's two worker threads (they overlap each other); dp_share_of_wall = HIP-event time of the "
-                "DP launches / wall time of a step",
+        "note": "phase seconds are sums over the step's chunks (the phases of different chunks overlap; a DP pass or MEA stage waiting for the "
+                "device's shared scratch counts in its phase); dp_share_of_wall = HIP-event time of the DP launches / wall time of a step",
     }
 
 

@@ -8,13 +8,13 @@ files gathered in input order and spliced into a copy of the input SAM (utils.py
   data-path collective: a rank writes the records of its range at its own offset of the one output file (an all_gather of
   the block sizes gives the offsets); one small gather (RCCL under backend nccl) brings the per-read results to rank 0 for
   the summary;
-* a rank cuts its range into chunks of about `CHUNK_BASES` read bases and keeps `WORKERS` (3) of them in flight: worker
-  threads, each with its own realigner context (stream, staging buffers) on the rank's GPU, take the chunks in turn --
-  stage (plan + H2D + device planner), DP, finish (MEA chain + cigar on the device), splice / format of the chunk's SAM
-  records -- so the host phases of one chunk, and the staging of the next, run under the DP sweep of a third (ctypes
-  releases the GIL inside the C ABI; the contexts of a device share its forward scratch, whose mutex lets one DP pass or
-  one MEA stage run at a time -- each fills the chip anyway); the main thread writes the finished blocks in order while
-  the workers go on.
+* a rank cuts its range into chunks of about `CHUNK_BASES` read bases and runs them as a pipeline with `WORKERS` (3) in
+  flight, one thread per phase: stage (plan + pack + H2D + device planner) -> DP -> finish (MEA chain + cigar on the
+  device) -> fetch + splice / format of the chunk's SAM records -> the caller's thread writes the blocks in order.  Chunk k
+  lives in realigner context k mod 3 (stream, staging buffers) on the rank's GPU, so the stager runs up to two chunks ahead
+  of the DP and the host phases of one chunk run under the DP sweep of another (ctypes releases the GIL inside the C
+  ABI; the contexts of a device share its forward scratch, whose mutex lets one DP pass or one MEA stage run at a time
+  -- each fills the chip anyway).
 
 `realign_sam_file` is what `analyses.utils.realignSamFile` (the plugin surface: AbstractMapper.realignSamFile,
 realignSamFileTargetFn) runs; `run_job` is the same pipeline over resident synthetic arrays (`bench.py --workload c3`).
@@ -31,7 +31,7 @@ from . import _lib
 from . import dist as npd
 
 CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", 100_000_000))  # ~12 k reads of 8 kb: two per resident wavefront
-WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 3))  # batches in flight: one in its DP, one being finished / written, one being staged
+WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 3))  # chunks in flight (contexts per GPU): one in its DP, one being finished / fetched, one staged ahead
 TRACE = os.environ.get("NPR_JOB_TRACE") is not None  # timings["trace"]: (phase, start, end) per chunk, seconds (tools/job_trace.py)
 
 
@@ -195,48 +195,18 @@ def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
-def _finish_batch(b, want_stats, tm, t0, t1):
-    try:
-        kms = b.run()
-        t2 = time.perf_counter()
-        b.finish()
-        t3 = time.perf_counter()
-        res = b.results()
-        off, words = b.ops_packed()
-        stats = b.align_stats() if want_stats else None
-        st = b.stats()
-    finally:
-        b.close()
-    t4 = time.perf_counter()
-    if TRACE:
-        tm["trace"] += [("stage", t0, t1), ("run", t1, t2), ("finish", t2, t3), ("fetch", t3, t4)]
-    tm["stage_s"] += t1 - t0
-    tm["run_s"] += t2 - t1
-    tm["finish_s"] += t3 - t2
-    tm["fetch_s"] += t4 - t3
-    tm["kernel_ms"] += kms
-    return res, off, words, stats, int(st["cells"])
+def _fetch(b, want_stats):
+    res = b.results()
+    off, words = b.ops_packed()
+    stats = b.align_stats() if want_stats else None
+    return res, off, words, stats
 
 
-def _realign_range(ctx, src, params, lo, hi, want_stats, tm):
-    """stage + run + finish of records lo .. hi on one context.  A range the device cannot hold (NPR_ERR_NOMEM: the
-    reference's per-read jobs have no such limit) is halved and retried; reads whose sparse posterior list overflowed its
-    capacity (NPR_ERR_CAPACITY: a diffuse model can put up to 1 / threshold pairs on a base) run again with a four times
-    larger `max_pairs_per_base` until they fit, as Context.realign does.  -> (results, ops_off, words, stats or None)"""
+def _rerun_overflowed(ctx, src, params, lo, res, off, words, stats, want_stats, tm):
+    """Reads whose sparse posterior list overflowed its capacity (NPR_ERR_CAPACITY: a diffuse model can put up to
+    1 / threshold pairs on a base) run again with a four times larger `max_pairs_per_base` until they fit, as
+    Context.realign does; their results and cigars replace the failed ones."""
     from . import realign
-    t0 = time.perf_counter()
-    try:
-        b = src.stage(ctx, params, lo, hi)
-    except realign.NprError as e:
-        if e.code != realign.ERR_NOMEM or hi - lo < 2:
-            raise
-        mid = (lo + hi) // 2
-        r1, o1, w1, s1 = _realign_range(ctx, src, params, lo, mid, want_stats, tm)
-        r2, o2, w2, s2 = _realign_range(ctx, src, params, mid, hi, want_stats, tm)
-        return (np.concatenate([r1, r2]), np.concatenate([o1, o1[-1] + o2[1:]]), np.concatenate([w1, w2]),
-                None if s1 is None else np.concatenate([s1, s2]))
-    res, off, words, stats, cells = _finish_batch(b, want_stats, tm, t0, time.perf_counter())
-    tm["cells"] += cells
     per_base = params.max_pairs_per_base if params.max_pairs_per_base > 0 else 6
     limit = int(1.0 / max(params.posterior_threshold, 1e-6)) + 1
     while per_base < limit:
@@ -246,9 +216,13 @@ def _realign_range(ctx, src, params, lo, hi, want_stats, tm):
         per_base = min(4 * per_base, limit)
         p2 = realign.Params.from_buffer_copy(params)
         p2.max_pairs_per_base = per_base
-        t0 = time.perf_counter()
         b = src.stage_records(ctx, p2, lo + again)
-        r2, o2, w2, s2, _ = _finish_batch(b, want_stats, tm, t0, time.perf_counter())
+        try:
+            tm["kernel_ms"] += b.run()
+            b.finish()
+            r2, o2, w2, s2 = _fetch(b, want_stats)
+        finally:
+            b.close()
         res[again] = r2
         if want_stats:
             stats[again] = s2
@@ -265,61 +239,158 @@ def _realign_range(ctx, src, params, lo, hi, want_stats, tm):
 
 
 def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=None):
-    """Records lo .. hi of `src` through the contexts `ctxs` (one worker thread each), chunks handed to `sink(block)` in
-    record order as they complete.  Returns (results[hi - lo], n_ops[hi - lo], stats or None, timings)."""
-    chunks = chunk_bounds(src.lengths(), lo, hi, chunk_bases, len(ctxs))
-    tms = [dict(stage_s=0.0, run_s=0.0, finish_s=0.0, fetch_s=0.0, format_s=0.0, kernel_ms=0.0, cells=0, trace=[]) for _ in ctxs]
-    done = queue.Queue()
-    stop = threading.Event()
+    """Records lo .. hi of `src` as a pipeline of chunks over the contexts `ctxs`, one thread per phase:
 
-    def worker(j):
-        try:
-            for k in range(j, len(chunks), len(ctxs)):
+        stager (band planning + pack + H2D + device planner)  ->  DP pass  ->  finish (MEA chain + cigar on the device)
+        ->  fetch + splice / format of the chunk's records  ->  `sink(block)` on the caller's thread, in record order.
+
+    Chunk k uses context k mod len(ctxs) from its staging to its close, so len(ctxs) chunks are in flight and the stager
+    runs that far ahead of the DP; the DP passes and MEA stages of different chunks take turns on the device's shared
+    scratch (its mutex), everything else overlaps them.  A chunk the device cannot hold (NPR_ERR_NOMEM: the reference's
+    per-read jobs have no such limit) is halved and staged again.  Returns (results[hi - lo], n_ops[hi - lo], stats or None,
+    timings)."""
+    from . import realign
+    pending = list(reversed(chunk_bounds(src.lengths(), lo, hi, chunk_bases, len(ctxs))))  # a stack: splits go back on top
+    n_planned = len(pending)
+    tm = dict(stage_s=0.0, run_s=0.0, finish_s=0.0, fetch_s=0.0, format_s=0.0, kernel_ms=0.0, cells=0, trace=[])
+    free = [threading.Semaphore(1) for _ in ctxs]
+    q_run, q_fin, q_out, done = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
+    stop = threading.Event()
+    END = object()
+
+    def note(label, t0, t1):
+        tm[label + "_s"] += t1 - t0
+        if TRACE:
+            tm["trace"].append((label, t0, t1))
+
+    def guarded(fn, downstream):
+        def run():
+            try:
+                fn()
+            except BaseException as e:  # handed to the caller's thread
+                stop.set()
+                done.put(e)
+            finally:
+                downstream.put(END)
+        return run
+
+    def stager():
+        k = 0
+        while pending and not stop.is_set():
+            a, b_ = pending.pop()
+            j = k % len(ctxs)
+            while not free[j].acquire(timeout=0.2):
                 if stop.is_set():
                     return
-                a, b = chunks[k]
-                res, off, words, stats = _realign_range(ctxs[j], src, params, a, b, want_stats, tms[j])
-                t0 = time.perf_counter()
-                block = src.format_block(a, b, off, words)
-                tms[j]["format_s"] += time.perf_counter() - t0
-                if TRACE:
-                    tms[j]["trace"].append(("format", t0, time.perf_counter()))
-                done.put((k, block, res, off[1:] - off[:-1], stats))
-        except BaseException as e:  # handed to the caller's thread
-            done.put((-1, e, None, None, None))
+            t0 = time.perf_counter()
+            try:
+                batch = src.stage(ctxs[j], params, a, b_)
+            except realign.NprError as e:
+                free[j].release()
+                if e.code != realign.ERR_NOMEM or b_ - a < 2:
+                    raise
+                mid = (a + b_) // 2
+                pending.extend([(mid, b_), (a, mid)])
+                continue
+            note("stage", t0, time.perf_counter())
+            q_run.put((j, a, b_, batch))
+            k += 1
 
-    threads = [threading.Thread(target=worker, args=(j,), daemon=True) for j in range(min(len(ctxs), max(len(chunks), 1)))]
+    def runner():
+        while True:
+            item = q_run.get()
+            if item is END:
+                return
+            j, a, b_, batch = item
+            if stop.is_set():
+                batch.close(), free[j].release()
+                continue
+            t0 = time.perf_counter()
+            try:
+                tm["kernel_ms"] += batch.run()
+            except BaseException:
+                batch.close(), free[j].release()
+                raise
+            note("run", t0, time.perf_counter())
+            q_fin.put(item)
+
+    def finisher():
+        while True:
+            item = q_fin.get()
+            if item is END:
+                return
+            j, a, b_, batch = item
+            if stop.is_set():
+                batch.close(), free[j].release()
+                continue
+            t0 = time.perf_counter()
+            try:
+                batch.finish()
+            except BaseException:
+                batch.close(), free[j].release()
+                raise
+            note("finish", t0, time.perf_counter())
+            q_out.put(item)
+
+    def fetcher():
+        while True:
+            item = q_out.get()
+            if item is END:
+                return
+            j, a, b_, batch = item
+            t0 = time.perf_counter()
+            try:
+                if stop.is_set():
+                    continue
+                res, off, words, stats = _fetch(batch, want_stats)
+                tm["cells"] += int(batch.stats()["cells"])
+            finally:
+                batch.close()
+                if stop.is_set():
+                    free[j].release()
+            try:
+                res, off, words, stats = _rerun_overflowed(ctxs[j], src, params, a, res, off, words, stats, want_stats, tm)
+            finally:
+                free[j].release()
+            t1 = time.perf_counter()
+            note("fetch", t0, t1)
+            block = src.format_block(a, b_, off, words)
+            note("format", t1, time.perf_counter())
+            done.put((block, res, off[1:] - off[:-1], stats))
+
+    threads = [threading.Thread(target=guarded(fn, q), daemon=True)
+               for fn, q in ((stager, q_run), (runner, q_fin), (finisher, q_out), (fetcher, done))]
     for t in threads:
         t.start()
-    ready, parts, nxt, sink_s = {}, [], 0, 0.0
-    try:
-        while nxt < len(chunks):
-            k, block, res, nops, stats = done.get()
-            if k < 0:
-                raise block
-            ready[k] = (block, res, nops, stats)
-            while nxt in ready:
-                block, res, nops, stats = ready.pop(nxt)
-                t0 = time.perf_counter()
-                sink(block)
-                sink_s += time.perf_counter() - t0
-                parts.append((res, nops, stats))
-                nxt += 1
-    finally:
-        stop.set()
-        for t in threads:
-            t.join()
+    parts, sink_s, error = [], 0.0, None
+    while True:
+        item = done.get()
+        if item is END:
+            break
+        if isinstance(item, BaseException):
+            error = error or item
+            continue
+        if error is None:
+            block, res, nops, stats = item
+            t0 = time.perf_counter()
+            sink(block)
+            sink_s += time.perf_counter() - t0
+            parts.append((res, nops, stats))
+    for t in threads:
+        t.join()
+    if error is not None:
+        raise error
     n = hi - lo
     results = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, dtype=_lib.RESULT_DTYPE)
     n_ops = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, dtype=np.int64)
     stats = np.concatenate([p[2] for p in parts]) if (parts and want_stats) else (np.zeros((0, _lib.STATS_WORDS), dtype=np.int32) if want_stats else None)
     assert len(results) == n
-    tm = {key: sum(t[key] for t in tms) for key in tms[0] if key != "trace"}
-    if TRACE:
-        tm["trace"] = [(j,) + ev for j, t in enumerate(tms) for ev in t["trace"]]
+    if not TRACE:
+        del tm["trace"]
     tm["sink_s"] = sink_s
-    tm["chunks"] = len(chunks)
-    tm["workers"] = len(threads)
+    tm["chunks"] = len(parts)
+    tm["planned_chunks"] = n_planned
+    tm["in_flight"] = len(ctxs)
     return results, n_ops, stats, tm
 
 

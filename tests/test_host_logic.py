@@ -169,7 +169,7 @@ def test_sam_records_are_formatted_natively_like_the_python_writer():
     def render(i, f, q):
         cig = b"".join(b"%d%s" % (int(wd) >> 2, b"MID"[int(wd) & 3:(int(wd) & 3) + 1]) for wd in words[word_off[i]:word_off[i] + nops[i]]) or b"*"
         return b"\t".join((qnames[i], b"%d" % f, ref_names[ref_index[i]], b"%d" % pos[i], b"%d" % q, cig, b"*", b"0", b"0",
-                           seq[seq_off[i]:seq_off[i + 1]].tobytes(), b"*")) + b"\n"
+                           seq[seq_off[i]:seq_off[i + 1]].tobytes() or b"*", b"*")) + b"\n"   # an empty SEQ is "*" in SAM
 
     buf, off = R.format_sam_records(qnames, ref_names, ref_index, pos, word_off, nops, words, seq, seq_off)
     assert buf.tobytes() == b"".join(render(i, 0, 255) for i in range(n))
