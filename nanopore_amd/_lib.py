@@ -18,6 +18,7 @@ ERR_INVALID, ERR_ZERO_PROB, ERR_CAPACITY, ERR_MODEL, ERR_NO_DEVICE, ERR_HIP, ERR
 OP_M, OP_I, OP_D = 0, 1, 2
 BAND_ANCHOR, BAND_FIXED = 0, 1
 MODE_REALIGN, MODE_RESCORE_ORIGINAL, MODE_ALL_POSTERIORS, MODE_EXPECTATIONS = 0, 1, 2, 3
+OPT_OVERLAP = 1
 STATS_WORDS = 40  # NPR_STATS_WORDS
 MAX_MODELS = 8
 E_DEAD = -(1 << 28)
@@ -88,7 +89,7 @@ EXPORTS = [
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
     "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_format_cigars_packed", "npr_format_sam_records", "npr_chain_hits", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
     "npr_sam_index", "npr_sam_parse", "npr_sam_guides", "npr_sam_splice", "npr_fasta_index", "npr_fasta_pack", "npr_fastq_index",
-    "npr_batch_create_spans", "npr_chain_merge",
+    "npr_batch_create_spans", "npr_chain_merge", "npr_ctx_option",
 ]
 
 _lib = None
@@ -113,6 +114,8 @@ def load():
     L.npr_destroy.argtypes = [vp]
     L.npr_last_error.restype = C.c_char_p
     L.npr_last_error.argtypes = [vp]
+    L.npr_ctx_option.restype = i32
+    L.npr_ctx_option.argtypes = [vp, i32, i64]
     L.npr_set_hmm.restype = i32
     L.npr_set_hmm.argtypes = [vp, i32, vp, vp]
     L.npr_batch_create.restype = i32

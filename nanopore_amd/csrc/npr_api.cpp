@@ -50,7 +50,7 @@ struct DeviceArena {
     std::mutex mu;
     char *F = nullptr;  // 8 bytes per cell
     std::atomic<size_t> cells{0};  // (read without the mutex where only its size matters: staging must not wait for a DP pass)
-    uint64_t epoch = 1;
+    std::atomic<uint64_t> epoch{1};
     int users = 0;
 };
 constexpr int kMaxDevices = 64;
@@ -74,6 +74,7 @@ struct npr_ctx {
     std::string last_error;
     int host_threads = 1;
     DeviceArena *arena = nullptr;  // the device's forward scratch (shared with the other contexts on this device)
+    bool overlap = false;          // NPR_OPT_OVERLAP: see include/nprealign.h
     static constexpr size_t kArenaPad = DeviceArena::kPad;
     float *arena_Fx = nullptr;  // E-step only: four more forward planes (per context)
     size_t arena_fx_cells = 0;
@@ -268,6 +269,7 @@ struct npr_batch {
     DevBuf<int64_t> d_region;  // k_dp_tile: first scratch cell of each resident workgroup
     std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
+    bool variable_regions = false;  // the one-wavefront frame launches have regions of their own size (not E-step capable)
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -281,6 +283,8 @@ struct npr_batch {
         int64_t cells;
         int64_t width;  // widest anti-diagonal of the class
         int slot_base;  // first forward-scratch region of this launch
+        int region_first;  // own_regions: index of its first entry in d_region
+        bool own_regions;  // one region per workgroup sized by its first task (d_region) instead of uniform ones
     };
     std::vector<Launch> launches;
     DevBuf<float> d_ring;
@@ -424,6 +428,14 @@ void npr_destroy(npr_ctx *ctx) {
 }
 
 const char *npr_last_error(npr_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int32_t npr_ctx_option(npr_ctx *ctx, int32_t option, int64_t value) {
+    if (!ctx) return NPR_ERR_INVALID;
+    switch (option) {
+        case NPR_OPT_OVERLAP: ctx->overlap = value != 0; return NPR_OK;
+        default: return fail(ctx, NPR_ERR_INVALID, "npr_ctx_option: unknown option");
+    }
+}
 
 int32_t npr_set_hmm(npr_ctx *ctx, int32_t slot, const double *T25, const double *E80) {
     if (!ctx || slot < 0 || slot >= NPR_MAX_MODELS) return NPR_ERR_INVALID;
@@ -842,11 +854,16 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     tm.lap("device stripe tables");
 
     // 5. tasks, grouped by class, the costliest first
+    // (the frame kernels' tasks by the forward scratch they need, which is what they cost too: a workgroup's scratch region
+    // may then be sized by its FIRST task, as the stripe kernel's are -- everything the queue hands it later is smaller)
+    std::vector<int64_t> pad_of(ntasks);
+    for (int64_t k = 0; k < ntasks; ++k) pad_of[k] = std::max(summary[k].generic_cells, is_register_class(cls_of[k]) ? sched_cells[k] : 0);  // either kernel may run the task
     std::vector<int32_t> rank(ntasks);
     std::iota(rank.begin(), rank.end(), 0);
     std::stable_sort(rank.begin(), rank.end(), [&](int32_t a, int32_t c) {
         if (cls_of[a] != cls_of[c]) return cls_of[a] < cls_of[c];
         if (tile_need[a] != tile_need[c]) return tile_need[a] > tile_need[c];
+        if (is_register_class(cls_of[a]) && pad_of[a] != pad_of[c]) return pad_of[a] > pad_of[c];
         return summary[a].cells > summary[c].cells;
     });
     b->task_of.assign(ntasks, 0);
@@ -883,7 +900,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         t.ctl_off = is_register_class(c) ? sched_off[g] : -1;
         t.tile_off = tile_off_of[g];
         t.rowmask_off = rowmask_off_of[g];
-        const int64_t pad = std::max(summary[g].generic_cells, is_register_class(c) ? sched_cells[g] : 0);  // either kernel may run the task
+        const int64_t pad = pad_of[g];
         if (pad >= (int64_t(1) << 32)) return fail(ctx, NPR_ERR_INVALID, "npr_batch_create: segment too large");
         t.cells_pad = static_cast<int32_t>(std::min<int64_t>(pad, INT32_MAX));
         max_pad = std::max(max_pad, pad);
@@ -919,6 +936,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         int waves_per_cu;
         if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
             waves_per_cu = c == 0 ? 28 : (c == 1 ? 24 : 12);
+            // NPR_OPT_OVERLAP: one wavefront slot per SIMD (and its registers) left to the staging and MEA kernels of the
+            // batches this one runs next to; the DP pass alone loses about 2 % (98 % VALU-busy at 5 wavefronts per SIMD)
+            if (ctx->overlap && c < 2) waves_per_cu -= 4;
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 64;
@@ -964,58 +984,86 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
                          (long long)cls_width[c], L.grid, L.threads);
         b->launches.push_back(L);
     }
-    // The launches run concurrently, each on its own scratch regions: the regions of all of them must fit.  The frame /
-    // generic launches take uniform regions of slot_stride cells; the stripe launch one region per workgroup, sized by the
-    // workgroup's first task (its tasks are sorted by need, so everything the queue hands out later is smaller).
+    // The launches run concurrently, each on its own scratch regions: the regions of all of them must fit.  Uniform regions
+    // of slot_stride cells (the largest task of the batch) for the generic / multi-wavefront launches, and for the
+    // one-wavefront frame launches of a small batch; the stripe launch one region per workgroup, sized by the workgroup's
+    // first task (its tasks are sorted by need, so everything the queue hands out later is smaller) -- and so the
+    // one-wavefront frame launches of a big realign batch (round 3): 6144 uniform regions sized for the one 20 kb read of a
+    // config-3 chunk took 252 GB where the reads that actually start in them need 130, which is what lets a pipelined job keep
+    // three batches on the device.  (Not for batches staged for the E-step, whose kernels index the planes of a region by
+    // slot_stride; npr_batch_expectations refuses a batch laid out this way.)
     npr_batch::Launch *tileL = nullptr;
     for (auto &L : b->launches)
         if (kClassTab[L.cls].kind == K_TILE) tileL = &L;
     const int64_t tile_min = tileL ? tile_need[rank[tileL->first]] : 0;
+    int64_t stair_grid = 0;
+    for (auto &L : b->launches)
+        if (kClassTab[L.cls].kind == K_STAIR) stair_grid += L.grid;
+    int64_t var_min_bytes = int64_t(32) << 30;  // NPR_VARIABLE_SCRATCH_MIN (bytes; 0: always, tests): uniform stair scratch above this goes variable
+    if (const char *v = std::getenv("NPR_VARIABLE_SCRATCH_MIN")) var_min_bytes = std::atoll(v);
+    b->variable_regions = b->params.mode != NPR_MODE_EXPECTATIONS && stair_grid > 0 && stair_grid * b->slot_stride * 8 >= var_min_bytes &&
+                          !force_generic;
+    auto uniform = [&](const npr_batch::Launch &L) { return &L != tileL && !(b->variable_regions && kClassTab[L.cls].kind == K_STAIR); };
     int64_t sum_grid = 0;
     for (auto &L : b->launches)
-        if (&L != tileL) sum_grid += L.grid;
+        if (uniform(L)) sum_grid += L.grid;
     if (tileL && tile_min * 8 > budget) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
     if (b->slot_stride > 0) fit = (budget - tile_min * 8) / (b->slot_stride * 8);
     if (sum_grid > fit) {
-        const int64_t others = static_cast<int64_t>(b->launches.size()) - (tileL ? 1 : 0);
+        int64_t others = 0;
+        for (auto &L : b->launches) others += uniform(L) ? 1 : 0;
         if (fit < others) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for one forward scratch region per kernel class");
         const double shrink = static_cast<double>(fit) / static_cast<double>(sum_grid);
         for (auto &L : b->launches)
-            if (&L != tileL) L.grid = std::max(1, static_cast<int>(L.grid * shrink));
+            if (uniform(L)) L.grid = std::max(1, static_cast<int>(L.grid * shrink));
     }
     sum_grid = 0;
     for (auto &L : b->launches) {
-        if (&L == tileL) continue;
+        if (!uniform(L)) continue;
         L.slot_base = static_cast<int>(sum_grid);
         sum_grid += L.grid;
         if (kClassTab[L.cls].kind == K_GENERIC_GLOBAL) ring_floats = static_cast<int64_t>(L.grid) * 18 * L.wcap;
         max_grid = std::max<int64_t>(max_grid, L.grid);
     }
-    std::vector<int64_t> region;  // first scratch cell of each workgroup of the stripe launch
-    int64_t tile_total = 0;
-    if (tileL) {
-        const int64_t room = budget / 8 - sum_grid * b->slot_stride;
+    // (at least one uniform region: npr_batch_dense runs any task there)
+    const int64_t uniform_cells = b->slot_stride * std::max<int64_t>(sum_grid, ntasks ? 1 : 0);
+    std::vector<int64_t> region;  // first scratch cell of each workgroup of the launches with their own regions
+    int64_t var_total = 0;
+    auto own_regions = [&](npr_batch::Launch &L, auto need_of) -> int32_t {
+        L.region_first = static_cast<int>(region.size());
+        const int64_t room = budget / 8 - uniform_cells - (tileL && &L != tileL ? tile_min : 0);
         int g = 0;
-        for (; g < tileL->grid; ++g) {
-            const int64_t need = tile_need[rank[tileL->first + g]];
-            if (g > 0 && tile_total + need > room) break;
-            region.push_back(sum_grid * b->slot_stride + tile_total);
-            tile_total += need;
-            b->region_end.push_back(sum_grid * b->slot_stride + tile_total);
+        for (; g < L.grid; ++g) {
+            const int64_t need = need_of(rank[L.first + g]);
+            if (var_total + need > room) break;
+            region.push_back(uniform_cells + var_total);
+            var_total += need;
+            if (&L == tileL) b->region_end.push_back(uniform_cells + var_total);
         }
-        tileL->grid = std::max(1, g);
-        tileL->slot_base = 0;
-        max_grid = std::max<int64_t>(max_grid, tileL->grid);
-    }
-    const int64_t grid = ntasks ? sum_grid + (tileL ? tileL->grid : 0) : 0;
+        if (g == 0) return NPR_ERR_NOMEM;
+        L.grid = g;
+        L.slot_base = 0;
+        L.own_regions = true;
+        max_grid = std::max<int64_t>(max_grid, L.grid);
+        return NPR_OK;
+    };
+    if (b->variable_regions)
+        for (auto &L : b->launches)
+            if (kClassTab[L.cls].kind == K_STAIR && own_regions(L, [&](int32_t g) { return (pad_of[g] + 63) & ~int64_t(63); }) != NPR_OK)
+                return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
+    if (tileL && own_regions(*tileL, [&](int32_t g) { return tile_need[g]; }) != NPR_OK)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
+    const int64_t tile_total = var_total;
+    int64_t own_grid = 0;
+    for (auto &L : b->launches) own_grid += L.own_regions ? L.grid : 0;
+    const int64_t grid = ntasks ? sum_grid + own_grid : 0;
     if ((e = b->d_tasks.alloc_from(ctx, ntasks)) != hipSuccess || (e = b->d_outs.alloc_from(ctx, ntasks)) != hipSuccess ||
         (e = b->d_queue.alloc_from(ctx, kQueueSlots)) != hipSuccess || (e = b->d_ring.alloc_from(ctx, ring_floats)) != hipSuccess ||
         (e = b->d_region.alloc_from(ctx, region.size())) != hipSuccess ||
         (e = b->d_px.alloc_from(ctx, pair_total)) != hipSuccess ||
         (e = b->d_py.alloc_from(ctx, pair_total)) != hipSuccess || (e = b->d_pp.alloc_from(ctx, pair_total)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
-    // (at least one uniform region: npr_batch_dense and the generic E-step run any task there)
-    b->scratch_cells = static_cast<size_t>(b->slot_stride) * static_cast<size_t>(std::max<int64_t>(sum_grid, ntasks ? 1 : 0)) + static_cast<size_t>(tile_total);
+    b->scratch_cells = static_cast<size_t>(uniform_cells) + static_cast<size_t>(tile_total);
     // The arena only grows, so a batch that fits what is there now goes on without the mutex -- staging the next batch must
     // not wait for the DP pass of the current one, which holds it.  Growing it (or poisoning it) waits for whatever another
     // context's batch is running there.
@@ -1079,7 +1127,7 @@ static KernelArgs make_args(npr_batch *b) {
     a.ctl = b->d_ctl.p;
     a.stripes = b->d_stripes.p;
     a.rowmask = b->d_rowmask.p;
-    a.region = b->d_region.p;
+    a.region = nullptr;  // set per launch (own_regions)
     a.F = b->ctx->arena->F;  // (the caller holds the arena's mutex)
     a.slot_stride = b->slot_stride;
     a.px = b->d_px.p;
@@ -1125,6 +1173,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.queue += L.cls;
         a.wcap = L.wcap;
         a.slot_base = L.slot_base;
+        a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
         const int rc = kc.kind == K_STAIR  ? launch_stair(a, kc.R, L.grid, s)
@@ -1260,7 +1309,10 @@ int32_t fetch_pairs(npr_batch *b) {
 // needs the host stage instead (a chain reaching back further than the prefix-maximum ring), NPR_OK or an error.
 int32_t device_mea(npr_batch *b) {
     npr_ctx *ctx = b->ctx;
-    std::lock_guard<std::mutex> arena_lock(ctx->arena->mu);  // the tables are carved out of the arena when they fit
+    // the tables are carved out of the arena when they fit -- unless the context runs next to others (NPR_OPT_OVERLAP): then
+    // they live in buffers of its own and the stage need not wait for another batch's DP pass
+    std::unique_lock<std::mutex> arena_lock(ctx->arena->mu, std::defer_lock);
+    if (!ctx->overlap) arena_lock.lock();
     ++ctx->arena->epoch;
     StageTimer tm("device_mea");
     const int64_t n = b->n_reads, ntasks = static_cast<int64_t>(b->tasks.size());
@@ -1293,7 +1345,7 @@ int32_t device_mea(npr_batch *b) {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
         const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (4 * total + 4)) +
                             al(4 * 4 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]);
-        const bool in_arena = ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
+        const bool in_arena = !ctx->overlap && ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
         char *cur = ctx->arena->F;
         if (in_arena && poison_byte() >= 0) {  // the DP launches are done (their streams feed this one): the tables start from poison
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1616,6 +1668,9 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     if (kernel_ms) *kernel_ms = 0.f;
     const int64_t ntasks = static_cast<int64_t>(b->tasks.size());
     if (!ntasks) return NPR_OK;
+    if (b->variable_regions)
+        return fail(ctx, NPR_ERR_STATE, "npr_batch_expectations: this batch was laid out for realignment only (scratch regions of their own size); "
+                                        "stage it with NPR_MODE_EXPECTATIONS");
     {
         const int32_t rc = ensure_coff(b);  // classes without a register E-step take the generic kernel
         if (rc != NPR_OK) return rc;
@@ -1631,6 +1686,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         int slot_base;    // first uniform forward-scratch region: the one its class had in the DP launch (the classes run concurrently)
         int dp_grid;      // ... and how many of them that launch owned
         int64_t cells;
+        int region_first;  // stripe class: its scratch regions in the batch's table
         size_t fx_off, ring_off;  // where its planes of the other four states / its HBM ring start (floats)
     };
     std::vector<L> launches;
@@ -1638,7 +1694,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     for (const auto &dl : b->launches) {  // one E-step launch per kernel class of the batch (tasks are grouped by class)
         L l{};
         l.first = dl.first, l.count = dl.count;
-        l.slot_base = dl.slot_base, l.dp_grid = dl.grid, l.cells = dl.cells;
+        l.slot_base = dl.slot_base, l.dp_grid = dl.grid, l.cells = dl.cells, l.region_first = dl.own_regions ? dl.region_first : -1;
         if (kClassTab[dl.cls].kind == K_STAIR && !std::getenv("NPR_EM_GENERIC")) {
             // 127 / 161 / 223 VGPRs and 9 KiB of LDS bins per wavefront: 16 / 12 / 8 wavefronts per CU
             l.stair_R = kClassTab[dl.cls].R;
@@ -1654,7 +1710,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
             // launch gave them (region i is sized for task i, and everything the queue hands out later is smaller)
             l.stair_R = 2, l.tile = true;
             l.lds = em_tile_lds_bytes(em_tile_waves());
-            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(l.count, dl.grid), static_cast<int64_t>(ctx->cu_count) * (12 / em_tile_waves()))));
+            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(l.count, dl.grid), static_cast<int64_t>(ctx->cu_count) * (em_tile_waves_per_cu() / em_tile_waves()))));
             launches.push_back(l);
             continue;
         }
@@ -1751,6 +1807,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         a.queue += static_cast<int>(i);  // at most kClasses launches, kQueueSlots counters
         a.wcap = l.wcap;
         a.slot_base = l.slot_base;
+        a.region = l.region_first >= 0 ? b->d_region.p + l.region_first : nullptr;
         a.ring = ring.p ? ring.p + l.ring_off : nullptr;
         // stair / wide / generic kernels index their planes by workgroup from a.Fx; the stripe kernel by its scratch region
         a.Fx = ctx->arena_Fx + l.fx_off;

@@ -44,7 +44,9 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // 8 ints: cell hand-off
 
     const int lane = threadIdx.x;
-    char *const F = a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
+    // the wavefront's forward scratch: its own region (big realign batches: sized by the region's first task, a.region) or
+    // the blockIdx-th uniform one
+    char *const F = a.region ? a.F + uni64(a.region[blockIdx.x]) * 8 : a.F + static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride * 8;
     const int voff = 8 * R * lane;  // byte offset of this lane's cells inside a row that starts at lane 0
     int jr[R];
 #pragma unroll

@@ -645,8 +645,11 @@ __device__ __forceinline__ void tile_em_cells(const StepEnv &E, const Diag<R> &i
     }
 }
 
+#ifndef NPR_EM_TILE_WPE
+#define NPR_EM_TILE_WPE 3  // wavefronts per SIMD the register allocation aims at (164 VGPRs unconstrained: 3)
+#endif
 template <int R>
-__global__ void __launch_bounds__(WAVE *EM_TILE_NW) k_em_tile(KernelArgs a) {
+__global__ void __launch_bounds__(WAVE *EM_TILE_NW) __attribute__((amdgpu_waves_per_eu(NPR_EM_TILE_WPE))) k_em_tile(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmodel = reinterpret_cast<float *>(smem);
     int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [5] next task
@@ -992,6 +995,7 @@ size_t tile_lds_bytes(int nw) { return sizeof(float) * (MODEL_FLOATS + 8 + TILE_
 int64_t tile_scratch_cells(int64_t rows, int R) { return rows * (64 * R + 2 * EDGE_FLOATS / 2); }
 
 size_t em_tile_lds_bytes(int nw) { return tile_lds_bytes(nw) + sizeof(float) * static_cast<size_t>(nw) * (EM_BINS + 1) * WAVE; }
+int em_tile_waves_per_cu() { return 4 * NPR_EM_TILE_WPE; }
 int em_tile_waves() {  // wavefronts per task: NPR_EM_TILE_WAVES (1..4) for A/B runs
     int nw = 2;  // trainer's band 2.24 / 2.53 / 2.40 / 2.16e10 cells/s on 1 / 2 / 3 / 4 wavefronts per task, a 560-cell band 2.6 / 3.3 / 3.1 / 3.3e10
     if (const char *w = std::getenv("NPR_EM_TILE_WAVES")) nw = std::min(EM_TILE_NW, std::max(1, std::atoi(w)));

@@ -220,6 +220,12 @@ class Context(object):
         self.device = device
         self._models = {}  # slot -> (T, E) or None, as installed: what another context on the same GPU copies
 
+    def set_option(self, option, value):
+        """include/nprealign.h: npr_ctx_option (e.g. _lib.OPT_OVERLAP for a context of a pipelined job)."""
+        rc = self._L.npr_ctx_option(self._h, option, int(value))
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_ctx_option", self.last_error())
+
     def copy_models_from(self, other):
         """Installs the models `other` holds (a second context of a pipelined job runs the same ones)."""
         for slot, m in other._models.items():
