@@ -251,9 +251,12 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     timings)."""
     from . import realign
     pending = list(reversed(chunk_bounds(src.lengths(), lo, hi, chunk_bases, len(ctxs))))  # a stack: splits go back on top
-    overlap = len(ctxs) > 1 and len(pending) > 1 and os.environ.get("NPR_JOB_NO_OVERLAP") is None
+    # NPR_OPT_OVERLAP (MEA tables off the shared scratch, a wavefront slot per SIMD left free beside a DP pass) is off by
+    # default: measured on config 3 it moves nothing (763 vs 762 ms per step) -- the finish then runs under the next DP pass
+    # but five times slower, and that DP pass 6 % slower: the phases compete for the same VALU cycles (DESIGN.md section 6b)
+    overlap = len(ctxs) > 1 and len(pending) > 1 and os.environ.get("NPR_JOB_OVERLAP") is not None
     for c in ctxs:
-        c.set_option(_lib.OPT_OVERLAP, overlap)  # MEA tables of their own, room beside a DP pass for the other chunks' kernels
+        c.set_option(_lib.OPT_OVERLAP, overlap)
     n_planned = len(pending)
     tm = dict(stage_s=0.0, run_s=0.0, finish_s=0.0, fetch_s=0.0, format_s=0.0, kernel_ms=0.0, cells=0, trace=[])
     free = [threading.Semaphore(1) for _ in ctxs]
