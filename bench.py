@@ -346,7 +346,8 @@ def main():
         out = resident(env)
         if args.workload == "northstar" and not args.no_also:
             # collective: the strong-scaling job of configs[2]/[3], files -> file, at this N
-            entry = c3_job(env, 50000, 2, 1, from_files=True)
+            # (NPR_BENCH_ALSO_READS: a smaller set for the shared-GPU test hook, where two ranks' scratch must fit one device)
+            entry = c3_job(env, int(os.environ.get("NPR_BENCH_ALSO_READS", 50000)), 2, 1, from_files=True)
             if rank == 0:
                 out.setdefault("also", []).append(entry)
     if rank == 0:

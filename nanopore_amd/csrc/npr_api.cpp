@@ -206,6 +206,9 @@ struct MeaScratch {
 };
 
 int32_t fail(npr_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuccess) {
+    // a launch or copy that finds the device full (a kernel's private segment is allocated at launch) is the same condition as
+    // a failed hipMalloc: callers halve the batch and try again on NPR_ERR_NOMEM
+    if (code == NPR_ERR_HIP && e == hipErrorOutOfMemory) code = NPR_ERR_NOMEM, (void)hipGetLastError();
     if (ctx) {
         ctx->last_error = what;
         if (e != hipSuccess) {
