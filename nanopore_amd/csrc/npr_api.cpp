@@ -484,17 +484,21 @@ bool build_stair_schedule(const Segment &s, int R, int NW, uint32_t *ctl, int64_
 // lane), the register kernel with NW wavefronts per task (k_dp_wide), the generic kernel with an LDS ring in three
 // width classes, the generic kernel with its ring in HBM.
 namespace {
-enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4 };
+enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4, K_PAIR = 5 };
 struct KClass {
     int kind, R, NW;
     int slots() const { return 64 * R * NW; }
 };
-constexpr int kClasses = 12;
+constexpr int kClasses = 15;
 constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STAIR, 4, 1}, {K_WIDE, 2, 4}, {K_WIDE, 2, 8},
                                         {K_WIDE, 4, 8}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
-                                        {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}, {K_TILE, 2, 0}};
-constexpr int kFirstGeneric = 7, kTileClass = 11, kQueueSlots = 16;
-inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE; }
+                                        {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}, {K_TILE, 2, 0},
+                                        // k_dp_pair<R>: the one-wavefront frame classes 0-2 with the two sweeps on two wavefronts
+                                        {K_PAIR, 1, 1}, {K_PAIR, 2, 1}, {K_PAIR, 4, 1}};
+constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kQueueSlots = 16;
+inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_PAIR; }
+// resident wavefronts per CU of the one-wavefront frame kernels (VGPR-limited: 71 / 80 / 162 registers: 7 / 6 / 3 per SIMD)
+inline int stair_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 12); }
 
 // Stripe table of k_dp_tile for one segment (npr_kernel_tile.hip): the lattice columns 0..lX cut into stripes of 64*R
 // columns; per stripe the first / last anti-diagonal on which the band has cells in it and the index of its first row in
@@ -818,6 +822,33 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         }
         any_generic |= kClassTab[c].kind == K_GENERIC_LDS || kClassTab[c].kind == K_GENERIC_GLOBAL;
     }
+    // A read on ONE wavefront is a serial chain of 2 * (lX + lY) steps: a launch lasts at least as long as its longest task,
+    // and a class with fewer tasks than the chip has wavefront slots leaves the rest idle.  Tasks longer than a wavefront's
+    // fair share of their class go to k_dp_pair (both sweeps at once on two wavefronts: half the chain, twice the memory
+    // traffic), the longest first, as far as a second wavefront is to be had: all of them when the class does not fill the
+    // chip anyway, else those that would outlast the others.  NPR_PAIR=0 / all: never / every task (A/B runs, tests).
+    bool any_pair = false;
+    {
+        const char *pe = std::getenv("NPR_PAIR");
+        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = pe && pe[0] == '0';
+        if (!pair_off && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS)
+            for (int c = 0; c < 3; ++c) {
+                std::vector<int32_t> mine;
+                int64_t cost = 0;
+                for (int64_t k = 0; k < ntasks; ++k)
+                    if (cls_of[k] == c) mine.push_back(static_cast<int32_t>(k)), cost += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
+                if (mine.empty()) continue;
+                const int64_t slots = static_cast<int64_t>(ctx->cu_count) * stair_waves_per_cu(kClassTab[c].R);
+                const int64_t n = static_cast<int64_t>(mine.size()), fair = cost / slots;
+                int64_t room = pair_all ? n : (n < slots ? slots - n : n);  // second wavefronts to be had
+                std::sort(mine.begin(), mine.end(), [&](int32_t x, int32_t y) { return pseg[x].lX + pseg[x].lY > pseg[y].lX + pseg[y].lY; });
+                for (int32_t k : mine) {
+                    const int64_t len = static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
+                    if (room <= 0 || (!pair_all && (len <= fair || len < 256))) break;
+                    cls_of[k] = static_cast<int8_t>(kFirstPair + c), --room, any_pair = true;
+                }
+            }
+    }
     // k_dp_tile tasks are ordered by the forward scratch they need (one row per anti-diagonal of a stripe: also what a
     // task costs): a workgroup's region is sized by its FIRST task, every later one from the queue is smaller
     std::vector<int64_t> tile_need(ntasks, 0), rowmask_off_of(ntasks, -1);
@@ -937,8 +968,13 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         L.width = cls_width[c];
         first += cls_count[c];
         int waves_per_cu;
-        if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
-            waves_per_cu = c == 0 ? 28 : (c == 1 ? 24 : 12);
+        if (kClassTab[c].kind == K_PAIR) {  // workgroups of two wavefronts
+            waves_per_cu = stair_waves_per_cu(kClassTab[c].R) / 2;
+            L.wcap = 0;
+            L.lds = stair_lds_bytes();
+            L.threads = 128;
+        } else if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
+            waves_per_cu = stair_waves_per_cu(kClassTab[c].R);
             // NPR_OPT_OVERLAP: one wavefront slot per SIMD (and its registers) left to the staging and MEA kernels of the
             // batches this one runs next to; the DP pass alone loses about 2 % (98 % VALU-busy at 5 wavefronts per SIMD)
             if (ctx->overlap && c < 2) waves_per_cu -= 4;
@@ -1006,7 +1042,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     if (const char *v = std::getenv("NPR_VARIABLE_SCRATCH_MIN")) var_min_bytes = std::atoll(v);
     b->variable_regions = b->params.mode != NPR_MODE_EXPECTATIONS && stair_grid > 0 && stair_grid * b->slot_stride * 8 >= var_min_bytes &&
                           !force_generic;
-    auto uniform = [&](const npr_batch::Launch &L) { return &L != tileL && !(b->variable_regions && kClassTab[L.cls].kind == K_STAIR); };
+    if (any_pair) b->variable_regions = true;  // (their regions hold two sets of rows: not a layout the E-step kernels know)
+    auto uniform = [&](const npr_batch::Launch &L) {
+        return &L != tileL && kClassTab[L.cls].kind != K_PAIR && !(b->variable_regions && kClassTab[L.cls].kind == K_STAIR);
+    };
     int64_t sum_grid = 0;
     for (auto &L : b->launches)
         if (uniform(L)) sum_grid += L.grid;
@@ -1050,10 +1089,14 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         max_grid = std::max<int64_t>(max_grid, L.grid);
         return NPR_OK;
     };
-    if (b->variable_regions)
-        for (auto &L : b->launches)
-            if (kClassTab[L.cls].kind == K_STAIR && own_regions(L, [&](int32_t g) { return (pad_of[g] + 63) & ~int64_t(63); }) != NPR_OK)
+    for (auto &L : b->launches) {
+        const int kind = kClassTab[L.cls].kind;
+        if ((kind == K_STAIR && b->variable_regions && !uniform(L)) || kind == K_PAIR) {
+            const int64_t sets = kind == K_PAIR ? 2 : 1;  // k_dp_pair keeps the backward rows too
+            if (own_regions(L, [&](int32_t g) { return sets * ((pad_of[g] + 63) & ~int64_t(63)); }) != NPR_OK)
                 return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
+        }
+    }
     if (tileL && own_regions(*tileL, [&](int32_t g) { return tile_need[g]; }) != NPR_OK)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
     const int64_t tile_total = var_total;
@@ -1179,7 +1222,8 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
-        const int rc = kc.kind == K_STAIR  ? launch_stair(a, kc.R, L.grid, s)
+        const int rc = kc.kind == K_PAIR   ? launch_pair(a, kc.R, L.grid, s)
+                       : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
                        : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
                                            : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);

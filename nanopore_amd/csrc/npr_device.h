@@ -247,6 +247,7 @@ int launch_mea_gather(const MeaArgs &a, void *stream);
 int launch_em_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
 int launch_em_tile(const KernelArgs &a, int R, int grid, void *stream);  // k_em_tile: the E-step on column stripes
 size_t em_tile_lds_bytes(int nw);
+int launch_pair(const KernelArgs &a, int R, int grid, void *stream);  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once
 int em_tile_waves();
 int em_tile_waves_per_cu();
 size_t em_wide_lds_bytes(int nw);
