@@ -67,7 +67,10 @@ extern "C" {
 #define NPR_MODE_ALL_POSTERIORS 2   /* marginAlignSnpCaller.py:136-146: --outputAllPosteriorProbs; the MEA
                                        cigar is produced as well (stdout of that call) */
 #define NPR_MODE_EXPECTATIONS 3     /* utils.py:509-528: the batch is staged for npr_batch_expectations (the E-step of
-                                       cactus_expectationMaximisation); npr_batch_run / finish behave as NPR_MODE_REALIGN */
+                                       cactus_expectationMaximisation); npr_batch_run / finish behave as NPR_MODE_REALIGN.
+                                       A batch staged in another mode may be laid out for realignment only (scratch regions
+                                       of their own size, long reads on two wavefronts): npr_batch_expectations then
+                                       returns NPR_ERR_STATE */
 
 #define NPR_MAX_MODELS 8
 
@@ -178,12 +181,15 @@ void npr_batch_destroy(npr_batch *b);
 
 int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
 /* Diagnostics: how the batch's DP problems (segments) were spread over the kernel classes.  tasks[c] / cells[c] for
- * class c (either may be NULL), capacity `cap` entries; returns the number of classes (12):
+ * class c (either may be NULL), capacity `cap` entries; returns the number of classes (15):
  *   0-2  register kernel, one wavefront per task, 64 / 128 / 256 slots (k_dp_stair<1|2|4>)
  *   3-6  register kernel, 4 / 8 / 8 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
  *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring
  *   11   register kernel on column stripes, any width (k_dp_tile; k_em_tile for npr_batch_expectations); takes what 3-10
- *        would take unless NPR_NO_TILE=1 is set */
+ *        would take unless NPR_NO_TILE=1 is set
+ *   12-14  classes 0-2 with the forward and the backward sweep of a task on two wavefronts at once (k_dp_pair<1|2|4>): the
+ *        tasks of 0-2 that are longer than a wavefront's fair share of their class -- a launch lasts as long as its longest
+ *        one-wavefront chain -- as far as second wavefronts are free (NPR_PAIR=0: none; =all: every task) */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* results, valid after npr_batch_finish */
 int32_t npr_batch_results(const npr_batch *b, npr_read_result *out /* [n_reads] */);

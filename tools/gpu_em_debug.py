@@ -14,7 +14,7 @@ def run(L, W, n, seed, indel=0.1, max_indel=5):
         if mode == "generic": os.environ["NPR_EM_GENERIC"] = "1"
         else: os.environ.pop("NPR_EM_GENERIC", None)
         ctx = R.Context(0); ctx.set_hmm(h)
-        b = ctx.stage(R.make_params(band_mode=1, fixed_width=W), refs, reads, [o for X, Y, o in cases])
+        b = ctx.stage(R.make_params(band_mode=1, fixed_width=W, mode=R.MODE_EXPECTATIONS), refs, reads, [o for X, Y, o in cases])
         T, E, ll, ms = b.expectations()
         out[mode] = (T[0].copy(), E[0].copy(), ll[0])
         b.close(); ctx.close()
