@@ -529,42 +529,56 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
         if (!alive) out.status = NPR_ERR_ZERO_PROB, out.btot_m = 0.f, out.btot_e = E_DEAD;
 
         // ================= both: the posteriors of half of the anti-diagonals each, rows streamed back =================
+        // Pure streaming, so the loads of G rows are issued before the first of them is used: with one row in flight a row
+        // cost a memory round trip (C2: no faster than one wavefront per read; 20 kb reads: slower).
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
             const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            constexpr int G = R == 1 ? 8 : (R == 2 ? 6 : 4);
             const int mid = D / 2;  // wavefront 0: d = 0 .. mid walking up from (0, 0); wavefront 1: d = D .. mid + 1 walking down
-            FRow<R> f0, b0, f1, b1;
+            FRow<R> fr[G], br[G];
 #pragma unroll
-            for (int r = 0; r < R; ++r) f0.v[r] = b0.v[r] = f1.v[r] = b1.v[r] = 0.f, f0.e[r] = b0.e[r] = f1.e[r] = b1.e[r] = E_DEAD;
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int r = 0; r < R; ++r) fr[g].v[r] = br[g].v[r] = 0.f, fr[g].e[r] = br[g].e[r] = E_DEAD;
             if (wv == 0) {
-                int x0 = -j0, y0 = j0;
-                RowCtl<R> cur = c0, nx = c0;
-                load_row<R>(frs, f0, cur, voff), load_row<R>(brs, b0, cur, voff);
-                for (int d = 0; d <= mid; ++d) {
-                    if (d + 1 <= mid) {
-                        nx = read_row_ctl<R>(ctl, d + 1);
-                        load_row<R>(frs, f1, nx, voff), load_row<R>(brs, b1, nx, voff);  // one ahead
-                    }
-                    emit_pairs_shared<R>(sink, b0, f0, d, x0, y0, cur.mk, tot_e, inv_tot, jr, &lmisc[5]);
-                    // the frame of d + 1: its rebase, then its step
-                    x0 += nx.reb, y0 -= nx.reb;
-                    if ((d + 1) & 1) x0 += 1; else y0 += 1;
-                    cur = nx, f0 = f1, b0 = b1;
+                int x0 = -j0, y0 = j0;  // the frame of anti-diagonal 0
+                for (int d = 0; d <= mid; d += G) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (d + g <= mid) {
+                            const RowCtl<R> c = read_row_ctl<R>(ctl, d + g);
+                            load_row<R>(frs, fr[g], c, voff), load_row<R>(brs, br[g], c, voff);
+                        }
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (d + g <= mid) {
+                            const RowCtl<R> c = read_row_ctl<R>(ctl, d + g);
+                            if (d + g > 0) {  // the frame of d + g: the rebase that leads into it, then its step
+                                x0 += c.reb, y0 -= c.reb;
+                                if ((d + g) & 1) x0 += 1; else y0 += 1;
+                            }
+                            emit_pairs_shared<R>(sink, br[g], fr[g], d + g, x0, y0, c.mk, tot_e, inv_tot, jr, &lmisc[5]);
+                        }
                 }
             } else {
-                int x0 = xD, y0 = yD;
-                RowCtl<R> cur = read_row_ctl<R>(ctl, D), nx = cur;
-                if (D > mid) load_row<R>(frs, f0, cur, voff), load_row<R>(brs, b0, cur, voff);
-                for (int d = D; d > mid; --d) {
-                    if (d - 1 > mid) {
-                        nx = read_row_ctl<R>(ctl, d - 1);
-                        load_row<R>(frs, f1, nx, voff), load_row<R>(brs, b1, nx, voff);
-                    }
-                    emit_pairs_shared<R>(sink, b0, f0, d, x0, y0, cur.mk, tot_e, inv_tot, jr, &lmisc[5]);
-                    // back to the frame of d - 1: undo the step into d, then the rebase that led into d
-                    if (d & 1) x0 -= 1; else y0 -= 1;
-                    x0 -= cur.reb, y0 += cur.reb;
-                    cur = nx, f0 = f1, b0 = b1;
+                int x0 = xD, y0 = yD;  // the frame of anti-diagonal D
+                for (int d = D; d > mid; d -= G) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (d - g > mid) {
+                            const RowCtl<R> c = read_row_ctl<R>(ctl, d - g);
+                            load_row<R>(frs, fr[g], c, voff), load_row<R>(brs, br[g], c, voff);
+                        }
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (d - g > mid) {
+                            const RowCtl<R> c = read_row_ctl<R>(ctl, d - g);
+                            emit_pairs_shared<R>(sink, br[g], fr[g], d - g, x0, y0, c.mk, tot_e, inv_tot, jr, &lmisc[5]);
+                            // back to the frame of d - g - 1: undo the step into d - g, then the rebase that led into it
+                            if ((d - g) & 1) x0 -= 1; else y0 -= 1;
+                            x0 -= c.reb, y0 += c.reb;
+                        }
                 }
             }
         }
