@@ -204,6 +204,8 @@ __device__ __forceinline__ uint64_t lane_run(uint32_t lo, uint32_t w) {
     return m;
 }
 template <int R>
+__device__ __forceinline__ RowCtl<R> row_ctl_of_words(uint32_t w0, uint32_t w1);
+template <int R>
 __device__ __forceinline__ RowCtl<R> read_row_ctl_at(cptr32 e) {  // e: the anti-diagonal's two control words
     RowCtl<R> c;
     if constexpr (R == 2) {
@@ -226,6 +228,28 @@ __device__ __forceinline__ RowCtl<R> read_row_ctl_at(cptr32 e) {  // e: the anti
 }
 template <int R>
 __device__ __forceinline__ RowCtl<R> read_row_ctl(cptr32 ctl, int d) { return read_row_ctl_at<R>(ctl + 2 * static_cast<int64_t>(d)); }
+// the same from the two words themselves (wave-uniform values that did not come through the scalar cache: k_dp_pair's
+// posterior pass fetches the words of 64 anti-diagonals with one vector load and hands them out by v_readlane)
+template <int R>
+__device__ __forceinline__ RowCtl<R> row_ctl_of_words(uint32_t w0, uint32_t w1) {
+    RowCtl<R> c;
+    if constexpr (R == 2) {
+        c.mk.cell[0] = lane_run(w1, w1 >> 14);
+        c.mk.cell[1] = lane_run(w1 >> 7, w1 >> 21);
+        c.mk.lanes = c.mk.cell[0] | c.mk.cell[1];
+        c.mk.l0 = static_cast<int>((w1 >> 7) & 127u);
+        c.soff = w0;
+        c.reb = static_cast<int>((w1 >> 28) & 3u) - 1;
+        c.jlo = static_cast<int>((w1 & 127u) + ((w1 >> 7) & 127u));
+    } else {
+        const Ctl t{w0, static_cast<int>(w1 & 8191u), static_cast<int>((w1 >> 13) & 8191u), static_cast<int>((w1 >> 26) & 3u) - 1};
+        c.mk = band_masks<R>(t.jlo, t.n);
+        c.soff = ((t.co - static_cast<uint32_t>(R * c.mk.l0)) << 3) + row_bias<R>();
+        c.reb = t.reb;
+        c.jlo = t.jlo;
+    }
+    return c;
+}
 // a packed control word (one-wavefront R = 2 tasks) in the terms of the other kernels (k_em_stair<2>)
 __device__ __forceinline__ Ctl read_ctl_packed(cptr32 ctl, int d) {
     const uint32_t so = ctl[2 * d], w = ctl[2 * d + 1];

@@ -529,55 +529,48 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
         if (!alive) out.status = NPR_ERR_ZERO_PROB, out.btot_m = 0.f, out.btot_e = E_DEAD;
 
         // ================= both: the posteriors of half of the anti-diagonals each, rows streamed back =================
-        // Pure streaming, so the loads of G rows are issued before the first of them is used: with one row in flight a row
-        // cost a memory round trip (C2: no faster than one wavefront per read; 20 kb reads: slower).
+        // Pure streaming, arranged so that nothing waits for memory row by row: the control words of 64 anti-diagonals come
+        // with ONE vector load (a lane each) and are handed out by v_readlane -- through the scalar cache every row cost a
+        // dependent s_load --, and the row loads of G anti-diagonals are issued before the first of them is used.  (With one
+        // row in flight this pass cost as much as the sweeps: C2 no faster than one wavefront per read.)
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
             const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
-            constexpr int G = R == 1 ? 8 : (R == 2 ? 6 : 4);
+            constexpr int G = R == 1 ? 8 : 4;
             const int mid = D / 2;  // wavefront 0: d = 0 .. mid walking up from (0, 0); wavefront 1: d = D .. mid + 1 walking down
+            const int first = wv == 0 ? 0 : D, dir = wv == 0 ? 1 : -1, count = wv == 0 ? mid + 1 : D - mid;
+            int x0 = wv == 0 ? -j0 : xD, y0 = wv == 0 ? j0 : yD;  // the frame of anti-diagonal `first`
+            const uint2 *gw = reinterpret_cast<const uint2 *>(a.ctl + 2 * ctl_off);
             FRow<R> fr[G], br[G];
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int r = 0; r < R; ++r) fr[g].v[r] = br[g].v[r] = 0.f, fr[g].e[r] = br[g].e[r] = E_DEAD;
-            if (wv == 0) {
-                int x0 = -j0, y0 = j0;  // the frame of anti-diagonal 0
-                for (int d = 0; d <= mid; d += G) {
+            for (int base = 0; base < count; base += WAVE) {
+                const int rows = min(WAVE, count - base);
+                uint2 w = make_uint2(0u, 0u);
+                if (lane < rows) w = gw[first + dir * (base + lane)];  // lane l: the words of the l-th anti-diagonal of this block
+                for (int q = 0; q < rows; q += G) {
 #pragma unroll
                     for (int g = 0; g < G; ++g)
-                        if (d + g <= mid) {
-                            const RowCtl<R> c = read_row_ctl<R>(ctl, d + g);
+                        if (q + g < rows) {
+                            const RowCtl<R> c = row_ctl_of_words<R>(__builtin_amdgcn_readlane(w.x, q + g), __builtin_amdgcn_readlane(w.y, q + g));
                             load_row<R>(frs, fr[g], c, voff), load_row<R>(brs, br[g], c, voff);
                         }
 #pragma unroll
                     for (int g = 0; g < G; ++g)
-                        if (d + g <= mid) {
-                            const RowCtl<R> c = read_row_ctl<R>(ctl, d + g);
-                            if (d + g > 0) {  // the frame of d + g: the rebase that leads into it, then its step
+                        if (q + g < rows) {
+                            const int d = first + dir * (base + q + g);
+                            const RowCtl<R> c = row_ctl_of_words<R>(__builtin_amdgcn_readlane(w.x, q + g), __builtin_amdgcn_readlane(w.y, q + g));
+                            if (wv == 0 && d > 0) {  // walking up: the rebase that leads into d, then its step
                                 x0 += c.reb, y0 -= c.reb;
-                                if ((d + g) & 1) x0 += 1; else y0 += 1;
+                                if (d & 1) x0 += 1; else y0 += 1;
                             }
-                            emit_pairs_shared<R>(sink, br[g], fr[g], d + g, x0, y0, c.mk, tot_e, inv_tot, jr, &lmisc[5]);
-                        }
-                }
-            } else {
-                int x0 = xD, y0 = yD;  // the frame of anti-diagonal D
-                for (int d = D; d > mid; d -= G) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        if (d - g > mid) {
-                            const RowCtl<R> c = read_row_ctl<R>(ctl, d - g);
-                            load_row<R>(frs, fr[g], c, voff), load_row<R>(brs, br[g], c, voff);
-                        }
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        if (d - g > mid) {
-                            const RowCtl<R> c = read_row_ctl<R>(ctl, d - g);
-                            emit_pairs_shared<R>(sink, br[g], fr[g], d - g, x0, y0, c.mk, tot_e, inv_tot, jr, &lmisc[5]);
-                            // back to the frame of d - g - 1: undo the step into d - g, then the rebase that led into it
-                            if ((d - g) & 1) x0 -= 1; else y0 -= 1;
-                            x0 -= c.reb, y0 += c.reb;
+                            emit_pairs_shared<R>(sink, br[g], fr[g], d, x0, y0, c.mk, tot_e, inv_tot, jr, &lmisc[5]);
+                            if (wv != 0) {  // walking down: undo the step into d, then the rebase that led into it
+                                if (d & 1) x0 -= 1; else y0 -= 1;
+                                x0 -= c.reb, y0 += c.reb;
+                            }
                         }
                 }
             }
