@@ -191,6 +191,13 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
  *        tasks of 0-2 that are longer than a wavefront's fair share of their class -- a launch lasts as long as its longest
  *        one-wavefront chain -- as far as second wavefronts are free (NPR_PAIR=0: none; =all: every task) */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
+/* Which device arithmetic each segment (matrix split) of each read ran in, in read order: seg_off[n_reads + 1], arith[seg_off
+ * [n_reads]] (pass arith == NULL for the offsets alone).  0: one exponent per cell (npr_cell.h: k_dp_tile, k_dp_generic, k_dp_wide
+ * and, under NPR_ARITH=cell, k_dp_stair / k_dp_pair); 1: one exponent per anti-diagonal row (npr_rs.h: k_dp_rs, the kernel of
+ * classes 0-2).  Both are fp32 evaluations of the same recurrences (cactus_realign's forward / backward pass, reference call
+ * site nanopore/analyses/utils.py:587) within the stated 1e-4 of the fp64 oracle; the parity tests ask so that they can
+ * compare bit for bit with the matching CPU restatement (oracle/realign_oracle_f32.c / realign_oracle_rs.c). */
+int32_t npr_batch_segment_arith(const npr_batch *b, int64_t *seg_off, int32_t *arith, int64_t cap);
 /* results, valid after npr_batch_finish */
 int32_t npr_batch_results(const npr_batch *b, npr_read_result *out /* [n_reads] */);
 /* output cigars, CSR: ops_off[n_reads+1] (in op pairs), ops[2*ops_off[n_reads]].  Pass ops == NULL to get

@@ -89,7 +89,7 @@ EXPORTS = [
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
     "npr_plan_segment_band", "npr_plan_frame_schedule", "npr_plan_stripes", "npr_format_cigars", "npr_format_cigars_packed", "npr_format_sam_records", "npr_chain_hits", "npr_mea_cigar", "npr_rescore", "npr_encode_bases",
     "npr_sam_index", "npr_sam_parse", "npr_sam_guides", "npr_sam_splice", "npr_fasta_index", "npr_fasta_pack", "npr_fastq_index",
-    "npr_batch_create_spans", "npr_chain_merge", "npr_ctx_option",
+    "npr_batch_create_spans", "npr_chain_merge", "npr_ctx_option", "npr_batch_segment_arith",
 ]
 
 _lib = None
@@ -124,6 +124,8 @@ def load():
     L.npr_plan_frame_schedule.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.npr_batch_class_stats.restype = i32
     L.npr_batch_class_stats.argtypes = [vp, vp, vp, i32]
+    L.npr_batch_segment_arith.restype = i32
+    L.npr_batch_segment_arith.argtypes = [vp, vp, vp, i64]
     L.npr_batch_create_at.restype = i32
     L.npr_batch_create_at.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.npr_batch_run.restype = i32

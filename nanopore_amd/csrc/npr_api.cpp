@@ -273,6 +273,7 @@ struct npr_batch {
     std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     bool variable_regions = false;  // the one-wavefront frame launches have regions of their own size (not E-step capable)
+    bool arith_rs = true;  // classes 0-2 run k_dp_rs (row-scaled arithmetic, npr_rs.h); NPR_ARITH=cell: k_dp_stair / k_dp_pair
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -499,6 +500,8 @@ constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kQueueSlots =
 inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_PAIR; }
 // resident wavefronts per CU of the one-wavefront frame kernels (VGPR-limited: 71 / 80 / 162 registers: 7 / 6 / 3 per SIMD)
 inline int stair_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 12); }
+// ... and of k_dp_rs<R> (76 / 106 / 151 registers: 6 / 4 / 3 per SIMD)
+inline int rs_waves_per_cu(int R) { return R == 1 ? 24 : (R == 2 ? 16 : 12); }
 
 // Stripe table of k_dp_tile for one segment (npr_kernel_tile.hip): the lattice columns 0..lX cut into stripes of 64*R
 // columns; per stripe the first / last anti-diagonal on which the band has cells in it and the index of its first row in
@@ -829,8 +832,14 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // chip anyway, else those that would outlast the others.  NPR_PAIR=0 / all: never / every task (A/B runs, tests).
     bool any_pair = false;
     {
+        const char *ae = std::getenv("NPR_ARITH");
+        b->arith_rs = !(ae && std::strcmp(ae, "cell") == 0);
+    }
+    {
+        // (k_dp_pair is a per-cell-exponent kernel: with the row-scaled k_dp_rs as the default one-wavefront kernel it is an
+        // A/B variant, NPR_ARITH=cell)
         const char *pe = std::getenv("NPR_PAIR");
-        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = pe && pe[0] == '0';
+        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = (pe && pe[0] == '0') || b->arith_rs;
         if (!pair_off && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS)
             for (int c = 0; c < 3; ++c) {
                 std::vector<int32_t> mine;
@@ -974,7 +983,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             L.lds = stair_lds_bytes();
             L.threads = 128;
         } else if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
-            waves_per_cu = stair_waves_per_cu(kClassTab[c].R);
+            waves_per_cu = b->arith_rs ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R);
             // NPR_OPT_OVERLAP: one wavefront slot per SIMD (and its registers) left to the staging and MEA kernels of the
             // batches this one runs next to; the DP pass alone loses about 2 % (98 % VALU-busy at 5 wavefronts per SIMD)
             if (ctx->overlap && c < 2) waves_per_cu -= 4;
@@ -1223,7 +1232,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
         const int rc = kc.kind == K_PAIR   ? launch_pair(a, kc.R, L.grid, s)
-                       : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
+                       : kc.kind == K_STAIR ? (b->arith_rs ? launch_rs(a, kc.R, L.grid, s) : launch_stair(a, kc.R, L.grid, s))
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
                        : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
                                            : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);
@@ -1257,6 +1266,22 @@ int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells
             if (cells) cells[L.cls] = L.cells;
         }
     return kClasses;
+}
+
+int32_t npr_batch_segment_arith(const npr_batch *b, int64_t *seg_off, int32_t *arith, int64_t cap) {
+    if (!b || !seg_off) return NPR_ERR_INVALID;
+    std::vector<int8_t> of_task(b->tasks.size(), 0);
+    for (const auto &L : b->launches)
+        if (kClassTab[L.cls].kind == K_STAIR && b->arith_rs)
+            for (int k = L.first; k < L.first + L.count; ++k) of_task[k] = 1;
+    int64_t n = 0;
+    for (int64_t r = 0; r < b->n_reads; ++r) {
+        seg_off[r] = n;
+        for (int32_t s2 = 0; s2 < b->read_ntasks[r]; ++s2, ++n)
+            if (arith && n < cap) arith[n] = of_task[b->task_of[b->read_first_task[r] + s2]];
+    }
+    seg_off[b->n_reads] = n;
+    return NPR_OK;
 }
 
 namespace {

@@ -247,7 +247,17 @@ int launch_mea_gather(const MeaArgs &a, void *stream);
 int launch_em_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
 int launch_em_tile(const KernelArgs &a, int R, int grid, void *stream);  // k_em_tile: the E-step on column stripes
 size_t em_tile_lds_bytes(int nw);
-int launch_pair(const KernelArgs &a, int R, int grid, void *stream);  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once
+int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
+// k_dp_rs<R> (npr_kernel_rs.hip): the one-wavefront frame kernel in row-scaled arithmetic (npr_rs.h) -- one exponent per
+// anti-diagonal row instead of one per cell.  A task's scratch region (8 bytes per cell of its frame schedule, as for
+// k_dp_stair) holds the forward rows at 4 bytes per cell in its first half and the row exponents, one word per NPR_RS_K
+// anti-diagonals, from byte 4 * rs_half_cells(cells) on.
+#ifndef NPR_RS_K
+#define NPR_RS_K 8
+#endif
+NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }
+int launch_rs(const KernelArgs &a, int R, int grid, void *stream);
+size_t rs_lds_bytes();  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once
 int em_tile_waves();
 int em_tile_waves_per_cu();
 size_t em_wide_lds_bytes(int nw);

@@ -1,0 +1,304 @@
+// npr_kernel_rs.hip -- k_dp_rs<R>: the one-wavefront frame kernel (k_dp_stair's mapping: npr_kernel_stair.hip) in
+// ROW-SCALED arithmetic (npr_rs.h): one exponent per anti-diagonal row of the wavefront instead of one per cell.
+//
+// Same recurrences -- cactus_realign's banded five-state forward / backward / posterior pass, SURVEY.md 8a rows
+// a5.3-a5.5, reference call sites nanopore/analyses/utils.py:587, alignmentUncertainty.py:41,
+// marginAlignSnpCaller.py:136-146 --, same frame, same frame schedule and control words (npr_sched.h), same outputs
+// (TaskOut, sparse posterior triples).  What differs from k_dp_stair is the cell: five plain fp32 values, the exponent in an
+// SGPR, 18 / 20 multiply-adds per cell and direction and nothing else in the recurrence, rows of 4 bytes per cell in the
+// forward scratch.  The kernel for every band a wavefront's frame can hold (classes 0-2: NPR_ARITH=cell brings the
+// per-cell-exponent kernels back for A/B runs).
+#include <hip/hip_runtime.h>
+
+#include "npr_device.h"
+#include "npr_frame.h"
+#include "npr_rs.h"
+
+namespace npr {
+
+namespace {
+
+// exponents of the forward rows, one per RS_K anti-diagonals, read back by the backward sweep 64 blocks at a time:
+// lane l holds the exponent of block `base` - l
+struct FexpWindow {
+    int v;
+    int base;
+};
+__device__ __forceinline__ void fexp_fill(FexpWindow &w, const int *fexp, int blk, int lane) {
+    w.base = blk;
+    const int k = blk - lane;
+    w.v = k >= 0 ? fexp[k] : 0;
+}
+__device__ __forceinline__ int fexp_of(FexpWindow &w, const int *fexp, int d, int lane) {
+    const int blk = d / RS_K;
+    if (w.base - blk >= WAVE) fexp_fill(w, fexp, blk, lane);  // uniform
+    return __builtin_amdgcn_readlane(w.v, w.base - blk);
+}
+
+template <int R>
+__global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RsTables *ltab = reinterpret_cast<RsTables *>(smem);
+    float *lmodel = reinterpret_cast<float *>(smem) + ((RS_TABLE_FLOATS + 3) & ~3);
+    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);
+
+    const int lane = threadIdx.x;
+    int64_t fcell = static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
+    if (a.region) fcell = a.region[blockIdx.x];
+    char *const F = a.F + uni64(fcell) * 8;
+    const int voff = 4 * R * lane;  // byte offset of this lane's cells inside a row that starts at lane 0
+    int jr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
+
+    int t = blockIdx.x;
+    while (t < a.ntasks) {
+        const Task *tp = a.tasks + t;
+        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off), pair_off = uni64(tp->pair_off);
+        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap), flags = uni(tp->flags),
+                  model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
+        const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(uni(tp->cells_pad))));
+        int *const fexp = reinterpret_cast<int *>(F + 4 * half);
+        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
+        const __amdgpu_buffer_rsrc_t frs = rs_task_rsrc<R>(F);
+        const int rs = flags & 1, re = (flags >> 1) & 1;
+
+        __syncthreads();
+        {
+            const float *gm = reinterpret_cast<const float *>(a.models + model);
+            for (int i = lane; i < MODEL_FLOATS; i += WAVE) lmodel[i] = gm[i];
+        }
+        __syncthreads();
+        rs_build_tables(ltab, reinterpret_cast<const DevModel *>(lmodel), lane, WAVE);
+        __syncthreads();
+        StepEnv E;
+        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
+        E.ltab = reinterpret_cast<const char *>(ltab);
+        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
+        {
+            Trans tr = load_trans(E.mdl->T);
+            if constexpr (R >= NPR_RS_T_SGPR_MIN_R) {
+                tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
+                tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
+                tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
+                tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
+            }
+            E.tr = tr;
+        }
+        const DevModel *mdl = E.mdl;
+
+        // =============================== forward ===============================
+        // A holds the even anti-diagonals, B the odd ones; X-steps lead into odd anti-diagonals, Y-steps into even ones.
+        RsState<R> Q;
+        Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
+        const RowCtl<R> c0 = read_row_ctl<R>(ctl, 0);
+        const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
+        Q.x0 = -j0, Q.y0 = j0;
+        Q.e = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r] - 1);
+            Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r] - 1);
+            Q.hA[r] = c0.mk.cell[r], Q.hB[r] = 0;
+        }
+        Q.S.xcap = Q.S.ycap = RS_N8;
+        feed8_init<+1>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);  // first X-step injects X[(x0 + 1) + 64R - 2]
+        feed8_init<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);               // first Y-step injects Y[(y0 + 1) - 1]
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (jr[r] == j0) {
+                RCell c;
+                c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
+                c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
+                Q.A.c[r] = c;
+            }
+        if (lane == 0) fexp[0] = 0;
+        rs_store_row<R>(frs, Q.A, c0, voff);
+        RowCtl<R> nx = c0;
+        if (D >= 1) nx = read_row_ctl<R>(ctl, 1);
+        int d = 1;
+        cptr32 cp = ctl + 2;  // the control words of d
+        for (; d + 1 <= D; d += 2, cp += 4) {
+            RowCtl<R> cur = nx;
+            nx = read_row_ctl_at<R>(cp + 2);  // one ahead
+            if (cur.reb) rs_fwd_rebase<R>(E, cur.reb, Q);
+            rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, cur.mk);
+            rs_store_row<R>(frs, Q.B, cur, voff);
+            cur = nx;
+            if (d + 2 <= D) nx = read_row_ctl_at<R>(cp + 4);
+            if (cur.reb) rs_fwd_rebase<R>(E, cur.reb, Q);
+            rs_fwd_y_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.y0, cur.mk);
+            if (((d + 1) & (RS_K - 1)) == 0) {  // a renormalising row: both held rows, then the row goes out with its new exponent
+                Q.e += rs_renorm<R>(Q.A, Q.B);
+                if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
+            }
+            rs_store_row<R>(frs, Q.A, cur, voff);
+        }
+        if (d <= D) {  // D odd: one more X-step, into B
+            if (nx.reb) rs_fwd_rebase<R>(E, nx.reb, Q);
+            rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, nx.mk);
+            rs_store_row<R>(frs, Q.B, nx, voff);
+        }
+        // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
+        {
+            const int je = lX - Q.x0;
+            const bool oddD = D & 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (jr[r] == je) {
+                    const RCell c = oddD ? Q.B.c[r] : Q.A.c[r];
+                    const float raw = rs_dot5(mdl->end + re * 5, c);
+                    float tm = 0.f;
+                    int te = E_DEAD;
+                    if (raw > 0.f) {
+                        int k;
+                        tm = __builtin_frexpf(raw, &k);
+                        te = Q.e + k;
+                    }
+                    reinterpret_cast<float *>(lmisc)[0] = tm;
+                    lmisc[1] = te;
+                }
+        }
+        __syncthreads();
+        const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
+        const int tot_e = uni(lmisc[1]);
+        __syncthreads();
+
+        TaskOut out;
+        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
+        out.status = NPR_OK;
+        const bool alive = tot_m > 0.f;
+        if (!alive) out.status = NPR_ERR_ZERO_PROB;
+
+        // =============================== backward + posteriors ===============================
+        int cnt = 0;
+        if (alive) {
+            const float inv_tot = 1.0f / tot_m;
+            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            // A holds the even anti-diagonals again, B the odd ones; fa / fb the forward rows that pair with them, loaded one
+            // anti-diagonal ahead.  S now holds X[x]*8 and Y[y]*8 of every slot.  Q.e: the backward rows' exponent.
+            Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
+            Q.e = 0;
+            const bool oddD = D & 1;
+            RowCtl<R> cur = read_row_ctl<R>(ctl, D);
+            FexpWindow fw;
+            fexp_fill(fw, fexp, D / RS_K, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r]);
+                Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r]);
+                Q.hA[r] = oddD ? 0 : cur.mk.cell[r], Q.hB[r] = oddD ? cur.mk.cell[r] : 0;
+                if (Q.x0 + jr[r] == lX) {  // the end corner (it is in the band by construction)
+                    RCell c;
+                    c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
+                    c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
+                    if (oddD) Q.B.c[r] = c; else Q.A.c[r] = c;
+                }
+            }
+            Q.S.xcap = Q.S.ycap = RS_N8;
+            // first undone X-step injects X[x0 - 1] at slot 0; first undone Y-step injects Y[y0 - 64R] on top
+            feed8_init<-1>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
+            feed8_init<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
+            RFRow<R> fa, fb;
+#pragma unroll
+            for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f;
+            RowCtl<R> nxt = cur;
+            if (oddD) {
+                rs_load_row<R>(frs, fb, cur, voff);
+                nxt = read_row_ctl<R>(ctl, D - 1);
+                rs_load_row<R>(frs, fa, nxt, voff);
+                rs_emit_pairs<R>(sink, Q.B, fb, D, Q.x0, Q.y0, cur.mk, fexp_of(fw, fexp, D, lane) + Q.e - tot_e, inv_tot, jr, cnt);
+            } else {
+                rs_load_row<R>(frs, fa, cur, voff);
+                if (D >= 1) {
+                    nxt = read_row_ctl<R>(ctl, D - 1);
+                    rs_load_row<R>(frs, fb, nxt, voff);
+                }
+                rs_emit_pairs<R>(sink, Q.A, fa, D, Q.x0, Q.y0, cur.mk, fexp_of(fw, fexp, D, lane) + Q.e - tot_e, inv_tot, jr, cnt);
+            }
+            // `cur` is the control word of the anti-diagonal above the one computed next: its rebase is undone first
+            int d2 = D - 1;
+            if (oddD) {  // peel one even anti-diagonal so that the loop below always starts on an odd one
+                const int reb = cur.reb;
+                cur = nxt;
+                if (d2 >= 1) {
+                    nxt = read_row_ctl<R>(ctl, d2 - 1);
+                    rs_load_row<R>(frs, fb, nxt, voff);
+                }
+                if (reb) rs_bwd_rebase<R>(E, reb, Q);
+                rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
+                if ((d2 & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
+                rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, fexp_of(fw, fexp, d2, lane) + Q.e - tot_e, inv_tot, jr, cnt);
+                d2 -= 1;
+            }
+            cptr32 cq = ctl + 2 * static_cast<int64_t>(d2 - 2);  // the control words of d2 - 2 (read only while d2 >= 2)
+            for (; d2 >= 1; d2 -= 2, cq -= 4) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
+                int reb = cur.reb;
+                cur = nxt;
+                nxt = read_row_ctl_at<R>(cq + 2);
+                rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
+                if (reb) rs_bwd_rebase<R>(E, reb, Q);
+                rs_bwd_y_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.y0, cur.mk);
+                const int ef = fexp_of(fw, fexp, d2, lane);  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
+                rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, ef + Q.e - tot_e, inv_tot, jr, cnt);
+                reb = cur.reb;
+                cur = nxt;
+                if (d2 >= 2) {
+                    nxt = read_row_ctl_at<R>(cq);
+                    rs_load_row<R>(frs, fb, nxt, voff);
+                }
+                if (reb) rs_bwd_rebase<R>(E, reb, Q);
+                rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
+                if (((d2 - 1) & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
+                rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, ef + Q.e - tot_e, inv_tot, jr, cnt);
+            }
+            // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (jr[r] == j0) {
+                    const RCell cz = Q.A.c[r];
+                    const float raw = rs_dot5(mdl->start + rs * 5, cz);
+                    float bm = 0.f;
+                    int be = E_DEAD;
+                    if (raw > 0.f) {
+                        int k;
+                        bm = __builtin_frexpf(raw, &k);
+                        be = Q.e + k;
+                    }
+                    reinterpret_cast<float *>(lmisc)[2] = bm;
+                    lmisc[3] = be;
+                }
+            __syncthreads();
+            out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
+            out.btot_e = uni(lmisc[3]);
+        }
+        if (lane == 0) {
+            out.npairs = cnt;
+            if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
+            a.outs[t] = out;
+        }
+        int nt = 0;
+        if (lane == 0) nt = atomicAdd(a.queue, 1);
+        t = uni(nt) + static_cast<int>(gridDim.x);
+    }
+}
+
+}  // namespace
+
+size_t rs_lds_bytes() { return sizeof(float) * (((RS_TABLE_FLOATS + 3) & ~3) + MODEL_FLOATS + 8); }
+
+int launch_rs(const KernelArgs &a, int R, int grid, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = rs_lds_bytes();
+    if (R == 1)
+        hipLaunchKernelGGL(k_dp_rs<1>, dim3(grid), dim3(WAVE), lds, s, a);
+    else if (R == 2)
+        hipLaunchKernelGGL(k_dp_rs<2>, dim3(grid), dim3(WAVE), lds, s, a);
+    else if (R == 4)
+        hipLaunchKernelGGL(k_dp_rs<4>, dim3(grid), dim3(WAVE), lds, s, a);
+    else
+        return static_cast<int>(hipErrorInvalidValue);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace npr

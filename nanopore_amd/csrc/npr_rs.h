@@ -1,0 +1,460 @@
+// npr_rs.h -- the ROW-SCALED arithmetic of the one-wavefront frame kernels (k_dp_rs<R>, npr_kernel_rs.hip; round 3).
+//
+// npr_cell.h carries one binary exponent per CELL next to its five mantissas.  That costs about 20 of a cell's ~55 vector
+// instructions per sweep direction (three scale factors built from exponent differences, the reference-exponent maximum,
+// the per-cell renormalisation, the exponent's own neighbour move and its band mask) and half of the forward row's bytes.
+// A wavefront that holds a whole band row of an anti-diagonal can share ONE exponent per row instead -- the classic
+// scaled forward / backward recurrence of an HMM (cactus_realign's five-state machine, SURVEY.md 8a rows a5.3-a5.5,
+// reference call sites nanopore/analyses/utils.py:587, alignmentUncertainty.py:41, marginAlignSnpCaller.py:136-146):
+//   * a cell is five plain fp32 values relative to 2^e, e wave-uniform (an SGPR); the two anti-diagonals held in registers
+//     always share the same e, so the recurrence is 18 (forward) / 20 (backward) multiplies and FMAs and nothing else;
+//   * after every RS_K-th anti-diagonal (d % RS_K == 0) the largest value of the two held rows is found (integer maximum of
+//     the bit patterns -- the values are non-negative --, six DPP steps across the wavefront), both rows are multiplied by the
+//     power of two that brings it into [0.5, 1), and e moves by as much.  In between a row loses at most a few binary
+//     orders per step, far inside fp32's range; cells more than ~2^-126 below their row's maximum denormalise and flush,
+//     which no posterior >= the reporting threshold can see;
+//   * slots outside the band hold exact zeros, kept so by computing a row under the band's lane mask (EXEC) and clearing
+//     the slots a band edge has left behind -- no per-cell select;
+//   * a forward row goes to the scratch as 4 bytes per cell (the match value) and the row exponents as one word per
+//     RS_K rows; the backward sweep multiplies F * B * 2^(eF + eB - eTot) / totMant with the exponent sum on the scalar unit.
+// oracle/realign_oracle_rs.c restates this sequence operation by operation; the parity tests demand identical bits.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "npr_frame.h"
+
+namespace npr {
+
+namespace {
+
+#ifndef NPR_RS_T_SGPR_MIN_R
+#define NPR_RS_T_SGPR_MIN_R 4  // transitions in SGPRs from this many slots per lane on (below: VGPRs)
+#endif
+constexpr int RS_K = NPR_RS_K;  // npr_device.h: shared with the host (scratch layout) and restated by the mirror
+static_assert(RS_K >= 2 && (RS_K & (RS_K - 1)) == 0 && (RS_K & 1) == 0, "renormalising rows must be even anti-diagonals");
+
+struct RCell {
+    float m, sx, sy, lx, ly;
+};
+template <int R>
+struct RDiag {
+    RCell c[R];
+};
+__device__ __forceinline__ RCell zero_rcell() { return RCell{0.f, 0.f, 0.f, 0.f, 0.f}; }
+template <int R>
+__device__ __forceinline__ RDiag<R> zero_rdiag() {
+    RDiag<R> d;
+#pragma unroll
+    for (int r = 0; r < R; ++r) d.c[r] = zero_rcell();
+    return d;
+}
+
+// out[j] = in[j+1] / in[j-1]; the vacated edge slot takes 0
+template <int R>
+__device__ __forceinline__ RDiag<R> rs_shift_up(const RDiag<R> &in) {
+    RDiag<R> o;
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) o.c[r] = in.c[r + 1];
+    o.c[R - 1].m = dppf_from_above(in.c[0].m);
+    o.c[R - 1].sx = dppf_from_above(in.c[0].sx);
+    o.c[R - 1].sy = dppf_from_above(in.c[0].sy);
+    o.c[R - 1].lx = dppf_from_above(in.c[0].lx);
+    o.c[R - 1].ly = dppf_from_above(in.c[0].ly);
+    return o;
+}
+template <int R>
+__device__ __forceinline__ RDiag<R> rs_shift_down(const RDiag<R> &in) {
+    RDiag<R> o;
+#pragma unroll
+    for (int r = 1; r < R; ++r) o.c[r] = in.c[r - 1];
+    o.c[0].m = dppf_from_below(in.c[R - 1].m);
+    o.c[0].sx = dppf_from_below(in.c[R - 1].sx);
+    o.c[0].sy = dppf_from_below(in.c[R - 1].sy);
+    o.c[0].lx = dppf_from_below(in.c[R - 1].lx);
+    o.c[0].ly = dppf_from_below(in.c[R - 1].ly);
+    return o;
+}
+
+// ---- base streams: codes pre-multiplied by 8 (byte offsets into the tables below); code 4 (N) = 32 ----
+constexpr int RS_N8 = 32;
+__device__ __forceinline__ int base8(const uint8_t *seq, int len, int idx) {
+    return (idx >= 0 && idx < len) ? 8 * static_cast<int>(seq[idx]) : RS_N8;
+}
+template <int DIR>
+__device__ __forceinline__ void feed8_init(Feed &f, const uint8_t *seq, int len, int first, int lane) {
+    f.base = first;
+    f.cur = base8(seq, len, first + DIR * lane);
+    f.nxt = base8(seq, len, first + DIR * (64 + lane));
+}
+template <int DIR>
+__device__ __forceinline__ int feed8_get(Feed &f, const uint8_t *seq, int len, int idx, int lane) {
+    int off = uni(DIR * (idx - f.base));
+    if (off >= 64) {  // uniform
+        f.cur = f.nxt;
+        f.base += DIR * 64;
+        f.nxt = base8(seq, len, f.base + DIR * (64 + lane));
+        off -= 64;
+    }
+    return __builtin_amdgcn_readlane(f.cur, off);
+}
+
+// ---- emission tables in LDS, laid out for byte offsets that are base codes * 8 ----
+//   em8[5x + y] (8-byte stride: byte offset 5 * bx + by), ex2[x] = (shortGapX, longGapX), ey2[y] = (shortGapY, longGapY)
+struct RsTables {
+    float em8[25][2];
+    float ex2[5][2];
+    float ey2[5][2];
+};
+constexpr int RS_TABLE_FLOATS = sizeof(RsTables) / sizeof(float);
+__device__ __forceinline__ void rs_build_tables(RsTables *t, const DevModel *m, int tid, int nthreads) {
+    for (int i = tid; i < 25; i += nthreads) t->em8[i][0] = m->em[i], t->em8[i][1] = 0.f;
+    for (int i = tid; i < 5; i += nthreads) {
+        t->ex2[i][0] = m->ex[5 + i], t->ex2[i][1] = m->ex[15 + i];
+        t->ey2[i][0] = m->ey[10 + i], t->ey2[i][1] = m->ey[20 + i];
+    }
+}
+__device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
+    constexpr int OFF_EX = offsetof(RsTables, ex2), OFF_EY = offsetof(RsTables, ey2);
+    em = *reinterpret_cast<const float *>(tab + (__umul24(static_cast<unsigned>(bx), 5u) + static_cast<unsigned>(by)));
+    const float2 ex = *reinterpret_cast<const float2 *>(tab + OFF_EX + bx);
+    const float2 ey = *reinterpret_cast<const float2 *>(tab + OFF_EY + by);
+    exs = ex.x, exl = ex.y, eys = ey.x, eyl = ey.y;
+}
+
+// ---- the recurrence (same operand order as npr_cell.h, minus the scale factors) ----
+// forward: L = (x-1, y), M = (x-1, y-1), U = (x, y-1)
+__device__ __forceinline__ RCell rs_fwd_cell(const Trans &t, const RCell &L, const RCell &M, const RCell &U, float em, float exs, float exl,
+                                             float eys, float eyl) {
+    RCell c;
+    float a;
+    a = t.mm * M.m;
+    a = __builtin_fmaf(t.sxm, M.sx, a);
+    a = __builtin_fmaf(t.sym, M.sy, a);
+    a = __builtin_fmaf(t.lxm, M.lx, a);
+    a = __builtin_fmaf(t.lym, M.ly, a);
+    c.m = em * a;
+    a = t.msx * L.m;
+    a = __builtin_fmaf(t.sxsx, L.sx, a);
+    a = __builtin_fmaf(t.sysx, L.sy, a);
+    c.sx = exs * a;
+    a = t.mlx * L.m;
+    a = __builtin_fmaf(t.lxlx, L.lx, a);
+    c.lx = exl * a;
+    a = t.msy * U.m;
+    a = __builtin_fmaf(t.sysy, U.sy, a);
+    a = __builtin_fmaf(t.sxsy, U.sx, a);
+    c.sy = eys * a;
+    a = t.mly * U.m;
+    a = __builtin_fmaf(t.lyly, U.ly, a);
+    c.ly = eyl * a;
+    return c;
+}
+// backward: Ms = (x+1, y+1), Xs = (x+1, y), Ys = (x, y+1)
+__device__ __forceinline__ RCell rs_bwd_cell(const Trans &t, const RCell &Ms, const RCell &Xs, const RCell &Ys, float em, float exs, float exl,
+                                             float eys, float eyl) {
+    const float am = em * Ms.m;
+    const float asx = exs * Xs.sx;
+    const float alx = exl * Xs.lx;
+    const float asy = eys * Ys.sy;
+    const float aly = eyl * Ys.ly;
+    RCell c;
+    float b;
+    b = t.mm * am;
+    b = __builtin_fmaf(t.msx, asx, b);
+    b = __builtin_fmaf(t.mlx, alx, b);
+    b = __builtin_fmaf(t.msy, asy, b);
+    b = __builtin_fmaf(t.mly, aly, b);
+    c.m = b;
+    b = t.sxm * am;
+    b = __builtin_fmaf(t.sxsx, asx, b);
+    b = __builtin_fmaf(t.sxsy, asy, b);
+    c.sx = b;
+    b = t.sym * am;
+    b = __builtin_fmaf(t.sysy, asy, b);
+    b = __builtin_fmaf(t.sysx, asx, b);
+    c.sy = b;
+    b = t.lxm * am;
+    b = __builtin_fmaf(t.lxlx, alx, b);
+    c.lx = b;
+    b = t.lym * am;
+    b = __builtin_fmaf(t.lyly, aly, b);
+    c.ly = b;
+    return c;
+}
+__device__ __forceinline__ float rs_dot5(const float *w, const RCell &c) {
+    float a = w[0] * c.m;
+    a = __builtin_fmaf(w[1], c.sx, a);
+    a = __builtin_fmaf(w[2], c.sy, a);
+    a = __builtin_fmaf(w[3], c.lx, a);
+    a = __builtin_fmaf(w[4], c.ly, a);
+    return a;
+}
+
+// ---- renormalisation of the two held rows ----
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    // row_shr:1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast:15 / :31 across them: lane 63 ends with the maximum
+    // (a lane without a valid source keeps its own value: `old` = v)
+    const int s = static_cast<int>(v);
+    int t = __builtin_amdgcn_update_dpp(s, s, 0x111, 0xf, 0xf, false);
+    int w = static_cast<int>(max(static_cast<uint32_t>(s), static_cast<uint32_t>(t)));
+    t = __builtin_amdgcn_update_dpp(w, w, 0x112, 0xf, 0xf, false);
+    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
+    t = __builtin_amdgcn_update_dpp(w, w, 0x114, 0xf, 0xf, false);
+    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
+    t = __builtin_amdgcn_update_dpp(w, w, 0x118, 0xf, 0xf, false);
+    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
+    t = __builtin_amdgcn_update_dpp(w, w, 0x142, 0xa, 0xf, false);
+    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
+    t = __builtin_amdgcn_update_dpp(w, w, 0x143, 0xc, 0xf, false);
+    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(w, 63));
+}
+__device__ __forceinline__ uint32_t rcell_max_bits(const RCell &c) {
+    return umax3(umax3(static_cast<uint32_t>(fbits(c.m)), static_cast<uint32_t>(fbits(c.sx)), static_cast<uint32_t>(fbits(c.sy))),
+                 static_cast<uint32_t>(fbits(c.lx)), static_cast<uint32_t>(fbits(c.ly)));
+}
+__device__ __forceinline__ void rcell_scale(RCell &c, float f) { c.m *= f, c.sx *= f, c.sy *= f, c.lx *= f, c.ly *= f; }
+// Brings the largest value of the two rows into [0.5, 1); returns what to add to the rows' exponent (wave-uniform).
+// A row pair without a normal number (all zero: a dead band) is left alone.
+template <int R>
+__device__ __forceinline__ int rs_renorm(RDiag<R> &P, RDiag<R> &Q) {
+    uint32_t u = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) u = umax3(u, rcell_max_bits(P.c[r]), rcell_max_bits(Q.c[r]));
+    const uint32_t top = wave_max_u32(u);
+    int eb = static_cast<int>(top >> 23);
+    if (eb == 0) return 0;
+    eb = min(eb, 252);
+    const float f = bitsf((253 - eb) << 23);  // 2^(126 - eb)
+#pragma unroll
+    for (int r = 0; r < R; ++r) rcell_scale(P.c[r], f), rcell_scale(Q.c[r], f);
+    return eb - 126;
+}
+
+// ---- in-place moves of a row by one slot (frame rebase); see npr_frame.h for why this is inline assembly ----
+template <int R>
+__device__ __forceinline__ void rdiag_up_inplace(RDiag<R> &g) {
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) {
+        rot_up(g.c[r].m, g.c[r + 1].m), rot_up(g.c[r].sx, g.c[r + 1].sx), rot_up(g.c[r].sy, g.c[r + 1].sy);
+        rot_up(g.c[r].lx, g.c[r + 1].lx), rot_up(g.c[r].ly, g.c[r + 1].ly);
+    }
+    RCell &t = g.c[R - 1];
+    dpp_up_inplace(t.m), dpp_up_inplace(t.sx), dpp_up_inplace(t.sy), dpp_up_inplace(t.lx), dpp_up_inplace(t.ly);
+}
+template <int R>
+__device__ __forceinline__ void rdiag_down_inplace(RDiag<R> &g) {
+#pragma unroll
+    for (int r = R - 1; r > 0; --r) {
+        rot_up(g.c[r].m, g.c[r - 1].m), rot_up(g.c[r].sx, g.c[r - 1].sx), rot_up(g.c[r].sy, g.c[r - 1].sy);
+        rot_up(g.c[r].lx, g.c[r - 1].lx), rot_up(g.c[r].ly, g.c[r - 1].ly);
+    }
+    RCell &t = g.c[0];
+    dpp_down_inplace(t.m), dpp_down_inplace(t.sx), dpp_down_inplace(t.sy), dpp_down_inplace(t.lx), dpp_down_inplace(t.ly);
+}
+// the lane masks of a held row move with it
+template <int R>
+__device__ __forceinline__ void held_up(uint64_t (&h)[R]) {
+    const uint64_t first = h[0];
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) h[r] = h[r + 1];
+    h[R - 1] = first >> 1;
+}
+template <int R>
+__device__ __forceinline__ void held_down(uint64_t (&h)[R]) {
+    const uint64_t last = h[R - 1];
+#pragma unroll
+    for (int r = R - 1; r > 0; --r) h[r] = h[r - 1];
+    h[0] = last << 1;
+}
+
+// A sweep's register state: the even anti-diagonals in A, the odd ones in B, the lane masks of the rows they hold (in
+// the frame's present coordinates), the base streams and the rows' common exponent.
+template <int R>
+struct RsState {
+    RDiag<R> A, B;
+    uint64_t hA[R], hB[R];
+    Streams<R> S;
+    int x0, y0;
+    int e;
+};
+
+template <int R>
+__device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
+    if (r > 0) {
+        rdiag_up_inplace<R>(Q.A), rdiag_up_inplace<R>(Q.B);
+        held_up<R>(Q.hA), held_up<R>(Q.hB);
+        Q.x0 += 1, Q.y0 -= 1;
+        bases_up_inplace<R>(Q.S.X, feed8_get<+1>(Q.S.fx, E.X, E.lX, Q.x0 + 64 * R - 2, E.lane));
+        bases_up_inplace<R>(Q.S.Y, Q.S.ycap);
+    } else {
+        rdiag_down_inplace<R>(Q.A), rdiag_down_inplace<R>(Q.B);
+        held_down<R>(Q.hA), held_down<R>(Q.hB);
+        Q.x0 -= 1, Q.y0 += 1;
+        bases_down_inplace<R>(Q.S.X, Q.S.xcap);
+        bases_down_inplace<R>(Q.S.Y, feed8_get<+1>(Q.S.fy, E.Y, E.lY, Q.y0 - 1, E.lane));
+    }
+}
+template <int R>
+__device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
+    if (r > 0) {
+        rdiag_down_inplace<R>(Q.A), rdiag_down_inplace<R>(Q.B);
+        held_down<R>(Q.hA), held_down<R>(Q.hB);
+        Q.x0 -= 1, Q.y0 += 1;
+        bases_down_inplace<R>(Q.S.X, feed8_get<-1>(Q.S.fx, E.X, E.lX, Q.x0, E.lane));
+        bases_down_inplace<R>(Q.S.Y, Q.S.ycap);
+    } else {
+        rdiag_up_inplace<R>(Q.A), rdiag_up_inplace<R>(Q.B);
+        held_up<R>(Q.hA), held_up<R>(Q.hB);
+        Q.x0 += 1, Q.y0 -= 1;
+        bases_up_inplace<R>(Q.S.X, Q.S.xcap);
+        bases_up_inplace<R>(Q.S.Y, feed8_get<-1>(Q.S.fy, E.Y, E.lY, Q.y0 - (64 * R - 1), E.lane));
+    }
+}
+
+// The new row replaces the one two anti-diagonals away, under the band's lane mask; slots that row had inside ITS band
+// and this one has not are cleared (a band edge moves by a slot now and then: a scalar test, seldom taken).
+template <class F>
+__device__ __forceinline__ void rs_put(RCell &dst, uint64_t in_band, uint64_t &held, F &&cell) {
+    if (lanes_of(in_band)) dst = cell();  // the arithmetic itself runs under the mask: no select per value
+    const uint64_t gone = held & ~in_band;
+    if (gone) {
+        if (lanes_of(gone)) dst = zero_rcell();
+    }
+    held = in_band;
+}
+
+// One forward anti-diagonal: `io` holds d-2 on entry and d on exit, `p1` holds d-1.  S.X / S.Y: X[x-1]*8, Y[y-1]*8.
+template <int R>
+__device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &p1, Streams<R> &S, int &x0,
+                                              const Masks<R> &mk) {
+    S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
+    x0 += 1;
+    bases_up<R>(S.X, feed8_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
+    const RDiag<R> U = rs_shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
+    }
+}
+template <int R>
+__device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &p1, Streams<R> &S, int &y0,
+                                              const Masks<R> &mk) {
+    S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
+    y0 += 1;
+    bases_down<R>(S.Y, feed8_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
+    const RDiag<R> L = rs_shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
+    }
+}
+// One backward anti-diagonal d: `io` holds d+2 on entry and d on exit, `s1` holds d+1.  S.X / S.Y: X[x]*8, Y[y]*8.
+template <int R>
+__device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &s1, Streams<R> &S, int &x0,
+                                              const Masks<R> &mk) {
+    S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
+    x0 -= 1;
+    bases_down<R>(S.X, feed8_get<-1>(S.fx, E.X, E.lX, x0, E.lane));
+    const RDiag<R> Ys = rs_shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
+    }
+}
+template <int R>
+__device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &s1, Streams<R> &S, int &y0,
+                                              const Masks<R> &mk) {
+    S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
+    y0 -= 1;
+    bases_up<R>(S.Y, feed8_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
+    const RDiag<R> Xs = rs_shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float em, exs, exl, eys, eyl;
+        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
+    }
+}
+
+// ---- forward rows in HBM: 4 bytes per slot (the match value); the row offsets of the control words are the 8-byte
+// layout's (npr_sched.h), halved ----
+typedef int v2i_rs __attribute__((ext_vector_type(2)));
+template <int R>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_task_rsrc(char *F) {
+    return __builtin_amdgcn_make_buffer_rsrc(F - static_cast<int64_t>(row_bias<R>() / 2), 0, -1, 0x00020000);
+}
+template <int R>
+__device__ __forceinline__ void rs_store_row(__amdgpu_buffer_rsrc_t rs, const RDiag<R> &C, const RowCtl<R> &ct, int voff) {
+    if (lanes_of(ct.mk.lanes)) {
+        const int vo = voff + static_cast<int>(ct.soff >> 1);
+        if constexpr (R == 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(fbits(C.c[0].m), rs, vo, 0, 0);
+        } else if constexpr (R == 2) {
+            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), fbits(C.c[1].m)}, rs, vo, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), fbits(C.c[1].m), fbits(C.c[2].m), fbits(C.c[3].m)}, rs, vo, 0, 0);
+        }
+    }
+}
+template <int R>
+struct RFRow {
+    float v[R];
+};
+template <int R>
+__device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> &f, const RowCtl<R> &ct, int voff) {
+    if (lanes_of(ct.mk.lanes)) {
+        const int vo = voff + static_cast<int>(ct.soff >> 1);
+        if constexpr (R == 1) {
+            f.v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0));
+        } else if constexpr (R == 2) {
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, 0);
+            f.v[0] = bitsf(q.x), f.v[1] = bitsf(q.y);
+        } else {
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            f.v[0] = bitsf(q.x), f.v[1] = bitsf(q.y), f.v[2] = bitsf(q.z), f.v[3] = bitsf(q.w);
+        }
+    }
+}
+
+// posteriors of one anti-diagonal: (F * B) * 2^s / totMant with s = eF + eB - eTot, wave-uniform
+template <int R>
+__device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> &B, const RFRow<R> &f, int d, int x0, int y0, const Masks<R> &mk,
+                                              int s, float inv_tot, const int (&jr)[R], int &cnt) {
+    s = min(max(s, -200), 200);
+    float p[R];
+    uint64_t hit[R], any = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        p[r] = __builtin_ldexpf(f.v[r] * B.c[r].m, s) * inv_tot;
+        hit[r] = __ballot(p[r] >= S.threshold) & mk.cell[r];
+        any |= hit[r];
+    }
+    if (d >= 2 && any) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (hit[r]) {
+                const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                const int slot = cnt + before;
+                if (lanes_of(hit[r]) && slot < S.cap) {
+                    S.px[S.off + slot] = x0 + jr[r] - 1 + S.xs;
+                    S.py[S.off + slot] = y0 - jr[r] - 1 + S.ys;
+                    S.pp[S.off + slot] = p[r];
+                }
+                cnt += __popcll(hit[r]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+}  // namespace npr

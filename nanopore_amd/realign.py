@@ -77,6 +77,17 @@ class Batch(object):
         k = self._L.npr_batch_class_stats(self._h, ptr(t), ptr(c), 16)
         return t[:k], c[:k]
 
+    def segment_arith(self):
+        """-> (seg_off[n+1], arith): per segment of every read, in read order, the device arithmetic it ran in (0: one
+        exponent per cell, 1: one per anti-diagonal row; include/nprealign.h: npr_batch_segment_arith)."""
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        rc = self._L.npr_batch_segment_arith(self._h, ptr(off), None, 0)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_segment_arith")
+        ar = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
+        self._L.npr_batch_segment_arith(self._h, ptr(off), ptr(ar), len(ar))
+        return off, ar[:int(off[-1])]
+
     def stats(self):
         st = _lib.BatchStats()
         self._L.npr_batch_get_stats(self._h, C.byref(st))
@@ -313,13 +324,15 @@ class Context(object):
             res = b.results()
             off, ops = b.ops()
             out = []
+            aoff, arith = b.segment_arith()
             if want_pairs:
                 poff, x, y, p = b.pairs()
             for i in range(b.n_reads):
                 d = dict(status=int(res["status"][i]), score=float(res["score"][i]), loglik=float(res["loglik"][i]),
                          loglik_bwd=float(res["loglik_bwd"][i]), cells=int(res["cells"][i]),
                          n_segments=int(res["n_segments"][i]), n_pairs=int(res["n_pairs"][i]),
-                         ops=[(int(a), int(c)) for a, c in ops[off[i]:off[i + 1]]])
+                         ops=[(int(a), int(c)) for a, c in ops[off[i]:off[i + 1]]],
+                         seg_arith=[int(v) for v in arith[aoff[i]:aoff[i + 1]]])
                 if want_pairs:
                     d["x"] = x[poff[i]:poff[i + 1]].copy()
                     d["y"] = y[poff[i]:poff[i + 1]].copy()

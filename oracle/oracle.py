@@ -52,12 +52,12 @@ def build(native=False, force=False):
     """Compile the oracle.  native=True builds liboracle_native.so with -march=native (CPU baseline)."""
     name = "liboracle_native.so" if native else "liboracle.so"
     path = os.path.join(_HERE, name)
-    srcs = [os.path.join(_HERE, f) for f in ("realign_oracle.c", "realign_oracle_f32.c", "realign_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("realign_oracle.c", "realign_oracle_f32.c", "realign_oracle_rs.c", "realign_oracle.h")]
     if not force and os.path.exists(path) and all(os.path.getmtime(path) >= os.path.getmtime(s) for s in srcs):
         return path
     march = "-march=native" if native else "-march=x86-64-v2"
     cmd = ["gcc", "-O3", march, "-std=gnu11", "-fPIC", "-fopenmp", "-ffp-contract=off", "-shared", "-o", path,
-           srcs[0], srcs[1], "-lm"]
+           srcs[0], srcs[1], srcs[2], "-lm"]
     subprocess.check_call(cmd)
     return path
 
@@ -84,6 +84,8 @@ def lib(native=False):
         L.orc_fb_f32.argtypes = [C.POINTER(Hmm), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_int32, C.c_float] + [C.c_void_p] * 11 + [
                                      C.c_int64, C.c_void_p]
+        L.orc_fb_f32_rs.restype = C.c_int32
+        L.orc_fb_f32_rs.argtypes = L.orc_fb_f32.argtypes
         L.orc_expectations_f64.restype = C.c_int32
         L.orc_expectations_f64.argtypes = [C.POINTER(Hmm), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -97,6 +99,13 @@ def lib(native=False):
         L.orc_realign_read.argtypes = [C.POINTER(Hmm), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ReadResult)]
+        L.orc_realign_read_arith.restype = C.c_int32
+        L.orc_realign_read_arith.argtypes = [C.POINTER(Hmm), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ReadResult)]
+        L.orc_realign_batch_arith.restype = C.c_int32
+        L.orc_realign_batch_arith.argtypes = [C.POINTER(Hmm), C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64] + [
+            C.c_void_p] * 13 + [C.c_int32]
         L.orc_realign_batch.restype = C.c_int32
         L.orc_realign_batch.argtypes = [C.POINTER(Hmm), C.POINTER(Params), C.c_int32, C.c_int64] + [
             C.c_void_p] * 13 + [C.c_int32]
@@ -201,7 +210,9 @@ def fb_f64(hmm, X, Y, lo, n, ragged_start=0, ragged_end=0, threshold=0.01, dense
                 px=px[:k].copy(), py=py[:k].copy(), pp=pp[:k].copy())
 
 
-def fb_f32(hmm, X, Y, lo, n, ragged_start=0, ragged_end=0, threshold=0.01, dense=True):
+def fb_f32(hmm, X, Y, lo, n, ragged_start=0, ragged_end=0, threshold=0.01, dense=True, arith=0):
+    """fp32 mirror of the device arithmetic: arith 0 = one exponent per cell (realign_oracle_f32.c), 1 = one per anti-diagonal
+    row (realign_oracle_rs.c)."""
     L = lib()
     X = np.ascontiguousarray(X, dtype=np.uint8)
     Y = np.ascontiguousarray(Y, dtype=np.uint8)
@@ -219,7 +230,7 @@ def fb_f32(hmm, X, Y, lo, n, ragged_start=0, ragged_end=0, threshold=0.01, dense
     tm, bm = C.c_float(0), C.c_float(0)
     te, be = C.c_int32(0), C.c_int32(0)
     npairs = C.c_int64(0)
-    rc = L.orc_fb_f32(C.byref(hmm), _p(X), len(X), _p(Y), len(Y), _p(lo), _p(n), ragged_start, ragged_end,
+    rc = (L.orc_fb_f32_rs if arith else L.orc_fb_f32)(C.byref(hmm), _p(X), len(X), _p(Y), len(Y), _p(lo), _p(n), ragged_start, ragged_end,
                       threshold, C.addressof(tm), C.addressof(te), C.addressof(bm), C.addressof(be), _p(Fv),
                       _p(Fe), _p(Bv), _p(Be), _p(px), _p(py), _p(pp), cap, C.addressof(npairs))
     k = npairs.value
@@ -266,8 +277,11 @@ def rescore(ops, px, py, pp):
     return L.orc_rescore(_p(ops), len(ops), _p(px), _p(py), _p(pp), len(px))
 
 
-def realign_read(hmm, params, X, Y, guide_ops, precision=0, want_pairs=True):
+def realign_read(hmm, params, X, Y, guide_ops, precision=0, want_pairs=True, seg_arith=None):
+    """seg_arith (precision 1 only): the fp32 arithmetic of each segment as the product reports it (`seg_arith` of a
+    Context.realign result / Batch.segment_arith): 0 per-cell exponents, 1 row-scaled; None: 0 everywhere."""
     L = lib()
+    sa = None if seg_arith is None else np.ascontiguousarray(seg_arith, dtype=np.int32)
     X = np.ascontiguousarray(X, dtype=np.uint8)
     Y = np.ascontiguousarray(Y, dtype=np.uint8)
     g = ops_array(guide_ops)
@@ -278,16 +292,17 @@ def realign_read(hmm, params, X, Y, guide_ops, precision=0, want_pairs=True):
     py = np.zeros(cap_pairs, dtype=np.int32)
     pp = np.zeros(cap_pairs, dtype=np.float64)
     res = ReadResult()
-    rc = L.orc_realign_read(C.byref(hmm), C.byref(params), precision, _p(X), len(X), _p(Y), len(Y), _p(g), len(g),
-                            _p(out), cap_ops, _p(px), _p(py), _p(pp), cap_pairs, C.byref(res))
+    rc = L.orc_realign_read_arith(C.byref(hmm), C.byref(params), precision, _p(sa), 0 if sa is None else len(sa), _p(X), len(X),
+                                  _p(Y), len(Y), _p(g), len(g), _p(out), cap_ops, _p(px), _p(py), _p(pp), cap_pairs, C.byref(res))
     k = res.npairs
     return dict(status=rc, cells=res.cells, total_ll=res.total_ll, score=res.score,
                 ops=[(int(a), int(b)) for a, b in out[:res.nops]], px=px[:k].copy(), py=py[:k].copy(),
                 pp=pp[:k].copy())
 
 
-def realign_batch(hmm, params, X, x_off, Y, y_off, guide_ops, g_off, precision=0, threads=0, native=False):
-    """CSR batch; returns dict(ops=list of arrays, score, total_ll, cells, status)."""
+def realign_batch(hmm, params, X, x_off, Y, y_off, guide_ops, g_off, precision=0, threads=0, native=False, seg_arith=None):
+    """CSR batch; returns dict(ops=list of arrays, score, total_ll, cells, status).  seg_arith: (seg_off, arith) as
+    Batch.segment_arith returns them (precision 1: which fp32 arithmetic each segment ran in on the device)."""
     L = lib(native=native)
     X = np.ascontiguousarray(X, dtype=np.uint8)
     Y = np.ascontiguousarray(Y, dtype=np.uint8)
@@ -305,8 +320,13 @@ def realign_batch(hmm, params, X, x_off, Y, y_off, guide_ops, g_off, precision=0
     ll = np.zeros(nreads)
     cells = np.zeros(nreads, dtype=np.int64)
     status = np.zeros(nreads, dtype=np.int32)
-    L.orc_realign_batch(C.byref(hmm), C.byref(params), precision, nreads, _p(X), _p(x_off), _p(Y), _p(y_off),
-                        _p(g), _p(g_off), _p(out), _p(o_off), _p(nops), _p(score), _p(ll), _p(cells),
-                        _p(status), threads)
+    so = sa = None
+    if seg_arith is not None:
+        so = np.ascontiguousarray(seg_arith[0], dtype=np.int64)
+        sa = np.ascontiguousarray(seg_arith[1], dtype=np.int32)
+        assert len(so) == nreads + 1
+    L.orc_realign_batch_arith(C.byref(hmm), C.byref(params), precision, _p(so), _p(sa), nreads, _p(X), _p(x_off), _p(Y), _p(y_off),
+                              _p(g), _p(g_off), _p(out), _p(o_off), _p(nops), _p(score), _p(ll), _p(cells),
+                              _p(status), threads)
     ops = [out[o_off[i]:o_off[i] + nops[i]].copy() for i in range(nreads)]
     return dict(ops=ops, score=score, total_ll=ll, cells=cells, status=status)

@@ -728,6 +728,14 @@ int32_t orc_realign_read(const orc_hmm *h, const orc_params *p, int32_t precisio
                          int64_t lX, const uint8_t *Y, int64_t lY, const int32_t *guide_ops,
                          int64_t n_guide_ops, int32_t *out_ops, int64_t cap_ops, int32_t *px, int32_t *py,
                          double *pp, int64_t cap_pairs, orc_read_result *res) {
+    return orc_realign_read_arith(h, p, precision, NULL, 0, X, lX, Y, lY, guide_ops, n_guide_ops, out_ops, cap_ops, px, py,
+                                  pp, cap_pairs, res);
+}
+
+int32_t orc_realign_read_arith(const orc_hmm *h, const orc_params *p, int32_t precision, const int32_t *seg_arith,
+                               int64_t n_seg_arith, const uint8_t *X, int64_t lX, const uint8_t *Y, int64_t lY,
+                               const int32_t *guide_ops, int64_t n_guide_ops, int32_t *out_ops, int64_t cap_ops,
+                               int32_t *px, int32_t *py, double *pp, int64_t cap_pairs, orc_read_result *res) {
     memset(res, 0, sizeof(*res));
     int32_t st = 0;
     orc_plan *pl = orc_plan_build(lX, lY, guide_ops, n_guide_ops, p, &st);
@@ -756,9 +764,11 @@ int32_t orc_realign_read(const orc_hmm *h, const orc_params *p, int32_t precisio
             float tm = 0.f, bm = 0.f;
             int32_t te = 0, be = 0;
             float *pf = (float *)malloc(sizeof(float) * (size_t)(cap_pairs - np + 1));
-            st = orc_fb_f32(h, X + g->xs, g->xe - g->xs, Y + g->ys, g->ye - g->ys, g->lo, g->n, g->ragged_start,
-                            g->ragged_end, (float)p->posterior_threshold, &tm, &te, &bm, &be, NULL, NULL, NULL,
-                            NULL, px + np, py + np, pf, cap_pairs - np, &got);
+            const int rs = seg_arith && s < n_seg_arith && seg_arith[s] == 1;
+            st = (rs ? orc_fb_f32_rs : orc_fb_f32)(h, X + g->xs, g->xe - g->xs, Y + g->ys, g->ye - g->ys, g->lo, g->n,
+                                                   g->ragged_start, g->ragged_end, (float)p->posterior_threshold, &tm, &te,
+                                                   &bm, &be, NULL, NULL, NULL, NULL, px + np, py + np, pf, cap_pairs - np,
+                                                   &got);
             if (st == 0)
                 for (int64_t i = 0; i < got; i++) pp[np + i] = (double)pf[i];
             free(pf);
@@ -814,15 +824,25 @@ int32_t orc_realign_batch(const orc_hmm *h, const orc_params *p, int32_t precisi
                           const int32_t *guide_ops, const int64_t *g_off, int32_t *out_ops, const int64_t *o_off,
                           int64_t *out_nops, double *out_score, double *out_ll, int64_t *out_cells,
                           int32_t *out_status, int32_t threads) {
+    return orc_realign_batch_arith(h, p, precision, NULL, NULL, nreads, X, x_off, Y, y_off, guide_ops, g_off, out_ops, o_off,
+                                   out_nops, out_score, out_ll, out_cells, out_status, threads);
+}
+
+int32_t orc_realign_batch_arith(const orc_hmm *h, const orc_params *p, int32_t precision, const int64_t *seg_off,
+                                const int32_t *seg_arith, int64_t nreads, const uint8_t *X, const int64_t *x_off,
+                                const uint8_t *Y, const int64_t *y_off, const int32_t *guide_ops, const int64_t *g_off,
+                                int32_t *out_ops, const int64_t *o_off, int64_t *out_nops, double *out_score,
+                                double *out_ll, int64_t *out_cells, int32_t *out_status, int32_t threads) {
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #pragma omp parallel for schedule(dynamic, 1)
 #endif
     for (int64_t i = 0; i < nreads; i++) {
         orc_read_result r;
-        orc_realign_read(h, p, precision, X + x_off[i], x_off[i + 1] - x_off[i], Y + y_off[i],
-                         y_off[i + 1] - y_off[i], guide_ops + 2 * g_off[i], g_off[i + 1] - g_off[i],
-                         out_ops + 2 * o_off[i], o_off[i + 1] - o_off[i], NULL, NULL, NULL, 0, &r);
+        orc_realign_read_arith(h, p, precision, seg_arith && seg_off ? seg_arith + seg_off[i] : NULL,
+                               seg_arith && seg_off ? seg_off[i + 1] - seg_off[i] : 0, X + x_off[i], x_off[i + 1] - x_off[i],
+                               Y + y_off[i], y_off[i + 1] - y_off[i], guide_ops + 2 * g_off[i], g_off[i + 1] - g_off[i],
+                               out_ops + 2 * o_off[i], o_off[i + 1] - o_off[i], NULL, NULL, NULL, 0, &r);
         out_nops[i] = r.nops;
         out_score[i] = r.score;
         out_ll[i] = r.total_ll;

@@ -126,6 +126,15 @@ int32_t orc_fb_f32(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
                    float *Fm_v, int32_t *Fm_e, float *Bm_v, int32_t *Bm_e, int32_t *px, int32_t *py,
                    float *pp, int64_t cap, int64_t *npairs);
 
+/* fp32 mirror of the device's ROW-SCALED arithmetic (realign_oracle_rs.c; nanopore_amd/csrc/npr_rs.h: the kernels of the
+ * bands one wavefront's frame holds): plain fp32 cells relative to one binary exponent per anti-diagonal row, both held
+ * rows renormalised after every 8th anti-diagonal.  Same signature; Fm / Bm are the match values with their row's exponent. */
+int32_t orc_fb_f32_rs(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t *Y, int64_t lY,
+                      const int32_t *lo, const int32_t *n, int32_t ragged_start, int32_t ragged_end,
+                      float threshold, float *tot_m, int32_t *tot_e, float *btot_m, int32_t *btot_e,
+                      float *Fm_v, int32_t *Fm_e, float *Bm_v, int32_t *Bm_e, int32_t *px, int32_t *py,
+                      float *pp, int64_t cap, int64_t *npairs);
+
 /* ---- maximum expected accuracy chain + cigar ---- */
 /* pairs in any order; lX,lY the full spans; out_ops receives (op,len) pairs (capacity cap_ops pairs).
  * Returns number of ops, or <0 on error. score = mean posterior of the chosen pairs. */
@@ -156,6 +165,19 @@ int32_t orc_realign_read(const orc_hmm *h, const orc_params *p, int32_t precisio
 
 /* batch of reads (CSR layout), OpenMP over reads; used by bench.py's cpu_baseline leg.
  * Only totals are returned: per-read cells, score, status. threads<=0 -> omp default. */
+/* orc_realign_read with the fp32 arithmetic named per segment (matrix split), as the product reports it
+ * (npr_batch_segment_arith): seg_arith[s] 0 = per-cell exponents (orc_fb_f32), 1 = row-scaled (orc_fb_f32_rs); NULL or
+ * fewer than the read's segments: 0.  Only read when precision == 1. */
+int32_t orc_realign_read_arith(const orc_hmm *h, const orc_params *p, int32_t precision, const int32_t *seg_arith,
+                               int64_t n_seg_arith, const uint8_t *X, int64_t lX, const uint8_t *Y, int64_t lY,
+                               const int32_t *guide_ops, int64_t n_guide_ops, int32_t *out_ops, int64_t cap_ops,
+                               int32_t *px, int32_t *py, double *pp, int64_t cap_pairs, orc_read_result *res);
+/* ... and for a batch: seg_off[nreads + 1] into seg_arith (NULL: all 0) */
+int32_t orc_realign_batch_arith(const orc_hmm *h, const orc_params *p, int32_t precision, const int64_t *seg_off,
+                                const int32_t *seg_arith, int64_t nreads, const uint8_t *X, const int64_t *x_off,
+                                const uint8_t *Y, const int64_t *y_off, const int32_t *guide_ops, const int64_t *g_off,
+                                int32_t *out_ops, const int64_t *o_off, int64_t *out_nops, double *out_score,
+                                double *out_ll, int64_t *out_cells, int32_t *out_status, int32_t threads);
 int32_t orc_realign_batch(const orc_hmm *h, const orc_params *p, int32_t precision, int64_t nreads,
                           const uint8_t *X, const int64_t *x_off, const uint8_t *Y, const int64_t *y_off,
                           const int32_t *guide_ops, const int64_t *g_off /* in op pairs */,
