@@ -500,8 +500,8 @@ constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kQueueSlots =
 inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_PAIR; }
 // resident wavefronts per CU of the one-wavefront frame kernels (VGPR-limited: 71 / 80 / 162 registers: 7 / 6 / 3 per SIMD)
 inline int stair_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 12); }
-// ... and of k_dp_rs<R> (76 / 106 / 151 registers: 6 / 4 / 3 per SIMD)
-inline int rs_waves_per_cu(int R) { return R == 1 ? 24 : (R == 2 ? 16 : 12); }
+// ... and of k_dp_rs<R> (72 / 79 / 101 registers: 7 / 6 / 4 per SIMD; R = 2 measured at 5 / 6 / 7 / 8 per SIMD: 6 is best)
+inline int rs_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 16); }
 
 // Stripe table of k_dp_tile for one segment (npr_kernel_tile.hip): the lattice columns 0..lX cut into stripes of 64*R
 // columns; per stripe the first / last anti-diagonal on which the band has cells in it and the index of its first row in
@@ -783,7 +783,8 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     }
     std::vector<int32_t> sched_cls(ntasks, -1);
     std::vector<int64_t> sched_cells(ntasks, 0);
-    if ((e = b->d_ctl.alloc_from(ctx, 2 * ctl_entries)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+    if ((e = b->d_ctl.alloc_from(ctx, 2 * ctl_entries + 8)) != hipSuccess)  // (+8: k_dp_rs reads its control words two rows ahead)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     if (ctl_entries) {
         DevBuf<uint32_t> d_cand;
         DevBuf<int64_t> d_off, d_cells;

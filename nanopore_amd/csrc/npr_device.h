@@ -253,7 +253,7 @@ int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
 // k_dp_stair) holds the forward rows at 4 bytes per cell in its first half and the row exponents, one word per NPR_RS_K
 // anti-diagonals, from byte 4 * rs_half_cells(cells) on.
 #ifndef NPR_RS_K
-#define NPR_RS_K 8
+#define NPR_RS_K 16
 #endif
 NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }
 int launch_rs(const KernelArgs &a, int R, int grid, void *stream);

@@ -35,12 +35,68 @@ __device__ __forceinline__ int fexp_of(FexpWindow &w, const int *fexp, int d, in
     return __builtin_amdgcn_readlane(w.v, w.base - blk);
 }
 
+// The control words of 64 anti-diagonals at a time, a lane each, fetched with one vector load a block ahead of their use
+// and handed out by v_readlane.  (Through the scalar cache every anti-diagonal began with an s_load and a wait for it --
+// scalar loads return out of order, so the wait is for everything the wavefront has in flight on that counter, the
+// emission look-ups included; k_dp_stair hides that behind a step twice as long.)
+template <int DIR>
+struct CtlFeed {
+    uint2 cur, nxt;  // lane l: the words of anti-diagonal base + DIR * l / base + DIR * (64 + l)
+    int base;
+};
+__device__ __forceinline__ uint2 ctl_words(const uint2 *gw, int D, int d) { return (d >= 0 && d <= D) ? gw[d] : make_uint2(0u, 0u); }
+template <int DIR>
+__device__ __forceinline__ void ctl_init(CtlFeed<DIR> &f, const uint2 *gw, int D, int first, int lane) {
+    f.base = first;
+    f.cur = ctl_words(gw, D, first + DIR * lane);
+    f.nxt = ctl_words(gw, D, first + DIR * (WAVE + lane));
+}
+// The words of anti-diagonals d and d + DIR.  d moves monotonically in direction DIR by at most 64 per request and is an
+// even number of rows away from `first` (so that both lie in the same block of 64).
+struct CtlPair {
+    uint32_t a0, a1, b0, b1;
+};
+template <int DIR>
+__device__ __forceinline__ CtlPair ctl_get2(CtlFeed<DIR> &f, const uint2 *gw, int D, int d, int lane) {
+    int off = uni(DIR * (d - f.base));
+    if (off >= WAVE) {  // uniform
+        f.cur = f.nxt;
+        f.base += DIR * WAVE;
+        f.nxt = ctl_words(gw, D, f.base + DIR * (WAVE + lane));
+        off -= WAVE;
+    }
+    CtlPair p;
+    p.a0 = __builtin_amdgcn_readlane(f.cur.x, off), p.a1 = __builtin_amdgcn_readlane(f.cur.y, off);
+    p.b0 = __builtin_amdgcn_readlane(f.cur.x, off + 1), p.b1 = __builtin_amdgcn_readlane(f.cur.y, off + 1);
+    return p;
+}
+#ifndef NPR_RS_REBASE_ASM
+#define NPR_RS_REBASE_ASM 1
+#endif
+#if NPR_RS_REBASE_ASM
+#define RS_FWD_REBASE(r) rs_fwd_rebase<R>(E, (r), Q)
+#define RS_BWD_REBASE(r) rs_bwd_rebase<R>(E, (r), Q)
+#else
+#define RS_FWD_REBASE(r) do { if (r) rs_fwd_rebase_c<R>(E, (r), Q); } while (0)
+#define RS_BWD_REBASE(r) do { if (r) rs_bwd_rebase_c<R>(E, (r), Q); } while (0)
+#endif
+#ifndef NPR_RS_CTL
+#define NPR_RS_CTL 2  // control words: 0 vector feed + readlane, 1 scalar load when needed, 2 scalar load one iteration ahead (measured: 3.19 / 3.44 / 3.66e11 cells/s)
+#endif
+__device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
+    cptr32 e = ctl + 2 * static_cast<int64_t>(d);
+    return CtlPair{e[0], e[1], e[2], e[3]};
+}
+#ifndef NPR_RS_WAVES2
+#define NPR_RS_WAVES2 1  // wavefronts per SIMD the R = 2 kernel is compiled for (1: whatever its registers allow)
+#endif
 template <int R>
-__global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    RsTables *ltab = reinterpret_cast<RsTables *>(smem);
-    float *lmodel = reinterpret_cast<float *>(smem) + ((RS_TABLE_FLOATS + 3) & ~3);
-    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_rs(KernelArgs a) {
+    // static LDS: the tables' addresses are compile-time constants and fold into the ds_read offsets
+    __shared__ __attribute__((aligned(16))) RsTables ltab_s;
+    __shared__ __attribute__((aligned(16))) float lmodel[MODEL_FLOATS];
+    __shared__ int lmisc[8];
+    RsTables *ltab = &ltab_s;
 
     const int lane = threadIdx.x;
     int64_t fcell = static_cast<int64_t>(a.slot_base + blockIdx.x) * a.slot_stride;
@@ -59,7 +115,7 @@ __global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
                   model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
         const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(uni(tp->cells_pad))));
         int *const fexp = reinterpret_cast<int *>(F + 4 * half);
-        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
+        const uint2 *const gw = reinterpret_cast<const uint2 *>(a.ctl + 2 * ctl_off);
         const __amdgpu_buffer_rsrc_t frs = rs_task_rsrc<R>(F);
         const int rs = flags & 1, re = (flags >> 1) & 1;
 
@@ -91,7 +147,10 @@ __global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
         // A holds the even anti-diagonals, B the odd ones; X-steps lead into odd anti-diagonals, Y-steps into even ones.
         RsState<R> Q;
         Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
+        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
         const RowCtl<R> c0 = read_row_ctl<R>(ctl, 0);
+        CtlFeed<+1> cf;
+        ctl_init<+1>(cf, gw, D, 1, lane);  // blocks [1, 64], [65, 128], ..: an odd anti-diagonal and the even one after it together
         const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
         Q.x0 = -j0, Q.y0 = j0;
         Q.e = 0;
@@ -114,19 +173,27 @@ __global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
             }
         if (lane == 0) fexp[0] = 0;
         rs_store_row<R>(frs, Q.A, c0, voff);
-        RowCtl<R> nx = c0;
-        if (D >= 1) nx = read_row_ctl<R>(ctl, 1);
         int d = 1;
-        cptr32 cp = ctl + 2;  // the control words of d
-        for (; d + 1 <= D; d += 2, cp += 4) {
-            RowCtl<R> cur = nx;
-            nx = read_row_ctl_at<R>(cp + 2);  // one ahead
-            if (cur.reb) rs_fwd_rebase<R>(E, cur.reb, Q);
-            rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, cur.mk);
-            rs_store_row<R>(frs, Q.B, cur, voff);
-            cur = nx;
-            if (d + 2 <= D) nx = read_row_ctl_at<R>(cp + 4);
-            if (cur.reb) rs_fwd_rebase<R>(E, cur.reb, Q);
+#if NPR_RS_CTL == 2
+        CtlPair wn = ctl_scalar2(ctl, 1);  // (two words past the task's last row at most: still inside d_ctl or its padding)
+#endif
+        for (; d + 1 <= D; d += 2) {
+#if NPR_RS_CTL == 0
+            const CtlPair w = ctl_get2<+1>(cf, gw, D, d, lane);
+#elif NPR_RS_CTL == 1
+            const CtlPair w = ctl_scalar2(ctl, d);
+#else
+            const CtlPair w = wn;
+            wn = ctl_scalar2(ctl, d + 2);
+#endif
+            {
+                const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
+                RS_FWD_REBASE(cur.reb);
+                rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, cur.mk);
+                rs_store_row<R>(frs, Q.B, cur, voff);
+            }
+            const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
+            RS_FWD_REBASE(cur.reb);
             rs_fwd_y_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.y0, cur.mk);
             if (((d + 1) & (RS_K - 1)) == 0) {  // a renormalising row: both held rows, then the row goes out with its new exponent
                 Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -135,9 +202,17 @@ __global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
             rs_store_row<R>(frs, Q.A, cur, voff);
         }
         if (d <= D) {  // D odd: one more X-step, into B
-            if (nx.reb) rs_fwd_rebase<R>(E, nx.reb, Q);
-            rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, nx.mk);
-            rs_store_row<R>(frs, Q.B, nx, voff);
+#if NPR_RS_CTL == 0
+            const CtlPair w = ctl_get2<+1>(cf, gw, D, d, lane);
+#elif NPR_RS_CTL == 1
+            const CtlPair w = ctl_scalar2(ctl, d);
+#else
+            const CtlPair w = wn;
+#endif
+            const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
+            RS_FWD_REBASE(cur.reb);
+            rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, cur.mk);
+            rs_store_row<R>(frs, Q.B, cur, voff);
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
         {
@@ -180,6 +255,10 @@ __global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
             Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
             Q.e = 0;
             const bool oddD = D & 1;
+            // the loop's first request is for an even anti-diagonal (D - 2, or D - 3 after the peeled step of an odd D) and the
+            // odd one below it: blocks of 64 counted down from there
+            CtlFeed<-1> cb;
+            ctl_init<-1>(cb, gw, D, oddD ? D - 3 : D - 2, lane);
             RowCtl<R> cur = read_row_ctl<R>(ctl, D);
             FexpWindow fw;
             fexp_fill(fw, fexp, D / RS_K, lane);
@@ -225,29 +304,42 @@ __global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
                     nxt = read_row_ctl<R>(ctl, d2 - 1);
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
-                if (reb) rs_bwd_rebase<R>(E, reb, Q);
+                RS_BWD_REBASE(reb);
                 rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
                 if ((d2 & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, fexp_of(fw, fexp, d2, lane) + Q.e - tot_e, inv_tot, jr, cnt);
                 d2 -= 1;
             }
-            cptr32 cq = ctl + 2 * static_cast<int64_t>(d2 - 2);  // the control words of d2 - 2 (read only while d2 >= 2)
-            for (; d2 >= 1; d2 -= 2, cq -= 4) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
+#if NPR_RS_CTL == 2
+            CtlPair wb = ctl_scalar2(ctl, max(d2 - 2, 0));  // {d2 - 2, d2 - 1}
+#endif
+            for (; d2 >= 1; d2 -= 2) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
+#if NPR_RS_CTL == 0
+                const CtlPair w = ctl_get2<-1>(cb, gw, D, d2 - 1, lane);  // the words of d2 - 1 and d2 - 2
+#else
+#if NPR_RS_CTL == 1
+                const CtlPair q = ctl_scalar2(ctl, max(d2 - 2, 0));
+#else
+                const CtlPair q = wb;
+                wb = ctl_scalar2(ctl, max(d2 - 4, 0));
+#endif
+                const CtlPair w = d2 >= 2 ? CtlPair{q.b0, q.b1, q.a0, q.a1} : CtlPair{q.a0, q.a1, 0u, 0u};  // d2 = 1: rows {0, 1} were read
+#endif
                 int reb = cur.reb;
                 cur = nxt;
-                nxt = read_row_ctl_at<R>(cq + 2);
+                nxt = row_ctl_of_words<R>(w.a0, w.a1);
                 rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
-                if (reb) rs_bwd_rebase<R>(E, reb, Q);
+                RS_BWD_REBASE(reb);
                 rs_bwd_y_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.y0, cur.mk);
                 const int ef = fexp_of(fw, fexp, d2, lane);  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
                 rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, ef + Q.e - tot_e, inv_tot, jr, cnt);
                 reb = cur.reb;
                 cur = nxt;
                 if (d2 >= 2) {
-                    nxt = read_row_ctl_at<R>(cq);
+                    nxt = row_ctl_of_words<R>(w.b0, w.b1);
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
-                if (reb) rs_bwd_rebase<R>(E, reb, Q);
+                RS_BWD_REBASE(reb);
                 rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
                 if (((d2 - 1) & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, ef + Q.e - tot_e, inv_tot, jr, cnt);
@@ -285,7 +377,7 @@ __global__ void __launch_bounds__(WAVE) k_dp_rs(KernelArgs a) {
 
 }  // namespace
 
-size_t rs_lds_bytes() { return sizeof(float) * (((RS_TABLE_FLOATS + 3) & ~3) + MODEL_FLOATS + 8); }
+size_t rs_lds_bytes() { return 0; }  // static LDS only
 
 int launch_rs(const KernelArgs &a, int R, int grid, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -232,27 +232,73 @@ __device__ __forceinline__ int rs_renorm(RDiag<R> &P, RDiag<R> &Q) {
     return eb - 126;
 }
 
-// ---- in-place moves of a row by one slot (frame rebase); see npr_frame.h for why this is inline assembly ----
-template <int R>
-__device__ __forceinline__ void rdiag_up_inplace(RDiag<R> &g) {
-#pragma unroll
-    for (int r = 0; r + 1 < R; ++r) {
-        rot_up(g.c[r].m, g.c[r + 1].m), rot_up(g.c[r].sx, g.c[r + 1].sx), rot_up(g.c[r].sy, g.c[r + 1].sy);
-        rot_up(g.c[r].lx, g.c[r + 1].lx), rot_up(g.c[r].ly, g.c[r + 1].ly);
-    }
-    RCell &t = g.c[R - 1];
-    dpp_up_inplace(t.m), dpp_up_inplace(t.sx), dpp_up_inplace(t.sy), dpp_up_inplace(t.lx), dpp_up_inplace(t.ly);
+// ---- frame rebase: the whole register state moves by one slot, in place ----
+// ONE asm statement per register group with the test for "no rebase" inside it.  Written as C++ around per-register asm
+// (npr_frame.h's way) the rebase is a branch, the moved registers are new values on one side of it, and the compiler pays
+// for the join by copying 20-odd registers on the path WITHOUT a rebase, every anti-diagonal.  Inside one statement there
+// is no join to pay for: the hot path costs two scalar instructions.  dir: +1 every slot takes its upper neighbour (the
+// vacated top slot takes 0 / the injected base), -1 its lower neighbour, 0 nothing.  (s_nop: a DPP read of a VGPR written by
+// the previous VALU instruction needs two wait states, which the compiler cannot see through inline assembly.)
+__device__ __forceinline__ void rs_rebase_regs(RDiag<1> &P, RDiag<1> &Q, Bases<1> &X, Bases<1> &Y, int dir, int injX, int injY) {
+    asm volatile("s_cmp_eq_u32 %12, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %12, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %10, %13, 63\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %11, %14, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %10, %13, 0\n\tv_mov_b32_dpp %11, %11 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %11, %14, 0\n\t"
+                 "2:"
+                 : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly), "+v"(X.b[0]), "+v"(Y.b[0])
+                 : "s"(dir), "s"(injX), "s"(injY)
+                 : "scc");
 }
-template <int R>
-__device__ __forceinline__ void rdiag_down_inplace(RDiag<R> &g) {
-#pragma unroll
-    for (int r = R - 1; r > 0; --r) {
-        rot_up(g.c[r].m, g.c[r - 1].m), rot_up(g.c[r].sx, g.c[r - 1].sx), rot_up(g.c[r].sy, g.c[r - 1].sy);
-        rot_up(g.c[r].lx, g.c[r - 1].lx), rot_up(g.c[r].ly, g.c[r - 1].ly);
-    }
-    RCell &t = g.c[0];
-    dpp_down_inplace(t.m), dpp_down_inplace(t.sx), dpp_down_inplace(t.sy), dpp_down_inplace(t.lx), dpp_down_inplace(t.ly);
+__device__ __forceinline__ void rs_rebase_regs(RDiag<2> &P, RDiag<2> &Q, Bases<2> &X, Bases<2> &Y, int dir, int injX, int injY) {
+    asm volatile("s_cmp_eq_u32 %24, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %24, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\tv_swap_b32 %20, %21\n\tv_swap_b32 %22, %23\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %21, %21 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %21, %25, 63\n\tv_mov_b32_dpp %23, %23 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %23, %26, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %21, %20\n\tv_swap_b32 %23, %22\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %20, %20 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %20, %25, 0\n\tv_mov_b32_dpp %22, %22 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %22, %26, 0\n\t"
+                 "2:"
+                 : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly), "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1])
+                 : "s"(dir), "s"(injX), "s"(injY)
+                 : "scc");
 }
+__device__ __forceinline__ void rs_rebase_row4(RDiag<4> &P, int dir) {
+    asm volatile("s_cmp_eq_u32 %20, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %20, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %9, %10\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %13, %14\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %17, %18\n\tv_swap_b32 %18, %19\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %10, %9\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %14, %13\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %18, %17\n\tv_swap_b32 %17, %16\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "2:"
+                 : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[2].m), "+v"(P.c[3].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[2].sx), "+v"(P.c[3].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[2].sy), "+v"(P.c[3].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[2].lx), "+v"(P.c[3].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(P.c[2].ly), "+v"(P.c[3].ly)
+                 : "s"(dir)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_bases4(Bases<4> &X, Bases<4> &Y, int dir, int injX, int injY) {
+    asm volatile("s_cmp_eq_u32 %8, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %8, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %3, %9, 63\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %7, %10, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %9, 0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %4, %10, 0\n\t"
+                 "2:"
+                 : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(X.b[2]), "+v"(X.b[3]), "+v"(Y.b[0]), "+v"(Y.b[1]), "+v"(Y.b[2]), "+v"(Y.b[3])
+                 : "s"(dir), "s"(injX), "s"(injY)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_regs(RDiag<4> &P, RDiag<4> &Q, Bases<4> &X, Bases<4> &Y, int dir, int injX, int injY) {
+    rs_rebase_row4(P, dir), rs_rebase_row4(Q, dir), rs_rebase_bases4(X, Y, dir, injX, injY);
+}
+
 // the lane masks of a held row move with it
 template <int R>
 __device__ __forceinline__ void held_up(uint64_t (&h)[R]) {
@@ -280,8 +326,30 @@ struct RsState {
     int e;
 };
 
+// (A/B: the rebase as a C++ branch around per-register asm, NPR_RS_REBASE_ASM=0)
+// ---- in-place moves of a row by one slot (frame rebase); see npr_frame.h for why this is inline assembly ----
 template <int R>
-__device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
+__device__ __forceinline__ void rdiag_up_inplace(RDiag<R> &g) {
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) {
+        rot_up(g.c[r].m, g.c[r + 1].m), rot_up(g.c[r].sx, g.c[r + 1].sx), rot_up(g.c[r].sy, g.c[r + 1].sy);
+        rot_up(g.c[r].lx, g.c[r + 1].lx), rot_up(g.c[r].ly, g.c[r + 1].ly);
+    }
+    RCell &t = g.c[R - 1];
+    dpp_up_inplace(t.m), dpp_up_inplace(t.sx), dpp_up_inplace(t.sy), dpp_up_inplace(t.lx), dpp_up_inplace(t.ly);
+}
+template <int R>
+__device__ __forceinline__ void rdiag_down_inplace(RDiag<R> &g) {
+#pragma unroll
+    for (int r = R - 1; r > 0; --r) {
+        rot_up(g.c[r].m, g.c[r - 1].m), rot_up(g.c[r].sx, g.c[r - 1].sx), rot_up(g.c[r].sy, g.c[r - 1].sy);
+        rot_up(g.c[r].lx, g.c[r - 1].lx), rot_up(g.c[r].ly, g.c[r - 1].ly);
+    }
+    RCell &t = g.c[0];
+    dpp_down_inplace(t.m), dpp_down_inplace(t.sx), dpp_down_inplace(t.sy), dpp_down_inplace(t.lx), dpp_down_inplace(t.ly);
+}
+template <int R>
+__device__ __forceinline__ void rs_fwd_rebase_c(const StepEnv &E, int r, RsState<R> &Q) {
     if (r > 0) {
         rdiag_up_inplace<R>(Q.A), rdiag_up_inplace<R>(Q.B);
         held_up<R>(Q.hA), held_up<R>(Q.hB);
@@ -297,7 +365,7 @@ __device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R
     }
 }
 template <int R>
-__device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
+__device__ __forceinline__ void rs_bwd_rebase_c(const StepEnv &E, int r, RsState<R> &Q) {
     if (r > 0) {
         rdiag_down_inplace<R>(Q.A), rdiag_down_inplace<R>(Q.B);
         held_down<R>(Q.hA), held_down<R>(Q.hB);
@@ -313,16 +381,58 @@ __device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R
     }
 }
 
-// The new row replaces the one two anti-diagonals away, under the band's lane mask; slots that row had inside ITS band
-// and this one has not are cleared (a band edge moves by a slot now and then: a scalar test, seldom taken).
-template <class F>
-__device__ __forceinline__ void rs_put(RCell &dst, uint64_t in_band, uint64_t &held, F &&cell) {
-    if (lanes_of(in_band)) dst = cell();  // the arithmetic itself runs under the mask: no select per value
-    const uint64_t gone = held & ~in_band;
-    if (gone) {
-        if (lanes_of(gone)) dst = zero_rcell();
+// Frame rebase of the forward sweep, r = +1: (x0, y0) -> (x0 + 1, y0 - 1), every slot takes its upper neighbour; r = 0: nothing
+// (called on every anti-diagonal: only scalar code is conditional here).
+template <int R>
+__device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
+    int injX = Q.S.xcap, injY = Q.S.ycap;
+    if (r > 0) {
+        held_up<R>(Q.hA), held_up<R>(Q.hB);
+        Q.x0 += 1, Q.y0 -= 1;
+        injX = feed8_get<+1>(Q.S.fx, E.X, E.lX, Q.x0 + 64 * R - 2, E.lane);
+    } else if (r < 0) {
+        held_down<R>(Q.hA), held_down<R>(Q.hB);
+        Q.x0 -= 1, Q.y0 += 1;
+        injY = feed8_get<+1>(Q.S.fy, E.Y, E.lY, Q.y0 - 1, E.lane);
     }
-    held = in_band;
+    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, uni(r), uni(injX), uni(injY));
+}
+// ... and of the backward sweep, which undoes the forward one: r is the forward rebase being undone.
+template <int R>
+__device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
+    int injX = Q.S.xcap, injY = Q.S.ycap;
+    if (r > 0) {  // back to lower x-y: (x0 - 1, y0 + 1)
+        held_down<R>(Q.hA), held_down<R>(Q.hB);
+        Q.x0 -= 1, Q.y0 += 1;
+        injX = feed8_get<-1>(Q.S.fx, E.X, E.lX, Q.x0, E.lane);
+    } else if (r < 0) {
+        held_up<R>(Q.hA), held_up<R>(Q.hB);
+        Q.x0 += 1, Q.y0 -= 1;
+        injY = feed8_get<-1>(Q.S.fy, E.Y, E.lY, Q.y0 - (64 * R - 1), E.lane);
+    }
+    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, uni(-r), uni(injX), uni(injY));
+}
+
+// The new row replaces the one two anti-diagonals away, under the band's lane mask (the arithmetic itself runs under the
+// mask: no select per value) ...
+template <class F>
+__device__ __forceinline__ void rs_put(RCell &dst, uint64_t in_band, F &&cell) {
+    if (lanes_of(in_band)) dst = cell();
+}
+// ... and the slots that row had inside ITS band and this one has not are cleared (a band edge moves by a slot now and then:
+// one scalar test per anti-diagonal, seldom taken).
+template <int R>
+__device__ __forceinline__ void rs_clear_left(RDiag<R> &io, uint64_t (&hio)[R], const Masks<R> &mk) {
+    uint64_t gone = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) gone |= hio[r] & ~mk.cell[r];
+    if (gone) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (lanes_of(hio[r] & ~mk.cell[r])) io.c[r] = zero_rcell();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) hio[r] = mk.cell[r];
 }
 
 // One forward anti-diagonal: `io` holds d-2 on entry and d on exit, `p1` holds d-1.  S.X / S.Y: X[x-1]*8, Y[y-1]*8.
@@ -337,8 +447,9 @@ __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, ui
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
+        rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
     }
+    rs_clear_left<R>(io, hio, mk);
 }
 template <int R>
 __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &p1, Streams<R> &S, int &y0,
@@ -351,8 +462,9 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, ui
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
+        rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
     }
+    rs_clear_left<R>(io, hio, mk);
 }
 // One backward anti-diagonal d: `io` holds d+2 on entry and d on exit, `s1` holds d+1.  S.X / S.Y: X[x]*8, Y[y]*8.
 template <int R>
@@ -366,8 +478,9 @@ __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, ui
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
+        rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
     }
+    rs_clear_left<R>(io, hio, mk);
 }
 template <int R>
 __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &s1, Streams<R> &S, int &y0,
@@ -380,8 +493,9 @@ __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, ui
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], hio[r], [&] { return rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
+        rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
     }
+    rs_clear_left<R>(io, hio, mk);
 }
 
 // ---- forward rows in HBM: 4 bytes per slot (the match value); the row offsets of the control words are the 8-byte

@@ -128,7 +128,7 @@ int32_t orc_fb_f32(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t
 
 /* fp32 mirror of the device's ROW-SCALED arithmetic (realign_oracle_rs.c; nanopore_amd/csrc/npr_rs.h: the kernels of the
  * bands one wavefront's frame holds): plain fp32 cells relative to one binary exponent per anti-diagonal row, both held
- * rows renormalised after every 8th anti-diagonal.  Same signature; Fm / Bm are the match values with their row's exponent. */
+ * rows renormalised after every 16th anti-diagonal.  Same signature; Fm / Bm are the match values with their row's exponent. */
 int32_t orc_fb_f32_rs(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint8_t *Y, int64_t lY,
                       const int32_t *lo, const int32_t *n, int32_t ragged_start, int32_t ragged_end,
                       float threshold, float *tot_m, int32_t *tot_e, float *btot_m, int32_t *btot_e,

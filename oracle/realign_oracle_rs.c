@@ -6,7 +6,7 @@
  * recurrences as orc_fb_f64 (call sites nanopore/analyses/utils.py:587,
  * alignmentUncertainty.py:41, marginAlignSnpCaller.py:136-146) as the classic scaled HMM recurrence: the cells of an
  * anti-diagonal are plain fp32 values relative to one binary exponent shared by the whole row.  The two rows the
- * recurrence reads always carry the same exponent; after every RS_K-th anti-diagonal (d % RS_K == 0) both are
+ * recurrence reads always carry the same exponent; after every RS_K-th anti-diagonal (d % RS_K == 0, RS_K = 16) both are
  * multiplied by the power of two that brings their largest value into [0.5, 1).  Cells outside the band are exact
  * zeros.  The forward sweep keeps, per row, the match values as they were when the row was finished together with
  * the exponent they were relative to; the backward sweep forms F * B * 2^(eF + eB - eTot) / totMant.
@@ -23,7 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define RS_K 8 /* nanopore_amd/csrc/npr_device.h: NPR_RS_K */
+#define RS_K 16 /* nanopore_amd/csrc/npr_device.h: NPR_RS_K */
 #define E_DEAD (-(1 << 28))
 
 typedef struct {
