@@ -54,7 +54,8 @@ NOMINAL_CYCLES_PER_VALU = 2.0  # one wave64 VALU instruction per 2 cycles per SI
 # kernel class (npr_batch_class_stats) -> kernel name in profiles/kernel_table.json
 CLASS_KERNEL = {0: "k_dp_stair<1>", 1: "k_dp_stair<2>", 2: "k_dp_stair<4>", 3: "k_dp_wide", 4: "k_dp_wide", 5: "k_dp_wide",
                 6: "k_dp_wide", 7: "k_dp_generic", 8: "k_dp_generic", 9: "k_dp_generic", 10: "k_dp_generic", 11: "k_dp_tile<2>",
-                12: "k_dp_pair<1>", 13: "k_dp_pair<2>", 14: "k_dp_pair<4>"}
+                12: "k_dp_pair<1>", 13: "k_dp_pair<2>", 14: "k_dp_pair<4>", 15: "k_dp_rs<1>", 16: "k_dp_rs<2>", 17: "k_dp_rs<4>"}
+RS_BYTES_PER_CELL = 8.0     # k_dp_rs (row-scaled arithmetic: the exponent is per row, not per cell): 4 B stored + 4 B reloaded
 PAIR_BYTES_PER_CELL = 32.0  # k_dp_pair: the match rows of BOTH sweeps stored (2 x 8 B) and streamed back (2 x 8 B)
 EM_CLASS_KERNEL = {0: "k_em_stair<1>", 1: "k_em_stair<2>", 2: "k_em_stair<4>", 11: "k_em_tile<2>"}
 
@@ -185,16 +186,23 @@ def roofline_block(cells, pairs, kms, class_cells, clock_hz):
     kname = CLASS_KERNEL.get(dom, "k_dp")
     tab = kernel_table().get(kname, {})
     t = kms * 1e-3
-    per_cell = PAIR_BYTES_PER_CELL if kname.startswith("k_dp_pair") else BYTES_PER_CELL
+    per_cell = PAIR_BYTES_PER_CELL if kname.startswith("k_dp_pair") else (RS_BYTES_PER_CELL if kname.startswith("k_dp_rs") else BYTES_PER_CELL)
     achieved = (per_cell * cells + BYTES_PER_PAIR * pairs) / t / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": None, "kernel": kname, "kernel_ms": kms,
            "kernel_share_of_cells": float(class_cells[dom]) / max(float(np.sum(class_cells)), 1.0) if len(class_cells) else 1.0,
-           "algorithmic_bytes": ("%g B/cell (match state: 8 B stored by the forward sweep + 8 B reloaded by the backward sweep%s) + "
+           "algorithmic_bytes": ("%g B/cell (match state: %g B stored by the forward sweep + %g B reloaded by the backward sweep%s) + "
                                  "%g B/posterior pair (%d pairs); DESIGN.md section 4"
-                                 % (per_cell, "; k_dp_pair runs the sweeps side by side and stores / reloads the backward rows too" if per_cell > BYTES_PER_CELL else "",
+                                 % (per_cell, min(per_cell, 16.0) / 2, min(per_cell, 16.0) / 2,
+                                    "; k_dp_pair runs the sweeps side by side and stores / reloads the backward rows too" if per_cell > BYTES_PER_CELL else
+                                    ("; k_dp_rs keeps one exponent per anti-diagonal row instead of one per cell: half of round 2's 16 B/cell, so the same "
+                                     "cells/s is half the HBM fraction -- see round2_16B_equiv" if per_cell < BYTES_PER_CELL else ""),
                                     BYTES_PER_PAIR, pairs)),
-           "binding": "valu issue, not HBM (see valu)",
+           "binding": "vector and scalar issue, not HBM (see valu)",
+           "round2_16B_equiv": {"GBps": (BYTES_PER_CELL * cells + BYTES_PER_PAIR * pairs) / t / 1e9,
+                                "frac": (BYTES_PER_CELL * cells + BYTES_PER_PAIR * pairs) / t / 1e9 / HBM_PEAK_GBPS,
+                                "note": "the same launch priced at the 16 B/cell of the per-cell-exponent kernels (k_dp_stair, rounds 1-2): "
+                                        "what `frac` would read had the bytes not been halved; comparison only"},
            "declared_40B_equiv": {"GBps": DECLARED_BYTES_PER_CELL * cells / t / 1e9,
                                   "note": "SURVEY.md 8d prices a cell at 40 B (all five states stored and reloaded); this design "
                                           "stores only the match state, so that figure is NOT traffic it generates -- kept for "

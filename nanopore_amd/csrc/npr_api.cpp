@@ -257,6 +257,7 @@ struct npr_batch {
     std::vector<int32_t> task_of;        // [read_first_task[r] + s] -> index into tasks
     std::vector<int64_t> task_cells;     // in-band lattice cells per task (device order)
     std::vector<TaskOut> outs;
+    std::vector<uint8_t> task_rerun;     // row-scaled tasks npr_batch_run ran again with a per-cell exponent
     npr_batch_stats stats{};
     // device
     DevBuf<Task> d_tasks;
@@ -273,7 +274,6 @@ struct npr_batch {
     std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     bool variable_regions = false;  // the one-wavefront frame launches have regions of their own size (not E-step capable)
-    bool arith_rs = true;  // classes 0-2 run k_dp_rs (row-scaled arithmetic, npr_rs.h); NPR_ARITH=cell: k_dp_stair / k_dp_pair
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -485,23 +485,45 @@ bool build_stair_schedule(const Segment &s, int R, int NW, uint32_t *ctl, int64_
 // lane), the register kernel with NW wavefronts per task (k_dp_wide), the generic kernel with an LDS ring in three
 // width classes, the generic kernel with its ring in HBM.
 namespace {
-enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4, K_PAIR = 5 };
+enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4, K_PAIR = 5, K_RS = 6 };
 struct KClass {
     int kind, R, NW;
     int slots() const { return 64 * R * NW; }
 };
-constexpr int kClasses = 15;
+constexpr int kClasses = 18;
 constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STAIR, 4, 1}, {K_WIDE, 2, 4}, {K_WIDE, 2, 8},
                                         {K_WIDE, 4, 8}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
                                         {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}, {K_TILE, 2, 0},
                                         // k_dp_pair<R>: the one-wavefront frame classes 0-2 with the two sweeps on two wavefronts
-                                        {K_PAIR, 1, 1}, {K_PAIR, 2, 1}, {K_PAIR, 4, 1}};
-constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kQueueSlots = 16;
-inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_PAIR; }
+                                        {K_PAIR, 1, 1}, {K_PAIR, 2, 1}, {K_PAIR, 4, 1},
+                                        // k_dp_rs<R>: the one-wavefront frame classes 0-2 in row-scaled arithmetic (npr_rs.h)
+                                        {K_RS, 1, 1}, {K_RS, 2, 1}, {K_RS, 4, 1}};
+constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kFirstRs = 15, kQueueSlots = 24;
+inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_PAIR || kClassTab[c].kind == K_RS; }
+inline bool is_one_wave_kind(int kind) { return kind == K_STAIR || kind == K_RS; }  // one wavefront per task on the frame schedule
 // resident wavefronts per CU of the one-wavefront frame kernels (VGPR-limited: 71 / 80 / 162 registers: 7 / 6 / 3 per SIMD)
 inline int stair_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 12); }
 // ... and of k_dp_rs<R> (72 / 79 / 101 registers: 7 / 6 / 4 per SIMD; R = 2 measured at 5 / 6 / 7 / 8 per SIMD: 6 is best)
 inline int rs_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 16); }
+
+// Whether the row-scaled arithmetic (npr_rs.h) may be used with a model: its rows are renormalised to 2^NPR_RS_TOP every
+// NPR_RS_K anti-diagonals with 2^6 of headroom, so nothing may grow by more than 2^(6 / NPR_RS_K) per anti-diagonal -- the sum of
+// the transitions into a state times that state's largest emission (0.57 for the shipped models: values only shrink).
+bool rs_model_ok(const DevModel &m) {
+    double grow = 0.0, em_max = 0.0;
+    for (int x = 0; x < 4; ++x)
+        for (int y = 0; y < 4; ++y) em_max = std::max(em_max, static_cast<double>(m.em[x * 5 + y]));
+    for (int to = 0; to < 5; ++to) {
+        double col = 0.0, e = em_max;
+        for (int from = 0; from < 5; ++from) col += static_cast<double>(m.T[from * 5 + to]);
+        if (to > 0) {
+            e = 0.0;
+            for (int b2 = 0; b2 < 5; ++b2) e = std::max(e, static_cast<double>((to == 1 || to == 3) ? m.ex[to * 5 + b2] : m.ey[to * 5 + b2]));
+        }
+        grow = std::max(grow, col * e);
+    }
+    return grow <= std::exp2(6.0 / NPR_RS_K);
+}
 
 // Stripe table of k_dp_tile for one segment (npr_kernel_tile.hip): the lattice columns 0..lX cut into stripes of 64*R
 // columns; per stripe the first / last anti-diagonal on which the band has cells in it and the index of its first row in
@@ -831,16 +853,24 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // fair share of their class go to k_dp_pair (both sweeps at once on two wavefronts: half the chain, twice the memory
     // traffic), the longest first, as far as a second wavefront is to be had: all of them when the class does not fill the
     // chip anyway, else those that would outlast the others.  NPR_PAIR=0 / all: never / every task (A/B runs, tests).
-    bool any_pair = false;
+    // The one-wavefront frame tasks run in row-scaled arithmetic: classes 15-17, k_dp_rs -- every one of them, provided the
+    // loaded models let a row's values be renormalised every NPR_RS_K anti-diagonals (rs_model_ok); a task for which one exponent
+    // per row turns out not to be enough says so and npr_batch_run runs it again in class 0-2's kernel.  NPR_ARITH=cell: none
+    // (the per-cell-exponent kernels throughout, A/B).
     {
         const char *ae = std::getenv("NPR_ARITH");
-        b->arith_rs = !(ae && std::strcmp(ae, "cell") == 0);
+        bool rs = !(ae && std::strcmp(ae, "cell") == 0) && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS;
+        for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
+            if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) rs = false;
+        if (rs)
+            for (int64_t k = 0; k < ntasks; ++k)
+                if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
     }
+    bool any_pair = false;
     {
-        // (k_dp_pair is a per-cell-exponent kernel: with the row-scaled k_dp_rs as the default one-wavefront kernel it is an
-        // A/B variant, NPR_ARITH=cell)
+        // (k_dp_pair -- a per-cell-exponent kernel -- takes tasks of classes 0-2 only when asked to: NPR_PAIR=1 / all)
         const char *pe = std::getenv("NPR_PAIR");
-        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = (pe && pe[0] == '0') || b->arith_rs;
+        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = !pe || pe[0] == '0';
         if (!pair_off && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS)
             for (int c = 0; c < 3; ++c) {
                 std::vector<int32_t> mine;
@@ -983,11 +1013,11 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 128;
-        } else if (kClassTab[c].kind == K_STAIR) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
-            waves_per_cu = b->arith_rs ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R);
+        } else if (is_one_wave_kind(kClassTab[c].kind)) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
+            waves_per_cu = kClassTab[c].kind == K_RS ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R);
             // NPR_OPT_OVERLAP: one wavefront slot per SIMD (and its registers) left to the staging and MEA kernels of the
             // batches this one runs next to; the DP pass alone loses about 2 % (98 % VALU-busy at 5 wavefronts per SIMD)
-            if (ctx->overlap && c < 2) waves_per_cu -= 4;
+            if (ctx->overlap && kClassTab[c].R <= 2) waves_per_cu -= 4;
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 64;
@@ -1047,14 +1077,14 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     const int64_t tile_min = tileL ? tile_need[rank[tileL->first]] : 0;
     int64_t stair_grid = 0;
     for (auto &L : b->launches)
-        if (kClassTab[L.cls].kind == K_STAIR) stair_grid += L.grid;
+        if (is_one_wave_kind(kClassTab[L.cls].kind)) stair_grid += L.grid;
     int64_t var_min_bytes = int64_t(32) << 30;  // NPR_VARIABLE_SCRATCH_MIN (bytes; 0: always, tests): uniform stair scratch above this goes variable
     if (const char *v = std::getenv("NPR_VARIABLE_SCRATCH_MIN")) var_min_bytes = std::atoll(v);
     b->variable_regions = b->params.mode != NPR_MODE_EXPECTATIONS && stair_grid > 0 && stair_grid * b->slot_stride * 8 >= var_min_bytes &&
                           !force_generic;
     if (any_pair) b->variable_regions = true;  // (their regions hold two sets of rows: not a layout the E-step kernels know)
     auto uniform = [&](const npr_batch::Launch &L) {
-        return &L != tileL && kClassTab[L.cls].kind != K_PAIR && !(b->variable_regions && kClassTab[L.cls].kind == K_STAIR);
+        return &L != tileL && kClassTab[L.cls].kind != K_PAIR && !(b->variable_regions && is_one_wave_kind(kClassTab[L.cls].kind));
     };
     int64_t sum_grid = 0;
     for (auto &L : b->launches)
@@ -1101,7 +1131,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     };
     for (auto &L : b->launches) {
         const int kind = kClassTab[L.cls].kind;
-        if ((kind == K_STAIR && b->variable_regions && !uniform(L)) || kind == K_PAIR) {
+        if ((is_one_wave_kind(kind) && b->variable_regions && !uniform(L)) || kind == K_PAIR) {
             const int64_t sets = kind == K_PAIR ? 2 : 1;  // k_dp_pair keeps the backward rows too
             if (own_regions(L, [&](int32_t g) { return sets * ((pad_of[g] + 63) & ~int64_t(63)); }) != NPR_OK)
                 return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
@@ -1233,7 +1263,8 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
         const int rc = kc.kind == K_PAIR   ? launch_pair(a, kc.R, L.grid, s)
-                       : kc.kind == K_STAIR ? (b->arith_rs ? launch_rs(a, kc.R, L.grid, s) : launch_stair(a, kc.R, L.grid, s))
+                       : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s)
+                       : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
                        : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
                                            : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);
@@ -1249,6 +1280,44 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         HIP_TRY(ctx, hipMemcpy(pf, d_prof.p, sizeof(pf), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[npr tile prof] wavefront cycles: waiting for a neighbour %.3g, for own stores %.3g, at barriers %.3g, total %.3g\n",
                      (double)pf[0], (double)pf[1], (double)pf[2], (double)pf[3]);
+    }
+    // The row-scaled kernels report the tasks for which one exponent per row may not have been enough (TASK_RERUN,
+    // npr_device.h): those run again here, with the per-cell-exponent kernel of their frame class, on the scratch regions the
+    // first launch had.  Rare -- a row of the alignment ~110 binary orders below the product of the row's largest forward and
+    // backward values: an indel of 70+ bases --, so one more small launch per class at most.
+    b->outs.resize(b->tasks.size());
+    b->task_rerun.assign(b->tasks.size(), 0);
+    for (const auto &L : b->launches) {
+        if (kClassTab[L.cls].kind != K_RS) continue;
+        HIP_TRY(ctx, hipMemcpy(b->outs.data() + L.first, b->d_outs.p + L.first, sizeof(TaskOut) * L.count, hipMemcpyDeviceToHost));
+        std::vector<int32_t> again;
+        for (int k = L.first; k < L.first + L.count; ++k)
+            if (b->outs[k].status == TASK_RERUN) again.push_back(k);
+        if (again.empty()) continue;
+        std::vector<Task> sub(again.size());
+        for (size_t j = 0; j < again.size(); ++j) sub[j] = b->tasks[again[j]];
+        DevBuf<Task> d_sub;
+        DevBuf<TaskOut> d_subout;
+        if (d_sub.alloc(sub.size()) != hipSuccess || d_subout.alloc(sub.size()) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_run: hipMalloc");
+        HIP_TRY(ctx, hipMemcpy(d_sub.p, sub.data(), sizeof(Task) * sub.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p + L.cls, 0, sizeof(int32_t), ctx->stream));
+        KernelArgs a = make_args(b);
+        a.tasks = d_sub.p, a.outs = d_subout.p, a.ntasks = static_cast<int32_t>(sub.size());
+        a.queue += L.cls;
+        a.slot_base = L.slot_base;
+        a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;  // (task j of `again` is no larger than the j-th task of the class)
+        const int grid = static_cast<int>(std::min<size_t>(sub.size(), static_cast<size_t>(L.grid)));
+        const int rc = launch_stair(a, kClassTab[L.cls].R, grid, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch (second pass)", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<TaskOut> subout(sub.size());
+        HIP_TRY(ctx, hipMemcpy(subout.data(), d_subout.p, sizeof(TaskOut) * sub.size(), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < again.size(); ++j) {
+            b->outs[again[j]] = subout[j];
+            b->task_rerun[again[j]] = 1;
+            HIP_TRY(ctx, hipMemcpy(b->d_outs.p + again[j], &subout[j], sizeof(TaskOut), hipMemcpyHostToDevice));
+        }
+        if (std::getenv("NPR_TIMING")) std::fprintf(stderr, "[npr] class %d: %zu of %d tasks run again with a per-cell exponent\n", L.cls, again.size(), L.count);
     }
     b->ran = true;
     b->finished = false;
@@ -1273,8 +1342,8 @@ int32_t npr_batch_segment_arith(const npr_batch *b, int64_t *seg_off, int32_t *a
     if (!b || !seg_off) return NPR_ERR_INVALID;
     std::vector<int8_t> of_task(b->tasks.size(), 0);
     for (const auto &L : b->launches)
-        if (kClassTab[L.cls].kind == K_STAIR && b->arith_rs)
-            for (int k = L.first; k < L.first + L.count; ++k) of_task[k] = 1;
+        if (kClassTab[L.cls].kind == K_RS)
+            for (int k = L.first; k < L.first + L.count; ++k) of_task[k] = (static_cast<size_t>(k) < b->task_rerun.size() && b->task_rerun[k]) ? 0 : 1;
     int64_t n = 0;
     for (int64_t r = 0; r < b->n_reads; ++r) {
         seg_off[r] = n;
@@ -1768,7 +1837,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         L l{};
         l.first = dl.first, l.count = dl.count;
         l.slot_base = dl.slot_base, l.dp_grid = dl.grid, l.cells = dl.cells, l.region_first = dl.own_regions ? dl.region_first : -1;
-        if (kClassTab[dl.cls].kind == K_STAIR && !std::getenv("NPR_EM_GENERIC")) {
+        if (is_one_wave_kind(kClassTab[dl.cls].kind) && !std::getenv("NPR_EM_GENERIC")) {
             // 127 / 161 / 223 VGPRs and 9 KiB of LDS bins per wavefront: 16 / 12 / 8 wavefronts per CU
             l.stair_R = kClassTab[dl.cls].R;
             l.lds = em_stair_lds_bytes();

@@ -255,6 +255,21 @@ int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
 #ifndef NPR_RS_K
 #define NPR_RS_K 16
 #endif
+#ifndef NPR_RS_TOP
+#define NPR_RS_TOP 85  // the renormalised maximum of a row pair lies in [2^84, 2^85)
+#endif
+// The certificate that one exponent per row was enough.  s = eF + eB - eTot of an anti-diagonal turns a
+// forward-backward product into a posterior; the rows' maxima stay below 2^(NPR_RS_TOP + 6), so no F * 2^s or B * 2^s of that
+// row exceeds 2^(NPR_RS_TOP + 6 + s), and a cell whose other factor fell below fp32's normal range (2^-126 in row units: flushed,
+// or a denormal that lost bits) carries a true posterior mass below 2^(NPR_RS_TOP + 6 + s - 126 + 1).  While every s stays below
+// NPR_RS_S_LIMIT that is 2^-60 per cell, and all the path mass the sweeps can have lost -- every lost path passes through a
+// flushed cell on the anti-diagonal where it was flushed -- is below cells x 2^-60: nothing a posterior, a total or a cigar can
+// see.  A task with a row at or above the limit (its alignment runs ~90 binary orders further below the product of the row's
+// largest forward and backward values than usual: the stretch between a long deletion and a long insertion, say) reports
+// TASK_RERUN instead of NPR_OK and npr_batch_run runs it again with the per-cell-exponent kernel (k_dp_stair), which has no
+// such limit.
+#define NPR_RS_S_LIMIT (126 - 60 - (NPR_RS_TOP + 6) - 1)
+constexpr int32_t TASK_RERUN = 1;  // TaskOut::status of such a task between the two launches (never leaves npr_batch_run)
 NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }
 int launch_rs(const KernelArgs &a, int R, int grid, void *stream);
 size_t rs_lds_bytes();  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once

@@ -70,6 +70,10 @@ __device__ __forceinline__ CtlPair ctl_get2(CtlFeed<DIR> &f, const uint2 *gw, in
     p.b0 = __builtin_amdgcn_readlane(f.cur.x, off + 1), p.b1 = __builtin_amdgcn_readlane(f.cur.y, off + 1);
     return p;
 }
+__device__ __forceinline__ int note_s(int &smax, int s) {
+    smax = max(smax, s);
+    return s;
+}
 #ifndef NPR_RS_REBASE_ASM
 #define NPR_RS_REBASE_ASM 1
 #endif
@@ -88,7 +92,7 @@ __device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
     return CtlPair{e[0], e[1], e[2], e[3]};
 }
 #ifndef NPR_RS_WAVES2
-#define NPR_RS_WAVES2 1  // wavefronts per SIMD the R = 2 kernel is compiled for (1: whatever its registers allow)
+#define NPR_RS_WAVES2 6  // wavefronts per SIMD the R = 2 kernel is compiled for: 79 VGPRs, two spilled (82 and 5 per SIMD without: 3 % slower)
 #endif
 template <int R>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_rs(KernelArgs a) {
@@ -247,6 +251,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 
         // =============================== backward + posteriors ===============================
         int cnt = 0;
+        int smax = -(1 << 30);  // the largest eF + eB - eTot of any anti-diagonal: the range certificate (npr_device.h)
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
             const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
@@ -286,14 +291,14 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 rs_load_row<R>(frs, fb, cur, voff);
                 nxt = read_row_ctl<R>(ctl, D - 1);
                 rs_load_row<R>(frs, fa, nxt, voff);
-                rs_emit_pairs<R>(sink, Q.B, fb, D, Q.x0, Q.y0, cur.mk, fexp_of(fw, fexp, D, lane) + Q.e - tot_e, inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.B, fb, D, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_of(fw, fexp, D, lane) + Q.e - tot_e), inv_tot, jr, cnt);
             } else {
                 rs_load_row<R>(frs, fa, cur, voff);
                 if (D >= 1) {
                     nxt = read_row_ctl<R>(ctl, D - 1);
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
-                rs_emit_pairs<R>(sink, Q.A, fa, D, Q.x0, Q.y0, cur.mk, fexp_of(fw, fexp, D, lane) + Q.e - tot_e, inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.A, fa, D, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_of(fw, fexp, D, lane) + Q.e - tot_e), inv_tot, jr, cnt);
             }
             // `cur` is the control word of the anti-diagonal above the one computed next: its rebase is undone first
             int d2 = D - 1;
@@ -307,7 +312,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 RS_BWD_REBASE(reb);
                 rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
                 if ((d2 & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
-                rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, fexp_of(fw, fexp, d2, lane) + Q.e - tot_e, inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_of(fw, fexp, d2, lane) + Q.e - tot_e), inv_tot, jr, cnt);
                 d2 -= 1;
             }
 #if NPR_RS_CTL == 2
@@ -332,7 +337,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 RS_BWD_REBASE(reb);
                 rs_bwd_y_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.y0, cur.mk);
                 const int ef = fexp_of(fw, fexp, d2, lane);  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
-                rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, ef + Q.e - tot_e, inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
                 reb = cur.reb;
                 cur = nxt;
                 if (d2 >= 2) {
@@ -342,7 +347,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 RS_BWD_REBASE(reb);
                 rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
                 if (((d2 - 1) & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
-                rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, ef + Q.e - tot_e, inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
             }
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll
@@ -367,6 +372,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         if (lane == 0) {
             out.npairs = cnt;
             if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
+            if (smax >= NPR_RS_S_LIMIT && out.status != NPR_ERR_ZERO_PROB) out.status = TASK_RERUN;  // one exponent per row may not have been enough
             a.outs[t] = out;
         }
         int nt = 0;

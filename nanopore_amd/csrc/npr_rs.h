@@ -10,9 +10,9 @@
 //     always share the same e, so the recurrence is 18 (forward) / 20 (backward) multiplies and FMAs and nothing else;
 //   * after every RS_K-th anti-diagonal (d % RS_K == 0) the largest value of the two held rows is found (integer maximum of
 //     the bit patterns -- the values are non-negative --, six DPP steps across the wavefront), both rows are multiplied by the
-//     power of two that brings it into [0.5, 1), and e moves by as much.  In between a row loses at most a few binary
-//     orders per step, far inside fp32's range; cells more than ~2^-126 below their row's maximum denormalise and flush,
-//     which no posterior >= the reporting threshold can see;
+//     power of two that brings it to 2^85, near the top of fp32's range, and e moves by as much: a cell stays a normal
+//     number down to 211 binary orders below its row's maximum (234 with denormals), which bounds the bands this
+//     arithmetic is used for (rs_band_limit) -- below that a cell flushes to zero;
 //   * slots outside the band hold exact zeros, kept so by computing a row under the band's lane mask (EXEC) and clearing
 //     the slots a band edge has left behind -- no per-cell select;
 //   * a forward row goes to the scratch as 4 bytes per cell (the match value) and the row exponents as one word per
@@ -215,21 +215,26 @@ __device__ __forceinline__ uint32_t rcell_max_bits(const RCell &c) {
                  static_cast<uint32_t>(fbits(c.lx)), static_cast<uint32_t>(fbits(c.ly)));
 }
 __device__ __forceinline__ void rcell_scale(RCell &c, float f) { c.m *= f, c.sx *= f, c.sy *= f, c.lx *= f, c.ly *= f; }
-// Brings the largest value of the two rows into [0.5, 1); returns what to add to the rows' exponent (wave-uniform).
-// A row pair without a normal number (all zero: a dead band) is left alone.
+// Brings the largest value of the two rows into [2^(RS_TOP-1), 2^RS_TOP); returns what to add to the rows' exponent
+// (wave-uniform).  Near the TOP of fp32's range, not at 1: what matters is how far BELOW its row's maximum a cell can lie and
+// still be a normal number -- RS_TOP + 126 binary orders --, because a cell far below the maximum of its forward row can still
+// carry posterior mass when its backward value is as far above the others (an alternative placement of a long indel).  Nothing
+// in the recurrence grows by more than the sum of the transitions into a state (< 5) per anti-diagonal, so RS_K steps stay
+// below 2^127 from RS_TOP = 85.  A row pair without a normal number (all zero: a dead band) is left alone.
+constexpr int RS_TOP = NPR_RS_TOP;
 template <int R>
 __device__ __forceinline__ int rs_renorm(RDiag<R> &P, RDiag<R> &Q) {
     uint32_t u = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) u = umax3(u, rcell_max_bits(P.c[r]), rcell_max_bits(Q.c[r]));
     const uint32_t top = wave_max_u32(u);
-    int eb = static_cast<int>(top >> 23);
+    const int eb = static_cast<int>(top >> 23);
     if (eb == 0) return 0;
-    eb = min(eb, 252);
-    const float f = bitsf((253 - eb) << 23);  // 2^(126 - eb)
+    const int k = min(max(RS_TOP + 126 - eb, -126), 127);
+    const float f = bitsf((k + 127) << 23);  // 2^k
 #pragma unroll
     for (int r = 0; r < R; ++r) rcell_scale(P.c[r], f), rcell_scale(Q.c[r], f);
-    return eb - 126;
+    return -k;
 }
 
 // ---- frame rebase: the whole register state moves by one slot, in place ----
@@ -297,6 +302,73 @@ __device__ __forceinline__ void rs_rebase_bases4(Bases<4> &X, Bases<4> &Y, int d
 }
 __device__ __forceinline__ void rs_rebase_regs(RDiag<4> &P, RDiag<4> &Q, Bases<4> &X, Bases<4> &Y, int dir, int injX, int injY) {
     rs_rebase_row4(P, dir), rs_rebase_row4(Q, dir), rs_rebase_bases4(X, Y, dir, injX, injY);
+}
+
+// ... and the scalar side of it: the lane masks of the held rows move with them, the frame's origin by one lattice point
+__device__ __forceinline__ void rs_rebase_scalars(uint64_t (&hA)[1], uint64_t (&hB)[1], int &x0, int &y0, int dir) {
+    uint64_t tmp;
+    uint64_t a0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[0]))), b0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[0])));
+    int xs = uni(x0), ys = uni(y0);
+    asm volatile("s_cmp_eq_u32 %5, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %5, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_lshr_b64 %0, %0, 1\n\ts_lshr_b64 %1, %1, 1\n\ts_add_i32 %2, %2, 1\n\ts_sub_i32 %3, %3, 1\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "s_lshl_b64 %0, %0, 1\n\ts_lshl_b64 %1, %1, 1\n\ts_sub_i32 %2, %2, 1\n\ts_add_i32 %3, %3, 1\n\t"
+                 "2:"
+                 : "+s"(a0), "+s"(b0), "+s"(xs), "+s"(ys), "=&s"(tmp)
+                 : "s"(dir)
+                 : "scc");
+    hA[0] = a0, hB[0] = b0;
+    x0 = xs, y0 = ys;
+}
+__device__ __forceinline__ void rs_rebase_scalars(uint64_t (&hA)[2], uint64_t (&hB)[2], int &x0, int &y0, int dir) {
+    uint64_t tmp;
+    uint64_t a0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[0]))), b0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[0])));
+    uint64_t a1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[1]))), b1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[1])));
+    int xs = uni(x0), ys = uni(y0);
+    asm volatile("s_cmp_eq_u32 %7, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %7, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_mov_b64 %6, %0\n\ts_mov_b64 %0, %1\n\ts_lshr_b64 %1, %6, 1\n\ts_mov_b64 %6, %2\n\ts_mov_b64 %2, %3\n\ts_lshr_b64 %3, %6, 1\n\ts_add_i32 %4, %4, 1\n\ts_sub_i32 %5, %5, 1\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "s_mov_b64 %6, %1\n\ts_mov_b64 %1, %0\n\ts_lshl_b64 %0, %6, 1\n\ts_mov_b64 %6, %3\n\ts_mov_b64 %3, %2\n\ts_lshl_b64 %2, %6, 1\n\ts_sub_i32 %4, %4, 1\n\ts_add_i32 %5, %5, 1\n\t"
+                 "2:"
+                 : "+s"(a0), "+s"(a1), "+s"(b0), "+s"(b1), "+s"(xs), "+s"(ys), "=&s"(tmp)
+                 : "s"(dir)
+                 : "scc");
+    hA[0] = a0, hB[0] = b0;
+    hA[1] = a1, hB[1] = b1;
+    x0 = xs, y0 = ys;
+}
+__device__ __forceinline__ void rs_rebase_scalars(uint64_t (&hA)[4], uint64_t (&hB)[4], int &x0, int &y0, int dir) {
+    uint64_t tmp;
+    uint64_t a0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[0]))), b0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[0])));
+    uint64_t a1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[1]))), b1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[1])));
+    uint64_t a2 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[2]))), b2 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[2])));
+    uint64_t a3 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[3]))), b3 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[3])));
+    int xs = uni(x0), ys = uni(y0);
+    asm volatile("s_cmp_eq_u32 %11, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %11, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_mov_b64 %10, %0\n\ts_mov_b64 %0, %1\n\ts_mov_b64 %1, %2\n\ts_mov_b64 %2, %3\n\ts_lshr_b64 %3, %10, 1\n\ts_mov_b64 %10, %4\n\ts_mov_b64 %4, %5\n\ts_mov_b64 %5, %6\n\ts_mov_b64 %6, %7\n\ts_lshr_b64 %7, %10, 1\n\ts_add_i32 %8, %8, 1\n\ts_sub_i32 %9, %9, 1\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "s_mov_b64 %10, %3\n\ts_mov_b64 %3, %2\n\ts_mov_b64 %2, %1\n\ts_mov_b64 %1, %0\n\ts_lshl_b64 %0, %10, 1\n\ts_mov_b64 %10, %7\n\ts_mov_b64 %7, %6\n\ts_mov_b64 %6, %5\n\ts_mov_b64 %5, %4\n\ts_lshl_b64 %4, %10, 1\n\ts_sub_i32 %8, %8, 1\n\ts_add_i32 %9, %9, 1\n\t"
+                 "2:"
+                 : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3), "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3), "+s"(xs), "+s"(ys), "=&s"(tmp)
+                 : "s"(dir)
+                 : "scc");
+    hA[0] = a0, hB[0] = b0;
+    hA[1] = a1, hB[1] = b1;
+    hA[2] = a2, hB[2] = b2;
+    hA[3] = a3, hB[3] = b3;
+    x0 = xs, y0 = ys;
 }
 
 // the lane masks of a held row move with it
@@ -382,35 +454,25 @@ __device__ __forceinline__ void rs_bwd_rebase_c(const StepEnv &E, int r, RsState
 }
 
 // Frame rebase of the forward sweep, r = +1: (x0, y0) -> (x0 + 1, y0 - 1), every slot takes its upper neighbour; r = 0: nothing
-// (called on every anti-diagonal: only scalar code is conditional here).
+// (called on every anti-diagonal: only the base a stream takes in at its open end is fetched conditionally here).
 template <int R>
 __device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
     int injX = Q.S.xcap, injY = Q.S.ycap;
-    if (r > 0) {
-        held_up<R>(Q.hA), held_up<R>(Q.hB);
-        Q.x0 += 1, Q.y0 -= 1;
-        injX = feed8_get<+1>(Q.S.fx, E.X, E.lX, Q.x0 + 64 * R - 2, E.lane);
-    } else if (r < 0) {
-        held_down<R>(Q.hA), held_down<R>(Q.hB);
-        Q.x0 -= 1, Q.y0 += 1;
-        injY = feed8_get<+1>(Q.S.fy, E.Y, E.lY, Q.y0 - 1, E.lane);
-    }
-    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, uni(r), uni(injX), uni(injY));
+    if (r > 0) injX = feed8_get<+1>(Q.S.fx, E.X, E.lX, Q.x0 + 1 + 64 * R - 2, E.lane);
+    else if (r < 0) injY = feed8_get<+1>(Q.S.fy, E.Y, E.lY, Q.y0 + 1 - 1, E.lane);
+    const int dir = uni(r);
+    rs_rebase_scalars(Q.hA, Q.hB, Q.x0, Q.y0, dir);
+    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, dir, uni(injX), uni(injY));
 }
 // ... and of the backward sweep, which undoes the forward one: r is the forward rebase being undone.
 template <int R>
 __device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
     int injX = Q.S.xcap, injY = Q.S.ycap;
-    if (r > 0) {  // back to lower x-y: (x0 - 1, y0 + 1)
-        held_down<R>(Q.hA), held_down<R>(Q.hB);
-        Q.x0 -= 1, Q.y0 += 1;
-        injX = feed8_get<-1>(Q.S.fx, E.X, E.lX, Q.x0, E.lane);
-    } else if (r < 0) {
-        held_up<R>(Q.hA), held_up<R>(Q.hB);
-        Q.x0 += 1, Q.y0 -= 1;
-        injY = feed8_get<-1>(Q.S.fy, E.Y, E.lY, Q.y0 - (64 * R - 1), E.lane);
-    }
-    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, uni(-r), uni(injX), uni(injY));
+    if (r > 0) injX = feed8_get<-1>(Q.S.fx, E.X, E.lX, Q.x0 - 1, E.lane);  // back to lower x-y: (x0 - 1, y0 + 1)
+    else if (r < 0) injY = feed8_get<-1>(Q.S.fy, E.Y, E.lY, Q.y0 - 1 - (64 * R - 1), E.lane);
+    const int dir = uni(-r);
+    rs_rebase_scalars(Q.hA, Q.hB, Q.x0, Q.y0, dir);
+    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, dir, uni(injX), uni(injY));
 }
 
 // The new row replaces the one two anti-diagonals away, under the band's lane mask (the arithmetic itself runs under the
@@ -538,16 +600,18 @@ __device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> 
     }
 }
 
-// posteriors of one anti-diagonal: (F * B) * 2^s / totMant with s = eF + eB - eTot, wave-uniform
+// posteriors of one anti-diagonal: F * (B * 2^s) / totMant with s = eF + eB - eTot, wave-uniform.  F and B each span fp32's
+// whole range, so their product may not be formed first; B * 2^s stays below 2^(RS_TOP + 6 + s), far from overflow while s
+// is below NPR_RS_S_LIMIT -- and a task with a row above the limit is run again anyway (npr_device.h).
+__device__ __forceinline__ float rs_posterior(float f, float b, int s, float inv_tot) { return (f * __builtin_ldexpf(b, s)) * inv_tot; }
 template <int R>
 __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> &B, const RFRow<R> &f, int d, int x0, int y0, const Masks<R> &mk,
                                               int s, float inv_tot, const int (&jr)[R], int &cnt) {
-    s = min(max(s, -200), 200);
     float p[R];
     uint64_t hit[R], any = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        p[r] = __builtin_ldexpf(f.v[r] * B.c[r].m, s) * inv_tot;
+        p[r] = rs_posterior(f.v[r], B.c[r].m, s, inv_tot);
         hit[r] = __ballot(p[r] >= S.threshold) & mk.cell[r];
         any |= hit[r];
     }

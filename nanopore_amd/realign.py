@@ -72,9 +72,9 @@ class Batch(object):
 
     def class_stats(self):
         """(tasks, cells) per kernel class (include/nprealign.h: npr_batch_class_stats)."""
-        t = np.zeros(16, dtype=np.int64)
-        c = np.zeros(16, dtype=np.int64)
-        k = self._L.npr_batch_class_stats(self._h, ptr(t), ptr(c), 16)
+        t = np.zeros(32, dtype=np.int64)
+        c = np.zeros(32, dtype=np.int64)
+        k = self._L.npr_batch_class_stats(self._h, ptr(t), ptr(c), 32)
         return t[:k], c[:k]
 
     def segment_arith(self):

@@ -769,6 +769,7 @@ int32_t orc_realign_read_arith(const orc_hmm *h, const orc_params *p, int32_t pr
                                                    g->ragged_start, g->ragged_end, (float)p->posterior_threshold, &tm, &te,
                                                    &bm, &be, NULL, NULL, NULL, NULL, px + np, py + np, pf, cap_pairs - np,
                                                    &got);
+            if (st == 1) st = 0; /* orc_fb_f32_rs: the range certificate failed (the caller asked for this arithmetic anyway) */
             if (st == 0)
                 for (int64_t i = 0; i < got; i++) pp[np + i] = (double)pf[i];
             free(pf);

@@ -7,9 +7,10 @@
  * alignmentUncertainty.py:41, marginAlignSnpCaller.py:136-146) as the classic scaled HMM recurrence: the cells of an
  * anti-diagonal are plain fp32 values relative to one binary exponent shared by the whole row.  The two rows the
  * recurrence reads always carry the same exponent; after every RS_K-th anti-diagonal (d % RS_K == 0, RS_K = 16) both are
- * multiplied by the power of two that brings their largest value into [0.5, 1).  Cells outside the band are exact
+ * multiplied by the power of two that brings their largest value into [2^84, 2^85) -- near the top of fp32's range, so that
+ * a cell stays a normal number down to 211 binary orders below its row's maximum.  Cells outside the band are exact
  * zeros.  The forward sweep keeps, per row, the match values as they were when the row was finished together with
- * the exponent they were relative to; the backward sweep forms F * B * 2^(eF + eB - eTot) / totMant.
+ * the exponent they were relative to; the backward sweep forms F * (B * 2^(eF + eB - eTot)) / totMant.
  *
  * This file restates that sequence operation by operation (every operation is an IEEE-754 single-rounding mul / fma /
  * ldexp / frexp, denormals included); the parity tests require the GPU results to be IDENTICAL to it and require it
@@ -24,6 +25,8 @@
 #include <string.h>
 
 #define RS_K 16 /* nanopore_amd/csrc/npr_device.h: NPR_RS_K */
+#define RS_TOP 85 /* NPR_RS_TOP */
+#define RS_S_LIMIT (126 - 60 - (RS_TOP + 6) - 1) /* NPR_RS_S_LIMIT: see nanopore_amd/csrc/npr_device.h */
 #define E_DEAD (-(1 << 28))
 
 typedef struct {
@@ -156,15 +159,17 @@ static int32_t renorm(rcell *V, int64_t a0, int64_t a1, int64_t b0, int64_t b1) 
     for (int64_t i = b0; i < b1; i++)
         for (int s = 0; s < 5; s++)
             if (to_bits(V[i].v[s]) > top) top = to_bits(V[i].v[s]);
-    int32_t eb = (int32_t)(top >> 23);
+    const int32_t eb = (int32_t)(top >> 23);
     if (eb == 0) return 0;
-    if (eb > 252) eb = 252;
-    const float f = from_bits((uint32_t)(253 - eb) << 23); /* 2^(126 - eb) */
+    int32_t k = RS_TOP + 126 - eb; /* the maximum goes to [2^(RS_TOP-1), 2^RS_TOP) */
+    if (k < -126) k = -126;
+    if (k > 127) k = 127;
+    const float f = from_bits((uint32_t)(k + 127) << 23); /* 2^k */
     for (int64_t i = a0; i < a1; i++)
         for (int s = 0; s < 5; s++) V[i].v[s] = V[i].v[s] * f;
     for (int64_t i = b0; i < b1; i++)
         for (int s = 0; s < 5; s++) V[i].v[s] = V[i].v[s] * f;
-    return eb - 126;
+    return -k;
 }
 
 static inline int64_t cidx(const int32_t *lo, const int32_t *n, const int64_t *off, int64_t D, int64_t d, int64_t xmy) {
@@ -247,6 +252,7 @@ int32_t orc_fb_f32_rs(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint
     if (rc == 0) {
         const float inv_tot = 1.0f / tm;
         int32_t eb = 0;
+        int32_t smax = -(1 << 30);
         for (int64_t d = D; d >= 0; d--) {
             for (int64_t j = 0; j < n[d]; j++) {
                 const int64_t xmy = lo[d] + 2 * j, x = (d + xmy) / 2, y = (d - xmy) / 2;
@@ -266,17 +272,18 @@ int32_t orc_fb_f32_rs(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint
             if (d < D && d % RS_K == 0) eb += renorm(V, off[d], off[d + 1], off[d + 1], off[d + 2]);
             if (Bm_v)
                 for (int64_t i = off[d]; i < off[d + 1]; i++) Bm_v[i] = V[i].v[0], Bm_e[i] = eb;
-            /* posterior of the row: p = (Fv*Bv) * 2^(eF+eB-eTot) * (1/totMant) */
+            /* posterior of the row: p = (Fv * (Bv * 2^(eF+eB-eTot))) * (1/totMant) */
+            {
+                const int32_t s = Fex[d] + eb - te;
+                if (s > smax) smax = s;
+            }
             if (d >= 2 && (px || npairs)) {
-                int32_t s = Fex[d] + eb - te;
-                if (s < -200) s = -200;
-                if (s > 200) s = 200;
+                const int32_t s = Fex[d] + eb - te;
                 for (int64_t j = 0; j < n[d]; j++) {
                     const int64_t xmy = lo[d] + 2 * j, x = (d + xmy) / 2, y = (d - xmy) / 2;
                     if (x < 1 || y < 1 || x > lX || y > lY) continue;
                     const int64_t ic = off[d] + j;
-                    const float q = Fst[ic] * V[ic].v[0];
-                    const float pr = ldexpf(q, s) * inv_tot;
+                    const float pr = (Fst[ic] * ldexpf(V[ic].v[0], s)) * inv_tot;
                     if (pr >= threshold) {
                         if (px) {
                             if (np < cap) {
@@ -298,6 +305,9 @@ int32_t orc_fb_f32_rs(const orc_hmm *h, const uint8_t *X, int64_t lX, const uint
             *btot_m = raw > 0.0f ? frexpf(raw, &k) : 0.0f;
             *btot_e = raw > 0.0f ? eb + k : E_DEAD;
         }
+        /* the range certificate failed: the device runs such a task again in the per-cell arithmetic (results stay valid
+         * as a restatement of what the row-scaled kernel computed) */
+        if (rc == 0 && smax >= RS_S_LIMIT) rc = 1;
     }
     if (npairs) *npairs = np;
     free(V);

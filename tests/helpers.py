@@ -120,3 +120,10 @@ def cigar_spans(ops):
     sx = sum(k for op, k in ops if op in (0, 2))
     sy = sum(k for op, k in ops if op in (0, 1))
     return sx, sy
+
+
+def seg_arith_of(batch):
+    """i -> which fp32 arithmetic the device ran each segment of read i in (Batch.segment_arith: 0 per-cell exponents, 1
+    row-scaled), for orc.realign_read(..., precision=1, seg_arith=...): the mirror restates whichever the kernel class used."""
+    off, ar = batch.segment_arith()
+    return lambda i: ar[off[i]:off[i + 1]]

@@ -42,6 +42,16 @@ def test_oracle_reproduces_golden(path):
     assert np.array_equal(np.array(r32["ops"], dtype=np.int32).reshape(-1, 2), z["f32_ops"].reshape(-1, 2))
     assert np.array_equal(r32["pp"].astype(np.float32), z["f32_pp"])          # the mirror is bit-reproducible
     assert r32["score"] == float(z["f32_score"])
+    # the row-scaled restatement of the same recurrences (realign_oracle_rs.c: the arithmetic of the one-wavefront kernels)
+    # lands on the same floats: scaling by powers of two is exact, so the two fp32 arithmetics part only where a cell falls
+    # out of fp32's range relative to its row -- nowhere near a posterior that is reported
+    rrs = orc.realign_read(h, _params(z, orc.make_params), z["X"], z["Y"], guide, precision=1, seg_arith=[1] * 4096)
+    assert np.array_equal(np.array(rrs["ops"], dtype=np.int32).reshape(-1, 2), z["f32_ops"].reshape(-1, 2))
+    key = lambda r: np.lexsort((r["py"], r["px"]))  # noqa: E731
+    a, b = key(rrs), key(r32)
+    assert np.array_equal(rrs["px"][a], r32["px"][b]) and np.array_equal(rrs["py"][a], r32["py"][b])
+    assert np.array_equal(rrs["pp"][a].astype(np.float32), r32["pp"][b].astype(np.float32))
+    assert rrs["score"] == float(z["f32_score"]) and rrs["total_ll"] == r32["total_ll"]
 
 
 @pytest.mark.gpu

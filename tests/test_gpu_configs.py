@@ -14,7 +14,7 @@ import socket
 import numpy as np
 import pytest
 
-from helpers import MODEL_DIR, load_model_arrays, orc
+from helpers import MODEL_DIR, load_model_arrays, orc, seg_arith_of
 
 pytestmark = pytest.mark.gpu
 
@@ -60,12 +60,14 @@ def test_config2_every_read_against_the_oracle(gpu_ctx):
                           w["guide_ops"], w["guide_off"])
     b.run(), b.finish()
     res, (off, ops) = b.results(), b.ops()
+    seg_arith = b.segment_arith()  # the mirror restates the arithmetic of the kernel class each segment ran in
     b.close()
     assert (res["status"] == 0).all() and len(res) == 1000
     h = orc.make_hmm(T, E)
     P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
     X, Y = _codes(w["ref"]), _codes(w["read"])
-    m32 = orc.realign_batch(h, P, X, w["ref_off"], Y, w["read_off"], w["guide_ops"], w["guide_off"], precision=1, threads=8, native=True)
+    m32 = orc.realign_batch(h, P, X, w["ref_off"], Y, w["read_off"], w["guide_ops"], w["guide_off"], precision=1, threads=8, native=True,
+                            seg_arith=seg_arith)
     m64 = orc.realign_batch(h, P, X, w["ref_off"], Y, w["read_off"], w["guide_ops"], w["guide_off"], precision=0, threads=8, native=True)
     assert np.array_equal(res["cells"], m32["cells"]) and int(res["cells"].sum()) > 9e7
     same64 = 0
@@ -124,6 +126,7 @@ def test_config3_shared_contig_50k_reads(gpu_ctx):
                           ref_index=sub["ref_index"], guide_start=sub["guide_start"])
     c.run(), c.finish()
     res2, (off2, ops2), (poff, px, py, pp) = c.results(), c.ops(), c.pairs()
+    arith2 = seg_arith_of(c)
     c.close()
     assert np.array_equal(res2["loglik"], res["loglik"][idx]) and np.array_equal(res2["score"], res["score"][idx])
     h = orc.make_hmm(T, E)
@@ -139,7 +142,7 @@ def test_config3_shared_contig_50k_reads(gpu_ctx):
         if k % 16 == 0:
             X, Y = _window(w, i)
             g = _guide(w, i)
-            m32 = orc.realign_read(h, PO, X, Y, g, precision=1)
+            m32 = orc.realign_read(h, PO, X, Y, g, precision=1, seg_arith=arith2(k))
             m64 = orc.realign_read(h, PO, X, Y, g, precision=0)
             assert m32["cells"] == res["cells"][i]
             assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m32["ops"]
@@ -163,6 +166,7 @@ def test_config5_three_read_types_with_their_own_models(gpu_ctx):
     b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"], model_slot=slot)
     b.run(), b.finish()
     res, (off, ops) = b.results(), b.ops()
+    arith = seg_arith_of(b)
     b.close()
     _set_models(gpu_ctx)
     rlen = w["read_off"][1:] - w["read_off"][:-1]
@@ -179,7 +183,7 @@ def test_config5_three_read_types_with_their_own_models(gpu_ctx):
     for i in shortest:
         X, Y = _window(w, i)
         g = _guide(w, i)
-        lls = [orc.realign_read(hm[s], PO, X, Y, g, precision=1) for s in range(3)]
+        lls = [orc.realign_read(hm[s], PO, X, Y, g, precision=1, seg_arith=arith(i)) for s in range(3)]
         m = lls[int(slot[i])]
         assert res["loglik"][i] == pytest.approx(m["total_ll"], rel=1e-12)
         assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]

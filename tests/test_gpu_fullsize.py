@@ -4,7 +4,7 @@ output cigars are global, per-read-type models (config 5) select the right table
 import numpy as np
 import pytest
 
-from helpers import load_model_arrays, orc
+from helpers import load_model_arrays, orc, seg_arith_of
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +45,7 @@ def test_north_star_shape_properties_and_oracle_sample(gpu_ctx):
     res = b.results()
     off, ops = b.ops()
     poff, px, py, pp = b.pairs()
+    arith = seg_arith_of(b)
     b.close()
     _check_invariants(w, res, off, ops, poff, px, py, pp)
     assert res["cells"].min() > 1e6
@@ -56,7 +57,7 @@ def test_north_star_shape_properties_and_oracle_sample(gpu_ctx):
         X = _codes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]])
         Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
         g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
-        m = orc.realign_read(h, P, X, Y, g, precision=1)
+        m = orc.realign_read(h, P, X, Y, g, precision=1, seg_arith=arith(i))
         assert m["cells"] == res["cells"][i]
         assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
         order = np.lexsort((m["py"], m["px"]))
@@ -78,6 +79,7 @@ def test_north_star_windowed_guides_match_explicit_slices(gpu_ctx):
     assert b.stats()["kernel_variant"] == 1
     b.run(), b.finish()
     res, (off, ops), (poff, px, py, pp) = b.results(), b.ops(), b.pairs()
+    arith = seg_arith_of(b)
     b.close()
     # the same windows cut out on the host
     lead, ilen = w["lead"], w["interval_len"]
@@ -106,7 +108,7 @@ def test_north_star_windowed_guides_match_explicit_slices(gpu_ctx):
     X = _codes(cut[cut_off[i]:cut_off[i + 1]])
     Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
     g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
-    m = orc.realign_read(h, PO, X, Y, g, precision=1)
+    m = orc.realign_read(h, PO, X, Y, g, precision=1, seg_arith=arith(i))
     assert m["cells"] == res["cells"][i]
     assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
     order = np.lexsort((m["py"], m["px"]))
@@ -132,7 +134,7 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
         b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
         tasks, cells = b.class_stats()
         b.run(), b.finish()
-        out = (b.results(), b.ops(), b.pairs(), tasks, cells, b.stats()["max_width"])
+        out = (b.results(), b.ops(), b.pairs(), tasks, cells, b.stats()["max_width"], seg_arith_of(b))
         b.close()
         return out
 
@@ -141,21 +143,21 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
     P_keep = P
     P = R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=700,
                       max_pairs_per_base=40)  # ragged ends blur the posteriors: more pairs per base than the default 6
-    r1, o1, p1, t1, _, w1 = run()
+    r1, o1, p1, t1, _, w1, _ = run()
     monkeypatch.setenv("NPR_NO_WIDE", "1")
-    r2, o2, p2, t2, _, _ = run()
+    r2, o2, p2, t2, _, _, _ = run()
     monkeypatch.delenv("NPR_NO_WIDE")
     assert (r1["status"] == 0).all() and r1["n_segments"].max() > 1 and t1[3:7].sum() > 0 and t2[3:7].sum() == 0 and 256 <= w1 <= 1400
     assert np.array_equal(r1["loglik"], r2["loglik"]) and np.array_equal(r1["loglik_bwd"], r2["loglik_bwd"])
     assert np.array_equal(o1[1], o2[1]) and np.array_equal(p1[3], p2[3]) and np.array_equal(p1[1], p2[1])
     P = P_keep
 
-    res, (off, ops), (poff, px, py, pp), tasks, cells, maxw = run()
+    res, (off, ops), (poff, px, py, pp), tasks, cells, maxw, arith = run()
     assert (res["status"] == 0).all() and maxw > 1024
     assert tasks[3:7].sum() > 0.5 * tasks.sum() and cells[3:7].sum() > 0.9 * cells.sum()   # k_dp_wide did the work
     assert (tasks[3:7] > 0).sum() >= 3                                                      # in several frame sizes
     monkeypatch.setenv("NPR_NO_WIDE", "1")
-    res2, (off2, ops2), (poff2, qx, qy, qp), tasks2, _, _ = run()
+    res2, (off2, ops2), (poff2, qx, qy, qp), tasks2, _, _, _ = run()
     assert tasks2[3:7].sum() == 0 and tasks2[7:].sum() == tasks[3:].sum()
     assert np.array_equal(res["cells"], res2["cells"]) and np.array_equal(res["loglik"], res2["loglik"])
     assert np.array_equal(res["loglik_bwd"], res2["loglik_bwd"]) and np.array_equal(res["score"], res2["score"])
@@ -170,7 +172,7 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
         X = _codes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]])
         Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
         g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
-        m = orc.realign_read(h, PO, X, Y, g, precision=1)
+        m = orc.realign_read(h, PO, X, Y, g, precision=1, seg_arith=arith(i))
         assert m["cells"] == res["cells"][i]
         assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
         order = np.lexsort((m["py"], m["px"]))
@@ -194,6 +196,7 @@ def test_long_reads_and_per_read_type_models(gpu_ctx):
     res = b.results()
     off, ops = b.ops()
     poff, px, py, pp = b.pairs()
+    arith = seg_arith_of(b)
     b.close()
     _check_invariants(w, res, off, ops, poff, px, py, pp)
     assert (w["read_off"][1:] - w["read_off"][:-1]).max() > 30000
@@ -206,7 +209,7 @@ def test_long_reads_and_per_read_type_models(gpu_ctx):
         lls = []
         for name in ("blasr_hmm_0.txt", "blasr_hmm_20.txt", "blasr_hmm_40.txt"):
             Tm, Em, _ = load_model_arrays(name)
-            lls.append(orc.realign_read(orc.make_hmm(Tm, Em), PO, X, Y, g, precision=1)["total_ll"])
+            lls.append(orc.realign_read(orc.make_hmm(Tm, Em), PO, X, Y, g, precision=1, seg_arith=arith(i))["total_ll"])
         assert res["loglik"][i] == pytest.approx(lls[slot[i]], rel=1e-12)
         assert all(abs(res["loglik"][i] - lls[k]) > 1.0 for k in range(3) if k != slot[i])
     gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"), slot=0)

@@ -42,7 +42,7 @@ def _run_case(gpu_ctx, rng, n_reads, lmin, lmax, kw, model="blasr_hmm_0.txt", in
     okw.pop("max_pairs_per_base", None)
     P = orc.make_params(**okw)
     for (X, Y, ops), g in zip(raw, out):
-        m32 = orc.realign_read(h, P, X, Y, ops, precision=1)
+        m32 = orc.realign_read(h, P, X, Y, ops, precision=1, seg_arith=g["seg_arith"])
         m64 = orc.realign_read(h, P, X, Y, ops, precision=0)
         assert g["status"] == 0 and m32["status"] == 0 and m64["status"] == 0
         assert g["cells"] == m32["cells"] == m64["cells"]
@@ -254,8 +254,43 @@ def test_base_dependent_gap_emissions(gpu_ctx):
         P = R.make_params(band_mode=1, fixed_width=W)
         out = gpu_ctx.realign(P, refs, reads, [g for _, _, g in cases], want_pairs=True)
         for (X, Y, g), o in zip(cases, out):
-            m = orc.realign_read(h, orc.make_params(band_mode=1, fixed_width=W), X, Y, g, precision=1)
+            m = orc.realign_read(h, orc.make_params(band_mode=1, fixed_width=W), X, Y, g, precision=1, seg_arith=o["seg_arith"])
             assert o["status"] == 0 and o["ops"] == m["ops"]
             order = np.lexsort((m["py"], m["px"]))
             assert np.array_equal(o["p"], m["pp"].astype(np.float32)[order])
     gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+
+
+def test_row_scaled_task_without_its_range_certificate_runs_again_per_cell(gpu_ctx):
+    """k_dp_rs keeps one exponent per anti-diagonal row; a task with a row whose alignment lies too far below the row's largest
+    forward and backward values to guarantee that nothing was flushed (NPR_RS_S_LIMIT, npr_device.h) is run again by
+    npr_batch_run with the per-cell-exponent kernel.  A read with a 235-base deletion and, 400 bases on, a 235-base insertion
+    the guide knows nothing of is such a task; its neighbours in the batch are not.  Either way the results are those of
+    the matching CPU restatement bit for bit, and within 1e-4 of fp64."""
+    from nanopore_amd import realign as R
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    h = oracle_hmm()
+    rng = np.random.default_rng(47)
+    cases = []
+    for gap in (235, 60):
+        core = rng.integers(0, 4, size=1200).astype(np.uint8)
+        X = np.concatenate([core[:400], rng.integers(0, 4, size=gap).astype(np.uint8), core[400:800], core[800:]])
+        Y = np.concatenate([core[:400], core[400:800], rng.integers(0, 4, size=gap).astype(np.uint8), core[800:]])
+        cases.append((X, Y, [(0, len(X))]))
+    cases += [random_pair(rng, int(rng.integers(300, 1500)), indel=0.15, max_indel=20) for _ in range(6)]
+    kw = dict(band_mode=1, fixed_width=500)  # 251 cells per anti-diagonal: the widest one-wavefront class
+    out = gpu_ctx.realign(R.make_params(**kw), [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases],
+                          [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases], [g for _, _, g in cases], want_pairs=True)
+    assert out[0]["seg_arith"] == [0] and all(o["seg_arith"] == [1] for o in out[1:])
+    P = orc.make_params(**kw)
+    for (X, Y, g), o in zip(cases, out):
+        m32 = orc.realign_read(h, P, X, Y, g, precision=1, seg_arith=o["seg_arith"])
+        m64 = orc.realign_read(h, P, X, Y, g, precision=0)
+        assert o["status"] == 0 and o["ops"] == m32["ops"] == m64["ops"]
+        gp, mp, dp = _pairs_dict(o["x"], o["y"], o["p"]), _pairs_dict(m32["px"], m32["py"], m32["pp"].astype(np.float32)), _pairs_dict(m64["px"], m64["py"], m64["pp"])
+        assert gp.keys() == mp.keys() and all(np.float32(gp[k]) == np.float32(mp[k]) for k in gp)
+        for k in set(gp) | set(dp):
+            a, b = gp.get(k), dp.get(k)
+            assert abs((a if a is not None else 0.01) - (b if b is not None else 0.01)) < 1e-4
+        assert o["loglik"] == pytest.approx(m64["total_ll"], rel=2e-6)
+    assert any(op == 2 and n >= 230 for op, n in out[0]["ops"]) and any(op == 1 and n >= 230 for op, n in out[0]["ops"])

@@ -5,7 +5,7 @@ wavefronts share a task."""
 import numpy as np
 import pytest
 
-from helpers import MODEL_DIR, load_model_arrays, orc
+from helpers import MODEL_DIR, load_model_arrays, orc, seg_arith_of
 from test_gpu_parity import _run_case
 
 pytestmark = pytest.mark.gpu
@@ -49,7 +49,7 @@ def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(
         b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
         tasks, cells = b.class_stats()
         b.run(), b.finish()
-        out = (b.results(), b.ops(), b.pairs(), tasks, cells, b.stats())
+        out = (b.results(), b.ops(), b.pairs(), tasks, cells, b.stats(), seg_arith_of(b))
         b.close()
         return out
 
@@ -81,13 +81,14 @@ def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(
     # two reads against the oracle's fp32 mirror
     h = orc.make_hmm(T, E)
     PO = orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)
-    res, (off, ops), (poff, px, py, pp) = run(R.make_params(band_mode=R.BAND_ANCHOR))[:3]
+    got = run(R.make_params(band_mode=R.BAND_ANCHOR))
+    res, (off, ops), (poff, px, py, pp), arith = got[0], got[1], got[2], got[6]
     order_by_cells = np.argsort(res["cells"])
     for i in (int(order_by_cells[len(order_by_cells) // 2]), int(order_by_cells[5])):
         X = _codes(w["ref"][w["ref_off"][i]:w["ref_off"][i + 1]])
         Y = _codes(w["read"][w["read_off"][i]:w["read_off"][i + 1]])
         g = [tuple(int(v) for v in r) for r in w["guide_ops"][w["guide_off"][i]:w["guide_off"][i + 1]]]
-        m = orc.realign_read(h, PO, X, Y, g, precision=1)
+        m = orc.realign_read(h, PO, X, Y, g, precision=1, seg_arith=arith(i))
         assert m["cells"] == res["cells"][i]
         assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
         order = np.lexsort((m["py"], m["px"]))
@@ -111,7 +112,7 @@ def test_repeated_launches_on_poisoned_scratch_give_identical_pairs(gpu_ctx, mon
               R.make_params(band_mode=R.BAND_FIXED, fixed_width=100), 60),
              (synth.make_workload(1009, 96, 2000, T, E, flank=0, length_sigma=0.4, len_min=200, len_max=5000),
               R.make_params(band_mode=R.BAND_FIXED, fixed_width=300), 60),
-             # band 200: the north-star class (k_dp_stair<2>, packed control words), next to a few narrow and wide stragglers
+             # band 200: the north-star class (k_dp_rs<2>, packed control words), next to a few narrow and wide stragglers
              (synth.make_workload(1010, 192, 2500, T, E, flank=0, length_sigma=0.6, len_min=100, len_max=8000),
               R.make_params(band_mode=R.BAND_FIXED, fixed_width=200), 80),
              # ... and the same class launched side by side with others: anchors +- 60 with 3 trimmed columns give bands of
@@ -137,5 +138,5 @@ def test_repeated_launches_on_poisoned_scratch_give_identical_pairs(gpu_ctx, mon
                 assert np.array_equal(out[0][key], first[0][key]), (rep, key)
             assert all(np.array_equal(a, c) for a, c in zip(out[1], first[1])), rep
             assert all(np.array_equal(a, c) for a, c in zip(out[2], first[2])), rep
-    # the north-star class (1) ran alone and next to other classes
-    assert (1,) in seen_classes and any(1 in c and len(c) > 1 for c in seen_classes), seen_classes
+    # the north-star class (16: k_dp_rs<2>, the row-scaled kernel of class 1's frame) ran alone and next to other classes
+    assert (16,) in seen_classes and any(16 in c and len(c) > 1 for c in seen_classes), seen_classes

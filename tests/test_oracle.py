@@ -291,7 +291,7 @@ def test_oracle_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_pa
     shutil.copytree(here, str(work), ignore=shutil.ignore_patterns("*.so", "__pycache__", "_ref"))
     subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
                            "-std=gnu11", "-fPIC", "-fopenmp", "-ffp-contract=off", "-shared", "-o", str(work / "liboracle.so"),
-                           str(work / "realign_oracle.c"), str(work / "realign_oracle_f32.c"), "-lm"])
+                           str(work / "realign_oracle.c"), str(work / "realign_oracle_f32.c"), str(work / "realign_oracle_rs.c"), "-lm"])
     shutil.copy(str(work / "liboracle.so"), str(work / "liboracle_native.so"))
     for so in ("liboracle.so", "liboracle_native.so"):   # newer than the sources: oracle.build() keeps them
         os.utime(str(work / so))
@@ -306,8 +306,8 @@ def test_oracle_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_pa
         "for n, P in ((40, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=20)), (300, orc.make_params(band_mode=orc.BAND_ANCHOR, constraint_trim=3, split_threshold=40)),\n"
         "             (200, orc.make_params(band_mode=orc.BAND_ANCHOR, mode=orc.MODE_RESCORE_ORIGINAL, split_threshold=100)), (0, orc.make_params())):\n"
         "    X, Y, g = random_pair(rng, n) if n else (np.zeros(0, np.uint8), np.zeros(0, np.uint8), [])\n"
-        "    for prec in (0, 1):\n"
-        "        r = orc.realign_read(h, P, X, Y, g, precision=prec)\n"
+        "    for prec, arith in ((0, None), (1, None), (1, [1] * 64)):\n"
+        "        r = orc.realign_read(h, P, X, Y, g, precision=prec, seg_arith=arith)\n"
         "        assert r['status'] in (0, -1), r['status']\n"
         "    for seg in (orc.plan(len(X), len(Y), g, P) if n else []):\n"
         "        e = orc.expectations(h, X[seg['xs']:seg['xe']], Y[seg['ys']:seg['ye']], seg['lo'], seg['n'], seg['ragged_start'], seg['ragged_end'])\n"
@@ -317,3 +317,69 @@ def test_oracle_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_pa
                OMP_NUM_THREADS="2")
     out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "SANITIZED OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def _pairs(r):
+    return {(int(a), int(b)): float(c) for a, b, c in zip(r["px"], r["py"], r["pp"])}
+
+
+def test_row_scaled_mirror_equals_the_per_cell_mirror_and_tracks_fp64():
+    """The two fp32 restatements of the device arithmetic (realign_oracle_f32.c: one exponent per cell; realign_oracle_rs.c:
+    one per anti-diagonal row, the kernels of narrow bands) differ only by exact powers of two while every cell stays inside
+    fp32's range relative to its row: same posterior bits, same cigars, same totals -- and both within 1e-4 of fp64."""
+    h = oracle_hmm()
+    rng = np.random.default_rng(41)
+    for W, n, lmax, indel, mi in ((40, 6, 400, 0.12, 6), (100, 6, 1500, 0.2, 30), (200, 6, 2500, 0.2, 60), (250, 3, 1500, 0.25, 100)):
+        P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W)
+        for _ in range(n):
+            X, Y, g = random_pair(rng, int(rng.integers(30, lmax)), indel=indel, max_indel=mi)
+            a = orc.realign_read(h, P, X, Y, g, precision=1)
+            b = orc.realign_read(h, P, X, Y, g, precision=1, seg_arith=[1] * 16)
+            c = orc.realign_read(h, P, X, Y, g, precision=0)
+            assert a["status"] == b["status"] == c["status"] == 0
+            pa, pb, pc = _pairs(a), _pairs(b), _pairs(c)
+            assert pa.keys() == pb.keys() and all(np.float32(pa[k]) == np.float32(pb[k]) for k in pa)
+            assert a["ops"] == b["ops"] and a["total_ll"] == b["total_ll"] and a["score"] == b["score"]
+            for k in set(pb) | set(pc):
+                u, v = pb.get(k), pc.get(k)
+                assert abs((u if u is not None else 0.01) - (v if v is not None else 0.01)) < 1e-4
+            assert b["total_ll"] == pytest.approx(c["total_ll"], rel=2e-6)
+
+
+def test_row_scaled_mirror_keeps_a_long_indel_the_guide_does_not_have_and_says_so():
+    """The hard case for one exponent per row: the guide is a plain diagonal, the truth has a long deletion followed by an
+    equally long insertion inside the band, so for a stretch the alignment runs along the far edge of the band while the
+    largest forward values of those rows belong to the diagonal it left -- up to ~270 binary orders apart where a gap base
+    costs ~1.4 bit more than an aligned one.  With its rows' maxima near the top of fp32's range the row-scaled arithmetic
+    still keeps those cells (posteriors within 1e-4 of fp64, the fp64 cigar, like the per-cell mirror), and its range
+    certificate (rc = 1: a row with eF + eB - eTot >= NPR_RS_S_LIMIT) marks the reads for which that was not guaranteed --
+    the device runs those again with a per-cell exponent -- while ordinary reads pass it."""
+    h = oracle_hmm()
+    rng = np.random.default_rng(43)
+    flagged = {}
+    for gap in (30, 60, 150, 260):
+        core = rng.integers(0, 4, size=1200).astype(np.uint8)
+        extra_ref = rng.integers(0, 4, size=gap).astype(np.uint8)
+        extra_read = rng.integers(0, 4, size=gap).astype(np.uint8)
+        X = np.concatenate([core[:400], extra_ref, core[400:800], core[800:]])   # reference has `gap` bases the read lacks ...
+        Y = np.concatenate([core[:400], core[400:800], extra_read, core[800:]])  # ... and the read `gap` bases of its own 400 later
+        g = [(0, len(X))]                                                        # the guide knows of neither
+        P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=2 * gap + 40)
+        a = orc.realign_read(h, P, X, Y, g, precision=1)
+        b = orc.realign_read(h, P, X, Y, g, precision=1, seg_arith=[1])
+        c = orc.realign_read(h, P, X, Y, g, precision=0)
+        assert a["status"] == b["status"] == c["status"] == 0
+        assert any(op == 2 and n >= gap - 5 for op, n in c["ops"]) and any(op == 1 and n >= gap - 5 for op, n in c["ops"])  # found
+        assert b["ops"] == c["ops"] == a["ops"]
+        pb, pc = _pairs(b), _pairs(c)
+        for k in set(pb) | set(pc):
+            u, v = pb.get(k), pc.get(k)
+            assert abs((u if u is not None else 0.01) - (v if v is not None else 0.01)) < 1e-4, (gap, k, u, v)
+        assert b["total_ll"] == pytest.approx(c["total_ll"], rel=2e-6)
+        seg = orc.plan(len(X), len(Y), g, P)[0]
+        flagged[gap] = orc.fb_f32(h, X, Y, seg["lo"], seg["n"], dense=False, arith=1)["rc"]
+    assert flagged[30] == 0 and flagged[60] == 0 and flagged[260] == 1, flagged
+    for _ in range(6):  # reads with the usual indels pass the certificate
+        X, Y, g = random_pair(rng, int(rng.integers(200, 2000)), indel=0.2, max_indel=30)
+        seg = orc.plan(len(X), len(Y), g, orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=200))[0]
+        assert orc.fb_f32(h, X, Y, seg["lo"], seg["n"], dense=False, arith=1)["rc"] == 0
