@@ -195,6 +195,7 @@ struct RowCtl {
     uint32_t soff;
     int reb;
     int jlo;
+    uint32_t moved;  // non-zero: the band is not where it was two anti-diagonals ago (bit 30 of the control word, npr_sched.h)
 };
 // lanes [lo, lo + w): s_bfm_b64 takes the low six bits of both operands (w <= 63; lo = 64 comes with w = 0), so the
 // bit fields of the control word need no masking -- one shift per field and this
@@ -217,12 +218,14 @@ __device__ __forceinline__ RowCtl<R> read_row_ctl_at(cptr32 e) {  // e: the anti
         c.soff = so;
         c.reb = static_cast<int>((w >> 28) & 3u) - 1;
         c.jlo = static_cast<int>((w & 127u) + ((w >> 7) & 127u));
+        c.moved = w & (1u << 30);
     } else {
         const Ctl t = read_ctl(e, 0);
         c.mk = band_masks<R>(t.jlo, t.n);
         c.soff = ((t.co - static_cast<uint32_t>(R * c.mk.l0)) << 3) + row_bias<R>();
         c.reb = t.reb;
         c.jlo = t.jlo;
+        c.moved = e[1] & (1u << 30);
     }
     return c;
 }
@@ -241,12 +244,14 @@ __device__ __forceinline__ RowCtl<R> row_ctl_of_words(uint32_t w0, uint32_t w1) 
         c.soff = w0;
         c.reb = static_cast<int>((w1 >> 28) & 3u) - 1;
         c.jlo = static_cast<int>((w1 & 127u) + ((w1 >> 7) & 127u));
+        c.moved = w1 & (1u << 30);
     } else {
         const Ctl t{w0, static_cast<int>(w1 & 8191u), static_cast<int>((w1 >> 13) & 8191u), static_cast<int>((w1 >> 26) & 3u) - 1};
         c.mk = band_masks<R>(t.jlo, t.n);
         c.soff = ((t.co - static_cast<uint32_t>(R * c.mk.l0)) << 3) + row_bias<R>();
         c.reb = t.reb;
         c.jlo = t.jlo;
+        c.moved = w1 & (1u << 30);
     }
     return c;
 }

@@ -74,16 +74,8 @@ __device__ __forceinline__ int note_s(int &smax, int s) {
     smax = max(smax, s);
     return s;
 }
-#ifndef NPR_RS_REBASE_ASM
-#define NPR_RS_REBASE_ASM 1
-#endif
-#if NPR_RS_REBASE_ASM
 #define RS_FWD_REBASE(r) rs_fwd_rebase<R>(E, (r), Q)
 #define RS_BWD_REBASE(r) rs_bwd_rebase<R>(E, (r), Q)
-#else
-#define RS_FWD_REBASE(r) do { if (r) rs_fwd_rebase_c<R>(E, (r), Q); } while (0)
-#define RS_BWD_REBASE(r) do { if (r) rs_bwd_rebase_c<R>(E, (r), Q); } while (0)
-#endif
 #ifndef NPR_RS_CTL
 #define NPR_RS_CTL 2  // control words: 0 vector feed + readlane, 1 scalar load when needed, 2 scalar load one iteration ahead (measured: 3.19 / 3.44 / 3.66e11 cells/s)
 #endif
@@ -162,7 +154,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         for (int r = 0; r < R; ++r) {
             Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r] - 1);
             Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r] - 1);
-            Q.hA[r] = c0.mk.cell[r], Q.hB[r] = 0;
         }
         Q.S.xcap = Q.S.ycap = RS_N8;
         feed8_init<+1>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);  // first X-step injects X[(x0 + 1) + 64R - 2]
@@ -193,12 +184,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             {
                 const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
                 RS_FWD_REBASE(cur.reb);
-                rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, cur.mk);
+                rs_fwd_x_step<R>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
                 rs_store_row<R>(frs, Q.B, cur, voff);
             }
             const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
             RS_FWD_REBASE(cur.reb);
-            rs_fwd_y_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.y0, cur.mk);
+            rs_fwd_y_step<R>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
             if (((d + 1) & (RS_K - 1)) == 0) {  // a renormalising row: both held rows, then the row goes out with its new exponent
                 Q.e += rs_renorm<R>(Q.A, Q.B);
                 if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
@@ -215,7 +206,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 #endif
             const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
             RS_FWD_REBASE(cur.reb);
-            rs_fwd_x_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.x0, cur.mk);
+            rs_fwd_x_step<R>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
             rs_store_row<R>(frs, Q.B, cur, voff);
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
@@ -265,13 +256,14 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             CtlFeed<-1> cb;
             ctl_init<-1>(cb, gw, D, oddD ? D - 3 : D - 2, lane);
             RowCtl<R> cur = read_row_ctl<R>(ctl, D);
+            // `moved` of the anti-diagonals one and two above the one being computed: the row two above is the one overwritten
+            uint32_t m1 = cur.moved, m2 = 0;
             FexpWindow fw;
             fexp_fill(fw, fexp, D / RS_K, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r]);
                 Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r]);
-                Q.hA[r] = oddD ? 0 : cur.mk.cell[r], Q.hB[r] = oddD ? cur.mk.cell[r] : 0;
                 if (Q.x0 + jr[r] == lX) {  // the end corner (it is in the band by construction)
                     RCell c;
                     c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
@@ -310,7 +302,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
+                rs_bwd_x_step<R>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                m2 = m1, m1 = cur.moved;
                 if ((d2 & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_of(fw, fexp, d2, lane) + Q.e - tot_e), inv_tot, jr, cnt);
                 d2 -= 1;
@@ -335,7 +328,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 nxt = row_ctl_of_words<R>(w.a0, w.a1);
                 rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
                 RS_BWD_REBASE(reb);
-                rs_bwd_y_step<R>(E, Q.B, Q.hB, Q.A, Q.S, Q.y0, cur.mk);
+                rs_bwd_y_step<R>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                m2 = m1, m1 = cur.moved;
                 const int ef = fexp_of(fw, fexp, d2, lane);  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
                 rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
                 reb = cur.reb;
@@ -345,7 +339,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R>(E, Q.A, Q.hA, Q.B, Q.S, Q.x0, cur.mk);
+                rs_bwd_x_step<R>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                m2 = m1, m1 = cur.moved;
                 if (((d2 - 1) & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
             }

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(64) k_plan_sched(SchedArgs a) {
             const bool active = cls < 0 && ((cand >> c) & 1u);
             if (!__any(active)) continue;
             const int R = kSchedR[c], NW = kSchedNW[c], rshift = stair_rshift(R), C = 64 * R * NW;
-            StairState st{0, 0};
+            StairState st{0, 0, 0, 0, 0, 0};
             int ok = 0;
             if (active) ok = stair_begin(st, a.lo[sg.band_off], a.n[sg.band_off], max_width, R, NW) ? 1 : 0;
             int Dmax = active ? D : -1;

@@ -304,154 +304,25 @@ __device__ __forceinline__ void rs_rebase_regs(RDiag<4> &P, RDiag<4> &Q, Bases<4
     rs_rebase_row4(P, dir), rs_rebase_row4(Q, dir), rs_rebase_bases4(X, Y, dir, injX, injY);
 }
 
-// ... and the scalar side of it: the lane masks of the held rows move with them, the frame's origin by one lattice point
-__device__ __forceinline__ void rs_rebase_scalars(uint64_t (&hA)[1], uint64_t (&hB)[1], int &x0, int &y0, int dir) {
-    uint64_t tmp;
-    uint64_t a0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[0]))), b0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[0])));
+// ... and the scalar side of it: the frame's origin moves by one lattice point
+__device__ __forceinline__ void rs_rebase_origin(int &x0, int &y0, int dir) {
     int xs = uni(x0), ys = uni(y0);
-    asm volatile("s_cmp_eq_u32 %5, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_lt_i32 %5, 0\n\t"
-                 "s_cbranch_scc1 1f\n\t"
-                 "s_lshr_b64 %0, %0, 1\n\ts_lshr_b64 %1, %1, 1\n\ts_add_i32 %2, %2, 1\n\ts_sub_i32 %3, %3, 1\n\t"
-                 "s_branch 2f\n\t"
-                 "1:\n\t"
-                 "s_lshl_b64 %0, %0, 1\n\ts_lshl_b64 %1, %1, 1\n\ts_sub_i32 %2, %2, 1\n\ts_add_i32 %3, %3, 1\n\t"
-                 "2:"
-                 : "+s"(a0), "+s"(b0), "+s"(xs), "+s"(ys), "=&s"(tmp)
+    asm volatile("s_add_i32 %0, %0, %2\n\t"
+                 "s_sub_i32 %1, %1, %2"
+                 : "+s"(xs), "+s"(ys)
                  : "s"(dir)
                  : "scc");
-    hA[0] = a0, hB[0] = b0;
-    x0 = xs, y0 = ys;
-}
-__device__ __forceinline__ void rs_rebase_scalars(uint64_t (&hA)[2], uint64_t (&hB)[2], int &x0, int &y0, int dir) {
-    uint64_t tmp;
-    uint64_t a0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[0]))), b0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[0])));
-    uint64_t a1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[1]))), b1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[1])));
-    int xs = uni(x0), ys = uni(y0);
-    asm volatile("s_cmp_eq_u32 %7, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_lt_i32 %7, 0\n\t"
-                 "s_cbranch_scc1 1f\n\t"
-                 "s_mov_b64 %6, %0\n\ts_mov_b64 %0, %1\n\ts_lshr_b64 %1, %6, 1\n\ts_mov_b64 %6, %2\n\ts_mov_b64 %2, %3\n\ts_lshr_b64 %3, %6, 1\n\ts_add_i32 %4, %4, 1\n\ts_sub_i32 %5, %5, 1\n\t"
-                 "s_branch 2f\n\t"
-                 "1:\n\t"
-                 "s_mov_b64 %6, %1\n\ts_mov_b64 %1, %0\n\ts_lshl_b64 %0, %6, 1\n\ts_mov_b64 %6, %3\n\ts_mov_b64 %3, %2\n\ts_lshl_b64 %2, %6, 1\n\ts_sub_i32 %4, %4, 1\n\ts_add_i32 %5, %5, 1\n\t"
-                 "2:"
-                 : "+s"(a0), "+s"(a1), "+s"(b0), "+s"(b1), "+s"(xs), "+s"(ys), "=&s"(tmp)
-                 : "s"(dir)
-                 : "scc");
-    hA[0] = a0, hB[0] = b0;
-    hA[1] = a1, hB[1] = b1;
-    x0 = xs, y0 = ys;
-}
-__device__ __forceinline__ void rs_rebase_scalars(uint64_t (&hA)[4], uint64_t (&hB)[4], int &x0, int &y0, int dir) {
-    uint64_t tmp;
-    uint64_t a0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[0]))), b0 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[0])));
-    uint64_t a1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[1]))), b1 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[1])));
-    uint64_t a2 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[2]))), b2 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[2])));
-    uint64_t a3 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hA[3]))), b3 = static_cast<uint64_t>(uni64(static_cast<int64_t>(hB[3])));
-    int xs = uni(x0), ys = uni(y0);
-    asm volatile("s_cmp_eq_u32 %11, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_lt_i32 %11, 0\n\t"
-                 "s_cbranch_scc1 1f\n\t"
-                 "s_mov_b64 %10, %0\n\ts_mov_b64 %0, %1\n\ts_mov_b64 %1, %2\n\ts_mov_b64 %2, %3\n\ts_lshr_b64 %3, %10, 1\n\ts_mov_b64 %10, %4\n\ts_mov_b64 %4, %5\n\ts_mov_b64 %5, %6\n\ts_mov_b64 %6, %7\n\ts_lshr_b64 %7, %10, 1\n\ts_add_i32 %8, %8, 1\n\ts_sub_i32 %9, %9, 1\n\t"
-                 "s_branch 2f\n\t"
-                 "1:\n\t"
-                 "s_mov_b64 %10, %3\n\ts_mov_b64 %3, %2\n\ts_mov_b64 %2, %1\n\ts_mov_b64 %1, %0\n\ts_lshl_b64 %0, %10, 1\n\ts_mov_b64 %10, %7\n\ts_mov_b64 %7, %6\n\ts_mov_b64 %6, %5\n\ts_mov_b64 %5, %4\n\ts_lshl_b64 %4, %10, 1\n\ts_sub_i32 %8, %8, 1\n\ts_add_i32 %9, %9, 1\n\t"
-                 "2:"
-                 : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3), "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3), "+s"(xs), "+s"(ys), "=&s"(tmp)
-                 : "s"(dir)
-                 : "scc");
-    hA[0] = a0, hB[0] = b0;
-    hA[1] = a1, hB[1] = b1;
-    hA[2] = a2, hB[2] = b2;
-    hA[3] = a3, hB[3] = b3;
     x0 = xs, y0 = ys;
 }
 
-// the lane masks of a held row move with it
-template <int R>
-__device__ __forceinline__ void held_up(uint64_t (&h)[R]) {
-    const uint64_t first = h[0];
-#pragma unroll
-    for (int r = 0; r + 1 < R; ++r) h[r] = h[r + 1];
-    h[R - 1] = first >> 1;
-}
-template <int R>
-__device__ __forceinline__ void held_down(uint64_t (&h)[R]) {
-    const uint64_t last = h[R - 1];
-#pragma unroll
-    for (int r = R - 1; r > 0; --r) h[r] = h[r - 1];
-    h[0] = last << 1;
-}
-
-// A sweep's register state: the even anti-diagonals in A, the odd ones in B, the lane masks of the rows they hold (in
-// the frame's present coordinates), the base streams and the rows' common exponent.
+// A sweep's register state: the even anti-diagonals in A, the odd ones in B, the base streams and the rows' common exponent.
 template <int R>
 struct RsState {
     RDiag<R> A, B;
-    uint64_t hA[R], hB[R];
     Streams<R> S;
     int x0, y0;
     int e;
 };
-
-// (A/B: the rebase as a C++ branch around per-register asm, NPR_RS_REBASE_ASM=0)
-// ---- in-place moves of a row by one slot (frame rebase); see npr_frame.h for why this is inline assembly ----
-template <int R>
-__device__ __forceinline__ void rdiag_up_inplace(RDiag<R> &g) {
-#pragma unroll
-    for (int r = 0; r + 1 < R; ++r) {
-        rot_up(g.c[r].m, g.c[r + 1].m), rot_up(g.c[r].sx, g.c[r + 1].sx), rot_up(g.c[r].sy, g.c[r + 1].sy);
-        rot_up(g.c[r].lx, g.c[r + 1].lx), rot_up(g.c[r].ly, g.c[r + 1].ly);
-    }
-    RCell &t = g.c[R - 1];
-    dpp_up_inplace(t.m), dpp_up_inplace(t.sx), dpp_up_inplace(t.sy), dpp_up_inplace(t.lx), dpp_up_inplace(t.ly);
-}
-template <int R>
-__device__ __forceinline__ void rdiag_down_inplace(RDiag<R> &g) {
-#pragma unroll
-    for (int r = R - 1; r > 0; --r) {
-        rot_up(g.c[r].m, g.c[r - 1].m), rot_up(g.c[r].sx, g.c[r - 1].sx), rot_up(g.c[r].sy, g.c[r - 1].sy);
-        rot_up(g.c[r].lx, g.c[r - 1].lx), rot_up(g.c[r].ly, g.c[r - 1].ly);
-    }
-    RCell &t = g.c[0];
-    dpp_down_inplace(t.m), dpp_down_inplace(t.sx), dpp_down_inplace(t.sy), dpp_down_inplace(t.lx), dpp_down_inplace(t.ly);
-}
-template <int R>
-__device__ __forceinline__ void rs_fwd_rebase_c(const StepEnv &E, int r, RsState<R> &Q) {
-    if (r > 0) {
-        rdiag_up_inplace<R>(Q.A), rdiag_up_inplace<R>(Q.B);
-        held_up<R>(Q.hA), held_up<R>(Q.hB);
-        Q.x0 += 1, Q.y0 -= 1;
-        bases_up_inplace<R>(Q.S.X, feed8_get<+1>(Q.S.fx, E.X, E.lX, Q.x0 + 64 * R - 2, E.lane));
-        bases_up_inplace<R>(Q.S.Y, Q.S.ycap);
-    } else {
-        rdiag_down_inplace<R>(Q.A), rdiag_down_inplace<R>(Q.B);
-        held_down<R>(Q.hA), held_down<R>(Q.hB);
-        Q.x0 -= 1, Q.y0 += 1;
-        bases_down_inplace<R>(Q.S.X, Q.S.xcap);
-        bases_down_inplace<R>(Q.S.Y, feed8_get<+1>(Q.S.fy, E.Y, E.lY, Q.y0 - 1, E.lane));
-    }
-}
-template <int R>
-__device__ __forceinline__ void rs_bwd_rebase_c(const StepEnv &E, int r, RsState<R> &Q) {
-    if (r > 0) {
-        rdiag_down_inplace<R>(Q.A), rdiag_down_inplace<R>(Q.B);
-        held_down<R>(Q.hA), held_down<R>(Q.hB);
-        Q.x0 -= 1, Q.y0 += 1;
-        bases_down_inplace<R>(Q.S.X, feed8_get<-1>(Q.S.fx, E.X, E.lX, Q.x0, E.lane));
-        bases_down_inplace<R>(Q.S.Y, Q.S.ycap);
-    } else {
-        rdiag_up_inplace<R>(Q.A), rdiag_up_inplace<R>(Q.B);
-        held_up<R>(Q.hA), held_up<R>(Q.hB);
-        Q.x0 += 1, Q.y0 -= 1;
-        bases_up_inplace<R>(Q.S.X, Q.S.xcap);
-        bases_up_inplace<R>(Q.S.Y, feed8_get<-1>(Q.S.fy, E.Y, E.lY, Q.y0 - (64 * R - 1), E.lane));
-    }
-}
 
 // Frame rebase of the forward sweep, r = +1: (x0, y0) -> (x0 + 1, y0 - 1), every slot takes its upper neighbour; r = 0: nothing
 // (called on every anti-diagonal: only the base a stream takes in at its open end is fetched conditionally here).
@@ -461,7 +332,7 @@ __device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R
     if (r > 0) injX = feed8_get<+1>(Q.S.fx, E.X, E.lX, Q.x0 + 1 + 64 * R - 2, E.lane);
     else if (r < 0) injY = feed8_get<+1>(Q.S.fy, E.Y, E.lY, Q.y0 + 1 - 1, E.lane);
     const int dir = uni(r);
-    rs_rebase_scalars(Q.hA, Q.hB, Q.x0, Q.y0, dir);
+    rs_rebase_origin(Q.x0, Q.y0, dir);
     rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, dir, uni(injX), uni(injY));
 }
 // ... and of the backward sweep, which undoes the forward one: r is the forward rebase being undone.
@@ -471,7 +342,7 @@ __device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R
     if (r > 0) injX = feed8_get<-1>(Q.S.fx, E.X, E.lX, Q.x0 - 1, E.lane);  // back to lower x-y: (x0 - 1, y0 + 1)
     else if (r < 0) injY = feed8_get<-1>(Q.S.fy, E.Y, E.lY, Q.y0 - 1 - (64 * R - 1), E.lane);
     const int dir = uni(-r);
-    rs_rebase_scalars(Q.hA, Q.hB, Q.x0, Q.y0, dir);
+    rs_rebase_origin(Q.x0, Q.y0, dir);
     rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, dir, uni(injX), uni(injY));
 }
 
@@ -481,26 +352,22 @@ template <class F>
 __device__ __forceinline__ void rs_put(RCell &dst, uint64_t in_band, F &&cell) {
     if (lanes_of(in_band)) dst = cell();
 }
-// ... and the slots that row had inside ITS band and this one has not are cleared (a band edge moves by a slot now and then:
-// one scalar test per anti-diagonal, seldom taken).
+// ... and when the band is not where it was two anti-diagonals ago (`moved`: a bit of the control word, npr_sched.h; once
+// in ten anti-diagonals on noisy guides) everything outside it is cleared: the row that was overwritten may have had cells
+// there.  One scalar test per anti-diagonal; no masks of the held rows to carry along.
 template <int R>
-__device__ __forceinline__ void rs_clear_left(RDiag<R> &io, uint64_t (&hio)[R], const Masks<R> &mk) {
-    uint64_t gone = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) gone |= hio[r] & ~mk.cell[r];
-    if (gone) {
+__device__ __forceinline__ void rs_clear_outside(RDiag<R> &io, const Masks<R> &mk, uint32_t moved) {
+    if (moved) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (lanes_of(hio[r] & ~mk.cell[r])) io.c[r] = zero_rcell();
+            if (lanes_of(~mk.cell[r])) io.c[r] = zero_rcell();
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) hio[r] = mk.cell[r];
 }
 
 // One forward anti-diagonal: `io` holds d-2 on entry and d on exit, `p1` holds d-1.  S.X / S.Y: X[x-1]*8, Y[y-1]*8.
 template <int R>
-__device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &p1, Streams<R> &S, int &x0,
-                                              const Masks<R> &mk) {
+__device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &x0,
+                                              const Masks<R> &mk, uint32_t moved) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     x0 += 1;
     bases_up<R>(S.X, feed8_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
@@ -511,11 +378,11 @@ __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, ui
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
         rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
     }
-    rs_clear_left<R>(io, hio, mk);
+    rs_clear_outside<R>(io, mk, moved);
 }
 template <int R>
-__device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &p1, Streams<R> &S, int &y0,
-                                              const Masks<R> &mk) {
+__device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &y0,
+                                              const Masks<R> &mk, uint32_t moved) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     y0 += 1;
     bases_down<R>(S.Y, feed8_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
@@ -526,12 +393,12 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, ui
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
         rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
     }
-    rs_clear_left<R>(io, hio, mk);
+    rs_clear_outside<R>(io, mk, moved);
 }
 // One backward anti-diagonal d: `io` holds d+2 on entry and d on exit, `s1` holds d+1.  S.X / S.Y: X[x]*8, Y[y]*8.
 template <int R>
-__device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &s1, Streams<R> &S, int &x0,
-                                              const Masks<R> &mk) {
+__device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &x0,
+                                              const Masks<R> &mk, uint32_t moved) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     x0 -= 1;
     bases_down<R>(S.X, feed8_get<-1>(S.fx, E.X, E.lX, x0, E.lane));
@@ -542,11 +409,11 @@ __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, ui
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
         rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
     }
-    rs_clear_left<R>(io, hio, mk);
+    rs_clear_outside<R>(io, mk, moved);
 }
 template <int R>
-__device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, uint64_t (&hio)[R], const RDiag<R> &s1, Streams<R> &S, int &y0,
-                                              const Masks<R> &mk) {
+__device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &y0,
+                                              const Masks<R> &mk, uint32_t moved) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     y0 -= 1;
     bases_up<R>(S.Y, feed8_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
@@ -557,7 +424,7 @@ __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, ui
         rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
         rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
     }
-    rs_clear_left<R>(io, hio, mk);
+    rs_clear_outside<R>(io, mk, moved);
 }
 
 // ---- forward rows in HBM: 4 bytes per slot (the match value); the row offsets of the control words are the 8-byte

@@ -29,6 +29,7 @@ namespace npr {
 struct StairState {
     int32_t flo;   // x-y of slot 0 of the current frame
     uint32_t off;  // scratch cells of the rows so far (a schedule that needs 2^32 or more is refused)
+    int32_t a1, b1, a2, b2;  // slots [a, b) of the band on the previous anti-diagonal / the one before, in the frame's present slots
 };
 NPR_HD inline bool stair_packed(int R, int NW) { return R == 2 && NW == 1; }
 // widest band a class takes
@@ -38,6 +39,7 @@ NPR_HD inline bool stair_begin(StairState &st, int32_t lo0, int32_t n0, int32_t 
     if (n0 != 1 || max_width > stair_max_width(R, NW)) return false;
     st.flo = lo0 - 2 * ((C - 1) / 2);
     st.off = 0;
+    st.a1 = st.b1 = st.a2 = st.b2 = 0;
     return true;
 }
 // one anti-diagonal: its band (lo, n), the next one's (lo_nx, n_nx; ignored when d == D) -> its two control words.
@@ -67,17 +69,24 @@ NPR_HD inline bool stair_step(StairState &st, int32_t d, int32_t D, int32_t lo, 
     const int32_t jlo = (lo - st.flo) >> 1;  // lo >= flo, same parity
     const int32_t l0 = jlo >> rshift, l1 = (jlo + n + R - 1) >> rshift;
     const uint32_t row = static_cast<uint32_t>(l1 - l0) << rshift;
+    // Bit 30 of the second word: the band does not occupy the slots it occupied two anti-diagonals ago (a rebase moves a
+    // held row by a slot: +1 takes every slot's upper neighbour).  k_dp_rs writes a row over the one two anti-diagonals
+    // away under the band's lane mask and clears what lies outside it only when this says that something may.
+    const int32_t a2 = st.a2 - reb, b2 = st.b2 - reb;
+    const uint32_t moved = (d >= 2) & ((a2 != jlo) | (b2 != jlo + n));
+    st.a2 = st.a1 - reb, st.b2 = st.b1 - reb;
+    st.a1 = jlo, st.b1 = jlo + n;
     if (rshift == 1 && C == 128) {  // stair_packed
         const uint32_t lo0 = static_cast<uint32_t>(jlo + 1) >> 1, lo1 = static_cast<uint32_t>(jlo) >> 1;
         const uint32_t hi0 = static_cast<uint32_t>(jlo + n + 1) >> 1, hi1 = static_cast<uint32_t>(jlo + n) >> 1;
         ok &= (hi0 - lo0 <= 63u) & (hi1 - lo1 <= 63u);
         ok &= st.off + row < (1u << 29) - 512u;  // the row offsets are 32-bit byte offsets (stair_fits)
         w0 = ((st.off - 2u * lo1) << 3) + row_bias<2>();
-        w1 = lo0 | (lo1 << 7) | ((hi0 - lo0) << 14) | ((hi1 - lo1) << 21) | (static_cast<uint32_t>(reb + 1) << 28);
+        w1 = lo0 | (lo1 << 7) | ((hi0 - lo0) << 14) | ((hi1 - lo1) << 21) | (static_cast<uint32_t>(reb + 1) << 28) | (moved << 30);
     } else {
         ok &= st.off + row >= st.off;  // 2^32 cells
         w0 = st.off;
-        w1 = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26);
+        w1 = static_cast<uint32_t>(jlo) | (static_cast<uint32_t>(n) << 13) | (static_cast<uint32_t>(reb + 1) << 26) | (moved << 30);
     }
     st.off += row;
     return ok != 0;
