@@ -299,8 +299,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3", "anchor", "em"])
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (resident workloads; default 12288 northstar = two per resident "
-                    "wavefront, 1000 c2, 8192 anchor, 6144 em) or in the whole set (c3; default 50000)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (resident workloads; default 24576 northstar = four per resident "
+                    "wavefront slot (rounds 1-2: 12288; the launch lasts as long as its longest chain of reads, which two per slot leave "
+                    "10 %% above the mean), 1000 c2, 8192 anchor, 6144 em) or in the whole set (c3; default 50000)")
     ap.add_argument("--resident-arrays", action="store_true", help="c3: the job from arrays in host memory instead of from files")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary lines of the default run (the reference's own band; the "
@@ -372,7 +373,7 @@ def main():
 
 def resident(env):
     args, ctx, rank, world, dist, coll_dev, sync, allreduce = (env[k] for k in ("args", "ctx", "rank", "world", "dist", "coll_dev", "sync", "allreduce"))
-    n_reads = args.reads or {"northstar": 12288, "c2": 1000, "anchor": 8192}[args.workload]
+    n_reads = args.reads or {"northstar": 24576, "c2": 1000, "anchor": 8192}[args.workload]
     h, w, W, label = build_workload(args.workload, n_reads, rank)
     ctx.set_hmm(h)
     r = timed_resident(ctx, h, w, W, args.steps, args.warmup, sync)
