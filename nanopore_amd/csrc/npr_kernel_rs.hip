@@ -18,22 +18,12 @@ namespace npr {
 
 namespace {
 
-// exponents of the forward rows, one per RS_K anti-diagonals, read back by the backward sweep 64 blocks at a time:
-// lane l holds the exponent of block `base` - l
-struct FexpWindow {
-    int v;
-    int base;
-};
-__device__ __forceinline__ void fexp_fill(FexpWindow &w, const int *fexp, int blk, int lane) {
-    w.base = blk;
-    const int k = blk - lane;
-    w.v = k >= 0 ? fexp[k] : 0;
-}
-__device__ __forceinline__ int fexp_of(FexpWindow &w, const int *fexp, int d, int lane) {
-    const int blk = d / RS_K;
-    if (w.base - blk >= WAVE) fexp_fill(w, fexp, blk, lane);  // uniform
-    return __builtin_amdgcn_readlane(w.v, w.base - blk);
-}
+// Exponents of the forward rows, one per RS_K anti-diagonals: written by lane 0 with vector stores during the forward sweep,
+// read back by the backward sweep through the scalar cache (one s_load per loop iteration, an iteration ahead) after an
+// s_dcache_inv between the sweeps -- the region is reused from task to task, so the cache may hold the previous task's words.
+// (Read with a vector load and handed out by v_readlane, every anti-diagonal waited for vmcnt(0): the compiler cannot know
+// that the register is not the target of a load in flight, and the forward rows prefetched for the next step were.)
+typedef const __attribute__((address_space(4))) int *cptr_i32;
 
 // The control words of 64 anti-diagonals at a time, a lane each, fetched with one vector load a block ahead of their use
 // and handed out by v_readlane.  (Through the scalar cache every anti-diagonal began with an s_load and a wait for it --
@@ -229,7 +219,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     lmisc[1] = te;
                 }
         }
-        __syncthreads();
+        __syncthreads();  // (waits for the wavefront's stores too: the rows and their exponents are in L2)
+        __builtin_amdgcn_s_dcache_inv();
         const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
         const int tot_e = uni(lmisc[1]);
         __syncthreads();
@@ -258,8 +249,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             RowCtl<R> cur = read_row_ctl<R>(ctl, D);
             // `moved` of the anti-diagonals one and two above the one being computed: the row two above is the one overwritten
             uint32_t m1 = cur.moved, m2 = 0;
-            FexpWindow fw;
-            fexp_fill(fw, fexp, D / RS_K, lane);
+            cptr_i32 fexp_c = (cptr_i32)fexp;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r]);
@@ -283,14 +273,14 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 rs_load_row<R>(frs, fb, cur, voff);
                 nxt = read_row_ctl<R>(ctl, D - 1);
                 rs_load_row<R>(frs, fa, nxt, voff);
-                rs_emit_pairs<R>(sink, Q.B, fb, D, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_of(fw, fexp, D, lane) + Q.e - tot_e), inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.B, fb, D, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_c[D / RS_K] + Q.e - tot_e), inv_tot, jr, cnt);
             } else {
                 rs_load_row<R>(frs, fa, cur, voff);
                 if (D >= 1) {
                     nxt = read_row_ctl<R>(ctl, D - 1);
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
-                rs_emit_pairs<R>(sink, Q.A, fa, D, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_of(fw, fexp, D, lane) + Q.e - tot_e), inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.A, fa, D, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_c[D / RS_K] + Q.e - tot_e), inv_tot, jr, cnt);
             }
             // `cur` is the control word of the anti-diagonal above the one computed next: its rebase is undone first
             int d2 = D - 1;
@@ -305,12 +295,13 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 rs_bwd_x_step<R>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 if ((d2 & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
-                rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_of(fw, fexp, d2, lane) + Q.e - tot_e), inv_tot, jr, cnt);
+                rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_c[d2 / RS_K] + Q.e - tot_e), inv_tot, jr, cnt);
                 d2 -= 1;
             }
 #if NPR_RS_CTL == 2
             CtlPair wb = ctl_scalar2(ctl, max(d2 - 2, 0));  // {d2 - 2, d2 - 1}
 #endif
+            int ef_next = fexp_c[max(d2, 0) / RS_K];
             for (; d2 >= 1; d2 -= 2) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
 #if NPR_RS_CTL == 0
                 const CtlPair w = ctl_get2<-1>(cb, gw, D, d2 - 1, lane);  // the words of d2 - 1 and d2 - 2
@@ -330,7 +321,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 RS_BWD_REBASE(reb);
                 rs_bwd_y_step<R>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
-                const int ef = fexp_of(fw, fexp, d2, lane);  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
+                const int ef = ef_next;  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
+                ef_next = fexp_c[max(d2 - 2, 0) / RS_K];
                 rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
                 reb = cur.reb;
                 cur = nxt;
