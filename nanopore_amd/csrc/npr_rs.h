@@ -238,41 +238,42 @@ __device__ __forceinline__ int rs_renorm(RDiag<R> &P, RDiag<R> &Q) {
 }
 
 // ---- frame rebase: the whole register state moves by one slot, in place ----
-// ONE asm statement per register group with the test for "no rebase" inside it.  Written as C++ around per-register asm
+// ONE asm statement per register group (the cells of the held rows; the base streams) with the test for "no rebase" inside it.  Written as C++ around per-register asm
 // (npr_frame.h's way) the rebase is a branch, the moved registers are new values on one side of it, and the compiler pays
 // for the join by copying 20-odd registers on the path WITHOUT a rebase, every anti-diagonal.  Inside one statement there
 // is no join to pay for: the hot path costs two scalar instructions.  dir: +1 every slot takes its upper neighbour (the
 // vacated top slot takes 0 / the injected base), -1 its lower neighbour, 0 nothing.  (s_nop: a DPP read of a VGPR written by
 // the previous VALU instruction needs two wait states, which the compiler cannot see through inline assembly.)
-__device__ __forceinline__ void rs_rebase_regs(RDiag<1> &P, RDiag<1> &Q, Bases<1> &X, Bases<1> &Y, int dir, int injX, int injY) {
-    asm volatile("s_cmp_eq_u32 %12, 0\n\t"
+// ---- generated by tools/gen_rs_rebase.py ----
+__device__ __forceinline__ void rs_rebase_rows(RDiag<1> &P, RDiag<1> &Q, int dir) {
+    asm volatile("s_cmp_eq_u32 %10, 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_lt_i32 %12, 0\n\t"
+                 "s_cmp_lt_i32 %10, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
-                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %10, %13, 63\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %11, %14, 63\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                  "s_branch 2f\n\t"
                  "1:\n\t"
-                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %10, %13, 0\n\tv_mov_b32_dpp %11, %11 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %11, %14, 0\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                  "2:"
-                 : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly), "+v"(X.b[0]), "+v"(Y.b[0])
-                 : "s"(dir), "s"(injX), "s"(injY)
+                 : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly)
+                 : "s"(dir)
                  : "scc");
 }
-__device__ __forceinline__ void rs_rebase_regs(RDiag<2> &P, RDiag<2> &Q, Bases<2> &X, Bases<2> &Y, int dir, int injX, int injY) {
-    asm volatile("s_cmp_eq_u32 %24, 0\n\t"
+__device__ __forceinline__ void rs_rebase_rows(RDiag<2> &P, RDiag<2> &Q, int dir) {
+    asm volatile("s_cmp_eq_u32 %20, 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_lt_i32 %24, 0\n\t"
+                 "s_cmp_lt_i32 %20, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
-                 "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\tv_swap_b32 %20, %21\n\tv_swap_b32 %22, %23\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %21, %21 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %21, %25, 63\n\tv_mov_b32_dpp %23, %23 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %23, %26, 63\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                  "s_branch 2f\n\t"
                  "1:\n\t"
-                 "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %21, %20\n\tv_swap_b32 %23, %22\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %20, %20 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %20, %25, 0\n\tv_mov_b32_dpp %22, %22 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %22, %26, 0\n\t"
+                 "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                  "2:"
-                 : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly), "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1])
-                 : "s"(dir), "s"(injX), "s"(injY)
+                 : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly)
+                 : "s"(dir)
                  : "scc");
 }
-__device__ __forceinline__ void rs_rebase_row4(RDiag<4> &P, int dir) {
+__device__ __forceinline__ void rs_rebase_rows(RDiag<4> &P, int dir) {
     asm volatile("s_cmp_eq_u32 %20, 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
                  "s_cmp_lt_i32 %20, 0\n\t"
@@ -286,23 +287,98 @@ __device__ __forceinline__ void rs_rebase_row4(RDiag<4> &P, int dir) {
                  : "s"(dir)
                  : "scc");
 }
-__device__ __forceinline__ void rs_rebase_bases4(Bases<4> &X, Bases<4> &Y, int dir, int injX, int injY) {
-    asm volatile("s_cmp_eq_u32 %8, 0\n\t"
+__device__ __forceinline__ void rs_rebase_rows(RDiag<4> &P, RDiag<4> &Q, int dir) { rs_rebase_rows(P, dir), rs_rebase_rows(Q, dir); }
+__device__ __forceinline__ void rs_rebase_streams_fwd(Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %3, 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_lt_i32 %8, 0\n\t"
+                 "s_cmp_lt_i32 %3, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
-                 "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %3, %9, 63\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %7, %10, 63\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %8, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %2, %4, %8\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %2, %8, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %5, %2\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %0, %2, 63\n\tv_writelane_b32 %1, %11, 63\n\t"
                  "s_branch 2f\n\t"
                  "1:\n\t"
-                 "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %0, %9, 0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %4, %10, 0\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %9, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %2, %6, %9\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %2, %9, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %7, %2\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %1, %2, 0\n\tv_writelane_b32 %0, %10, 0\n\t"
                  "2:"
-                 : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(X.b[2]), "+v"(X.b[3]), "+v"(Y.b[0]), "+v"(Y.b[1]), "+v"(Y.b[2]), "+v"(Y.b[3])
-                 : "s"(dir), "s"(injX), "s"(injY)
+                 : "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
-__device__ __forceinline__ void rs_rebase_regs(RDiag<4> &P, RDiag<4> &Q, Bases<4> &X, Bases<4> &Y, int dir, int injX, int injY) {
-    rs_rebase_row4(P, dir), rs_rebase_row4(Q, dir), rs_rebase_bases4(X, Y, dir, injX, injY);
+__device__ __forceinline__ void rs_rebase_streams_bwd(Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %3, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %3, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %9, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %2, %6, %9\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %2, %9, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %7, %2\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %1, %2, 63\n\tv_writelane_b32 %0, %10, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %8, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %2, %4, %8\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %2, %8, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %5, %2\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %11, 0\n\t"
+                 "2:"
+                 : "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
 }
+__device__ __forceinline__ void rs_rebase_streams_fwd(Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %5, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %5, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %10, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %4, %6, %10\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %4, %10, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %7, %4\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %1, %4, 63\n\tv_writelane_b32 %3, %13, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %11, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %4, %8, %11\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %4, %11, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %9, %4\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %2, %4, 0\n\tv_writelane_b32 %0, %12, 0\n\t"
+                 "2:"
+                 : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_streams_bwd(Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %5, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %5, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %11, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %4, %8, %11\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %4, %11, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %9, %4\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %3, %4, 63\n\tv_writelane_b32 %1, %12, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %10, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %4, %6, %10\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %4, %10, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %7, %4\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %0, %4, 0\n\tv_writelane_b32 %2, %13, 0\n\t"
+                 "2:"
+                 : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_streams_fwd(Bases<4> &X, Bases<4> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %9, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %9, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %14, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %8, %10, %14\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %8, %14, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %11, %8\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %3, %8, 63\n\tv_writelane_b32 %7, %17, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %15, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %8, %12, %15\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %8, %15, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %13, %8\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %4, %8, 0\n\tv_writelane_b32 %0, %16, 0\n\t"
+                 "2:"
+                 : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(X.b[2]), "+v"(X.b[3]), "+v"(Y.b[0]), "+v"(Y.b[1]), "+v"(Y.b[2]), "+v"(Y.b[3]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_streams_bwd(Bases<4> &X, Bases<4> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %9, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %9, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %15, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %8, %12, %15\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %8, %15, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %13, %8\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %7, %8, 63\n\tv_writelane_b32 %3, %16, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %14, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %8, %10, %14\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %8, %14, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %11, %8\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %0, %8, 0\n\tv_writelane_b32 %4, %17, 0\n\t"
+                 "2:"
+                 : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(X.b[2]), "+v"(X.b[3]), "+v"(Y.b[0]), "+v"(Y.b[1]), "+v"(Y.b[2]), "+v"(Y.b[3]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
+// ---- end of generated code ----
 
 // ... and the scalar side of it: the frame's origin moves by one lattice point
 __device__ __forceinline__ void rs_rebase_origin(int &x0, int &y0, int dir) {
@@ -324,33 +400,35 @@ struct RsState {
     int e;
 };
 
-// Frame rebase of the forward sweep, r = +1: (x0, y0) -> (x0 + 1, y0 - 1), every slot takes its upper neighbour; r = 0: nothing
-// (called on every anti-diagonal: only the base a stream takes in at its open end is fetched conditionally here).
+// Frame rebase of the forward sweep, r = +1: (x0, y0) -> (x0 + 1, y0 - 1), every slot takes its upper neighbour; r = 0: nothing.
+// Called on every anti-diagonal; nothing here is conditional in C++: the statements test r themselves, and the base a stream
+// takes in from its feed is read inside the statement (from the feed's current or next block: at most one base ahead of
+// the steps, which do the refills).
 template <int R>
 __device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
-    int injX = Q.S.xcap, injY = Q.S.ycap;
-    if (r > 0) injX = feed8_get<+1>(Q.S.fx, E.X, E.lX, Q.x0 + 1 + 64 * R - 2, E.lane);
-    else if (r < 0) injY = feed8_get<+1>(Q.S.fy, E.Y, E.lY, Q.y0 + 1 - 1, E.lane);
     const int dir = uni(r);
+    const int offX = uni((Q.x0 + 64 * R - 1) - Q.S.fx.base);  // up: the X stream takes in X[(x0 + 1) + 64R - 2]
+    const int offY = uni(Q.y0 - Q.S.fy.base);                  // down: the Y stream takes in Y[(y0 + 1) - 1]
+    rs_rebase_streams_fwd(Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
     rs_rebase_origin(Q.x0, Q.y0, dir);
-    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, dir, uni(injX), uni(injY));
+    rs_rebase_rows(Q.A, Q.B, dir);
 }
 // ... and of the backward sweep, which undoes the forward one: r is the forward rebase being undone.
 template <int R>
 __device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R> &Q) {
-    int injX = Q.S.xcap, injY = Q.S.ycap;
-    if (r > 0) injX = feed8_get<-1>(Q.S.fx, E.X, E.lX, Q.x0 - 1, E.lane);  // back to lower x-y: (x0 - 1, y0 + 1)
-    else if (r < 0) injY = feed8_get<-1>(Q.S.fy, E.Y, E.lY, Q.y0 - 1 - (64 * R - 1), E.lane);
     const int dir = uni(-r);
+    const int offX = uni(Q.S.fx.base - (Q.x0 - 1));        // down (r > 0): the X stream takes in X[x0 - 1] at slot 0
+    const int offY = uni(Q.S.fy.base - (Q.y0 - 64 * R));   // up (r < 0): the Y stream takes in Y[(y0 - 1) - (64R - 1)] on top
+    rs_rebase_streams_bwd(Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
     rs_rebase_origin(Q.x0, Q.y0, dir);
-    rs_rebase_regs(Q.A, Q.B, Q.S.X, Q.S.Y, dir, uni(injX), uni(injY));
+    rs_rebase_rows(Q.A, Q.B, dir);
 }
 
 // The new row replaces the one two anti-diagonals away, under the band's lane mask (the arithmetic itself runs under the
 // mask: no select per value) ...
 template <class F>
 __device__ __forceinline__ void rs_put(RCell &dst, uint64_t in_band, F &&cell) {
-    if (lanes_of(in_band)) dst = cell();
+    if (__builtin_expect(lanes_of(in_band), 1)) dst = cell();  // (expected: keeps the block in line instead of behind two taken branches)
 }
 // ... and when the band is not where it was two anti-diagonals ago (`moved`: a bit of the control word, npr_sched.h; once
 // in ten anti-diagonals on noisy guides) everything outside it is cleared: the row that was overwritten may have had cells
