@@ -99,23 +99,32 @@ __device__ __forceinline__ int feed8_get(Feed &f, const uint8_t *seq, int len, i
 }
 
 // ---- emission tables in LDS, laid out for byte offsets that are base codes * 8 ----
-//   em8[5x + y] (8-byte stride: byte offset 5 * bx + by), ex2[x] = (shortGapX, longGapX), ey2[y] = (shortGapY, longGapY)
+//   em8[6x + y] (8-byte stride: byte offset 6 * bx + by), ex2[x] = (shortGapX, longGapX), ey2[y] = (shortGapY, longGapY)
+//   Code 5 (byte offset 40, RS_DEAD8) is the base of a slot OUTSIDE the band: all its emissions are 0, so every state of the cell
+//   computed there is an exact zero (two selects per cell instead of an EXEC-mask region per cell row and the clearing of what the band left behind; NPR_RS_DEADCODE_MAX_R).
 struct RsTables {
-    float em8[25][2];
-    float ex2[5][2];
-    float ey2[5][2];
+    float em8[36][2];  // [6 x + y]
+    float ex2[6][2];
+    float ey2[6][2];
 };
+constexpr int RS_DEAD8 = 40;
+#ifndef NPR_RS_DEADCODE_MAX_R
+#define NPR_RS_DEADCODE_MAX_R 1  // slots per lane up to which it is used: one cell per lane gains 4 % (config 2: 1.75 -> 1.69 ms), two lose 1 %
+#endif
 constexpr int RS_TABLE_FLOATS = sizeof(RsTables) / sizeof(float);
 __device__ __forceinline__ void rs_build_tables(RsTables *t, const DevModel *m, int tid, int nthreads) {
-    for (int i = tid; i < 25; i += nthreads) t->em8[i][0] = m->em[i], t->em8[i][1] = 0.f;
-    for (int i = tid; i < 5; i += nthreads) {
-        t->ex2[i][0] = m->ex[5 + i], t->ex2[i][1] = m->ex[15 + i];
-        t->ey2[i][0] = m->ey[10 + i], t->ey2[i][1] = m->ey[20 + i];
+    for (int i = tid; i < 36; i += nthreads) {
+        const int x = i / 6, y = i % 6;
+        t->em8[i][0] = (x < 5 && y < 5) ? m->em[5 * x + y] : 0.f, t->em8[i][1] = 0.f;
+    }
+    for (int i = tid; i < 6; i += nthreads) {
+        t->ex2[i][0] = i < 5 ? m->ex[5 + i] : 0.f, t->ex2[i][1] = i < 5 ? m->ex[15 + i] : 0.f;
+        t->ey2[i][0] = i < 5 ? m->ey[10 + i] : 0.f, t->ey2[i][1] = i < 5 ? m->ey[20 + i] : 0.f;
     }
 }
 __device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
     constexpr int OFF_EX = offsetof(RsTables, ex2), OFF_EY = offsetof(RsTables, ey2);
-    em = *reinterpret_cast<const float *>(tab + (__umul24(static_cast<unsigned>(bx), 5u) + static_cast<unsigned>(by)));
+    em = *reinterpret_cast<const float *>(tab + (__umul24(static_cast<unsigned>(bx), 6u) + static_cast<unsigned>(by)));
     const float2 ex = *reinterpret_cast<const float2 *>(tab + OFF_EX + bx);
     const float2 ey = *reinterpret_cast<const float2 *>(tab + OFF_EY + by);
     exs = ex.x, exl = ex.y, eys = ey.x, eyl = ey.y;
@@ -450,13 +459,20 @@ __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, co
     x0 += 1;
     bases_up<R>(S.X, feed8_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
     const RDiag<R> U = rs_shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
+    RDiag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
-        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
+        if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            o.c[r] = rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
+        } else {
+            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
+        }
     }
-    rs_clear_outside<R>(io, mk, moved);
+    if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
+    else rs_clear_outside<R>(io, mk, moved);
 }
 template <int R>
 __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &y0,
@@ -465,13 +481,20 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, co
     y0 += 1;
     bases_down<R>(S.Y, feed8_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
     const RDiag<R> L = rs_shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
+    RDiag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
-        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
+        if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            o.c[r] = rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
+        } else {
+            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
+        }
     }
-    rs_clear_outside<R>(io, mk, moved);
+    if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
+    else rs_clear_outside<R>(io, mk, moved);
 }
 // One backward anti-diagonal d: `io` holds d+2 on entry and d on exit, `s1` holds d+1.  S.X / S.Y: X[x]*8, Y[y]*8.
 template <int R>
@@ -481,13 +504,20 @@ __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, co
     x0 -= 1;
     bases_down<R>(S.X, feed8_get<-1>(S.fx, E.X, E.lX, x0, E.lane));
     const RDiag<R> Ys = rs_shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
+    RDiag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
-        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
+        if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            o.c[r] = rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
+        } else {
+            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
+        }
     }
-    rs_clear_outside<R>(io, mk, moved);
+    if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
+    else rs_clear_outside<R>(io, mk, moved);
 }
 template <int R>
 __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &y0,
@@ -496,13 +526,20 @@ __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, co
     y0 -= 1;
     bases_up<R>(S.Y, feed8_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
     const RDiag<R> Xs = rs_shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
+    RDiag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
-        rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-        rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
+        if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            o.c[r] = rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
+        } else {
+            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
+        }
     }
-    rs_clear_outside<R>(io, mk, moved);
+    if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
+    else rs_clear_outside<R>(io, mk, moved);
 }
 
 // ---- forward rows in HBM: 4 bytes per slot (the match value); the row offsets of the control words are the 8-byte
