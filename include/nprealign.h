@@ -194,7 +194,8 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
  *        one per cell, about 1.4 times the cells per second): every task of 0-2 unless NPR_ARITH=cell is set or a loaded model's
  *        values can grow from one anti-diagonal to the next.  A task for which one exponent per row was not enough (a stretch of
  *        its alignment ~110 binary orders below the row's largest values: an indel of 70+ bases) is run again by npr_batch_run
- *        with the kernel of 0-2; npr_batch_segment_arith says which arithmetic a segment's results come from. */
+ *        with the kernel of 0-2; npr_batch_segment_arith says which arithmetic a segment's results come from.
+ *   18   class 11's column stripes in row-scaled arithmetic (k_dp_tile_rs; only under NPR_TILE_RS=1: same bits, not faster yet) */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* Which device arithmetic each segment (matrix split) of each read ran in, in read order: seg_off[n_reads + 1], arith[seg_off
  * [n_reads]] (pass arith == NULL for the offsets alone).  0: one exponent per cell (npr_cell.h: k_dp_tile, k_dp_generic, k_dp_wide

@@ -485,22 +485,25 @@ bool build_stair_schedule(const Segment &s, int R, int NW, uint32_t *ctl, int64_
 // lane), the register kernel with NW wavefronts per task (k_dp_wide), the generic kernel with an LDS ring in three
 // width classes, the generic kernel with its ring in HBM.
 namespace {
-enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4, K_PAIR = 5, K_RS = 6 };
+enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4, K_PAIR = 5, K_RS = 6, K_TILE_RS = 7 };
 struct KClass {
     int kind, R, NW;
     int slots() const { return 64 * R * NW; }
 };
-constexpr int kClasses = 18;
+constexpr int kClasses = 19;
 constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STAIR, 4, 1}, {K_WIDE, 2, 4}, {K_WIDE, 2, 8},
                                         {K_WIDE, 4, 8}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
                                         {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}, {K_TILE, 2, 0},
                                         // k_dp_pair<R>: the one-wavefront frame classes 0-2 with the two sweeps on two wavefronts
                                         {K_PAIR, 1, 1}, {K_PAIR, 2, 1}, {K_PAIR, 4, 1},
                                         // k_dp_rs<R>: the one-wavefront frame classes 0-2 in row-scaled arithmetic (npr_rs.h)
-                                        {K_RS, 1, 1}, {K_RS, 2, 1}, {K_RS, 4, 1}};
-constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kFirstRs = 15, kQueueSlots = 24;
+                                        {K_RS, 1, 1}, {K_RS, 2, 1}, {K_RS, 4, 1},
+                                        // k_dp_tile_rs: class 11's column stripes in row-scaled arithmetic (one exponent per stripe row)
+                                        {K_TILE_RS, 2, 0}};
+constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kFirstRs = 15, kTileRsClass = 18, kQueueSlots = 24;
 inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_PAIR || kClassTab[c].kind == K_RS; }
-inline bool is_one_wave_kind(int kind) { return kind == K_STAIR || kind == K_RS; }  // one wavefront per task on the frame schedule
+inline bool is_one_wave_kind(int kind) { return kind == K_STAIR || kind == K_RS; }
+inline bool is_tile_kind(int kind) { return kind == K_TILE || kind == K_TILE_RS; }  // column stripes, NW wavefronts per task  // one wavefront per task on the frame schedule
 // resident wavefronts per CU of the one-wavefront frame kernels (VGPR-limited: 71 / 80 / 162 registers: 7 / 6 / 3 per SIMD)
 inline int stair_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 12); }
 // ... and of k_dp_rs<R> (72 / 79 / 101 registers: 7 / 6 / 4 per SIMD; R = 2 measured at 5 / 6 / 7 / 8 per SIMD: 6 is best)
@@ -863,8 +866,12 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
             if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) rs = false;
         if (rs)
-            for (int64_t k = 0; k < ntasks; ++k)
+            for (int64_t k = 0; k < ntasks; ++k) {
                 if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
+                // (the stripe kernel in row-scaled arithmetic, k_dp_tile_rs, is opt-in: same bits, first pass 7 % faster on the
+                // reference's band, but one task in eight fails the range certificate there and runs twice -- DESIGN.md 5.1f)
+                else if (cls_of[k] == kTileClass && std::getenv("NPR_TILE_RS")) cls_of[k] = static_cast<int8_t>(kTileRsClass);
+            }
     }
     bool any_pair = false;
     {
@@ -1029,7 +1036,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             L.wcap = 0;
             L.lds = wide_lds_bytes(nw);
             L.threads = 64 * nw;
-        } else if (kClassTab[c].kind == K_TILE) {
+        } else if (is_tile_kind(kClassTab[c].kind)) {
             // 80 VGPRs: 6 wavefronts per SIMD, 24 per CU, shared by workgroups of NW wavefronts.  A read's band offers a
             // parallelism of about four stripes on average (rectangles of ~1000 columns, each stripe starting 128 + 16..31
             // anti-diagonals after its left neighbour): measured on 8192 x 8 kb reads in the reference's band, 2 / 3 / 4 / 6 / 8
@@ -1038,7 +1045,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             if (const char *w = std::getenv("NPR_TILE_WAVES")) nw = std::min(8, std::max(1, std::atoi(w)));
             waves_per_cu = std::max(1, 24 / nw);
             L.wcap = nw;
-            L.lds = tile_lds_bytes(nw);
+            L.lds = kClassTab[c].kind == K_TILE_RS ? tile_rs_lds_bytes(nw) : tile_lds_bytes(nw);
             L.threads = 64 * nw;
         } else if (kClassTab[c].kind == K_GENERIC_LDS) {
             // several wavefronts per task: these tasks are big, their forward scratch caps how many can be
@@ -1073,7 +1080,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // slot_stride; npr_batch_expectations refuses a batch laid out this way.)
     npr_batch::Launch *tileL = nullptr;
     for (auto &L : b->launches)
-        if (kClassTab[L.cls].kind == K_TILE) tileL = &L;
+        if (is_tile_kind(kClassTab[L.cls].kind)) tileL = &L;
     const int64_t tile_min = tileL ? tile_need[rank[tileL->first]] : 0;
     int64_t stair_grid = 0;
     for (auto &L : b->launches)
@@ -1191,7 +1198,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     {   // report the class that carries most cells
         int64_t best = -1;
         for (const auto &L : b->launches)
-            if (L.cells > best) best = L.cells, b->stats.kernel_variant = kClassTab[L.cls].kind == K_TILE ? 2 : (is_register_class(L.cls) ? 1 : 0);
+            if (L.cells > best) best = L.cells, b->stats.kernel_variant = is_tile_kind(kClassTab[L.cls].kind) ? 2 : (is_register_class(L.cls) ? 1 : 0);
     }
     b->stats.device_bytes = fixed + static_cast<int64_t>(b->scratch_cells) * 8 + ring_floats * 4;
     drain.armed = false;
@@ -1266,6 +1273,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
                        : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
+                       : kc.kind == K_TILE_RS ? launch_tile_rs(a, L.wcap, L.grid, s)
                        : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
                                            : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));
@@ -1288,7 +1296,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     b->outs.resize(b->tasks.size());
     b->task_rerun.assign(b->tasks.size(), 0);
     for (const auto &L : b->launches) {
-        if (kClassTab[L.cls].kind != K_RS) continue;
+        if (kClassTab[L.cls].kind != K_RS && kClassTab[L.cls].kind != K_TILE_RS) continue;
         HIP_TRY(ctx, hipMemcpy(b->outs.data() + L.first, b->d_outs.p + L.first, sizeof(TaskOut) * L.count, hipMemcpyDeviceToHost));
         std::vector<int32_t> again;
         for (int k = L.first; k < L.first + L.count; ++k)
@@ -1307,7 +1315,8 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.slot_base = L.slot_base;
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;  // (task j of `again` is no larger than the j-th task of the class)
         const int grid = static_cast<int>(std::min<size_t>(sub.size(), static_cast<size_t>(L.grid)));
-        const int rc = launch_stair(a, kClassTab[L.cls].R, grid, ctx->stream);
+        a.wcap = L.wcap;
+        const int rc = kClassTab[L.cls].kind == K_TILE_RS ? launch_tile(a, 2, L.wcap, grid, ctx->stream) : launch_stair(a, kClassTab[L.cls].R, grid, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch (second pass)", static_cast<hipError_t>(rc));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<TaskOut> subout(sub.size());
@@ -1847,7 +1856,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
             launches.push_back(l);
             continue;
         }
-        if (kClassTab[dl.cls].kind == K_TILE && kClassTab[dl.cls].R == 2 && !std::getenv("NPR_EM_GENERIC")) {
+        if (is_tile_kind(kClassTab[dl.cls].kind) && kClassTab[dl.cls].R == 2 && !std::getenv("NPR_EM_GENERIC")) {
             // 164 VGPRs: 3 wavefronts per SIMD, 12 per CU -> 3 workgroups of 4; the workgroups keep the scratch regions the DP
             // launch gave them (region i is sized for task i, and everything the queue hands out later is smaller)
             l.stair_R = 2, l.tile = true;

@@ -78,6 +78,15 @@ def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(
         assert old[3][11] == 0 and old[3][3:11].sum() == tasks[11]
         same(ref, old)
 
+    # the stripes in row-scaled arithmetic (k_dp_tile_rs, opt-in: one exponent per stripe row, neighbour cells handed over with
+    # their row's exponent, tasks without a range certificate run again in k_dp_tile): the same bits
+    ref = run(R.make_params(band_mode=R.BAND_ANCHOR))
+    monkeypatch.setenv("NPR_TILE_RS", "1")
+    rs = run(R.make_params(band_mode=R.BAND_ANCHOR))
+    monkeypatch.delenv("NPR_TILE_RS")
+    assert rs[3][18] > 0 and rs[3][11] == 0 and ref[3][11] == rs[3][18]
+    same(ref, rs)
+
     # two reads against the oracle's fp32 mirror
     h = orc.make_hmm(T, E)
     PO = orc.make_params(band_mode=orc.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)

@@ -21,12 +21,18 @@ for kw, n, lmin, lmax, indel, mi in ((dict(band_mode=1, fixed_width=40), 24, 5, 
                                      (dict(band_mode=1, fixed_width=200), 12, 300, 2500, 0.2, 40),
                                      (dict(band_mode=1, fixed_width=400), 6, 400, 1500, 0.2, 40),
                                      (dict(band_mode=0, diagonal_expansion=10, constraint_trim=2, split_threshold=12), 16, 50, 500, 0.2, 40),
-                                     (dict(band_mode=0, diagonal_expansion=60, constraint_trim=3, split_threshold=3000), 8, 300, 3000, 0.15, 20)):
+                                     (dict(band_mode=0, diagonal_expansion=60, constraint_trim=3, split_threshold=3000), 8, 300, 3000, 0.15, 20),
+                                     # the reference's own band: unanchored rectangles up to 3000 cells across -> the stripe kernel
+                                     (dict(band_mode=0, diagonal_expansion=10, constraint_trim=14, split_threshold=3000), 6, 1500, 6000, 0.2, 40),
+                                     (dict(band_mode=0, diagonal_expansion=10, constraint_trim=14, split_threshold=700, max_pairs_per_base=40), 4, 1500, 4000, 0.25, 60),
+                                     (dict(band_mode=1, fixed_width=700), 4, 400, 1500, 0.2, 40)):
     cases = [random_pair(rng, int(rng.integers(lmin, lmax + 1)), indel=indel, max_indel=mi) for _ in range(n)]
     refs = [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases]
     reads = [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases]
     out = ctx.realign(R.make_params(**kw), refs, reads, [g for _, _, g in cases], want_pairs=True)
-    P = orc.make_params(**kw)
+    okw = dict(kw)
+    okw.pop("max_pairs_per_base", None)
+    P = orc.make_params(**okw)
     bad = 0
     narith = 0
     for (X, Y, ops), g in zip(cases, out):
