@@ -267,7 +267,8 @@ int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
 // see.  A task with a row at or above the limit (its alignment runs ~90 binary orders further below the product of the row's
 // largest forward and backward values than usual: the stretch between a long deletion and a long insertion, say) reports
 // TASK_RERUN instead of NPR_OK and npr_batch_run runs it again with the per-cell-exponent kernel (k_dp_stair), which has no
-// such limit.
+// such limit.  So does a task whose forward sweep arrives at the end corner with nothing: whether that band really carries
+// no probability (NPR_ERR_ZERO_PROB) is for the kernel without a range limit to say.
 #define NPR_RS_S_LIMIT (126 - 60 - (NPR_RS_TOP + 6) - 1)
 constexpr int32_t TASK_RERUN = 1;  // TaskOut::status of such a task between the two launches (never leaves npr_batch_run)
 NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }

@@ -359,7 +359,9 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         if (lane == 0) {
             out.npairs = cnt;
             if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
-            if (smax >= NPR_RS_S_LIMIT && out.status != NPR_ERR_ZERO_PROB) out.status = TASK_RERUN;  // one exponent per row may not have been enough
+            // one exponent per row may not have been enough -- also when nothing arrived at the end corner: the per-cell kernel decides
+            // whether the band really carries no probability
+            if (smax >= NPR_RS_S_LIMIT || !alive) out.status = TASK_RERUN;
             a.outs[t] = out;
         }
         int nt = 0;

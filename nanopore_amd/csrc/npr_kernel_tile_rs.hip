@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(WAVE *TRS_MAX_NW) __attribute__((amdgpu_waves_
             const int cnt = lmisc[4];
             out.npairs = cnt;
             if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
-            if (alive && lmisc[6] >= TRS_S_LIMIT) out.status = TASK_RERUN;  // one exponent per stripe row may not have been enough
+            if (!alive || lmisc[6] >= TRS_S_LIMIT) out.status = TASK_RERUN;  // one exponent per stripe row may not have been enough (or nothing arrived: k_dp_tile decides)
             a.outs[t] = out;
             lmisc[5] = atomicAdd(a.queue, 1);
         }

@@ -294,3 +294,31 @@ def test_row_scaled_task_without_its_range_certificate_runs_again_per_cell(gpu_c
             assert abs((a if a is not None else 0.01) - (b if b is not None else 0.01)) < 1e-4
         assert o["loglik"] == pytest.approx(m64["total_ll"], rel=2e-6)
     assert any(op == 2 and n >= 230 for op, n in out[0]["ops"]) and any(op == 1 and n >= 230 for op, n in out[0]["ops"])
+
+
+def test_band_without_probability_is_reported_by_the_per_cell_kernel(gpu_ctx):
+    """A row-scaled task whose forward sweep arrives at the end corner with nothing cannot tell a band that carries no
+    probability from one whose probability fell out of a row's range, so it too runs again with a per-cell exponent
+    (npr_device.h TASK_RERUN): NPR_ERR_ZERO_PROB then comes from the kernel without a range limit.  A model without gaps and
+    without mismatches makes a read with one substitution such a band; its twin without the substitution aligns."""
+    from nanopore_amd import realign as R
+    from nanopore_amd.hmm import Hmm
+    T = np.zeros(25)
+    T[0] = 1.0                                   # match -> match only
+    E = np.zeros(80)
+    for s in range(5):
+        for b in range(4):
+            E[16 * s + 5 * b] = 0.25             # every state emits identical bases only
+    hm = Hmm()
+    hm.transitions, hm.emissions = [float(v) for v in T], [float(v) for v in E]
+    gpu_ctx.set_hmm(hm)
+    rng = np.random.default_rng(53)
+    X = rng.integers(0, 4, size=300).astype(np.uint8)
+    Y = X.copy()
+    Y[150] = (Y[150] + 1) % 4
+    refs = [bytes(b"ACGT"[c] for c in X)] * 2
+    reads = [bytes(b"ACGT"[c] for c in Y), bytes(b"ACGT"[c] for c in X)]
+    out = gpu_ctx.realign(R.make_params(band_mode=1, fixed_width=40), refs, reads, [[(0, 300)], [(0, 300)]])
+    assert out[0]["status"] == -2 and out[0]["seg_arith"] == [0]     # NPR_ERR_ZERO_PROB, said by k_dp_stair
+    assert out[1]["status"] == 0 and out[1]["ops"] == [(0, 300)] and out[1]["seg_arith"] == [1]
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
