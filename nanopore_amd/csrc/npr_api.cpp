@@ -274,6 +274,7 @@ struct npr_batch {
     std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     bool variable_regions = false;  // the one-wavefront frame launches have regions of their own size (not E-step capable)
+    bool pair_rs = false;  // classes 12-14 run k_dp_pair_rs (row-scaled arithmetic) rather than k_dp_pair
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -865,6 +866,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         bool rs = !(ae && std::strcmp(ae, "cell") == 0) && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS;
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
             if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) rs = false;
+        b->pair_rs = rs;
         if (rs)
             for (int64_t k = 0; k < ntasks; ++k) {
                 if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
@@ -875,23 +877,30 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     }
     bool any_pair = false;
     {
-        // (k_dp_pair -- a per-cell-exponent kernel -- takes tasks of classes 0-2 only when asked to: NPR_PAIR=1 / all)
+        // By default a class of more than 256 tasks that fill at most half of the chip's wavefront slots goes to the pair kernel as a whole
+        // (BASELINE.json configs[1]: 1000 reads on 7168 slots -- DP 1.71 -> 1.42 ms); a fuller class does not (a 1/8 shard of
+        // configs[3], 6250 reads: 51 -> 59 ms with every read on two wavefronts, 67 with the longest ones only -- the second
+        // wavefronts then compete with the reads that have one).  NPR_PAIR=0: never; =1: the tasks longer than a
+        // wavefront's fair share; =all: every task.
         const char *pe = std::getenv("NPR_PAIR");
-        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = !pe || pe[0] == '0';
+        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = pe && pe[0] == '0', pair_long = pe && pe[0] == '1';
         if (!pair_off && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS)
             for (int c = 0; c < 3; ++c) {
                 std::vector<int32_t> mine;
                 int64_t cost = 0;
+                const int from = b->pair_rs ? kFirstRs + c : c;  // the one-wavefront class the tasks come from
                 for (int64_t k = 0; k < ntasks; ++k)
-                    if (cls_of[k] == c) mine.push_back(static_cast<int32_t>(k)), cost += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
+                    if (cls_of[k] == from) mine.push_back(static_cast<int32_t>(k)), cost += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
                 if (mine.empty()) continue;
-                const int64_t slots = static_cast<int64_t>(ctx->cu_count) * stair_waves_per_cu(kClassTab[c].R);
+                const int64_t slots = static_cast<int64_t>(ctx->cu_count) * (b->pair_rs ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R));
                 const int64_t n = static_cast<int64_t>(mine.size()), fair = cost / slots;
-                int64_t room = pair_all ? n : (n < slots ? slots - n : n);  // second wavefronts to be had
+                if (!pair_all && !pair_long && (2 * n > slots || n <= 256)) continue;  // (default rule: the class fills more than half of the chip, or is too small for it to matter)
+                const bool whole = pair_all || !pair_long;
+                int64_t room = whole ? n : (n < slots ? slots - n : n);  // second wavefronts to be had
                 std::sort(mine.begin(), mine.end(), [&](int32_t x, int32_t y) { return pseg[x].lX + pseg[x].lY > pseg[y].lX + pseg[y].lY; });
                 for (int32_t k : mine) {
                     const int64_t len = static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
-                    if (room <= 0 || (!pair_all && (len <= fair || len < 256))) break;
+                    if (room <= 0 || (!whole && (len <= fair || len < 256))) break;
                     cls_of[k] = static_cast<int8_t>(kFirstPair + c), --room, any_pair = true;
                 }
             }
@@ -1016,7 +1025,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         first += cls_count[c];
         int waves_per_cu;
         if (kClassTab[c].kind == K_PAIR) {  // workgroups of two wavefronts
-            waves_per_cu = stair_waves_per_cu(kClassTab[c].R) / 2;
+            waves_per_cu = (b->pair_rs ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R)) / 2;
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 128;
@@ -1269,7 +1278,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
-        const int rc = kc.kind == K_PAIR   ? launch_pair(a, kc.R, L.grid, s)
+        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_pair_rs(a, kc.R, L.grid, s) : launch_pair(a, kc.R, L.grid, s))
                        : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
@@ -1296,7 +1305,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     b->outs.resize(b->tasks.size());
     b->task_rerun.assign(b->tasks.size(), 0);
     for (const auto &L : b->launches) {
-        if (kClassTab[L.cls].kind != K_RS && kClassTab[L.cls].kind != K_TILE_RS) continue;
+        if (kClassTab[L.cls].kind != K_RS && kClassTab[L.cls].kind != K_TILE_RS && !(kClassTab[L.cls].kind == K_PAIR && b->pair_rs)) continue;
         HIP_TRY(ctx, hipMemcpy(b->outs.data() + L.first, b->d_outs.p + L.first, sizeof(TaskOut) * L.count, hipMemcpyDeviceToHost));
         std::vector<int32_t> again;
         for (int k = L.first; k < L.first + L.count; ++k)
@@ -1351,7 +1360,7 @@ int32_t npr_batch_segment_arith(const npr_batch *b, int64_t *seg_off, int32_t *a
     if (!b || !seg_off) return NPR_ERR_INVALID;
     std::vector<int8_t> of_task(b->tasks.size(), 0);
     for (const auto &L : b->launches)
-        if (kClassTab[L.cls].kind == K_RS)
+        if (kClassTab[L.cls].kind == K_RS || (kClassTab[L.cls].kind == K_PAIR && b->pair_rs))
             for (int k = L.first; k < L.first + L.count; ++k) of_task[k] = (static_cast<size_t>(k) < b->task_rerun.size() && b->task_rerun[k]) ? 0 : 1;
     int64_t n = 0;
     for (int64_t r = 0; r < b->n_reads; ++r) {

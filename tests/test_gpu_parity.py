@@ -322,3 +322,25 @@ def test_band_without_probability_is_reported_by_the_per_cell_kernel(gpu_ctx):
     assert out[0]["status"] == -2 and out[0]["seg_arith"] == [0]     # NPR_ERR_ZERO_PROB, said by k_dp_stair
     assert out[1]["status"] == 0 and out[1]["ops"] == [(0, 300)] and out[1]["seg_arith"] == [1]
     gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+
+
+def test_pair_kernel_in_row_scaled_arithmetic(gpu_ctx, monkeypatch):
+    """k_dp_pair_rs (a read's two sweeps on two wavefronts at once, the posteriors from the stored rows of both): what a class of
+    257+ tasks that fills at most half of the chip runs by default (BASELINE.json configs[1]); NPR_PAIR=all sends every
+    one-wavefront task there.  Same bits as the mirror of k_dp_rs, over the three frame classes, bands that drift (rebases), an
+    odd and an even number of anti-diagonals, single-base reads."""
+    monkeypatch.setenv("NPR_PAIR", "all")
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(61)
+    out = _run_case(gpu_ctx, rng, 24, 1, 400, dict(band_mode=1, fixed_width=40))
+    out += _run_case(gpu_ctx, rng, 8, 300, 1500, dict(band_mode=1, fixed_width=200), indel=0.2, max_indel=40)
+    out += _run_case(gpu_ctx, rng, 4, 400, 900, dict(band_mode=1, fixed_width=400), indel=0.2, max_indel=30)
+    # a read of a handful of bases can miss its range certificate (its start rows) and run again per cell: _run_case compared it
+    # with the per-cell mirror then
+    assert sum(o["seg_arith"] == [1] for o in out) >= len(out) - 2 and all(len(o["seg_arith"]) == 1 for o in out)
+    cases = [random_pair(rng, 300) for _ in range(5)]
+    b = gpu_ctx.stage(R.make_params(band_mode=1, fixed_width=40), [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases],
+                      [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases], [g for _, _, g in cases])
+    tasks, _ = b.class_stats()
+    b.close()
+    assert tasks[12] == 5 and tasks[15] == 0, tasks

@@ -38,7 +38,7 @@ print(json.dumps(out))
 for arg in sys.argv[1:]:
     tag, _, wpc = arg.partition(":")
     lib = os.path.join(ROOT, "nanopore_amd", "libnprealign.so" if tag == "default" else "libnprealign_%s.so" % tag)
-    env = dict(os.environ, NPR_LIB=lib)
+    env = dict(os.environ); env.setdefault("NPR_LIB", lib)
     if wpc:
         env["NPR_WAVES_PER_CU"] = wpc
     p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True)
