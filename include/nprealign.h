@@ -181,15 +181,17 @@ void npr_batch_destroy(npr_batch *b);
 
 int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
 /* Diagnostics: how the batch's DP problems (segments) were spread over the kernel classes.  tasks[c] / cells[c] for
- * class c (either may be NULL), capacity `cap` entries; returns the number of classes (15):
+ * class c (either may be NULL), capacity `cap` entries; returns the number of classes (19):
  *   0-2  register kernel, one wavefront per task, 64 / 128 / 256 slots (k_dp_stair<1|2|4>)
  *   3-6  register kernel, 4 / 8 / 8 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
  *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring
  *   11   register kernel on column stripes, any width (k_dp_tile; k_em_tile for npr_batch_expectations); takes what 3-10
  *        would take unless NPR_NO_TILE=1 is set
- *   12-14  classes 0-2 with the forward and the backward sweep of a task on two wavefronts at once (k_dp_pair<1|2|4>): the
- *        tasks of 0-2 that are longer than a wavefront's fair share of their class -- a launch lasts as long as its longest
- *        one-wavefront chain -- as far as second wavefronts are free; only when asked for (NPR_PAIR=1; =all: every task)
+ *   12-14  classes 0-2 / 15-17 with the forward and the backward sweep of a task on two wavefronts at once (k_dp_pair_rs<1|2|4>
+ *        in row-scaled arithmetic, k_dp_pair<1|2|4> under NPR_ARITH=cell): a launch lasts as long as its longest one-wavefront
+ *        chain, which this halves for a pass over twice the rows.  Every task of a class of more than 256 tasks that fills at
+ *        most half of the launch's wavefront slots (BASELINE.json configs[1]); NPR_PAIR=0: never, =all: every task, =1: the
+ *        tasks longer than a wavefront's fair share of their class as far as second wavefronts are free
  *   15-17  classes 0-2 in row-scaled arithmetic (k_dp_rs<1|2|4>: one exponent per anti-diagonal row of the wavefront instead of
  *        one per cell, about 1.4 times the cells per second): every task of 0-2 unless NPR_ARITH=cell is set or a loaded model's
  *        values can grow from one anti-diagonal to the next.  A task for which one exponent per row was not enough (a stretch of
@@ -199,7 +201,7 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* Which device arithmetic each segment (matrix split) of each read ran in, in read order: seg_off[n_reads + 1], arith[seg_off
  * [n_reads]] (pass arith == NULL for the offsets alone).  0: one exponent per cell (npr_cell.h: k_dp_tile, k_dp_generic, k_dp_wide
- * k_dp_stair / k_dp_pair); 1: one exponent per anti-diagonal row (npr_rs.h: k_dp_rs, classes 15-17).  Both are fp32 evaluations of the same recurrences (cactus_realign's forward / backward pass, reference call
+ * k_dp_stair / k_dp_pair); 1: one exponent per anti-diagonal row (npr_rs.h: k_dp_rs, k_dp_pair_rs; classes 15-17, 12-14).  Both are fp32 evaluations of the same recurrences (cactus_realign's forward / backward pass, reference call
  * site nanopore/analyses/utils.py:587) within the stated 1e-4 of the fp64 oracle; the parity tests ask so that they can
  * compare bit for bit with the matching CPU restatement (oracle/realign_oracle_f32.c / realign_oracle_rs.c). */
 int32_t npr_batch_segment_arith(const npr_batch *b, int64_t *seg_off, int32_t *arith, int64_t cap);
