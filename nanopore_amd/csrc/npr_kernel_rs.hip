@@ -146,11 +146,11 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         Q.e = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r] - 1);
+            Q.S.X.b[r] = base8<RS_XS>(E.X, lX, Q.x0 + jr[r] - 1);
             Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r] - 1);
         }
-        Q.S.xcap = Q.S.ycap = RS_N8;
-        feed8_init<+1>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);  // first X-step injects X[(x0 + 1) + 64R - 2]
+        Q.S.xcap = RS_NX, Q.S.ycap = RS_N8;
+        feed8_init<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);  // first X-step injects X[(x0 + 1) + 64R - 2]
         feed8_init<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);               // first Y-step injects Y[(y0 + 1) - 1]
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             cptr_i32 fexp_c = (cptr_i32)fexp;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r]);
+                Q.S.X.b[r] = base8<RS_XS>(E.X, lX, Q.x0 + jr[r]);
                 Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r]);
                 if (Q.x0 + jr[r] == lX) {  // the end corner (it is in the band by construction)
                     RCell c;
@@ -265,9 +265,9 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     if (oddD) Q.B.c[r] = c; else Q.A.c[r] = c;
                 }
             }
-            Q.S.xcap = Q.S.ycap = RS_N8;
+            Q.S.xcap = RS_NX, Q.S.ycap = RS_N8;
             // first undone X-step injects X[x0 - 1] at slot 0; first undone Y-step injects Y[y0 - 64R] on top
-            feed8_init<-1>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
+            feed8_init<-1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
             feed8_init<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
             RFRow<R> fa, fb;
 #pragma unroll
@@ -461,11 +461,11 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             Q.x0 = -j0, Q.y0 = j0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r] - 1);
+                Q.S.X.b[r] = base8<RS_XS>(E.X, lX, Q.x0 + jr[r] - 1);
                 Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r] - 1);
             }
-            Q.S.xcap = Q.S.ycap = RS_N8;
-            feed8_init<+1>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
+            Q.S.xcap = RS_NX, Q.S.ycap = RS_N8;
+            feed8_init<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
             feed8_init<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             uint32_t m1 = cur.moved, m2 = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                Q.S.X.b[r] = base8(E.X, lX, Q.x0 + jr[r]);
+                Q.S.X.b[r] = base8<RS_XS>(E.X, lX, Q.x0 + jr[r]);
                 Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r]);
                 if (Q.x0 + jr[r] == lX) {
                     RCell c;
@@ -534,8 +534,8 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                     if (oddD) Q.B.c[r] = c; else Q.A.c[r] = c;
                 }
             }
-            Q.S.xcap = Q.S.ycap = RS_N8;
-            feed8_init<-1>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
+            Q.S.xcap = RS_NX, Q.S.ycap = RS_N8;
+            feed8_init<-1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
             feed8_init<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
             if (lane == 0) bexp[(D + RS_K - 1) / RS_K] = 0;
             rs_store_row<R>(brs, oddD ? Q.B : Q.A, cur, voff);

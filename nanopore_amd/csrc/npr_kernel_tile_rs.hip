@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(WAVE *TRS_MAX_NW) __attribute__((amdgpu_waves_
             Bases<R> bx, by;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                bx.b[r] = base8(E.X, lX, st.X + jr[r] - 1);
+                bx.b[r] = base8<RS_XS>(E.X, lX, st.X + jr[r] - 1);
                 by.b[r] = base8(E.Y, lY, (st.df - 1) - st.X - jr[r] - 1);  // as of anti-diagonal df - 1
             }
             Feed fy;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(WAVE *TRS_MAX_NW) __attribute__((amdgpu_waves_
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float em, exs, exl, eys, eyl;
-                    rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? bx.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? by.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+                    rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? bx.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? by.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
                     o.c[r] = rs_fwd_cell(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : Q.carry, p1.c[r], em, exs, exl, eys, eyl);
                 }
                 io = o;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(WAVE *TRS_MAX_NW) __attribute__((amdgpu_waves_
                 Bases<R> bx, by;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    bx.b[r] = base8(E.X, lX, X0 + jr[r]);
+                    bx.b[r] = base8<RS_XS>(E.X, lX, X0 + jr[r]);
                     by.b[r] = base8(E.Y, lY, (st.dl + 1) - X0 - jr[r]);  // as of anti-diagonal dl + 1
                 }
                 Feed fy;
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(WAVE *TRS_MAX_NW) __attribute__((amdgpu_waves_
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         float em, exs, exl, eys, eyl;
-                        rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? bx.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? by.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+                        rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? bx.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? by.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
                         o.c[r] = rs_bwd_cell(E.tr, r + 1 < R ? io.c[r + 1] : Q.carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
                     }
                     io = o;

@@ -76,38 +76,43 @@ __device__ __forceinline__ RDiag<R> rs_shift_down(const RDiag<R> &in) {
 }
 
 // ---- base streams: codes pre-multiplied by 8 (byte offsets into the tables below); code 4 (N) = 32 ----
-constexpr int RS_N8 = 32;
+//      The read's codes (Y) by 8, the reference's (X) by 48 = 6 * 8: the match emission of (x, y) is then at byte offset bx + by of
+//      em8 -- one add per cell instead of a multiply and an add.
+constexpr int RS_YS = 8, RS_XS = 48;
+constexpr int RS_N8 = 4 * RS_YS, RS_NX = 4 * RS_XS;
+template <int S = RS_YS>
 __device__ __forceinline__ int base8(const uint8_t *seq, int len, int idx) {
-    return (idx >= 0 && idx < len) ? 8 * static_cast<int>(seq[idx]) : RS_N8;
+    return (idx >= 0 && idx < len) ? S * static_cast<int>(seq[idx]) : 4 * S;
 }
-template <int DIR>
+template <int DIR, int S = RS_YS>
 __device__ __forceinline__ void feed8_init(Feed &f, const uint8_t *seq, int len, int first, int lane) {
     f.base = first;
-    f.cur = base8(seq, len, first + DIR * lane);
-    f.nxt = base8(seq, len, first + DIR * (64 + lane));
+    f.cur = base8<S>(seq, len, first + DIR * lane);
+    f.nxt = base8<S>(seq, len, first + DIR * (64 + lane));
 }
-template <int DIR>
+template <int DIR, int S = RS_YS>
 __device__ __forceinline__ int feed8_get(Feed &f, const uint8_t *seq, int len, int idx, int lane) {
     int off = uni(DIR * (idx - f.base));
     if (off >= 64) {  // uniform
         f.cur = f.nxt;
         f.base += DIR * 64;
-        f.nxt = base8(seq, len, f.base + DIR * (64 + lane));
+        f.nxt = base8<S>(seq, len, f.base + DIR * (64 + lane));
         off -= 64;
     }
     return __builtin_amdgcn_readlane(f.cur, off);
 }
 
 // ---- emission tables in LDS, laid out for byte offsets that are base codes * 8 ----
-//   em8[6x + y] (8-byte stride: byte offset 6 * bx + by), ex2[x] = (shortGapX, longGapX), ey2[y] = (shortGapY, longGapY)
-//   Code 5 (byte offset 40, RS_DEAD8) is the base of a slot OUTSIDE the band: all its emissions are 0, so every state of the cell
+//   em8[6x + y] (8-byte stride: byte offset bx + by), ex2[x] = (shortGapX, longGapX) at byte offset bx (48-byte stride),
+//   ey2[y] = (shortGapY, longGapY) at byte offset by
+//   Code 5 (byte offsets RS_DEAD8 / RS_DEADX) is the base of a slot OUTSIDE the band: all its emissions are 0, so every state of the cell
 //   computed there is an exact zero (two selects per cell instead of an EXEC-mask region per cell row and the clearing of what the band left behind; NPR_RS_DEADCODE_MAX_R).
 struct RsTables {
     float em8[36][2];  // [6 x + y]
-    float ex2[6][2];
+    float ex2[6][RS_XS / 4];  // [x][0 .. 1]
     float ey2[6][2];
 };
-constexpr int RS_DEAD8 = 40;
+constexpr int RS_DEAD8 = 5 * RS_YS, RS_DEADX = 5 * RS_XS;
 #ifndef NPR_RS_DEADCODE_MAX_R
 #define NPR_RS_DEADCODE_MAX_R 1  // slots per lane up to which it is used: one cell per lane gains 4 % (config 2: 1.75 -> 1.69 ms), two lose 1 %
 #endif
@@ -124,7 +129,7 @@ __device__ __forceinline__ void rs_build_tables(RsTables *t, const DevModel *m, 
 }
 __device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
     constexpr int OFF_EX = offsetof(RsTables, ex2), OFF_EY = offsetof(RsTables, ey2);
-    em = *reinterpret_cast<const float *>(tab + (__umul24(static_cast<unsigned>(bx), 6u) + static_cast<unsigned>(by)));
+    em = *reinterpret_cast<const float *>(tab + (bx + by));
     const float2 ex = *reinterpret_cast<const float2 *>(tab + OFF_EX + bx);
     const float2 ey = *reinterpret_cast<const float2 *>(tab + OFF_EY + by);
     exs = ex.x, exl = ex.y, eys = ey.x, eyl = ey.y;
@@ -387,6 +392,66 @@ __device__ __forceinline__ void rs_rebase_streams_bwd(Bases<4> &X, Bases<4> &Y, 
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
+__device__ __forceinline__ void rs_rebase_all_fwd(RDiag<1> &P, RDiag<1> &Q, Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %13, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %13, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %18, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %12, %14, %18\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %12, %18, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %15, %12\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %10, %12, 63\n\tv_writelane_b32 %11, %21, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %19, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %12, %16, %19\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %12, %19, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %17, %12\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %11, %12, 0\n\tv_writelane_b32 %10, %20, 0\n\t"
+                 "2:"
+                 : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly), "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_all_bwd(RDiag<1> &P, RDiag<1> &Q, Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %13, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %13, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %19, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %12, %16, %19\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %12, %19, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %17, %12\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %11, %12, 63\n\tv_writelane_b32 %10, %20, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %18, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %12, %14, %18\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %12, %18, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %15, %12\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %10, %12, 0\n\tv_writelane_b32 %11, %21, 0\n\t"
+                 "2:"
+                 : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly), "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_all_fwd(RDiag<2> &P, RDiag<2> &Q, Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %25, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %25, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\tv_swap_b32 %20, %21\n\tv_swap_b32 %22, %23\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %21, %21 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %23, %23 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %30, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %24, %26, %30\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %24, %30, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %27, %24\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %21, %24, 63\n\tv_writelane_b32 %23, %33, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %21, %20\n\tv_swap_b32 %23, %22\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %20, %20 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %22, %22 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %31, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %24, %28, %31\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %24, %31, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %29, %24\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %22, %24, 0\n\tv_writelane_b32 %20, %32, 0\n\t"
+                 "2:"
+                 : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly), "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
+__device__ __forceinline__ void rs_rebase_all_bwd(RDiag<2> &P, RDiag<2> &Q, Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
+    int tmp;
+    asm volatile("s_cmp_eq_u32 %25, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_i32 %25, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\tv_swap_b32 %20, %21\n\tv_swap_b32 %22, %23\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %21, %21 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %23, %23 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %31, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %24, %28, %31\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %24, %31, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %29, %24\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %23, %24, 63\n\tv_writelane_b32 %21, %32, 63\n\t"
+                 "s_branch 2f\n\t"
+                 "1:\n\t"
+                 "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %21, %20\n\tv_swap_b32 %23, %22\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %20, %20 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %22, %22 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %30, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %24, %26, %30\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %24, %30, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %27, %24\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %20, %24, 0\n\tv_writelane_b32 %22, %33, 0\n\t"
+                 "2:"
+                 : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly), "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
+                 : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
+                 : "scc");
+}
 // ---- end of generated code ----
 
 // ... and the scalar side of it: the frame's origin moves by one lattice point
@@ -400,6 +465,9 @@ __device__ __forceinline__ void rs_rebase_origin(int &x0, int &y0, int dir) {
     x0 = xs, y0 = ys;
 }
 
+#ifndef NPR_RS_ONE_REBASE_MAX_R
+#define NPR_RS_ONE_REBASE_MAX_R 2  // slots per lane up to which rows and streams rebase in ONE asm statement (rs_rebase_all_*)
+#endif
 // A sweep's register state: the even anti-diagonals in A, the odd ones in B, the base streams and the rows' common exponent.
 template <int R>
 struct RsState {
@@ -418,9 +486,14 @@ __device__ __forceinline__ void rs_fwd_rebase(const StepEnv &E, int r, RsState<R
     const int dir = uni(r);
     const int offX = uni((Q.x0 + 64 * R - 1) - Q.S.fx.base);  // up: the X stream takes in X[(x0 + 1) + 64R - 2]
     const int offY = uni(Q.y0 - Q.S.fy.base);                  // down: the Y stream takes in Y[(y0 + 1) - 1]
-    rs_rebase_streams_fwd(Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
-    rs_rebase_origin(Q.x0, Q.y0, dir);
-    rs_rebase_rows(Q.A, Q.B, dir);
+    if constexpr (R <= NPR_RS_ONE_REBASE_MAX_R) {  // rows and streams in one statement: one skip test per anti-diagonal
+        rs_rebase_all_fwd(Q.A, Q.B, Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
+        rs_rebase_origin(Q.x0, Q.y0, dir);
+    } else {
+        rs_rebase_streams_fwd(Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
+        rs_rebase_origin(Q.x0, Q.y0, dir);
+        rs_rebase_rows(Q.A, Q.B, dir);
+    }
 }
 // ... and of the backward sweep, which undoes the forward one: r is the forward rebase being undone.
 template <int R>
@@ -428,9 +501,14 @@ __device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R
     const int dir = uni(-r);
     const int offX = uni(Q.S.fx.base - (Q.x0 - 1));        // down (r > 0): the X stream takes in X[x0 - 1] at slot 0
     const int offY = uni(Q.S.fy.base - (Q.y0 - 64 * R));   // up (r < 0): the Y stream takes in Y[(y0 - 1) - (64R - 1)] on top
-    rs_rebase_streams_bwd(Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
-    rs_rebase_origin(Q.x0, Q.y0, dir);
-    rs_rebase_rows(Q.A, Q.B, dir);
+    if constexpr (R <= NPR_RS_ONE_REBASE_MAX_R) {
+        rs_rebase_all_bwd(Q.A, Q.B, Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
+        rs_rebase_origin(Q.x0, Q.y0, dir);
+    } else {
+        rs_rebase_streams_bwd(Q.S.X, Q.S.Y, Q.S.fx, Q.S.fy, dir, offX, offY, uni(Q.S.xcap), uni(Q.S.ycap));
+        rs_rebase_origin(Q.x0, Q.y0, dir);
+        rs_rebase_rows(Q.A, Q.B, dir);
+    }
 }
 
 // The new row replaces the one two anti-diagonals away, under the band's lane mask (the arithmetic itself runs under the
@@ -457,14 +535,14 @@ __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, co
                                               const Masks<R> &mk, uint32_t moved) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     x0 += 1;
-    bases_up<R>(S.X, feed8_get<+1>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
+    bases_up<R>(S.X, feed8_get<+1, RS_XS>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
     const RDiag<R> U = rs_shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
             o.c[r] = rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
@@ -486,7 +564,7 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, co
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
             o.c[r] = rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
@@ -502,14 +580,14 @@ __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, co
                                               const Masks<R> &mk, uint32_t moved) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     x0 -= 1;
-    bases_down<R>(S.X, feed8_get<-1>(S.fx, E.X, E.lX, x0, E.lane));
+    bases_down<R>(S.X, feed8_get<-1, RS_XS>(S.fx, E.X, E.lX, x0, E.lane));
     const RDiag<R> Ys = rs_shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
             o.c[r] = rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
@@ -531,7 +609,7 @@ __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, co
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEAD8, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
             o.c[r] = rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);

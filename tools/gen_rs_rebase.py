@@ -84,10 +84,55 @@ def streams(R, fwd):
     return out
 
 
+def merged(R, fwd):
+    """rows + streams of one rebase in ONE statement (R <= 2: 10R + 2R tied registers): one skip test per anti-diagonal instead of two."""
+    k, groups, ops = 0, [], []
+    for row in ("P", "Q"):
+        for st in ("m", "sx", "sy", "lx", "ly"):
+            g = []
+            for r in range(R):
+                g.append("%%%d" % k)
+                k += 1
+                ops.append('"+v"(%s.c[%d].%s)' % (row, r, st))
+            groups.append(g)
+    X = ["%%%d" % (k + i) for i in range(R)]; k += R
+    Y = ["%%%d" % (k + i) for i in range(R)]; k += R
+    ops += ['"+v"(X.b[%d])' % i for i in range(R)] + ['"+v"(Y.b[%d])' % i for i in range(R)] + ['"=&s"(tmp)']
+    tmp = "%%%d" % k; k += 1
+    d, fxc, fxn, fyc, fyn, ox, oy, xcap, ycap = ("%%%d" % (k + i) for i in range(9))
+    def feed_read(cur, nxt, off):
+        return ("s_cmp_lt_i32 %s, 64\\n\\ts_cbranch_scc0 3f\\n\\ts_nop 3\\n\\tv_readlane_b32 %s, %s, %s\\n\\ts_branch 4f\\n\\t3:\\n\\t"
+                "s_sub_i32 %s, %s, 64\\n\\ts_nop 3\\n\\tv_readlane_b32 %s, %s, %s\\n\\t4:\\n\\t" % (off, tmp, cur, off, tmp, off, tmp, nxt, tmp))
+    def body(up):
+        x_from_feed = (fwd and up) or (not fwd and not up)
+        s = "".join(rot(g, R, up) for g in groups) + rot(X, R, up) + rot(Y, R, up) + "s_nop 1\\n\\t"
+        for g in groups:
+            s += dpp(g[R - 1] if up else g[0], "shl" if up else "shr", True)
+        xr, yr = (X[R - 1], Y[R - 1]) if up else (X[0], Y[0])
+        lane = 63 if up else 0
+        s += dpp(xr, "shl" if up else "shr", False) + dpp(yr, "shl" if up else "shr", False)
+        if x_from_feed:
+            s += feed_read(fxc, fxn, ox) + "s_nop 3\\n\\tv_writelane_b32 %s, %s, %d\\n\\tv_writelane_b32 %s, %s, %d\\n\\t" % (xr, tmp, lane, yr, ycap, lane)
+        else:
+            s += feed_read(fyc, fyn, oy) + "s_nop 3\\n\\tv_writelane_b32 %s, %s, %d\\n\\tv_writelane_b32 %s, %s, %d\\n\\t" % (yr, tmp, lane, xr, xcap, lane)
+        return s
+    up_b = body(True).replace("3f", "31f").replace("3:", "31:").replace("4f", "41f").replace("4:", "41:")
+    dn_b = body(False).replace("3f", "32f").replace("3:", "32:").replace("4f", "42f").replace("4:", "42:")
+    ins = ['"s"(dir)', '"v"(fx.cur)', '"v"(fx.nxt)', '"v"(fy.cur)', '"v"(fy.nxt)', '"s"(offX)', '"s"(offY)', '"s"(xcap)', '"s"(ycap)']
+    out = "__device__ __forceinline__ void rs_rebase_all_%s(RDiag<%d> &P, RDiag<%d> &Q, Bases<%d> &X, Bases<%d> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {\n" % ("fwd" if fwd else "bwd", R, R, R, R)
+    out += "    int tmp;\n"
+    out += '    asm volatile("s_cmp_eq_u32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 2f\\n\\t"\n                 "s_cmp_lt_i32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 1f\\n\\t"\n' % (d, d)
+    out += '                 "%s"\n                 "s_branch 2f\\n\\t"\n                 "1:\\n\\t"\n                 "%s"\n                 "2:"\n' % (up_b, dn_b)
+    out += '                 : %s\n                 : %s\n                 : "scc");\n}\n' % (", ".join(ops), ", ".join(ins))
+    return out
+
+
 if __name__ == "__main__":
     print("// ---- generated by tools/gen_rs_rebase.py ----")
     print(rows(1, 2) + rows(2, 2) + rows(4, 1), end="")
     print("__device__ __forceinline__ void rs_rebase_rows(RDiag<4> &P, RDiag<4> &Q, int dir) { rs_rebase_rows(P, dir), rs_rebase_rows(Q, dir); }")
     for R in (1, 2, 4):
         print(streams(R, True) + streams(R, False), end="")
+    for R in (1, 2):
+        print(merged(R, True) + merged(R, False), end="")
     print("// ---- end of generated code ----")
