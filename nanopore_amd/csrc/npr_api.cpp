@@ -797,7 +797,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     const bool use_tile = !force_generic && !(notile_env && notile_env[0] == '1');  // (E-step batches too: k_em_tile)
     std::vector<uint32_t> cand(ntasks, 0);
     std::vector<int64_t> sched_off(ntasks, -1);
-    int64_t ctl_entries = 0;
+    // (the first task's words start kCtlFrontPad rows into d_ctl: the backward sweep of k_dp_rs reads its control words up to
+    // three rows below the one it is on, row 0 included, without a clamp)
+    constexpr int64_t kCtlFrontPad = 4;
+    int64_t ctl_entries = kCtlFrontPad;
     for (int64_t k = 0; k < ntasks; ++k) {
         if (force_generic) break;
         for (int c = cmin; c < kSchedClasses; ++c) {
@@ -811,7 +814,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     std::vector<int64_t> sched_cells(ntasks, 0);
     if ((e = b->d_ctl.alloc_from(ctx, 2 * ctl_entries + 8)) != hipSuccess)  // (+8: k_dp_rs reads its control words two rows ahead)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
-    if (ctl_entries) {
+    if (ctl_entries > kCtlFrontPad) {
         DevBuf<uint32_t> d_cand;
         DevBuf<int64_t> d_off, d_cells;
         DevBuf<int32_t> d_cls;

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
     while (t < a.ntasks) {
         const Task *tp = a.tasks + t;
         const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off), pair_off = uni64(tp->pair_off);
-        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap), flags = uni(tp->flags),
+        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = min(uni(tp->pair_cap), (1 << 29) - 1) /* (pair slots are 32-bit byte offsets) */, flags = uni(tp->flags),
                   model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
         const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(uni(tp->cells_pad))));
         int *const fexp = reinterpret_cast<int *>(F + 4 * half);
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         int smax = -(1 << 30);  // the largest eF + eB - eTot of any anti-diagonal: the range certificate (npr_device.h)
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
-            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            const PairSink sink{a.px + pair_off, a.py + pair_off, a.pp + pair_off, 0, pair_cap, xs, ys, a.threshold};  // (32-bit slots from here)
             // A holds the even anti-diagonals again, B the odd ones; fa / fb the forward rows that pair with them, loaded one
             // anti-diagonal ahead.  S now holds X[x]*8 and Y[y]*8 of every slot.  Q.e: the backward rows' exponent.
             Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
@@ -303,7 +303,13 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 d2 -= 1;
             }
 #if NPR_RS_CTL == 2
-            CtlPair wb = ctl_scalar2(ctl, max(d2 - 2, 0));  // {d2 - 2, d2 - 1}
+            // rows {d2 - 2, d2 - 1}, then two rows further down every iteration: down to row -3 of the task (d2 = 1), which lies in the
+            // previous task's words or d_ctl's front padding (npr_api.cpp kCtlFrontPad) and is never looked at
+#ifdef NPR_RS_CTL_CLAMP
+            CtlPair wb = ctl_scalar2(ctl, max(d2 - 2, 0));
+#else
+            CtlPair wb = ctl_scalar2(ctl, d2 - 2);
+#endif
 #endif
             int ef_next = fexp_c[max(d2, 0) / RS_K];
             for (; d2 >= 1; d2 -= 2) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
@@ -311,12 +317,20 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 const CtlPair w = ctl_get2<-1>(cb, gw, D, d2 - 1, lane);  // the words of d2 - 1 and d2 - 2
 #else
 #if NPR_RS_CTL == 1
-                const CtlPair q = ctl_scalar2(ctl, max(d2 - 2, 0));
+                const CtlPair q = ctl_scalar2(ctl, d2 - 2);
 #else
                 const CtlPair q = wb;
+#ifdef NPR_RS_CTL_CLAMP
                 wb = ctl_scalar2(ctl, max(d2 - 4, 0));
+#else
+                wb = ctl_scalar2(ctl, d2 - 4);
 #endif
-                const CtlPair w = d2 >= 2 ? CtlPair{q.b0, q.b1, q.a0, q.a1} : CtlPair{q.a0, q.a1, 0u, 0u};  // d2 = 1: rows {0, 1} were read
+#endif
+#ifdef NPR_RS_CTL_CLAMP
+                const CtlPair w = d2 >= 2 ? CtlPair{q.b0, q.b1, q.a0, q.a1} : CtlPair{q.a0, q.a1, 0u, 0u};
+#else
+                const CtlPair w{q.b0, q.b1, q.a0, q.a1};  // (d2 = 1: the words of row -1 go unused)
+#endif
 #endif
                 int reb = cur.reb;
                 cur = nxt;
@@ -326,7 +340,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 rs_bwd_y_step<R>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 const int ef = ef_next;  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
-                ef_next = fexp_c[max(d2 - 2, 0) / RS_K];
+                ef_next = fexp_c[(d2 - 2) >> __builtin_ctz(RS_K)];  // (d2 = 1: the word before the exponents, a forward cell; not used)
                 rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
                 reb = cur.reb;
                 cur = nxt;
@@ -404,7 +418,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
     while (t < a.ntasks) {
         const Task *tp = a.tasks + t;
         const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off), pair_off = uni64(tp->pair_off);
-        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap), flags = uni(tp->flags),
+        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = min(uni(tp->pair_cap), (1 << 29) - 1) /* (pair slots are 32-bit byte offsets) */, flags = uni(tp->flags),
                   model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
         const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(uni(tp->cells_pad))));
         char *const Bs = F + 8 * half;  // the backward sweep's half of the region
@@ -608,7 +622,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
         int smax = -(1 << 30);
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
-            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            const PairSink sink{a.px + pair_off, a.py + pair_off, a.pp + pair_off, 0, pair_cap, xs, ys, a.threshold};  // (32-bit slots from here)
             constexpr int G = R == 1 ? 8 : 4;
             const int mid = D / 2;  // wavefront 0: d = 0 .. mid walking up from (0, 0); wavefront 1: d = D .. mid + 1 walking down
             const int first = wv == 0 ? 0 : D, dir = wv == 0 ? 1 : -1, count = wv == 0 ? mid + 1 : D - mid;
@@ -714,9 +728,10 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                                                                                  __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[g][r]), 0));
                                     const int slot = slot0 + before;
                                     if (lanes_of(hit[g][r]) && slot < sink.cap) {
-                                        sink.px[sink.off + slot] = x0 + jr[r] - 1 + sink.xs;
-                                        sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
-                                        sink.pp[sink.off + slot] = p[g][r];
+                                        const uint32_t u = static_cast<uint32_t>(slot) << 2;
+                                        rs_at<int32_t>(sink.px, u) = x0 + jr[r] - 1 + sink.xs;
+                                        rs_at<int32_t>(sink.py, u) = y0 - jr[r] - 1 + sink.ys;
+                                        rs_at<float>(sink.pp, u) = p[g][r];
                                     }
                                     slot0 += __popcll(hit[g][r]);
                                 }

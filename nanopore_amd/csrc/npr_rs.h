@@ -663,6 +663,8 @@ __device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> 
 // posteriors of one anti-diagonal: F * (B * 2^s) / totMant with s = eF + eB - eTot, wave-uniform.  F and B each span fp32's
 // whole range, so their product may not be formed first; B * 2^s stays below 2^(RS_TOP + 6 + s), far from overflow while s
 // is below NPR_RS_S_LIMIT -- and a task with a row above the limit is run again anyway (npr_device.h).
+template <typename T>
+__device__ __forceinline__ T &rs_at(T *base, uint32_t byte_off) { return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off); }
 __device__ __forceinline__ float rs_posterior(float f, float b, int s, float inv_tot) { return (f * __builtin_ldexpf(b, s)) * inv_tot; }
 template <int R>
 __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> &B, const RFRow<R> &f, int d, int x0, int y0, const Masks<R> &mk,
@@ -682,10 +684,15 @@ __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> 
                 const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
                 const int slot = cnt + before;
-                if (lanes_of(hit[r]) && slot < S.cap) {
-                    S.px[S.off + slot] = x0 + jr[r] - 1 + S.xs;
-                    S.py[S.off + slot] = y0 - jr[r] - 1 + S.ys;
-                    S.pp[S.off + slot] = p[r];
+                if (lanes_of(hit[r]) && slot < S.cap) {  // (S.off is 0: the sink's pointers are the task's; unsigned slots: scalar base + 32-bit offset)
+#ifdef NPR_RS_PAIR64
+                    S.px[slot] = x0 + jr[r] - 1 + S.xs, S.py[slot] = y0 - jr[r] - 1 + S.ys, S.pp[slot] = p[r];
+#else
+                    const uint32_t u = static_cast<uint32_t>(slot) << 2;  // a byte offset that fits 32 bits (pair_cap < 2^29): one shift, the arrays' addresses stay scalar
+                    rs_at<int32_t>(S.px, u) = x0 + jr[r] - 1 + S.xs;
+                    rs_at<int32_t>(S.py, u) = y0 - jr[r] - 1 + S.ys;
+                    rs_at<float>(S.pp, u) = p[r];
+#endif
                 }
                 cnt += __popcll(hit[r]);
             }

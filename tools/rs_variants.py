@@ -16,13 +16,15 @@ from nanopore_amd.hmm import Hmm
 h = Hmm.loadHmm(os.path.join(%(root)r, "nanopore_amd", "mappers", "blasr_hmm_0.txt"))
 ctx = R.Context(0); ctx.set_hmm(h)
 out = {}
-w, W = synth.config_north_star(h.transitions, h.emissions, n_reads=12288, seed=1003)
+w, W = synth.config_north_star(h.transitions, h.emissions, n_reads=int(os.environ.get("RS_NS_READS", "12288")), seed=1003)
 b = ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"], guide_start=w.get("guide_start"))
 ms = [b.run() for _ in range(5)]
 b.finish(); res = b.results()
 out["ns_ms"] = round(min(ms[1:]), 2); out["ns_cells_per_s"] = "%%.3e" %% (b.stats()["cells"] / min(ms[1:]) * 1e3); out["ok"] = int((res["status"] == 0).sum())
 out["score"] = float(res["score"].mean())
 b.close()
+if os.environ.get("RS_ONLY") == "ns":
+    print(json.dumps(out)); sys.exit(0)
 w = synth.make_workload(77, 49152, 2500, h.transitions, h.emissions, flank=0)
 b = ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=200), w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
 ms = [b.run() for _ in range(4)]
