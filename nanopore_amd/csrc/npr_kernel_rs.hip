@@ -9,6 +9,7 @@
 // forward scratch.  The kernel for every band a wavefront's frame can hold (classes 0-2: NPR_ARITH=cell brings the
 // per-cell-exponent kernels back for A/B runs).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "npr_device.h"
 #include "npr_frame.h"
@@ -77,6 +78,9 @@ __device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
     cptr32 e = ctl + 2 * static_cast<int64_t>(d);
     return CtlPair{e[0], e[1], e[2], e[3]};
 }
+#ifndef NPR_RS_BLOCK
+#define NPR_RS_BLOCK 1  // the sweeps of k_dp_rs in blocks of RS_K anti-diagonals: stream refills and renormalisation outside the steps
+#endif
 #ifndef NPR_RS_WAVES2
 #define NPR_RS_WAVES2 6  // wavefronts per SIMD the R = 2 kernel is compiled for: 79 VGPRs, two spilled (82 and 5 per SIMD without: 3 % slower)
 #endif
@@ -166,6 +170,43 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 #if NPR_RS_CTL == 2
         CtlPair wn = ctl_scalar2(ctl, 1);  // (two words past the task's last row at most: still inside d_ctl or its padding)
 #endif
+#if NPR_RS_BLOCK
+        {
+            // Blocks of RS_K anti-diagonals, d = 1 (mod RS_K) at the head of each: the base streams are looked after once per block
+            // (feed8_ahead) and the renormalisation needs no test -- it belongs to the block's last pair.  The pairs of a block are
+            // one loop body, the last pair a second one; the rows after the last full block run through the first.
+            auto pair = [&](auto last) __attribute__((always_inline)) {
+                const CtlPair w = wn;
+                wn = ctl_scalar2(ctl, d + 2);
+                {
+                    const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
+                    RS_FWD_REBASE(cur.reb);
+                    rs_fwd_x_step<R, false>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                    rs_store_row<R>(frs, Q.B, cur, voff);
+                }
+                const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
+                RS_FWD_REBASE(cur.reb);
+                rs_fwd_y_step<R, false>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
+                if constexpr (decltype(last)::value) {
+                    Q.e += rs_renorm<R>(Q.A, Q.B);
+                    if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
+                }
+                rs_store_row<R>(frs, Q.A, cur, voff);
+                d += 2;
+            };
+            while (d + RS_K - 1 <= D) {
+                feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
+                feed8_ahead<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
+#pragma nounroll
+                for (int k = 0; k < RS_K / 2 - 1; ++k) pair(std::false_type{});
+                pair(std::true_type{});
+            }
+            feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
+            feed8_ahead<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
+#pragma nounroll
+            while (d + 1 <= D) pair(std::false_type{});
+        }
+#else
         for (; d + 1 <= D; d += 2) {
 #if NPR_RS_CTL == 0
             const CtlPair w = ctl_get2<+1>(cf, gw, D, d, lane);
@@ -190,6 +231,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             }
             rs_store_row<R>(frs, Q.A, cur, voff);
         }
+#endif
         if (d <= D) {  // D odd: one more X-step, into B
 #if NPR_RS_CTL == 0
             const CtlPair w = ctl_get2<+1>(cf, gw, D, d, lane);
@@ -302,6 +344,52 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_c[d2 / RS_K] + Q.e - tot_e), inv_tot, jr, cnt);
                 d2 -= 1;
             }
+#if NPR_RS_BLOCK
+            {
+                // Blocks that end on a renormalising row: the pairs (d2, d2 - 1) from d2 down to RS_K m + 1 with m = d2 / RS_K; the rows of a
+                // block share the forward exponent fexp[m]; the last pair ends on row RS_K m, renormalises there and is a loop body of its
+                // own.  (The first block is as long as it takes to get there; the control words are read down to row -3: kCtlFrontPad.)
+                CtlPair wb = ctl_scalar2(ctl, d2 - 2);
+                int ef = 0, sblk = 0;
+                auto pair = [&](auto last) __attribute__((always_inline)) {
+                    const CtlPair q = wb;
+                    wb = ctl_scalar2(ctl, d2 - 4);
+                    int reb = cur.reb;
+                    cur = nxt;
+                    nxt = row_ctl_of_words<R>(q.b0, q.b1);
+                    rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
+                    RS_BWD_REBASE(reb);
+                    rs_bwd_y_step<R, false>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                    m2 = m1, m1 = cur.moved;
+                    rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
+                    reb = cur.reb;
+                    cur = nxt;
+                    if (!decltype(last)::value || d2 >= 2) {
+                        nxt = row_ctl_of_words<R>(q.a0, q.a1);
+                        rs_load_row<R>(frs, fb, nxt, voff);
+                    }
+                    RS_BWD_REBASE(reb);
+                    rs_bwd_x_step<R, false>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                    m2 = m1, m1 = cur.moved;
+                    if constexpr (decltype(last)::value) {
+                        Q.e += rs_renorm<R>(Q.A, Q.B);
+                        sblk = note_s(smax, ef + Q.e - tot_e);
+                    }
+                    rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
+                    d2 -= 2;
+                };
+                while (d2 >= 1) {
+                    ef = fexp_c[d2 / RS_K];
+                    sblk = note_s(smax, ef + Q.e - tot_e);
+                    feed8_ahead<-1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
+                    feed8_ahead<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
+                    const int n = (d2 & (RS_K - 1)) >> 1;
+#pragma nounroll
+                    for (int k = 0; k < n; ++k) pair(std::false_type{});
+                    pair(std::true_type{});
+                }
+            }
+#else
 #if NPR_RS_CTL == 2
             // rows {d2 - 2, d2 - 1}, then two rows further down every iteration: down to row -3 of the task (d2 = 1), which lies in the
             // previous task's words or d_ctl's front padding (npr_api.cpp kCtlFrontPad) and is never looked at
@@ -354,6 +442,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 if (((d2 - 1) & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
             }
+#endif
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll
             for (int r = 0; r < R; ++r)

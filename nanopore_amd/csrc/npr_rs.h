@@ -101,6 +101,25 @@ __device__ __forceinline__ int feed8_get(Feed &f, const uint8_t *seq, int len, i
     }
     return __builtin_amdgcn_readlane(f.cur, off);
 }
+// ... and for the sweeps that run in blocks of RS_K anti-diagonals (NPR_RS_BLOCK): the window is looked after once per block --
+// brought to where every base the block can ask for lies in `cur` -- and the steps read it without a test.  A block moves a stream's
+// index by at most RS_K / 2 own steps + RS_K rebases (and the rebase statements look one base further, into `nxt` if need be).
+constexpr int RS_FEED_BACK = 4;                               // bases kept behind the index (a frame that steps back; today's refill keeps none)
+constexpr int RS_FEED_MAX0 = 63 - (RS_K / 2 + RS_K) + 1;      // largest offset a block may start with
+template <int DIR, int S = RS_YS>
+__device__ __forceinline__ void feed8_ahead(Feed &f, const uint8_t *seq, int len, int idx, int lane) {
+    const int off = uni(DIR * (idx - f.base));
+    if (off > RS_FEED_MAX0 || off < 0) {  // uniform
+        f.base = idx - DIR * RS_FEED_BACK;
+        f.cur = base8<S>(seq, len, f.base + DIR * lane);
+        f.nxt = base8<S>(seq, len, f.base + DIR * (64 + lane));
+    }
+}
+template <int DIR, int S = RS_YS, bool CHK = true>
+__device__ __forceinline__ int feed8_take(Feed &f, const uint8_t *seq, int len, int idx, int lane) {
+    if constexpr (CHK) return feed8_get<DIR, S>(f, seq, len, idx, lane);
+    else return __builtin_amdgcn_readlane(f.cur, uni(DIR * (idx - f.base)));
+}
 
 // ---- emission tables in LDS, laid out for byte offsets that are base codes * 8 ----
 //   em8[6x + y] (8-byte stride: byte offset bx + by), ex2[x] = (shortGapX, longGapX) at byte offset bx (48-byte stride),
@@ -207,22 +226,24 @@ __device__ __forceinline__ float rs_dot5(const float *w, const RCell &c) {
 // ---- renormalisation of the two held rows ----
 __device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    // row_shr:1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast:15 / :31 across them: lane 63 ends with the maximum
-    // (a lane without a valid source keeps its own value: `old` = v)
-    const int s = static_cast<int>(v);
-    int t = __builtin_amdgcn_update_dpp(s, s, 0x111, 0xf, 0xf, false);
-    int w = static_cast<int>(max(static_cast<uint32_t>(s), static_cast<uint32_t>(t)));
-    t = __builtin_amdgcn_update_dpp(w, w, 0x112, 0xf, 0xf, false);
-    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
-    t = __builtin_amdgcn_update_dpp(w, w, 0x114, 0xf, 0xf, false);
-    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
-    t = __builtin_amdgcn_update_dpp(w, w, 0x118, 0xf, 0xf, false);
-    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
-    t = __builtin_amdgcn_update_dpp(w, w, 0x142, 0xa, 0xf, false);
-    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
-    t = __builtin_amdgcn_update_dpp(w, w, 0x143, 0xc, 0xf, false);
-    w = static_cast<int>(max(static_cast<uint32_t>(w), static_cast<uint32_t>(t)));
-    return static_cast<uint32_t>(__builtin_amdgcn_readlane(w, 63));
+    // row_shr:1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast:15 / :31 across them: lane 63 ends with the maximum.  The DPP
+    // operand sits on the maximum itself (a lane without a valid source reads 0, the identity); written as assembly because the
+    // compiler expands update_dpp + max into three instructions per stage.  (s_nop: DPP read of a VGPR the previous VALU wrote.)
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(v));
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 __device__ __forceinline__ uint32_t rcell_max_bits(const RCell &c) {
     return umax3(umax3(static_cast<uint32_t>(fbits(c.m)), static_cast<uint32_t>(fbits(c.sx)), static_cast<uint32_t>(fbits(c.sy))),
@@ -244,8 +265,9 @@ __device__ __forceinline__ int rs_renorm(RDiag<R> &P, RDiag<R> &Q) {
     const uint32_t top = wave_max_u32(u);
     const int eb = static_cast<int>(top >> 23);
     if (eb == 0) return 0;
-    const int k = min(max(RS_TOP + 126 - eb, -126), 127);
-    const float f = bitsf((k + 127) << 23);  // 2^k
+    const int k = uni(min(max(RS_TOP + 126 - eb, -126), 127));  // (scalar: the rows' exponent and everything derived from it stay on the scalar unit)
+    float f;
+    asm("v_mov_b32 %0, %1" : "=v"(f) : "s"((k + 127) << 23));  // 2^k, in a vector register: twenty multiplies with a scalar operand each cost more
 #pragma unroll
     for (int r = 0; r < R; ++r) rcell_scale(P.c[r], f), rcell_scale(Q.c[r], f);
     return -k;
@@ -530,12 +552,12 @@ __device__ __forceinline__ void rs_clear_outside(RDiag<R> &io, const Masks<R> &m
 }
 
 // One forward anti-diagonal: `io` holds d-2 on entry and d on exit, `p1` holds d-1.  S.X / S.Y: X[x-1]*8, Y[y-1]*8.
-template <int R>
+template <int R, bool CHK = true>
 __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     x0 += 1;
-    bases_up<R>(S.X, feed8_get<+1, RS_XS>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
+    bases_up<R>(S.X, feed8_take<+1, RS_XS, CHK>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
     const RDiag<R> U = rs_shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -552,12 +574,12 @@ __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, co
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
     else rs_clear_outside<R>(io, mk, moved);
 }
-template <int R>
+template <int R, bool CHK = true>
 __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     y0 += 1;
-    bases_down<R>(S.Y, feed8_get<+1>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
+    bases_down<R>(S.Y, feed8_take<+1, RS_YS, CHK>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
     const RDiag<R> L = rs_shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -575,12 +597,12 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, co
     else rs_clear_outside<R>(io, mk, moved);
 }
 // One backward anti-diagonal d: `io` holds d+2 on entry and d on exit, `s1` holds d+1.  S.X / S.Y: X[x]*8, Y[y]*8.
-template <int R>
+template <int R, bool CHK = true>
 __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
     S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     x0 -= 1;
-    bases_down<R>(S.X, feed8_get<-1, RS_XS>(S.fx, E.X, E.lX, x0, E.lane));
+    bases_down<R>(S.X, feed8_take<-1, RS_XS, CHK>(S.fx, E.X, E.lX, x0, E.lane));
     const RDiag<R> Ys = rs_shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -597,12 +619,12 @@ __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, co
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
     else rs_clear_outside<R>(io, mk, moved);
 }
-template <int R>
+template <int R, bool CHK = true>
 __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     y0 -= 1;
-    bases_up<R>(S.Y, feed8_get<-1>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
+    bases_up<R>(S.Y, feed8_take<-1, RS_YS, CHK>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
     const RDiag<R> Xs = rs_shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
     RDiag<R> o;
 #pragma unroll
