@@ -324,6 +324,46 @@ def test_band_without_probability_is_reported_by_the_per_cell_kernel(gpu_ctx):
     gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
 
 
+def test_row_scaled_sweeps_in_blocks_of_sixteen_anti_diagonals(gpu_ctx):
+    """k_dp_rs runs both sweeps in blocks of NPR_RS_K = 16 anti-diagonals (stream windows looked after once per block, the
+    renormalising row the last of its block): every number of anti-diagonals from 2 to 70 -- shorter than a block, exactly one or
+    several, one more, one less, odd and even -- and reads whose bands drift across several refills of the base streams, in the
+    three frame classes.  Same bits as the mirror, which knows nothing of blocks."""
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(77)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    h = oracle_hmm("blasr_hmm_0.txt")
+    kw = dict(band_mode=1, fixed_width=40)
+    raw = []
+    for D in range(2, 71):  # lX + lY = D exactly: a copy with substitutions, one inserted base when D is odd
+        lx = D // 2
+        X = rng.integers(0, 4, size=lx).astype(np.uint8)
+        Y = np.where(rng.random(lx) < 0.1, (X + 1) % 4, X).astype(np.uint8)
+        ops = [(0, lx)]
+        if D & 1:
+            Y, ops = np.append(Y, np.uint8(rng.integers(0, 4))), [(0, lx), (1, 1)]
+        raw.append((X, Y, ops))
+    for lx in range(1, 36):
+        X, Y, ops = random_pair(rng, lx, indel=0.15, max_indel=2)
+        if len(Y):
+            raw.append((X, Y, ops))
+    out = gpu_ctx.realign(R.make_params(**kw), [bytes(b"ACGT"[c] for c in X) for X, _, _ in raw],
+                          [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in raw], [g for _, _, g in raw], want_pairs=True)
+    P = orc.make_params(**kw)
+    n_rs = 0
+    for (X, Y, ops), g in zip(raw, out):
+        m = orc.realign_read(h, P, X, Y, ops, precision=1, seg_arith=g["seg_arith"])
+        n_rs += g["seg_arith"] == [1]
+        assert g["status"] == 0 and g["ops"] == m["ops"]
+        gp, mp = _pairs_dict(g["x"], g["y"], g["p"]), _pairs_dict(m["px"], m["py"], m["pp"].astype(np.float32))
+        assert gp.keys() == mp.keys() and all(np.float32(gp[k]) == np.float32(mp[k]) for k in gp), (len(X), len(Y))
+    assert n_rs > len(raw) // 2
+    # long drifting bands: many refills of both streams in both sweeps, rebases in both directions
+    _run_case(gpu_ctx, rng, 6, 2000, 4000, dict(band_mode=1, fixed_width=40), indel=0.25, max_indel=30)
+    _run_case(gpu_ctx, rng, 4, 2000, 4000, dict(band_mode=1, fixed_width=200), indel=0.25, max_indel=60)
+    _run_case(gpu_ctx, rng, 3, 1500, 3000, dict(band_mode=1, fixed_width=400), indel=0.25, max_indel=60)
+
+
 def test_pair_kernel_in_row_scaled_arithmetic(gpu_ctx, monkeypatch):
     """k_dp_pair_rs (a read's two sweeps on two wavefronts at once, the posteriors from the stored rows of both): what a class of
     257+ tasks that fills at most half of the chip runs by default (BASELINE.json configs[1]); NPR_PAIR=all sends every
