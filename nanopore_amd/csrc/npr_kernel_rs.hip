@@ -81,6 +81,9 @@ __device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
 #ifndef NPR_RS_BLOCK
 #define NPR_RS_BLOCK 1  // the sweeps of k_dp_rs in blocks of RS_K anti-diagonals: stream refills and renormalisation outside the steps
 #endif
+#ifndef NPR_PAIR_BLOCK
+#define NPR_PAIR_BLOCK NPR_RS_BLOCK  // the same for the two sweeps of k_dp_pair_rs
+#endif
 #ifndef NPR_RS_WAVES2
 #define NPR_RS_WAVES2 6  // wavefronts per SIMD the R = 2 kernel is compiled for: 79 VGPRs, two spilled (82 and 5 per SIMD without: 3 % slower)
 #endif
@@ -582,6 +585,40 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             rs_store_row<R>(frs, Q.A, c0, voff);
             int d = 1;
             CtlPair wn = ctl_scalar2(ctl, 1);
+#if NPR_PAIR_BLOCK
+            {  // blocks of RS_K anti-diagonals, as in k_dp_rs
+                auto pair = [&](auto last) __attribute__((always_inline)) {
+                    const CtlPair w = wn;
+                    wn = ctl_scalar2(ctl, d + 2);
+                    {
+                        const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
+                        RS_FWD_REBASE(cur.reb);
+                        rs_fwd_x_step<R, false>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                        rs_store_row<R>(frs, Q.B, cur, voff);
+                    }
+                    const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
+                    RS_FWD_REBASE(cur.reb);
+                    rs_fwd_y_step<R, false>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
+                    if constexpr (decltype(last)::value) {
+                        Q.e += rs_renorm<R>(Q.A, Q.B);
+                        if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
+                    }
+                    rs_store_row<R>(frs, Q.A, cur, voff);
+                    d += 2;
+                };
+                while (d + RS_K - 1 <= D) {
+                    feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
+                    feed8_ahead<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
+#pragma nounroll
+                    for (int k = 0; k < RS_K / 2 - 1; ++k) pair(std::false_type{});
+                    pair(std::true_type{});
+                }
+                feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
+                feed8_ahead<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
+#pragma nounroll
+                while (d + 1 <= D) pair(std::false_type{});
+            }
+#else
             for (; d + 1 <= D; d += 2) {
                 const CtlPair w = wn;
                 wn = ctl_scalar2(ctl, d + 2);
@@ -600,6 +637,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 }
                 rs_store_row<R>(frs, Q.A, cur, voff);
             }
+#endif
             if (d <= D) {
                 const RowCtl<R> cur = row_ctl_of_words<R>(wn.a0, wn.a1);
                 RS_FWD_REBASE(cur.reb);
@@ -659,6 +697,42 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 rs_store_row<R>(brs, Q.A, cur, voff);
                 d2 -= 1;
             }
+#if NPR_PAIR_BLOCK
+            {  // blocks that end on a renormalising row, as in k_dp_rs (control words read down to row -3: kCtlFrontPad)
+                CtlPair wb = ctl_scalar2(ctl, d2 - 2);
+                auto pair = [&](auto last) __attribute__((always_inline)) {
+                    const CtlPair q = wb;
+                    wb = ctl_scalar2(ctl, d2 - 4);
+                    int reb = cur.reb;
+                    cur = nxt;
+                    nxt = row_ctl_of_words<R>(q.b0, q.b1);
+                    RS_BWD_REBASE(reb);
+                    rs_bwd_y_step<R, false>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                    m2 = m1, m1 = cur.moved;
+                    rs_store_row<R>(brs, Q.B, cur, voff);
+                    reb = cur.reb;
+                    cur = nxt;
+                    if (!decltype(last)::value || d2 >= 2) nxt = row_ctl_of_words<R>(q.a0, q.a1);
+                    RS_BWD_REBASE(reb);
+                    rs_bwd_x_step<R, false>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                    m2 = m1, m1 = cur.moved;
+                    if constexpr (decltype(last)::value) {
+                        Q.e += rs_renorm<R>(Q.A, Q.B);
+                        if (lane == 0) bexp[(d2 - 1) / RS_K] = Q.e;
+                    }
+                    rs_store_row<R>(brs, Q.A, cur, voff);
+                    d2 -= 2;
+                };
+                while (d2 >= 1) {
+                    feed8_ahead<-1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
+                    feed8_ahead<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
+                    const int n = (d2 & (RS_K - 1)) >> 1;
+#pragma nounroll
+                    for (int k = 0; k < n; ++k) pair(std::false_type{});
+                    pair(std::true_type{});
+                }
+            }
+#else
             CtlPair wb = ctl_scalar2(ctl, max(d2 - 2, 0));  // {d2 - 2, d2 - 1}
             for (; d2 >= 1; d2 -= 2) {
                 const CtlPair q = wb;
@@ -683,6 +757,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 }
                 rs_store_row<R>(brs, Q.A, cur, voff);
             }
+#endif
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (jr[r] == j0) {
