@@ -293,6 +293,22 @@ def from_cold(ctx, w, params, cells):
             "note": "host buffers -> results: npr_batch_create (plan, pack, H2D) + npr_batch_run + npr_batch_finish"}
 
 
+def self_launch(n):
+    """Re-executes this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
+    port) and returns its exit code; rank 0's JSON line goes to this process's stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,13 +324,18 @@ def main():
                     "files -> file strong-scaling job of configs[2]/[3])")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # a plain `python bench.py --gpus N ...`: start the N ranks ourselves (one process per GPU, the launch line the
+        # driver uses) and hand their one JSON line through
+        raise SystemExit(self_launch(args.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ... (or plainly: python bench.py --gpus %d)"
+                         % (world, args.gpus, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     # test hook: NPR_BENCH_SHARE_GPU=1 lets N ranks share cuda:0 with gloo collectives, to exercise the
@@ -518,9 +539,32 @@ def c3_job(env, n_reads, steps, warmup, from_files):
     sync()
     elapsed = time.perf_counter() - t0
     cells_rank = tms[-1]["cells"]
+    solo = None
     if dist is not None:
         elapsed = allreduce([elapsed], dist.ReduceOp.MAX)[0]
         total_cells = int(allreduce([cells_rank], dist.ReduceOp.SUM)[0])
+        if from_files:
+            # the SAME job on rank 0 alone (the other ranks wait at the barrier), with the host threads a one-rank launch has:
+            # the N = 1 point of the strong-scaling series measured inside the N-rank run, on the same box, so that
+            # `speedup_vs_n1` does not depend on a second invocation
+            if rank == 0:
+                threads_env = os.environ.get("NPR_HOST_THREADS")
+                os.environ["NPR_HOST_THREADS"] = str(usable_cpus())
+
+                def alone():
+                    step_no[0] += 1
+                    return job.realign_sam_file(sam, os.path.join(tmp, "realigned_solo_%d.sam" % step_no[0]), fa, params=params, gpu=gpu,
+                                                set_models=False, group=job.SOLO)
+                alone()
+                ts = time.perf_counter()
+                for _ in range(steps):
+                    alone()
+                solo = (time.perf_counter() - ts) / steps
+                if threads_env is None:
+                    del os.environ["NPR_HOST_THREADS"]
+                else:
+                    os.environ["NPR_HOST_THREADS"] = threads_env
+            sync()
     else:
         total_cells = cells_rank
     if rank != 0:
@@ -563,6 +607,12 @@ def c3_job(env, n_reads, steps, warmup, from_files):
                 "per rank: the same pipeline over arrays resident in host memory, records formatted natively",
         "rank0_phase_seconds": mean,
         "dp_share_of_wall": (kms * 1e-3) / wall,
+        "speedup_vs_n1": None if solo is None else solo / wall,
+        "n1_ms_per_step": None if solo is None else solo * 1e3,
+        "n1_reads_per_s": None if solo is None else n_reads / solo,
+        "speedup_note": ("the same files -> file job run by rank 0 ALONE inside this launch (the other ranks wait), all host cores "
+                         "to it: ms_per_step(N = 1) / ms_per_step(N = %d); the >= 6x target at N = 8 is read off this field" % world)
+                        if solo is not None else "N = 1: this line is the reference point of the series",
         "dp_sweep_only_rank0": {"value": cells_rank / (kms * 1e-3), "unit": "cells/s", "ms": kms},
         "note": "phase seconds are sums over the step's chunks (the phases of different chunks overlap; a DP pass or MEA stage waiting for the "
                 "device's shared scratch counts in its phase); dp_share_of_wall = HIP-event time of the DP launches / wall time of a step",

@@ -369,16 +369,20 @@ int64_t npr_sam_index(const char *text, int64_t len, int64_t *header_end, int64_
 /* Fields of n alignment lines (span as from npr_sam_index, possibly a sub-range: a rank's shard).  fields[i * NPR_SAM_COLS + c]:
  *   0 end of QNAME (it starts at span[2 * i])      1, 2  RNAME [start, end)       3, 4  CIGAR [start, end)
  *   5, 6 SEQ [start, end)                          7 FLAG     8 POS - 1 (0-based, pysam's aR.pos)     9 MAPQ
- *   10 tid = index of RNAME in the given name table (the @SQ order), -1 for "*" or a name not in it: samIterator drops
- *      those records (utils.py:287-293)
+ *   10 tid = index of RNAME in the given name table (the @SQ order), -1 for "*" or a name not in it (column 15 says which)
  *   11, 12 [start, end) of the aligned part of SEQ in the text (soft clips cut off: aR.query, the sequence handed to
  *      cactus_realign, utils.py:570); empty for SEQ "*"
  *   13 operations M / I / D of the cigar (the guide: clips carry no operation, utils.py:173)
  *   14 reference bases the cigar consumes (aR.aend - aR.pos)
- *   15 NPR_OK, or NPR_ERR_INVALID: fewer than 11 columns, a malformed number or cigar, or an operation outside M I D S H
- *      (the reference asserts `op in (0, 1, 2, 4, 5)`, utils.py:171)
+ *   15 NPR_OK; NPR_ERR_INVALID: fewer than 11 columns, a malformed number or cigar, or an operation outside M I D S H
+ *      (the reference asserts `op in (0, 1, 2, 4, 5)`, utils.py:171; pysam's iterator raises on a line it cannot parse);
+ *      NPR_SAM_NO_REFERENCE: RNAME is "*" -- the only records samIterator drops (utils.py:287-293);
+ *      NPR_SAM_UNKNOWN_REFERENCE: RNAME names a sequence the table (the header's @SQ lines) does not have -- an error of
+ *      the file (a SAM without its @SQ lines, a truncated header), never a record to drop silently
  * rnames / rname_off: the n_refs reference names, CSR.  Threaded. */
 #define NPR_SAM_COLS 16
+#define NPR_SAM_NO_REFERENCE 1
+#define NPR_SAM_UNKNOWN_REFERENCE 2
 int32_t npr_sam_parse(const char *text, const int64_t *span, int64_t n, const char *rnames, const int64_t *rname_off, int64_t n_refs,
                       int64_t *fields);
 /* The guides of n parsed lines as the batch entry points take them: (op, length) pairs of the M / I / D operations of line i

@@ -98,7 +98,7 @@ class SamAlignmentStats(object):
         self = cls.__new__(cls)
         sam = ingest.SamText(samFile)
         f = sam.parse()
-        kept = np.nonzero(f[:, ingest.F_TID] >= 0)[0]
+        kept = np.nonzero(sam.records_with_a_reference(f, sam.span))[0]
         f = f[kept]
         if len(f) != len(table):
             raise ValueError("%d records with a reference in %s, %d rows of statistics" % (len(f), samFile, len(table)))

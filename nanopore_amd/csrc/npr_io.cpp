@@ -151,6 +151,10 @@ int32_t npr_sam_parse(const char *text, const int64_t *span, int64_t n, const ch
                 const std::string_view rn(col[2], static_cast<size_t>(col_end[2] - col[2]));
                 const auto it = tid.find(rn);
                 f[10] = it == tid.end() ? -1 : it->second;
+                if (it == tid.end()) {  // no reference: "*" is a record samIterator drops, any other name is an error of the file
+                    f[15] = (rn.size() == 1 && rn[0] == '*') ? NPR_SAM_NO_REFERENCE : NPR_SAM_UNKNOWN_REFERENCE;
+                    continue;
+                }
                 const bool no_seq = col_end[9] - col[9] == 1 && *col[9] == '*';
                 const int64_t seq_len = no_seq ? 0 : col_end[9] - col[9];
                 // the cigar: clips at both ends, M / I / D count, reference bases consumed

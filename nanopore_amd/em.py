@@ -111,7 +111,7 @@ def allReduceExpectations(T, E, ll, device=None, group=None):
         import torch.distributed as dist
     except ImportError:
         return T, E, ll
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return T, E, ll
     flat = np.concatenate([np.asarray(T).reshape(-1), np.asarray(E).reshape(-1), np.asarray(ll).reshape(-1)])
     t = torch.from_numpy(flat.copy()).to(_collectiveDevice(device, group))
@@ -130,7 +130,7 @@ def broadcastModel(hmm, device=None, group=None, src=0):
         import torch.distributed as dist
     except ImportError:
         return hmm
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return hmm
     t = torch.tensor(list(hmm.transitions) + list(hmm.emissions) + [float(hmm.likelihood)], dtype=torch.float64).to(_collectiveDevice(device, group))
     dist.broadcast(t, src=src, group=group)

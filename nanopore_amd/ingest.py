@@ -19,6 +19,7 @@ from ._lib import ptr
 SAM_COLS = 16
 (F_QNAME_END, F_RNAME_LO, F_RNAME_HI, F_CIGAR_LO, F_CIGAR_HI, F_SEQ_LO, F_SEQ_HI, F_FLAG, F_POS, F_MAPQ, F_TID, F_QUERY_LO,
  F_QUERY_HI, F_GUIDE_OPS, F_REF_SPAN, F_STATUS) = range(SAM_COLS)
+SAM_NO_REFERENCE, SAM_UNKNOWN_REFERENCE = 1, 2  # F_STATUS besides NPR_OK / NPR_ERR_INVALID (include/nprealign.h)
 
 
 def _map(path):
@@ -77,6 +78,22 @@ class SamText(object):
             _check(_lib.load().npr_sam_parse(ptr(self.text), ptr(span), n, ptr(self._rn), ptr(self._rn_off), len(self.references),
                                              ptr(fields)), "npr_sam_parse")
         return fields
+
+    def records_with_a_reference(self, fields, span):
+        """The mask of the lines samIterator keeps (utils.py:287-293: every record whose RNAME is not "*"), after the checks the
+        reference's reader and asserts make on EVERY line: a line that does not parse, a cigar operation outside M I D S H
+        (utils.py:171) or an RNAME the header does not name raises -- pysam's iterator raises on such a file; nothing
+        disappears without an error."""
+        status = fields[:, F_STATUS]
+        bad = np.nonzero((status != 0) & (status != SAM_NO_REFERENCE))[0]
+        if len(bad):
+            k = int(bad[0])
+            line = self.field_bytes(int(span[k, 0]), min(int(span[k, 1]), int(span[k, 0]) + 200)).decode(errors="replace")
+            if status[k] == SAM_UNKNOWN_REFERENCE:
+                raise KeyError("SAM record %r: RNAME %r is not among the header's @SQ lines"
+                               % (line.split("\t")[0], self.field_bytes(int(fields[k, F_RNAME_LO]), int(fields[k, F_RNAME_HI])).decode(errors="replace")))
+            raise AssertionError("SAM line %r: malformed, or a cigar operation outside M I D S H (utils.py:171)" % line)
+        return status == 0
 
     def guides(self, fields):
         """CSR guides of parsed lines: (guide_off[n + 1], guide_ops[k, 2]) -- the M / I / D operations of each cigar, the

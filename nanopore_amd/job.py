@@ -404,9 +404,13 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
 # the job: shard, pipeline, write, gather
 # ---------------------------------------------------------------------------------------------------------
 
+SOLO = "solo"  # as `group`: this process alone runs the whole job although torch.distributed is initialised (bench.py's one-rank
+               # reference run of the strong-scaling job inside an N-rank launch)
+
+
 def _dist_state(group):
     import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized()
+    multi = group is not SOLO and dist.is_available() and dist.is_initialized()
     if not multi:
         return None, 1, 0
     return dist, dist.get_world_size(group), dist.get_rank(group)
@@ -549,14 +553,11 @@ def realign_sam_file(samFile, outputSamFile, referenceFastaFile, hmm=None, gapGa
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     fields = sam.parse(lo, hi)
     span = sam.span[lo:hi]
-    keep = fields[:, ingest.F_TID] >= 0  # samIterator: records without a reference are not realigned and not written (utils.py:287-293)
+    # every line is checked BEFORE anything is dropped (a truncated SAM or one without @SQ lines must not yield a successful job
+    # with fewer records); samIterator drops the records whose RNAME is "*", and only those (utils.py:287-293)
+    keep = sam.records_with_a_reference(fields, span)
     if not keep.all():
         fields, span = fields[keep], span[keep]
-    bad = np.nonzero(fields[:, ingest.F_STATUS] != 0)[0]
-    if len(bad):
-        k = int(bad[0])
-        raise AssertionError("SAM record %r: malformed, or a cigar operation outside M I D S H (utils.py:171)"
-                             % sam.field_bytes(int(span[k, 0]), int(fields[k, ingest.F_QNAME_END])).decode(errors="replace"))
     src = SamSource(sam, fasta, span, fields, model_slot=None if not model_slot else np.full(len(fields), model_slot, dtype=np.int32))
     t2 = time.perf_counter()
     ctxs = contexts(gpu, workers or WORKERS)

@@ -17,7 +17,7 @@ EDGE = [
     "r1\t0\tchr1\t11\t60\t2S5M1I3M2D4M3S\t*\t0\t0\tACGTACGTACGTACGTAC\tIIIIIIIIIIIIIIIIII\tNM:i:3\tXX:Z:foo",
     "r2\t16\tchr2\t1\t255\t3H4M2H\t*\t0\t0\tACGT\t*",
     "r3\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\t*",                    # unmapped: samIterator drops it
-    "r4\t0\tchrUn\t5\t1\t4M\t*\t0\t0\tACGT\t*",               # RNAME not in the header: tid -1, dropped
+    "r4\t0\tchrUn\t5\t1\t4M\t*\t0\t0\tACGT\t*",               # RNAME not in the header: tid -1, flagged (SAM_UNKNOWN_REFERENCE)
     "",
     "r5\t0\tchr1\t100\t3\t10M\t=\t7\t-3\tACGTACGTAC\tJJJJJJJJJJ",
     "r6\t0\tchr1\t1\t3\t1H2S3M1D2I1M1S4H\t*\t0\t0\tACGTACGTA\t*",
@@ -40,7 +40,9 @@ def _check_against_mirror(path):
     for i, a in enumerate(recs):
         assert a.rname == f[i, ingest.F_TID]
         assert st.field_bytes(int(st.span[i, 0]), int(f[i, ingest.F_QNAME_END])).decode() == a.qname
-        if a.cigar:
+        if a.rname < 0:   # "*": the record samIterator drops; any other name: an error of the file, never dropped silently
+            assert f[i, ingest.F_STATUS] == (ingest.SAM_NO_REFERENCE if a._rname == "*" else ingest.SAM_UNKNOWN_REFERENCE)
+        elif a.cigar:
             assert f[i, ingest.F_STATUS] == 0
             assert st.field_bytes(int(f[i, ingest.F_QUERY_LO]), int(f[i, ingest.F_QUERY_HI])).decode() == (a.query or "")
             assert (f[i, ingest.F_POS], f[i, ingest.F_FLAG], f[i, ingest.F_MAPQ]) == (a.pos, a.flag, a.mapq)
@@ -89,6 +91,29 @@ def test_malformed_records_are_flagged_not_skipped(tmp_path):
     st = ingest.SamText(_write(tmp_path, lines))
     f = st.parse()
     assert list(f[:, ingest.F_STATUS]) == [-1, -1, -1, -1, -1, 0]
+
+
+def test_nothing_is_dropped_without_an_error(tmp_path):
+    """Only RNAME "*" is dropped (samIterator, utils.py:287-293).  A line that does not parse, or an RNAME the header does not
+    name (a SAM without its @SQ lines, a truncated file), raises before any record is filtered -- pysam's iterator raises on
+    such files; a successful job with fewer records would be silent data loss."""
+    head, recs = EDGE[:4], [EDGE[4], EDGE[5], EDGE[6], EDGE[9], EDGE[10]]
+    st = ingest.SamText(_write(tmp_path, head + recs))
+    f = st.parse()
+    keep = st.records_with_a_reference(f, st.span)
+    assert list(keep) == [True, True, False, True, True] and list(f[:, ingest.F_STATUS]) == [0, 0, ingest.SAM_NO_REFERENCE, 0, 0]
+    for bad, exc in (("r4\t0\tchrUn\t5\t1\t4M\t*\t0\t0\tACGT\t*", KeyError),         # RNAME missing from the header
+                     ("no tabs at all", AssertionError),
+                     ("r7\tzz\tchr1\t5\t1\t4M\t*\t0\t0\tACGT\t*", AssertionError),      # FLAG not a number
+                     ("r8\t0\tchr1\t5\t1\t4M\t*\t0\t0\tAC", AssertionError)):            # truncated in the middle of a record
+        st = ingest.SamText(_write(tmp_path, head + recs + [bad], name="bad.sam"))
+        f = st.parse()
+        with pytest.raises(exc):
+            st.records_with_a_reference(f, st.span)
+    # a file without its @SQ lines: every mapped record names an unknown reference
+    st = ingest.SamText(_write(tmp_path, ["@HD\tVN:1.0"] + recs, name="nosq.sam"))
+    with pytest.raises(KeyError):
+        st.records_with_a_reference(st.parse(), st.span)
 
 
 def test_random_sam_files(tmp_path):
