@@ -1266,6 +1266,11 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     std::vector<const npr_batch::Launch *> order;
     for (const auto &L : b->launches) order.push_back(&L);
     std::sort(order.begin(), order.end(), [](const npr_batch::Launch *x, const npr_batch::Launch *y) { return x->cells < y->cells; });
+    // the row-scaled kernels leave out the two short-gap switch terms of a cell when no loaded model has such a transition (the
+    // shipped ones have none): exact zeros either way (npr_rs.h)
+    bool sw = false;
+    for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
+        if (ctx->model_set[sl] && (ctx->models[sl].T[1 * 5 + 2] != 0.f || ctx->models[sl].T[2 * 5 + 1] != 0.f)) sw = true;
     for (size_t i = 0; i < order.size(); ++i) {
         const npr_batch::Launch &L = *order[i];
         const bool last = i + 1 == order.size();
@@ -1281,8 +1286,8 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
-        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_pair_rs(a, kc.R, L.grid, s) : launch_pair(a, kc.R, L.grid, s))
-                       : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s)
+        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_pair_rs(a, kc.R, L.grid, s, sw) : launch_pair(a, kc.R, L.grid, s))
+                       : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
                        : kc.kind == K_TILE_RS ? launch_tile_rs(a, L.wcap, L.grid, s)

@@ -272,8 +272,8 @@ int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
 #define NPR_RS_S_LIMIT (126 - 60 - (NPR_RS_TOP + 6) - 1)
 constexpr int32_t TASK_RERUN = 1;  // TaskOut::status of such a task between the two launches (never leaves npr_batch_run)
 NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }
-int launch_rs(const KernelArgs &a, int R, int grid, void *stream);
-int launch_pair_rs(const KernelArgs &a, int R, int grid, void *stream);  // k_dp_pair_rs: k_dp_rs's sweeps on two wavefronts at once
+int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);  // sw: a loaded model has short-gap switches (npr_rs.h)
+int launch_pair_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);  // k_dp_pair_rs: k_dp_rs's sweeps on two wavefronts at once
 int launch_tile_rs(const KernelArgs &a, int NW, int grid, void *stream);  // k_dp_tile_rs: k_dp_tile's stripes, one exponent per stripe row
 size_t tile_rs_lds_bytes(int nw);
 size_t rs_lds_bytes();  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once

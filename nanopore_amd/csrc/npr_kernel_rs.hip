@@ -87,7 +87,7 @@ __device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
 #ifndef NPR_RS_WAVES2
 #define NPR_RS_WAVES2 6  // wavefronts per SIMD the R = 2 kernel is compiled for: 79 VGPRs, two spilled (82 and 5 per SIMD without: 3 % slower)
 #endif
-template <int R>
+template <int R, bool SW>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_rs(KernelArgs a) {
     // static LDS: the tables' addresses are compile-time constants and fold into the ds_read offsets
     __shared__ __attribute__((aligned(16))) RsTables ltab_s;
@@ -184,12 +184,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 {
                     const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
                     RS_FWD_REBASE(cur.reb);
-                    rs_fwd_x_step<R, false>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                    rs_fwd_x_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
                     rs_store_row<R>(frs, Q.B, cur, voff);
                 }
                 const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
                 RS_FWD_REBASE(cur.reb);
-                rs_fwd_y_step<R, false>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
+                rs_fwd_y_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
                 if constexpr (decltype(last)::value) {
                     Q.e += rs_renorm<R>(Q.A, Q.B);
                     if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
@@ -222,12 +222,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             {
                 const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
                 RS_FWD_REBASE(cur.reb);
-                rs_fwd_x_step<R>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
                 rs_store_row<R>(frs, Q.B, cur, voff);
             }
             const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
             RS_FWD_REBASE(cur.reb);
-            rs_fwd_y_step<R>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
+            rs_fwd_y_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
             if (((d + 1) & (RS_K - 1)) == 0) {  // a renormalising row: both held rows, then the row goes out with its new exponent
                 Q.e += rs_renorm<R>(Q.A, Q.B);
                 if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 #endif
             const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
             RS_FWD_REBASE(cur.reb);
-            rs_fwd_x_step<R>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+            rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
             rs_store_row<R>(frs, Q.B, cur, voff);
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
@@ -277,7 +277,11 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         TaskOut out;
         out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
         out.status = NPR_OK;
+#ifdef NPR_EXP_FWDONLY
+        const bool alive = false;
+#else
         const bool alive = tot_m > 0.f;
+#endif
         if (!alive) out.status = NPR_ERR_ZERO_PROB;
 
         // =============================== backward + posteriors ===============================
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 if ((d2 & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_c[d2 / RS_K] + Q.e - tot_e), inv_tot, jr, cnt);
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     nxt = row_ctl_of_words<R>(q.b0, q.b1);
                     rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
                     RS_BWD_REBASE(reb);
-                    rs_bwd_y_step<R, false>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                    rs_bwd_y_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
                     m2 = m1, m1 = cur.moved;
                     rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
                     reb = cur.reb;
@@ -372,7 +376,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                         rs_load_row<R>(frs, fb, nxt, voff);
                     }
                     RS_BWD_REBASE(reb);
-                    rs_bwd_x_step<R, false>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                    rs_bwd_x_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                     m2 = m1, m1 = cur.moved;
                     if constexpr (decltype(last)::value) {
                         Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -428,7 +432,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 nxt = row_ctl_of_words<R>(w.a0, w.a1);
                 rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
                 RS_BWD_REBASE(reb);
-                rs_bwd_y_step<R>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                rs_bwd_y_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 const int ef = ef_next;  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
                 ef_next = fexp_c[(d2 - 2) >> __builtin_ctz(RS_K)];  // (d2 = 1: the word before the exponents, a forward cell; not used)
@@ -440,7 +444,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 if (((d2 - 1) & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
@@ -471,7 +475,11 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
             // one exponent per row may not have been enough -- also when nothing arrived at the end corner: the per-cell kernel decides
             // whether the band really carries no probability
+#ifndef NPR_EXP_FWDONLY
             if (smax >= NPR_RS_S_LIMIT || !alive) out.status = TASK_RERUN;
+#else
+            out.status = NPR_OK;
+#endif
             a.outs[t] = out;
         }
         int nt = 0;
@@ -491,7 +499,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 // cells, the same total, the same expression as k_dp_rs, so the same bits (the pairs land in another order, which every consumer
 // sorts away), and the same range certificate.
 // =====================================================================================================================
-template <int R>
+template <int R, bool SW>
 __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_pair_rs(KernelArgs a) {
     __shared__ __attribute__((aligned(16))) RsTables ltab_s;
     __shared__ __attribute__((aligned(16))) float lmodel[MODEL_FLOATS];
@@ -593,12 +601,12 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                     {
                         const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
                         RS_FWD_REBASE(cur.reb);
-                        rs_fwd_x_step<R, false>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                        rs_fwd_x_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
                         rs_store_row<R>(frs, Q.B, cur, voff);
                     }
                     const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
                     RS_FWD_REBASE(cur.reb);
-                    rs_fwd_y_step<R, false>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
+                    rs_fwd_y_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
                     if constexpr (decltype(last)::value) {
                         Q.e += rs_renorm<R>(Q.A, Q.B);
                         if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
@@ -625,12 +633,12 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 {
                     const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
                     RS_FWD_REBASE(cur.reb);
-                    rs_fwd_x_step<R>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                    rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
                     rs_store_row<R>(frs, Q.B, cur, voff);
                 }
                 const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
                 RS_FWD_REBASE(cur.reb);
-                rs_fwd_y_step<R>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
+                rs_fwd_y_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
                 if (((d + 1) & (RS_K - 1)) == 0) {
                     Q.e += rs_renorm<R>(Q.A, Q.B);
                     if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
@@ -641,7 +649,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             if (d <= D) {
                 const RowCtl<R> cur = row_ctl_of_words<R>(wn.a0, wn.a1);
                 RS_FWD_REBASE(cur.reb);
-                rs_fwd_x_step<R>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
                 rs_store_row<R>(frs, Q.B, cur, voff);
             }
             const int je = lX - Q.x0;
@@ -688,7 +696,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 cur = nxt;
                 if (d2 >= 1) nxt = read_row_ctl<R>(ctl, d2 - 1);
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 if ((d2 & (RS_K - 1)) == 0) {
                     Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -707,14 +715,14 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                     cur = nxt;
                     nxt = row_ctl_of_words<R>(q.b0, q.b1);
                     RS_BWD_REBASE(reb);
-                    rs_bwd_y_step<R, false>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                    rs_bwd_y_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
                     m2 = m1, m1 = cur.moved;
                     rs_store_row<R>(brs, Q.B, cur, voff);
                     reb = cur.reb;
                     cur = nxt;
                     if (!decltype(last)::value || d2 >= 2) nxt = row_ctl_of_words<R>(q.a0, q.a1);
                     RS_BWD_REBASE(reb);
-                    rs_bwd_x_step<R, false>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                    rs_bwd_x_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                     m2 = m1, m1 = cur.moved;
                     if constexpr (decltype(last)::value) {
                         Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -742,14 +750,14 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 cur = nxt;
                 nxt = row_ctl_of_words<R>(w.a0, w.a1);
                 RS_BWD_REBASE(reb);
-                rs_bwd_y_step<R>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                rs_bwd_y_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 rs_store_row<R>(brs, Q.B, cur, voff);
                 reb = cur.reb;
                 cur = nxt;
                 if (d2 >= 2) nxt = row_ctl_of_words<R>(w.b0, w.b1);
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 if (((d2 - 1) & (RS_K - 1)) == 0) {
                     Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -926,31 +934,34 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
 
 size_t rs_lds_bytes() { return 0; }  // static LDS only
 
-int launch_pair_rs(const KernelArgs &a, int R, int grid, void *stream) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (R == 1)
-        hipLaunchKernelGGL(k_dp_pair_rs<1>, dim3(grid), dim3(2 * WAVE), 0, s, a);
-    else if (R == 2)
-        hipLaunchKernelGGL(k_dp_pair_rs<2>, dim3(grid), dim3(2 * WAVE), 0, s, a);
-    else if (R == 4)
-        hipLaunchKernelGGL(k_dp_pair_rs<4>, dim3(grid), dim3(2 * WAVE), 0, s, a);
-    else
-        return static_cast<int>(hipErrorInvalidValue);
+// sw: some loaded model has a short-gap switch (shortGapX <-> shortGapY); without one the two multiply-adds per cell and
+// direction that would add an exact zero are not issued (same bits: npr_rs.h)
+template <int R>
+static int launch_pair_rs_r(const KernelArgs &a, bool sw, int grid, hipStream_t s) {
+    if (sw) hipLaunchKernelGGL((k_dp_pair_rs<R, true>), dim3(grid), dim3(2 * WAVE), 0, s, a);
+    else hipLaunchKernelGGL((k_dp_pair_rs<R, false>), dim3(grid), dim3(2 * WAVE), 0, s, a);
     return static_cast<int>(hipGetLastError());
 }
-
-int launch_rs(const KernelArgs &a, int R, int grid, void *stream) {
+int launch_pair_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = rs_lds_bytes();
-    if (R == 1)
-        hipLaunchKernelGGL(k_dp_rs<1>, dim3(grid), dim3(WAVE), lds, s, a);
-    else if (R == 2)
-        hipLaunchKernelGGL(k_dp_rs<2>, dim3(grid), dim3(WAVE), lds, s, a);
-    else if (R == 4)
-        hipLaunchKernelGGL(k_dp_rs<4>, dim3(grid), dim3(WAVE), lds, s, a);
-    else
-        return static_cast<int>(hipErrorInvalidValue);
+    if (R == 1) return launch_pair_rs_r<1>(a, sw, grid, s);
+    if (R == 2) return launch_pair_rs_r<2>(a, sw, grid, s);
+    if (R == 4) return launch_pair_rs_r<4>(a, sw, grid, s);
+    return static_cast<int>(hipErrorInvalidValue);
+}
+
+template <int R>
+static int launch_rs_r(const KernelArgs &a, bool sw, int grid, hipStream_t s) {
+    if (sw) hipLaunchKernelGGL((k_dp_rs<R, true>), dim3(grid), dim3(WAVE), 0, s, a);
+    else hipLaunchKernelGGL((k_dp_rs<R, false>), dim3(grid), dim3(WAVE), 0, s, a);
     return static_cast<int>(hipGetLastError());
+}
+int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (R == 1) return launch_rs_r<1>(a, sw, grid, s);
+    if (R == 2) return launch_rs_r<2>(a, sw, grid, s);
+    if (R == 4) return launch_rs_r<4>(a, sw, grid, s);
+    return static_cast<int>(hipErrorInvalidValue);
 }
 
 }  // namespace npr

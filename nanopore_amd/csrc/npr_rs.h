@@ -148,6 +148,10 @@ __device__ __forceinline__ void rs_build_tables(RsTables *t, const DevModel *m, 
 }
 __device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
     constexpr int OFF_EX = offsetof(RsTables, ex2), OFF_EY = offsetof(RsTables, ey2);
+#ifdef NPR_EXP_NOLDS
+    em = __int_as_float(bx + by + 0x3e000000), exs = __int_as_float(bx + 0x3e000000), exl = exs, eys = __int_as_float(by + 0x3e000000), eyl = eys;
+    return;
+#endif
     em = *reinterpret_cast<const float *>(tab + (bx + by));
     const float2 ex = *reinterpret_cast<const float2 *>(tab + OFF_EX + bx);
     const float2 ey = *reinterpret_cast<const float2 *>(tab + OFF_EY + by);
@@ -156,6 +160,10 @@ __device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, fl
 
 // ---- the recurrence (same operand order as npr_cell.h, minus the scale factors) ----
 // forward: L = (x-1, y), M = (x-1, y-1), U = (x, y-1)
+// SW: whether the model has short-gap switches (shortGapX <-> shortGapY).  None of the shipped models has (13 of cPecan's 15
+// transitions); their two multiply-adds with a zero transition add exact zeros, so leaving them out changes no bit
+// (the kernels are instantiated both ways, npr_batch_run picks by the loaded models).
+template <bool SW = true>
 __device__ __forceinline__ RCell rs_fwd_cell(const Trans &t, const RCell &L, const RCell &M, const RCell &U, float em, float exs, float exl,
                                              float eys, float eyl) {
     RCell c;
@@ -168,14 +176,14 @@ __device__ __forceinline__ RCell rs_fwd_cell(const Trans &t, const RCell &L, con
     c.m = em * a;
     a = t.msx * L.m;
     a = __builtin_fmaf(t.sxsx, L.sx, a);
-    a = __builtin_fmaf(t.sysx, L.sy, a);
+    if constexpr (SW) a = __builtin_fmaf(t.sysx, L.sy, a);
     c.sx = exs * a;
     a = t.mlx * L.m;
     a = __builtin_fmaf(t.lxlx, L.lx, a);
     c.lx = exl * a;
     a = t.msy * U.m;
     a = __builtin_fmaf(t.sysy, U.sy, a);
-    a = __builtin_fmaf(t.sxsy, U.sx, a);
+    if constexpr (SW) a = __builtin_fmaf(t.sxsy, U.sx, a);
     c.sy = eys * a;
     a = t.mly * U.m;
     a = __builtin_fmaf(t.lyly, U.ly, a);
@@ -183,6 +191,7 @@ __device__ __forceinline__ RCell rs_fwd_cell(const Trans &t, const RCell &L, con
     return c;
 }
 // backward: Ms = (x+1, y+1), Xs = (x+1, y), Ys = (x, y+1)
+template <bool SW = true>
 __device__ __forceinline__ RCell rs_bwd_cell(const Trans &t, const RCell &Ms, const RCell &Xs, const RCell &Ys, float em, float exs, float exl,
                                              float eys, float eyl) {
     const float am = em * Ms.m;
@@ -200,11 +209,11 @@ __device__ __forceinline__ RCell rs_bwd_cell(const Trans &t, const RCell &Ms, co
     c.m = b;
     b = t.sxm * am;
     b = __builtin_fmaf(t.sxsx, asx, b);
-    b = __builtin_fmaf(t.sxsy, asy, b);
+    if constexpr (SW) b = __builtin_fmaf(t.sxsy, asy, b);
     c.sx = b;
     b = t.sym * am;
     b = __builtin_fmaf(t.sysy, asy, b);
-    b = __builtin_fmaf(t.sysx, asx, b);
+    if constexpr (SW) b = __builtin_fmaf(t.sysx, asx, b);
     c.sy = b;
     b = t.lxm * am;
     b = __builtin_fmaf(t.lxlx, alx, b);
@@ -537,7 +546,11 @@ __device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R
 // mask: no select per value) ...
 template <class F>
 __device__ __forceinline__ void rs_put(RCell &dst, uint64_t in_band, F &&cell) {
+#ifdef NPR_EXP_NOMASK
+    dst = cell();
+#else
     if (__builtin_expect(lanes_of(in_band), 1)) dst = cell();  // (expected: keeps the block in line instead of behind two taken branches)
+#endif
 }
 // ... and when the band is not where it was two anti-diagonals ago (`moved`: a bit of the control word, npr_sched.h; once
 // in ten anti-diagonals on noisy guides) everything outside it is cleared: the row that was overwritten may have had cells
@@ -552,12 +565,14 @@ __device__ __forceinline__ void rs_clear_outside(RDiag<R> &io, const Masks<R> &m
 }
 
 // One forward anti-diagonal: `io` holds d-2 on entry and d on exit, `p1` holds d-1.  S.X / S.Y: X[x-1]*8, Y[y-1]*8.
-template <int R, bool CHK = true>
+template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
-    S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     x0 += 1;
+#ifndef NPR_EXP_NOSTREAM
+    S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     bases_up<R>(S.X, feed8_take<+1, RS_XS, CHK>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
+#endif
     const RDiag<R> U = rs_shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -565,21 +580,23 @@ __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, co
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
             rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
-            o.c[r] = rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
+            o.c[r] = rs_fwd_cell<SW>(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-            rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell<SW>(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
         }
     }
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
     else rs_clear_outside<R>(io, mk, moved);
 }
-template <int R, bool CHK = true>
+template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
-    S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     y0 += 1;
+#ifndef NPR_EXP_NOSTREAM
+    S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     bases_down<R>(S.Y, feed8_take<+1, RS_YS, CHK>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
+#endif
     const RDiag<R> L = rs_shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -587,22 +604,24 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, co
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
             rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
-            o.c[r] = rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
+            o.c[r] = rs_fwd_cell<SW>(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-            rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell<SW>(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
         }
     }
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
     else rs_clear_outside<R>(io, mk, moved);
 }
 // One backward anti-diagonal d: `io` holds d+2 on entry and d on exit, `s1` holds d+1.  S.X / S.Y: X[x]*8, Y[y]*8.
-template <int R, bool CHK = true>
+template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
-    S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     x0 -= 1;
+#ifndef NPR_EXP_NOSTREAM
+    S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     bases_down<R>(S.X, feed8_take<-1, RS_XS, CHK>(S.fx, E.X, E.lX, x0, E.lane));
+#endif
     const RDiag<R> Ys = rs_shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -610,21 +629,23 @@ __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, co
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
             rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
-            o.c[r] = rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
+            o.c[r] = rs_bwd_cell<SW>(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-            rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell<SW>(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
         }
     }
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
     else rs_clear_outside<R>(io, mk, moved);
 }
-template <int R, bool CHK = true>
+template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
-    S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     y0 -= 1;
+#ifndef NPR_EXP_NOSTREAM
+    S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     bases_up<R>(S.Y, feed8_take<-1, RS_YS, CHK>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
+#endif
     const RDiag<R> Xs = rs_shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -632,10 +653,10 @@ __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, co
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
             rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
-            o.c[r] = rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
+            o.c[r] = rs_bwd_cell<SW>(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
         } else {
             rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
-            rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
+            rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell<SW>(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
         }
     }
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
@@ -651,6 +672,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_task_rsrc(char *F) {
 }
 template <int R>
 __device__ __forceinline__ void rs_store_row(__amdgpu_buffer_rsrc_t rs, const RDiag<R> &C, const RowCtl<R> &ct, int voff) {
+#ifdef NPR_EXP_NOROWS
+    return;
+#endif
     if (lanes_of(ct.mk.lanes)) {
         const int vo = voff + static_cast<int>(ct.soff >> 1);
         if constexpr (R == 1) {
@@ -668,8 +692,23 @@ struct RFRow {
 };
 template <int R>
 __device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> &f, const RowCtl<R> &ct, int voff) {
+#ifdef NPR_EXP_NOROWS
+    return;
+#endif
+#ifndef NPR_RS_MASKED_LOAD
+    // Every lane loads, band or not: what a lane outside the band reads (a neighbouring row's bytes, the arena's padding) is never
+    // looked at -- rs_emit_pairs masks its hits with the band -- and a load the compiler knows to be issued on every path lets it
+    // wait for the OLDER of two rows in flight (s_waitcnt vmcnt(1)) instead of for both: behind a lane-mask branch it had to assume
+    // the younger load might not exist and waited for everything, one step after the issue instead of two.
+    {
+#else
     if (lanes_of(ct.mk.lanes)) {
+#endif
+#ifdef NPR_EXP_LOADSAME
+        const int vo = voff + static_cast<int>((ct.soff >> 1) & 0xfff);
+#else
         const int vo = voff + static_cast<int>(ct.soff >> 1);
+#endif
         if constexpr (R == 1) {
             f.v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0));
         } else if constexpr (R == 2) {
@@ -687,10 +726,17 @@ __device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> 
 // is below NPR_RS_S_LIMIT -- and a task with a row above the limit is run again anyway (npr_device.h).
 template <typename T>
 __device__ __forceinline__ T &rs_at(T *base, uint32_t byte_off) { return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off); }
+#ifdef NPR_EXP_POST2
+__device__ __forceinline__ float rs_posterior(float f, float b, int s, float inv_tot) { return f * (b * inv_tot); }
+#else
 __device__ __forceinline__ float rs_posterior(float f, float b, int s, float inv_tot) { return (f * __builtin_ldexpf(b, s)) * inv_tot; }
+#endif
 template <int R>
 __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> &B, const RFRow<R> &f, int d, int x0, int y0, const Masks<R> &mk,
                                               int s, float inv_tot, const int (&jr)[R], int &cnt) {
+#ifdef NPR_EXP_NOPOST
+    return;
+#endif
     float p[R];
     uint64_t hit[R], any = 0;
 #pragma unroll
@@ -699,6 +745,10 @@ __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> 
         hit[r] = __ballot(p[r] >= S.threshold) & mk.cell[r];
         any |= hit[r];
     }
+#ifdef NPR_EXP_NOEMIT
+    if (any) cnt += __popcll(any);
+    return;
+#endif
     if (d >= 2 && any) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -711,9 +761,13 @@ __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> 
                     S.px[slot] = x0 + jr[r] - 1 + S.xs, S.py[slot] = y0 - jr[r] - 1 + S.ys, S.pp[slot] = p[r];
 #else
                     const uint32_t u = static_cast<uint32_t>(slot) << 2;  // a byte offset that fits 32 bits (pair_cap < 2^29): one shift, the arrays' addresses stay scalar
+#ifdef NPR_EXP_STORE1
+                    rs_at<float>(S.pp, u) = p[r] + __int_as_float((x0 + jr[r] - 1 + S.xs) ^ (y0 - jr[r] - 1 + S.ys));
+#elif !defined(NPR_EXP_STORE0)
                     rs_at<int32_t>(S.px, u) = x0 + jr[r] - 1 + S.xs;
                     rs_at<int32_t>(S.py, u) = y0 - jr[r] - 1 + S.ys;
                     rs_at<float>(S.pp, u) = p[r];
+#endif
 #endif
                 }
                 cnt += __popcll(hit[r]);
