@@ -201,7 +201,7 @@ struct DevBuf {
 // cost more than the kernels
 struct MeaScratch {
     DevBuf<int64_t> off, mass, od;
-    DevBuf<int32_t> cnt, start, col, sorted, small, tmp, map;
+    DevBuf<int32_t> cnt, start, col, sorted, small, tmp, map, pieces;
     DevBuf<uint32_t> dense;
 };
 
@@ -1498,6 +1498,11 @@ int32_t device_mea(npr_batch *b) {
     // the host stage
     const int ring = 8192;
     const int64_t total = rp[n];
+    // the pieces the chain of every read is cut into (npr_mea.hip k_mea_cuts): about 2000 posterior pairs (1200 kept) each
+    constexpr int64_t kPiecePairs = 2048, kMaxPieces = 64;
+    std::vector<int32_t> np(n);
+    int64_t n_pieces = 0;
+    for (int64_t i = 0; i < n; ++i) np[i] = static_cast<int32_t>(std::min(kMaxPieces, std::max<int64_t>(1, (rp[i + 1] - rp[i] + kPiecePairs - 1) / kPiecePairs))), n_pieces += np[i];
     if (!ctx->mea) ctx->mea = new MeaScratch;
     MeaScratch &m = *ctx->mea;
     hipError_t e;
@@ -1511,8 +1516,8 @@ int32_t device_mea(npr_batch *b) {
     const size_t n_cnt = sort_in_lds ? 1 : rx[n];
     {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
-        const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (4 * total + 4)) +
-                            al(4 * 4 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]);
+        const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (12 * total + 16)) +
+                            al(4 * 5 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]) + al(4 * (4 * n_pieces + 4 * n));
         const bool in_arena = !ctx->overlap && ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
         char *cur = ctx->arena->F;
         if (in_arena && poison_byte() >= 0) {  // the DP launches are done (their streams feed this one): the tables start from poison
@@ -1528,8 +1533,9 @@ int32_t device_mea(npr_batch *b) {
         };
         if ((e = take(m.off, 4 * (n + 1))) != hipSuccess || (e = take(m.mass, n)) != hipSuccess || (e = take(m.od, n + 1)) != hipSuccess ||
             (e = take(m.cnt, n_cnt)) != hipSuccess || (e = take(m.start, n_cnt)) != hipSuccess || (e = take(m.col, ry[n] + 1)) != hipSuccess ||
-            (e = take(m.sorted, 4 * total + 4)) != hipSuccess || (e = take(m.small, 4 * n)) != hipSuccess || (e = take(m.tmp, 2 * ot[n])) != hipSuccess ||
-            (e = take(m.map, 3 * n + ntask_map)) != hipSuccess || (e = take(m.dense, ot[n])) != hipSuccess) {
+            (e = take(m.sorted, 12 * total + 16)) != hipSuccess || (e = take(m.small, 5 * n)) != hipSuccess || (e = take(m.tmp, 2 * ot[n])) != hipSuccess ||
+            (e = take(m.map, 3 * n + ntask_map)) != hipSuccess || (e = take(m.dense, ot[n])) != hipSuccess ||
+            (e = take(m.pieces, 4 * n_pieces + 4 * n)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;  // no room on the device: the host stage takes the batch
         }
@@ -1541,6 +1547,19 @@ int32_t device_mea(npr_batch *b) {
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rp[x + 1] - rp[x] > rp[y + 1] - rp[y]; });
     HIP_TRY(ctx, hipMemcpyAsync(m.map.p + 2 * n + ntask_map, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    {
+        // layout of m.pieces: np[n] | poff[n] | pboff[n] | lane_read[P] | lane_piece[P] | pbest[P] | pb[P + n]; lanes in the reads' order
+        std::vector<int32_t> tab(3 * n + 2 * n_pieces);
+        int32_t *const t_np = tab.data(), *const t_poff = t_np + n, *const t_pboff = t_poff + n, *const t_lr = t_pboff + n, *const t_lp = t_lr + n_pieces;
+        int64_t at = 0;
+        for (int64_t k = 0; k < n; ++k) {
+            const int32_t r = order[k];
+            t_np[r] = np[r], t_poff[r] = static_cast<int32_t>(at), t_pboff[r] = static_cast<int32_t>(at + k);
+            for (int32_t j = 0; j < np[r]; ++j) t_lr[at + j] = r, t_lp[at + j] = j;
+            at += np[r];
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(m.pieces.p, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
     std::vector<int64_t> offs(4 * (n + 1));
     std::copy(rx.begin(), rx.end(), offs.begin());
     std::copy(ry.begin(), ry.end(), offs.begin() + (n + 1));
@@ -1558,8 +1577,12 @@ int32_t device_mea(npr_batch *b) {
     a.rx_off = m.off.p, a.ry_off = m.off.p + (n + 1), a.rp_off = m.off.p + 2 * (n + 1), a.ot_off = m.off.p + 3 * (n + 1);
     a.cnt = m.cnt.p, a.start = m.start.p, a.colsum = m.col.p;
     a.sx = m.sorted.p, a.sy = m.sorted.p + total + 1, a.sq = m.sorted.p + 2 * (total + 1), a.back = m.sorted.p + 3 * (total + 1);
-    a.best_who = m.small.p, a.read_flag = m.small.p + n, a.n_ops = m.small.p + 2 * n, a.chain_len = m.small.p + 3 * n;
+    a.kx = m.sorted.p + 4 * (total + 1), a.ky = m.sorted.p + 5 * (total + 1), a.kq = m.sorted.p + 6 * (total + 1), a.kback = m.sorted.p + 7 * (total + 1);
+    a.vrec = reinterpret_cast<int4 *>(m.sorted.p + ((8 * (total + 1) + 3) & ~int64_t(3)));  // (16-byte records: the arena's tables start 256-byte aligned)
+    a.best_who = m.small.p, a.read_flag = m.small.p + n, a.n_ops = m.small.p + 2 * n, a.chain_len = m.small.p + 3 * n, a.kept = m.small.p + 4 * n;
     a.chain_mass = m.mass.p;
+    a.np = m.pieces.p, a.poff = m.pieces.p + n, a.pboff = m.pieces.p + 2 * n, a.lane_read = m.pieces.p + 3 * n, a.lane_piece = m.pieces.p + 3 * n + n_pieces;
+    a.pbest = m.pieces.p + 3 * n + 2 * n_pieces, a.pb = m.pieces.p + 3 * n + 3 * n_pieces, a.n_pieces = static_cast<int32_t>(n_pieces);
     a.gap_gamma = b->params.gap_gamma, a.match_gamma = b->params.match_gamma, a.ring = ring;
     a.ring_only = std::getenv("NPR_MEA_RING_ONLY") ? 1 : 0;
     a.read_first = m.map.p, a.read_ntasks = m.map.p + n, a.task_of = m.map.p + 2 * n, a.order = m.map.p + 2 * n + ntask_map;
@@ -1568,7 +1591,7 @@ int32_t device_mea(npr_batch *b) {
     int rc = launch_mea_sort(a, ctx->stream);
     if (rc == 0) rc = launch_mea_chain(a, ctx->stream);
     if (rc != 0) return fail(ctx, NPR_ERR_HIP, "MEA kernel launch", static_cast<hipError_t>(rc));
-    std::vector<int32_t> small(4 * n);
+    std::vector<int32_t> small(5 * n);
     std::vector<int64_t> mass(n);
     HIP_TRY(ctx, hipMemcpyAsync(small.data(), m.small.p, m.small.bytes(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mass.data(), m.mass.p, m.mass.bytes(), hipMemcpyDeviceToHost, ctx->stream));
@@ -1670,7 +1693,7 @@ static int32_t batch_finish_impl(npr_batch *b) {
     if (b->params.mode == NPR_MODE_REALIGN && n > 0 && ntasks > 0 && !std::getenv("NPR_HOST_MEA")) {
         int64_t scratch = 0;
         for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 36 * std::min(b->ref_len[i], b->read_len[i]) + 128;
-        scratch += 16 * b->pair_off[n];
+        scratch += 48 * b->pair_off[n];
         size_t mem_free = 0, mem_total = 0;
         const size_t arena_bytes = ctx->arena->cells.load() * 8;
         if (static_cast<size_t>(scratch) <= arena_bytes ||

@@ -117,6 +117,17 @@ struct MeaArgs {
     const int64_t *rp_off;   // pairs: the read's slice of sx / sy / sq / back
     int32_t *cnt, *start, *colsum;
     int32_t *sx, *sy, *sq, *back;
+    // the kept pairs (weight above matchGamma) of every read, at the read's slice too: by id = in (x, y) order (kx, ky, kq and
+    // the chain's back pointers kback), and in the order the chain visits them (vrec: read position, weight, id, 0)
+    int32_t *kx, *ky, *kq, *kback;
+    int4 *vrec;
+    int32_t *kept;           // per read: kept pairs; -1: the ring kernel took the read (back pointers over the sorted pairs)
+    // the pieces a read's chain problem is cut into (k_mea_cuts): np[r] planned pieces, boundaries pb[pboff[r] + 0 .. np[r]] among
+    // the kept pairs, the last pair of each piece's heaviest chain pbest[poff[r] + j]; lane s of k_mea_chain_lanes takes piece
+    // lane_piece[s] of read lane_read[s]
+    const int32_t *np, *poff, *pboff, *lane_read, *lane_piece;
+    int32_t *pb, *pbest;
+    int32_t n_pieces;
     int32_t *best_who;       // last pair of the heaviest chain, -1 if none
     int32_t *read_flag;      // 0 or an NPR_ERR_* raised by this stage
     double gap_gamma, match_gamma;

@@ -9,13 +9,18 @@
 //                  add the quantum to its read position's column sum
 //   k_mea_scan     per read: exclusive scan of the counts -> first sorted slot of every reference position
 //   k_mea_scatter  per pair: move to its reference position's group (order inside a group arbitrary)
-//   k_mea_chain_win  one wavefront per read: groups in reference order; inside a 64-pair chunk the lanes sort their
-//                  groups by read position, weigh the pairs (posterior - gapGamma * gap mass of row and column) and
-//                  drop those not above matchGamma; the heaviest chain ending below every read position y is a
-//                  monotone prefix maximum kept in registers for a window of 128 read positions (a query is a
-//                  readlane, an insert one compare-and-select); ties go to the pair that sorts last
-//   k_mea_chain    the same with the prefix maximum in an LDS ring of any length, for the reads whose pairs reach
-//                  back further than the window (none on usual data)
+//   k_mea_weigh    one workgroup per read, a thread per sorted pair: the pair's weight (posterior - gapGamma * gap mass of
+//                  its row and column), the pairs not above matchGamma dropped, the kept ones written out twice -- in
+//                  (x, y) order (their ids: what back pointers and the trace use) and in the order the chain visits them
+//                  (reference positions in order, the pairs of one position from the highest read position down)
+//   k_mea_chain_lanes  ONE LANE per read, 64 reads per wavefront (round 4; before: one wavefront per read, every
+//                  instruction doing one lane's worth of work -- 21 ms for 4.5e8 pairs, half of the finish): each lane walks
+//                  its read's kept pairs; the heaviest chain ending at or below every read position is a monotone prefix
+//                  maximum held for a window of 128 read positions in the lane's column of an LDS table; ties go to the
+//                  pair that sorts last
+//   k_mea_chain    one wavefront per read with the prefix maximum in an LDS ring of any length, over the sorted pairs
+//                  themselves (prep_chunk weighs them): the reads whose pairs reach back further than the window (none
+//                  on usual data; forced in the tests)
 //   k_mea_trace    one wavefront per read: walk the back pointers from the best chain's last pair, writing the ops
 //                  backwards (run-length merged) into the read's scratch, and sum the chain's posterior mass
 //   k_mea_gather   dense copy of every read's ops, one word each, for one D2H
@@ -221,85 +226,292 @@ __device__ __forceinline__ Chunk prep_chunk(const MeaArgs &a, int *sx, int *sy, 
     return c;
 }
 
-// The heaviest chain ending at or below each read position, for the 128 positions [ybase, ybase + 127], in registers:
-// position k lives in lane k & 63, register (k >> 6) & 1.  Positions above the window all hold `top`.  A chain is one
-// 64-bit key, score << 23 | (last pair + 1): "heavier, ties to the pair that sorts last" is an integer compare (scores
-// are not negative: a chain of negative weight beats nothing, the empty chain included, so it is never inserted).
-// An insert at position vy raises every held position >= vy the new chain beats -- one compare-and-select per
-// register, no loop: the prefix maximum is monotone.  The window moves up when an insert lands above it (the
-// positions it leaves are forgotten); a query or insert below the window hands the read to the LDS-ring kernel
-// (MEA_RETRY), and so do reads too long for the key (scores from 2^40, pairs from 2^23).
-constexpr int WHO_BITS = 23;
-__global__ void __launch_bounds__(WAVE) k_mea_chain_win(MeaArgs a) {
-    __shared__ int64_t tw[WAVE];
-    __shared__ int ty[WAVE], tq[WAVE];
-    const int lane = threadIdx.x;
-    const int r = a.order[blockIdx.x];
+// Weights of a read's sorted pairs and the two compacted forms of the kept ones.  The pairs of a reference position (a
+// "group") are contiguous after the sort, in arbitrary order; a thread looks at its own group only: the group's posterior
+// mass (row sum), which of its pairs are kept, where its own pair ranks among them.  ids: the kept pairs in (x, y) order
+// (the order ties are decided by: the later pair wins, as in npr_host.cpp's mea_cigar); visit order: groups in order, a
+// group from its highest read position down (a pair must not see the chains of its own reference position, and an insert
+// at y leaves every position below y alone).
+constexpr int WEIGH_CHUNK = 128;  // positions a wavefront weighs per round (two per lane)
+constexpr int WEIGH_RING = 512;   // LDS ring of staged positions: the round's chunk, the one before and the one after, and the one being loaded
+constexpr int WEIGH_HALO = 64;    // a group (the pairs of one reference position) is looked for this far on both sides
+__device__ __forceinline__ int64_t pair_weight(int q, int rowsum, int colsum, double gap_gamma) {
+    const int64_t gap = max(P1 - rowsum, int64_t(0)) + max(P1 - colsum, int64_t(0));
+    return q - static_cast<int64_t>(floor(gap_gamma * static_cast<double>(gap)));
+}
+// One wavefront per read, rounds of 128 sorted positions.  The positions are staged in an LDS ring with the column sums of their
+// read positions -- the chunk after the round's is fetched while the round is worked on (its x / y / q a round ahead, its column
+// sums when they have arrived) --, and everything a lane then does for its two pairs -- the bounds and the posterior mass of
+// their groups, which of a group's pairs are kept, the pair's rank among them -- reads LDS.  Many reads are in flight per CU (a
+// wavefront and 8 KB of LDS each), which is what hides the latency of a round's one dependent load.  A group that reaches past the
+// halo (more than 64 pairs on one reference position: cannot happen above a 0.01 threshold) hands the read to the ring kernel,
+// which reports it.
+__global__ void __launch_bounds__(WAVE) k_mea_weigh(MeaArgs a) {
+    __shared__ int X[WEIGH_RING], Y[WEIGH_RING], Q[WEIGH_RING], C[WEIGH_RING];
+    const int r = a.order[blockIdx.x], lane = threadIdx.x;
     const int64_t rp = a.rp_off[r], ry = a.ry_off[r];
     const int n = a.read_flag[r] ? 0 : static_cast<int>(a.rp_off[r + 1] - rp);  // (flagged: the scatter was incomplete)
-    const int lmin = static_cast<int>(min(a.rx_off[r + 1] - a.rx_off[r] - 1, a.ry_off[r + 1] - ry));
-    if (a.ring_only || n >= (1 << WHO_BITS) - 1 || lmin > 100000) {
-        if (lane == 0 && a.read_flag[r] == 0) a.read_flag[r] = MEA_RETRY;
-        return;
-    }
-    int *const sx = a.sx + rp, *const sy = a.sy + rp, *const sq = a.sq + rp, *const back = a.back + rp;
+    const int *const sx = a.sx + rp, *const sy = a.sy + rp, *const sq = a.sq + rp;
+    const int *const col = a.colsum + ry;
     const int64_t floor_w = static_cast<int64_t>(floor(a.match_gamma * static_cast<double>(P1)));
-    constexpr int64_t WHO_MASK = (int64_t(1) << WHO_BITS) - 1;
-    int ybase = 0;
-    int64_t p0 = 0, p1 = 0, top = 0;
-    int k0 = lane, k1 = lane + 64;  // positions held
-    int flag = 0;
-    // heaviest chain over the pairs inserted so far with read position <= key
-    auto query = [&](int key) -> int64_t {
-        if (static_cast<unsigned>(key - ybase) < 128u) return (key & 64) ? rdlane64(p1, key & 63) : rdlane64(p0, key & 63);  // the usual case
-        if (key < 0) return 0;
-        if (key > ybase + 127) return top;
-        flag = MEA_RETRY;  // below the window
-        return 0;
+    constexpr int RM = WEIGH_RING - 1;
+    const int nc = (n + WEIGH_CHUNK - 1) / WEIGH_CHUNK;
+    int giveup = 0;
+    // registers of the chunk in flight: positions base + lane, base + 64 + lane
+    int fx[2], fy[2], fq[2];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = chunk * WEIGH_CHUNK + h * WAVE + lane;
+            const bool ok = j < n;
+            fx[h] = ok ? sx[j] : -1, fy[h] = ok ? sy[j] : 0, fq[h] = ok ? sq[j] : 0;  // (-1: no position's group)
+        }
     };
-    auto insert = [&](int vy, int64_t total, int who) {
-        if (total < 0) return;
-        const int64_t v = (total << WHO_BITS) | static_cast<int64_t>(who + 1);
-        if (static_cast<unsigned>(vy - ybase) >= 128u) {
-            if (vy < ybase) {
-                flag = MEA_RETRY;
-            } else {  // move the window up: the positions it gains hold the overall maximum
-                ybase = vy - 127;
-                if (k0 < ybase) p0 = top;
-                if (k1 < ybase) p1 = top;
-                k0 = ybase + ((lane - ybase) & 127), k1 = ybase + ((lane + 64 - ybase) & 127);
-            }
+    auto stage = [&](int chunk) {  // the fetched chunk and its column sums into the ring
+        int fc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fc[h] = fx[h] >= 0 ? col[fy[h]] : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = (chunk * WEIGH_CHUNK + h * WAVE + lane) & RM;
+            X[k] = fx[h], Y[k] = fy[h], Q[k] = fq[h], C[k] = fc[h];
         }
-        top = max(top, v);
-        if (k0 >= vy) p0 = max(p0, v);
-        if (k1 >= vy) p1 = max(p1, v);
     };
-    for (int base = 0; base < n && !flag;) {
-        const Chunk c = prep_chunk(a, sx, sy, sq, ry, base, n, lane, floor_w, tw, ty, tq);
-        if (!c.valid) {
-            flag = MEA_RETRY;
-            break;
-        }
-        int bk = -1;
-        // The pairs of one reference position must not see each other's chains.  Taken from the highest read position
-        // down (the lane order prep_chunk leaves), each can query and insert in one go: an insert at y leaves every
-        // position below y alone.
-        for (uint64_t todo = c.keep; todo; todo &= todo - 1) {
-            const int i = __builtin_ctzll(todo), y = rdlane(c.y, i);
-            const int64_t k = query(y - 1);
-            if (lane == i) bk = static_cast<int>(k & WHO_MASK) - 1;
-            insert(y, rdlane64(c.w, i) + (k >> WHO_BITS), base + rdlane(c.who, i));
-        }
-        if ((c.keep >> lane) & 1) back[base + c.who] = bk;
-        base += c.valid;
+    for (int k = lane; k < WEIGH_CHUNK; k += WAVE) X[(-WEIGH_CHUNK + k) & RM] = -2;  // "chunk -1": before the first position
+    if (nc > 0) {
+        fetch(0);
+        stage(0);
+        fetch(1);
     }
+    int carry = 0;  // kept pairs before this round's positions
+    for (int c = 0; c < nc; ++c) {
+        stage(c + 1);  // (past the end: sentinels)
+        fetch(c + 2);
+        wave_sync();
+        int keep[2], below[2], above[2], before[2], xs[2], ys[2], qs[2];
+        int64_t ws[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = c * WEIGH_CHUNK + h * WAVE + lane, me = i & RM;
+            const bool in = i < n;
+            const int x = X[me], y = Y[me], q = Q[me];
+            int gs = i, ge = i, rowsum = q;
+            if (in) {
+                while (gs > i - WEIGH_HALO && X[(gs - 1) & RM] == x) rowsum += Q[(--gs) & RM];
+                while (ge < i + WEIGH_HALO && X[(ge + 1) & RM] == x) rowsum += Q[(++ge) & RM];
+                if (gs == i - WEIGH_HALO || ge == i + WEIGH_HALO) giveup = 1;  // (the group may go on beyond the halo)
+            }
+            const int64_t w = in ? pair_weight(q, rowsum, C[me], a.gap_gamma) : 0;
+            keep[h] = in && w > floor_w;
+            // kept pairs of the group: at positions before mine, with a smaller / a larger read position
+            before[h] = below[h] = above[h] = 0;
+            if (keep[h])
+                for (int j = gs; j <= ge; ++j) {
+                    const int k = j & RM;
+                    if (j != i && pair_weight(Q[k], rowsum, C[k], a.gap_gamma) > floor_w) before[h] += j < i, below[h] += Y[k] < y, above[h] += Y[k] > y;
+                }
+            xs[h] = x, ys[h] = y, qs[h] = q, ws[h] = w;
+        }
+        // exclusive prefix count of the kept pairs by position: the first halves of all lanes, then the second halves
+        int sc0 = keep[0], sc1 = keep[1];
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int t0 = __shfl_up(sc0, o), t1 = __shfl_up(sc1, o);
+            if (lane >= o) sc0 += t0, sc1 += t1;
+        }
+        const int tot0 = __shfl(sc0, WAVE - 1), tot1 = __shfl(sc1, WAVE - 1);
+        const int ex[2] = {sc0 - keep[0], tot0 + sc1 - keep[1]};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (keep[h]) {
+                const int64_t g0 = rp + carry + ex[h] - before[h];  // kept pairs before the group
+                const int64_t id = g0 + below[h], at = g0 + above[h];
+                a.kx[id] = xs[h], a.ky[id] = ys[h], a.kq[id] = qs[h];
+                a.vrec[at] = make_int4(ys[h], static_cast<int>(ws[h]), static_cast<int>(id - rp), 0);
+            }
+        carry += tot0 + tot1;
+        wave_sync();
+    }
+    giveup = __any(giveup);
     if (lane == 0) {
-        a.best_who[r] = static_cast<int>(top & WHO_MASK) - 1;
-        if (flag) a.read_flag[r] = flag;
+        a.kept[r] = giveup ? -1 : carry;
+        if (giveup && a.read_flag[r] == 0) a.read_flag[r] = MEA_RETRY;
     }
 }
 
-// The general version, for the reads k_mea_chain_win gave up on: the prefix maximum in an LDS ring of `ring` read
+// Where a read's chain may be cut.  Between the kept pairs i and i + 1 (ids: (x, y) order) the read's chain problem falls apart
+// when every pair up to i lies below AND left of every pair from i + 1 on: prefix maximum of y over [0, i] < suffix minimum of y
+// over (i, m), and x[i] < x[i + 1].  Every pair behind such a cut dominates every pair before it, so a chain behind it is the
+// heaviest chain before it plus a chain of the pairs behind it alone: the pieces are independent problems, the best chain is the
+// concatenation of theirs, ties included (a later pair wins a tie, and every pair of a later piece is later).  On nanopore
+// posteriors two pairs in three are such cuts.  The host plans np[r] pieces of about 1200 kept pairs; one wavefront per read
+// looks for a cut inside the 64-pair block at each planned boundary (forward sweep: prefix maxima at those blocks; backward
+// sweep: suffix minima) and writes the boundaries it found, pb[0] = 0 <= pb[1] <= .. <= pb[np] = m; a planned boundary without
+// a cut in its block leaves its piece empty (the neighbour takes the pairs).
+constexpr int MEA_MAX_PIECES = 64;
+__global__ void __launch_bounds__(WAVE) k_mea_cuts(MeaArgs a) {
+    __shared__ int PM[MEA_MAX_PIECES][WAVE];
+    const int r = a.order[blockIdx.x], lane = threadIdx.x;
+    const int np = a.np[r];
+    int *const pb = a.pb + a.pboff[r];
+    const int m = a.read_flag[r] == 0 ? max(a.kept[r], 0) : 0;
+    const int64_t rp = a.rp_off[r];
+    const int *const kx = a.kx + rp, *const ky = a.ky + rp;
+    const int nb = (m + WAVE - 1) / WAVE;
+    if (np <= 1 || nb < 2) {
+        for (int k = lane; k <= np; k += WAVE) pb[k] = k == 0 ? 0 : m;  // one piece with everything, the others empty
+        return;
+    }
+    auto target = [&](int j) { return static_cast<int>(static_cast<int64_t>(j) * nb / np); };  // block of the j-th planned boundary
+    constexpr int NEG = -(1 << 30), POS = 1 << 30;
+    // forward: inclusive prefix maximum of y at the target blocks
+    int rm = NEG, j = 1;
+    for (int b = 0; b < nb && j < np; ++b) {
+        const int idx = b * WAVE + lane;
+        const int v = idx < m ? ky[idx] : NEG;
+        if (target(j) == b) {
+            int before = rm;
+            for (int o = 32; o; o >>= 1) before = max(before, __shfl_xor(before, o));
+            int sc = v;
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const int t = __shfl_up(sc, o);
+                if (lane >= o) sc = max(sc, t);
+            }
+            const int pm = max(sc, before);
+            while (j < np && target(j) == b) PM[j][lane] = pm, ++j;
+        }
+        rm = max(rm, v);
+    }
+    // backward: exclusive suffix minimum at the target blocks; a cut where the prefix maximum lies below it
+    int rn = POS;
+    j = np - 1;
+    for (int b = nb - 1; b >= 0 && j >= 1; --b) {
+        const int idx = b * WAVE + lane;
+        const int v = idx < m ? ky[idx] : POS;
+        if (target(j) == b) {
+            int after = rn;
+            for (int o = 32; o; o >>= 1) after = min(after, __shfl_xor(after, o));
+            int sc = v;  // inclusive suffix minimum
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const int t = __shfl_down(sc, o);
+                if (lane + o < WAVE) sc = min(sc, t);
+            }
+            int ex = __shfl_down(sc, 1);  // of the lanes above
+            if (lane == WAVE - 1) ex = POS;
+            const int sm = min(ex, after);
+            const bool can = idx + 1 < m && kx[idx] != kx[idx + 1];
+            while (j >= 1 && target(j) == b) {
+                const uint64_t ok = __ballot(can && PM[j][lane] < sm);
+                int at = -1;
+                if (ok >> 32) at = 32 + __builtin_ctzll(ok >> 32);
+                else if (ok) at = 63 - __builtin_clzll(ok);
+                if (lane == 0) pb[j] = at < 0 ? -1 : b * WAVE + at + 1;
+                --j;
+            }
+        }
+        rn = min(rn, v);
+    }
+    wave_sync();
+    if (lane == 0) {
+        pb[0] = 0, pb[np] = m;
+        for (int k = 1; k < np; ++k)
+            if (pb[k] < pb[k - 1]) pb[k] = pb[k - 1];  // (no cut in the block, or two planned boundaries in one block)
+    }
+}
+
+// One LANE per piece of a read (k_mea_cuts), 64 pieces per wavefront.  A chain is one 64-bit key, score << 23 | (id of its last
+// pair + 1): "heavier, ties to the pair that sorts last" is an integer compare (scores are not negative: a chain of negative
+// weight beats nothing, the empty chain included, so it is never inserted).  M[k & 63] (the lane's column of the LDS table) =
+// heaviest chain over the pairs inserted so far with read position <= k, for the 64 positions up to ymax; every position
+// above ymax holds `top`.  The prefix maximum is monotone, so an insert at y raises the run of positions from y on that the
+// new chain beats and stops at the first it does not.  A query or an insert more than the window below ymax hands the READ to
+// the LDS-ring kernel (MEA_RETRY; kept[r] = -1 tells the trace that the read's back pointers are positions among the sorted
+// pairs, not ids), and so do reads too long for the key (scores from 2^40, pairs from 2^23).  Nothing hides a step's latency
+// in a launch of few wavefronts, so the records are fetched a block of LBLK steps ahead: no memory in the dependent chain but the
+// lane's own LDS column.
+constexpr int WHO_BITS = 23;
+constexpr int LWIN = 64;
+constexpr int LBLK = 8;
+__global__ void __launch_bounds__(WAVE) k_mea_chain_lanes(MeaArgs a) {
+    extern __shared__ __align__(16) char lds_raw[];
+    int64_t *const M = reinterpret_cast<int64_t *>(lds_raw) + threadIdx.x;  // M[k * WAVE]: the lane's own banks
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * WAVE + lane;
+    const int r = slot < a.n_pieces ? a.lane_read[slot] : -1;
+    int m = 0, flag = 0;
+    int64_t first = 0;
+    int *best = nullptr;
+    if (r >= 0) {
+        const int j = a.lane_piece[slot];
+        best = a.pbest + a.poff[r] + j;
+        if (a.read_flag[r] == 0 && a.kept[r] >= 0) {
+            const int lmin = static_cast<int>(min(a.rx_off[r + 1] - a.rx_off[r] - 1, a.ry_off[r + 1] - a.ry_off[r]));
+            if (a.ring_only || a.rp_off[r + 1] - a.rp_off[r] >= (1 << WHO_BITS) - 1 || lmin > 100000) {
+                flag = MEA_RETRY;
+            } else {
+                const int *const pb = a.pb + a.pboff[r] + j;
+                first = a.rp_off[r] + pb[0];
+                m = pb[1] - pb[0];
+            }
+        }
+    }
+    const int4 *const vrec = a.vrec + first;
+    int *const kback = a.kback + (r >= 0 ? a.rp_off[r] : 0);
+    constexpr int64_t WHO_MASK = (int64_t(1) << WHO_BITS) - 1;
+    int mmax = m;
+    for (int o = 32; o; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o));
+    int ymax = -1;
+    int64_t top = 0;
+    int4 nxt[LBLK];
+#pragma unroll
+    for (int k = 0; k < LBLK; ++k) nxt[k] = k < m ? vrec[k] : make_int4(0, 0, 0, 0);
+    for (int t0 = 0; t0 < mmax; t0 += LBLK) {
+        int4 cur[LBLK];
+#pragma unroll
+        for (int k = 0; k < LBLK; ++k) cur[k] = nxt[k];
+#pragma unroll
+        for (int k = 0; k < LBLK; ++k) nxt[k] = t0 + LBLK + k < m ? vrec[t0 + LBLK + k] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < LBLK; ++k) {
+            const int y = cur[k].x, w = cur[k].y, id = cur[k].z;
+            if (t0 + k < m && !flag) {
+                // heaviest chain over the pairs inserted so far with read position < y
+                const int key = y - 1;
+                int64_t kk = 0;
+                if (key > ymax) kk = top;
+                else if (key >= 0) {
+                    if (key <= ymax - LWIN) flag = MEA_RETRY;
+                    else kk = M[(key & (LWIN - 1)) * WAVE];
+                }
+                kback[id] = static_cast<int>(kk & WHO_MASK) - 1;
+                const int64_t total = w + (kk >> WHO_BITS);
+                if (total >= 0 && !flag) {
+                    const int64_t v = (total << WHO_BITS) | static_cast<int64_t>(id + 1);
+                    if (y > ymax) {  // the positions in between hold what every position above ymax holds
+                        for (int p = max(ymax + 1, y - (LWIN - 1)); p < y; ++p) M[(p & (LWIN - 1)) * WAVE] = top;
+                        top = max(top, v);
+                        M[(y & (LWIN - 1)) * WAVE] = top;
+                        ymax = y;
+                    } else if (y <= ymax - LWIN) {
+                        flag = MEA_RETRY;
+                    } else {
+                        for (int p = y; p <= ymax; ++p) {
+                            int64_t *const e = M + (p & (LWIN - 1)) * WAVE;
+                            if (*e >= v) break;
+                            *e = v;
+                        }
+                        top = max(top, v);
+                    }
+                }
+            }
+        }
+    }
+    if (r >= 0) {
+        *best = static_cast<int>(top & WHO_MASK) - 1;
+        if (flag) a.read_flag[r] = flag, a.kept[r] = -1;  // (every piece of the read may write this: the same values)
+    }
+}
+
+// The general version, for the reads k_mea_chain_lanes gave up on: the prefix maximum in an LDS ring of `ring` read
 // positions (score int64, who int32); an insert overwrites the run of entries the new chain beats, all lanes at once.
 __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
     extern __shared__ __align__(16) char lds[];
@@ -392,7 +604,9 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
 __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
     const int r = a.order[blockIdx.x], lane = threadIdx.x;
     const int64_t rp = a.rp_off[r];
-    const int *sx = a.sx + rp, *sy = a.sy + rp, *sq = a.sq + rp, *back = a.back + rp;
+    // the kept pairs by id (k_mea_chain_lanes), or the sorted pairs themselves for a read the ring kernel took over
+    const bool by_id = __builtin_amdgcn_readfirstlane(a.kept[r]) >= 0;
+    const int *sx = (by_id ? a.kx : a.sx) + rp, *sy = (by_id ? a.ky : a.sy) + rp, *sq = (by_id ? a.kq : a.sq) + rp, *back = (by_id ? a.kback : a.back) + rp;
     const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
     int2 *const lo = reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r];
     int2 *p = reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r + 1];  // filled from the end
@@ -411,7 +625,12 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
     };
     int cx = lX, cy = lY, len = 0;
     int64_t mass = 0;
-    int i = a.read_flag[r] == 0 ? __builtin_amdgcn_readfirstlane(a.best_who[r]) : -1;
+    // the pieces of the read from the last to the first, each from its heaviest chain's last pair down (by_id); one chain else
+    const bool alive = a.read_flag[r] == 0;
+    int piece = by_id ? __builtin_amdgcn_readfirstlane(a.np[r]) : 1;
+    const int *const pbest = a.pbest + (by_id ? a.poff[r] : 0);
+    while (piece-- > 0) {
+    int i = !alive ? -1 : __builtin_amdgcn_readfirstlane(by_id ? pbest[piece] : a.best_who[r]);
     while (i >= 0) {
         const int cb = max(i - (WAVE - 1), 0), idx = min(cb + lane, i);
         const int vb = back[idx], vx = sx[idx], vy = sy[idx], vq = sq[idx];
@@ -435,6 +654,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
             cx = hx, cy = hy, mass += rdlane(val, l) + rdlane(vq, h), len += x - hx + 1;
             i = rdlane(vb, h);
         }
+    }
     }
     emit(NPR_OP_I, cy);
     emit(NPR_OP_D, cx);
@@ -482,7 +702,12 @@ int launch_mea_chain(const MeaArgs &a, void *stream) {
     const size_t lds = mea_chain_lds_bytes(a.ring);
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mea_chain), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL(k_mea_chain_win, dim3(a.n_reads), dim3(WAVE), 0, s, a);
+    const int lanes_lds = LWIN * WAVE * static_cast<int>(sizeof(int64_t));
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mea_chain_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, lanes_lds);
+    if (e2 != hipSuccess) return static_cast<int>(e2);
+    hipLaunchKernelGGL(k_mea_weigh, dim3(a.n_reads), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL(k_mea_cuts, dim3(a.n_reads), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL(k_mea_chain_lanes, dim3((a.n_pieces + WAVE - 1) / WAVE), dim3(WAVE), lanes_lds, s, a);
     hipLaunchKernelGGL(k_mea_chain, dim3(a.n_reads), dim3(WAVE), lds, s, a);  // returns at once unless the read was handed over
     hipLaunchKernelGGL(k_mea_trace, dim3(a.n_reads), dim3(WAVE), 0, s, a);
     return static_cast<int>(hipGetLastError());
