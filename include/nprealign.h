@@ -134,6 +134,34 @@ const char *npr_last_error(npr_ctx *ctx);
  * another batch's DP pass), and the DP launches of narrow bands leave one wavefront slot per SIMD free so that the staging
  * and MEA kernels of the other batches find room beside them.  Results do not change. */
 #define NPR_OPT_OVERLAP 1
+/* NPR_OPT_RELEASE_SCRATCH (an action; value ignored): the device's forward scratch (shared by the contexts of the device; the
+ * next batch that needs it allocates it again) and this context's cache of released device buffers go back to the driver.  For
+ * a process that stays alive after a big batch (the parent of a pipeline, a test session) next to others that need the HBM. */
+#define NPR_OPT_RELEASE_SCRATCH 2
+/* TEST AND BRING-UP SWITCHES (all 0 by default; none changes a result -- every kernel class computes the same bits or is checked
+ * against the same oracle -- only which kernel runs or where a table lives).  They select the code paths the parity tests
+ * compare with each other; a caller of the drop-in path never sets them.  Since round 4 these are context options, not
+ * environment variables: what the library runs does not depend on the caller's environment.  (Still read from the environment,
+ * and changing no choice of kernel: NPR_TIMING=1 stage times on stderr, NPR_POISON=<byte> device buffers filled when handed
+ * out, NPR_TILE_PROF=1 wait cycles of the stripe kernel, NPR_HOST_THREADS=<n> host worker threads.) */
+#define NPR_OPT_KERNEL 3           /* 1: the any-band kernel (k_dp_generic) for every task */
+#define NPR_OPT_ARITH 4            /* 1: one exponent per cell (k_dp_stair / k_dp_pair) instead of one per row (k_dp_rs / k_dp_pair_rs) */
+#define NPR_OPT_PAIR 5             /* a read's two sweeps on two wavefronts: 0 the default rule, 1 never, 2 the tasks longer than a fair share, 3 always */
+#define NPR_OPT_NO_TILE 6          /* 1: no stripe kernel (wide bands take k_dp_wide / k_dp_generic) */
+#define NPR_OPT_NO_WIDE 7          /* 1: no multi-wavefront frame kernel */
+#define NPR_OPT_TILE_RS 8          /* 1: the stripe kernel in row-scaled arithmetic */
+#define NPR_OPT_TILE_WAVES 9       /* wavefronts per stripe task (1 .. 8; 0: default 4) */
+#define NPR_OPT_WAVES_PER_CU 10    /* resident wavefronts / workgroups per CU of every DP launch (0: per class) */
+#define NPR_OPT_CLASS_MIN 11       /* smallest frame class considered */
+#define NPR_OPT_VARIABLE_SCRATCH 12 /* scratch regions sized per task: 0 above 32 GB, 1 always, 2 never */
+#define NPR_OPT_HOST_MEA 13        /* 1: chain + cigar on the host in realign mode too */
+#define NPR_OPT_MEA_RING_ONLY 14   /* 1: every read through the LDS-ring chain kernel */
+#define NPR_OPT_MEA_GLOBAL_SORT 15 /* 1: the sort's tables in HBM whatever the span */
+#define NPR_OPT_MEA_OWN_SCRATCH 16 /* 1: the MEA tables in buffers of the context's own, not in the forward scratch */
+#define NPR_OPT_EM_GENERIC 17      /* 1: the E-step on the any-band kernel */
+#define NPR_OPT_EM_SERIAL 18       /* 1: the E-step's launches one after the other */
+#define NPR_OPT_EM_WAVES 19        /* wavefronts per CU of k_em_stair (0: per class) */
+#define NPR_OPT_COUNT 20
 int32_t npr_ctx_option(npr_ctx *ctx, int32_t option, int64_t value);
 
 /* --loadHmm=<file> (utils.py:586-587): the 25 transition and 80 emission PROBABILITIES exactly as they
@@ -186,18 +214,18 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
  *   3-6  register kernel, 4 / 8 / 8 / 12 wavefronts per task, 512 / 1024 / 2048 / 3072 slots (k_dp_wide)
  *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring
  *   11   register kernel on column stripes, any width (k_dp_tile; k_em_tile for npr_batch_expectations); takes what 3-10
- *        would take unless NPR_NO_TILE=1 is set
+ *        would take unless NPR_OPT_NO_TILE is set
  *   12-14  classes 0-2 / 15-17 with the forward and the backward sweep of a task on two wavefronts at once (k_dp_pair_rs<1|2|4>
- *        in row-scaled arithmetic, k_dp_pair<1|2|4> under NPR_ARITH=cell): a launch lasts as long as its longest one-wavefront
+ *        in row-scaled arithmetic, k_dp_pair<1|2|4> under NPR_OPT_ARITH = 1): a launch lasts as long as its longest one-wavefront
  *        chain, which this halves for a pass over twice the rows.  Every task of a class of more than 256 tasks that fills at
- *        most half of the launch's wavefront slots (BASELINE.json configs[1]); NPR_PAIR=0: never, =all: every task, =1: the
+ *        most half of the launch's wavefront slots (BASELINE.json configs[1]); NPR_OPT_PAIR 1: never, 3: every task, =1: the
  *        tasks longer than a wavefront's fair share of their class as far as second wavefronts are free
  *   15-17  classes 0-2 in row-scaled arithmetic (k_dp_rs<1|2|4>: one exponent per anti-diagonal row of the wavefront instead of
- *        one per cell, about 1.4 times the cells per second): every task of 0-2 unless NPR_ARITH=cell is set or a loaded model's
+ *        one per cell, about 1.4 times the cells per second): every task of 0-2 unless NPR_OPT_ARITH = 1 is set or a loaded model's
  *        values can grow from one anti-diagonal to the next.  A task for which one exponent per row was not enough (a stretch of
  *        its alignment ~110 binary orders below the row's largest values: an indel of 70+ bases) is run again by npr_batch_run
  *        with the kernel of 0-2; npr_batch_segment_arith says which arithmetic a segment's results come from.
- *   18   class 11's column stripes in row-scaled arithmetic (k_dp_tile_rs; only under NPR_TILE_RS=1: same bits, not faster yet) */
+ *   18   class 11's column stripes in row-scaled arithmetic (k_dp_tile_rs; only under NPR_OPT_TILE_RS: same bits, not faster yet) */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* Which device arithmetic each segment (matrix split) of each read ran in, in read order: seg_off[n_reads + 1], arith[seg_off
  * [n_reads]] (pass arith == NULL for the offsets alone).  0: one exponent per cell (npr_cell.h: k_dp_tile, k_dp_generic, k_dp_wide

@@ -75,6 +75,7 @@ struct npr_ctx {
     int host_threads = 1;
     DeviceArena *arena = nullptr;  // the device's forward scratch (shared with the other contexts on this device)
     bool overlap = false;          // NPR_OPT_OVERLAP: see include/nprealign.h
+    int64_t opt[NPR_OPT_COUNT] = {};  // npr_ctx_option: the test / bring-up switches (all 0 by default)
     static constexpr size_t kArenaPad = DeviceArena::kPad;
     float *arena_Fx = nullptr;  // E-step only: four more forward planes (per context)
     size_t arena_fx_cells = 0;
@@ -434,11 +435,36 @@ void npr_destroy(npr_ctx *ctx) {
 
 const char *npr_last_error(npr_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
+// NPR_OPT_RELEASE_SCRATCH: the device's forward scratch (shared by the contexts of the device, regrown by the next batch that needs
+// it) and this context's cache of released device buffers go back to the driver -- a process that is done with a big batch
+// and stays alive (a pipeline's parent, a test session) need not keep a hundred GB of HBM from the next one.
+static int32_t release_scratch(npr_ctx *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cache_flush();
+    if (ctx->arena) {
+        std::lock_guard<std::mutex> lock(ctx->arena->mu);
+        if (ctx->arena->F) (void)hipFree(ctx->arena->F - DeviceArena::kPad);
+        ctx->arena->F = nullptr, ctx->arena->cells = 0, ++ctx->arena->epoch;
+    }
+    if (ctx->arena_Fx) (void)hipFree(reinterpret_cast<char *>(ctx->arena_Fx) - npr_ctx::kArenaPad);
+    ctx->arena_Fx = nullptr, ctx->arena_fx_cells = 0;
+    delete ctx->mea;
+    ctx->mea = nullptr;
+    return NPR_OK;
+}
+
 int32_t npr_ctx_option(npr_ctx *ctx, int32_t option, int64_t value) {
     if (!ctx) return NPR_ERR_INVALID;
     switch (option) {
         case NPR_OPT_OVERLAP: ctx->overlap = value != 0; return NPR_OK;
-        default: return fail(ctx, NPR_ERR_INVALID, "npr_ctx_option: unknown option");
+        case NPR_OPT_RELEASE_SCRATCH: return release_scratch(ctx);
+        default:
+            if (option > NPR_OPT_RELEASE_SCRATCH && option < NPR_OPT_COUNT) {
+                ctx->opt[option] = value;
+                return NPR_OK;
+            }
+            return fail(ctx, NPR_ERR_INVALID, "npr_ctx_option: unknown option");
     }
 }
 
@@ -507,8 +533,8 @@ inline bool is_one_wave_kind(int kind) { return kind == K_STAIR || kind == K_RS;
 inline bool is_tile_kind(int kind) { return kind == K_TILE || kind == K_TILE_RS; }  // column stripes, NW wavefronts per task  // one wavefront per task on the frame schedule
 // resident wavefronts per CU of the one-wavefront frame kernels (VGPR-limited: 71 / 80 / 162 registers: 7 / 6 / 3 per SIMD)
 inline int stair_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 12); }
-// ... and of k_dp_rs<R> (72 / 79 / 101 registers: 7 / 6 / 4 per SIMD; R = 2 measured at 5 / 6 / 7 / 8 per SIMD: 6 is best)
-inline int rs_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 24 : 16); }
+// ... and of k_dp_rs<R> (72 / 72 / 105 registers: 7 / 7 / 4 per SIMD; R = 2 measured at 6 / 7 / 8 per SIMD in round 4: 7 is best)
+inline int rs_waves_per_cu(int R) { return R == 1 ? 28 : (R == 2 ? 28 : 16); }
 
 // Whether the row-scaled arithmetic (npr_rs.h) may be used with a model: its rows are renormalised to 2^NPR_RS_TOP every
 // NPR_RS_K anti-diagonals with 2^6 of headroom, so nothing may grow by more than 2^(6 / NPR_RS_K) per anti-diagonal -- the sum of
@@ -786,15 +812,11 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // exists, tried from the smallest frame up (on the device: the schedule is sequential per segment); bands too wide for
     // one wavefront's frame go to the stripe kernel (k_dp_tile), whatever their shape.  A batch staged for the E-step
     // (NPR_MODE_EXPECTATIONS) keeps the classes that have an E-step kernel.
-    const char *force = std::getenv("NPR_KERNEL");  // "generic": no register kernel (A/B runs, tests)
-    const bool force_generic = force && std::strcmp(force, "generic") == 0;
+    const bool force_generic = ctx->opt[NPR_OPT_KERNEL] == 1;  // no register kernel (A/B runs, tests)
     const int lds_max_w = generic_max_wcap();
-    const char *nowide_env = std::getenv("NPR_NO_WIDE");  // "1": no multi-wavefront register kernel (A/B runs, tests)
-    const bool no_wide = nowide_env && nowide_env[0] == '1';
-    const char *cmin_env = std::getenv("NPR_CLASS_MIN");  // bring-up: smallest register class to use
-    const int cmin = cmin_env ? std::atoi(cmin_env) : 0;
-    const char *notile_env = std::getenv("NPR_NO_TILE");  // "1": no stripe kernel (A/B runs, tests)
-    const bool use_tile = !force_generic && !(notile_env && notile_env[0] == '1');  // (E-step batches too: k_em_tile)
+    const bool no_wide = ctx->opt[NPR_OPT_NO_WIDE] != 0;  // no multi-wavefront register kernel (A/B runs, tests)
+    const int cmin = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(kSchedClasses, ctx->opt[NPR_OPT_CLASS_MIN])));  // bring-up: smallest register class to use
+    const bool use_tile = !force_generic && ctx->opt[NPR_OPT_NO_TILE] == 0;  // (E-step batches too: k_em_tile)
     std::vector<uint32_t> cand(ntasks, 0);
     std::vector<int64_t> sched_off(ntasks, -1);
     // (the first task's words start kCtlFrontPad rows into d_ctl: the backward sweep of k_dp_rs reads its control words up to
@@ -859,14 +881,13 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // and a class with fewer tasks than the chip has wavefront slots leaves the rest idle.  Tasks longer than a wavefront's
     // fair share of their class go to k_dp_pair (both sweeps at once on two wavefronts: half the chain, twice the memory
     // traffic), the longest first, as far as a second wavefront is to be had: all of them when the class does not fill the
-    // chip anyway, else those that would outlast the others.  NPR_PAIR=0 / all: never / every task (A/B runs, tests).
+    // chip anyway, else those that would outlast the others.  NPR_OPT_PAIR 1 / 3: never / every task (A/B runs, tests).
     // The one-wavefront frame tasks run in row-scaled arithmetic: classes 15-17, k_dp_rs -- every one of them, provided the
     // loaded models let a row's values be renormalised every NPR_RS_K anti-diagonals (rs_model_ok); a task for which one exponent
-    // per row turns out not to be enough says so and npr_batch_run runs it again in class 0-2's kernel.  NPR_ARITH=cell: none
+    // per row turns out not to be enough says so and npr_batch_run runs it again in class 0-2's kernel.  NPR_OPT_ARITH = 1: none
     // (the per-cell-exponent kernels throughout, A/B).
     {
-        const char *ae = std::getenv("NPR_ARITH");
-        bool rs = !(ae && std::strcmp(ae, "cell") == 0) && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS;
+        bool rs = ctx->opt[NPR_OPT_ARITH] != 1 && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS;
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
             if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) rs = false;
         b->pair_rs = rs;
@@ -875,7 +896,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
                 if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
                 // (the stripe kernel in row-scaled arithmetic, k_dp_tile_rs, is opt-in: same bits, first pass 7 % faster on the
                 // reference's band, but one task in eight fails the range certificate there and runs twice -- DESIGN.md 5.1f)
-                else if (cls_of[k] == kTileClass && std::getenv("NPR_TILE_RS")) cls_of[k] = static_cast<int8_t>(kTileRsClass);
+                else if (cls_of[k] == kTileClass && ctx->opt[NPR_OPT_TILE_RS] != 0) cls_of[k] = static_cast<int8_t>(kTileRsClass);
             }
     }
     bool any_pair = false;
@@ -883,10 +904,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         // By default a class of more than 256 tasks that fill at most half of the chip's wavefront slots goes to the pair kernel as a whole
         // (BASELINE.json configs[1]: 1000 reads on 7168 slots -- DP 1.71 -> 1.42 ms); a fuller class does not (a 1/8 shard of
         // configs[3], 6250 reads: 51 -> 59 ms with every read on two wavefronts, 67 with the longest ones only -- the second
-        // wavefronts then compete with the reads that have one).  NPR_PAIR=0: never; =1: the tasks longer than a
-        // wavefront's fair share; =all: every task.
-        const char *pe = std::getenv("NPR_PAIR");
-        const bool pair_all = pe && std::strcmp(pe, "all") == 0, pair_off = pe && pe[0] == '0', pair_long = pe && pe[0] == '1';
+        // wavefronts then compete with the reads that have one).  NPR_OPT_PAIR 1: never; 2: the tasks longer than a
+        // wavefront's fair share; 3: every task.
+        const int64_t pe = ctx->opt[NPR_OPT_PAIR];
+        const bool pair_all = pe == 3, pair_off = pe == 1, pair_long = pe == 2;
         if (!pair_off && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS)
             for (int c = 0; c < 3; ++c) {
                 std::vector<int32_t> mine;
@@ -1054,7 +1075,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             // anti-diagonals after its left neighbour): measured on 8192 x 8 kb reads in the reference's band, 2 / 3 / 4 / 6 / 8
             // wavefronts per task give 1.26 / 1.71 / 2.06 / 1.42 / 1.64e11 cells/s (more tasks in flight need more scratch)
             int nw = 4;
-            if (const char *w = std::getenv("NPR_TILE_WAVES")) nw = std::min(8, std::max(1, std::atoi(w)));
+            if (ctx->opt[NPR_OPT_TILE_WAVES] > 0) nw = static_cast<int>(std::min<int64_t>(8, ctx->opt[NPR_OPT_TILE_WAVES]));
             waves_per_cu = std::max(1, 24 / nw);
             L.wcap = nw;
             L.lds = kClassTab[c].kind == K_TILE_RS ? tile_rs_lds_bytes(nw) : tile_lds_bytes(nw);
@@ -1073,7 +1094,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             L.threads = 512;
             waves_per_cu = 2;  // workgroups per CU
         }
-        if (const char *w = std::getenv("NPR_WAVES_PER_CU")) waves_per_cu = std::max(1, std::atoi(w));
+        if (ctx->opt[NPR_OPT_WAVES_PER_CU] > 0) waves_per_cu = static_cast<int>(std::min<int64_t>(64, ctx->opt[NPR_OPT_WAVES_PER_CU]));
         int64_t grid = std::min<int64_t>(L.count, static_cast<int64_t>(ctx->cu_count) * waves_per_cu);
         L.grid = static_cast<int>(std::max<int64_t>(1, grid));
         if (std::getenv("NPR_TIMING"))
@@ -1097,8 +1118,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     int64_t stair_grid = 0;
     for (auto &L : b->launches)
         if (is_one_wave_kind(kClassTab[L.cls].kind)) stair_grid += L.grid;
-    int64_t var_min_bytes = int64_t(32) << 30;  // NPR_VARIABLE_SCRATCH_MIN (bytes; 0: always, tests): uniform stair scratch above this goes variable
-    if (const char *v = std::getenv("NPR_VARIABLE_SCRATCH_MIN")) var_min_bytes = std::atoll(v);
+    int64_t var_min_bytes = int64_t(32) << 30;  // uniform stair scratch above this goes variable (NPR_OPT_VARIABLE_SCRATCH: 1 always, 2 never; tests)
+    if (ctx->opt[NPR_OPT_VARIABLE_SCRATCH] == 1) var_min_bytes = 0;
+    if (ctx->opt[NPR_OPT_VARIABLE_SCRATCH] == 2) var_min_bytes = int64_t(1) << 60;
     b->variable_regions = b->params.mode != NPR_MODE_EXPECTATIONS && stair_grid > 0 && stair_grid * b->slot_stride * 8 >= var_min_bytes &&
                           !force_generic;
     if (any_pair) b->variable_regions = true;  // (their regions hold two sets of rows: not a layout the E-step kernels know)
@@ -1509,7 +1531,7 @@ int32_t device_mea(npr_batch *b) {
     // per-position tables of one read in LDS (count + scan + scatter in one kernel) when the longest span fits
     int64_t span = 0;
     for (int64_t i = 0; i < n; ++i) span = std::max(span, rx[i + 1] - rx[i]), span = std::max(span, ry[i + 1] - ry[i]);
-    const bool sort_in_lds = 4 * span <= 64 * 1024 && !std::getenv("NPR_MEA_GLOBAL_SORT");
+    const bool sort_in_lds = 4 * span <= 64 * 1024 && ctx->opt[NPR_OPT_MEA_GLOBAL_SORT] == 0;
     const size_t ntask_map = b->task_of.size();
     // The forward scratch of the DP launches is idle now and usually far larger than what this stage needs: carve the
     // tables out of it (a batch that fills the device's memory leaves nothing to hipMalloc).  Else: grow-only buffers.
@@ -1518,7 +1540,7 @@ int32_t device_mea(npr_batch *b) {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
         const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (12 * total + 16)) +
                             al(4 * 5 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]) + al(4 * (4 * n_pieces + 4 * n));
-        const bool in_arena = !ctx->overlap && ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && !std::getenv("NPR_MEA_OWN_SCRATCH");
+        const bool in_arena = !ctx->overlap && ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && ctx->opt[NPR_OPT_MEA_OWN_SCRATCH] == 0;
         char *cur = ctx->arena->F;
         if (in_arena && poison_byte() >= 0) {  // the DP launches are done (their streams feed this one): the tables start from poison
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1584,7 +1606,7 @@ int32_t device_mea(npr_batch *b) {
     a.np = m.pieces.p, a.poff = m.pieces.p + n, a.pboff = m.pieces.p + 2 * n, a.lane_read = m.pieces.p + 3 * n, a.lane_piece = m.pieces.p + 3 * n + n_pieces;
     a.pbest = m.pieces.p + 3 * n + 2 * n_pieces, a.pb = m.pieces.p + 3 * n + 3 * n_pieces, a.n_pieces = static_cast<int32_t>(n_pieces);
     a.gap_gamma = b->params.gap_gamma, a.match_gamma = b->params.match_gamma, a.ring = ring;
-    a.ring_only = std::getenv("NPR_MEA_RING_ONLY") ? 1 : 0;
+    a.ring_only = ctx->opt[NPR_OPT_MEA_RING_ONLY] != 0 ? 1 : 0;
     a.read_first = m.map.p, a.read_ntasks = m.map.p + n, a.task_of = m.map.p + 2 * n, a.order = m.map.p + 2 * n + ntask_map;
     a.sort_lds_bytes = sort_in_lds ? static_cast<int32_t>(4 * span) : 0;
     a.ops_tmp = m.tmp.p, a.od_off = m.od.p;
@@ -1690,7 +1712,7 @@ static int32_t batch_finish_impl(npr_batch *b) {
     }
     tm.lap("task results");
     // --- realign mode: chain and cigar on the device, the pairs stay in HBM until npr_batch_pairs asks for them ---
-    if (b->params.mode == NPR_MODE_REALIGN && n > 0 && ntasks > 0 && !std::getenv("NPR_HOST_MEA")) {
+    if (b->params.mode == NPR_MODE_REALIGN && n > 0 && ntasks > 0 && ctx->opt[NPR_OPT_HOST_MEA] == 0) {
         int64_t scratch = 0;
         for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 36 * std::min(b->ref_len[i], b->read_len[i]) + 128;
         scratch += 48 * b->pair_off[n];
@@ -1886,17 +1908,17 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         L l{};
         l.first = dl.first, l.count = dl.count;
         l.slot_base = dl.slot_base, l.dp_grid = dl.grid, l.cells = dl.cells, l.region_first = dl.own_regions ? dl.region_first : -1;
-        if (is_one_wave_kind(kClassTab[dl.cls].kind) && !std::getenv("NPR_EM_GENERIC")) {
+        if (is_one_wave_kind(kClassTab[dl.cls].kind) && ctx->opt[NPR_OPT_EM_GENERIC] == 0) {
             // 127 / 161 / 223 VGPRs and 9 KiB of LDS bins per wavefront: 16 / 12 / 8 wavefronts per CU
             l.stair_R = kClassTab[dl.cls].R;
             l.lds = em_stair_lds_bytes();
             int em_waves = l.stair_R == 4 ? 8 : (l.stair_R == 2 ? 12 : 16);
-            if (const char *w = std::getenv("NPR_EM_WAVES")) em_waves = std::max(1, std::atoi(w));  // bring-up
+            if (ctx->opt[NPR_OPT_EM_WAVES] > 0) em_waves = static_cast<int>(std::min<int64_t>(32, ctx->opt[NPR_OPT_EM_WAVES]));  // bring-up
             l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * em_waves)));
             launches.push_back(l);
             continue;
         }
-        if (is_tile_kind(kClassTab[dl.cls].kind) && kClassTab[dl.cls].R == 2 && !std::getenv("NPR_EM_GENERIC")) {
+        if (is_tile_kind(kClassTab[dl.cls].kind) && kClassTab[dl.cls].R == 2 && ctx->opt[NPR_OPT_EM_GENERIC] == 0) {
             // 164 VGPRs: 3 wavefronts per SIMD, 12 per CU -> 3 workgroups of 4; the workgroups keep the scratch regions the DP
             // launch gave them (region i is sized for task i, and everything the queue hands out later is smaller)
             l.stair_R = 2, l.tile = true;
@@ -1905,7 +1927,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
             launches.push_back(l);
             continue;
         }
-        if (kClassTab[dl.cls].kind == K_WIDE && kClassTab[dl.cls].R == 2 && !std::getenv("NPR_EM_GENERIC")) {
+        if (kClassTab[dl.cls].kind == K_WIDE && kClassTab[dl.cls].R == 2 && ctx->opt[NPR_OPT_EM_GENERIC] == 0) {
             // 157 VGPRs: 3 wavefronts per SIMD, 12 per CU -> 3 / 1 tasks per CU on 4 / 8 wavefronts each
             l.stair_R = 2, l.wide_NW = kClassTab[dl.cls].NW;
             const int per_cu = 12 / l.wide_NW;
@@ -1985,7 +2007,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     std::vector<const L *> order;
     for (const auto &l : launches) order.push_back(&l);
     std::stable_sort(order.begin(), order.end(), [](const L *x, const L *y) { return x->cells < y->cells; });
-    const bool serial = std::getenv("NPR_EM_SERIAL") != nullptr;  // A/B switch: one launch after the other, as before round 3
+    const bool serial = ctx->opt[NPR_OPT_EM_SERIAL] != 0;  // A/B switch: one launch after the other, as before round 3
     for (size_t i = 0; i < order.size(); ++i) {
         const L &l = *order[i];
         const bool last = serial || i + 1 == order.size();

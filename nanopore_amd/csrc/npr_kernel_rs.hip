@@ -6,7 +6,7 @@
 // marginAlignSnpCaller.py:136-146 --, same frame, same frame schedule and control words (npr_sched.h), same outputs
 // (TaskOut, sparse posterior triples).  What differs from k_dp_stair is the cell: five plain fp32 values, the exponent in an
 // SGPR, 18 / 20 multiply-adds per cell and direction and nothing else in the recurrence, rows of 4 bytes per cell in the
-// forward scratch.  The kernel for every band a wavefront's frame can hold (classes 0-2: NPR_ARITH=cell brings the
+// forward scratch.  The kernel for every band a wavefront's frame can hold (classes 0-2: NPR_OPT_ARITH = 1 brings the
 // per-cell-exponent kernels back for A/B runs).
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -85,7 +85,8 @@ __device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
 #define NPR_PAIR_BLOCK NPR_RS_BLOCK  // the same for the two sweeps of k_dp_pair_rs
 #endif
 #ifndef NPR_RS_WAVES2
-#define NPR_RS_WAVES2 6  // wavefronts per SIMD the R = 2 kernel is compiled for: 79 VGPRs, two spilled (82 and 5 per SIMD without: 3 % slower)
+#define NPR_RS_WAVES2 7  // wavefronts per SIMD the R = 2 kernel is compiled for: 72 VGPRs, six spilled outside the sweeps' loops (round 4, without the
+                         // short-gap switch terms: 138.1 ms at 7 per SIMD, 140.4 at 6, 138.6 at 8 on the headline batch; round 3, with them: 6 was best)
 #endif
 template <int R, bool SW>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_rs(KernelArgs a) {

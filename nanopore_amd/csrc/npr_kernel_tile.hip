@@ -996,10 +996,8 @@ int64_t tile_scratch_cells(int64_t rows, int R) { return rows * (64 * R + 2 * ED
 
 size_t em_tile_lds_bytes(int nw) { return tile_lds_bytes(nw) + sizeof(float) * static_cast<size_t>(nw) * (EM_BINS + 1) * WAVE; }
 int em_tile_waves_per_cu() { return 4 * NPR_EM_TILE_WPE; }
-int em_tile_waves() {  // wavefronts per task: NPR_EM_TILE_WAVES (1..4) for A/B runs
-    int nw = 2;  // trainer's band 2.24 / 2.53 / 2.40 / 2.16e10 cells/s on 1 / 2 / 3 / 4 wavefronts per task, a 560-cell band 2.6 / 3.3 / 3.1 / 3.3e10
-    if (const char *w = std::getenv("NPR_EM_TILE_WAVES")) nw = std::min(EM_TILE_NW, std::max(1, std::atoi(w)));
-    return nw;
+int em_tile_waves() {  // wavefronts per task
+    return 2;  // trainer's band 2.24 / 2.53 / 2.40 / 2.16e10 cells/s on 1 / 2 / 3 / 4 wavefronts per task, a 560-cell band 2.6 / 3.3 / 3.1 / 3.3e10
 }
 
 int launch_em_tile(const KernelArgs &a, int R, int grid, void *stream) {

@@ -4,6 +4,7 @@
 (nanopore/analyses/utils.py:557-609: one jobTree job + one `cactus_realign` process per SAM record):
 all reads of a SAM file go to the GPU in one call.  Device work only -- no CPU fallback.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -236,6 +237,22 @@ class Context(object):
         rc = self._L.npr_ctx_option(self._h, option, int(value))
         if rc != _lib.OK:
             raise NprError(rc, "npr_ctx_option", self.last_error())
+
+    def release_scratch(self):
+        """NPR_OPT_RELEASE_SCRATCH: the device's forward scratch and this context's cached buffers go back to the driver."""
+        self.set_option(_lib.OPT_RELEASE_SCRATCH, 1)
+
+    @contextlib.contextmanager
+    def options(self, **kw):
+        """The test / bring-up switches of include/nprealign.h by name (_lib.OPTIONS), set for the body and back to 0 after it:
+        `with ctx.options(arith=_lib.ARITH_CELL): ...`.  None changes a result."""
+        for k, v in kw.items():
+            self.set_option(_lib.OPTIONS[k], v)
+        try:
+            yield self
+        finally:
+            for k in kw:
+                self.set_option(_lib.OPTIONS[k], 0)
 
     def copy_models_from(self, other):
         """Installs the models `other` holds (a second context of a pipelined job runs the same ones)."""

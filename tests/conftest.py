@@ -21,3 +21,14 @@ def gpu_ctx():
     ctx = realign.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(autouse=True)
+def _reset_context_options(request):
+    """The test / bring-up switches a test set on the session's context (npr_ctx_option, include/nprealign.h) do not outlive it."""
+    yield
+    if "gpu_ctx" in request.fixturenames:
+        from nanopore_amd import _lib
+        ctx = request.getfixturevalue("gpu_ctx")
+        for opt in _lib.OPTIONS.values():
+            ctx.set_option(opt, 0)

@@ -4,6 +4,8 @@ output cigars are global, per-read-type models (config 5) select the right table
 import numpy as np
 import pytest
 
+from nanopore_amd import _lib
+
 from helpers import load_model_arrays, orc, seg_arith_of
 
 pytestmark = pytest.mark.gpu
@@ -128,7 +130,7 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
     w = synth.make_workload(1007, 48, 3000, T, E, flank=0, length_sigma=0.5, len_min=300, len_max=9000)
     gpu_ctx.set_hmm(Hmm.loadHmm(MODEL_DIR + "/blasr_hmm_0.txt"))
     P = R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)
-    monkeypatch.setenv("NPR_NO_TILE", "1")  # the stripe kernel (tests/test_gpu_tile.py) would take these bands
+    gpu_ctx.set_option(_lib.OPTIONS["no_tile"], 1)  # the stripe kernel (tests/test_gpu_tile.py) would take these bands
 
     def run():
         b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
@@ -144,9 +146,9 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
     P = R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=700,
                       max_pairs_per_base=40)  # ragged ends blur the posteriors: more pairs per base than the default 6
     r1, o1, p1, t1, _, w1, _ = run()
-    monkeypatch.setenv("NPR_NO_WIDE", "1")
+    gpu_ctx.set_option(_lib.OPTIONS["no_wide"], 1)
     r2, o2, p2, t2, _, _, _ = run()
-    monkeypatch.delenv("NPR_NO_WIDE")
+    gpu_ctx.set_option(_lib.OPTIONS["no_wide"], 0)
     assert (r1["status"] == 0).all() and r1["n_segments"].max() > 1 and t1[3:7].sum() > 0 and t2[3:7].sum() == 0 and 256 <= w1 <= 1400
     assert np.array_equal(r1["loglik"], r2["loglik"]) and np.array_equal(r1["loglik_bwd"], r2["loglik_bwd"])
     assert np.array_equal(o1[1], o2[1]) and np.array_equal(p1[3], p2[3]) and np.array_equal(p1[1], p2[1])
@@ -156,7 +158,7 @@ def test_reference_anchor_band_wide_register_kernel(gpu_ctx, monkeypatch):
     assert (res["status"] == 0).all() and maxw > 1024
     assert tasks[3:7].sum() > 0.5 * tasks.sum() and cells[3:7].sum() > 0.9 * cells.sum()   # k_dp_wide did the work
     assert (tasks[3:7] > 0).sum() >= 3                                                      # in several frame sizes
-    monkeypatch.setenv("NPR_NO_WIDE", "1")
+    gpu_ctx.set_option(_lib.OPTIONS["no_wide"], 1)
     res2, (off2, ops2), (poff2, qx, qy, qp), tasks2, _, _, _ = run()
     assert tasks2[3:7].sum() == 0 and tasks2[7:].sum() == tasks[3:].sum()
     assert np.array_equal(res["cells"], res2["cells"]) and np.array_equal(res["loglik"], res2["loglik"])

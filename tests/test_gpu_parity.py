@@ -8,6 +8,8 @@ Two bars (DESIGN.md "Parity"):
 import numpy as np
 import pytest
 
+from nanopore_amd import _lib
+
 from helpers import load_model_arrays, oracle_hmm, orc, random_pair, cigar_spans  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -87,7 +89,7 @@ def test_generic_and_register_kernels_agree(gpu_ctx, monkeypatch):
     rng = np.random.default_rng(16)
     st = np.random.default_rng(16).bit_generator.state
     a = _run_case(gpu_ctx, rng, 6, 200, 900, dict(band_mode=1, fixed_width=100), indel=0.2, max_indel=30)
-    monkeypatch.setenv("NPR_KERNEL", "generic")
+    gpu_ctx.set_option(_lib.OPTIONS["kernel"], 1)
     rng2 = np.random.default_rng(16)
     b = _run_case(gpu_ctx, rng2, 6, 200, 900, dict(band_mode=1, fixed_width=100), indel=0.2, max_indel=30)
     for u, v in zip(a, b):
@@ -174,7 +176,7 @@ def test_posterior_capacity_overflow_is_reported_and_retried(gpu_ctx):
 
 def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
     """The chain + cigar stage runs on the device in realign mode (npr_mea.hip) and on the host in the other modes,
-    for hand-made pair lists (npr_mea_cigar) and with NPR_HOST_MEA=1: same integers, so same ops and same scores --
+    for hand-made pair lists (npr_mea_cigar) and with NPR_OPT_HOST_MEA: same integers, so same ops and same scores --
     over gapGamma / matchGamma settings, reads of several segments, N bases, reads without any pair above matchGamma,
     and with the pairs fetched afterwards."""
     from nanopore_amd import realign as R
@@ -194,16 +196,16 @@ def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
         # device_ring: the general (LDS-ring) chain kernel for every read and the global-memory sort kernels (the
         # variants long spans and far-reaching pairs fall back to)
         for where in ("device", "device_ring", "host"):
-            for k in ("NPR_HOST_MEA", "NPR_MEA_RING_ONLY", "NPR_MEA_GLOBAL_SORT"):
-                monkeypatch.delenv(k, raising=False)
+            for k in ("host_mea", "mea_ring_only", "mea_global_sort"):
+                gpu_ctx.set_option(_lib.OPTIONS[k], 0)
             if where == "host":
-                monkeypatch.setenv("NPR_HOST_MEA", "1")
+                gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 1)
             elif where == "device_ring":
-                monkeypatch.setenv("NPR_MEA_RING_ONLY", "1")
-                monkeypatch.setenv("NPR_MEA_GLOBAL_SORT", "1")
+                gpu_ctx.set_option(_lib.OPTIONS["mea_ring_only"], 1)
+                gpu_ctx.set_option(_lib.OPTIONS["mea_global_sort"], 1)
             got[where] = gpu_ctx.realign(R.make_params(**kw), refs, reads, guides, want_pairs=(where == "device"))
-        for k in ("NPR_HOST_MEA", "NPR_MEA_RING_ONLY", "NPR_MEA_GLOBAL_SORT"):
-            monkeypatch.delenv(k, raising=False)
+        for k in ("host_mea", "mea_ring_only", "mea_global_sort"):
+            gpu_ctx.set_option(_lib.OPTIONS[k], 0)
         for u, t, v in zip(got["device"], got["device_ring"], got["host"]):
             assert u["status"] == t["status"] == v["status"] == 0
             assert u["ops"] == v["ops"] and u["score"] == v["score"] and u["n_pairs"] == v["n_pairs"], kw
@@ -223,9 +225,9 @@ def test_device_mea_long_spans(gpu_ctx, monkeypatch):
     guides = [g for _, _, g in cases]
     P = R.make_params(band_mode=1, fixed_width=80)
     dev = gpu_ctx.realign(P, refs, reads, guides)
-    monkeypatch.setenv("NPR_HOST_MEA", "1")
+    gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 1)
     host = gpu_ctx.realign(P, refs, reads, guides)
-    monkeypatch.delenv("NPR_HOST_MEA", raising=False)
+    gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 0)
     for u, v, (X, Y, _) in zip(dev, host, cases):
         assert u["status"] == v["status"] == 0 and u["ops"] == v["ops"] and u["score"] == v["score"]
         assert cigar_spans(u["ops"]) == (len(X), len(Y))
@@ -366,10 +368,10 @@ def test_row_scaled_sweeps_in_blocks_of_sixteen_anti_diagonals(gpu_ctx):
 
 def test_pair_kernel_in_row_scaled_arithmetic(gpu_ctx, monkeypatch):
     """k_dp_pair_rs (a read's two sweeps on two wavefronts at once, the posteriors from the stored rows of both): what a class of
-    257+ tasks that fills at most half of the chip runs by default (BASELINE.json configs[1]); NPR_PAIR=all sends every
+    257+ tasks that fills at most half of the chip runs by default (BASELINE.json configs[1]); NPR_OPT_PAIR = 3 sends every
     one-wavefront task there.  Same bits as the mirror of k_dp_rs, over the three frame classes, bands that drift (rebases), an
     odd and an even number of anti-diagonals, single-base reads."""
-    monkeypatch.setenv("NPR_PAIR", "all")
+    gpu_ctx.set_option(_lib.OPTIONS["pair"], 3)
     from nanopore_amd import realign as R
     rng = np.random.default_rng(61)
     out = _run_case(gpu_ctx, rng, 24, 1, 400, dict(band_mode=1, fixed_width=40))

@@ -21,15 +21,12 @@ def test_device_plans_equal_host_plans_on_random_guides(gpu_ctx, monkeypatch):
                  for _ in range(24)]
         kw = dict(band_mode=it % 2, diagonal_expansion=int(rng.integers(0, 8)) * 2, constraint_trim=int(rng.integers(0, 16)),
                   split_threshold=int(rng.choice([0, 5, 40, 300, 3000])), fixed_width=int(rng.choice([2, 9, 40, 100, 200, 420, 900])))
-        for env in ({}, {"NPR_NO_TILE": "1"}, {"NPR_KERNEL": "generic"}):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            b = gpu_ctx.stage(R.make_params(**kw), [_ascii(X) for X, _, _ in cases], [_ascii(Y) for _, Y, _ in cases],
-                              [g for _, _, g in cases])
-            assert b.plan_check() == 0, (kw, env)
-            b.close()
-            for k in env:
-                monkeypatch.delenv(k)
+        for env in ({}, {"no_tile": 1}, {"kernel": 1}):   # (context options: include/nprealign.h NPR_OPT_NO_TILE, NPR_OPT_KERNEL)
+            with gpu_ctx.options(**env):
+                b = gpu_ctx.stage(R.make_params(**kw), [_ascii(X) for X, _, _ in cases], [_ascii(Y) for _, Y, _ in cases],
+                                  [g for _, _, g in cases])
+                assert b.plan_check() == 0, (kw, env)
+                b.close()
 
 
 def test_device_plans_of_the_named_workloads(gpu_ctx):

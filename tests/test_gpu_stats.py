@@ -7,6 +7,8 @@ import xml.etree.ElementTree as ET
 import numpy as np
 import pytest
 
+from nanopore_amd import _lib
+
 from nanopore_amd import bioio
 from nanopore_amd.analyses.coverage import GlobalCoverage, LocalCoverage
 from nanopore_amd.analyses.indels import Indels
@@ -209,13 +211,13 @@ def test_statistics_of_a_realigned_batch_where_it_lies(gpu_ctx, monkeypatch):
         tables = []
         for host_mea in (False, True):
             if host_mea:
-                monkeypatch.setenv("NPR_HOST_MEA", "1")
+                gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 1)
             b = gpu_ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
             b.run(), b.finish()
             res, (off, ops) = b.results(), b.ops()
             tables.append(b.align_stats())
             b.close()
-            monkeypatch.delenv("NPR_HOST_MEA", raising=False)
+            gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 0)
         assert (res["status"] == 0).all() and np.array_equal(tables[0], tables[1])
         if P.band_mode == R.BAND_ANCHOR:
             assert res["n_segments"].max() > 1

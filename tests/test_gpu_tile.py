@@ -1,9 +1,11 @@
 """k_dp_tile (the wide-band register kernel on column stripes, nanopore_amd/csrc/npr_kernel_tile.hip) on the GPU, through
 the C ABI: bit-exact against the oracle's fp32 mirror and within 1e-4 of the fp64 log-space oracle (test_gpu_parity's two
-bars), bit-identical to the kernels it replaces (k_dp_wide / k_dp_generic under NPR_NO_TILE=1), and independent of how many
+bars), bit-identical to the kernels it replaces (k_dp_wide / k_dp_generic under NPR_OPT_NO_TILE), and independent of how many
 wavefronts share a task."""
 import numpy as np
 import pytest
+
+from nanopore_amd import _lib
 
 from helpers import MODEL_DIR, load_model_arrays, orc, seg_arith_of
 from test_gpu_parity import _run_case
@@ -69,21 +71,21 @@ def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(
         assert (res["status"] == 0).all() and np.abs(res["loglik"] - res["loglik_bwd"]).max() < 1e-2
         assert tasks[3:11].sum() == 0 and tasks[11] > 0 and cells[11] > 0.9 * cells.sum() and st["kernel_variant"] == 2
         for nw in ("1", "3", "4"):
-            monkeypatch.setenv("NPR_TILE_WAVES", nw)
+            gpu_ctx.set_option(_lib.OPTIONS["tile_waves"], int(nw))
             same(ref, run(P))
-        monkeypatch.delenv("NPR_TILE_WAVES")
-        monkeypatch.setenv("NPR_NO_TILE", "1")
+        gpu_ctx.set_option(_lib.OPTIONS["tile_waves"], 0)
+        gpu_ctx.set_option(_lib.OPTIONS["no_tile"], 1)
         old = run(P)
-        monkeypatch.delenv("NPR_NO_TILE")
+        gpu_ctx.set_option(_lib.OPTIONS["no_tile"], 0)
         assert old[3][11] == 0 and old[3][3:11].sum() == tasks[11]
         same(ref, old)
 
     # the stripes in row-scaled arithmetic (k_dp_tile_rs, opt-in: one exponent per stripe row, neighbour cells handed over with
     # their row's exponent, tasks without a range certificate run again in k_dp_tile): the same bits
     ref = run(R.make_params(band_mode=R.BAND_ANCHOR))
-    monkeypatch.setenv("NPR_TILE_RS", "1")
+    gpu_ctx.set_option(_lib.OPTIONS["tile_rs"], 1)
     rs = run(R.make_params(band_mode=R.BAND_ANCHOR))
-    monkeypatch.delenv("NPR_TILE_RS")
+    gpu_ctx.set_option(_lib.OPTIONS["tile_rs"], 0)
     assert rs[3][18] > 0 and rs[3][11] == 0 and ref[3][11] == rs[3][18]
     same(ref, rs)
 

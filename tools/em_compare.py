@@ -2,7 +2,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
-from nanopore_amd import realign as R, synth
+from nanopore_amd import _lib, realign as R, synth
 from nanopore_amd.hmm import Hmm
 h = Hmm.loadHmm(os.path.join(ROOT, 'nanopore_amd', 'mappers', 'blasr_hmm_0.txt'))
 n, L, W = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
@@ -11,14 +11,14 @@ ctx = R.Context(0); ctx.set_hmm(h)
 P = (R.make_params(band_mode=1, fixed_width=W, mode=R.MODE_EXPECTATIONS) if W > 0 else
      R.make_params(band_mode=0, split_threshold=300, mode=R.MODE_EXPECTATIONS))
 got = {}
-for name, env in (('stripes', {}), ('frames', {'NPR_NO_TILE': '1'}), ('generic', {'NPR_EM_GENERIC': '1'})):
-    os.environ.update(env)
+for name, env in (('stripes', {}), ('frames', {'no_tile': 1}), ('generic', {'em_generic': 1})):  # context options (include/nprealign.h)
+    for k, v in env.items(): ctx.set_option(_lib.OPTIONS[k], v)
     b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
     tasks, _ = b.class_stats()
     T, E, ll, ms = b.expectations()
     T2, E2, ll2, ms2 = b.expectations()
     b.close()
-    for k in env: del os.environ[k]
+    for k in env: ctx.set_option(_lib.OPTIONS[k], 0)
     got[name] = (T[0], E[0], ll[0])
     print(name, 'classes', np.nonzero(tasks)[0].tolist(), 'kernel %.1f ms' % ms2, 'll %.6f' % ll[0], 'repeat dT %.2e' % (np.abs(T2[0] - T[0]).max() / T[0].sum()), flush=True)
 s = got['generic'][0].sum()

@@ -2,17 +2,14 @@
 import os, sys, time
 import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
-from nanopore_amd import realign as R, synth
+from nanopore_amd import _lib, realign as R, synth
 from nanopore_amd.hmm import Hmm
 h = Hmm.loadHmm(os.path.join(ROOT, 'nanopore_amd', 'mappers', 'blasr_hmm_0.txt'))
 n = int(sys.argv[1]); L = int(sys.argv[2]); W = int(sys.argv[3])  # W = 0: the reference's anchor band (expansion 10, trim 14, split 3000)
 w = synth.make_workload(7, n, L, h.transitions, h.emissions, flank=0)
 ctx = R.Context(0); ctx.set_hmm(h)
 for wpc in sys.argv[4:]:
-    if wpc == 'auto':
-        os.environ.pop('NPR_WAVES_PER_CU', None)
-    else:
-        os.environ['NPR_WAVES_PER_CU'] = wpc
+    ctx.set_option(_lib.OPTIONS['waves_per_cu'], 0 if wpc == 'auto' else int(wpc))  # NPR_OPT_WAVES_PER_CU
     t0 = time.time()
     P = R.make_params(band_mode=1, fixed_width=W) if W > 0 else R.make_params(band_mode=0)
     b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])

@@ -15,6 +15,7 @@ from nanopore_amd import realign as R, synth
 from nanopore_amd.hmm import Hmm
 h = Hmm.loadHmm(os.path.join(%(root)r, "nanopore_amd", "mappers", "blasr_hmm_0.txt"))
 ctx = R.Context(0); ctx.set_hmm(h)
+if os.environ.get("RS_WAVES_PER_CU"): ctx.set_option(10, int(os.environ["RS_WAVES_PER_CU"]))  # NPR_OPT_WAVES_PER_CU
 out = {}
 w, W = synth.config_north_star(h.transitions, h.emissions, n_reads=int(os.environ.get("RS_NS_READS", "12288")), seed=1003)
 b = ctx.stage_csr(R.make_params(band_mode=R.BAND_FIXED, fixed_width=W), w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"], guide_start=w.get("guide_start"))
@@ -42,7 +43,7 @@ for arg in sys.argv[1:]:
     lib = os.path.join(ROOT, "nanopore_amd", "libnprealign.so" if tag == "default" else "libnprealign_%s.so" % tag)
     env = dict(os.environ); env.setdefault("NPR_LIB", lib)
     if wpc:
-        env["NPR_WAVES_PER_CU"] = wpc
+        env["RS_WAVES_PER_CU"] = wpc
     p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True)
     line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-600:]
     print(arg, line, flush=True)

@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 import numpy as np
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-from nanopore_amd import realign as R, synth
+from nanopore_amd import _lib, realign as R, synth
 from nanopore_amd.hmm import Hmm
 from helpers import load_model_arrays, MODEL_DIR
 T, E, _ = load_model_arrays()
@@ -17,9 +17,9 @@ def run():
     r = b.results(); pr = b.pairs()
     b.close()
     return r, pr, ms
-os.environ['NPR_TILE_WAVES'] = '1'
+ctx.set_option(_lib.OPTIONS['tile_waves'], 1)  # NPR_OPT_TILE_WAVES: one wavefront per task
 good = run()
-del os.environ['NPR_TILE_WAVES']
+ctx.set_option(_lib.OPTIONS['tile_waves'], 0)
 bad_ll = bad_pairs = 0
 t0 = time.time(); tms = []
 for rep in range(N):
