@@ -131,8 +131,10 @@ def test_plain_bench_command_line_starts_its_own_ranks(gpu_ctx, tmp_path):
     test hook (gloo collectives), rank 0 prints ONE JSON line with the weak-scaling headline and the strong-scaling job beside
     it, and the exit code is 0."""
     from nanopore_amd import job
-    job.close_contexts()
-    gpu_ctx.release_scratch()  # the ranks need the HBM this session's earlier (full-size) tests left in the device's scratch
+    # the ranks need the HBM this session's earlier (full-size) tests left in the device's scratch and in the contexts' caches
+    for c in [gpu_ctx] + [c for pool in job._ctx_pool.values() for c in pool]:
+        if getattr(c, "_h", None):
+            c.release_scratch()
     env = dict(os.environ, NPR_BENCH_SHARE_GPU="1", NPR_BENCH_ALSO_READS="1024", TMPDIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
