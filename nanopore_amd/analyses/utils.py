@@ -175,6 +175,10 @@ def mergeChainedAlignedReads(chainedAlignedReads, refSequence, readSequence):
     head = blocks[0]
     if any(aR.is_reverse != head.is_reverse for aR in blocks):
         raise AssertionError("blocks of one chain lie on both strands (%s)" % head.qname)
+    for aR in blocks:  # the reference asserts `op in (0, 1, 2, 4, 5)` (utils.py:357, :366): an = / X / N / P block would be under-counted
+        for op, _ in aR.cigar:
+            if op not in (0, 1, 2, 4, 5):
+                raise AssertionError("cigar operation %d of %s is outside M I D S H" % (op, aR.qname))
     guides = [_guideOf(aR) for aR in blocks]
     ref_pos = np.array([aR.pos for aR in blocks], dtype=np.int64)
     read_pos = np.array([clipLengths(aR)[0] for aR in blocks], dtype=np.int64)  # first aligned base in SEQ orientation, either strand

@@ -552,6 +552,19 @@ bool rs_model_ok(const DevModel &m) {
         }
         grow = std::max(grow, col * e);
     }
+    // ... and the backward sweep grows by the ROW sums: a state's value is the sum over its successors of transition times the
+    // successor's emission (a stochastic model's rows sum to 1; a user's model need not be stochastic)
+    auto emax = [&](int st) {
+        if (st == 0) return em_max;
+        double e = 0.0;
+        for (int b2 = 0; b2 < 5; ++b2) e = std::max(e, static_cast<double>((st == 1 || st == 3) ? m.ex[st * 5 + b2] : m.ey[st * 5 + b2]));
+        return e;
+    };
+    for (int from = 0; from < 5; ++from) {
+        double row = 0.0;
+        for (int to = 0; to < 5; ++to) row += static_cast<double>(m.T[from * 5 + to]) * emax(to);
+        grow = std::max(grow, row);
+    }
     return grow <= std::exp2(6.0 / NPR_RS_K);
 }
 
@@ -1288,6 +1301,10 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     std::vector<const npr_batch::Launch *> order;
     for (const auto &L : b->launches) order.push_back(&L);
     std::sort(order.begin(), order.end(), [](const npr_batch::Launch *x, const npr_batch::Launch *y) { return x->cells < y->cells; });
+    if (b->pair_rs)  // (staged for the row-scaled kernels under the models of that moment)
+        for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
+            if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl]))
+                return fail(ctx, NPR_ERR_MODEL, "npr_batch_run: a model loaded after the batch was staged grows faster than the row-scaled kernels allow: stage the batch again");
     // the row-scaled kernels leave out the two short-gap switch terms of a cell when no loaded model has such a transition (the
     // shipped ones have none): exact zeros either way (npr_rs.h)
     bool sw = false;

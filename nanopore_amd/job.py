@@ -269,13 +269,21 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
         if TRACE:
             tm["trace"].append((label, t0, t1))
 
-    def guarded(fn, downstream):
+    def guarded(fn, upstream, downstream):
         def run():
             try:
                 fn()
             except BaseException as e:  # handed to the caller's thread
                 stop.set()
                 done.put(e)
+                # what the phases before this one still hand over is closed here: nobody else will look at this queue again
+                while upstream is not None:
+                    item = upstream.get()
+                    if item is END:
+                        break
+                    item[3].close()
+                    if item[4]:
+                        free[item[0]].release()
             finally:
                 downstream.put(END)
         return run
@@ -299,7 +307,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 pending.extend([(mid, b_), (a, mid)])
                 continue
             note("stage", t0, time.perf_counter())
-            q_run.put((j, a, b_, batch))
+            q_run.put((j, a, b_, batch, True))  # (the last field: the chunk's end gives the context back)
             k += 1
 
     def runner():
@@ -307,13 +315,35 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             item = q_run.get()
             if item is END:
                 return
-            j, a, b_, batch = item
+            j, a, b_, batch, last = item
             if stop.is_set():
                 batch.close(), free[j].release()
                 continue
             t0 = time.perf_counter()
             try:
                 tm["kernel_ms"] += batch.run()
+            except realign.NprError as e:
+                batch.close()
+                if e.code != realign.ERR_NOMEM or b_ - a < 2:
+                    free[j].release()
+                    raise
+                # the device was full at launch (a kernel's private segment, the scratch regrown): the chunk's halves one after
+                # the other in the same context, as the stager does for a chunk that does not fit at staging
+                try:
+                    mid = (a + b_) // 2
+                    for x, y, fin in ((a, mid, False), (mid, b_, True)):
+                        half = src.stage(ctxs[j], params, x, y)
+                        try:
+                            tm["kernel_ms"] += half.run()
+                        except BaseException:
+                            half.close()
+                            raise
+                        q_fin.put((j, x, y, half, fin))
+                except BaseException:
+                    free[j].release()
+                    raise
+                note("run", t0, time.perf_counter())
+                continue
             except BaseException:
                 batch.close(), free[j].release()
                 raise
@@ -325,15 +355,19 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             item = q_fin.get()
             if item is END:
                 return
-            j, a, b_, batch = item
+            j, a, b_, batch, last = item
             if stop.is_set():
-                batch.close(), free[j].release()
+                batch.close()
+                if last:
+                    free[j].release()
                 continue
             t0 = time.perf_counter()
             try:
                 batch.finish()
             except BaseException:
-                batch.close(), free[j].release()
+                batch.close()
+                if last:
+                    free[j].release()
                 raise
             note("finish", t0, time.perf_counter())
             q_out.put(item)
@@ -343,47 +377,54 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             item = q_out.get()
             if item is END:
                 return
-            j, a, b_, batch = item
+            j, a, b_, batch, last = item
             t0 = time.perf_counter()
-            try:
-                if stop.is_set():
-                    continue
-                res, off, words, stats = _fetch(batch, want_stats)
-                tm["cells"] += int(batch.stats()["cells"])
-            finally:
-                batch.close()
-                if stop.is_set():
-                    free[j].release()
-            try:
+            try:  # the context goes back exactly once, whatever happens in between
+                try:
+                    if stop.is_set():
+                        continue
+                    res, off, words, stats = _fetch(batch, want_stats)
+                    tm["cells"] += int(batch.stats()["cells"])
+                finally:
+                    batch.close()
                 res, off, words, stats = _rerun_overflowed(ctxs[j], src, params, a, res, off, words, stats, want_stats, tm)
             finally:
-                free[j].release()
+                if last:
+                    free[j].release()
             t1 = time.perf_counter()
             note("fetch", t0, t1)
             block = src.format_block(a, b_, off, words)
             note("format", t1, time.perf_counter())
             done.put((block, res, off[1:] - off[:-1], stats))
 
-    threads = [threading.Thread(target=guarded(fn, q), daemon=True)
-               for fn, q in ((stager, q_run), (runner, q_fin), (finisher, q_out), (fetcher, done))]
+    threads = [threading.Thread(target=guarded(fn, up, down), daemon=True)
+               for fn, up, down in ((stager, None, q_run), (runner, q_run, q_fin), (finisher, q_fin, q_out), (fetcher, q_out, done))]
     for t in threads:
         t.start()
     parts, sink_s, error = [], 0.0, None
-    while True:
-        item = done.get()
-        if item is END:
-            break
-        if isinstance(item, BaseException):
-            error = error or item
-            continue
-        if error is None:
-            block, res, nops, stats = item
-            t0 = time.perf_counter()
-            sink(block)
-            sink_s += time.perf_counter() - t0
-            parts.append((res, nops, stats))
-    for t in threads:
-        t.join()
+    finished = False
+    try:
+        while True:
+            item = done.get()
+            if item is END:
+                finished = True
+                break
+            if isinstance(item, BaseException):
+                error = error or item
+                continue
+            if error is None:
+                block, res, nops, stats = item
+                t0 = time.perf_counter()
+                sink(block)
+                sink_s += time.perf_counter() - t0
+                parts.append((res, nops, stats))
+    finally:
+        if not finished:  # the sink failed on this thread (a full disk): the phases stop, what is in flight is closed, nothing keeps a context
+            stop.set()
+            while done.get() is not END:
+                pass
+        for t in threads:
+            t.join()
     if error is not None:
         raise error
     n = hi - lo

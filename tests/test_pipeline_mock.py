@@ -1,0 +1,135 @@
+"""The per-rank pipeline of the files -> file job (nanopore_amd/job.py::run_pipeline: stage | DP | finish | fetch + format, one thread
+per phase, chunks in flight on a pool of contexts) over stand-in batches, no GPU: record order, the halving of a chunk the device
+cannot hold (at staging and at launch), and the error paths -- whatever fails, every staged batch is closed, every context is given
+back exactly once and the phase threads are gone.  Reference: one jobTree job per record (nanopore/analyses/utils.py:565-570) has
+no such state to clean up; a failed job fails the tree (pipeline.py:209-210), here the exception reaches the caller."""
+import threading
+
+import numpy as np
+import pytest
+
+from nanopore_amd import _lib, job, realign
+
+
+class FakeCtx(object):
+    def __init__(self):
+        self.open = 0
+        self.peak = 0
+
+    def set_option(self, option, value):
+        pass
+
+
+class FakeBatch(object):
+    def __init__(self, src, ctx, a, b):
+        self.src, self.ctx, self.a, self.b = src, ctx, a, b
+        ctx.open += 1
+        ctx.peak = max(ctx.peak, ctx.open)
+        src.staged.append((a, b))
+        self.closed = False
+
+    def run(self):
+        if self.src.fail_run == "nomem" and self.b - self.a > self.src.max_run:
+            raise realign.NprError(realign.ERR_NOMEM, "npr_batch_run", "device full")
+        if self.src.fail_run == "boom":
+            raise RuntimeError("launch failed")
+        return 1.0
+
+    def finish(self):
+        if self.src.fail_finish:
+            raise RuntimeError("finish failed")
+
+    def results(self):
+        r = np.zeros(self.b - self.a, dtype=_lib.RESULT_DTYPE)
+        r["score"] = np.arange(self.a, self.b)
+        return r
+
+    def ops_packed(self):
+        n = self.b - self.a
+        return np.arange(n + 1, dtype=np.int64), np.arange(self.a, self.b).astype(np.uint32)
+
+    def stats(self):
+        return {"cells": 10 * (self.b - self.a)}
+
+    def close(self):
+        assert not self.closed, "a batch is closed twice"
+        self.closed = True
+        self.ctx.open -= 1
+        self.src.closed += 1
+
+
+class FakeSrc(object):
+    def __init__(self, n, max_stage=1 << 30, max_run=1 << 30, fail_run=None, fail_finish=False):
+        self.n, self.max_stage, self.max_run, self.fail_run, self.fail_finish = n, max_stage, max_run, fail_run, fail_finish
+        self.staged, self.closed = [], 0
+
+    def lengths(self):
+        return np.full(self.n, 1000, dtype=np.int64)
+
+    def stage(self, ctx, params, lo, hi):
+        if hi - lo > self.max_stage:
+            raise realign.NprError(realign.ERR_NOMEM, "npr_batch_create", "device full")
+        return FakeBatch(self, ctx, lo, hi)
+
+    def format_block(self, lo, hi, ops_off, words):
+        assert list(words) == list(range(lo, hi))
+        return np.arange(lo, hi, dtype=np.int64).tobytes()
+
+
+def _run(src, ctxs, sink=None, chunk_bases=100000):
+    blocks = []
+    params = realign.make_params()
+    out = job.run_pipeline(src, params, 0, src.n, ctxs, sink or blocks.append, chunk_bases=chunk_bases)
+    return out, blocks
+
+
+def _all_back(src, ctxs, threads_before):
+    assert src.closed == len(src.staged) and all(c.open == 0 for c in ctxs)
+    assert threading.active_count() <= threads_before
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_stage=60), dict(fail_run="nomem", max_run=60)], ids=["plain", "nomem_at_staging", "nomem_at_launch"])
+def test_blocks_come_in_record_order_and_chunks_that_do_not_fit_are_halved(kw):
+    before = threading.active_count()
+    ctxs = [FakeCtx() for _ in range(3)]
+    src = FakeSrc(1000, **kw)
+    (res, nops, stats, tm), blocks = _run(src, ctxs)
+    got = np.frombuffer(b"".join(blocks), dtype=np.int64)
+    assert list(got) == list(range(1000)) and list(res["score"]) == list(range(1000)) and tm["cells"] == 10000
+    assert all(c.peak <= 2 for c in ctxs)  # (two only while the halves of a chunk the launch refused pass through)
+    if kw:
+        assert max(b - a for a, b in src.staged if not kw.get("fail_run") or True) >= 50 and len(src.staged) > 10
+    _all_back(src, ctxs, before)
+
+
+@pytest.mark.parametrize("kw,exc", [(dict(fail_run="boom"), RuntimeError), (dict(fail_finish=True), RuntimeError),
+                                    (dict(max_stage=0), realign.NprError)], ids=["launch", "finish", "staging"])
+def test_a_failing_phase_reaches_the_caller_and_leaves_nothing_behind(kw, exc):
+    before = threading.active_count()
+    ctxs = [FakeCtx() for _ in range(3)]
+    src = FakeSrc(1000, **kw)
+    with pytest.raises(exc):
+        _run(src, ctxs)
+    _all_back(src, ctxs, before)
+
+
+def test_a_failing_sink_stops_the_phases():
+    """os.pwrite failing on the caller's thread (a full disk): the exception is the caller's, the phase threads stop, every batch in
+    flight is closed and every context given back."""
+    before = threading.active_count()
+    ctxs = [FakeCtx() for _ in range(3)]
+    src = FakeSrc(2000)
+    seen = []
+
+    def sink(block):
+        seen.append(len(block))
+        if len(seen) == 2:
+            raise OSError(28, "No space left on device")
+
+    with pytest.raises(OSError):
+        _run(src, ctxs, sink=sink)
+    _all_back(src, ctxs, before)
+    # the contexts can be used again at once: nothing holds their semaphores
+    src2 = FakeSrc(300)
+    (res, _, _, _), blocks = _run(src2, ctxs)
+    assert len(res) == 300
