@@ -295,6 +295,14 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
 int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, float *Bm_v,
                         int32_t *Bm_e, int64_t cap);
 
+/* debugging / parity aid for the north-star kernel: the forward match values k_dp_rs (row-scaled arithmetic: one exponent per
+ * anti-diagonal row, renormalised every 16 rows) leaves in its scratch for the backward sweep, read i, task-major, band order,
+ * as (value, exponent of the cell's row): F = value * 2^exponent.  A cell more than ~211 binary orders below its rows' maximum
+ * is 0 (flushed) -- the range certificate (npr_batch_segment_arith reports the tasks that ran again without it) bounds the
+ * posterior mass such cells can carry by 2^-60.  Runs the read's tasks again, one at a time; NPR_ERR_STATE when a segment of
+ * the read is not in a class k_dp_rs runs.  Buffers sized npr_read_result.cells. */
+int32_t npr_batch_rs_forward(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, int64_t cap);
+
 /* Test aid: npr_batch_create expands band rows, frame schedules, stripe tables and row offsets on the device; this
  * recomputes every task of the batch with the host planner (the npr_plan_* functions below, the ones the tests pin
  * against the oracle) and compares entry by entry.  Returns the number of tasks that differ (0 = identical) or NPR_ERR_*. */

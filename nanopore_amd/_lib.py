@@ -89,7 +89,7 @@ class NprError(RuntimeError):
 EXPORTS = [
     "npr_abi_version", "npr_strerror", "npr_create", "npr_destroy", "npr_last_error", "npr_set_hmm",
     "npr_batch_create", "npr_batch_create_at", "npr_batch_run", "npr_batch_finish", "npr_batch_destroy", "npr_batch_get_stats", "npr_batch_class_stats",
-    "npr_batch_results", "npr_batch_ops", "npr_batch_ops_packed", "npr_batch_pairs", "npr_batch_dense", "npr_batch_expectations",
+    "npr_batch_results", "npr_batch_ops", "npr_batch_ops_packed", "npr_batch_pairs", "npr_batch_dense", "npr_batch_rs_forward", "npr_batch_expectations",
     "npr_batch_align_stats", "npr_align_stats", "npr_batch_plan_check", "npr_batch_base_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
@@ -162,6 +162,8 @@ def load():
     L.npr_align_stats.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.npr_batch_dense.restype = i32
     L.npr_batch_dense.argtypes = [vp, i64, vp, vp, vp, vp, i64]
+    L.npr_batch_rs_forward.restype = i32
+    L.npr_batch_rs_forward.argtypes = [vp, i64, vp, vp, i64]
     L.npr_realign_batch.restype = i32
     L.npr_realign_batch.argtypes = [vp, C.POINTER(Params), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]
     L.npr_plan_create.restype = i32

@@ -93,7 +93,7 @@ class SamAlignmentStats(object):
         the alignments lay (job.realign_sam_file(..., want_stats=True): npr_batch_align_stats per chunk) -- no second pass over
         the aligned pairs, and no Python object per record: names, positions and lengths come from the native scanners
         (nanopore_amd/ingest.py).  Row i of `table` belongs to record i of `samFile` (the records with a reference, in order).
-        The individual gap lengths (indels.xml) are not available in this form."""
+        The individual gap lengths (indels.xml) come from the cigars of `samFile`, scanned natively."""
         from .. import ingest
         self = cls.__new__(cls)
         sam = ingest.SamText(samFile)
@@ -118,6 +118,7 @@ class SamAlignmentStats(object):
         self.clipBefore = f[:, ingest.F_QUERY_LO] - f[:, ingest.F_SEQ_LO]
         self.clipAfter = f[:, ingest.F_SEQ_HI] - f[:, ingest.F_QUERY_HI]
         self.cigars = None
+        self._cigar_csr = sam.guides(f)  # (offsets, (op, length) of the M / I / D operations): what the indel lengths are read from
         self.table = np.ascontiguousarray(table, dtype=np.int32)
         bad = np.flatnonzero(self.table[:, STATUS] != 0)
         if len(bad):
@@ -134,23 +135,30 @@ class SamAlignmentStats(object):
         if self._gaps is None:
             n = len(self)
             ins, dels = [[] for _ in range(n)], [[] for _ in range(n)]
-            counts = np.array([len(c) for c in self.cigars], dtype=np.int64)
+            if self.cigars is not None:
+                counts = np.array([len(c) for c in self.cigars], dtype=np.int64)
+                ops = np.array([o for c in self.cigars for o in c], dtype=np.int64).reshape(-1, 2) if counts.sum() else np.zeros((0, 2), dtype=np.int64)
+            else:  # fromRealignedSam: the cigars' M / I / D operations as the native scanner left them (CSR)
+                off, csr = self._cigar_csr
+                counts, ops = (off[1:] - off[:-1]).astype(np.int64), csr.astype(np.int64)
             if counts.sum():
-                ops = np.array([o for c in self.cigars for o in c], dtype=np.int64).reshape(-1, 2)
                 rec = np.repeat(np.arange(n), counts)
                 first = np.concatenate([[0], np.cumsum(counts)[:-1]])
                 is_m = (ops[:, 0] == 0) & (ops[:, 1] > 0)
                 before = np.cumsum(is_m) - is_m                      # aligned blocks before this op, file-wide
-                gap = before - np.repeat(before[first], counts)      # ... within its record: 0 = before the first block
+                gap = before - np.repeat(before[np.minimum(first, len(before) - 1)], counts)  # ... within its record: 0 = before the first block
                 blocks = np.bincount(rec, weights=is_m, minlength=n).astype(np.int64)
                 inner = (~is_m) & (gap > 0) & (gap < blocks[rec])
+                span = int(gap.max()) + 1
                 for code, out in ((1, ins), (2, dels)):
                     sel = inner & (ops[:, 0] == code) & (ops[:, 1] > 0)
-                    key = rec[sel] * (int(gap.max()) + 1) + gap[sel]
+                    key = rec[sel] * span + gap[sel]
                     uniq, inv = np.unique(key, return_inverse=True)
                     total = np.bincount(inv, weights=ops[sel, 1]).astype(np.int64)
-                    for k, v in zip(uniq // (int(gap.max()) + 1), total):
-                        out[int(k)].append(int(v))
+                    owner = uniq // span                                # (sorted: a record's gaps are contiguous, in alignment order)
+                    cuts = np.searchsorted(owner, np.arange(n + 1))
+                    for k in np.flatnonzero(cuts[1:] > cuts[:-1]):
+                        out[int(k)] = total[cuts[k]:cuts[k + 1]].tolist()
             self._gaps = (ins, dels)
         return self._gaps
 

@@ -53,9 +53,11 @@ def getAggregateIndelStats(stats):
 
 
 class Indels(AbstractAnalysis):
-    def run(self, ctx=None):
+    def run(self, ctx=None, stats=None):
+        """`stats`: a SamAlignmentStats made elsewhere (SamAlignmentStats.fromRealignedSam: the table a realignment job reduced
+        on the device); default: the records of self.samFile are counted now."""
         AbstractAnalysis.run(self)
-        stats = SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
+        stats = stats or SamAlignmentStats(self.samFile, self.referenceFastaFile, self.readFastqFile, ctx=ctx)
         if len(stats):
             root = getAggregateIndelStats(stats)
             with open(os.path.join(self.outputDir, "indels.xml"), "w") as fh:

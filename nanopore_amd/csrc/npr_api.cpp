@@ -2427,6 +2427,67 @@ int32_t npr_batch_dense(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *
     return NPR_OK;
 }
 
+int32_t npr_batch_rs_forward(npr_batch *b, int64_t read_index, float *Fm_v, int32_t *Fm_e, int64_t cap) {
+    if (!b || read_index < 0 || read_index >= b->n_reads || !Fm_v || !Fm_e) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    if (b->read_status[read_index] != NPR_OK) return b->read_status[read_index];
+    if (!b->ran) return fail(ctx, NPR_ERR_STATE, "npr_batch_rs_forward before npr_batch_run (which sizes the forward scratch)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> arena_lock(ctx->arena->mu);  // the task runs in region 0 of the arena
+    ++ctx->arena->epoch;
+    DevBuf<TaskOut> d_out1;
+    if (d_out1.alloc(1) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_rs_forward: hipMalloc");
+    bool sw = false;
+    for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
+        if (ctx->model_set[sl] && (ctx->models[sl].T[1 * 5 + 2] != 0.f || ctx->models[sl].T[2 * 5 + 1] != 0.f)) sw = true;
+    int64_t written = 0;
+    for (int32_t s = 0; s < b->read_ntasks[read_index]; ++s) {
+        const int32_t k = b->task_of[b->read_first_task[read_index] + s];
+        const Task &t = b->tasks[k];
+        int R = 0;
+        for (const auto &L : b->launches)
+            if (k >= L.first && k < L.first + L.count && kClassTab[L.cls].kind == K_RS) R = kClassTab[L.cls].R;
+        if (R == 0 || t.ctl_off < 0) return fail(ctx, NPR_ERR_STATE, "npr_batch_rs_forward: the read has a segment that k_dp_rs does not run");
+        KernelArgs a = make_args(b);
+        a.tasks = b->d_tasks.p + k, a.ntasks = 1, a.outs = d_out1.p, a.slot_base = 0, a.region = nullptr;
+        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * kQueueSlots, ctx->stream));
+        const int rc = launch_rs(a, R, 1, ctx->stream, sw);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_rs launch", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(t.cells_pad)));
+        std::vector<float> fv(static_cast<size_t>(t.cells_pad));
+        std::vector<int32_t> fe(static_cast<size_t>(t.D / NPR_RS_K + 1));
+        std::vector<uint32_t> ctl(2 * (static_cast<size_t>(t.D) + 1));
+        HIP_TRY(ctx, hipMemcpy(fv.data(), ctx->arena->F, sizeof(float) * fv.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fe.data(), ctx->arena->F + 4 * half, sizeof(int32_t) * fe.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(ctl.data(), b->d_ctl.p + 2 * t.ctl_off, sizeof(uint32_t) * ctl.size(), hipMemcpyDeviceToHost));
+        const int rshift = stair_rshift(R);
+        for (int32_t d = 0; d <= t.D; ++d) {
+            const uint32_t w0 = ctl[2 * d], w1 = ctl[2 * d + 1];
+            int64_t first;  // scratch cell of the row's first band cell
+            int32_t n;
+            if (stair_packed(R, 1)) {
+                const uint32_t lo0 = w1 & 127u, lo1 = (w1 >> 7) & 127u;
+                n = static_cast<int32_t>(((w1 >> 14) & 127u) + ((w1 >> 21) & 127u));
+                // (word 0 is where lane 0 WOULD land: below the region's start for a row whose first lanes are outside the band)
+                first = static_cast<int64_t>(static_cast<int32_t>(w0 - row_bias<2>()) >> 3) + 2 * lo1 + ((lo0 + lo1) - 2 * lo1);
+            } else {
+                const int32_t jlo = static_cast<int32_t>(w1 & 8191u);
+                n = static_cast<int32_t>((w1 >> 13) & 8191u);
+                first = static_cast<int64_t>(w0) + (jlo - ((jlo >> rshift) << rshift));
+            }
+            for (int32_t j = 0; j < n; ++j) {
+                if (written >= cap) return NPR_ERR_CAPACITY;
+                if (first + j < 0 || first + j >= static_cast<int64_t>(fv.size())) return fail(ctx, NPR_ERR_STATE, "npr_batch_rs_forward: a control word points outside the task's scratch");
+                Fm_v[written] = fv[static_cast<size_t>(first + j)], Fm_e[written] = fe[static_cast<size_t>(d / NPR_RS_K)];
+                ++written;
+            }
+        }
+    }
+    b->ran = false;  // the pair buffers of this read were overwritten by the debug launch
+    return NPR_OK;
+}
+
 int32_t npr_realign_batch(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
                           const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
                           const uint8_t *read, const int64_t *read_off, const int32_t *guide_ops,

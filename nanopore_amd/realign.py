@@ -206,6 +206,15 @@ class Batch(object):
             raise NprError(rc, "npr_batch_dense", self.ctx.last_error())
         return fv, fe, bv, be
 
+    def rs_forward(self, read_index, cells):
+        """include/nprealign.h: npr_batch_rs_forward -- the forward match rows k_dp_rs stores, (value, row exponent) in band order."""
+        fv = np.zeros(cells, dtype=np.float32)
+        fe = np.zeros(cells, dtype=np.int32)
+        rc = self._L.npr_batch_rs_forward(self._h, read_index, ptr(fv), ptr(fe), cells)
+        if rc != _lib.OK:
+            raise NprError(rc, "npr_batch_rs_forward", self.ctx.last_error())
+        return fv, fe
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.npr_batch_destroy(self._h)

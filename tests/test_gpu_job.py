@@ -168,6 +168,8 @@ def test_config5_at_full_size_through_the_job_with_device_statistics(tmp_path, g
     from nanopore_amd import ingest, job, realign as R
     from nanopore_amd.analyses.alignmentStats import MATCHES, MISMATCHES, AGAINST_N, PAIRS, SamAlignmentStats
     from nanopore_amd.analyses.coverage import LocalCoverage
+    from nanopore_amd.analyses.indels import Indels
+    from nanopore_amd.analyses.alignmentStats import N_INS
     from nanopore_amd.analyses.substitutions import Substitutions
     from nanopore_amd import synth
     from nanopore_amd.hmm import Hmm
@@ -242,6 +244,30 @@ def test_config5_at_full_size_through_the_job_with_device_statistics(tmp_path, g
         ident = np.array([float(v) for v in croot.attrib["distributionidentity"].split()])
         m, x = table[:, MATCHES].astype(np.float64), table[:, MISMATCHES].astype(np.float64)
         assert np.allclose(ident, m / (m + x + table[:, 5]), rtol=1e-12)
+        # indels.xml / indels.tsv (nanopore/analyses/indels.py:9-45) at this size: the gap lengths from the output's cigars (native
+        # scan), their number per record cross-checked against the device table inside getAggregateIndelStats
+        idir = os.path.join(tmp, "indels_%d" % t)
+        os.makedirs(idir)
+        Indels(fq, types[t], fa, out, idir).run(stats=stats)
+        iroot = ET.parse(os.path.join(idir, "indels.xml")).getroot()
+        assert iroot.attrib["numberOfReadAlignments"] == str(n_type) and len(iroot) == n_type
+        nins = np.array([int(v) for v in iroot.attrib["NumberReadInsertions"].split()])
+        assert nins.sum() == int(table[:, N_INS].astype(np.int64).sum()) == len(iroot.attrib["readInsertionLengths"].split())
+        j = int(np.argmax(rlen))                                  # one record against its own cigar
+        cig = [(int(a), int(b)) for a, b in gops[goff[j]:goff[j + 1]]]
+        runs, cur = [], [0, 0]                                    # (insertion, deletion) bases between consecutive aligned blocks
+        for op, ln in cig:
+            if op == 0:
+                runs.append(cur), None
+                cur = [0, 0]
+            else:
+                cur[op - 1] += ln
+        inner = runs[1:]                                          # (what precedes the first block is not between two pairs)
+        assert iroot[j].attrib["readSeqName"] == "read_%d" % j
+        assert [int(v) for v in iroot[j].attrib["readInsertionLengths"].split()] == [a for a, _ in inner if a]
+        assert [int(v) for v in iroot[j].attrib["readDeletionLengths"].split()] == [b for _, b in inner if b]
+        tsv = open(os.path.join(idir, "indels.tsv")).readline().split("\t")
+        assert tsv[0] == "readInsertionLengths" and len(tsv) == 7
         # each type ran under ITS model: a few reads again through a plain batch with the slot's model alone
         idx = np.argsort(rlen)[:6]
         sub = synth.take_reads(w, idx)

@@ -134,6 +134,43 @@ def test_dense_forward_backward_bit_exact(gpu_ctx):
     assert np.abs((lb - d["Bm"][aliveb])).max() < 1e-4
 
 
+@pytest.mark.parametrize("L,W,indel", [(400, 100, 0.1), (1500, 200, 0.2), (700, 40, 0.15), (900, 400, 0.2)], ids=["w100", "w200", "w40", "w400"])
+def test_row_scaled_forward_rows_against_the_fp64_oracle(gpu_ctx, L, W, indel):
+    """The rows k_dp_rs itself stores (one exponent per anti-diagonal row of the wavefront, renormalised every 16 rows), read out of
+    its scratch: renormalised log-probabilities within the 1e-4 north_star states on every cell that carries posterior mass of
+    2^-60 or more.  Below that a cell may have been flushed to zero (its forward value lies more than ~211 binary orders under
+    its rows' maximum): then -- and only then -- the device holds 0 where the oracle holds a finite value, and the range certificate
+    has bounded what such cells can carry.  The three frame classes, drifting bands (rebases)."""
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(151 + W)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    h = oracle_hmm()
+    X, Y, ops = random_pair(rng, L, indel=indel, max_indel=30)
+    kw = dict(band_mode=1, fixed_width=W)
+    seg = orc.plan(len(X), len(Y), ops, orc.make_params(**kw))[0]
+    b = gpu_ctx.stage(R.make_params(**kw), [bytes(b"ACGT"[c] for c in X)], [bytes(b"ACGT"[c] for c in Y)], [ops])
+    tasks, _ = b.class_stats()
+    assert tasks[15:18].sum() == 1                       # a k_dp_rs class took it
+    b.run()
+    assert b.segment_arith()[1][0] == 1                  # ... and kept its range certificate
+    fv, fe = b.rs_forward(0, seg["cells"])
+    b.close()
+    d = orc.fb_f64(h, X, Y, seg["lo"], seg["n"])
+    post = d["Fm"] + d["Bm"]                             # log of forward x backward of the match state: total + log posterior
+    tot = d["total_ll"]
+    heavy = np.isfinite(post) & (post >= tot - 60 * LN2)
+    assert heavy.sum() > L and (fv[heavy] > 0).all()    # nothing that matters was flushed
+    lf = (np.log2(fv[heavy].astype(np.float64)) + fe[heavy]) * LN2
+    assert np.abs(lf - d["Fm"][heavy]).max() < 1e-4
+    # ... and everywhere else a positive value is as accurate; a zero is a flushed cell or one outside every path
+    rest = np.isfinite(d["Fm"]) & (fv > 0) & ~heavy
+    if rest.any():
+        lr = (np.log2(fv[rest].astype(np.float64)) + fe[rest]) * LN2
+        assert np.abs(lr - d["Fm"][rest]).max() < 1e-3  # (denormals: fewer bits)
+    flushed = np.isfinite(d["Fm"]) & (fv == 0)
+    assert not (flushed & heavy).any()
+
+
 def test_edge_cases(gpu_ctx):
     from nanopore_amd import realign as R
     gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))

@@ -122,6 +122,60 @@ def test_full_size_reference_test_data_runs(tmp_path, gpu_ctx):
     assert res[0]["n_segments"] >= 1 and res[0]["cells"] > 1e6
 
 
+def test_both_reference_test_reads_and_an_oracle_window_of_the_longer_one(tmp_path, gpu_ctx):
+    """BASELINE.json configs[0] with BOTH reads of the reference's tests/readFastqFiles fixture (32 750 and 38 435 bases) against
+    its 57.5 kb reference, either strand, through chainSamFile and the files -> file job.  The reads are repeats unrelated to the
+    reference (no co-linear homology), so the realigner works on wide unanchored rectangles: invariants for both, and for the
+    longer one a window checked against the oracle -- the matrix split (splitMatrixBiggerThanThis) makes every segment of the plan
+    an independent problem, so the fp64 oracle is run on one segment the CPU finishes in seconds and its posteriors compared
+    with the device's on that segment (1e-4, the tolerance north_star states)."""
+    from nanopore_amd import bioio, realign as R, sam as pysam
+    from nanopore_amd.analyses import utils
+    from nanopore_amd.hmm import Hmm
+    reads = [(n.split()[0], s) for n, s, _ in bioio.fastqRead(os.path.join(C1, "reads.fq"))]
+    rname, rseq = next(iter(bioio.fastaRead(os.path.join(C1, "reference.fa"))))
+    rname = rname.split()[0]
+    assert [len(s) for _, s in reads] == [32750, 38435]
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as fh:
+        for n, s in reads:
+            fh.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    mapping, chained, out = (str(tmp_path / k) for k in ("mapping.sam", "chained.sam", "realigned.sam"))
+    assert write_local_hits_sam(mapping, {rname: rseq}, dict(reads), k=18, min_len=24, both_strands=True) >= 2
+    fa = os.path.join(C1, "reference.fa")
+    utils.chainSamFile(mapping, chained, fq, fa)
+    res = utils.realignSamFile(chained, out, fq, fa, utils.trainedModelPath("blasr_hmm_0.txt"), 0.5, 0.0, ctx=gpu_ctx)
+    recs = list(pysam.Samfile(out, "r"))
+    guides = {a.qname: a for a in pysam.Samfile(chained, "r")}
+    assert sorted(a.qname for a in recs) == sorted(n for n, _ in reads) and len(res) == 2 and (res["status"] == 0).all()
+    by_name = dict(reads)
+    for a, r in zip(recs, res):
+        assert cigar_spans(a.cigar) == (len(rseq), len(by_name[a.qname]))
+        assert r["loglik"] == pytest.approx(r["loglik_bwd"], rel=1e-5) and r["cells"] > 1e6
+    # the longer read: one segment of its plan against the fp64 oracle
+    long_name = reads[1][0]
+    g = guides[long_name]
+    seq = g.seq.upper()
+    X = np.array(["ACGT".index(c) if c in "ACGT" else 4 for c in rseq.upper()], dtype=np.uint8)
+    Y = np.array(["ACGT".index(c) if c in "ACGT" else 4 for c in seq], dtype=np.uint8)
+    guide = [(op, n) for op, n in g.cigar if op in (0, 1, 2)]
+    kw = dict(band_mode=0, diagonal_expansion=10, constraint_trim=14, split_threshold=3000)
+    segs = orc.plan(len(X), len(Y), guide, orc.make_params(**kw))
+    pick = [s for s in segs if 2e4 <= s["cells"] <= 1.2e7]   # (a 3000 x 3000 rectangle: 9e6 cells, ~3 s of the fp64 oracle)
+    assert pick, [s["cells"] for s in segs]
+    seg = min(pick, key=lambda s: s["cells"])
+    gpu_ctx.set_hmm(Hmm.loadHmm(utils.trainedModelPath("blasr_hmm_0.txt")))
+    got = gpu_ctx.realign(R.make_params(max_pairs_per_base=24, **kw), [rseq.upper().encode()], [seq.encode()], [guide], want_pairs=True)[0]
+    assert got["status"] == 0 and got["n_segments"] == len(segs)
+    d = orc.fb_f64(oracle_hmm(), X[seg["xs"]:seg["xe"]], Y[seg["ys"]:seg["ye"]], seg["lo"], seg["n"], seg["ragged_start"], seg["ragged_end"], dense=False)
+    want = {(int(a) + seg["xs"], int(b) + seg["ys"]): float(c) for a, b, c in zip(d["px"], d["py"], d["pp"])}
+    have = {(int(a), int(b)): float(c) for a, b, c in zip(got["x"], got["y"], got["p"])
+            if seg["xs"] <= a < seg["xe"] and seg["ys"] <= b < seg["ye"]}
+    assert len(want) > 50
+    for key in set(want) | set(have):
+        assert abs(want.get(key, 0.01) - have.get(key, 0.01)) < 1e-4, key
+
+
 def test_all_posteriors_mode_and_tsv(tmp_path, gpu_ctx):
     """marginAlignSnpCaller.py:136-149: --outputAllPosteriorProbs TSV = 3 numeric columns, col0 a valid
     reference index, col1 a valid index into aR.query."""
