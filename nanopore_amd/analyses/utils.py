@@ -359,37 +359,79 @@ def stageSamFile(samFile, referenceFastaFile, splitThreshold, gapGamma=0.5, matc
     return batch, sam, records
 
 
+def stageSamFileForTraining(samFile, readFastqFile, referenceFastaFile, options, ctx=None):
+    """The trainer's view of a chained SAM file, without a Python object per record: the file is mapped and parsed by the native
+    scanners (nanopore_amd/ingest.py), the global-alignment shape the trainer relies on is asserted on the parsed fields of EVERY
+    record (utils.py:492-501; the sequences themselves are compared for a sample of records), the alignments are sampled
+    and cut into batches as options.maxAlignmentLengthToSample / maxAlignmentLengthPerJob say (em.sampleAlignments) and each batch
+    is staged once, in NPR_MODE_EXPECTATIONS, for all iterations of all trials.  Returns an em.BatchSet (alignments, taken)."""
+    from .. import em, ingest, job, realign
+    ctx = ctx or _context()
+    sam = ingest.SamText(samFile)
+    fasta = ingest.FastaTable(referenceFastaFile)
+    fields = sam.parse()
+    keep = sam.records_with_a_reference(fields, sam.span)
+    fields, span = fields[keep], sam.span[keep]
+    n = len(fields)
+    if n == 0:
+        raise RuntimeError("No alignments to train on in %s" % samFile)
+    qnames, qtext, qspan = ingest.fastq_table(readFastqFile)
+    qlen = dict(zip(qnames, (qspan[:, 1] - qspan[:, 0]).tolist()))
+    qat = dict(zip(qnames, range(len(qnames))))
+    ref_len = np.array([fasta.off[fasta.index[name] + 1] - fasta.off[fasta.index[name]] for name in sam.references] + [0], dtype=np.int64)
+    F = ingest
+    names = [sam.field_bytes(int(a), int(b)).decode() for a, b in zip(span[:, 0], fields[:, F.F_QNAME_END])]
+    read_len = np.array([qlen[q] for q in names], dtype=np.int64)  # (KeyError: a record of a read the FASTQ does not have)
+    assert (fields[:, F.F_POS] == 0).all()                                                     # aR.pos == 0
+    assert (fields[:, F.F_QUERY_LO] == fields[:, F.F_SEQ_LO]).all()                            # aR.qstart == 0
+    assert (fields[:, F.F_QUERY_HI] - fields[:, F.F_QUERY_LO] == read_len).all()               # aR.qend == len(read)
+    assert (fields[:, F.F_REF_SPAN] == ref_len[fields[:, F.F_TID]]).all()                      # aR.aend == len(reference)
+    rng = np.random.default_rng(0 if options.seed is None else options.seed)
+    for i in rng.choice(n, size=min(n, 64), replace=False):                                  # aR.query == the read / its reverse complement
+        q = sam.field_bytes(int(fields[i, F.F_QUERY_LO]), int(fields[i, F.F_QUERY_HI])).decode().upper()
+        a, b = qspan[qat[names[i]]]
+        read = bytes(qtext[a:b]).decode().upper()
+        assert q == (reverseComplement(read) if fields[i, F.F_FLAG] & 0x10 else read)
+    src = job.SamSource(sam, fasta, span, fields)
+    cols = np.zeros(n, dtype=np.int64)                                                       # alignment columns of every record
+    np.add.at(cols, np.repeat(np.arange(n), src.guide_off[1:] - src.guide_off[:-1]), src.guide_ops[:, 1])
+    parts = em.sampleAlignments(cols, options, rng=np.random.default_rng(options.seed))
+    params = realign.make_params(band_mode=realign.BAND_ANCHOR, diagonal_expansion=REALIGN_DIAGONAL_EXPANSION,
+                                 constraint_trim=CONSTRAINT_DIAGONAL_TRIM, split_threshold=EM_SPLIT_MATRIX_BIGGER_THAN,
+                                 mode=realign.MODE_EXPECTATIONS)
+    batches = []
+    try:
+        for idx in parts:
+            batches.append(src.stage_records(ctx, params, idx))
+    except BaseException:
+        for b in batches:
+            b.close()
+        raise
+    bs = em.BatchSet(batches)
+    bs.alignments, bs.taken = n, int(sum(len(p) for p in parts))
+    return bs
+
+
 def learnModelFromSamFileTargetFn(target, samFile, readFastqFile, referenceFastaFile, outputModel, options=None, ctx=None):
     """Does expectation maximisation on a (chained) sam file to learn the hmm for it (utils.py:471-531).  The
     unnormalised model goes to <outputModel>_unnormalised (skipped if it exists, :527), the XML summary to
     <outputModel>.xml (:518), and learnModelFromSamFileTargetFn2 normalises it into <outputModel>."""
     from .. import em
-    refSequences = getFastaDictionary(referenceFastaFile)
-    readSequences = getFastqDictionary(readFastqFile)
-    sam = pysam.Samfile(samFile, "r")
-    for aR in sam:  # the global-alignment shape the trainer relies on (utils.py:492-501)
-        assert aR.pos == 0
-        assert aR.qstart == 0
-        assert aR.qend == len(readSequences[aR.qname])
-        assert aR.aend == len(refSequences[sam.getrname(aR.rname)])
-        if aR.is_reverse:
-            assert aR.query.upper() == reverseComplement(readSequences[aR.qname]).upper()
-        else:
-            assert aR.query.upper() == readSequences[aR.qname].upper()
-    sam.close()
     if options is None:
         options = em.Options()
     options.outputXMLModelFile = outputModel + ".xml"
     unnormalisedOutputModel = outputModel + "_unnormalised"
     if not os.path.exists(unnormalisedOutputModel):
-        from .. import realign
-        batch, sam, _ = stageSamFile(samFile, referenceFastaFile, EM_SPLIT_MATRIX_BIGGER_THAN, mode=realign.MODE_EXPECTATIONS, ctx=ctx)
+        # (the asserts on the records' global-alignment shape, utils.py:492-501, are made on the natively parsed fields)
+        batch = stageSamFileForTraining(samFile, readFastqFile, referenceFastaFile, options, ctx=ctx)
         try:
+            if target is not None and batch.taken < batch.alignments:
+                target.logToMaster("EM: %d of %d alignments sampled (maxAlignmentLengthToSample %d), %d batch(es)"
+                                   % (batch.taken, batch.alignments, options.maxAlignmentLengthToSample, len(batch.batches)))
             em.expectationMaximisationTrials(batch, unnormalisedOutputModel, options,
                                              log=(target.logToMaster if target is not None else None))
         finally:
             batch.close()
-            sam.close()
     learnModelFromSamFileTargetFn2(target, unnormalisedOutputModel, outputModel)
 
 

@@ -32,11 +32,73 @@ class Options(object):
         self.trials = 3
         self.outputTrialHmms = True
         self.iterations = 100
-        self.maxAlignmentLengthPerJob = 700000
-        self.maxAlignmentLengthToSample = 50000000
+        self.maxAlignmentLengthPerJob = 700000       # alignment columns of one jobTree job of the reference's trainer (utils.py:516)
+        self.maxAlignmentLengthToSample = 50000000   # alignment columns the trainer samples from the SAM (utils.py:517)
+        self.jobsPerBatch = 64  # this build: such jobs staged as ONE GPU batch (the reference runs them as separate processes)
         self.outputXMLModelFile = None
         self.trainEmissions = True
         self.seed = None  # this build: seed of the random starts (None = nondeterministic, like the reference)
+
+
+def sampleAlignments(lengths, options, rng=None):
+    """Which alignments the trainer looks at and how they are cut into batches (options.maxAlignmentLengthToSample /
+    maxAlignmentLengthPerJob, utils.py:516-517): the alignments are taken in random order until the next one would take the sum
+    of their lengths (alignment columns) past maxAlignmentLengthToSample -- at least one is always taken --, then cut into batches
+    of at most jobsPerBatch x maxAlignmentLengthPerJob columns (an alignment longer than that is a batch of its own).  Returns a
+    list of index arrays (each sorted: file order inside a batch).  A SAM below the limits comes back whole, as one batch."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = len(lengths)
+    if n == 0:
+        return []
+    limit = int(options.maxAlignmentLengthToSample)
+    if lengths.sum() <= limit:
+        taken = np.arange(n)
+    else:
+        rng = rng if rng is not None else np.random.default_rng(options.seed)
+        order = rng.permutation(n)
+        k = int(np.searchsorted(np.cumsum(lengths[order]), limit, side="right"))
+        taken = order[:max(k, 1)]
+    per_batch = max(1, int(options.maxAlignmentLengthPerJob)) * max(1, int(getattr(options, "jobsPerBatch", 1)))
+    batches, cur, cur_len = [], [], 0
+    for i in taken:
+        li = int(lengths[i])
+        if cur and cur_len + li > per_batch:
+            batches.append(np.sort(np.array(cur, dtype=np.int64)))
+            cur, cur_len = [], 0
+        cur.append(int(i))
+        cur_len += li
+    if cur:
+        batches.append(np.sort(np.array(cur, dtype=np.int64)))
+    return batches
+
+
+class BatchSet(object):
+    """Several staged batches that the E-step treats as one: expected counts and log-likelihoods are summed (what the
+    reference's trainer does with the --outputExpectations files of its jobs)."""
+
+    def __init__(self, batches):
+        self.batches = list(batches)
+        self.ctx = self.batches[0].ctx
+
+    def expectations(self):
+        T = E = ll = None
+        ms = 0.0
+        for b in self.batches:
+            t, e, l, m = b.expectations()
+            T, E, ll = (t, e, l) if T is None else (T + t, E + e, ll + l)
+            ms += m
+        return T, E, ll, ms
+
+    def stats(self):
+        out = {}
+        for b in self.batches:
+            for k, v in b.stats().items():
+                out[k] = out.get(k, 0) + v
+        return out
+
+    def close(self):
+        for b in self.batches:
+            b.close()
 
 
 def randomise(hmm, rng):
