@@ -1538,7 +1538,10 @@ int32_t device_mea(npr_batch *b) {
     const int ring = 8192;
     const int64_t total = rp[n];
     // the pieces the chain of every read is cut into (npr_mea.hip k_mea_cuts): about 2000 posterior pairs (1200 kept) each
-    constexpr int64_t kPiecePairs = 2048, kMaxPieces = 64;
+    // ... fewer in a small batch, so that the pieces (one lane each, a serial walk) still fill the chip: 1000 reads of 1 kb as 1000
+    // pieces of 1100 kept pairs took 0.9 ms where 14 000 pieces of 80 take 0.1
+    constexpr int64_t kMaxPieces = 64, kLanesWanted = 64 * 5 * 256;
+    const int64_t kPiecePairs = std::min<int64_t>(2048, std::max<int64_t>(128, total / kLanesWanted));
     std::vector<int32_t> np(n);
     int64_t n_pieces = 0;
     for (int64_t i = 0; i < n; ++i) np[i] = static_cast<int32_t>(std::min(kMaxPieces, std::max<int64_t>(1, (rp[i + 1] - rp[i] + kPiecePairs - 1) / kPiecePairs))), n_pieces += np[i];

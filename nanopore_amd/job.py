@@ -30,7 +30,9 @@ import numpy as np
 from . import _lib
 from . import dist as npd
 
-CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", 100_000_000))  # ~12 k reads of 8 kb: two per resident wavefront
+_DEFAULT_CHUNK_BASES = 100_000_000
+CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", _DEFAULT_CHUNK_BASES))  # ~12 k reads of 8 kb: two per resident wavefront
+MIN_CHUNK_READS = int(os.environ.get("NPR_JOB_MIN_CHUNK_READS", 12288))  # reads of a chunk at the default chunk size (a caller who asks for smaller chunks gets them)
 WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 3))  # chunks in flight (contexts per GPU): one in its DP, one being finished / fetched, one staged ahead
 TRACE = os.environ.get("NPR_JOB_TRACE") is not None  # timings["trace"]: (phase, start, end) per chunk, seconds (tools/job_trace.py)
 
@@ -179,8 +181,9 @@ def close_contexts():
 
 
 def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
-    """[lo, hi) cut into chunks of about chunk_bases read bases (equal shares of the bases), at least `workers` of them when
-    the range can keep as many batches busy (a chunk below ~4 k reads leaves most wavefront slots of a DP launch idle)."""
+    """[lo, hi) cut into chunks of about chunk_bases read bases (equal shares of the bases), none below MIN_CHUNK_READS reads at the
+    default chunk size."""
+    min_reads = MIN_CHUNK_READS if (chunk_bases is None and CHUNK_BASES == _DEFAULT_CHUNK_BASES) else 1
     chunk_bases = chunk_bases or CHUNK_BASES
     workers = workers or WORKERS
     n = hi - lo
@@ -188,8 +191,10 @@ def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
         return []
     total = float(np.sum(lengths[lo:hi]))
     k = max(1, int(round(total / chunk_bases)))
-    if k < workers and n >= 4096 * workers:
-        k = workers
+    # A DP launch lasts at least as long as its longest read on its one wavefront (a 20 kb read: 45 ms, what 12 000 reads of 8 kb
+    # take when they fill the chip), so a chunk below ~12 k reads buys its overlap with DP time: 12 500 reads as three chunks ran
+    # 3 x 40 ms of DP launches where one launch takes 59 (round 4).  Fewer, fuller chunks; one when the range is small.
+    k = max(1, min(k, n // min_reads))
     k = min(k, n)
     cuts = lo + npd.shard_ranges(lengths[lo:hi], k)
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
