@@ -795,7 +795,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     DevBuf<PlanPoint> d_points;
     DevBuf<SegSummary> d_summary;
     if ((e = d_points.alloc_from(ctx, npoints)) != hipSuccess || (e = b->d_pseg.alloc_from(ctx, ntasks)) != hipSuccess || (e = d_summary.alloc_from(ctx, ntasks)) != hipSuccess ||
-        (e = b->d_lo.alloc_from(ctx, band_entries)) != hipSuccess || (e = b->d_n.alloc_from(ctx, band_entries)) != hipSuccess ||
+        (e = b->d_lo.alloc_from(ctx, band_entries + 16)) != hipSuccess || (e = b->d_n.alloc_from(ctx, band_entries + 16)) != hipSuccess ||  // (+16: the schedule's walkers read rows four at a time, up to eight past a segment's last)
         (e = b->d_seq.alloc_from(ctx, seq_bytes + 16)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     std::vector<SegSummary> summary(ntasks);
@@ -859,7 +859,22 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         HIP_TRY(ctx, hipMemcpyAsync(d_cand.p, cand.data(), d_cand.bytes(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(d_off.p, sched_off.data(), d_off.bytes(), hipMemcpyHostToDevice, ctx->stream));
         SchedArgs sa{static_cast<int32_t>(ntasks), b->d_pseg.p, d_summary.p, b->d_lo.p, b->d_n.p, d_off.p, d_cand.p, b->d_ctl.p, d_cls.p, d_cells.p};
-        const int rc = launch_plan_sched(sa, ctx->stream);
+        // the walk of a segment in chunks that compose (npr_plan.hip): chunk tables
+        std::vector<int64_t> chunk_off(ntasks + 1, 0);
+        uint32_t cand_union = 0;
+        for (int64_t k = 0; k < ntasks; ++k) {
+            chunk_off[k + 1] = chunk_off[k] + (cand[k] ? plan_sched_chunks_of(static_cast<int64_t>(pseg[k].lX) + pseg[k].lY) : 0);
+            cand_union |= cand[k];
+        }
+        const int64_t n_chunks = chunk_off[ntasks];
+        DevBuf<int64_t> d_chunk_off;
+        DevBuf<uint8_t> d_chunks;
+        DevBuf<int32_t> d_cur;
+        if ((e = d_chunk_off.alloc_from(ctx, ntasks + 1)) != hipSuccess || (e = d_chunks.alloc_from(ctx, plan_sched_chunk_bytes(n_chunks))) != hipSuccess ||
+            (e = d_cur.alloc_from(ctx, ntasks + kSchedClasses)) != hipSuccess)
+            return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
+        HIP_TRY(ctx, hipMemcpyAsync(d_chunk_off.p, chunk_off.data(), d_chunk_off.bytes(), hipMemcpyHostToDevice, ctx->stream));
+        const int rc = launch_plan_sched(sa, d_chunk_off.p, n_chunks, d_chunks.p, d_cur.p, cand_union, ctx->stream);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_plan_sched launch", static_cast<hipError_t>(rc));
         HIP_TRY(ctx, hipMemcpyAsync(sched_cls.data(), d_cls.p, d_cls.bytes(), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(sched_cells.data(), d_cells.p, d_cells.bytes(), hipMemcpyDeviceToHost, ctx->stream));

@@ -217,7 +217,11 @@ struct RowMaskArgs {
     uint32_t *out;
 };
 int launch_plan_rowmask(const RowMaskArgs &a, void *stream);
-int launch_plan_sched(const SchedArgs &a, void *stream);
+// the frame schedules in chunks (npr_plan.hip): chunk_off = prefix sum of plan_sched_chunks_of(D) over the segments (device, n_segs + 1
+// entries), `chunks` = plan_sched_chunk_bytes(n_chunks) of scratch, cur = n_segs + kSchedClasses ints of scratch, cand_union = OR of the segments' candidate masks
+size_t plan_sched_chunk_bytes(int64_t n_chunks);
+int64_t plan_sched_chunks_of(int64_t D);
+int launch_plan_sched(const SchedArgs &a, const int64_t *chunk_off, int64_t n_chunks, void *chunks, int32_t *cur, uint32_t cand_union, void *stream);
 int launch_plan_stripes(const StripeArgs &a, void *stream);
 int launch_plan_coff(const CoffArgs &a, void *stream);
 int launch_encode(uint8_t *seq, int64_t n, void *stream);

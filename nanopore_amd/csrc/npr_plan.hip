@@ -80,89 +80,209 @@ __global__ void __launch_bounds__(BAND_THREADS) k_plan_bands(PlanArgs a) {
     }
 }
 
-// The schedule is a sequential scan per segment (every rebase depends on all steps before it), so the parallelism is ACROSS
-// segments: a wavefront takes 16 of them and 16 of its lanes walk them in lockstep.  What a walking lane needs -- its own
-// segment's band rows, one after the other -- is the worst pattern for memory, so the rows go through LDS: for every tile
-// of 31 anti-diagonals all 64 lanes load the 32 rows (31 + the one looked ahead) of two segments per instruction, eight
-// independent instructions per tile; the finished control words go back the same way, coalesced.  Few walking lanes per
-// wavefront on purpose: the walk is a chain of dependent integer operations, what hides its latency is the number of
-// wavefronts, not their width.  (One lane per segment straight from memory: 47 ms for the 12288 reads of the default bench;
-// one wavefront per segment on the scalar unit: 40 ms -- a CU issues one scalar instruction per cycle whatever its
-// occupancy; 64 segments per wavefront: 28 ms.)
-#ifndef NPR_SCHED_SEGS
-#define NPR_SCHED_SEGS 8  // segments per wavefront: 16 left the chip with less than one wavefront per SIMD on 12 k segments (46 -> 42 ms staging)
-#endif
-constexpr int SCHED_TILE = 31, SCHED_SEGS = NPR_SCHED_SEGS;
-__global__ void __launch_bounds__(64) k_plan_sched(SchedArgs a) {
-    __shared__ int t_lo[SCHED_SEGS][SCHED_TILE + 2], t_n[SCHED_SEGS][SCHED_TILE + 2];  // (row stride 33: conflict-free walks)
-    __shared__ uint32_t t_w0[SCHED_SEGS][SCHED_TILE + 2], t_w1[SCHED_SEGS][SCHED_TILE + 2];
-    const int lane = threadIdx.x;
-    const int half = lane >> 5, row = lane & 31;
-    for (int g0 = blockIdx.x * SCHED_SEGS; g0 < a.n_segs; g0 += gridDim.x * SCHED_SEGS) {
-        const int g = g0 + lane;
-        const bool have = lane < SCHED_SEGS && g < a.n_segs;
-        PlanSeg sg{};
-        if (have) sg = a.segs[g];
-        const int64_t ctl_off = have ? a.ctl_off[g] : -1;
-        const uint32_t cand = (have && ctl_off >= 0 && a.summary[g].bad == 0) ? a.cand[g] : 0u;
-        const int max_width = have ? a.summary[g].max_width : 0;
-        const int D = sg.lX + sg.lY;
-        int cls = -1;
-        uint32_t cells = 0;
-        for (int c = 0; c < kSchedClasses; ++c) {
-            const bool active = cls < 0 && ((cand >> c) & 1u);
-            if (!__any(active)) continue;
-            const int R = kSchedR[c], NW = kSchedNW[c], rshift = stair_rshift(R), C = 64 * R * NW;
-            StairState st{0, 0, 0, 0, 0, 0};
-            int ok = 0;
-            if (active) ok = stair_begin(st, a.lo[sg.band_off], a.n[sg.band_off], max_width, R, NW) ? 1 : 0;
-            int Dmax = active ? D : -1;
+// The frame schedule is a sequential scan per segment -- every rebase depends on the frame's position, which depends on every
+// step before it -- and rounds 1-3 walked it that way (k_plan_sched: a lane per segment, eight segments per wavefront, rows staged
+// through LDS): 14 ms for the 24 576 segments of the headline batch and 20 ms for ANY batch that holds one 20 kb read, because the
+// walk of the longest segment (40 000 steps of ~1 000 cycles) is what the staging waits for.  Round 4 cuts the walk into chunks:
+//
+//   The only state a step depends on is flo, the frame's first x-y (npr_sched.h stair_step), and on the positions a valid
+//   schedule can be in a step is a CLAMP of it: an X-step takes flo to max(flo + 1, c) with c = max(hi - span, hi_next - span + 1)
+//   (rebase when the band's top would leave the frame now, or at the Y-step after it, which cannot rebase upwards), a Y-step to
+//   min(flo - 1, c) with c = min(lo, lo_next - 1).  Clamps of a shifted argument compose to a clamp of a shifted argument:
+//   SCHED_CHUNK steps take flo to min(max(flo + A, L), U).
+//
+//   k_sched_compose  a lane per chunk: (A, L, U) of its steps -- no state, a few integer operations per step
+//   k_sched_starts   a lane per segment: flo at the head of each of its chunks, chunk after chunk (a few dozen clamps)
+//   k_sched_walk     a lane per chunk: the real walk (stair_step: the host planner's function) from that flo, control words with the
+//                    chunk's own row offsets; it goes on two steps into the next chunk to learn their `moved` bits (which need the
+//                    band of the two rows before)
+//   k_sched_finish   a lane per segment: prefix of the chunks' cells (the row offsets' base), whether every chunk could be followed and the
+//                    schedule fits its class -> the segment's class, or on to its next candidate class
+//   k_sched_patch    a wavefront per chunk: the offset base added to its words, the first two rows' `moved` bits set
+//
+// once per class that is a candidate of any segment, smallest frame first.  A chunk whose walk leaves the valid positions (ok = 0) fails
+// the segment for that class exactly as the sequential walk would: the clamp form only differs from stair_step where that one fails.
+// npr_batch_plan_check compares the result word for word with the host planner's sequential stair_schedule (tests/test_gpu_plan.py).
+constexpr int SCHED_CHUNK = 256;
+struct SchedChunk {
+    int32_t A, L, U;       // the chunk's steps as a map of flo
+    int32_t flo;           // at its head (before its first step)
+    uint32_t cells;        // rows of its steps, in scratch cells
+    int32_t ok;
+    uint32_t moved_next;   // bit 0 / 1: the `moved` bits of the first / second row of the NEXT chunk
+    uint32_t base;         // scratch cells before the chunk
+    int32_t seg;           // the segment it belongs to
+    int32_t pad[3];
+};
+struct SchedWork {
+    SchedArgs a;
+    const int64_t *chunk_off;  // per segment: its first chunk (prefix sum of the chunks per segment; n_segs + 1 entries)
+    SchedChunk *chunks;
+    int32_t *cur;              // per segment: the class being tried, or -1 when it has its class / no candidate is left
+    int64_t n_chunks;
+    int32_t cls;               // the class of this round
+    int32_t *active;           // [kSchedClasses]: segments that try class c (a round without any returns at once)
+};
+struct RowQuad {
+    int lo[4], n[4];
+};
+__device__ __forceinline__ RowQuad row_quad(const int32_t *lo_, const int32_t *n_, int d) {  // rows d .. d + 3 (dword-aligned 16-byte loads)
+    typedef int v4 __attribute__((ext_vector_type(4), aligned(4)));
+    const v4 a = *reinterpret_cast<const v4 *>(lo_ + d), b = *reinterpret_cast<const v4 *>(n_ + d);
+    return RowQuad{{a.x, a.y, a.z, a.w}, {b.x, b.y, b.z, b.w}};
+}
+__global__ void __launch_bounds__(64) k_sched_begin(SchedWork w) {  // the first candidate class of every segment
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= w.a.n_segs) return;
+    const uint32_t cand = (w.a.ctl_off[g] >= 0 && w.a.summary[g].bad == 0) ? w.a.cand[g] : 0u;
+    w.cur[g] = cand ? __builtin_ctz(cand) : -1;
+    if (cand) atomicAdd(w.active + __builtin_ctz(cand), 1);
+    w.a.cls[g] = -1, w.a.cells[g] = 0;
+    for (int64_t ci = w.chunk_off[g]; ci < w.chunk_off[g + 1]; ++ci) w.chunks[ci].seg = g;
+}
+__global__ void __launch_bounds__(64) k_sched_compose(SchedWork w) {
+    if (w.active[w.cls] == 0) return;
+    const int64_t ci = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
+    if (ci >= w.n_chunks) return;
+    const int g = w.chunks[ci].seg;
+    if (w.cur[g] != w.cls) return;
+    const PlanSeg sg = w.a.segs[g];
+    const int D = sg.lX + sg.lY, C = 64 * kSchedR[w.cls] * kSchedNW[w.cls], span = 2 * (C - 1);
+    const int d0 = static_cast<int>(ci - w.chunk_off[g]) * SCHED_CHUNK, d1 = min(d0 + SCHED_CHUNK - 1, D);
+    const int32_t *lo_ = w.a.lo + sg.band_off, *n_ = w.a.n + sg.band_off;
+    constexpr int BIG = 1 << 29;
+    int A = 0, L = -BIG, U = BIG;
+    // rows four at a time (a lane's rows are its own cache lines: a 16-byte load per array and four steps instead of four 4-byte ones;
+    // d_lo / d_n are padded so that the look-ahead past a segment's last row stays inside them), the next four fetched ahead
+    RowQuad cur = row_quad(lo_, n_, d0), nxt = row_quad(lo_, n_, d0 + 4);
+    for (int q0 = d0; q0 <= d1; q0 += 4) {
+        const RowQuad far = row_quad(lo_, n_, q0 + 8);
 #pragma unroll
-            for (int k = 32; k > 0; k >>= 1) Dmax = max(Dmax, __shfl_xor(Dmax, k, 64));
-            for (int base = 0; base <= Dmax; base += SCHED_TILE) {
-                if (!__any(ok && base <= D)) break;
-                // rows base .. base + 31 of the walking segments into LDS: two segments per instruction
-#pragma unroll
-                for (int q = 0; q < SCHED_SEGS / 2; ++q) {
-                    const int s2 = 2 * q + half;
-                    const int walking = __shfl(ok && base <= D, s2, 64);
-                    const int64_t off = __shfl(sg.band_off, s2, 64);
-                    const int Ds = __shfl(D, s2, 64);
-                    if (walking && base + row <= Ds) {
-                        t_lo[s2][row] = a.lo[off + base + row];
-                        t_n[s2][row] = a.n[off + base + row];
-                    }
+        for (int i = 0; i < 4; ++i) {
+            const int d = q0 + i;
+            if (d > d1) break;
+            const bool next = d < D;
+            const int lo_c = cur.lo[i], n_c = cur.n[i];
+            const int lo_x = i < 3 ? cur.lo[i + 1] : nxt.lo[0], n_x = i < 3 ? cur.n[i + 1] : nxt.n[0];
+            if (d > 0) {
+                if (d & 1) {
+                    const int hi = lo_c + 2 * (n_c - 1), hi_nx = lo_x + 2 * (n_x - 1);
+                    const int c = max(hi - span, next ? hi_nx - span + 1 : -BIG);
+                    A += 1, L = max(L + 1, c), U = max(U + 1, c);
+                } else {
+                    const int c = min(lo_c, next ? lo_x - 1 : BIG);
+                    A -= 1, L = min(L - 1, c), U = min(U - 1, c);
                 }
-                __syncthreads();
-                const bool walk = ok && base <= D;
-                if (walk) {
-                    const int cnt = min(SCHED_TILE, D + 1 - base);
-                    int lo_c = t_lo[lane][0], n_c = t_n[lane][0];  // the row in hand stays in registers: two LDS reads per step, not four
-                    for (int i = 0; i < cnt && ok; ++i) {
-                        const int lo_x = t_lo[lane][i + 1], n_x = t_n[lane][i + 1];
-                        uint32_t w0 = 0, w1 = 0;
-                        ok = stair_step(st, base + i, D, lo_c, n_c, lo_x, n_x, rshift, C, w0, w1) ? 1 : 0;
-                        t_w0[lane][i] = w0, t_w1[lane][i] = w1;
-                        lo_c = lo_x, n_c = n_x;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < SCHED_SEGS / 2; ++q) {
-                    const int s2 = 2 * q + half;
-                    const int done = __shfl(walk && ok, s2, 64);  // (a segment that failed in this tile is retried in the next class)
-                    const int64_t off = __shfl(ctl_off, s2, 64);
-                    const int Ds = __shfl(D, s2, 64);
-                    if (done && row < SCHED_TILE && base + row <= Ds) {
-                        uint2 *dst = reinterpret_cast<uint2 *>(a.ctl + 2 * (off + base + row));
-                        *dst = make_uint2(t_w0[s2][row], t_w1[s2][row]);
-                    }
-                }
-                __syncthreads();
             }
-            if (active && ok) cls = c, cells = st.off;
         }
-        if (have) a.cls[g] = cls, a.cells[g] = cls >= 0 ? static_cast<int64_t>(cells) : 0;
+        cur = nxt, nxt = far;
+    }
+    SchedChunk &k = w.chunks[ci];
+    k.A = A, k.L = L, k.U = U;
+}
+__global__ void __launch_bounds__(64) k_sched_starts(SchedWork w) {
+    if (w.active[w.cls] == 0) return;
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= w.a.n_segs || w.cur[g] != w.cls) return;
+    const PlanSeg sg = w.a.segs[g];
+    const int R = kSchedR[w.cls], NW = kSchedNW[w.cls];
+    StairState st{0, 0, 0, 0, 0, 0};
+    const bool ok = stair_begin(st, w.a.lo[sg.band_off], w.a.n[sg.band_off], w.a.summary[g].max_width, R, NW);
+    int flo = st.flo;
+    for (int64_t ci = w.chunk_off[g]; ci < w.chunk_off[g + 1]; ++ci) {
+        SchedChunk &k = w.chunks[ci];
+        k.flo = flo, k.ok = ok ? 1 : 0;
+        flo = min(max(flo + k.A, k.L), k.U);
+    }
+}
+__global__ void __launch_bounds__(64) k_sched_walk(SchedWork w) {
+    if (w.active[w.cls] == 0) return;
+    const int64_t ci = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
+    if (ci >= w.n_chunks) return;
+    const int g = w.chunks[ci].seg;
+    if (w.cur[g] != w.cls) return;
+    SchedChunk &k = w.chunks[ci];
+    if (!k.ok) return;  // (stair_begin refused the class)
+    const PlanSeg sg = w.a.segs[g];
+    const int R = kSchedR[w.cls], NW = kSchedNW[w.cls], rshift = stair_rshift(R), C = 64 * R * NW;
+    const int D = sg.lX + sg.lY;
+    const int d0 = static_cast<int>(ci - w.chunk_off[g]) * SCHED_CHUNK, d1 = min(d0 + SCHED_CHUNK - 1, D);
+    const int32_t *lo_ = w.a.lo + sg.band_off, *n_ = w.a.n + sg.band_off;
+    uint2 *ctl = reinterpret_cast<uint2 *>(w.a.ctl + 2 * w.a.ctl_off[g]);
+    StairState st{k.flo, 0, 0, 0, 0, 0};
+    int ok = 1;
+    typedef unsigned v4u __attribute__((ext_vector_type(4), aligned(8)));
+    uint32_t cells = 0, moved_next = 0;
+    const int dlast = min(d1 + 2, D);  // two rows into the next chunk: their `moved` bits need this chunk's last two bands
+    RowQuad cur = row_quad(lo_, n_, d0), nxt = row_quad(lo_, n_, d0 + 4);
+    for (int q0 = d0; q0 <= dlast && ok; q0 += 4) {
+        const RowQuad far = row_quad(lo_, n_, q0 + 8);
+        uint32_t w0[4], w1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = q0 + i;
+            w0[i] = w1[i] = 0;
+            if (d > dlast || !ok) continue;
+            const int lo_x = i < 3 ? cur.lo[i + 1] : nxt.lo[0], n_x = i < 3 ? cur.n[i + 1] : nxt.n[0];
+            ok = stair_step(st, d, D, cur.lo[i], cur.n[i], d < D ? lo_x : 0, d < D ? n_x : 0, rshift, C, w0[i], w1[i]) ? 1 : 0;
+            if (d <= d1) {
+                cells = st.off;
+            } else {
+                moved_next |= ((w1[i] >> 30) & 1u) << (d - d1 - 1);
+                ok = 1;  // (what goes wrong in the next chunk's rows is that chunk's to report)
+            }
+        }
+        // the four rows' words (a chunk's rows are whole quads but the segment's last; a failed chunk's words are never looked at)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2)
+            if (q0 + i + 1 <= d1) *reinterpret_cast<v4u *>(ctl + q0 + i) = v4u{w0[i], w1[i], w0[i + 1], w1[i + 1]};
+            else if (q0 + i <= d1) ctl[q0 + i] = make_uint2(w0[i], w1[i]);
+        cur = nxt, nxt = far;
+    }
+    k.cells = cells, k.ok = ok, k.moved_next = moved_next;
+}
+__global__ void __launch_bounds__(64) k_sched_finish(SchedWork w) {
+    if (w.active[w.cls] == 0) return;
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= w.a.n_segs || w.cur[g] != w.cls) return;
+    const bool packed = stair_packed(kSchedR[w.cls], kSchedNW[w.cls]);
+    uint64_t total = 0;
+    bool ok = true;
+    for (int64_t ci = w.chunk_off[g]; ci < w.chunk_off[g + 1]; ++ci) {
+        SchedChunk &k = w.chunks[ci];
+        k.base = static_cast<uint32_t>(total);
+        ok = ok && k.ok != 0;
+        total += k.cells;
+        if (total >= (packed ? uint64_t((1u << 29) - 512u) : (uint64_t(1) << 32))) ok = false;  // (stair_step's limit on the row offsets)
+    }
+    if (ok) {
+        w.a.cls[g] = w.cls, w.a.cells[g] = static_cast<int64_t>(total);
+        w.cur[g] = -1 - w.cls - 1;  // done in this round: k_sched_patch finishes its words (-2 - cls), then nothing looks at it again
+    } else {
+        const uint32_t left = w.a.cand[g] & ~((2u << w.cls) - 1u);
+        w.cur[g] = left ? __builtin_ctz(left) : -1;
+        if (left) atomicAdd(w.active + __builtin_ctz(left), 1);
+    }
+}
+__global__ void __launch_bounds__(64) k_sched_patch(SchedWork w) {
+    if (w.active[w.cls] == 0) return;
+    const int64_t ci = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int g = w.chunks[ci].seg;
+    if (w.cur[g] != -2 - w.cls) return;
+    const PlanSeg sg = w.a.segs[g];
+    const int D = sg.lX + sg.lY;
+    const int64_t c0 = w.chunk_off[g];
+    const int d0 = static_cast<int>(ci - c0) * SCHED_CHUNK, d1 = min(d0 + SCHED_CHUNK - 1, D);
+    const bool packed = stair_packed(kSchedR[w.cls], kSchedNW[w.cls]);
+    const uint32_t add = packed ? w.chunks[ci].base << 3 : w.chunks[ci].base;
+    const uint32_t mv = ci > c0 ? w.chunks[ci - 1].moved_next : 0u;
+    uint2 *ctl = reinterpret_cast<uint2 *>(w.a.ctl + 2 * w.a.ctl_off[g]);
+    for (int d = d0 + lane; d <= d1; d += 64) {
+        uint2 v = ctl[d];
+        v.x += add;
+        if (ci > c0 && d - d0 < 2) v.y = (v.y & ~(1u << 30)) | (((mv >> (d - d0)) & 1u) << 30);
+        ctl[d] = v;
     }
 }
 
@@ -286,9 +406,24 @@ int launch_plan_bands(const PlanArgs &a, void *stream) {
     hipLaunchKernelGGL(k_plan_bands, dim3(grid), dim3(BAND_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return static_cast<int>(hipGetLastError());
 }
-int launch_plan_sched(const SchedArgs &a, void *stream) {
-    const int grid = (a.n_segs + SCHED_SEGS - 1) / SCHED_SEGS > 0 ? (a.n_segs + SCHED_SEGS - 1) / SCHED_SEGS : 1;
-    hipLaunchKernelGGL(k_plan_sched, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+size_t plan_sched_chunk_bytes(int64_t n_chunks) { return sizeof(SchedChunk) * static_cast<size_t>(n_chunks > 0 ? n_chunks : 1); }
+int64_t plan_sched_chunks_of(int64_t D) { return D / SCHED_CHUNK + 1; }  // chunks of a segment with D + 1 anti-diagonals
+int launch_plan_sched(const SchedArgs &a, const int64_t *chunk_off, int64_t n_chunks, void *chunks, int32_t *cur, uint32_t cand_union, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SchedWork w{a, chunk_off, static_cast<SchedChunk *>(chunks), cur, n_chunks, 0, cur + a.n_segs};  // (cur: n_segs + kSchedClasses ints)
+    if (hipMemsetAsync(w.active, 0, sizeof(int32_t) * kSchedClasses, s) != hipSuccess) return static_cast<int>(hipGetLastError());
+    const int gs = (a.n_segs + 63) / 64 > 0 ? (a.n_segs + 63) / 64 : 1;
+    const int gc = static_cast<int>((n_chunks + 63) / 64 > 0 ? (n_chunks + 63) / 64 : 1);
+    hipLaunchKernelGGL(k_sched_begin, dim3(gs), dim3(64), 0, s, w);
+    for (int c = 0; c < kSchedClasses; ++c) {
+        if (!((cand_union >> c) & 1u)) continue;
+        w.cls = c;
+        hipLaunchKernelGGL(k_sched_compose, dim3(gc), dim3(64), 0, s, w);
+        hipLaunchKernelGGL(k_sched_starts, dim3(gs), dim3(64), 0, s, w);
+        hipLaunchKernelGGL(k_sched_walk, dim3(gc), dim3(64), 0, s, w);
+        hipLaunchKernelGGL(k_sched_finish, dim3(gs), dim3(64), 0, s, w);
+        hipLaunchKernelGGL(k_sched_patch, dim3(static_cast<unsigned>(n_chunks > 0 ? n_chunks : 1)), dim3(64), 0, s, w);
+    }
     return static_cast<int>(hipGetLastError());
 }
 int launch_plan_stripes(const StripeArgs &a, void *stream) {

@@ -43,6 +43,15 @@ def _em_batch(ctx):
     return ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
 
 
+def _release_device_memory(gpu_ctx):
+    """The processes these tests start need the HBM this session's earlier (full-size) tests left in the device's scratch and in the
+    contexts' caches (npr_ctx_option NPR_OPT_RELEASE_SCRATCH)."""
+    from nanopore_amd import job
+    for c in [gpu_ctx] + [c for pool in job._ctx_pool.values() for c in pool]:
+        if getattr(c, "_h", None):
+            c.release_scratch()
+
+
 def _nccl_rank(rank, port, n_reads, out_dir):
     import torch
     import torch.distributed as dist
@@ -98,6 +107,7 @@ def test_job_and_em_collectives_run_on_device_tensors_under_nccl(gpu_ctx, tmp_pa
     n_reads = 640
     out_dir = str(tmp_path / "nccl")
     os.makedirs(out_dir)
+    _release_device_memory(gpu_ctx)
     mp.spawn(_nccl_rank, args=(_free_port(), n_reads, out_dir), nprocs=1, join=True)
     # the same calls without torch.distributed
     w, W = _workload(n_reads)
@@ -131,10 +141,7 @@ def test_plain_bench_command_line_starts_its_own_ranks(gpu_ctx, tmp_path):
     test hook (gloo collectives), rank 0 prints ONE JSON line with the weak-scaling headline and the strong-scaling job beside
     it, and the exit code is 0."""
     from nanopore_amd import job
-    # the ranks need the HBM this session's earlier (full-size) tests left in the device's scratch and in the contexts' caches
-    for c in [gpu_ctx] + [c for pool in job._ctx_pool.values() for c in pool]:
-        if getattr(c, "_h", None):
-            c.release_scratch()
+    _release_device_memory(gpu_ctx)
     env = dict(os.environ, NPR_BENCH_SHARE_GPU="1", NPR_BENCH_ALSO_READS="1024", TMPDIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
