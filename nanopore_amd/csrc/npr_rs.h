@@ -133,7 +133,9 @@ struct RsTables {
 };
 constexpr int RS_DEAD8 = 5 * RS_YS, RS_DEADX = 5 * RS_XS;
 #ifndef NPR_RS_DEADCODE_MAX_R
-#define NPR_RS_DEADCODE_MAX_R 1  // slots per lane up to which it is used: one cell per lane gains 4 % (config 2: 1.75 -> 1.69 ms), two lose 1 %
+#define NPR_RS_DEADCODE_MAX_R 2  // slots per lane up to which it is used: one cell per lane gains 4 % (config 2: 1.75 -> 1.69 ms); two lost 1 % in round 3 and
+                                 // gain since round 4 (no switch terms, seven wavefronts per SIMD): a 1/8 shard of config 3 -- a launch that is its longest read's
+                                 // serial chain -- 44.5 -> 42.1 ms (two lane-mask regions and their branches fewer per step), the headline batch 139.0 -> 138.5
 #endif
 constexpr int RS_TABLE_FLOATS = sizeof(RsTables) / sizeof(float);
 __device__ __forceinline__ void rs_build_tables(RsTables *t, const DevModel *m, int tid, int nthreads) {
@@ -291,43 +293,55 @@ __device__ __forceinline__ int rs_renorm(RDiag<R> &P, RDiag<R> &Q) {
 // the previous VALU instruction needs two wait states, which the compiler cannot see through inline assembly.)
 // ---- generated by tools/gen_rs_rebase.py ----
 __device__ __forceinline__ void rs_rebase_rows(RDiag<1> &P, RDiag<1> &Q, int dir) {
-    asm volatile("s_cmp_eq_u32 %10, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %10, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %10, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly)
                  : "s"(dir)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_rows(RDiag<2> &P, RDiag<2> &Q, int dir) {
-    asm volatile("s_cmp_eq_u32 %20, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %20, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %20, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly)
                  : "s"(dir)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_rows(RDiag<4> &P, int dir) {
-    asm volatile("s_cmp_eq_u32 %20, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %20, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %20, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %9, %10\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %13, %14\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %17, %18\n\tv_swap_b32 %18, %19\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %10, %9\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %14, %13\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %18, %17\n\tv_swap_b32 %17, %16\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[2].m), "+v"(P.c[3].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[2].sx), "+v"(P.c[3].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[2].sy), "+v"(P.c[3].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[2].lx), "+v"(P.c[3].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(P.c[2].ly), "+v"(P.c[3].ly)
                  : "s"(dir)
                  : "scc");
@@ -335,150 +349,190 @@ __device__ __forceinline__ void rs_rebase_rows(RDiag<4> &P, int dir) {
 __device__ __forceinline__ void rs_rebase_rows(RDiag<4> &P, RDiag<4> &Q, int dir) { rs_rebase_rows(P, dir), rs_rebase_rows(Q, dir); }
 __device__ __forceinline__ void rs_rebase_streams_fwd(Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %3, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %3, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %3, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %8, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %2, %4, %8\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %2, %8, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %5, %2\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %0, %2, 63\n\tv_writelane_b32 %1, %11, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %9, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %2, %6, %9\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %2, %9, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %7, %2\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %1, %2, 0\n\tv_writelane_b32 %0, %10, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_streams_bwd(Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %3, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %3, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %3, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %9, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %2, %6, %9\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %2, %9, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %7, %2\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %1, %2, 63\n\tv_writelane_b32 %0, %10, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %8, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %2, %4, %8\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %2, %8, 64\n\ts_nop 3\n\tv_readlane_b32 %2, %5, %2\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %11, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_streams_fwd(Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %5, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %5, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %5, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %10, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %4, %6, %10\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %4, %10, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %7, %4\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %1, %4, 63\n\tv_writelane_b32 %3, %13, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %11, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %4, %8, %11\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %4, %11, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %9, %4\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %2, %4, 0\n\tv_writelane_b32 %0, %12, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_streams_bwd(Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %5, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %5, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %5, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %11, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %4, %8, %11\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %4, %11, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %9, %4\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %3, %4, 63\n\tv_writelane_b32 %1, %12, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %10, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %4, %6, %10\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %4, %10, 64\n\ts_nop 3\n\tv_readlane_b32 %4, %7, %4\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %0, %4, 0\n\tv_writelane_b32 %2, %13, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_streams_fwd(Bases<4> &X, Bases<4> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %9, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %9, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %9, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %14, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %8, %10, %14\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %8, %14, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %11, %8\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %3, %8, 63\n\tv_writelane_b32 %7, %17, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %15, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %8, %12, %15\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %8, %15, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %13, %8\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %4, %8, 0\n\tv_writelane_b32 %0, %16, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(X.b[2]), "+v"(X.b[3]), "+v"(Y.b[0]), "+v"(Y.b[1]), "+v"(Y.b[2]), "+v"(Y.b[3]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_streams_bwd(Bases<4> &X, Bases<4> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %9, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %9, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %9, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %5, %6\n\tv_swap_b32 %6, %7\n\ts_nop 1\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %15, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %8, %12, %15\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %8, %15, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %13, %8\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %7, %8, 63\n\tv_writelane_b32 %3, %16, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %3, %2\n\tv_swap_b32 %2, %1\n\tv_swap_b32 %1, %0\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %6, %5\n\tv_swap_b32 %5, %4\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %14, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %8, %10, %14\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %8, %14, 64\n\ts_nop 3\n\tv_readlane_b32 %8, %11, %8\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %0, %8, 0\n\tv_writelane_b32 %4, %17, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(X.b[0]), "+v"(X.b[1]), "+v"(X.b[2]), "+v"(X.b[3]), "+v"(Y.b[0]), "+v"(Y.b[1]), "+v"(Y.b[2]), "+v"(Y.b[3]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_all_fwd(RDiag<1> &P, RDiag<1> &Q, Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %13, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %13, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %13, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %18, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %12, %14, %18\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %12, %18, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %15, %12\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %10, %12, 63\n\tv_writelane_b32 %11, %21, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %19, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %12, %16, %19\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %12, %19, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %17, %12\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %11, %12, 0\n\tv_writelane_b32 %10, %20, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly), "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_all_bwd(RDiag<1> &P, RDiag<1> &Q, Bases<1> &X, Bases<1> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %13, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %13, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %13, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %19, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %12, %16, %19\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %12, %19, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %17, %12\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %11, %12, 63\n\tv_writelane_b32 %10, %20, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "s_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %11, %11 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %18, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %12, %14, %18\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %12, %18, 64\n\ts_nop 3\n\tv_readlane_b32 %12, %15, %12\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %10, %12, 0\n\tv_writelane_b32 %11, %21, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(P.c[0].m), "+v"(P.c[0].sx), "+v"(P.c[0].sy), "+v"(P.c[0].lx), "+v"(P.c[0].ly), "+v"(Q.c[0].m), "+v"(Q.c[0].sx), "+v"(Q.c[0].sy), "+v"(Q.c[0].lx), "+v"(Q.c[0].ly), "+v"(X.b[0]), "+v"(Y.b[0]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_all_fwd(RDiag<2> &P, RDiag<2> &Q, Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %25, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %25, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %25, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\tv_swap_b32 %20, %21\n\tv_swap_b32 %22, %23\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %21, %21 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %23, %23 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %30, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %24, %26, %30\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %24, %30, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %27, %24\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %21, %24, 63\n\tv_writelane_b32 %23, %33, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %21, %20\n\tv_swap_b32 %23, %22\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %20, %20 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %22, %22 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %31, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %24, %28, %31\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %24, %31, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %29, %24\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %22, %24, 0\n\tv_writelane_b32 %20, %32, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly), "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");
 }
 __device__ __forceinline__ void rs_rebase_all_bwd(RDiag<2> &P, RDiag<2> &Q, Bases<2> &X, Bases<2> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {
     int tmp;
-    asm volatile("s_cmp_eq_u32 %25, 0\n\t"
-                 "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_cmp_lg_u32 %25, 0\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "2:\n\t"
+                 ".subsection 1\n\t"
+                 "9:\n\t"
                  "s_cmp_lt_i32 %25, 0\n\t"
                  "s_cbranch_scc1 1f\n\t"
                  "v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %4, %5\n\tv_swap_b32 %6, %7\n\tv_swap_b32 %8, %9\n\tv_swap_b32 %10, %11\n\tv_swap_b32 %12, %13\n\tv_swap_b32 %14, %15\n\tv_swap_b32 %16, %17\n\tv_swap_b32 %18, %19\n\tv_swap_b32 %20, %21\n\tv_swap_b32 %22, %23\n\ts_nop 1\n\tv_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %7, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %9, %9 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %11, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %13, %13 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %15, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %17, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %19, %19 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %21, %21 wave_shl:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %23, %23 wave_shl:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %31, 64\n\ts_cbranch_scc0 31f\n\ts_nop 3\n\tv_readlane_b32 %24, %28, %31\n\ts_branch 41f\n\t31:\n\ts_sub_i32 %24, %31, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %29, %24\n\t41:\n\ts_nop 3\n\tv_writelane_b32 %23, %24, 63\n\tv_writelane_b32 %21, %32, 63\n\t"
-                 "s_branch 2f\n\t"
+                 "s_branch 2b\n\t"
                  "1:\n\t"
                  "v_swap_b32 %1, %0\n\tv_swap_b32 %3, %2\n\tv_swap_b32 %5, %4\n\tv_swap_b32 %7, %6\n\tv_swap_b32 %9, %8\n\tv_swap_b32 %11, %10\n\tv_swap_b32 %13, %12\n\tv_swap_b32 %15, %14\n\tv_swap_b32 %17, %16\n\tv_swap_b32 %19, %18\n\tv_swap_b32 %21, %20\n\tv_swap_b32 %23, %22\n\ts_nop 1\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %8, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %10, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %12, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %14, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %16, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %18, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %20, %20 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %22, %22 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_cmp_lt_i32 %30, 64\n\ts_cbranch_scc0 32f\n\ts_nop 3\n\tv_readlane_b32 %24, %26, %30\n\ts_branch 42f\n\t32:\n\ts_sub_i32 %24, %30, 64\n\ts_nop 3\n\tv_readlane_b32 %24, %27, %24\n\t42:\n\ts_nop 3\n\tv_writelane_b32 %20, %24, 0\n\tv_writelane_b32 %22, %33, 0\n\t"
-                 "2:"
+                 "s_branch 2b\n\t"
+                 ".subsection 0"
                  : "+v"(P.c[0].m), "+v"(P.c[1].m), "+v"(P.c[0].sx), "+v"(P.c[1].sx), "+v"(P.c[0].sy), "+v"(P.c[1].sy), "+v"(P.c[0].lx), "+v"(P.c[1].lx), "+v"(P.c[0].ly), "+v"(P.c[1].ly), "+v"(Q.c[0].m), "+v"(Q.c[1].m), "+v"(Q.c[0].sx), "+v"(Q.c[1].sx), "+v"(Q.c[0].sy), "+v"(Q.c[1].sy), "+v"(Q.c[0].lx), "+v"(Q.c[1].lx), "+v"(Q.c[0].ly), "+v"(Q.c[1].ly), "+v"(X.b[0]), "+v"(X.b[1]), "+v"(Y.b[0]), "+v"(Y.b[1]), "=&s"(tmp)
                  : "s"(dir), "v"(fx.cur), "v"(fx.nxt), "v"(fy.cur), "v"(fy.nxt), "s"(offX), "s"(offY), "s"(xcap), "s"(ycap)
                  : "scc");

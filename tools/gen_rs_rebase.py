@@ -26,6 +26,17 @@ def rot(g, R, up):
     return s
 
 
+def frame(d, up, down):
+    """The statement's control flow.  The rebase itself lies OUT OF LINE (.subsection 1: behind the kernel's own code, in its
+    section), so that the anti-diagonals without a rebase -- nineteen in twenty -- fall through one compare and one branch that is
+    not taken; laid out in line they jumped over the two bodies, a taken branch per step and direction on the serial chain of
+    every step (round 4: a launch that is one long read's chain)."""
+    return ('    asm volatile("s_cmp_lg_u32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 9f\\n\\t"\n                 "2:\\n\\t"\n'
+            '                 ".subsection 1\\n\\t"\n                 "9:\\n\\t"\n                 "s_cmp_lt_i32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 1f\\n\\t"\n'
+            '                 "%s"\n                 "s_branch 2b\\n\\t"\n                 "1:\\n\\t"\n                 "%s"\n                 "s_branch 2b\\n\\t"\n'
+            '                 ".subsection 0"\n' % (d, d, up, down))
+
+
 def rows(R, nrows):
     k, groups, ops = 0, [], []
     for row in range(nrows):
@@ -44,8 +55,7 @@ def rows(R, nrows):
         return s
     sig = "RDiag<%d> &P, RDiag<%d> &Q" % (R, R) if nrows == 2 else "RDiag<%d> &P" % R
     out = "__device__ __forceinline__ void rs_rebase_rows(%s, int dir) {\n" % sig
-    out += '    asm volatile("s_cmp_eq_u32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 2f\\n\\t"\n                 "s_cmp_lt_i32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 1f\\n\\t"\n' % (d, d)
-    out += '                 "%s"\n                 "s_branch 2f\\n\\t"\n                 "1:\\n\\t"\n                 "%s"\n                 "2:"\n' % (body(True), body(False))
+    out += frame(d, body(True), body(False))
     out += '                 : %s\n                 : "s"(dir)\n                 : "scc");\n}\n' % ", ".join(ops)
     return out
 
@@ -78,8 +88,7 @@ def streams(R, fwd):
     ins = ['"s"(dir)', '"v"(fx.cur)', '"v"(fx.nxt)', '"v"(fy.cur)', '"v"(fy.nxt)', '"s"(offX)', '"s"(offY)', '"s"(xcap)', '"s"(ycap)']
     out = "__device__ __forceinline__ void rs_rebase_streams_%s(Bases<%d> &X, Bases<%d> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {\n" % ("fwd" if fwd else "bwd", R, R)
     out += "    int tmp;\n"
-    out += '    asm volatile("s_cmp_eq_u32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 2f\\n\\t"\n                 "s_cmp_lt_i32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 1f\\n\\t"\n' % (d, d)
-    out += '                 "%s"\n                 "s_branch 2f\\n\\t"\n                 "1:\\n\\t"\n                 "%s"\n                 "2:"\n' % (up_b, dn_b)
+    out += frame(d, up_b, dn_b)
     out += '                 : %s\n                 : %s\n                 : "scc");\n}\n' % (", ".join(ops), ", ".join(ins))
     return out
 
@@ -121,8 +130,7 @@ def merged(R, fwd):
     ins = ['"s"(dir)', '"v"(fx.cur)', '"v"(fx.nxt)', '"v"(fy.cur)', '"v"(fy.nxt)', '"s"(offX)', '"s"(offY)', '"s"(xcap)', '"s"(ycap)']
     out = "__device__ __forceinline__ void rs_rebase_all_%s(RDiag<%d> &P, RDiag<%d> &Q, Bases<%d> &X, Bases<%d> &Y, const Feed &fx, const Feed &fy, int dir, int offX, int offY, int xcap, int ycap) {\n" % ("fwd" if fwd else "bwd", R, R, R, R)
     out += "    int tmp;\n"
-    out += '    asm volatile("s_cmp_eq_u32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 2f\\n\\t"\n                 "s_cmp_lt_i32 %s, 0\\n\\t"\n                 "s_cbranch_scc1 1f\\n\\t"\n' % (d, d)
-    out += '                 "%s"\n                 "s_branch 2f\\n\\t"\n                 "1:\\n\\t"\n                 "%s"\n                 "2:"\n' % (up_b, dn_b)
+    out += frame(d, up_b, dn_b)
     out += '                 : %s\n                 : %s\n                 : "scc");\n}\n' % (", ".join(ops), ", ".join(ins))
     return out
 
