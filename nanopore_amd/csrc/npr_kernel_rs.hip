@@ -198,11 +198,15 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 rs_store_row<R>(frs, Q.A, cur, voff);
                 d += 2;
             };
+            // (two pairs per loop body: a step moves its stream's registers on by one slot -- with two slots per lane the registers
+            // trade places, and a body of ONE pair paid for that with four copies per step; after two pairs they are back)
+            static_assert((RS_K / 2) % 2 == 0, "a block is a whole number of double pairs");
             while (d + RS_K - 1 <= D) {
                 feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
                 feed8_ahead<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
 #pragma nounroll
-                for (int k = 0; k < RS_K / 2 - 1; ++k) pair(std::false_type{});
+                for (int k = 0; k < RS_K / 4 - 1; ++k) pair(std::false_type{}), pair(std::false_type{});
+                pair(std::false_type{});
                 pair(std::true_type{});
             }
             feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
@@ -386,14 +390,24 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
                     d2 -= 2;
                 };
-                while (d2 >= 1) {
+                auto block_head = [&]() __attribute__((always_inline)) {
                     ef = fexp_c[d2 / RS_K];
                     sblk = note_s(smax, ef + Q.e - tot_e);
                     feed8_ahead<-1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
                     feed8_ahead<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
+                };
+                if (d2 >= 1) {  // the first block: as long as it takes to get to a renormalising row, an odd number of pairs maybe
+                    block_head();
                     const int n = (d2 & (RS_K - 1)) >> 1;
 #pragma nounroll
                     for (int k = 0; k < n; ++k) pair(std::false_type{});
+                    pair(std::true_type{});
+                }
+                while (d2 >= 1) {  // whole blocks: two pairs per loop body (the streams' registers are back where they were: see the forward sweep)
+                    block_head();
+#pragma nounroll
+                    for (int k = 0; k < RS_K / 4 - 1; ++k) pair(std::false_type{}), pair(std::false_type{});
+                    pair(std::false_type{});
                     pair(std::true_type{});
                 }
             }
