@@ -511,7 +511,8 @@ def c3_job(env, n_reads, steps, warmup, from_files):
     h, w, W, tmp, sam, fa = c3_inputs(n_reads, rank, dist, from_files)
     ctxs = job.contexts(gpu, job.WORKERS)
     for c in ctxs:
-        c.set_hmm(h)
+        c.release_scratch()  # as a fresh process would find the device: the resident workloads before this one leave a scratch sized for
+        c.set_hmm(h)         # THEIR batches and gigabytes of cached buffers behind (three chunks in flight then do not fit and are halved)
     params = make_params(W)
     step_no = [0]
     out_sam = None

@@ -134,7 +134,7 @@ const char *npr_last_error(npr_ctx *ctx);
  * another batch's DP pass), and the DP launches of narrow bands leave one wavefront slot per SIMD free so that the staging
  * and MEA kernels of the other batches find room beside them.  Results do not change. */
 #define NPR_OPT_OVERLAP 1
-/* NPR_OPT_RELEASE_SCRATCH (an action; value ignored): the device's forward scratch (shared by the contexts of the device; the
+/* NPR_OPT_RELEASE_SCRATCH (an action; value 2: only the context's cache of released device buffers, the scratch stays): the device's forward scratch (shared by the contexts of the device; the
  * next batch that needs it allocates it again) and this context's cache of released device buffers go back to the driver.  For
  * a process that stays alive after a big batch (the parent of a pipeline, a test session) next to others that need the HBM. */
 #define NPR_OPT_RELEASE_SCRATCH 2

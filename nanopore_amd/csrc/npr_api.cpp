@@ -438,10 +438,11 @@ const char *npr_last_error(npr_ctx *ctx) { return ctx ? ctx->last_error.c_str() 
 // NPR_OPT_RELEASE_SCRATCH: the device's forward scratch (shared by the contexts of the device, regrown by the next batch that needs
 // it) and this context's cache of released device buffers go back to the driver -- a process that is done with a big batch
 // and stays alive (a pipeline's parent, a test session) need not keep a hundred GB of HBM from the next one.
-static int32_t release_scratch(npr_ctx *ctx) {
+static int32_t release_scratch(npr_ctx *ctx, bool caches_only) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cache_flush();
+    if (caches_only) return NPR_OK;  // (value 2: what a pipeline does when a batch does not fit, before it halves it: the scratch may be in use)
     if (ctx->arena) {
         std::lock_guard<std::mutex> lock(ctx->arena->mu);
         if (ctx->arena->F) (void)hipFree(ctx->arena->F - DeviceArena::kPad);
@@ -458,7 +459,7 @@ int32_t npr_ctx_option(npr_ctx *ctx, int32_t option, int64_t value) {
     if (!ctx) return NPR_ERR_INVALID;
     switch (option) {
         case NPR_OPT_OVERLAP: ctx->overlap = value != 0; return NPR_OK;
-        case NPR_OPT_RELEASE_SCRATCH: return release_scratch(ctx);
+        case NPR_OPT_RELEASE_SCRATCH: return release_scratch(ctx, value == 2);
         default:
             if (option > NPR_OPT_RELEASE_SCRATCH && option < NPR_OPT_COUNT) {
                 ctx->opt[option] = value;

@@ -293,6 +293,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 downstream.put(END)
         return run
 
+    flushed = set()
+
     def stager():
         k = 0
         while pending and not stop.is_set():
@@ -308,6 +310,11 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 free[j].release()
                 if e.code != realign.ERR_NOMEM or b_ - a < 2:
                     raise
+                if j not in flushed:  # once per context: the buffers it cached from earlier, differently sized batches may be what is in the
+                    flushed.add(j)    # way (only this context's: nobody else touches it while the stager holds it)
+                    ctxs[j].set_option(_lib.OPT_RELEASE_SCRATCH, 2)
+                    pending.append((a, b_))
+                    continue
                 mid = (a + b_) // 2
                 pending.extend([(mid, b_), (a, mid)])
                 continue
