@@ -1565,16 +1565,24 @@ int32_t device_mea(npr_batch *b) {
     MeaScratch &m = *ctx->mea;
     hipError_t e;
     // per-position tables of one read in LDS (count + scan + scatter in one kernel) when the longest span fits
-    int64_t span = 0;
-    for (int64_t i = 0; i < n; ++i) span = std::max(span, rx[i + 1] - rx[i]), span = std::max(span, ry[i + 1] - ry[i]);
-    const bool sort_in_lds = 4 * span <= 64 * 1024 && ctx->opt[NPR_OPT_MEA_GLOBAL_SORT] == 0;
+    // ... read by read (round 4: one read of more than 16 k bases used to send its whole batch through the global-memory kernels)
+    const int64_t lds_span = ctx->opt[NPR_OPT_MEA_GLOBAL_SORT] != 0 ? 0 : 16 * 1024;
+    int64_t span = 0;  // the widest table among the reads that sort in LDS
+    std::vector<int64_t> cnt_off(n + 1, -1);
+    int64_t cnt_total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t sp = std::max(rx[i + 1] - rx[i], ry[i + 1] - ry[i]);
+        if (sp <= lds_span) span = std::max(span, sp);
+        else cnt_off[i] = cnt_total, cnt_total += rx[i + 1] - rx[i];
+    }
+    const bool sort_in_lds = cnt_total == 0;
     const size_t ntask_map = b->task_of.size();
     // The forward scratch of the DP launches is idle now and usually far larger than what this stage needs: carve the
     // tables out of it (a batch that fills the device's memory leaves nothing to hipMalloc).  Else: grow-only buffers.
-    const size_t n_cnt = sort_in_lds ? 1 : rx[n];
+    const size_t n_cnt = sort_in_lds ? 1 : static_cast<size_t>(cnt_total);
     {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
-        const size_t need = al(8 * 4 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (12 * total + 16)) +
+        const size_t need = al(8 * 5 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (12 * total + 16)) +
                             al(4 * 5 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]) + al(4 * (4 * n_pieces + 4 * n));
         const bool in_arena = !ctx->overlap && ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && ctx->opt[NPR_OPT_MEA_OWN_SCRATCH] == 0;
         char *cur = ctx->arena->F;
@@ -1589,7 +1597,7 @@ int32_t device_mea(npr_batch *b) {
             cur += al(sizeof(T) * count);
             return hipSuccess;
         };
-        if ((e = take(m.off, 4 * (n + 1))) != hipSuccess || (e = take(m.mass, n)) != hipSuccess || (e = take(m.od, n + 1)) != hipSuccess ||
+        if ((e = take(m.off, 5 * (n + 1))) != hipSuccess || (e = take(m.mass, n)) != hipSuccess || (e = take(m.od, n + 1)) != hipSuccess ||
             (e = take(m.cnt, n_cnt)) != hipSuccess || (e = take(m.start, n_cnt)) != hipSuccess || (e = take(m.col, ry[n] + 1)) != hipSuccess ||
             (e = take(m.sorted, 12 * total + 16)) != hipSuccess || (e = take(m.small, 5 * n)) != hipSuccess || (e = take(m.tmp, 2 * ot[n])) != hipSuccess ||
             (e = take(m.map, 3 * n + ntask_map)) != hipSuccess || (e = take(m.dense, ot[n])) != hipSuccess ||
@@ -1618,16 +1626,13 @@ int32_t device_mea(npr_batch *b) {
         }
         HIP_TRY(ctx, hipMemcpyAsync(m.pieces.p, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
     }
-    std::vector<int64_t> offs(4 * (n + 1));
+    std::vector<int64_t> offs(5 * (n + 1));
+    std::copy(cnt_off.begin(), cnt_off.end(), offs.begin() + 4 * (n + 1));
     std::copy(rx.begin(), rx.end(), offs.begin());
     std::copy(ry.begin(), ry.end(), offs.begin() + (n + 1));
     std::copy(rp.begin(), rp.end(), offs.begin() + 2 * (n + 1));
     std::copy(ot.begin(), ot.end(), offs.begin() + 3 * (n + 1));
     HIP_TRY(ctx, hipMemcpyAsync(m.off.p, offs.data(), m.off.bytes(), hipMemcpyHostToDevice, ctx->stream));
-    if (!sort_in_lds) {
-        HIP_TRY(ctx, hipMemsetAsync(m.cnt.p, 0, m.cnt.bytes(), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(m.col.p, 0, m.col.bytes(), ctx->stream));
-    }
     HIP_TRY(ctx, hipMemsetAsync(m.small.p, 0, m.small.bytes(), ctx->stream));
     MeaArgs a{};
     a.tasks = b->d_tasks.p, a.outs = b->d_outs.p, a.ntasks = static_cast<int32_t>(ntasks), a.n_reads = static_cast<int32_t>(n);
@@ -1644,7 +1649,9 @@ int32_t device_mea(npr_batch *b) {
     a.gap_gamma = b->params.gap_gamma, a.match_gamma = b->params.match_gamma, a.ring = ring;
     a.ring_only = ctx->opt[NPR_OPT_MEA_RING_ONLY] != 0 ? 1 : 0;
     a.read_first = m.map.p, a.read_ntasks = m.map.p + n, a.task_of = m.map.p + 2 * n, a.order = m.map.p + 2 * n + ntask_map;
-    a.sort_lds_bytes = sort_in_lds ? static_cast<int32_t>(4 * span) : 0;
+    a.sort_lds_bytes = static_cast<int32_t>(4 * span);
+    a.any_global_sort = sort_in_lds ? 0 : 1;
+    a.cnt_off = m.off.p + 4 * (n + 1);
     a.ops_tmp = m.tmp.p, a.od_off = m.od.p;
     int rc = launch_mea_sort(a, ctx->stream);
     if (rc == 0) rc = launch_mea_chain(a, ctx->stream);

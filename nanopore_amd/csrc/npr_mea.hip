@@ -50,13 +50,24 @@ __device__ __forceinline__ void wave_sync() {
 }
 __device__ __forceinline__ bool beats(int64_t s, int w, int64_t os, int ow) { return s > os || (s == os && w > ow); }
 
+// the tables of the reads whose spans do not fit the LDS (the others never touch global tables): counts and column sums start from zero
+__global__ void __launch_bounds__(256) k_mea_zero(MeaArgs a) {
+    const int r = blockIdx.x;
+    const int64_t c0 = a.cnt_off[r];
+    if (c0 < 0) return;
+    const int nx = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]), ny = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
+    for (int i = threadIdx.x; i < nx; i += blockDim.x) a.cnt[c0 + i] = 0;
+    for (int i = threadIdx.x; i < ny; i += blockDim.x) a.colsum[a.ry_off[r] + i] = 0;
+}
+
 __global__ void __launch_bounds__(256) k_mea_count(MeaArgs a) {
     for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
         const Task &tk = a.tasks[t];
         const int n = min(a.outs[t].npairs, tk.pair_cap);
         const int r = tk.read;
-        const int64_t rx = a.rx_off[r], ry = a.ry_off[r];
-        const int lX = static_cast<int>(a.rx_off[r + 1] - rx) - 1, lY = static_cast<int>(a.ry_off[r + 1] - ry);
+        const int64_t rx = a.cnt_off[r], ry = a.ry_off[r];
+        if (rx < 0) continue;  // (a read whose tables fit the LDS: k_mea_sort_lds)
+        const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - ry);
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
             if (x < 0 || x >= lX || y < 0 || y >= lY) {
@@ -74,8 +85,9 @@ __global__ void __launch_bounds__(256) k_mea_count(MeaArgs a) {
 __global__ void __launch_bounds__(256) k_mea_scan(MeaArgs a) {
     __shared__ int wsum[4];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t rx = a.rx_off[r];
-    const int n = static_cast<int>(a.rx_off[r + 1] - rx);  // lX + 1 entries (the last count is zero)
+    const int64_t rx = a.cnt_off[r];
+    if (rx < 0) return;
+    const int n = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]);  // lX + 1 entries (the last count is zero)
     int carry = 0;
     for (int base = 0; base < n; base += 256) {
         const int i = base + tid;
@@ -100,8 +112,9 @@ __global__ void __launch_bounds__(256) k_mea_scatter(MeaArgs a) {
         const Task &tk = a.tasks[t];
         const int n = min(a.outs[t].npairs, tk.pair_cap);
         const int r = tk.read;
-        const int64_t rx = a.rx_off[r], rp = a.rp_off[r];
-        const int lX = static_cast<int>(a.rx_off[r + 1] - rx) - 1, lY = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
+        const int64_t rx = a.cnt_off[r], rp = a.rp_off[r];
+        if (rx < 0) continue;
+        const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
             if (x < 0 || x >= lX || y < 0 || y >= lY) continue;
@@ -121,7 +134,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
     const int r = a.order[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t rx = a.rx_off[r], ry = a.ry_off[r], rp = a.rp_off[r];
     const int lX = static_cast<int>(a.rx_off[r + 1] - rx) - 1, lY = static_cast<int>(a.ry_off[r + 1] - ry);
-    if (a.rp_off[r + 1] == rp) return;
+    if (a.rp_off[r + 1] == rp || a.cnt_off[r] >= 0) return;  // (no pairs; or a span beyond the LDS: the three kernels above)
     const int ft = a.read_first[r], nt = a.read_ntasks[r];
     int bad = 0;
     // the pairs of every task of the read, f(x, y, p-quantum)
@@ -522,8 +535,10 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
     int *const ty = reinterpret_cast<int *>(tw + WAVE);
     int *const tq = ty + WAVE;
     const int lane = threadIdx.x;
-    const int r = blockIdx.x;
-    if (a.read_flag[r] != MEA_RETRY) return;
+    // (a fixed grid over the reads: a block per read, each with the ring's 100 KB of LDS, cost 1 ms of launches that return at once)
+    for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    if (a.read_flag[r] != MEA_RETRY) continue;
+    wave_sync();
     const int64_t rp = a.rp_off[r], ry = a.ry_off[r];
     const int n = static_cast<int>(a.rp_off[r + 1] - rp);
     int *const sx = a.sx + rp, *const sy = a.sy + rp, *const sq = a.sq + rp, *const back = a.back + rp;
@@ -596,6 +611,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_chain(MeaArgs a) {
     if (lane == 0) {
         a.best_who[r] = top_w;
         a.read_flag[r] = flag;
+    }
     }
 }
 
@@ -684,16 +700,18 @@ size_t mea_chain_lds_bytes(int ring) { return static_cast<size_t>(ring) * 12 + W
 
 int launch_mea_sort(const MeaArgs &a, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a.sort_lds_bytes > 0) {
+    if (a.sort_lds_bytes > 0) {  // the reads whose per-position tables fit the LDS
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mea_sort_lds), hipFuncAttributeMaxDynamicSharedMemorySize, a.sort_lds_bytes);
         if (e != hipSuccess) return static_cast<int>(e);
         hipLaunchKernelGGL(k_mea_sort_lds, dim3(a.n_reads), dim3(SORT_THREADS), a.sort_lds_bytes, s, a);
-        return static_cast<int>(hipGetLastError());
     }
-    const int tg = a.ntasks < 8192 ? (a.ntasks > 0 ? a.ntasks : 1) : 8192;
-    hipLaunchKernelGGL(k_mea_count, dim3(tg), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_mea_scan, dim3(a.n_reads), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_mea_scatter, dim3(tg), dim3(256), 0, s, a);
+    if (a.any_global_sort) {  // the others (a read of more than 16 k bases among 12 000 shorter ones used to send ALL of them this way)
+        const int tg = a.ntasks < 8192 ? (a.ntasks > 0 ? a.ntasks : 1) : 8192;
+        hipLaunchKernelGGL(k_mea_zero, dim3(a.n_reads), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_mea_count, dim3(tg), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_mea_scan, dim3(a.n_reads), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_mea_scatter, dim3(tg), dim3(256), 0, s, a);
+    }
     return static_cast<int>(hipGetLastError());
 }
 
@@ -708,7 +726,7 @@ int launch_mea_chain(const MeaArgs &a, void *stream) {
     hipLaunchKernelGGL(k_mea_weigh, dim3(a.n_reads), dim3(WAVE), 0, s, a);
     hipLaunchKernelGGL(k_mea_cuts, dim3(a.n_reads), dim3(WAVE), 0, s, a);
     hipLaunchKernelGGL(k_mea_chain_lanes, dim3((a.n_pieces + WAVE - 1) / WAVE), dim3(WAVE), lanes_lds, s, a);
-    hipLaunchKernelGGL(k_mea_chain, dim3(a.n_reads), dim3(WAVE), lds, s, a);  // returns at once unless the read was handed over
+    hipLaunchKernelGGL(k_mea_chain, dim3(a.n_reads < 512 ? (a.n_reads > 0 ? a.n_reads : 1) : 512), dim3(WAVE), lds, s, a);  // (looks at the reads that were handed over)
     hipLaunchKernelGGL(k_mea_trace, dim3(a.n_reads), dim3(WAVE), 0, s, a);
     return static_cast<int>(hipGetLastError());
 }
