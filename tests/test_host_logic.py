@@ -120,6 +120,67 @@ def test_register_kernel_frame_schedule(seed):
     assert followed > 200 and rebases > 50
 
 
+def _clamp_walk(lo, n, slots, flo0, chunk):
+    """The device planner's form of the walk (npr_plan.hip: k_sched_compose / k_sched_starts): a step is a clamp of flo, the
+    x-y of slot 0 -- an X-step takes it to max(flo + 1, c), a Y-step to min(flo - 1, c) -- and `chunk` steps compose to
+    min(max(flo + A, L), U).  Returns flo after every step (step by step) and flo at the head of every chunk (composed)."""
+    D, span, BIG = len(lo) - 1, 2 * (slots - 1), 1 << 29
+    hi = lo + 2 * (n - 1)
+    flo, step_by_step, heads = flo0, [flo0], []
+    for d0 in range(0, D + 1, chunk):
+        A, L, U = 0, -BIG, BIG
+        for d in range(max(d0, 1), min(d0 + chunk, D + 1)):
+            if d % 2:
+                c = max(hi[d] - span, hi[d + 1] - span + 1 if d < D else -BIG)
+                A, L, U = A + 1, max(L + 1, c), max(U + 1, c)
+                flo = max(flo + 1, c)
+            else:
+                c = min(lo[d], lo[d + 1] - 1 if d < D else BIG)
+                A, L, U = A - 1, min(L - 1, c), min(U - 1, c)
+                flo = min(flo - 1, c)
+            step_by_step.append(flo)
+        heads.append((A, L, U))
+    composed, f = [], flo0
+    for A, L, U in heads:
+        composed.append(f)
+        f = min(max(f + A, L), U)
+    return np.array(step_by_step), np.array(composed)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_frame_schedule_is_a_clamp_that_composes_in_chunks(seed):
+    """The device planner does not walk a schedule step after step: it composes chunks of steps as clamps of the frame's
+    position and walks the chunks side by side (npr_plan.hip).  Wherever the host planner's sequential walk
+    (build_stair_schedule, through npr_plan_frame_schedule) can follow a band, both forms give the same frame position on every
+    anti-diagonal, for every chunk length."""
+    rng = np.random.default_rng(1700 + seed)
+    followed = rebased = 0
+    for it in range(30):
+        Lr = int(rng.integers(40, 2500))
+        X, Y, ops = random_pair(rng, Lr, indel=rng.random() * 0.3, max_indel=int(rng.integers(1, 80)))
+        if it % 2:
+            kw = dict(band_mode=1, fixed_width=int(rng.integers(4, 250)))
+        else:
+            kw = dict(band_mode=0, diagonal_expansion=int(rng.integers(1, 8)) * 2, constraint_trim=int(rng.integers(0, 16)),
+                      split_threshold=int(rng.integers(20, 3000)))
+        P = R.make_params(**kw)
+        for s, seg in enumerate(R.plan(P, len(X), len(Y), ops)):
+            lo, n = seg["lo"].astype(np.int64), seg["n"].astype(np.int64)
+            for slots, per_lane in ((64, 1), (128, 2), (256, 4), (1024, 2)):
+                sch = R.frame_schedule(P, len(X), len(Y), ops, slots, per_lane, segment=s)
+                if sch is None:
+                    continue
+                want = lo - 2 * sch["jlo"].astype(np.int64)
+                for chunk in (1, 7, 256):
+                    steps, heads = _clamp_walk(lo, n, slots, int(want[0]), chunk)
+                    assert np.array_equal(steps, want), (it, s, slots, chunk)
+                    head_rows = np.maximum(np.arange(0, len(want), chunk) - 1, 0)     # a chunk's head: before its first step
+                    assert np.array_equal(heads, want[head_rows]), (it, s, slots, chunk)
+                followed += 1
+                rebased += int(np.abs(sch["rebase"]).sum() > 0)
+    assert followed > 60 and rebased > 10
+
+
 def test_frame_schedule_long_gap_rebases_every_other_step():
     """A 600-base deletion inside a W = 100 band: the frame drifts one slot per two anti-diagonals."""
     ops = [(0, 300), (2, 600), (0, 300)]
