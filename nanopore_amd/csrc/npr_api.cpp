@@ -932,9 +932,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     {
         // By default a class of more than 256 tasks that fill at most half of the chip's wavefront slots goes to the pair kernel as a whole
         // (BASELINE.json configs[1]: 1000 reads on 7168 slots -- DP 1.71 -> 1.42 ms); a fuller class does not (a 1/8 shard of
-        // configs[3], 6250 reads: 51 -> 59 ms with every read on two wavefronts, 67 with the longest ones only -- the second
-        // wavefronts then compete with the reads that have one).  NPR_OPT_PAIR 1: never; 2: the tasks longer than a
-        // wavefront's fair share; 3: every task.
+        // configs[3], 6250 reads, round 4: 41 -> 49.5 ms with every read on two wavefronts; with the longest ones only 59 -- the
+        // two launches then share one of the runtime's four hardware queues and run one after the other, tools/queues_of.py -- and
+        // 44 with GPU_MAX_HW_QUEUES=8, side by side: the second wavefronts compete with the reads that have one, and a higher
+        // s_setprio for them changes nothing).  NPR_OPT_PAIR 1: never; 2: the tasks longer than a wavefront's fair share; 3: every task.
         const int64_t pe = ctx->opt[NPR_OPT_PAIR];
         const bool pair_all = pe == 3, pair_off = pe == 1, pair_long = pe == 2;
         if (!pair_off && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS)
