@@ -52,8 +52,8 @@ class ArraySource(object):
         self.text = text
         self.read_begin = np.ascontiguousarray(read_begin, dtype=np.int64)
         self.read_end = np.ascontiguousarray(read_end, dtype=np.int64)
-        self.guide_ops = np.ascontiguousarray(guide_ops, dtype=np.int32).reshape(-1, 2)
-        self.guide_off = np.ascontiguousarray(guide_off, dtype=np.int64)
+        self.guide_ops = None if guide_ops is None else np.ascontiguousarray(guide_ops, dtype=np.int32).reshape(-1, 2)  # (None: the subclass has its own)
+        self.guide_off = None if guide_off is None else np.ascontiguousarray(guide_off, dtype=np.int64)
         self.ref_index = None if ref_index is None else np.ascontiguousarray(ref_index, dtype=np.int32)
         self.guide_start = None if guide_start is None else np.ascontiguousarray(guide_start, dtype=np.int64).reshape(-1, 2)
         self.model_slot = None if model_slot is None else np.ascontiguousarray(model_slot, dtype=np.int32)
@@ -138,7 +138,7 @@ class SamSource(ArraySource):
         self.sam = sam
         self.span = np.ascontiguousarray(span, dtype=np.int64)
         self.fields = np.ascontiguousarray(fields, dtype=np.int64)
-        guide_off, guide_ops = sam.guides(self.fields)
+        self._guides = None  # (guide_off, guide_ops) of ALL records, built when someone asks; the job builds a chunk's as it stages it
         tid_to_ref = np.array([fasta.index.get(name, -1) for name in sam.references] + [-1], dtype=np.int32)
         ref_index = tid_to_ref[self.fields[:, ing.F_TID]]
         if len(ref_index) and (ref_index < 0).any():
@@ -146,9 +146,33 @@ class SamSource(ArraySource):
             raise KeyError(sam.references[int(self.fields[k, ing.F_TID])])  # refSequences[sam.getrname(aR.rname)] (utils.py:570)
         gs = np.zeros((len(self.fields), 2), dtype=np.int64)
         gs[:, 0] = self.fields[:, ing.F_POS]
-        ArraySource.__init__(self, fasta.seq, fasta.off, sam.text, self.fields[:, ing.F_QUERY_LO], self.fields[:, ing.F_QUERY_HI], guide_ops,
-                             guide_off, ref_index=ref_index, guide_start=gs, model_slot=model_slot)
+        ArraySource.__init__(self, fasta.seq, fasta.off, sam.text, self.fields[:, ing.F_QUERY_LO], self.fields[:, ing.F_QUERY_HI], None,
+                             None, ref_index=ref_index, guide_start=gs, model_slot=model_slot)
         self.header = sam.header
+
+    # The guides (the M / I / D operations of every cigar) of a 50 000-record file take 25 ms to build, with nothing else running: a
+    # chunk's are built when it is staged, under the DP pass of the chunk before (round 4); the whole table only for who reads it.
+    def _all_guides(self):
+        if self._guides is None:
+            self._guides = self.sam.guides(self.fields)
+        return self._guides
+
+    guide_off = property(lambda self: self._all_guides()[0], lambda self, value: None)
+    guide_ops = property(lambda self: self._all_guides()[1], lambda self, value: None)
+
+    def stage(self, ctx, params, lo, hi):
+        sl = slice(lo, hi)
+        goff, gops = self.sam.guides(self.fields[sl])
+        return ctx.stage_spans(params, self.ref, self.ref_off, self.text, self.read_begin[sl], self.read_end[sl], gops, goff,
+                               model_slot=None if self.model_slot is None else self.model_slot[sl], ref_index=self.ref_index[sl],
+                               guide_start=self.guide_start[sl])
+
+    def stage_records(self, ctx, params, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        goff, gops = self.sam.guides(self.fields[idx])
+        return ctx.stage_spans(params, self.ref, self.ref_off, self.text, self.read_begin[idx], self.read_end[idx], gops, goff,
+                               model_slot=None if self.model_slot is None else self.model_slot[idx], ref_index=self.ref_index[idx],
+                               guide_start=self.guide_start[idx])
 
     def format_block(self, lo, hi, ops_off, words):
         nops = np.asarray(ops_off[1:]) - np.asarray(ops_off[:-1])
@@ -398,7 +422,10 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                     res, off, words, stats = _fetch(batch, want_stats)
                     tm["cells"] += int(batch.stats()["cells"])
                 finally:
+                    tc = time.perf_counter()
                     batch.close()
+                    if TRACE:
+                        tm["trace"].append(("close", tc, time.perf_counter()))
                 res, off, words, stats = _rerun_overflowed(ctxs[j], src, params, a, res, off, words, stats, want_stats, tm)
             finally:
                 if last:
@@ -429,6 +456,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 t0 = time.perf_counter()
                 sink(block)
                 sink_s += time.perf_counter() - t0
+                if TRACE:
+                    tm["trace"].append(("sink", t0, time.perf_counter()))
                 parts.append((res, nops, stats))
     finally:
         if not finished:  # the sink failed on this thread (a full disk): the phases stop, what is in flight is closed, nothing keeps a context

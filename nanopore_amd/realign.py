@@ -134,7 +134,7 @@ class Batch(object):
         rc = self._L.npr_batch_ops_packed(self._h, ptr(off), None, 0)
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_ops_packed", self.ctx.last_error())
-        words = np.zeros(max(int(off[-1]), 1), dtype=np.uint32)
+        words = np.empty(max(int(off[-1]), 1), dtype=np.uint32)  # (filled by the call: no 150 MB memset first)
         rc = self._L.npr_batch_ops_packed(self._h, ptr(off), ptr(words), int(off[-1]))
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_ops_packed", self.ctx.last_error())
