@@ -95,13 +95,17 @@ class SamText(object):
             raise AssertionError("SAM line %r: malformed, or a cigar operation outside M I D S H (utils.py:171)" % line)
         return status == 0
 
-    def guides(self, fields):
+    def guides(self, fields, buffer=None):
         """CSR guides of parsed lines: (guide_off[n + 1], guide_ops[k, 2]) -- the M / I / D operations of each cigar, the
-        operations the exonerate line carries (utils.py:173)."""
+        operations the exonerate line carries (utils.py:173).  `buffer`: an int32 array the operations may be written into (a view
+        of it is returned when it is large enough: a job's chunks then reuse one allocation of a few hundred MB)."""
         n = len(fields)
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.where(fields[:, F_STATUS] == 0, fields[:, F_GUIDE_OPS], 0), out=off[1:])
-        ops = np.zeros((int(off[-1]), 2), dtype=np.int32)
+        if buffer is not None and buffer.size >= 2 * int(off[-1]):
+            ops = buffer[:2 * int(off[-1])].reshape(-1, 2)
+        else:
+            ops = np.zeros((int(off[-1]), 2), dtype=np.int32)
         if n:
             fields = np.ascontiguousarray(fields)
             _check(_lib.load().npr_sam_guides(ptr(self.text), ptr(fields), n, ptr(off), ptr(ops)), "npr_sam_guides")

@@ -19,6 +19,7 @@ files gathered in input order and spliced into a copy of the input SAM (utils.py
 `realign_sam_file` is what `analyses.utils.realignSamFile` (the plugin surface: AbstractMapper.realignSamFile,
 realignSamFileTargetFn) runs; `run_job` is the same pipeline over resident synthetic arrays (`bench.py --workload c3`).
 """
+import gc
 import os
 import queue
 import threading
@@ -139,6 +140,8 @@ class SamSource(ArraySource):
         self.span = np.ascontiguousarray(span, dtype=np.int64)
         self.fields = np.ascontiguousarray(fields, dtype=np.int64)
         self._guides = None  # (guide_off, guide_ops) of ALL records, built when someone asks; the job builds a chunk's as it stages it
+        self._gbuf = None    # ... into this buffer
+        self._F_GUIDE_OPS = ing.F_GUIDE_OPS
         tid_to_ref = np.array([fasta.index.get(name, -1) for name in sam.references] + [-1], dtype=np.int32)
         ref_index = tid_to_ref[self.fields[:, ing.F_TID]]
         if len(ref_index) and (ref_index < 0).any():
@@ -161,8 +164,14 @@ class SamSource(ArraySource):
     guide_ops = property(lambda self: self._all_guides()[1], lambda self, value: None)
 
     def stage(self, ctx, params, lo, hi):
+        # (one stager thread per source; the batch holds its own copy of the guides when stage_spans returns.  The operations of a
+        # chunk of 12 500 reads are 300 MB: allocated and released per chunk they cost two rounds of page faults and an munmap under the
+        # interpreter lock, during which no other phase of the pipeline can pick up its next chunk)
         sl = slice(lo, hi)
-        goff, gops = self.sam.guides(self.fields[sl])
+        need = 2 * int(np.sum(self.fields[sl, self._F_GUIDE_OPS]))
+        if self._gbuf is None or self._gbuf.size < need:
+            self._gbuf = np.empty(need + need // 4, dtype=np.int32)
+        goff, gops = self.sam.guides(self.fields[sl], buffer=self._gbuf)
         return ctx.stage_spans(params, self.ref, self.ref_off, self.text, self.read_begin[sl], self.read_end[sl], gops, goff,
                                model_slot=None if self.model_slot is None else self.model_slot[sl], ref_index=self.ref_index[sl],
                                guide_start=self.guide_start[sl])
@@ -224,11 +233,13 @@ def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
-def _fetch(b, want_stats):
+def _fetch(b, want_stats, buffer=None):
+    """-> (buffer, results, ops_off, words, stats): the packed cigars land in `buffer` when it is large enough, else in a new one
+    (returned for the next chunk: 150 MB allocated and released per chunk are page faults and an munmap under the interpreter lock)."""
     res = b.results()
-    off, words = b.ops_packed()
+    off, words, buffer = b.ops_packed_into(buffer)
     stats = b.align_stats() if want_stats else None
-    return res, off, words, stats
+    return buffer, res, off, words, stats
 
 
 def _rerun_overflowed(ctx, src, params, lo, res, off, words, stats, want_stats, tm):
@@ -249,7 +260,7 @@ def _rerun_overflowed(ctx, src, params, lo, res, off, words, stats, want_stats, 
         try:
             tm["kernel_ms"] += b.run()
             b.finish()
-            r2, o2, w2, s2 = _fetch(b, want_stats)
+            _, r2, o2, w2, s2 = _fetch(b, want_stats)
         finally:
             b.close()
         res[again] = r2
@@ -409,35 +420,48 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             q_out.put(item)
 
     def fetcher():
+        words_buf = [None]
         while True:
             item = q_out.get()
             if item is END:
                 return
             j, a, b_, batch, last = item
             t0 = time.perf_counter()
+            open_batch = [batch]
             try:  # the context goes back exactly once, whatever happens in between
                 try:
                     if stop.is_set():
                         continue
-                    res, off, words, stats = _fetch(batch, want_stats)
+                    words_buf[0], res, off, words, stats = _fetch(batch, want_stats, words_buf[0])
                     tm["cells"] += int(batch.stats()["cells"])
+                    if (res["status"] == realign.ERR_CAPACITY).any():
+                        batch.close(), open_batch.clear()  # (the reads that overflowed run again on this context)
+                        res, off, words, stats = _rerun_overflowed(ctxs[j], src, params, a, res, off, words, stats, want_stats, tm)
+                    t1 = time.perf_counter()
+                    note("fetch", t0, t1)
+                    block = src.format_block(a, b_, off, words)
+                    note("format", t1, time.perf_counter())
+                    done.put((block, res, off[1:] - off[:-1], stats))
+                    del block, res, off, words, stats
                 finally:
+                    # the batch goes after its block is on its way (releasing its host buffers takes 13 ms); the context after the batch
                     tc = time.perf_counter()
-                    batch.close()
+                    if open_batch:
+                        batch.close()
                     if TRACE:
                         tm["trace"].append(("close", tc, time.perf_counter()))
-                res, off, words, stats = _rerun_overflowed(ctxs[j], src, params, a, res, off, words, stats, want_stats, tm)
             finally:
                 if last:
                     free[j].release()
-            t1 = time.perf_counter()
-            note("fetch", t0, t1)
-            block = src.format_block(a, b_, off, words)
-            note("format", t1, time.perf_counter())
-            done.put((block, res, off[1:] - off[:-1], stats))
 
     threads = [threading.Thread(target=guarded(fn, up, down), daemon=True)
                for fn, up, down in ((stager, None, q_run), (runner, q_run, q_fin), (finisher, q_fin, q_out), (fetcher, q_out, done))]
+    # The cyclic collector stays out of the job: a full collection walks every object of the process (millions once torch is
+    # imported) with the interpreter lock held, and the phase that was about to take a chunk over waits 10-25 ms for it (round 4: the
+    # gaps between one phase's end and the next one's start in the trace).  The pipeline itself makes no cycles worth collecting.
+    gc_was_on = gc.isenabled() and os.environ.get("NPR_JOB_GC") is None
+    if gc_was_on:
+        gc.disable()
     for t in threads:
         t.start()
     parts, sink_s, error = [], 0.0, None
@@ -458,6 +482,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 sink_s += time.perf_counter() - t0
                 if TRACE:
                     tm["trace"].append(("sink", t0, time.perf_counter()))
+                del block, item  # (150 MB: released now, not when the next block is waiting to be written)
                 parts.append((res, nops, stats))
     finally:
         if not finished:  # the sink failed on this thread (a full disk): the phases stop, what is in flight is closed, nothing keeps a context
@@ -466,6 +491,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 pass
         for t in threads:
             t.join()
+        if gc_was_on:
+            gc.enable()
     if error is not None:
         raise error
     n = hi - lo

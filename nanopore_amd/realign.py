@@ -130,15 +130,23 @@ class Batch(object):
 
     def ops_packed(self):
         """Output cigars, one uint32 per op (length << 2 | op): (offsets[n+1], words)."""
+        off, words, _ = self.ops_packed_into(None, slack=False)
+        return off, words
+
+    def ops_packed_into(self, buffer, slack=True):
+        """ops_packed for a caller that fetches batch after batch: -> (offsets, words, buffer) -- the words are a view of `buffer`
+        (a uint32 array or None) when it is large enough, else of a new, larger one, which is returned for the next call."""
         off = np.zeros(self.n_reads + 1, dtype=np.int64)
         rc = self._L.npr_batch_ops_packed(self._h, ptr(off), None, 0)
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_ops_packed", self.ctx.last_error())
-        words = np.empty(max(int(off[-1]), 1), dtype=np.uint32)  # (filled by the call: no 150 MB memset first)
-        rc = self._L.npr_batch_ops_packed(self._h, ptr(off), ptr(words), int(off[-1]))
+        total = int(off[-1])
+        if buffer is None or buffer.size < max(total, 1):
+            buffer = np.empty(max(total + (total // 4 if slack else 0), 1), dtype=np.uint32)  # (filled by the call: no memset first)
+        rc = self._L.npr_batch_ops_packed(self._h, ptr(off), ptr(buffer), total)
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_ops_packed", self.ctx.last_error())
-        return off, words[:int(off[-1])]
+        return off, buffer[:total], buffer
 
     def pairs(self):
         """-> (pair_off[n+1], x, y, p) sparse posterior match probabilities sorted by (x, y)."""

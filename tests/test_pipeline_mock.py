@@ -48,6 +48,13 @@ class FakeBatch(object):
         n = self.b - self.a
         return np.arange(n + 1, dtype=np.int64), np.arange(self.a, self.b).astype(np.uint32)
 
+    def ops_packed_into(self, buffer):
+        off, words = self.ops_packed()
+        if buffer is None or buffer.size < len(words):
+            buffer = np.empty(len(words) + 8, dtype=np.uint32)
+        buffer[:len(words)] = words
+        return off, buffer[:len(words)], buffer
+
     def stats(self):
         return {"cells": 10 * (self.b - self.a)}
 
