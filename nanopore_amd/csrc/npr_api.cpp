@@ -83,6 +83,13 @@ struct npr_ctx {
     // the D2H rate and the copy is a GB per batch
     void *pin_pairs = nullptr;
     size_t pin_pairs_bytes = 0;
+    // the packed cigars of the last batch or two that were destroyed: a batch's 75-150 MB, whose pages cost 3 ms to touch when the
+    // next batch is finished and 6 ms to give back when it is destroyed (with a caller waiting for the context)
+    struct HostWords {
+        std::unique_ptr<uint32_t[]> p;
+        int64_t cap = 0;
+    };
+    std::vector<HostWords> packed_pool;
     // pinned host staging of npr_batch_create (plan points + sequence windows), grow-only
     void *pin_stage = nullptr;
     size_t pin_stage_bytes = 0;
@@ -452,6 +459,7 @@ static int32_t release_scratch(npr_ctx *ctx, bool caches_only) {
     ctx->arena_Fx = nullptr, ctx->arena_fx_cells = 0;
     delete ctx->mea;
     ctx->mea = nullptr;
+    ctx->packed_pool.clear();
     return NPR_OK;
 }
 
@@ -1677,9 +1685,16 @@ int32_t device_mea(npr_batch *b) {
     b->ops_off = od;
     b->ops_words = 2 * od[n];
     b->have_pairs_form = false, b->have_packed_form = true;
-    if (od[n] > b->packed_cap) {  // kept when the batch is finished again
-        b->packed.reset(new uint32_t[od[n]]);
-        b->packed_cap = od[n];
+    if (od[n] > b->packed_cap)  // kept when the batch is finished again; else one a destroyed batch left behind, if it is large enough
+        for (size_t i = 0; i < ctx->packed_pool.size(); ++i)
+            if (ctx->packed_pool[i].cap >= od[n]) {
+                b->packed = std::move(ctx->packed_pool[i].p), b->packed_cap = ctx->packed_pool[i].cap;
+                ctx->packed_pool.erase(ctx->packed_pool.begin() + static_cast<std::ptrdiff_t>(i));
+                break;
+            }
+    if (od[n] > b->packed_cap) {
+        b->packed.reset(new uint32_t[od[n] + od[n] / 8]);  // (some room: the chunks of a job are about the same size, not exactly)
+        b->packed_cap = od[n] + od[n] / 8;
     }
     if (od[n]) {
         // one packed word per op (length << 2 | op) through the pinned staging; (op, length) pairs are made on demand
@@ -1816,6 +1831,13 @@ static int32_t batch_finish_impl(npr_batch *b) {
 void npr_batch_destroy(npr_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
+    if (b->packed && b->ctx->packed_pool.size() < 2) {
+        b->ctx->packed_pool.push_back(npr_ctx::HostWords{std::move(b->packed), b->packed_cap});
+    } else if (b->packed && !b->ctx->packed_pool.empty()) {  // the pool keeps the larger ones
+        auto &smallest = *std::min_element(b->ctx->packed_pool.begin(), b->ctx->packed_pool.end(),
+                                           [](const npr_ctx::HostWords &x, const npr_ctx::HostWords &y) { return x.cap < y.cap; });
+        if (smallest.cap < b->packed_cap) smallest.p = std::move(b->packed), smallest.cap = b->packed_cap;
+    }
     delete b;
 }
 

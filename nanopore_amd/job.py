@@ -439,7 +439,12 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                         res, off, words, stats = _rerun_overflowed(ctxs[j], src, params, a, res, off, words, stats, want_stats, tm)
                     t1 = time.perf_counter()
                     note("fetch", t0, t1)
-                    block = src.format_block(a, b_, off, words)
+                    # the records in two halves: the first is being written while the second is formatted (a job of one chunk -- a rank's
+                    # share of a sharded set -- has nothing else to overlap its 8 ms of pwrite with)
+                    m = (b_ - a) // 2
+                    block = src.format_block(a, a + m, off[:m + 1], words[:int(off[m])])
+                    done.put((block, None, None, None))
+                    block = src.format_block(a + m, b_, off[m:] - off[m], words[int(off[m]):])
                     note("format", t1, time.perf_counter())
                     done.put((block, res, off[1:] - off[:-1], stats))
                     del block, res, off, words, stats
@@ -480,10 +485,11 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 t0 = time.perf_counter()
                 sink(block)
                 sink_s += time.perf_counter() - t0
+                if res is not None:
+                    parts.append((res, nops, stats))
                 if TRACE:
                     tm["trace"].append(("sink", t0, time.perf_counter()))
                 del block, item  # (150 MB: released now, not when the next block is waiting to be written)
-                parts.append((res, nops, stats))
     finally:
         if not finished:  # the sink failed on this thread (a full disk): the phases stop, what is in flight is closed, nothing keeps a context
             stop.set()
@@ -637,6 +643,8 @@ def run_source(src, params, bounds, out_path, ctxs=None, gpu=None, group=None, w
         dist.barrier(group=group)  # every rank's block is on disk when rank 0 returns
     tm["gather_s"] = time.perf_counter() - t0
     tm["wall_s"] = time.perf_counter() - t_begin
+    if TRACE:
+        tm["trace"] += [("source", t_begin, t_begin), ("gather", t0, time.perf_counter())]
     if rank == 0:
         out.update(results=results, n_ops=n_ops, stats=stats, sam=out_path)
     return out
@@ -682,6 +690,8 @@ def realign_sam_file(samFile, outputSamFile, referenceFastaFile, hmm=None, gapGa
                      coll_device=coll_device)
     out["timings"].update(index_s=t1 - t0, parse_s=t2 - t1)
     out["timings"]["wall_s"] += t2 - t0
+    if TRACE:
+        out["timings"]["trace"] += [("index", t0, t1), ("parse", t1, t2), ("return", time.perf_counter(), time.perf_counter())]
     if rank == 0:
         out["records"] = len(out["results"])
     return out
