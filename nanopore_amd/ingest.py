@@ -111,8 +111,9 @@ class SamText(object):
             _check(_lib.load().npr_sam_guides(ptr(self.text), ptr(fields), n, ptr(off), ptr(ops)), "npr_sam_guides")
         return off, ops
 
-    def splice(self, span, fields, word_off, n_ops, words):
-        """The records with their CIGAR replaced by the packed cigars (include/nprealign.h: npr_sam_splice): uint8 array."""
+    def splice(self, span, fields, word_off, n_ops, words, take=None):
+        """The records with their CIGAR replaced by the packed cigars (include/nprealign.h: npr_sam_splice): uint8 array -- a view
+        of the buffer `take(nbytes)` returns (a uint8 array of at least that size), when the caller has a pool of them."""
         L = _lib.load()
         n = len(fields)
         span = np.ascontiguousarray(span, dtype=np.int64)
@@ -123,7 +124,7 @@ class SamText(object):
         rec_off = np.zeros(n + 1, dtype=np.int64)
         args = [ptr(self.text), ptr(span), ptr(fields), n, ptr(word_off), ptr(n_ops), ptr(words), ptr(rec_off)]
         total = _check(L.npr_sam_splice(*args, None, 0), "npr_sam_splice")
-        out = np.empty(max(int(total), 1), dtype=np.uint8)
+        out = take(max(int(total), 1)) if take is not None else np.empty(max(int(total), 1), dtype=np.uint8)
         _check(L.npr_sam_splice(*args, ptr(out), int(total)), "npr_sam_splice")
         return out[:int(total)]
 

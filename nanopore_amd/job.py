@@ -139,8 +139,7 @@ class SamSource(ArraySource):
         self.sam = sam
         self.span = np.ascontiguousarray(span, dtype=np.int64)
         self.fields = np.ascontiguousarray(fields, dtype=np.int64)
-        self._guides = None  # (guide_off, guide_ops) of ALL records, built when someone asks; the job builds a chunk's as it stages it
-        self._gbuf = None    # ... into this buffer
+        self._guides = None  # (guide_off, guide_ops) of ALL records, built when someone asks; the job builds a chunk's as it stages it, in a pooled buffer
         self._F_GUIDE_OPS = ing.F_GUIDE_OPS
         tid_to_ref = np.array([fasta.index.get(name, -1) for name in sam.references] + [-1], dtype=np.int32)
         ref_index = tid_to_ref[self.fields[:, ing.F_TID]]
@@ -168,13 +167,16 @@ class SamSource(ArraySource):
         # chunk of 12 500 reads are 300 MB: allocated and released per chunk they cost two rounds of page faults and an munmap under the
         # interpreter lock, during which no other phase of the pipeline can pick up its next chunk)
         sl = slice(lo, hi)
-        need = 2 * int(np.sum(self.fields[sl, self._F_GUIDE_OPS]))
-        if self._gbuf is None or self._gbuf.size < need:
-            self._gbuf = np.empty(need + need // 4, dtype=np.int32)
-        goff, gops = self.sam.guides(self.fields[sl], buffer=self._gbuf)
-        return ctx.stage_spans(params, self.ref, self.ref_off, self.text, self.read_begin[sl], self.read_end[sl], gops, goff,
-                               model_slot=None if self.model_slot is None else self.model_slot[sl], ref_index=self.ref_index[sl],
-                               guide_start=self.guide_start[sl])
+        buf = _take(8 * int(np.sum(self.fields[sl, self._F_GUIDE_OPS])))
+        goff = gops = None
+        try:
+            goff, gops = self.sam.guides(self.fields[sl], buffer=buf.view(np.int32))
+            return ctx.stage_spans(params, self.ref, self.ref_off, self.text, self.read_begin[sl], self.read_end[sl], gops, goff,
+                                   model_slot=None if self.model_slot is None else self.model_slot[sl], ref_index=self.ref_index[sl],
+                                   guide_start=self.guide_start[sl])
+        finally:
+            del goff, gops
+            _give(buf)
 
     def stage_records(self, ctx, params, idx):
         idx = np.asarray(idx, dtype=np.int64)
@@ -185,7 +187,7 @@ class SamSource(ArraySource):
 
     def format_block(self, lo, hi, ops_off, words):
         nops = np.asarray(ops_off[1:]) - np.asarray(ops_off[:-1])
-        return self.sam.splice(self.span[lo:hi], self.fields[lo:hi], ops_off[:-1], nops, words)
+        return self.sam.splice(self.span[lo:hi], self.fields[lo:hi], ops_off[:-1], nops, words, take=_take)  # (run_pipeline gives it back)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -211,6 +213,41 @@ def close_contexts():
         for c in pool:
             c.close()
     _ctx_pool.clear()
+    with _host_lock:
+        _host_pool.clear()
+
+
+# Host buffers of a job's chunks -- the guide operations being staged (300 MB for 12 500 reads), the packed cigars fetched (150 MB),
+# the formatted records on their way to the file (2 x 75 MB) -- kept from chunk to chunk and from job to job, like the contexts:
+# allocated and released per chunk they are page faults on the way in and an munmap under the interpreter lock on the way out,
+# 5-25 ms during which no phase of the pipeline can pick up its next chunk (round 4).  At most _HOST_POOL_MAX buffers are kept;
+# close_contexts() drops them.
+_HOST_POOL_MAX = 8
+_host_pool = []
+_host_lock = threading.Lock()
+
+
+def _take(nbytes):
+    """A uint8 buffer of at least nbytes (a multiple of 4096 bytes long): the smallest of the pool that fits, else a new one."""
+    with _host_lock:
+        best = None
+        for i, b in enumerate(_host_pool):
+            if b.nbytes >= nbytes and (best is None or b.nbytes < _host_pool[best].nbytes):
+                best = i
+        if best is not None:
+            return _host_pool.pop(best)
+    return np.empty((nbytes + nbytes // 8 + 4095) // 4096 * 4096, dtype=np.uint8)
+
+
+def _give(buf):
+    """A buffer from _take (or any view of it) back to the pool."""
+    while isinstance(buf, np.ndarray) and buf.base is not None:
+        buf = buf.base
+    if not isinstance(buf, np.ndarray) or buf.dtype != np.uint8 or buf.nbytes % 4096:
+        return
+    with _host_lock:
+        if len(_host_pool) < _HOST_POOL_MAX and not any(b is buf for b in _host_pool):
+            _host_pool.append(buf)
 
 
 def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
@@ -237,6 +274,10 @@ def _fetch(b, want_stats, buffer=None):
     """-> (buffer, results, ops_off, words, stats): the packed cigars land in `buffer` when it is large enough, else in a new one
     (returned for the next chunk: 150 MB allocated and released per chunk are page faults and an munmap under the interpreter lock)."""
     res = b.results()
+    need = int(res["n_ops"].sum())
+    if buffer is None or buffer.size < need:
+        _give(buffer)
+        buffer = _take(4 * need).view(np.uint32)
     off, words, buffer = b.ops_packed_into(buffer)
     stats = b.align_stats() if want_stats else None
     return buffer, res, off, words, stats
@@ -282,7 +323,9 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     """Records lo .. hi of `src` as a pipeline of chunks over the contexts `ctxs`, one thread per phase:
 
         stager (band planning + pack + H2D + device planner)  ->  DP pass  ->  finish (MEA chain + cigar on the device)
-        ->  fetch + splice / format of the chunk's records  ->  `sink(block)` on the caller's thread, in record order.
+        ->  fetch + splice / format of the chunk's records  ->  `sink(block)` on the caller's thread, in record order
+        (a sink that is done with a block when it returns says so by returning CONSUMED: the block's buffer is then used again;
+        any other sink keeps what it was given).
 
     Chunk k uses context k mod len(ctxs) from its staging to its close, so len(ctxs) chunks are in flight and the stager
     runs that far ahead of the DP; the DP passes and MEA stages of different chunks take turns on the device's shared
@@ -424,6 +467,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
         while True:
             item = q_out.get()
             if item is END:
+                _give(words_buf[0])
                 return
             j, a, b_, batch, last = item
             t0 = time.perf_counter()
@@ -483,13 +527,15 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             if error is None:
                 block, res, nops, stats = item
                 t0 = time.perf_counter()
-                sink(block)
+                consumed = sink(block) is CONSUMED
                 sink_s += time.perf_counter() - t0
                 if res is not None:
                     parts.append((res, nops, stats))
                 if TRACE:
                     tm["trace"].append(("sink", t0, time.perf_counter()))
-                del block, item  # (150 MB: released now, not when the next block is waiting to be written)
+                if consumed:
+                    _give(block)  # (a pooled buffer goes back; anything else is released now, not when the next block is waiting to be written)
+                del block, item
     finally:
         if not finished:  # the sink failed on this thread (a full disk): the phases stop, what is in flight is closed, nothing keeps a context
             stop.set()
@@ -519,6 +565,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
 # the job: shard, pipeline, write, gather
 # ---------------------------------------------------------------------------------------------------------
 
+CONSUMED = "consumed"  # what a sink of run_pipeline returns when it is done with the block it was given (its buffer is used again)
 SOLO = "solo"  # as `group`: this process alone runs the whole job although torch.distributed is initialised (bench.py's one-rank
                # reference run of the strong-scaling job inside an N-rank launch)
 
@@ -592,12 +639,12 @@ def run_source(src, params, bounds, out_path, ctxs=None, gpu=None, group=None, w
 
     def sink(block):
         if out_path is None:
-            return
+            return CONSUMED
         if rank == 0:
             os.pwrite(fd, memoryview(block), state["off"])
             state["off"] += len(block)
-        else:
-            kept.append(block)
+            return CONSUMED
+        kept.append(block)  # (written after the all_gather of the sizes: the block stays this rank's)
 
     try:
         results, n_ops, stats, tm = run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=want_stats, chunk_bases=chunk_bases)

@@ -140,3 +140,27 @@ def test_a_failing_sink_stops_the_phases():
     src2 = FakeSrc(300)
     (res, _, _, _), blocks = _run(src2, ctxs)
     assert len(res) == 300
+
+
+def test_host_buffers_go_round():
+    """job._take / job._give: the per-chunk host buffers of a job (guide operations, packed cigars, formatted records) are kept from
+    chunk to chunk; a view finds its way back to its buffer, foreign arrays are not adopted, the pool is bounded and close_contexts()
+    empties it."""
+    job.close_contexts()
+    a = job._take(1000)
+    assert a.dtype == np.uint8 and a.nbytes >= 1000 and a.nbytes % 4096 == 0
+    job._give(a.view(np.uint32)[3:50])
+    assert job._take(500) is a and len(job._host_pool) == 0
+    job._give(a), job._give(a)                                    # (given back twice: kept once)
+    assert len(job._host_pool) == 1
+    big = job._take(10 * a.nbytes)
+    assert big is not a and big.nbytes >= 10 * a.nbytes           # the pooled one is too small: a new one
+    job._give(np.zeros(4096 * 3 + 1, dtype=np.uint8)), job._give(b"bytes"), job._give(None), job._give(np.zeros(4096, dtype=np.int32))
+    assert len(job._host_pool) == 1
+    job._give(big)
+    assert job._take(a.nbytes + 1) is big and job._take(1) is a   # the smallest that fits
+    for _ in range(2 * job._HOST_POOL_MAX):
+        job._give(np.empty(4096, dtype=np.uint8))
+    assert len(job._host_pool) == job._HOST_POOL_MAX
+    job.close_contexts()
+    assert len(job._host_pool) == 0
