@@ -60,6 +60,10 @@ inline int digits(int64_t v) {
     while (v >= 10) v /= 10, ++k;
     return k;
 }
+// ... of a cigar length (30 bits), without a division: a job formats 10^8 of them
+inline int digits30(uint32_t v) {
+    return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6 : v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
+}
 
 }  // namespace
 
@@ -245,7 +249,7 @@ int64_t npr_sam_splice(const char *text, const int64_t *span, const int64_t *fie
                 for (int64_t q = 0; q < n_ops[i]; ++q) {
                     const uint32_t w = words[word_off[i] + q];
                     if ((w & 3u) > 2u) bad = 1;
-                    k += digits(static_cast<int64_t>(w >> 2)) + 1;
+                    k += digits30(w >> 2) + 1;
                 }
                 lens[i] = (f[3] - span[2 * i]) + (k ? k : 1) + (span[2 * i + 1] - f[4]) + 1;
             }
@@ -264,9 +268,13 @@ int64_t npr_sam_splice(const char *text, const int64_t *span, const int64_t *fie
                 if (n_ops[i] == 0) *w++ = '*';
                 for (int64_t q = 0; q < n_ops[i]; ++q) {
                     const uint32_t cw = words[word_off[i] + q];
-                    int64_t v = static_cast<int64_t>(cw >> 2);
-                    const int k = digits(v);
-                    for (int j = k - 1; j >= 0; --j) w[j] = static_cast<char>('0' + v % 10), v /= 10;
+                    uint32_t v = cw >> 2;
+                    if (v < 10u) {  // (most operations of a realigned nanopore read)
+                        w[0] = static_cast<char>('0' + v), w[1] = code[cw & 3u], w += 2;
+                        continue;
+                    }
+                    const int k = digits30(v);
+                    for (int j = k - 1; j >= 0; --j) w[j] = static_cast<char>('0' + v % 10u), v /= 10u;
                     w[k] = code[cw & 3u];
                     w += k + 1;
                 }

@@ -123,8 +123,15 @@ class SamText(object):
         words = np.ascontiguousarray(words, dtype=np.uint32)
         rec_off = np.zeros(n + 1, dtype=np.int64)
         args = [ptr(self.text), ptr(span), ptr(fields), n, ptr(word_off), ptr(n_ops), ptr(words), ptr(rec_off)]
+        if take is not None:
+            # one call into a buffer sized by a bound (a record's bytes + 11 per operation: ten digits and a letter) instead of a sizing
+            # call first: the sizing pass over 10^7-10^8 operations is a third of the work, and pages nobody touches cost nothing
+            bound = int((span[:, 1] - span[:, 0]).sum() + 11 * n_ops.sum() + 2 * n + 1)
+            out = take(bound)
+            total = _check(L.npr_sam_splice(*args, ptr(out), out.nbytes), "npr_sam_splice")
+            return out[:int(total)]
         total = _check(L.npr_sam_splice(*args, None, 0), "npr_sam_splice")
-        out = take(max(int(total), 1)) if take is not None else np.empty(max(int(total), 1), dtype=np.uint8)
+        out = np.empty(max(int(total), 1), dtype=np.uint8)
         _check(L.npr_sam_splice(*args, ptr(out), int(total)), "npr_sam_splice")
         return out[:int(total)]
 

@@ -71,6 +71,14 @@ def test_splice_equals_the_record_writer(tmp_path):
     nops = np.array([len(c) for c in new], dtype=np.int64)
     woff = np.concatenate([[0], np.cumsum(nops)[:-1]]).astype(np.int64)
     got = st.header + bytes(st.splice(sp, ff, woff, nops, words))
+    # ... and the same bytes in one call into a buffer sized by a bound (what the job's pooled buffers get); long operations too
+    pooled = st.splice(sp, ff, woff, nops, words, take=lambda nbytes: np.full(nbytes + 5, 0x55, dtype=np.uint8))
+    assert st.header + bytes(pooled) == got
+    big = words.copy()
+    big[::3] = (np.array([9, 10, 99, 100, 12345, (1 << 29) - 1], dtype=np.uint32)[np.arange(len(big[::3])) % 6] << 2) | (big[::3] & 3)
+    assert bytes(st.splice(sp, ff, woff, nops, big, take=lambda nbytes: np.empty(nbytes, dtype=np.uint8))) == bytes(st.splice(sp, ff, woff, nops, big))
+    text = bytes(st.splice(sp, ff, woff, nops, big)).decode()
+    assert all(("%d%s" % (int(w) >> 2, "MID"[int(w) & 3])) in text for w in big[:12])
     out = str(tmp_path / "b.sam")
     src = pysam.Samfile(path, "r")
     dst = pysam.Samfile(out, "wh", template=src)
