@@ -45,10 +45,18 @@ class SamText(object):
         self.text = _map(path)
         n_bytes = len(self.text)
         hend = C.c_int64(0)
-        n = _check(L.npr_sam_index(ptr(self.text), n_bytes, C.byref(hend), None, 0), "npr_sam_index")
-        self.span = np.zeros((n, 2), dtype=np.int64)
-        if n:
-            _check(L.npr_sam_index(ptr(self.text), n_bytes, C.byref(hend), ptr(self.span), n), "npr_sam_index")
+        # one scan when the lines are 256 bytes or more on average (reads are): the table is sized by that guess, and pages nobody
+        # touches cost nothing; else count first, then fill
+        guess = n_bytes // 256 + 1024
+        self.span = np.zeros((guess, 2), dtype=np.int64)
+        n = L.npr_sam_index(ptr(self.text), n_bytes, C.byref(hend), ptr(self.span), guess)
+        if n == _lib.ERR_CAPACITY:
+            n = _check(L.npr_sam_index(ptr(self.text), n_bytes, C.byref(hend), None, 0), "npr_sam_index")
+            self.span = np.zeros((n, 2), dtype=np.int64)
+            if n:
+                _check(L.npr_sam_index(ptr(self.text), n_bytes, C.byref(hend), ptr(self.span), n), "npr_sam_index")
+        else:
+            self.span = self.span[:_check(n, "npr_sam_index")]
         self.header = bytes(self.text[:hend.value])
         self.references, self.lengths = [], []
         for line in self.header.decode("ascii", errors="replace").splitlines():

@@ -215,3 +215,13 @@ def test_a_workload_written_as_files_reads_back_as_the_same_arrays(tmp_path, win
     assert [a.qname for a in recs] == ["read_%d" % i for i in range(n)]
     assert [a.query.encode() for a in recs] == [bytes(w["read"][w["read_off"][i]:w["read_off"][i + 1]]) for i in range(n)]
     assert [s for _, s, _ in bioio.fastqRead(fq)] == [a.seq for a in recs]
+
+
+def test_many_short_lines_take_the_counting_path(tmp_path):
+    """SamText sizes its line table by a guess (lines of 256 bytes or more: one scan) and counts first when the guess is too small:
+    4000 records of 40 bytes, against the record reader."""
+    lines = EDGE[:4] + ["s%d\t0\tchr1\t%d\t60\t4M\t*\t0\t0\tACGT\tIIII" % (i, 1 + i % 900) for i in range(4000)]
+    path = _write(tmp_path, lines, name="short.sam")
+    assert os.path.getsize(path) // 256 + 1024 < 4000
+    st, ff, sp, kept = _check_against_mirror(path)
+    assert len(st) == 4000 and (st.line_lengths() >= 30).all()
