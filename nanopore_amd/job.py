@@ -506,8 +506,9 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     threads = [threading.Thread(target=guarded(fn, up, down), daemon=True)
                for fn, up, down in ((stager, None, q_run), (runner, q_run, q_fin), (finisher, q_fin, q_out), (fetcher, q_out, done))]
     # The cyclic collector stays out of the job: a full collection walks every object of the process (millions once torch is
-    # imported) with the interpreter lock held, and the phase that was about to take a chunk over waits 10-25 ms for it (round 4: the
-    # gaps between one phase's end and the next one's start in the trace).  The pipeline itself makes no cycles worth collecting.
+    # imported) with the interpreter lock held, tens of ms during which no phase can take its next chunk over.  (The 10-25 ms gaps
+    # in round 4's traces turned out to be something else -- munmaps of the chunks' buffers under the same lock, see _take -- and
+    # the job times the same with the collector on, NPR_JOB_GC=1; it is kept out because the pipeline makes no cycles worth collecting.)
     gc_was_on = gc.isenabled() and os.environ.get("NPR_JOB_GC") is None
     if gc_was_on:
         gc.disable()
