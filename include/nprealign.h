@@ -126,13 +126,15 @@ const char *npr_strerror(int32_t code);
 int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen);
 void npr_destroy(npr_ctx *ctx);
 const char *npr_last_error(npr_ctx *ctx);
-/* Context options.  NPR_OPT_OVERLAP (value 0 / 1, default 0): the context is one of several on its device whose batches are
+/* Context options.  NPR_OPT_OVERLAP (value 0 / 1 / 2, default 0): the context is one of several on its device whose batches are
  * in flight together -- a pipelined job stages batch k+1 and finishes batch k-1 while batch k is in its DP pass
  * (nanopore_amd/job.py; the reference's analogue is jobTree running several cactus_realign processes at once,
  * /root/reference/Makefile:1 maxThreads).  The contexts of a device share its forward scratch and take turns in it; with this
  * option the device MEA stage keeps its tables in buffers of the context's own instead (so npr_batch_finish need not wait for
  * another batch's DP pass), and the DP launches of narrow bands leave one wavefront slot per SIMD free so that the staging
- * and MEA kernels of the other batches find room beside them.  Results do not change. */
+ * and MEA kernels of the other batches find room beside them.  Value 2: the tables of its own only -- the next batch's DP pass
+ * starts when it is staged, not when this batch's MEA stage has given the shared scratch back; the MEA kernels take the slots the
+ * DP pass leaves as its wavefronts run out (nanopore_amd/job.py's default since round 4).  Results do not change. */
 #define NPR_OPT_OVERLAP 1
 /* NPR_OPT_RELEASE_SCRATCH (an action; value 2: only the context's cache of released device buffers, the scratch stays): the device's forward scratch (shared by the contexts of the device; the
  * next batch that needs it allocates it again) and this context's cache of released device buffers go back to the driver.  For

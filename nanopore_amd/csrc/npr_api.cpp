@@ -74,7 +74,7 @@ struct npr_ctx {
     std::string last_error;
     int host_threads = 1;
     DeviceArena *arena = nullptr;  // the device's forward scratch (shared with the other contexts on this device)
-    bool overlap = false;          // NPR_OPT_OVERLAP: see include/nprealign.h
+    int overlap = 0;               // NPR_OPT_OVERLAP: see include/nprealign.h (1: own MEA tables + a wavefront slot per SIMD left free; 2: own MEA tables only)
     int64_t opt[NPR_OPT_COUNT] = {};  // npr_ctx_option: the test / bring-up switches (all 0 by default)
     static constexpr size_t kArenaPad = DeviceArena::kPad;
     float *arena_Fx = nullptr;  // E-step only: four more forward planes (per context)
@@ -466,7 +466,7 @@ static int32_t release_scratch(npr_ctx *ctx, bool caches_only) {
 int32_t npr_ctx_option(npr_ctx *ctx, int32_t option, int64_t value) {
     if (!ctx) return NPR_ERR_INVALID;
     switch (option) {
-        case NPR_OPT_OVERLAP: ctx->overlap = value != 0; return NPR_OK;
+        case NPR_OPT_OVERLAP: ctx->overlap = value == 2 ? 2 : (value != 0 ? 1 : 0); return NPR_OK;
         case NPR_OPT_RELEASE_SCRATCH: return release_scratch(ctx, value == 2);
         default:
             if (option > NPR_OPT_RELEASE_SCRATCH && option < NPR_OPT_COUNT) {
@@ -1095,7 +1095,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             waves_per_cu = kClassTab[c].kind == K_RS ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R);
             // NPR_OPT_OVERLAP: one wavefront slot per SIMD (and its registers) left to the staging and MEA kernels of the
             // batches this one runs next to; the DP pass alone loses about 2 % (98 % VALU-busy at 5 wavefronts per SIMD)
-            if (ctx->overlap && kClassTab[c].R <= 2) waves_per_cu -= 4;
+            if (ctx->overlap == 1 && kClassTab[c].R <= 2) waves_per_cu -= 4;
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 64;

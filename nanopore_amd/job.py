@@ -334,10 +334,12 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     timings)."""
     from . import realign
     pending = list(reversed(chunk_bounds(src.lengths(), lo, hi, chunk_bases, len(ctxs))))  # a stack: splits go back on top
-    # NPR_OPT_OVERLAP (MEA tables off the shared scratch, a wavefront slot per SIMD left free beside a DP pass) is off by
-    # default: measured on config 3 it moves nothing (763 vs 762 ms per step) -- the finish then runs under the next DP pass
-    # but five times slower, and that DP pass 6 % slower: the phases compete for the same VALU cycles (DESIGN.md section 6b)
-    overlap = len(ctxs) > 1 and len(pending) > 1 and os.environ.get("NPR_JOB_OVERLAP") is not None
+    # NPR_OPT_OVERLAP = 2: the MEA tables of a chunk off the device's shared scratch, so that the next chunk's DP pass starts when it
+    # is staged and not when this chunk's MEA stage has given the scratch back (a kernel trace showed 10-15 ms per chunk of exactly
+    # that wait: 414 -> 403 ms per 50 000 reads, 393 with GPU_MAX_HW_QUEUES=8).  Value 1 also leaves a wavefront slot per SIMD free
+    # beside a DP pass: measured twice, it gives the DP pass 5 % more time and the other kernels nothing they do not get anyway
+    # (DESIGN.md section 6b).  NPR_JOB_OVERLAP=0 / 1 / 2 picks one for an A/B run.
+    overlap = int(os.environ.get("NPR_JOB_OVERLAP", "2")) if (len(ctxs) > 1 and len(pending) > 1) else 0
     for c in ctxs:
         c.set_option(_lib.OPT_OVERLAP, overlap)
     n_planned = len(pending)
