@@ -39,7 +39,16 @@ inline bool parse_int(const char *p, const char *end, int64_t &v) {
     return true;
 }
 
-// SAM cigar operation letters in pysam's numbering: M I D N S H P = X
+// SAM cigar operation letters in pysam's numbering: M I D N S H P = X (-1: anything else)
+struct OpTable {
+    int8_t t[256];
+    constexpr OpTable() : t{} {
+        for (int i = 0; i < 256; ++i) t[i] = -1;
+        t['M'] = 0, t['I'] = 1, t['D'] = 2, t['N'] = 3, t['S'] = 4, t['H'] = 5, t['P'] = 6, t['='] = 7, t['X'] = 8;
+    }
+    constexpr int operator[](unsigned char c) const { return t[c]; }
+};
+constexpr OpTable kOpCode{};
 inline int op_code(char c) {
     switch (c) {
         case 'M': return 0;
@@ -167,26 +176,29 @@ int32_t npr_sam_parse(const char *text, const int64_t *span, int64_t n, const ch
                 bool ok = !(ce - q == 1 && *q == '*') && q < ce;
                 int64_t lead = 0, trail = 0, mid = 0, refspan = 0;
                 bool in_lead = true;
+                // (10^8 operations per job: the digits without a bound test -- the column ends in a tab, which is no digit --, the
+                // letter through a table, M / I / D first)
                 while (ok && q < ce) {
-                    int64_t v = 0;
+                    uint64_t v = 0;
                     const char *d = q;
-                    while (d < ce && *d >= '0' && *d <= '9' && d - q < 10) v = v * 10 + (*d - '0'), ++d;
-                    if (d == q || d >= ce) {
+                    unsigned c;
+                    while ((c = static_cast<unsigned>(static_cast<unsigned char>(*d)) - '0') <= 9u) v = v * 10 + c, ++d;
+                    if (d == q || d - q > 10 || d >= ce) {
                         ok = false;
                         break;
                     }
-                    const int op = op_code(*d);
+                    const int op = kOpCode[static_cast<unsigned char>(*d)];
                     q = d + 1;
-                    if (op < 0 || v >= (int64_t(1) << 29)) {
+                    if (static_cast<unsigned>(op) <= 2u && v < (uint64_t(1) << 29)) {
+                        in_lead = false, trail = 0, ++mid;
+                        if (op != 1) refspan += static_cast<int64_t>(v);
+                    } else if (op < 0 || v >= (uint64_t(1) << 29)) {
                         ok = false;
                     } else if (op == 4) {
-                        if (in_lead) lead += v;
-                        trail += v;
+                        if (in_lead) lead += static_cast<int64_t>(v);
+                        trail += static_cast<int64_t>(v);
                     } else if (op == 5) {
                         // hard clips: no bases in SEQ, no operation (pysam's qstart / qend skip them)
-                    } else if (op <= 2) {
-                        in_lead = false, trail = 0, ++mid;
-                        if (op != 1) refspan += v;
                     } else {
                         ok = false;  // N P = X: the reference asserts op in (0, 1, 2, 4, 5) (utils.py:171)
                     }
@@ -215,12 +227,13 @@ int32_t npr_sam_guides(const char *text, const int64_t *fields, int64_t n, const
                 const int32_t *const we = guide_ops + 2 * guide_off[i + 1];
                 const char *q = text + f[3];
                 const char *const ce = text + f[4];
-                while (q < ce && w < we) {
-                    int64_t v = 0;
-                    while (q < ce && *q >= '0' && *q <= '9') v = v * 10 + (*q - '0'), ++q;
+                while (q < ce && w < we) {  // (a column npr_sam_parse accepted: numbers below 2^29, each followed by a letter, a tab behind it)
+                    uint32_t v = 0;
+                    unsigned c;
+                    while ((c = static_cast<unsigned>(static_cast<unsigned char>(*q)) - '0') <= 9u) v = v * 10 + c, ++q;
                     if (q >= ce) break;
-                    const int op = op_code(*q++);
-                    if (op >= 0 && op <= 2) *w++ = op, *w++ = static_cast<int32_t>(v);
+                    const int op = kOpCode[static_cast<unsigned char>(*q++)];
+                    if (static_cast<unsigned>(op) <= 2u) w[0] = op, w[1] = static_cast<int32_t>(v), w += 2;
                 }
             }
         });
