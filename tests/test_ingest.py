@@ -95,10 +95,19 @@ def test_malformed_records_are_flagged_not_skipped(tmp_path):
                         "bad3\tx\tchr1\t5\t1\t4M\t*\t0\t0\tACGT\t*",            # FLAG not a number
                         "bad4\t0\tchr1\t5\t1\t4\t*\t0\t0\tACGT\t*",             # cigar without an operation
                         "bad5\t0\tchr1\t5\t1\t*\t*\t0\t0\tACGT\t*",             # mapped, no cigar
-                        "ok\t0\tchr1\t5\t1\t4M\t*\t0\t0\tACGT\t*"]
+                        "bad6\t0\tchr1\t5\t1\t99999999999M\t*\t0\t0\tACGT\t*",   # eleven digits
+                        "bad7\t0\tchr1\t5\t1\t4294967296M\t*\t0\t0\tACGT\t*",    # ten digits, beyond 2^29
+                        "bad8\t0\tchr1\t5\t1\t" + "9" * 40 + "M\t*\t0\t0\tACGT\t*",  # a number that wraps 64 bits
+                        "bad9\t0\tchr1\t5\t1\tM4\t*\t0\t0\tACGT\t*",             # a letter without a number
+                        "bad10\t0\tchr1\t5\t1\t2M2m\t*\t0\t0\tACGT\t*",          # a letter that is no operation
+                        "ok\t0\tchr1\t5\t1\t4M\t*\t0\t0\tACGT\t*",
+                        "ok2\t0\tchr1\t5\t1\t2S536870911M1I2D3H\t*\t0\t0\tACGT\t*"]   # the largest length there is
     st = ingest.SamText(_write(tmp_path, lines))
     f = st.parse()
-    assert list(f[:, ingest.F_STATUS]) == [-1, -1, -1, -1, -1, 0]
+    assert list(f[:, ingest.F_STATUS]) == [-1] * 10 + [0, 0]
+    assert f[11, ingest.F_GUIDE_OPS] == 3 and f[11, ingest.F_REF_SPAN] == 536870911 + 2
+    off, ops = st.guides(f)
+    assert ops.tolist() == [[0, 4], [0, 536870911], [1, 1], [2, 2]] and off.tolist() == [0] * 11 + [1, 4]
 
 
 def test_nothing_is_dropped_without_an_error(tmp_path):
