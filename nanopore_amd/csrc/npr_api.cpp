@@ -282,7 +282,8 @@ struct npr_batch {
     std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     bool variable_regions = false;  // the one-wavefront frame launches have regions of their own size (not E-step capable)
-    bool pair_rs = false;  // classes 12-14 run k_dp_pair_rs (row-scaled arithmetic) rather than k_dp_pair
+    bool pair_rs = false;  // classes 12-14 run in row-scaled arithmetic (k_dp_mid_rs / k_dp_pair_rs) rather than k_dp_pair
+    bool mid = true;       // ... as k_dp_mid_rs: the sweeps meet in the middle (NPR_OPT_MID = 1: k_dp_pair_rs)
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -856,7 +857,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     }
     std::vector<int32_t> sched_cls(ntasks, -1);
     std::vector<int64_t> sched_cells(ntasks, 0);
-    if ((e = b->d_ctl.alloc_from(ctx, 2 * ctl_entries + 8)) != hipSuccess)  // (+8: k_dp_rs reads its control words two rows ahead)
+    if ((e = b->d_ctl.alloc_from(ctx, 2 * ctl_entries + 16)) != hipSuccess)  // (+16: k_dp_rs reads its control words two rows ahead, k_dp_mid_rs up to six)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc", e);
     if (ctl_entries > kCtlFrontPad) {
         DevBuf<uint32_t> d_cand;
@@ -928,6 +929,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
             if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) rs = false;
         b->pair_rs = rs;
+        b->mid = ctx->opt[NPR_OPT_MID] != 1;  // the two-wavefront classes in row-scaled arithmetic: k_dp_mid_rs (1: k_dp_pair_rs, A/B)
         if (rs)
             for (int64_t k = 0; k < ntasks; ++k) {
                 if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
@@ -963,6 +965,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
                 for (int32_t k : mine) {
                     const int64_t len = static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
                     if (room <= 0 || (!whole && (len <= fair || len < 256))) break;
+                    if (b->pair_rs && b->mid && len - 1 < MID_MIN_D) break;  // (sorted by length: the rest is shorter still; k_dp_mid_rs needs a block on either side of its cut)
                     cls_of[k] = static_cast<int8_t>(kFirstPair + c), --room, any_pair = true;
                 }
             }
@@ -1211,7 +1214,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     for (auto &L : b->launches) {
         const int kind = kClassTab[L.cls].kind;
         if ((is_one_wave_kind(kind) && b->variable_regions && !uniform(L)) || kind == K_PAIR) {
-            const int64_t sets = kind == K_PAIR ? 2 : 1;  // k_dp_pair keeps the backward rows too
+            const int64_t sets = kind == K_PAIR && !(b->pair_rs && b->mid) ? 2 : 1;  // k_dp_pair / k_dp_pair_rs keep the backward rows too; k_dp_mid_rs's two sweeps share one set
             if (own_regions(L, [&](int32_t g) { return sets * ((pad_of[g] + 63) & ~int64_t(63)); }) != NPR_OK)
                 return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
         }
@@ -1350,7 +1353,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
-        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_pair_rs(a, kc.R, L.grid, s, sw) : launch_pair(a, kc.R, L.grid, s))
+        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? (b->mid ? launch_mid_rs(a, kc.R, L.grid, s, sw) : launch_pair_rs(a, kc.R, L.grid, s, sw)) : launch_pair(a, kc.R, L.grid, s))
                        : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
@@ -1381,7 +1384,10 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         HIP_TRY(ctx, hipMemcpy(b->outs.data() + L.first, b->d_outs.p + L.first, sizeof(TaskOut) * L.count, hipMemcpyDeviceToHost));
         std::vector<int32_t> again;
         for (int k = L.first; k < L.first + L.count; ++k)
-            if (b->outs[k].status == TASK_RERUN) again.push_back(k);
+            if (b->outs[k].status == TASK_RERUN) {
+                again.push_back(k);
+                if (std::getenv("NPR_TIMING")) std::fprintf(stderr, "[npr] task %d (D %d) runs again: why %d ratio %.9g de %d tot %g %d\n", k, b->tasks[k].D, b->outs[k].npairs, b->outs[k].btot_m, b->outs[k].btot_e, b->outs[k].tot_m, b->outs[k].tot_e);
+            }
         if (again.empty()) continue;
         std::vector<Task> sub(again.size());
         for (size_t j = 0; j < again.size(); ++j) sub[j] = b->tasks[again[j]];

@@ -291,6 +291,10 @@ constexpr int32_t TASK_RERUN = 1;  // TaskOut::status of such a task between the
 NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }
 int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);  // sw: a loaded model has short-gap switches (npr_rs.h)
 int launch_pair_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);  // k_dp_pair_rs: k_dp_rs's sweeps on two wavefronts at once
+// k_dp_mid_rs (npr_kernel_mid.hip): k_dp_rs's sweeps on two wavefronts that meet in the middle -- the forward one from row 0, the backward one from
+// row D, each going on past the cut against the other's stored rows.  Tasks of fewer than MID_MIN_D anti-diagonals stay with k_dp_rs.
+constexpr int32_t MID_MIN_D = 4 * NPR_RS_K;
+int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);
 int launch_tile_rs(const KernelArgs &a, int NW, int grid, void *stream);  // k_dp_tile_rs: k_dp_tile's stripes, one exponent per stripe row
 size_t tile_rs_lds_bytes(int nw);
 size_t rs_lds_bytes();  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once

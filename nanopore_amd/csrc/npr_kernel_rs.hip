@@ -19,75 +19,6 @@ namespace npr {
 
 namespace {
 
-// Exponents of the forward rows, one per RS_K anti-diagonals: written by lane 0 with vector stores during the forward sweep,
-// read back by the backward sweep through the scalar cache (one s_load per loop iteration, an iteration ahead) after an
-// s_dcache_inv between the sweeps -- the region is reused from task to task, so the cache may hold the previous task's words.
-// (Read with a vector load and handed out by v_readlane, every anti-diagonal waited for vmcnt(0): the compiler cannot know
-// that the register is not the target of a load in flight, and the forward rows prefetched for the next step were.)
-typedef const __attribute__((address_space(4))) int *cptr_i32;
-
-// The control words of 64 anti-diagonals at a time, a lane each, fetched with one vector load a block ahead of their use
-// and handed out by v_readlane.  (Through the scalar cache every anti-diagonal began with an s_load and a wait for it --
-// scalar loads return out of order, so the wait is for everything the wavefront has in flight on that counter, the
-// emission look-ups included; k_dp_stair hides that behind a step twice as long.)
-template <int DIR>
-struct CtlFeed {
-    uint2 cur, nxt;  // lane l: the words of anti-diagonal base + DIR * l / base + DIR * (64 + l)
-    int base;
-};
-__device__ __forceinline__ uint2 ctl_words(const uint2 *gw, int D, int d) { return (d >= 0 && d <= D) ? gw[d] : make_uint2(0u, 0u); }
-template <int DIR>
-__device__ __forceinline__ void ctl_init(CtlFeed<DIR> &f, const uint2 *gw, int D, int first, int lane) {
-    f.base = first;
-    f.cur = ctl_words(gw, D, first + DIR * lane);
-    f.nxt = ctl_words(gw, D, first + DIR * (WAVE + lane));
-}
-// The words of anti-diagonals d and d + DIR.  d moves monotonically in direction DIR by at most 64 per request and is an
-// even number of rows away from `first` (so that both lie in the same block of 64).
-struct CtlPair {
-    uint32_t a0, a1, b0, b1;
-};
-template <int DIR>
-__device__ __forceinline__ CtlPair ctl_get2(CtlFeed<DIR> &f, const uint2 *gw, int D, int d, int lane) {
-    int off = uni(DIR * (d - f.base));
-    if (off >= WAVE) {  // uniform
-        f.cur = f.nxt;
-        f.base += DIR * WAVE;
-        f.nxt = ctl_words(gw, D, f.base + DIR * (WAVE + lane));
-        off -= WAVE;
-    }
-    CtlPair p;
-    p.a0 = __builtin_amdgcn_readlane(f.cur.x, off), p.a1 = __builtin_amdgcn_readlane(f.cur.y, off);
-    p.b0 = __builtin_amdgcn_readlane(f.cur.x, off + 1), p.b1 = __builtin_amdgcn_readlane(f.cur.y, off + 1);
-    return p;
-}
-template <int R>
-__device__ __forceinline__ int ctl_rebase_of(uint32_t w1) {  // the rebase a control word asks for, whatever the class's word format
-    return R == 2 ? static_cast<int>((w1 >> 28) & 3u) - 1 : static_cast<int>((w1 >> 26) & 3u) - 1;
-}
-__device__ __forceinline__ int note_s(int &smax, int s) {
-    smax = max(smax, s);
-    return s;
-}
-#define RS_FWD_REBASE(r) rs_fwd_rebase<R>(E, (r), Q)
-#define RS_BWD_REBASE(r) rs_bwd_rebase<R>(E, (r), Q)
-#ifndef NPR_RS_CTL
-#define NPR_RS_CTL 2  // control words: 0 vector feed + readlane, 1 scalar load when needed, 2 scalar load one iteration ahead (measured: 3.19 / 3.44 / 3.66e11 cells/s)
-#endif
-__device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
-    cptr32 e = ctl + 2 * static_cast<int64_t>(d);
-    return CtlPair{e[0], e[1], e[2], e[3]};
-}
-#ifndef NPR_RS_BLOCK
-#define NPR_RS_BLOCK 1  // the sweeps of k_dp_rs in blocks of RS_K anti-diagonals: stream refills and renormalisation outside the steps
-#endif
-#ifndef NPR_PAIR_BLOCK
-#define NPR_PAIR_BLOCK NPR_RS_BLOCK  // the same for the two sweeps of k_dp_pair_rs
-#endif
-#ifndef NPR_RS_WAVES2
-#define NPR_RS_WAVES2 7  // wavefronts per SIMD the R = 2 kernel is compiled for: 72 VGPRs, six spilled outside the sweeps' loops (round 4, without the
-                         // short-gap switch terms: 138.1 ms at 7 per SIMD, 140.4 at 6, 138.6 at 8 on the headline batch; round 3, with them: 6 was best)
-#endif
 template <int R, bool SW>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_rs(KernelArgs a) {
     // static LDS: the tables' addresses are compile-time constants and fold into the ds_read offsets
@@ -113,7 +44,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                   model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
         const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(uni(tp->cells_pad))));
         int *const fexp = reinterpret_cast<int *>(F + 4 * half);
-        const uint2 *const gw = reinterpret_cast<const uint2 *>(a.ctl + 2 * ctl_off);
         const __amdgpu_buffer_rsrc_t frs = rs_task_rsrc<R>(F);
         const int rs = flags & 1, re = (flags >> 1) & 1;
 
@@ -147,8 +77,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
         cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
         const RowCtl<R> c0 = read_row_ctl<R>(ctl, 0);
-        CtlFeed<+1> cf;
-        ctl_init<+1>(cf, gw, D, 1, lane);  // blocks [1, 64], [65, 128], ..: an odd anti-diagonal and the even one after it together
         const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
         Q.x0 = -j0, Q.y0 = j0;
         Q.e = 0;
@@ -171,10 +99,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         if (lane == 0) fexp[0] = 0;
         rs_store_row<R>(frs, Q.A, c0, voff);
         int d = 1;
-#if NPR_RS_CTL == 2
         CtlPair wn = ctl_scalar2(ctl, 1);  // (two words past the task's last row at most: still inside d_ctl or its padding)
-#endif
-#if NPR_RS_BLOCK
         {
             // Blocks of RS_K anti-diagonals, d = 1 (mod RS_K) at the head of each: the base streams are looked after once per block
             // (feed8_ahead) and the renormalisation needs no test -- it belongs to the block's last pair.  The pairs of a block are
@@ -214,40 +139,8 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 #pragma nounroll
             while (d + 1 <= D) pair(std::false_type{});
         }
-#else
-        for (; d + 1 <= D; d += 2) {
-#if NPR_RS_CTL == 0
-            const CtlPair w = ctl_get2<+1>(cf, gw, D, d, lane);
-#elif NPR_RS_CTL == 1
-            const CtlPair w = ctl_scalar2(ctl, d);
-#else
-            const CtlPair w = wn;
-            wn = ctl_scalar2(ctl, d + 2);
-#endif
-            {
-                const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
-                RS_FWD_REBASE(cur.reb);
-                rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
-                rs_store_row<R>(frs, Q.B, cur, voff);
-            }
-            const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
-            RS_FWD_REBASE(cur.reb);
-            rs_fwd_y_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
-            if (((d + 1) & (RS_K - 1)) == 0) {  // a renormalising row: both held rows, then the row goes out with its new exponent
-                Q.e += rs_renorm<R>(Q.A, Q.B);
-                if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
-            }
-            rs_store_row<R>(frs, Q.A, cur, voff);
-        }
-#endif
         if (d <= D) {  // D odd: one more X-step, into B
-#if NPR_RS_CTL == 0
-            const CtlPair w = ctl_get2<+1>(cf, gw, D, d, lane);
-#elif NPR_RS_CTL == 1
-            const CtlPair w = ctl_scalar2(ctl, d);
-#else
             const CtlPair w = wn;
-#endif
             const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
             RS_FWD_REBASE(cur.reb);
             rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
@@ -282,11 +175,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
         TaskOut out;
         out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
         out.status = NPR_OK;
-#ifdef NPR_EXP_FWDONLY
-        const bool alive = false;
-#else
         const bool alive = tot_m > 0.f;
-#endif
         if (!alive) out.status = NPR_ERR_ZERO_PROB;
 
         // =============================== backward + posteriors ===============================
@@ -300,10 +189,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
             Q.e = 0;
             const bool oddD = D & 1;
-            // the loop's first request is for an even anti-diagonal (D - 2, or D - 3 after the peeled step of an odd D) and the
-            // odd one below it: blocks of 64 counted down from there
-            CtlFeed<-1> cb;
-            ctl_init<-1>(cb, gw, D, oddD ? D - 3 : D - 2, lane);
             RowCtl<R> cur = read_row_ctl<R>(ctl, D);
             // `moved` of the anti-diagonals one and two above the one being computed: the row two above is the one overwritten
             uint32_t m1 = cur.moved, m2 = 0;
@@ -356,7 +241,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_c[d2 / RS_K] + Q.e - tot_e), inv_tot, jr, cnt);
                 d2 -= 1;
             }
-#if NPR_RS_BLOCK
             {
                 // Blocks that end on a renormalising row: the pairs (d2, d2 - 1) from d2 down to RS_K m + 1 with m = d2 / RS_K; the rows of a
                 // block share the forward exponent fexp[m]; the last pair ends on row RS_K m, renormalises there and is a loop body of its
@@ -411,60 +295,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     pair(std::true_type{});
                 }
             }
-#else
-#if NPR_RS_CTL == 2
-            // rows {d2 - 2, d2 - 1}, then two rows further down every iteration: down to row -3 of the task (d2 = 1), which lies in the
-            // previous task's words or d_ctl's front padding (npr_api.cpp kCtlFrontPad) and is never looked at
-#ifdef NPR_RS_CTL_CLAMP
-            CtlPair wb = ctl_scalar2(ctl, max(d2 - 2, 0));
-#else
-            CtlPair wb = ctl_scalar2(ctl, d2 - 2);
-#endif
-#endif
-            int ef_next = fexp_c[max(d2, 0) / RS_K];
-            for (; d2 >= 1; d2 -= 2) {  // d2 odd: undo the Y-step into d2 + 1, then the X-step into d2
-#if NPR_RS_CTL == 0
-                const CtlPair w = ctl_get2<-1>(cb, gw, D, d2 - 1, lane);  // the words of d2 - 1 and d2 - 2
-#else
-#if NPR_RS_CTL == 1
-                const CtlPair q = ctl_scalar2(ctl, d2 - 2);
-#else
-                const CtlPair q = wb;
-#ifdef NPR_RS_CTL_CLAMP
-                wb = ctl_scalar2(ctl, max(d2 - 4, 0));
-#else
-                wb = ctl_scalar2(ctl, d2 - 4);
-#endif
-#endif
-#ifdef NPR_RS_CTL_CLAMP
-                const CtlPair w = d2 >= 2 ? CtlPair{q.b0, q.b1, q.a0, q.a1} : CtlPair{q.a0, q.a1, 0u, 0u};
-#else
-                const CtlPair w{q.b0, q.b1, q.a0, q.a1};  // (d2 = 1: the words of row -1 go unused)
-#endif
-#endif
-                int reb = cur.reb;
-                cur = nxt;
-                nxt = row_ctl_of_words<R>(w.a0, w.a1);
-                rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
-                RS_BWD_REBASE(reb);
-                rs_bwd_y_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
-                m2 = m1, m1 = cur.moved;
-                const int ef = ef_next;  // d2 and d2 - 1 lie in the same block of RS_K rows (d2 is odd)
-                ef_next = fexp_c[(d2 - 2) >> __builtin_ctz(RS_K)];  // (d2 = 1: the word before the exponents, a forward cell; not used)
-                rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
-                reb = cur.reb;
-                cur = nxt;
-                if (d2 >= 2) {
-                    nxt = row_ctl_of_words<R>(w.b0, w.b1);
-                    rs_load_row<R>(frs, fb, nxt, voff);
-                }
-                RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
-                m2 = m1, m1 = cur.moved;
-                if (((d2 - 1) & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
-                rs_emit_pairs<R>(sink, Q.A, fa, d2 - 1, Q.x0, Q.y0, cur.mk, note_s(smax, ef + Q.e - tot_e), inv_tot, jr, cnt);
-            }
-#endif
             // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -490,11 +320,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
             // one exponent per row may not have been enough -- also when nothing arrived at the end corner: the per-cell kernel decides
             // whether the band really carries no probability
-#ifndef NPR_EXP_FWDONLY
             if (smax >= NPR_RS_S_LIMIT || !alive) out.status = TASK_RERUN;
-#else
-            out.status = NPR_OK;
-#endif
             a.outs[t] = out;
         }
         int nt = 0;
@@ -608,7 +434,6 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             rs_store_row<R>(frs, Q.A, c0, voff);
             int d = 1;
             CtlPair wn = ctl_scalar2(ctl, 1);
-#if NPR_PAIR_BLOCK
             {  // blocks of RS_K anti-diagonals, as in k_dp_rs
                 auto pair = [&](auto last) __attribute__((always_inline)) {
                     const CtlPair w = wn;
@@ -641,26 +466,6 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
 #pragma nounroll
                 while (d + 1 <= D) pair(std::false_type{});
             }
-#else
-            for (; d + 1 <= D; d += 2) {
-                const CtlPair w = wn;
-                wn = ctl_scalar2(ctl, d + 2);
-                {
-                    const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
-                    RS_FWD_REBASE(cur.reb);
-                    rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
-                    rs_store_row<R>(frs, Q.B, cur, voff);
-                }
-                const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
-                RS_FWD_REBASE(cur.reb);
-                rs_fwd_y_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
-                if (((d + 1) & (RS_K - 1)) == 0) {
-                    Q.e += rs_renorm<R>(Q.A, Q.B);
-                    if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
-                }
-                rs_store_row<R>(frs, Q.A, cur, voff);
-            }
-#endif
             if (d <= D) {
                 const RowCtl<R> cur = row_ctl_of_words<R>(wn.a0, wn.a1);
                 RS_FWD_REBASE(cur.reb);
@@ -720,7 +525,6 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 rs_store_row<R>(brs, Q.A, cur, voff);
                 d2 -= 1;
             }
-#if NPR_PAIR_BLOCK
             {  // blocks that end on a renormalising row, as in k_dp_rs (control words read down to row -3: kCtlFrontPad)
                 CtlPair wb = ctl_scalar2(ctl, d2 - 2);
                 auto pair = [&](auto last) __attribute__((always_inline)) {
@@ -755,32 +559,6 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                     pair(std::true_type{});
                 }
             }
-#else
-            CtlPair wb = ctl_scalar2(ctl, max(d2 - 2, 0));  // {d2 - 2, d2 - 1}
-            for (; d2 >= 1; d2 -= 2) {
-                const CtlPair q = wb;
-                wb = ctl_scalar2(ctl, max(d2 - 4, 0));
-                const CtlPair w = d2 >= 2 ? CtlPair{q.b0, q.b1, q.a0, q.a1} : CtlPair{q.a0, q.a1, 0u, 0u};
-                int reb = cur.reb;
-                cur = nxt;
-                nxt = row_ctl_of_words<R>(w.a0, w.a1);
-                RS_BWD_REBASE(reb);
-                rs_bwd_y_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
-                m2 = m1, m1 = cur.moved;
-                rs_store_row<R>(brs, Q.B, cur, voff);
-                reb = cur.reb;
-                cur = nxt;
-                if (d2 >= 2) nxt = row_ctl_of_words<R>(w.b0, w.b1);
-                RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
-                m2 = m1, m1 = cur.moved;
-                if (((d2 - 1) & (RS_K - 1)) == 0) {
-                    Q.e += rs_renorm<R>(Q.A, Q.B);
-                    if (lane == 0) bexp[(d2 - 1) / RS_K] = Q.e;
-                }
-                rs_store_row<R>(brs, Q.A, cur, voff);
-            }
-#endif
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (jr[r] == j0) {

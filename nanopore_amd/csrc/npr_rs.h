@@ -150,10 +150,6 @@ __device__ __forceinline__ void rs_build_tables(RsTables *t, const DevModel *m, 
 }
 __device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
     constexpr int OFF_EX = offsetof(RsTables, ex2), OFF_EY = offsetof(RsTables, ey2);
-#ifdef NPR_EXP_NOLDS
-    em = __int_as_float(bx + by + 0x3e000000), exs = __int_as_float(bx + 0x3e000000), exl = exs, eys = __int_as_float(by + 0x3e000000), eyl = eys;
-    return;
-#endif
     em = *reinterpret_cast<const float *>(tab + (bx + by));
     const float2 ex = *reinterpret_cast<const float2 *>(tab + OFF_EX + bx);
     const float2 ey = *reinterpret_cast<const float2 *>(tab + OFF_EY + by);
@@ -600,11 +596,7 @@ __device__ __forceinline__ void rs_bwd_rebase(const StepEnv &E, int r, RsState<R
 // mask: no select per value) ...
 template <class F>
 __device__ __forceinline__ void rs_put(RCell &dst, uint64_t in_band, F &&cell) {
-#ifdef NPR_EXP_NOMASK
-    dst = cell();
-#else
     if (__builtin_expect(lanes_of(in_band), 1)) dst = cell();  // (expected: keeps the block in line instead of behind two taken branches)
-#endif
 }
 // ... and when the band is not where it was two anti-diagonals ago (`moved`: a bit of the control word, npr_sched.h; once
 // in ten anti-diagonals on noisy guides) everything outside it is cleared: the row that was overwritten may have had cells
@@ -623,10 +615,8 @@ template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
     x0 += 1;
-#ifndef NPR_EXP_NOSTREAM
     S.xcap = __builtin_amdgcn_readlane(S.X.b[0], 0);
     bases_up<R>(S.X, feed8_take<+1, RS_XS, CHK>(S.fx, E.X, E.lX, x0 + 64 * R - 2, E.lane));
-#endif
     const RDiag<R> U = rs_shift_up<R>(p1);  // (x, y-1) is slot j+1 of d-1; (x-1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -647,10 +637,8 @@ template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
     y0 += 1;
-#ifndef NPR_EXP_NOSTREAM
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[R - 1], 63);
     bases_down<R>(S.Y, feed8_take<+1, RS_YS, CHK>(S.fy, E.Y, E.lY, y0 - 1, E.lane));
-#endif
     const RDiag<R> L = rs_shift_down<R>(p1);  // (x-1, y) is slot j-1 of d-1; (x, y-1) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -672,10 +660,8 @@ template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
     x0 -= 1;
-#ifndef NPR_EXP_NOSTREAM
     S.xcap = __builtin_amdgcn_readlane(S.X.b[R - 1], 63);
     bases_down<R>(S.X, feed8_take<-1, RS_XS, CHK>(S.fx, E.X, E.lX, x0, E.lane));
-#endif
     const RDiag<R> Ys = rs_shift_down<R>(s1);  // (x, y+1) is slot j-1 of d+1; (x+1, y) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -696,10 +682,8 @@ template <int R, bool CHK = true, bool SW = true>
 __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
     y0 -= 1;
-#ifndef NPR_EXP_NOSTREAM
     S.ycap = __builtin_amdgcn_readlane(S.Y.b[0], 0);
     bases_up<R>(S.Y, feed8_take<-1, RS_YS, CHK>(S.fy, E.Y, E.lY, y0 - (64 * R - 1), E.lane));
-#endif
     const RDiag<R> Xs = rs_shift_up<R>(s1);  // (x+1, y) is slot j+1 of d+1; (x, y+1) keeps slot j
     RDiag<R> o;
 #pragma unroll
@@ -726,9 +710,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_task_rsrc(char *F) {
 }
 template <int R>
 __device__ __forceinline__ void rs_store_row(__amdgpu_buffer_rsrc_t rs, const RDiag<R> &C, const RowCtl<R> &ct, int voff) {
-#ifdef NPR_EXP_NOROWS
-    return;
-#endif
     if (lanes_of(ct.mk.lanes)) {
         const int vo = voff + static_cast<int>(ct.soff >> 1);
         if constexpr (R == 1) {
@@ -746,23 +727,12 @@ struct RFRow {
 };
 template <int R>
 __device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> &f, const RowCtl<R> &ct, int voff) {
-#ifdef NPR_EXP_NOROWS
-    return;
-#endif
-#ifndef NPR_RS_MASKED_LOAD
     // Every lane loads, band or not: what a lane outside the band reads (a neighbouring row's bytes, the arena's padding) is never
     // looked at -- rs_emit_pairs masks its hits with the band -- and a load the compiler knows to be issued on every path lets it
     // wait for the OLDER of two rows in flight (s_waitcnt vmcnt(1)) instead of for both: behind a lane-mask branch it had to assume
     // the younger load might not exist and waited for everything, one step after the issue instead of two.
     {
-#else
-    if (lanes_of(ct.mk.lanes)) {
-#endif
-#ifdef NPR_EXP_LOADSAME
-        const int vo = voff + static_cast<int>((ct.soff >> 1) & 0xfff);
-#else
         const int vo = voff + static_cast<int>(ct.soff >> 1);
-#endif
         if constexpr (R == 1) {
             f.v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0));
         } else if constexpr (R == 2) {
@@ -780,17 +750,10 @@ __device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> 
 // is below NPR_RS_S_LIMIT -- and a task with a row above the limit is run again anyway (npr_device.h).
 template <typename T>
 __device__ __forceinline__ T &rs_at(T *base, uint32_t byte_off) { return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off); }
-#ifdef NPR_EXP_POST2
-__device__ __forceinline__ float rs_posterior(float f, float b, int s, float inv_tot) { return f * (b * inv_tot); }
-#else
 __device__ __forceinline__ float rs_posterior(float f, float b, int s, float inv_tot) { return (f * __builtin_ldexpf(b, s)) * inv_tot; }
-#endif
 template <int R>
 __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> &B, const RFRow<R> &f, int d, int x0, int y0, const Masks<R> &mk,
                                               int s, float inv_tot, const int (&jr)[R], int &cnt) {
-#ifdef NPR_EXP_NOPOST
-    return;
-#endif
     float p[R];
     uint64_t hit[R], any = 0;
 #pragma unroll
@@ -799,10 +762,6 @@ __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> 
         hit[r] = __ballot(p[r] >= S.threshold) & mk.cell[r];
         any |= hit[r];
     }
-#ifdef NPR_EXP_NOEMIT
-    if (any) cnt += __popcll(any);
-    return;
-#endif
     if (d >= 2 && any) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -811,24 +770,48 @@ __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> 
                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
                 const int slot = cnt + before;
                 if (lanes_of(hit[r]) && slot < S.cap) {  // (S.off is 0: the sink's pointers are the task's; unsigned slots: scalar base + 32-bit offset)
-#ifdef NPR_RS_PAIR64
-                    S.px[slot] = x0 + jr[r] - 1 + S.xs, S.py[slot] = y0 - jr[r] - 1 + S.ys, S.pp[slot] = p[r];
-#else
                     const uint32_t u = static_cast<uint32_t>(slot) << 2;  // a byte offset that fits 32 bits (pair_cap < 2^29): one shift, the arrays' addresses stay scalar
-#ifdef NPR_EXP_STORE1
-                    rs_at<float>(S.pp, u) = p[r] + __int_as_float((x0 + jr[r] - 1 + S.xs) ^ (y0 - jr[r] - 1 + S.ys));
-#elif !defined(NPR_EXP_STORE0)
                     rs_at<int32_t>(S.px, u) = x0 + jr[r] - 1 + S.xs;
                     rs_at<int32_t>(S.py, u) = y0 - jr[r] - 1 + S.ys;
                     rs_at<float>(S.pp, u) = p[r];
-#endif
-#endif
                 }
                 cnt += __popcll(hit[r]);
             }
         }
     }
 }
+
+// ---- what the sweeps of k_dp_rs and k_dp_mid_rs share around the steps ----
+// Exponents of the stored rows, one per RS_K anti-diagonals: written by lane 0 with vector stores during a sweep, read back by the
+// other sweep through the scalar cache (one s_load per block) after an s_dcache_inv -- the region is reused from task to task, so
+// the cache may hold the previous task's words.  (Read with a vector load and handed out by v_readlane, every anti-diagonal waited
+// for vmcnt(0): the compiler cannot know that the register is not the target of a load in flight, and the rows prefetched for
+// the next step were.)
+typedef const __attribute__((address_space(4))) int *cptr_i32;
+// The control words of two anti-diagonals, d and d + 1, by ONE scalar load, issued a loop iteration ahead of their use.  (Loaded when
+// needed, every step began with s_load + s_waitcnt lgkmcnt(0) -- scalar loads return out of order, so the wait covers the emission
+// look-ups in flight too; 64 rows by one vector load handed out by v_readlane was slower still: 3.19 / 3.44 / 3.66e11 cells/s.)
+struct CtlPair {
+    uint32_t a0, a1, b0, b1;
+};
+__device__ __forceinline__ CtlPair ctl_scalar2(cptr32 ctl, int d) {
+    cptr32 e = ctl + 2 * static_cast<int64_t>(d);
+    return CtlPair{e[0], e[1], e[2], e[3]};
+}
+__device__ __forceinline__ int note_s(int &smax, int s) {
+    smax = max(smax, s);
+    return s;
+}
+template <int R>
+__device__ __forceinline__ int ctl_rebase_of(uint32_t w1) {  // the rebase a control word asks for, whatever the class's word format
+    return R == 2 ? static_cast<int>((w1 >> 28) & 3u) - 1 : static_cast<int>((w1 >> 26) & 3u) - 1;
+}
+#ifndef NPR_RS_WAVES2
+#define NPR_RS_WAVES2 7  // wavefronts per SIMD the R = 2 kernel is compiled for: 72 VGPRs, six spilled outside the sweeps' loops (round 4, without the
+                         // short-gap switch terms: 138.1 ms at 7 per SIMD, 140.4 at 6, 138.6 at 8 on the headline batch; round 3, with them: 6 was best)
+#endif
+#define RS_FWD_REBASE(r) rs_fwd_rebase<R>(E, (r), Q)
+#define RS_BWD_REBASE(r) rs_bwd_rebase<R>(E, (r), Q)
 
 }  // namespace
 
