@@ -282,8 +282,7 @@ struct npr_batch {
     std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     bool variable_regions = false;  // the one-wavefront frame launches have regions of their own size (not E-step capable)
-    bool pair_rs = false;  // classes 12-14 run in row-scaled arithmetic (k_dp_mid_rs / k_dp_pair_rs) rather than k_dp_pair
-    bool mid = true;       // ... as k_dp_mid_rs: the sweeps meet in the middle (NPR_OPT_MID = 1: k_dp_pair_rs)
+    bool pair_rs = false;  // classes 12-14 run k_dp_mid_rs (row-scaled arithmetic, the sweeps meet in the middle) rather than k_dp_pair
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -929,7 +928,6 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
             if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) rs = false;
         b->pair_rs = rs;
-        b->mid = ctx->opt[NPR_OPT_MID] != 1;  // the two-wavefront classes in row-scaled arithmetic: k_dp_mid_rs (1: k_dp_pair_rs, A/B)
         if (rs)
             for (int64_t k = 0; k < ntasks; ++k) {
                 if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
@@ -956,16 +954,20 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
                 for (int64_t k = 0; k < ntasks; ++k)
                     if (cls_of[k] == from) mine.push_back(static_cast<int32_t>(k)), cost += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
                 if (mine.empty()) continue;
-                const int64_t slots = static_cast<int64_t>(ctx->cu_count) * (b->pair_rs ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R));
+                const int64_t slots = static_cast<int64_t>(ctx->cu_count) * (b->pair_rs ? mid_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R));
                 const int64_t n = static_cast<int64_t>(mine.size()), fair = cost / slots;
-                if (!pair_all && !pair_long && (2 * n > slots || n <= 256)) continue;  // (default rule: the class fills more than half of the chip, or is too small for it to matter)
+                // (default rule of the kernel with a third pass, k_dp_pair -- and of round 3-4's k_dp_pair_rs --: not when the class fills more than half of the chip, or is too
+                // small for it to matter.  k_dp_mid_rs has no third pass and moves no more bytes than k_dp_rs: every task, round 5 -- a 1/8 shard of
+                // configs[3] 41.7 -> 29.4 ms, configs[1] 1.27 -> 0.77 ms, the headline batch 138.9 -> 137.1 ms)
+                const bool mid_all = b->pair_rs && !pair_long;
+                if (!pair_all && !pair_long && !mid_all && (2 * n > slots || n <= 256)) continue;
                 const bool whole = pair_all || !pair_long;
                 int64_t room = whole ? n : (n < slots ? slots - n : n);  // second wavefronts to be had
                 std::sort(mine.begin(), mine.end(), [&](int32_t x, int32_t y) { return pseg[x].lX + pseg[x].lY > pseg[y].lX + pseg[y].lY; });
                 for (int32_t k : mine) {
                     const int64_t len = static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
                     if (room <= 0 || (!whole && (len <= fair || len < 256))) break;
-                    if (b->pair_rs && b->mid && len - 1 < MID_MIN_D) break;  // (sorted by length: the rest is shorter still; k_dp_mid_rs needs a block on either side of its cut)
+                    if (b->pair_rs && len - 1 < MID_MIN_D) break;  // (sorted by length: the rest is shorter still; k_dp_mid_rs needs a block on either side of its cut)
                     cls_of[k] = static_cast<int8_t>(kFirstPair + c), --room, any_pair = true;
                 }
             }
@@ -1090,7 +1092,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         first += cls_count[c];
         int waves_per_cu;
         if (kClassTab[c].kind == K_PAIR) {  // workgroups of two wavefronts
-            waves_per_cu = (b->pair_rs ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R)) / 2;
+            waves_per_cu = (b->pair_rs ? mid_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R)) / 2;
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 128;
@@ -1214,7 +1216,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     for (auto &L : b->launches) {
         const int kind = kClassTab[L.cls].kind;
         if ((is_one_wave_kind(kind) && b->variable_regions && !uniform(L)) || kind == K_PAIR) {
-            const int64_t sets = kind == K_PAIR && !(b->pair_rs && b->mid) ? 2 : 1;  // k_dp_pair / k_dp_pair_rs keep the backward rows too; k_dp_mid_rs's two sweeps share one set
+            const int64_t sets = kind == K_PAIR && !b->pair_rs ? 2 : 1;  // k_dp_pair keeps the backward rows too; k_dp_mid_rs's two sweeps share one set
             if (own_regions(L, [&](int32_t g) { return sets * ((pad_of[g] + 63) & ~int64_t(63)); }) != NPR_OK)
                 return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
         }
@@ -1353,7 +1355,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
-        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? (b->mid ? launch_mid_rs(a, kc.R, L.grid, s, sw) : launch_pair_rs(a, kc.R, L.grid, s, sw)) : launch_pair(a, kc.R, L.grid, s))
+        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_mid_rs(a, kc.R, L.grid, s, sw) : launch_pair(a, kc.R, L.grid, s))
                        : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
@@ -2506,7 +2508,7 @@ int32_t npr_batch_rs_forward(npr_batch *b, int64_t read_index, float *Fm_v, int3
         const Task &t = b->tasks[k];
         int R = 0;
         for (const auto &L : b->launches)
-            if (k >= L.first && k < L.first + L.count && kClassTab[L.cls].kind == K_RS) R = kClassTab[L.cls].R;
+            if (k >= L.first && k < L.first + L.count && (kClassTab[L.cls].kind == K_RS || (kClassTab[L.cls].kind == K_PAIR && b->pair_rs))) R = kClassTab[L.cls].R;
         if (R == 0 || t.ctl_off < 0) return fail(ctx, NPR_ERR_STATE, "npr_batch_rs_forward: the read has a segment that k_dp_rs does not run");
         KernelArgs a = make_args(b);
         a.tasks = b->d_tasks.p + k, a.ntasks = 1, a.outs = d_out1.p, a.slot_base = 0, a.region = nullptr;

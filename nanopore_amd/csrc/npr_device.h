@@ -290,10 +290,14 @@ int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
 constexpr int32_t TASK_RERUN = 1;  // TaskOut::status of such a task between the two launches (never leaves npr_batch_run)
 NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }
 int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);  // sw: a loaded model has short-gap switches (npr_rs.h)
-int launch_pair_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);  // k_dp_pair_rs: k_dp_rs's sweeps on two wavefronts at once
 // k_dp_mid_rs (npr_kernel_mid.hip): k_dp_rs's sweeps on two wavefronts that meet in the middle -- the forward one from row 0, the backward one from
 // row D, each going on past the cut against the other's stored rows.  Tasks of fewer than MID_MIN_D anti-diagonals stay with k_dp_rs.
 constexpr int32_t MID_MIN_D = 4 * NPR_RS_K;
+#ifndef NPR_MID_WAVES2
+#define NPR_MID_WAVES2 7  // wavefronts per SIMD k_dp_mid_rs<2> is compiled for
+#endif
+// resident wavefronts per CU of k_dp_mid_rs<R> (80 / .. / 124 registers)
+inline int mid_waves_per_cu(int R) { return R == 1 ? 24 : (R == 2 ? 4 * NPR_MID_WAVES2 : 16); }
 int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);
 int launch_tile_rs(const KernelArgs &a, int NW, int grid, void *stream);  // k_dp_tile_rs: k_dp_tile's stripes, one exponent per stripe row
 size_t tile_rs_lds_bytes(int nw);

@@ -79,7 +79,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 }
 
 template <int R, bool SW>
-__global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_mid_rs(KernelArgs a) {
+__global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 : (R == 2 ? NPR_MID_WAVES2 : 4)))) k_dp_mid_rs(KernelArgs a) {
     __shared__ __attribute__((aligned(16))) RsTables ltab_s;
     __shared__ __attribute__((aligned(16))) float lmodel[MODEL_FLOATS];
     // [0..1] total (forward, at the end corner), [2..3] total (backward), [4] sum of rebases, [5] / [12] candidates of wavefront 0 / 1,
@@ -222,8 +222,8 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             }
         };
         // wavefront 1, a pair of anti-diagonals (d, d - 1), d odd: the undone Y-step into d + 1, then the undone X-step into d; EMIT: against the
-        // forward rows; KEEP: the even row is stored (not the cut row's: wavefront 0's is there)
-        auto bpair = [&](auto emit, auto last, auto keep) __attribute__((always_inline)) {
+        // forward rows
+        auto bpair = [&](auto emit, auto last) __attribute__((always_inline)) {
             constexpr bool EMIT = decltype(emit)::value;
             const CtlPair q = w2;
             w2 = ctl_scalar2(ctl, d - 4);  // (down to row -3 of the task: kCtlFrontPad)
@@ -261,8 +261,10 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
 #pragma unroll
                 for (int r = 0; r < R; ++r) bv[r] = Q.A.c[r].m;
                 mid_emit<R, true>(sink, ra.v, bv, d - 1, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
-            } else if constexpr (decltype(keep)::value) {
-                rs_store_row<R>(frs, Q.A, cur, voff);
+            } else {
+                // (not the cut row's: wavefront 0's forward row lies there.  A scalar test around the store alone: two variants of the pair behind
+                // a test would meet at a join, which is paid with a second copy of the rows' registers)
+                if (d - 1 != c) rs_store_row<R>(frs, Q.A, cur, voff);
             }
             d -= 2;
         };
@@ -415,13 +417,19 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 d -= 1;
             }
             w2 = ctl_scalar2(ctl, d - 2);
-            while (d > c) {  // blocks that end on a renormalising row; the first as long as it takes to get to one
+            {  // blocks that end on a renormalising row; the first as long as it takes to get to one (d > c: D - c >= 2 RS_K)
                 bhead(N);
                 const int n = (d & (RS_K - 1)) >> 1;
 #pragma nounroll
-                for (int k = 0; k < n; ++k) bpair(N, N, Y);
-                if (d - 1 > c) bpair(N, Y, Y);
-                else bpair(N, Y, N);
+                for (int k = 0; k < n; ++k) bpair(N, N);
+                bpair(N, Y);
+            }
+            while (d > c) {  // whole blocks: two pairs per loop body (the streams' registers are back where they were: k_dp_rs)
+                bhead(N);
+#pragma nounroll
+                for (int k = 0; k < RS_K / 4 - 1; ++k) bpair(N, N), bpair(N, N);
+                bpair(N, N);
+                bpair(N, Y);
             }
             // d = c - 1; Q.A holds row c, Q.B row c + 1; cur the words of c, nxt those of c - 1
             mid_meet();
@@ -474,9 +482,9 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 while (d >= 1) {  // whole blocks: d = c - 1 = RS_K m - 1
                     bhead(Y);
 #pragma nounroll
-                    for (int k = 0; k < RS_K / 4 - 1; ++k) bpair(Y, N, N), bpair(Y, N, N);
-                    bpair(Y, N, N);
-                    bpair(Y, Y, N);
+                    for (int k = 0; k < RS_K / 4 - 1; ++k) bpair(Y, N), bpair(Y, N);
+                    bpair(Y, N);
+                    bpair(Y, Y);
                 }
                 // total from the backward side: the lattice point (0, 0) is slot j0 of anti-diagonal 0
 #pragma unroll

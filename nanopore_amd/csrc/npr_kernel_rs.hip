@@ -330,419 +330,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 }
 
 
-// =====================================================================================================================
-// k_dp_pair_rs<R>: k_dp_rs with the two sweeps of a read on TWO wavefronts at the same time (k_dp_pair's idea, npr_kernel_stair.hip,
-// in row-scaled arithmetic).  One wavefront per read makes a read a serial chain of 2 (lX + lY) steps: a launch lasts at least as
-// long as its longest read, and a batch with fewer reads than the chip has wavefront slots leaves the rest idle (BASELINE.json
-// configs[1]; one rank's eighth of configs[3]).  Wavefront 0 runs k_dp_rs's forward sweep, wavefront 1 its backward sweep,
-// storing ITS match rows (4 bytes per cell) and their exponents in a second scratch area; after one barrier both stream the two
-// sets of rows back, half of the anti-diagonals each, and emit the posteriors: F * ldexp(B, eF + eB - eTot) / totMant -- the same
-// cells, the same total, the same expression as k_dp_rs, so the same bits (the pairs land in another order, which every consumer
-// sorts away), and the same range certificate.
-// =====================================================================================================================
-template <int R, bool SW>
-__global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_pair_rs(KernelArgs a) {
-    __shared__ __attribute__((aligned(16))) RsTables ltab_s;
-    __shared__ __attribute__((aligned(16))) float lmodel[MODEL_FLOATS];
-    __shared__ int lmisc[8];  // [0..3] totals, [4] sum of rebases, [5] pair counter, [6] next task, [7] largest s
-    RsTables *ltab = &ltab_s;
-
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
-    char *const F = a.F + uni64(a.region[blockIdx.x]) * 8;  // the workgroup's region: forward rows + exponents, then the backward ones
-    const int voff = 4 * R * lane;
-    int jr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
-
-    int t = blockIdx.x;
-    while (t < a.ntasks) {
-        const Task *tp = a.tasks + t;
-        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off), pair_off = uni64(tp->pair_off);
-        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = min(uni(tp->pair_cap), (1 << 29) - 1) /* (pair slots are 32-bit byte offsets) */, flags = uni(tp->flags),
-                  model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
-        const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(uni(tp->cells_pad))));
-        char *const Bs = F + 8 * half;  // the backward sweep's half of the region
-        int *const fexp = reinterpret_cast<int *>(F + 4 * half), *const bexp = reinterpret_cast<int *>(Bs + 4 * half);
-        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
-        const __amdgpu_buffer_rsrc_t frs = rs_task_rsrc<R>(F), brs = rs_task_rsrc<R>(Bs);
-        const int rs = flags & 1, re = (flags >> 1) & 1;
-
-        __syncthreads();
-        {
-            const float *gm = reinterpret_cast<const float *>(a.models + model);
-            for (int i = threadIdx.x; i < MODEL_FLOATS; i += 2 * WAVE) lmodel[i] = gm[i];
-            if (threadIdx.x < 8) lmisc[threadIdx.x] = threadIdx.x == 1 || threadIdx.x == 3 ? E_DEAD : (threadIdx.x == 7 ? -(1 << 30) : 0);
-        }
-        __syncthreads();
-        rs_build_tables(ltab, reinterpret_cast<const DevModel *>(lmodel), threadIdx.x, 2 * WAVE);
-        StepEnv E;
-        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
-        E.ltab = reinterpret_cast<const char *>(ltab);
-        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
-        const DevModel *mdl = E.mdl;
-        const RowCtl<R> c0 = read_row_ctl<R>(ctl, 0);
-        const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
-        // where the frame stands on the last anti-diagonal: an X-step into every odd one, a Y-step into every even one, and the
-        // rebases of the schedule (the forward sweep arrives there by itself; the backward sweep starts there)
-        {
-            int sum = 0;
-            const uint32_t *gw1 = a.ctl + 2 * ctl_off;
-            for (int dd = 1 + static_cast<int>(threadIdx.x); dd <= D; dd += 2 * WAVE) {
-                const uint32_t w1 = gw1[2 * dd + 1];
-                sum += R == 2 ? static_cast<int>((w1 >> 28) & 3u) - 1 : static_cast<int>((w1 >> 26) & 3u) - 1;
-            }
-            if (sum) atomicAdd(&lmisc[4], sum);
-        }
-        __syncthreads();
-        {
-            Trans tr = load_trans(E.mdl->T);
-            if constexpr (R >= NPR_RS_T_SGPR_MIN_R) {
-                tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
-                tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
-                tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
-                tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
-            }
-            E.tr = tr;
-        }
-        const int rebs = uni(lmisc[4]);
-        const int xD = -j0 + (D + 1) / 2 + rebs, yD = j0 + D / 2 - rebs;
-
-        RsState<R> Q;
-        Q.A = zero_rdiag<R>(), Q.B = zero_rdiag<R>();
-        Q.e = 0;
-        if (wv == 0) {
-            // =============================== wavefront 0: forward, as k_dp_rs ===============================
-            Q.x0 = -j0, Q.y0 = j0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                Q.S.X.b[r] = base8<RS_XS>(E.X, lX, Q.x0 + jr[r] - 1);
-                Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r] - 1);
-            }
-            Q.S.xcap = RS_NX, Q.S.ycap = RS_N8;
-            feed8_init<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
-            feed8_init<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (jr[r] == j0) {
-                    RCell c;
-                    c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
-                    c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
-                    Q.A.c[r] = c;
-                }
-            if (lane == 0) fexp[0] = 0;
-            rs_store_row<R>(frs, Q.A, c0, voff);
-            int d = 1;
-            CtlPair wn = ctl_scalar2(ctl, 1);
-            {  // blocks of RS_K anti-diagonals, as in k_dp_rs
-                auto pair = [&](auto last) __attribute__((always_inline)) {
-                    const CtlPair w = wn;
-                    wn = ctl_scalar2(ctl, d + 2);
-                    {
-                        const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
-                        RS_FWD_REBASE(cur.reb);
-                        rs_fwd_x_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
-                        rs_store_row<R>(frs, Q.B, cur, voff);
-                    }
-                    const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
-                    RS_FWD_REBASE(cur.reb);
-                    rs_fwd_y_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
-                    if constexpr (decltype(last)::value) {
-                        Q.e += rs_renorm<R>(Q.A, Q.B);
-                        if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
-                    }
-                    rs_store_row<R>(frs, Q.A, cur, voff);
-                    d += 2;
-                };
-                while (d + RS_K - 1 <= D) {
-                    feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
-                    feed8_ahead<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
-#pragma nounroll
-                    for (int k = 0; k < RS_K / 2 - 1; ++k) pair(std::false_type{});
-                    pair(std::true_type{});
-                }
-                feed8_ahead<+1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 + 64 * R - 1, lane);
-                feed8_ahead<+1>(Q.S.fy, E.Y, lY, Q.y0, lane);
-#pragma nounroll
-                while (d + 1 <= D) pair(std::false_type{});
-            }
-            if (d <= D) {
-                const RowCtl<R> cur = row_ctl_of_words<R>(wn.a0, wn.a1);
-                RS_FWD_REBASE(cur.reb);
-                rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
-                rs_store_row<R>(frs, Q.B, cur, voff);
-            }
-            const int je = lX - Q.x0;
-            const bool oddD = D & 1;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (jr[r] == je) {
-                    const RCell c = oddD ? Q.B.c[r] : Q.A.c[r];
-                    const float raw = rs_dot5(mdl->end + re * 5, c);
-                    if (raw > 0.f) {
-                        int k;
-                        reinterpret_cast<float *>(lmisc)[0] = __builtin_frexpf(raw, &k);
-                        lmisc[1] = Q.e + k;
-                    }
-                }
-        } else {
-            // ============ wavefront 1: backward, as k_dp_rs's, its match rows and their exponents stored ============
-            // the rows 16 (k - 1) + 1 .. 16 k share the exponent bexp[k]: the one set when anti-diagonal 16 k was renormalised
-            Q.x0 = xD, Q.y0 = yD;
-            const bool oddD = D & 1;
-            RowCtl<R> cur = read_row_ctl<R>(ctl, D);
-            uint32_t m1 = cur.moved, m2 = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                Q.S.X.b[r] = base8<RS_XS>(E.X, lX, Q.x0 + jr[r]);
-                Q.S.Y.b[r] = base8(E.Y, lY, Q.y0 - jr[r]);
-                if (Q.x0 + jr[r] == lX) {
-                    RCell c;
-                    c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
-                    c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
-                    if (oddD) Q.B.c[r] = c; else Q.A.c[r] = c;
-                }
-            }
-            Q.S.xcap = RS_NX, Q.S.ycap = RS_N8;
-            feed8_init<-1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
-            feed8_init<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
-            if (lane == 0) bexp[(D + RS_K - 1) / RS_K] = 0;
-            rs_store_row<R>(brs, oddD ? Q.B : Q.A, cur, voff);
-            RowCtl<R> nxt = cur;
-            if (D >= 1) nxt = read_row_ctl<R>(ctl, D - 1);
-            int d2 = D - 1;
-            if (oddD) {  // peel one even anti-diagonal so that the loop below always starts on an odd one
-                const int reb = cur.reb;
-                cur = nxt;
-                if (d2 >= 1) nxt = read_row_ctl<R>(ctl, d2 - 1);
-                RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
-                m2 = m1, m1 = cur.moved;
-                if ((d2 & (RS_K - 1)) == 0) {
-                    Q.e += rs_renorm<R>(Q.A, Q.B);
-                    if (lane == 0) bexp[d2 / RS_K] = Q.e;
-                }
-                rs_store_row<R>(brs, Q.A, cur, voff);
-                d2 -= 1;
-            }
-            {  // blocks that end on a renormalising row, as in k_dp_rs (control words read down to row -3: kCtlFrontPad)
-                CtlPair wb = ctl_scalar2(ctl, d2 - 2);
-                auto pair = [&](auto last) __attribute__((always_inline)) {
-                    const CtlPair q = wb;
-                    wb = ctl_scalar2(ctl, d2 - 4);
-                    int reb = cur.reb;
-                    cur = nxt;
-                    nxt = row_ctl_of_words<R>(q.b0, q.b1);
-                    RS_BWD_REBASE(reb);
-                    rs_bwd_y_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
-                    m2 = m1, m1 = cur.moved;
-                    rs_store_row<R>(brs, Q.B, cur, voff);
-                    reb = cur.reb;
-                    cur = nxt;
-                    if (!decltype(last)::value || d2 >= 2) nxt = row_ctl_of_words<R>(q.a0, q.a1);
-                    RS_BWD_REBASE(reb);
-                    rs_bwd_x_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
-                    m2 = m1, m1 = cur.moved;
-                    if constexpr (decltype(last)::value) {
-                        Q.e += rs_renorm<R>(Q.A, Q.B);
-                        if (lane == 0) bexp[(d2 - 1) / RS_K] = Q.e;
-                    }
-                    rs_store_row<R>(brs, Q.A, cur, voff);
-                    d2 -= 2;
-                };
-                while (d2 >= 1) {
-                    feed8_ahead<-1, RS_XS>(Q.S.fx, E.X, lX, Q.x0 - 1, lane);
-                    feed8_ahead<-1>(Q.S.fy, E.Y, lY, Q.y0 - 64 * R, lane);
-                    const int n = (d2 & (RS_K - 1)) >> 1;
-#pragma nounroll
-                    for (int k = 0; k < n; ++k) pair(std::false_type{});
-                    pair(std::true_type{});
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (jr[r] == j0) {
-                    const RCell cz = Q.A.c[r];
-                    const float raw = rs_dot5(mdl->start + rs * 5, cz);
-                    if (raw > 0.f) {
-                        int k;
-                        reinterpret_cast<float *>(lmisc)[2] = __builtin_frexpf(raw, &k);
-                        lmisc[3] = Q.e + k;
-                    }
-                }
-        }
-        __builtin_amdgcn_s_waitcnt(0);  // the rows of both sweeps are on their way to memory before the barrier is passed
-        __threadfence_block();
-        __syncthreads();
-        __builtin_amdgcn_s_dcache_inv();  // the exponents come back through the scalar cache
-        const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
-        const int tot_e = uni(lmisc[1]);
-        TaskOut out;
-        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]), out.btot_e = uni(lmisc[3]);
-        out.npairs = 0, out.status = NPR_OK;
-        const bool alive = tot_m > 0.f;
-        if (!alive) out.status = NPR_ERR_ZERO_PROB, out.btot_m = 0.f, out.btot_e = E_DEAD;
-
-        // ================= both: the posteriors of half of the anti-diagonals each, rows streamed back =================
-        int smax = -(1 << 30);
-        if (alive) {
-            const float inv_tot = 1.0f / tot_m;
-            const PairSink sink{a.px + pair_off, a.py + pair_off, a.pp + pair_off, 0, pair_cap, xs, ys, a.threshold};  // (32-bit slots from here)
-            constexpr int G = R == 1 ? 8 : 4;
-            const int mid = D / 2;  // wavefront 0: d = 0 .. mid walking up from (0, 0); wavefront 1: d = D .. mid + 1 walking down
-            const int first = wv == 0 ? 0 : D, dir = wv == 0 ? 1 : -1, count = wv == 0 ? mid + 1 : D - mid;
-            int x0 = wv == 0 ? -j0 : xD, y0 = wv == 0 ? j0 : yD;  // the frame of anti-diagonal `first`
-            const uint2 *gw = reinterpret_cast<const uint2 *>(a.ctl + 2 * ctl_off);
-            RFRow<R> fr[G], br[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int r = 0; r < R; ++r) fr[g].v[r] = br[g].v[r] = 0.f;
-            // Pure streaming, arranged so that nothing waits row by row: the control words AND the exponent sum of 64
-            // anti-diagonals come with vector loads (a lane each) and are handed out by v_readlane, the row loads of G anti-diagonals
-            // are issued before the first of them is used, and the G rows claim their slots of the pair list with ONE LDS atomic.
-            // (With a scalar load of the exponents and an atomic per row this pass took as long as both sweeps together.)
-            for (int base = 0; base < count; base += WAVE) {
-                const int rows = min(WAVE, count - base);
-                // lane l decodes the control words of the l-th anti-diagonal of this block ONCE, in vector registers: first / one
-                // past the last lane of each slot's run, the row's byte offset, its rebase, its eF + eB - eTot.  (Decoded per row
-                // on the scalar unit, twice, the unpacked words of R = 1 / 4 cost ~80 scalar instructions per row: more than a DP step.)
-                int v_lo[R], v_hi[R], v_soff = 0, v_reb = 0, sv = -(1 << 30);
-#pragma unroll
-                for (int r = 0; r < R; ++r) v_lo[r] = v_hi[r] = 0;
-                if (lane < rows) {
-                    const int dl = first + dir * (base + lane);
-                    const uint2 w = gw[dl];
-                    sv = fexp[dl / RS_K] + bexp[(dl + RS_K - 1) / RS_K] - tot_e;
-                    smax = max(smax, sv);
-                    v_reb = ctl_rebase_of<R>(w.y);
-                    if constexpr (R == 2) {
-                        v_lo[0] = w.y & 127u, v_lo[1] = (w.y >> 7) & 127u;
-                        v_hi[0] = v_lo[0] + ((w.y >> 14) & 127u), v_hi[1] = v_lo[1] + ((w.y >> 21) & 127u);
-                        v_soff = static_cast<int>(w.x >> 1);
-                    } else {
-                        constexpr int SH = R == 1 ? 0 : 2;
-                        const int jlo = w.y & 8191u, n = (w.y >> 13) & 8191u;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) v_lo[r] = (jlo - r + R - 1) >> SH, v_hi[r] = (jlo + n - r + R - 1) >> SH;
-                        v_soff = static_cast<int>((((w.x - static_cast<uint32_t>(R * (jlo >> SH))) << 3) + row_bias<R>()) >> 1);
-                    }
-                }
-                for (int q = 0; q < rows; q += G) {
-                    uint64_t cellm[G][R];
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        uint64_t lanes = 0;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            cellm[g][r] = 0;
-                            if (q + g < rows) cellm[g][r] = low_lanes(__builtin_amdgcn_readlane(v_hi[r], q + g)) & ~low_lanes(__builtin_amdgcn_readlane(v_lo[r], q + g));
-                            lanes |= cellm[g][r];
-                        }
-                        if (q + g < rows && lanes_of(lanes)) {
-                            const int vo = voff + __builtin_amdgcn_readlane(v_soff, q + g);
-                            if constexpr (R == 1) {
-                                fr[g].v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(frs, vo, 0, 0));
-                                br[g].v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(brs, vo, 0, 0));
-                            } else if constexpr (R == 2) {
-                                const v2i qf = __builtin_amdgcn_raw_buffer_load_b64(frs, vo, 0, 0), qb = __builtin_amdgcn_raw_buffer_load_b64(brs, vo, 0, 0);
-                                fr[g].v[0] = bitsf(qf.x), fr[g].v[1] = bitsf(qf.y), br[g].v[0] = bitsf(qb.x), br[g].v[1] = bitsf(qb.y);
-                            } else {
-                                const v4i qf = __builtin_amdgcn_raw_buffer_load_b128(frs, vo, 0, 0), qb = __builtin_amdgcn_raw_buffer_load_b128(brs, vo, 0, 0);
-                                fr[g].v[0] = bitsf(qf.x), fr[g].v[1] = bitsf(qf.y), fr[g].v[2] = bitsf(qf.z), fr[g].v[3] = bitsf(qf.w);
-                                br[g].v[0] = bitsf(qb.x), br[g].v[1] = bitsf(qb.y), br[g].v[2] = bitsf(qb.z), br[g].v[3] = bitsf(qb.w);
-                            }
-                        }
-                    }
-                    float p[G][R];
-                    uint64_t hit[G][R];
-                    int total = 0;
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) p[g][r] = 0.f, hit[g][r] = 0;
-                        if (q + g < rows) {
-                            const int d = first + dir * (base + q + g);
-                            const int sx = __builtin_amdgcn_readlane(sv, q + g);
-#pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                p[g][r] = rs_posterior(fr[g].v[r], br[g].v[r], sx, inv_tot);
-                                hit[g][r] = d >= 2 ? (__ballot(p[g][r] >= sink.threshold) & cellm[g][r]) : 0;
-                                total += __popcll(hit[g][r]);
-                            }
-                        }
-                    }
-                    int slot0 = 0;
-                    if (total) {
-                        if (lane == 0) slot0 = atomicAdd(&lmisc[5], total);
-                        slot0 = uni(slot0);
-                    }
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        if (q + g < rows) {
-                            const int d = first + dir * (base + q + g);
-                            const int reb = __builtin_amdgcn_readlane(v_reb, q + g);
-                            if (wv == 0 && d > 0) {  // walking up: the rebase that leads into d, then its step
-                                x0 += reb, y0 -= reb;
-                                if (d & 1) x0 += 1; else y0 += 1;
-                            }
-#pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                if (hit[g][r]) {
-                                    const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[g][r] >> 32),
-                                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[g][r]), 0));
-                                    const int slot = slot0 + before;
-                                    if (lanes_of(hit[g][r]) && slot < sink.cap) {
-                                        const uint32_t u = static_cast<uint32_t>(slot) << 2;
-                                        rs_at<int32_t>(sink.px, u) = x0 + jr[r] - 1 + sink.xs;
-                                        rs_at<int32_t>(sink.py, u) = y0 - jr[r] - 1 + sink.ys;
-                                        rs_at<float>(sink.pp, u) = p[g][r];
-                                    }
-                                    slot0 += __popcll(hit[g][r]);
-                                }
-                            }
-                            if (wv != 0) {  // walking down: undo the step into d, then the rebase that led into it
-                                if (d & 1) x0 -= 1; else y0 -= 1;
-                                x0 -= reb, y0 += reb;
-                            }
-                        }
-                }
-            }
-            if (lane == 0) atomicMax(&lmisc[7], smax);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            out.npairs = lmisc[5];
-            if (out.npairs > pair_cap) out.status = NPR_ERR_CAPACITY;
-            if (!alive || lmisc[7] >= NPR_RS_S_LIMIT) out.status = TASK_RERUN;
-            a.outs[t] = out;
-            lmisc[6] = atomicAdd(a.queue, 1);
-        }
-        __syncthreads();
-        t = uni(lmisc[6]) + static_cast<int>(gridDim.x);
-    }
-}
-
 }  // namespace
 
 size_t rs_lds_bytes() { return 0; }  // static LDS only
 
 // sw: some loaded model has a short-gap switch (shortGapX <-> shortGapY); without one the two multiply-adds per cell and
 // direction that would add an exact zero are not issued (same bits: npr_rs.h)
-template <int R>
-static int launch_pair_rs_r(const KernelArgs &a, bool sw, int grid, hipStream_t s) {
-    if (sw) hipLaunchKernelGGL((k_dp_pair_rs<R, true>), dim3(grid), dim3(2 * WAVE), 0, s, a);
-    else hipLaunchKernelGGL((k_dp_pair_rs<R, false>), dim3(grid), dim3(2 * WAVE), 0, s, a);
-    return static_cast<int>(hipGetLastError());
-}
-int launch_pair_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (R == 1) return launch_pair_rs_r<1>(a, sw, grid, s);
-    if (R == 2) return launch_pair_rs_r<2>(a, sw, grid, s);
-    if (R == 4) return launch_pair_rs_r<4>(a, sw, grid, s);
-    return static_cast<int>(hipErrorInvalidValue);
-}
-
 template <int R>
 static int launch_rs_r(const KernelArgs &a, bool sw, int grid, hipStream_t s) {
     if (sw) hipLaunchKernelGGL((k_dp_rs<R, true>), dim3(grid), dim3(WAVE), 0, s, a);

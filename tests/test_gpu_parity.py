@@ -150,7 +150,7 @@ def test_row_scaled_forward_rows_against_the_fp64_oracle(gpu_ctx, L, W, indel):
     seg = orc.plan(len(X), len(Y), ops, orc.make_params(**kw))[0]
     b = gpu_ctx.stage(R.make_params(**kw), [bytes(b"ACGT"[c] for c in X)], [bytes(b"ACGT"[c] for c in Y)], [ops])
     tasks, _ = b.class_stats()
-    assert tasks[15:18].sum() == 1                       # a k_dp_rs class took it
+    assert tasks[15:18].sum() + tasks[12:15].sum() == 1  # a row-scaled class took it (k_dp_rs, or its sweeps on two wavefronts: the same rows)
     b.run()
     assert b.segment_arith()[1][0] == 1                  # ... and kept its range certificate
     fv, fe = b.rs_forward(0, seg["cells"])
@@ -403,23 +403,40 @@ def test_row_scaled_sweeps_in_blocks_of_sixteen_anti_diagonals(gpu_ctx):
     _run_case(gpu_ctx, rng, 3, 1500, 3000, dict(band_mode=1, fixed_width=400), indel=0.25, max_indel=60)
 
 
-def test_pair_kernel_in_row_scaled_arithmetic(gpu_ctx, monkeypatch):
-    """k_dp_pair_rs (a read's two sweeps on two wavefronts at once, the posteriors from the stored rows of both): what a class of
-    257+ tasks that fills at most half of the chip runs by default (BASELINE.json configs[1]); NPR_OPT_PAIR = 3 sends every
-    one-wavefront task there.  Same bits as the mirror of k_dp_rs, over the three frame classes, bands that drift (rebases), an
-    odd and an even number of anti-diagonals, single-base reads."""
-    gpu_ctx.set_option(_lib.OPTIONS["pair"], 3)
+def test_sweeps_that_meet_in_the_middle(gpu_ctx, monkeypatch):
+    """k_dp_mid_rs (a read's forward and backward sweeps on two wavefronts that start at the two ends, meet in the middle and go on
+    against each other's stored rows; the second halves emit candidates that one pass rescales by the forward sweep's own total):
+    what every one-wavefront task of 64+ anti-diagonals runs by default.  Same bits as the mirror of k_dp_rs -- and as k_dp_rs itself
+    (NPR_OPT_PAIR = 1), pair list for pair list once both are sorted -- over the three frame classes, bands that drift (rebases,
+    also across the cut), odd and even numbers of anti-diagonals, every remainder of D modulo 32 (where the cut and the last block
+    fall), reads around the 64-anti-diagonal limit below which a task stays with k_dp_rs, single-base reads."""
     from nanopore_amd import realign as R
     rng = np.random.default_rng(61)
     out = _run_case(gpu_ctx, rng, 24, 1, 400, dict(band_mode=1, fixed_width=40))
+    out += _run_case(gpu_ctx, rng, 40, 28, 52, dict(band_mode=1, fixed_width=40))     # D = 56 .. 104: either side of the limit, every D mod 32
     out += _run_case(gpu_ctx, rng, 8, 300, 1500, dict(band_mode=1, fixed_width=200), indel=0.2, max_indel=40)
     out += _run_case(gpu_ctx, rng, 4, 400, 900, dict(band_mode=1, fixed_width=400), indel=0.2, max_indel=30)
     # a read of a handful of bases can miss its range certificate (its start rows) and run again per cell: _run_case compared it
     # with the per-cell mirror then
     assert sum(o["seg_arith"] == [1] for o in out) >= len(out) - 2 and all(len(o["seg_arith"]) == 1 for o in out)
-    cases = [random_pair(rng, 300) for _ in range(5)]
-    b = gpu_ctx.stage(R.make_params(band_mode=1, fixed_width=40), [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases],
-                      [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases], [g for _, _, g in cases])
+    cases = [random_pair(rng, int(L)) for L in (300, 300, 300, 300, 300, 20, 31, 33)]
+    refs, reads, guides = ([bytes(b"ACGT"[c] for c in X) for X, _, _ in cases], [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases], [g for _, _, g in cases])
+    P = R.make_params(band_mode=1, fixed_width=40)
+    b = gpu_ctx.stage(P, refs, reads, guides)
     tasks, _ = b.class_stats()
     b.close()
-    assert tasks[12] == 5 and tasks[15] == 0, tasks
+    short = sum(len(X) + len(Y) < 64 for X, Y, _ in cases)
+    assert tasks[12] == len(cases) - short and tasks[15] == short and short >= 2, tasks
+    # against k_dp_rs on the device: the same pairs, bit for bit, whatever order the two wavefronts left them in
+    mid = gpu_ctx.realign(P, refs, reads, guides, want_pairs=True)
+    gpu_ctx.set_option(_lib.OPTIONS["pair"], 1)
+    b = gpu_ctx.stage(P, refs, reads, guides)
+    tasks, _ = b.class_stats()
+    b.close()
+    assert tasks[12] == 0 and tasks[15] == len(cases)
+    one = gpu_ctx.realign(P, refs, reads, guides, want_pairs=True)
+    for u, v in zip(mid, one):
+        ku, kv = np.lexsort((u["y"], u["x"])), np.lexsort((v["y"], v["x"]))
+        assert np.array_equal(u["x"][ku], v["x"][kv]) and np.array_equal(u["y"][ku], v["y"][kv])
+        assert np.array_equal(u["p"][ku].view(np.uint32), v["p"][kv].view(np.uint32))
+        assert u["ops"] == v["ops"] and u["loglik"] == v["loglik"] and u["loglik_bwd"] == v["loglik_bwd"] and u["score"] == v["score"]

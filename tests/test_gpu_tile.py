@@ -123,7 +123,7 @@ def test_repeated_launches_on_poisoned_scratch_give_identical_pairs(gpu_ctx, mon
               R.make_params(band_mode=R.BAND_FIXED, fixed_width=100), 60),
              (synth.make_workload(1009, 96, 2000, T, E, flank=0, length_sigma=0.4, len_min=200, len_max=5000),
               R.make_params(band_mode=R.BAND_FIXED, fixed_width=300), 60),
-             # band 200: the north-star class (k_dp_rs<2>, packed control words), next to a few narrow and wide stragglers
+             # band 200: the north-star class (k_dp_mid_rs<2>, packed control words), next to a few narrow and wide stragglers
              (synth.make_workload(1010, 192, 2500, T, E, flank=0, length_sigma=0.6, len_min=100, len_max=8000),
               R.make_params(band_mode=R.BAND_FIXED, fixed_width=200), 80),
              # ... and the same class launched side by side with others: anchors +- 60 with 3 trimmed columns give bands of
@@ -149,5 +149,5 @@ def test_repeated_launches_on_poisoned_scratch_give_identical_pairs(gpu_ctx, mon
                 assert np.array_equal(out[0][key], first[0][key]), (rep, key)
             assert all(np.array_equal(a, c) for a, c in zip(out[1], first[1])), rep
             assert all(np.array_equal(a, c) for a, c in zip(out[2], first[2])), rep
-    # the north-star class (16: k_dp_rs<2>, the row-scaled kernel of class 1's frame) ran alone and next to other classes
-    assert (16,) in seen_classes and any(16 in c and len(c) > 1 for c in seen_classes), seen_classes
+    # the north-star class (13: class 1's frame in row-scaled arithmetic on two wavefronts, k_dp_mid_rs<2>) ran alone and next to other classes
+    assert (13,) in seen_classes and any(13 in c and len(c) > 1 for c in seen_classes), seen_classes
