@@ -60,9 +60,9 @@ NOMINAL_CYCLES_PER_VALU = 2.0  # one wave64 VALU instruction per 2 cycles per SI
 # kernel class (npr_batch_class_stats) -> kernel name in profiles/kernel_table.json
 CLASS_KERNEL = {0: "k_dp_stair<1>", 1: "k_dp_stair<2>", 2: "k_dp_stair<4>", 3: "k_dp_wide", 4: "k_dp_wide", 5: "k_dp_wide",
                 6: "k_dp_wide", 7: "k_dp_generic", 8: "k_dp_generic", 9: "k_dp_generic", 10: "k_dp_generic", 11: "k_dp_tile<2>",
-                12: "k_dp_pair_rs<1>", 13: "k_dp_pair_rs<2>", 14: "k_dp_pair_rs<4>", 15: "k_dp_rs<1>", 16: "k_dp_rs<2>", 17: "k_dp_rs<4>", 18: "k_dp_tile_rs"}
-RS_BYTES_PER_CELL = 8.0     # k_dp_rs (row-scaled arithmetic: the exponent is per row, not per cell): 4 B stored + 4 B reloaded
-PAIR_BYTES_PER_CELL = 16.0  # k_dp_pair_rs: the match rows of BOTH sweeps stored (2 x 4 B) and streamed back (2 x 4 B)
+                12: "k_dp_mid_rs<1>", 13: "k_dp_mid_rs<2>", 14: "k_dp_mid_rs<4>", 15: "k_dp_rs<1>", 16: "k_dp_rs<2>", 17: "k_dp_rs<4>", 18: "k_dp_tile_rs"}
+RS_BYTES_PER_CELL = 8.0     # k_dp_rs / k_dp_mid_rs (row-scaled arithmetic: the exponent is per row, not per cell): 4 B stored + 4 B reloaded
+                            # (k_dp_mid_rs: the forward sweep stores the rows up to the cut and the backward sweep the rows above it: the same bytes)
 EM_CLASS_KERNEL = {0: "k_em_stair<1>", 1: "k_em_stair<2>", 2: "k_em_stair<4>", 11: "k_em_tile<2>"}
 
 
@@ -192,16 +192,18 @@ def roofline_block(cells, pairs, kms, class_cells, clock_hz):
     kname = CLASS_KERNEL.get(dom, "k_dp")
     tab = kernel_table().get(kname, {})
     t = kms * 1e-3
-    per_cell = PAIR_BYTES_PER_CELL if kname.startswith("k_dp_pair") else (RS_BYTES_PER_CELL if kname.startswith("k_dp_rs") or kname == "k_dp_tile_rs" else BYTES_PER_CELL)
+    rs_kernel = kname.startswith("k_dp_rs") or kname.startswith("k_dp_mid_rs") or kname == "k_dp_tile_rs"
+    per_cell = RS_BYTES_PER_CELL if rs_kernel else BYTES_PER_CELL
     achieved = (per_cell * cells + BYTES_PER_PAIR * pairs) / t / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": None, "kernel": kname, "kernel_ms": kms,
            "kernel_share_of_cells": float(class_cells[dom]) / max(float(np.sum(class_cells)), 1.0) if len(class_cells) else 1.0,
-           "algorithmic_bytes": ("%g B/cell (match state: %g B stored by the forward sweep + %g B reloaded by the backward sweep%s) + "
+           "algorithmic_bytes": ("%g B/cell (match state: %g B stored by one sweep + %g B reloaded by the other%s%s) + "
                                  "%g B/posterior pair (%d pairs); DESIGN.md section 4"
-                                 % (per_cell, (4.0 if kname.startswith("k_dp_pair") else per_cell / 2), (4.0 if kname.startswith("k_dp_pair") else per_cell / 2),
-                                    "; k_dp_pair_rs runs the sweeps side by side on two wavefronts and stores / reloads the backward rows too" if kname.startswith("k_dp_pair") else
-                                    ("; k_dp_rs keeps one exponent per anti-diagonal row instead of one per cell: half of round 2's 16 B/cell, so the same "
+                                 % (per_cell, per_cell / 2, per_cell / 2,
+                                    "; k_dp_mid_rs runs a read's sweeps on two wavefronts that meet in the middle: the forward one stores the rows up to the cut, "
+                                    "the backward one the rows above it, each reloads the other's -- the bytes of k_dp_rs" if kname.startswith("k_dp_mid") else "",
+                                    ("; one exponent per anti-diagonal row instead of one per cell: half of round 2's 16 B/cell, so the same "
                                      "cells/s is half the HBM fraction -- see round2_16B_equiv" if per_cell < BYTES_PER_CELL else ""),
                                     BYTES_PER_PAIR, pairs)),
            "binding": "vector and scalar issue, not HBM (see valu)",

@@ -1093,6 +1093,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         int waves_per_cu;
         if (kClassTab[c].kind == K_PAIR) {  // workgroups of two wavefronts
             waves_per_cu = (b->pair_rs ? mid_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R)) / 2;
+            if (ctx->overlap == 1 && kClassTab[c].R <= 2) waves_per_cu -= 2;  // (a wavefront slot per SIMD left free: see the one-wavefront classes below)
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 128;
