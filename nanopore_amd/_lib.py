@@ -10,6 +10,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue runs its kernels in
+# submission order.  The files -> file job (job.py) keeps three batches in flight, each with its own streams: with four queues the MEA
+# stage of one chunk and the DP pass of the next regularly share one (403 against 393 ms per 50 000 reads).  The
+# runtime reads the variable when it starts, i.e. at the process's first HIP call -- so it is set here, when the binding is imported,
+# unless the host application has chosen a value itself.  (Too late if the process has already used the GPU; harmless then.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = os.environ.get("NPR_LIB") or os.path.join(_HERE, "libnprealign.so")  # NPR_LIB: a variant build (bring-up, tools/variant_bench.py)
 
 OK = 0

@@ -362,7 +362,7 @@ def stageSamFile(samFile, referenceFastaFile, splitThreshold, gapGamma=0.5, matc
 def stageSamFileForTraining(samFile, readFastqFile, referenceFastaFile, options, ctx=None):
     """The trainer's view of a chained SAM file, without a Python object per record: the file is mapped and parsed by the native
     scanners (nanopore_amd/ingest.py), the global-alignment shape the trainer relies on is asserted on the parsed fields of EVERY
-    record (utils.py:492-501; the sequences themselves are compared for a sample of records), the alignments are sampled
+    record, sequences included (utils.py:492-501), the alignments are sampled
     and cut into batches as options.maxAlignmentLengthToSample / maxAlignmentLengthPerJob say (em.sampleAlignments) and each batch
     is staged once, in NPR_MODE_EXPECTATIONS, for all iterations of all trials.  Returns an em.BatchSet (alignments, taken)."""
     from .. import em, ingest, job, realign
@@ -386,12 +386,19 @@ def stageSamFileForTraining(samFile, readFastqFile, referenceFastaFile, options,
     assert (fields[:, F.F_QUERY_LO] == fields[:, F.F_SEQ_LO]).all()                            # aR.qstart == 0
     assert (fields[:, F.F_QUERY_HI] - fields[:, F.F_QUERY_LO] == read_len).all()               # aR.qend == len(read)
     assert (fields[:, F.F_REF_SPAN] == ref_len[fields[:, F.F_TID]]).all()                      # aR.aend == len(reference)
-    rng = np.random.default_rng(0 if options.seed is None else options.seed)
-    for i in rng.choice(n, size=min(n, 64), replace=False):                                  # aR.query == the read / its reverse complement
-        q = sam.field_bytes(int(fields[i, F.F_QUERY_LO]), int(fields[i, F.F_QUERY_HI])).decode().upper()
+    # aR.query == the read / its reverse complement, for EVERY record as the reference asserts it (utils.py:496-501): byte tables for
+    # the case fold and the complement, one vector compare per record on the mapped texts (no strings made)
+    up = np.arange(256, dtype=np.uint8)
+    up[ord("a"):ord("z") + 1] -= 32
+    rc = up.copy()
+    for x, y in zip(b"ACGTN", b"TGCAN"):
+        rc[x] = rc[x + 32] = y
+    sam_text, fq_text = np.asarray(sam.text), np.asarray(qtext)
+    for i in range(n):
         a, b = qspan[qat[names[i]]]
-        read = bytes(qtext[a:b]).decode().upper()
-        assert q == (reverseComplement(read) if fields[i, F.F_FLAG] & 0x10 else read)
+        q = up[sam_text[fields[i, F.F_QUERY_LO]:fields[i, F.F_QUERY_HI]]]
+        read = rc[fq_text[a:b]][::-1] if fields[i, F.F_FLAG] & 0x10 else up[fq_text[a:b]]
+        assert np.array_equal(q, read), "record %d (%s): SEQ is neither the read nor its reverse complement" % (i, names[i])
     src = job.SamSource(sam, fasta, span, fields)
     cols = np.zeros(n, dtype=np.int64)                                                       # alignment columns of every record
     np.add.at(cols, np.repeat(np.arange(n), src.guide_off[1:] - src.guide_off[:-1]), src.guide_ops[:, 1])

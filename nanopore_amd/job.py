@@ -223,8 +223,17 @@ def close_contexts():
 # 5-25 ms during which no phase of the pipeline can pick up its next chunk (round 4).  At most _HOST_POOL_MAX buffers are kept;
 # close_contexts() drops them.
 _HOST_POOL_MAX = 8
+_HOST_POOL_BYTES = int(os.environ.get("NPR_JOB_HOST_POOL_MB", 1536)) << 20  # kept between chunks; run_source trims to a quarter when a job ends
 _host_pool = []
 _host_lock = threading.Lock()
+
+
+def _trim_host_pool(limit):
+    """Drops the largest buffers of the pool until what is kept fits `limit` bytes."""
+    with _host_lock:
+        _host_pool.sort(key=lambda b: b.nbytes)
+        while _host_pool and sum(b.nbytes for b in _host_pool) > limit:
+            _host_pool.pop()
 
 
 def _take(nbytes):
@@ -246,8 +255,32 @@ def _give(buf):
     if not isinstance(buf, np.ndarray) or buf.dtype != np.uint8 or buf.nbytes % 4096:
         return
     with _host_lock:
-        if len(_host_pool) < _HOST_POOL_MAX and not any(b is buf for b in _host_pool):
+        if (len(_host_pool) < _HOST_POOL_MAX and not any(b is buf for b in _host_pool)
+                and sum(b.nbytes for b in _host_pool) + buf.nbytes <= _HOST_POOL_BYTES):
             _host_pool.append(buf)
+
+
+_gc_lock = threading.Lock()
+_gc_jobs = [0, False]  # pipelines that hold the collector off; whether it was on when the first of them came
+
+
+def _gc_hold():
+    """The cyclic collector off for the duration of a pipeline; counted, so that jobs running side by side in one process switch it back
+    on once, when the last of them ends, and only if it was on."""
+    with _gc_lock:
+        if _gc_jobs[0] == 0:
+            _gc_jobs[1] = gc.isenabled()
+            if _gc_jobs[1]:
+                gc.disable()
+        _gc_jobs[0] += 1
+    return True
+
+
+def _gc_release():
+    with _gc_lock:
+        _gc_jobs[0] -= 1
+        if _gc_jobs[0] == 0 and _gc_jobs[1]:
+            gc.enable()
 
 
 def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
@@ -265,6 +298,9 @@ def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
     # take when they fill the chip), so a chunk below ~12 k reads buys its overlap with DP time: 12 500 reads as three chunks ran
     # 3 x 40 ms of DP launches where one launch takes 59 (round 4).  Fewer, fuller chunks; one when the range is small.
     k = max(1, min(k, n // min_reads))
+    # ... but never more than four times the bases asked for: MIN_CHUNK_READS reads of 50-100 kb would be six to twelve chunks' worth, three
+    # of them in flight -- such a job would live in the halve-and-stage-again path that is meant for the exception
+    k = max(k, int(total // (4 * chunk_bases)))
     k = min(k, n)
     cuts = lo + npd.shard_ranges(lengths[lo:hi], k)
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
@@ -339,7 +375,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     # that wait: 414 -> 403 ms per 50 000 reads, 393 with GPU_MAX_HW_QUEUES=8).  Value 1 also leaves a wavefront slot per SIMD free
     # beside a DP pass: measured twice, it gives the DP pass 5 % more time and the other kernels nothing they do not get anyway
     # (DESIGN.md section 6b).  NPR_JOB_OVERLAP=0 / 1 / 2 picks one for an A/B run.
-    overlap = int(os.environ.get("NPR_JOB_OVERLAP", "2")) if (len(ctxs) > 1 and len(pending) > 1) else 0
+    overlap = int(os.environ.get("NPR_JOB_OVERLAP") or "2") if (len(ctxs) > 1 and len(pending) > 1) else 0  # (set but empty: the default)
     for c in ctxs:
         c.set_option(_lib.OPT_OVERLAP, overlap)
     n_planned = len(pending)
@@ -367,6 +403,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                     if item is END:
                         break
                     item[3].close()
+                    if item[5] is not None:
+                        item[5].set()
                     if item[4]:
                         free[item[0]].release()
             finally:
@@ -399,7 +437,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 pending.extend([(mid, b_), (a, mid)])
                 continue
             note("stage", t0, time.perf_counter())
-            q_run.put((j, a, b_, batch, True))  # (the last field: the chunk's end gives the context back)
+            q_run.put((j, a, b_, batch, True, None))  # (last: the chunk's end gives the context back; gate: set when the batch is closed)
             k += 1
 
     def runner():
@@ -407,7 +445,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             item = q_run.get()
             if item is END:
                 return
-            j, a, b_, batch, last = item
+            j, a, b_, batch, last, gate = item
             if stop.is_set():
                 batch.close(), free[j].release()
                 continue
@@ -420,7 +458,9 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                     free[j].release()
                     raise
                 # the device was full at launch (a kernel's private segment, the scratch regrown): the chunk's halves one after
-                # the other in the same context, as the stager does for a chunk that does not fit at staging
+                # the other in the same context, as the stager does for a chunk that does not fit at staging.  ONE AFTER THE OTHER all the
+                # way: calls on one context must be serialised (include/nprealign.h), and the finisher and the fetcher work on the first
+                # half's batch from their own threads -- the second half is staged when the fetcher has closed the first (its gate).
                 try:
                     mid = (a + b_) // 2
                     for x, y, fin in ((a, mid, False), (mid, b_, True)):
@@ -430,7 +470,11 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                         except BaseException:
                             half.close()
                             raise
-                        q_fin.put((j, x, y, half, fin))
+                        gate = None if fin else threading.Event()
+                        q_fin.put((j, x, y, half, fin, gate))
+                        while gate is not None and not gate.wait(0.2):
+                            if stop.is_set():  # a later phase failed (it closes what it was handed): nothing more is staged here
+                                raise RuntimeError("pipeline stopped while a chunk's first half was in flight")
                 except BaseException:
                     free[j].release()
                     raise
@@ -447,9 +491,11 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             item = q_fin.get()
             if item is END:
                 return
-            j, a, b_, batch, last = item
+            j, a, b_, batch, last, gate = item
             if stop.is_set():
                 batch.close()
+                if gate is not None:
+                    gate.set()
                 if last:
                     free[j].release()
                 continue
@@ -458,6 +504,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 batch.finish()
             except BaseException:
                 batch.close()
+                if gate is not None:
+                    gate.set()
                 if last:
                     free[j].release()
                 raise
@@ -471,7 +519,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
             if item is END:
                 _give(words_buf[0])
                 return
-            j, a, b_, batch, last = item
+            j, a, b_, batch, last, gate = item
             t0 = time.perf_counter()
             open_batch = [batch]
             try:  # the context goes back exactly once, whatever happens in between
@@ -502,6 +550,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                     if TRACE:
                         tm["trace"].append(("close", tc, time.perf_counter()))
             finally:
+                if gate is not None:
+                    gate.set()  # (the runner may stage the chunk's second half on this context now)
                 if last:
                     free[j].release()
 
@@ -511,9 +561,7 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     # imported) with the interpreter lock held, tens of ms during which no phase can take its next chunk over.  (The 10-25 ms gaps
     # in round 4's traces turned out to be something else -- munmaps of the chunks' buffers under the same lock, see _take -- and
     # the job times the same with the collector on, NPR_JOB_GC=1; it is kept out because the pipeline makes no cycles worth collecting.)
-    gc_was_on = gc.isenabled() and os.environ.get("NPR_JOB_GC") is None
-    if gc_was_on:
-        gc.disable()
+    gc_held = os.environ.get("NPR_JOB_GC") is None and _gc_hold()
     for t in threads:
         t.start()
     parts, sink_s, error = [], 0.0, None
@@ -546,8 +594,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                 pass
         for t in threads:
             t.join()
-        if gc_was_on:
-            gc.enable()
+        if gc_held:
+            _gc_release()
     if error is not None:
         raise error
     n = hi - lo
@@ -693,6 +741,7 @@ def run_source(src, params, bounds, out_path, ctxs=None, gpu=None, group=None, w
         dist.barrier(group=group)  # every rank's block is on disk when rank 0 returns
     tm["gather_s"] = time.perf_counter() - t0
     tm["wall_s"] = time.perf_counter() - t_begin
+    _trim_host_pool(_HOST_POOL_BYTES // 4)  # a long-lived host application does not keep a job's gigabyte of chunk buffers
     if TRACE:
         tm["trace"] += [("source", t_begin, t_begin), ("gather", t0, time.perf_counter())]
     if rank == 0:
