@@ -1,5 +1,5 @@
-"""Multi-GPU path on CPU: world_size 2 over gloo.  Reads shard with no data-path collective; one
-variable-length gather brings packed results to rank 0 where the input order is restored."""
+"""Multi-GPU path on CPU: world_size 2 -- and 8, the node BASELINE.json configs[3] names -- over gloo.  Reads shard with no data-path
+collective; one variable-length gather brings packed results to rank 0 where the input order is restored."""
 import os
 import socket
 
@@ -180,3 +180,67 @@ def test_two_rank_gather_restores_input_order():
     assert st == status.tolist() and sc == score.tolist()
     for i in range(n_total):
         assert ol[i] == ops[off[i]:off[i + 1]].tolist()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_gather_restores_input_order():
+    """The same with the eight payloads of one node (BASELINE.json configs[3]): dist.shard_indices / gather_to_root / merge_in_input_order."""
+    n_total = 203
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, n_total, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    st, sc, ol = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    status, score, off, ops = _fake_results(np.arange(n_total))
+    assert st == status.tolist() and sc == score.tolist()
+    assert all(ol[i] == ops[off[i]:off[i + 1]].tolist() for i in range(n_total))
+
+
+def _job_worker(rank, world, port, path, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["NPR_HOST_THREADS"] = str(max(1, 16 // world))  # what bench.py gives a rank of eight on a 16-core grant
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nanopore_amd import job, realign
+    from test_pipeline_mock import FakeCtx, FakeSrc
+    src = FakeSrc(n)
+    src.header = b"@HD\tVN:1.0\n@SQ\tSN:ref\tLN:1000\n"
+    work = np.random.default_rng(5).integers(200, 2000, size=n)      # every rank computes the same ranges from the same lengths
+    bounds = npd.shard_ranges(work, world)
+    out = job.run_source(src, realign.make_params(), bounds, path, ctxs=[FakeCtx() for _ in range(3)], gpu=0, chunk_bases=50000, coll_device="cpu")
+    assert src.closed == len(src.staged) and out["timings"]["chunks"] >= 1
+    if rank == 0:
+        q.put((out["results"]["score"].tolist(), out["n_ops"].tolist(), bounds.tolist()))
+    else:
+        assert "results" not in out
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_ranks_write_one_file_at_gathered_offsets(tmp_path):
+    """job.run_source over eight ranks (stand-in batches, no GPU): every rank runs its contiguous range through the pipeline, the
+    all_gather of the block sizes gives each its offset in the ONE output file, it writes its block there, and the per-read results
+    arrive on rank 0 in input order -- the collectives of BASELINE.json configs[3] (nanopore/analyses/utils.py:591-609 gathers the
+    per-read cigar files serially instead) with the world size of the node."""
+    n, path = 4000, str(tmp_path / "out.bin")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, 8, port, path, n, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    score, nops, bounds = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(bounds) == 9 and bounds[0] == 0 and bounds[-1] == n and all(b > a for a, b in zip(bounds[:-1], bounds[1:]))
+    assert score == list(range(n)) and nops == [1] * n
+    data = open(path, "rb").read()
+    header = b"@HD\tVN:1.0\n@SQ\tSN:ref\tLN:1000\n"
+    assert data[:len(header)] == header
+    assert np.frombuffer(data[len(header):], dtype=np.int64).tolist() == list(range(n))  # every rank's block where it belongs

@@ -135,24 +135,26 @@ def test_job_and_em_collectives_run_on_device_tensors_under_nccl(gpu_ctx, tmp_pa
     gpu_ctx.set_hmm(Hmm.loadHmm(HMM0))
 
 
-@pytest.mark.timeout(1200)
-def test_plain_bench_command_line_starts_its_own_ranks(gpu_ctx, tmp_path):
-    """`python bench.py --gpus 2 ...` without a launcher (the driver's form): two ranks are spawned, share cuda:0 through the
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("ranks,reads", [(2, 1024), (8, 512)], ids=["two_ranks", "eight_ranks"])
+def test_plain_bench_command_line_starts_its_own_ranks(gpu_ctx, tmp_path, ranks, reads):
+    """`python bench.py --gpus N ...` without a launcher (the driver's form): N ranks are spawned, share cuda:0 through the
     test hook (gloo collectives), rank 0 prints ONE JSON line with the weak-scaling headline and the strong-scaling job beside
-    it, and the exit code is 0."""
+    it, and the exit code is 0.  N = 8: the rehearsal of the node BASELINE.json configs[3] names -- eight processes map one SAM,
+    each with 16 // 8 host threads, eight offsets are gathered, eight blocks land in one file."""
     from nanopore_amd import job
     _release_device_memory(gpu_ctx)
-    env = dict(os.environ, NPR_BENCH_SHARE_GPU="1", NPR_BENCH_ALSO_READS="1024", TMPDIR=str(tmp_path))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env = dict(os.environ, NPR_BENCH_SHARE_GPU="1", NPR_BENCH_ALSO_READS=str(max(1024, 8 * ranks)), TMPDIR=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NPR_HOST_THREADS"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "1024"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1100)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--reads", str(reads)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1400)
     err = p.stderr.decode()
     assert p.returncode == 0, "\n".join([l for l in err.split("\n") if "[rank0]" in l][-25:]) + err[-1500:]
     lines = [l for l in p.stdout.decode().split("\n") if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["ok_reads"] == 1024 and out["value"] > 0
+    assert out["n_gpus"] == ranks and out["scaling"] == "weak" and out["ok_reads"] == reads and out["value"] > 0
     also = [a for a in out["also"] if a.get("scaling") == "strong"]
-    assert len(also) == 1 and also[0]["n_gpus"] == 2 and also[0]["ok_reads"] == 1024
+    assert len(also) == 1 and also[0]["n_gpus"] == ranks and also[0]["ok_reads"] == max(1024, 8 * ranks)
     assert also[0]["speedup_vs_n1"] > 0 and also[0]["n1_ms_per_step"] > 0
