@@ -96,14 +96,34 @@ def build_workload(name, n_reads, rank):
         w, W = synth.make_workload(1004 + 7919 * rank, n_reads, 8000, h.transitions, h.emissions), 0
         label = ("synthetic ~8kb reads, the reference's own band: anchors +- diagonalExpansion 10, 14 trimmed columns, "
                  "splitMatrixBiggerThanThis 3000 (nanopore/analyses/utils.py:587), blasr_hmm_0")
+    elif name == "rescore":
+        # (jitter 0: the guide is the alignment being scored, as the analysis scores the mapper's or the realigner's own; with the indels slid by
+        # +- 20 columns a guide can leave the band of +- 10 around its own anchors)
+        w, W = synth.make_workload(1006 + 7919 * rank, n_reads, 8000, h.transitions, h.emissions, jitter=0), -1
+        label = ("synthetic ~8kb reads, NPR_MODE_RESCORE_ORIGINAL with the analyses' call parameters: --rescoreOriginalAlignment "
+                 "--diagonalExpansion=10 --splitMatrixBiggerThanThis=100, blasr_hmm_0 (nanopore/analyses/alignmentUncertainty.py:41: the analysis "
+                 "every experiment runs by default, pipeline.py:81); score = mean posterior over the guide's M columns")
     else:
         raise SystemExit("unknown workload %s" % name)
     return h, w, W, label
 
 
+def param_kwargs(W, mod):
+    """npr_params of a workload as keyword arguments, for the library (mod = nanopore_amd.realign) and for the oracle (mod = oracle.oracle).
+    W > 0: fixed band; 0: the reference's own realign call (anchors +- 10, trim 14, split 3000; utils.py:587); -1: the analyses' rescore call."""
+    if W > 0:
+        return dict(band_mode=mod.BAND_FIXED, fixed_width=W)
+    if W == 0:
+        return dict(band_mode=mod.BAND_ANCHOR)
+    return dict(band_mode=mod.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=100, mode=mod.MODE_RESCORE_ORIGINAL)
+
+
 def make_params(W):
     from nanopore_amd import realign as R
-    return R.make_params(band_mode=R.BAND_FIXED, fixed_width=W) if W > 0 else R.make_params(band_mode=R.BAND_ANCHOR, max_pairs_per_base=24)
+    kw = param_kwargs(W, R)
+    if W <= 0:
+        kw["max_pairs_per_base"] = 24  # (the anchor bands' wide rectangles hold more pairs per base than the default list has room for)
+    return R.make_params(**kw)
 
 
 def usable_cpus():
@@ -141,8 +161,8 @@ def cpu_baseline(h, w, W, cells_per_read, budget_s=9.0):
     from nanopore_amd.realign import encode
     cores = usable_cpus()
     oh = orc.make_hmm(h.transitions, h.emissions)
-    # W = 0: the reference's own call parameters (anchors +- 10, trim 14, splitMatrixBiggerThanThis 3000; utils.py:587)
-    P = orc.make_params(band_mode=orc.BAND_FIXED, fixed_width=W) if W > 0 else orc.make_params(band_mode=orc.BAND_ANCHOR)
+    # W = 0: the reference's own call parameters (anchors +- 10, trim 14, splitMatrixBiggerThanThis 3000; utils.py:587); -1: the analyses' rescore call
+    P = orc.make_params(**param_kwargs(W, orc))
 
     def run(k, threads):
         if w.get("guide_start") is not None:
@@ -323,7 +343,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3", "anchor", "em"])
+    ap.add_argument("--workload", default="northstar", choices=["northstar", "c2", "c3", "anchor", "em", "rescore"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (resident workloads; default 24576 northstar = four per resident "
                     "wavefront slot (rounds 1-2: 12288; the launch lasts as long as its longest chain of reads, which two per slot leave "
                     "10 %% above the mean), 1000 c2, 8192 anchor, 6144 em) or in the whole set (c3; default 50000)")
@@ -403,7 +423,7 @@ def main():
 
 def resident(env):
     args, ctx, rank, world, dist, coll_dev, sync, allreduce = (env[k] for k in ("args", "ctx", "rank", "world", "dist", "coll_dev", "sync", "allreduce"))
-    n_reads = args.reads or {"northstar": 24576, "c2": 1000, "anchor": 8192}[args.workload]
+    n_reads = args.reads or {"northstar": 24576, "c2": 1000, "anchor": 8192, "rescore": 8192}[args.workload]
     h, w, W, label = build_workload(args.workload, n_reads, rank)
     ctx.set_hmm(h)
     r = timed_resident(ctx, h, w, W, args.steps, args.warmup, sync)
@@ -455,7 +475,9 @@ def resident(env):
         "reads_per_s": total_reads * args.steps / elapsed,
         "roofline": roofline_block(cells, pairs, kms, r["class_cells"], gpu_clock_hz()),
         "ok_reads": int((res["status"] == 0).sum()),
-        "step": "npr_batch_run (DP sweep) + npr_batch_finish (MEA chain + cigar on the device, ops to the host)",
+        "step": ("npr_batch_run (DP sweep) + npr_batch_finish (the guide's M columns looked up where the pairs lie, summed in fixed point on the device: "
+                 "eight bytes per read come back)" if W < 0 else
+                 "npr_batch_run (DP sweep) + npr_batch_finish (MEA chain + cigar on the device, ops to the host)"),
         "dp_sweep_only": {"value": cells / (kms * 1e-3), "unit": "cells/s", "ms": kms},
         "finish_ms": r["finish_ms"],
         "gather_ms": gather_ms,
@@ -472,6 +494,8 @@ def resident(env):
         same = sum(1 for i in range(k) if np.array_equal(ops[off[i]:off[i + 1]], ro["ops"][i]))
         out["cigar_identical_to_builds_own_fp64_oracle"] = "%d/%d (PARITY UNPINNED: the oracle is this build's restatement, " \
                                                            "the reference binary is absent)" % (same, k)
+        if W < 0:  # rescore mode: the cigars are the guides'; what is computed is the score
+            out["max_score_difference_to_builds_own_fp64_oracle"] = float(np.max(np.abs(res["score"][:k] - np.asarray(ro["score"])[:k]))) if k else 0.0
     batch.close()
     if world == 1 and args.workload == "northstar" and not args.no_also:
         # the band the drop-in path actually runs (realignSamFile: the reference's own call parameters), driver-visible
@@ -484,6 +508,16 @@ def resident(env):
                         "roofline": roofline_block(c2, int(r2["res"]["n_pairs"].sum()), k2, r2["class_cells"], gpu_clock_hz()),
                         "ok_reads": int((r2["res"]["status"] == 0).sum())}]
         r2["batch"].close()
+        # ... and the posterior consumers' call-site mode (alignmentUncertainty.py:41), finished on the device since round 5
+        h3, w3, W3, label3 = build_workload("rescore", 8192, 0)
+        r3 = timed_resident(ctx, h3, w3, W3, 3, 1, sync)
+        c3_, k3 = r3["stats"]["cells"], r3["kernel_ms"]
+        out["also"].append({"workload": label3, "reads": 8192, "value": c3_ * 3 / r3["elapsed"], "unit": "cells/s",
+                            "reads_per_s": 8192 * 3 / r3["elapsed"], "ms_per_step": r3["elapsed"] / 3 * 1e3,
+                            "dp_sweep_only": {"value": c3_ / (k3 * 1e-3), "unit": "cells/s", "ms": k3}, "finish_ms": r3["finish_ms"],
+                            "roofline": roofline_block(c3_, int(r3["res"]["n_pairs"].sum()), k3, r3["class_cells"], gpu_clock_hz()),
+                            "ok_reads": int((r3["res"]["status"] == 0).sum())})
+        r3["batch"].close()
     return out
 
 

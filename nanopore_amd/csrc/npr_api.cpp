@@ -312,6 +312,15 @@ struct npr_batch {
     std::unique_ptr<uint32_t[]> packed;
     int64_t packed_cap = 0;
     bool have_pairs_form = false, have_packed_form = false;
+    // NPR_MODE_RESCORE_ORIGINAL: the cigars are the guide's (operations of length 0 left out), made from b->guide_ops the first time somebody asks
+    bool ops_from_guide = false;
+    // ... and what npr_batch_create leaves for npr_batch_finish: the guide's M columns as a table on the device (rescore_stage), per read the
+    // number of M columns and of operations kept; rs_staged = false: the host stage scores (NPR_OPT_HOST_MEA, or a sum that could not be exact)
+    bool rs_staged = false;
+    int rs_shift = 0;
+    std::vector<int64_t> rs_columns, rs_kept;
+    DevBuf<int32_t> d_rs_gy;
+    DevBuf<int64_t> d_rs_gx_off;
     std::vector<int64_t> pair_off;
     std::vector<Pair> pairs;             // filled by fetch_pairs(): at finish in the host modes, on demand after the device MEA
     bool pairs_ready = false;
@@ -599,6 +608,10 @@ inline int64_t stripes_of(const Segment &s, int R) { return (s.xe - s.xs) / (64 
 // --------------------------------------------------------------------------------------------------
 // batch
 // --------------------------------------------------------------------------------------------------
+
+namespace {
+int32_t rescore_stage(npr_batch *b);  // NPR_MODE_RESCORE_ORIGINAL: the guide's M columns as a device table (below, with the finish stages)
+}
 
 int32_t npr_batch_create(npr_ctx *ctx, const npr_params *params, int64_t n_reads, int64_t n_refs,
                          const uint8_t *ref, const int64_t *ref_off, const int32_t *ref_index,
@@ -1279,6 +1292,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             if (L.cells > best) best = L.cells, b->stats.kernel_variant = is_tile_kind(kClassTab[L.cls].kind) ? 2 : (is_register_class(L.cls) ? 1 : 0);
     }
     b->stats.device_bytes = fixed + static_cast<int64_t>(b->scratch_cells) * 8 + ring_floats * 4;
+    if (b->params.mode == NPR_MODE_RESCORE_ORIGINAL) {
+        const int32_t rc = rescore_stage(b.get());
+        if (rc != NPR_OK) return rc;
+    }
     drain.armed = false;
     *out = b.release();
     return NPR_OK;
@@ -1546,6 +1563,101 @@ int32_t fetch_pairs(npr_batch *b) {
     return NPR_OK;
 }
 
+// NPR_MODE_RESCORE_ORIGINAL on the device (npr_stats.hip k_rescore_table / k_rescore_sum; the reference's call site: alignmentUncertainty.py:41,
+// the analysis that runs on every experiment by default, pipeline.py:81).  At staging the guide's M runs go up once (12 bytes per run) and are
+// spread into a table over the reference positions of each read's window; every pass then is one sweep over the pairs where the DP kernels
+// left them and eight bytes per read coming back -- no pair crosses PCIe, and the guide's operations are not copied until somebody asks for
+// the cigars.  rescore_stage leaves b->rs_staged false when the fixed-point sum could not be exact (a threshold below 2^-20, a guide of
+// 2^(53 - shift) M columns): the host stage scores then.
+int32_t rescore_stage(npr_batch *b) {
+    npr_ctx *ctx = b->ctx;
+    const int64_t n = b->n_reads;
+    StageTimer tm("rescore_stage");
+    b->rs_staged = false;
+    b->rs_columns.assign(n, 0), b->rs_kept.assign(n, 0);
+    std::vector<int64_t> run_off(n + 1, 0), gx_off(n + 1, 0);
+    parallel_for(n, ctx->host_threads, [&](int64_t i) {
+        int64_t runs = 0, cols = 0, kept = 0;
+        for (int64_t q = b->guide_off[i]; q < b->guide_off[i + 1]; ++q) {
+            const int32_t len = b->guide_ops[2 * q + 1];
+            kept += len > 0;
+            if (b->guide_ops[2 * q] == NPR_OP_M && len > 0) ++runs, cols += len;
+        }
+        b->rs_columns[i] = cols, b->rs_kept[i] = kept, run_off[i + 1] = b->read_status[i] == NPR_OK ? runs : 0;
+    });
+    if (ctx->opt[NPR_OPT_HOST_MEA] != 0 || n == 0) return NPR_OK;
+    int e2 = 0;
+    (void)std::frexp(b->params.posterior_threshold, &e2);  // threshold = m * 2^e2, m in [0.5, 1): an fp32 p >= threshold is a multiple of 2^(e2 - 1 - 23)
+    const int shift = 24 - e2;
+    if (!(b->params.posterior_threshold > 0.0) || shift > 44 || shift < 0) return NPR_OK;
+    for (int64_t i = 0; i < n; ++i) {
+        if (b->rs_columns[i] >= (int64_t(1) << (53 - shift))) return NPR_OK;
+        run_off[i + 1] += run_off[i];
+        gx_off[i + 1] = gx_off[i] + (b->read_status[i] == NPR_OK ? b->ref_len[i] + 1 : 0);
+    }
+    // the runs through the context's pinned staging buffer when it is there (157 MB for 8192 reads of 8 kb: pageable memory halves the copy's rate)
+    std::vector<int32_t> runs_v;
+    int32_t *runs = nullptr;
+    const size_t run_bytes = sizeof(int32_t) * 3 * static_cast<size_t>(run_off[n]);
+    if (ctx->pin_stage && ctx->pin_stage_bytes >= run_bytes) runs = static_cast<int32_t *>(ctx->pin_stage);
+    else runs_v.resize(3 * static_cast<size_t>(run_off[n])), runs = runs_v.data();
+    parallel_for(n, ctx->host_threads, [&](int64_t i) {
+        if (b->read_status[i] != NPR_OK) return;
+        int32_t *out = runs + 3 * run_off[i];
+        int64_t x = 0, y = 0;
+        for (int64_t q = b->guide_off[i]; q < b->guide_off[i + 1]; ++q) {
+            const int32_t op = b->guide_ops[2 * q], len = b->guide_ops[2 * q + 1];
+            if (op == NPR_OP_M) {
+                if (len > 0) out[0] = static_cast<int32_t>(x), out[1] = static_cast<int32_t>(y), out[2] = len, out += 3;
+                x += len, y += len;
+            } else if (op == NPR_OP_I) {
+                y += len;
+            } else {
+                x += len;
+            }
+        }
+    });
+    tm.lap("runs");
+    DevBuf<int64_t> d_run_off;
+    DevBuf<int32_t> d_runs;
+    hipError_t e;
+    if ((e = d_run_off.alloc_from(ctx, n + 1)) != hipSuccess || (e = b->d_rs_gx_off.alloc_from(ctx, n + 1)) != hipSuccess ||
+        (e = d_runs.alloc_from(ctx, std::max<size_t>(3 * static_cast<size_t>(run_off[n]), 1))) != hipSuccess ||
+        (e = b->d_rs_gy.alloc_from(ctx, std::max<int64_t>(gx_off[n], 1))) != hipSuccess)
+        return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: hipMalloc (rescore tables)", e);
+    HIP_TRY(ctx, hipMemcpyAsync(d_run_off.p, run_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_rs_gx_off.p, gx_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (run_bytes) HIP_TRY(ctx, hipMemcpyAsync(d_runs.p, runs, run_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_rs_gy.p, 0xff, sizeof(int32_t) * std::max<int64_t>(gx_off[n], 1), ctx->stream));
+    RescoreArgs ra{static_cast<int32_t>(n), 0, d_run_off.p, d_runs.p, b->d_rs_gx_off.p, b->d_rs_gy.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, shift};
+    const int rc = launch_rescore_table(ra, ctx->stream);
+    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_rescore_table launch", static_cast<hipError_t>(rc));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the staging buffer and d_runs go back)
+    tm.lap("table");
+    b->rs_shift = shift, b->rs_staged = true;
+    return NPR_OK;
+}
+
+int32_t rescore_sum(npr_batch *b, std::vector<double> &score) {
+    npr_ctx *ctx = b->ctx;
+    const int64_t n = b->n_reads, ntasks = static_cast<int64_t>(b->tasks.size());
+    DevBuf<unsigned long long> d_sum;
+    hipError_t e;
+    if ((e = d_sum.alloc_from(ctx, n)) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipMalloc (rescore sums)", e);
+    HIP_TRY(ctx, hipMemsetAsync(d_sum.p, 0, sizeof(unsigned long long) * n, ctx->stream));
+    RescoreArgs ra{static_cast<int32_t>(n), static_cast<int32_t>(ntasks), nullptr, nullptr, b->d_rs_gx_off.p, b->d_rs_gy.p, b->d_tasks.p, b->d_outs.p,
+                   b->d_px.p, b->d_py.p, b->d_pp.p, d_sum.p, b->rs_shift};
+    const int rc = launch_rescore_sum(ra, ctx->stream);
+    if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_rescore_sum launch", static_cast<hipError_t>(rc));
+    std::vector<unsigned long long> sum(n);
+    HIP_TRY(ctx, hipMemcpyAsync(sum.data(), d_sum.p, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    score.assign(n, 0.0);
+    for (int64_t i = 0; i < n; ++i)
+        if (b->rs_columns[i] > 0) score[i] = std::ldexp(static_cast<double>(sum[i]), -b->rs_shift) / static_cast<double>(b->rs_columns[i]);
+    return NPR_OK;
+}
+
 // MEA chain + cigar of every read on the device (npr_mea.hip): only the ops cross PCIe.  Returns 1 when some read
 // needs the host stage instead (a chain reaching back further than the prefix-maximum ring), NPR_OK or an error.
 int32_t device_mea(npr_batch *b) {
@@ -1779,8 +1891,17 @@ static int32_t batch_finish_impl(npr_batch *b) {
         b->pair_off[i + 1] = b->pair_off[i] + c;
     }
     tm.lap("task results");
-    // --- realign mode: chain and cigar on the device, the pairs stay in HBM until npr_batch_pairs asks for them ---
-    if (b->params.mode == NPR_MODE_REALIGN && n > 0 && ntasks > 0 && ctx->opt[NPR_OPT_HOST_MEA] == 0) {
+    // --- rescore mode: the guide's M columns looked up where the pairs lie (round 5) ---
+    std::vector<double> dev_score;
+    bool have_dev_score = false;
+    if (b->params.mode == NPR_MODE_RESCORE_ORIGINAL && n > 0 && ntasks > 0 && b->rs_staged && ctx->opt[NPR_OPT_HOST_MEA] == 0) {
+        const int32_t rc = rescore_sum(b, dev_score);
+        if (rc < 0) return rc;
+        have_dev_score = true;
+        tm.lap("device rescore");
+    }
+    // --- realign and all-posteriors modes: chain and cigar on the device, the pairs stay in HBM until npr_batch_pairs asks for them ---
+    if ((b->params.mode == NPR_MODE_REALIGN || b->params.mode == NPR_MODE_ALL_POSTERIORS) && n > 0 && ntasks > 0 && ctx->opt[NPR_OPT_HOST_MEA] == 0) {
         int64_t scratch = 0;
         for (int64_t i = 0; i < n; ++i) scratch += 8 * (b->ref_len[i] + 1) + 4 * b->read_len[i] + 36 * std::min(b->ref_len[i], b->read_len[i]) + 128;
         scratch += 48 * b->pair_off[n];
@@ -1797,29 +1918,36 @@ static int32_t batch_finish_impl(npr_batch *b) {
             }
         }
     }
-    // --- host stage: all-posteriors and rescore modes need the pairs on the host anyway; realign comes here when the
-    // per-position tables of the device stage would not fit (records chained across a whole contig) ---
-    {
+    // --- host stage: what the device stages could not take (per-position tables that would not fit: records chained across a whole contig;
+    // a fixed-point sum that could not be exact), and NPR_OPT_HOST_MEA ---
+    if (!have_dev_score) {
         const int32_t rc = fetch_pairs(b);
         if (rc != NPR_OK) return rc;
+    }
+    if (b->params.mode == NPR_MODE_RESCORE_ORIGINAL) {
+        // --rescoreOriginalAlignment: ops verbatim (alignmentUncertainty.py:51-52), new score.  The guide's operations are not copied here
+        // (10^7-10^8 per batch): npr_batch_ops / npr_batch_ops_packed make the form they are asked for from b->guide_ops
+        b->ops_off.assign(n + 1, 0);
+        parallel_for(n, ctx->host_threads, [&](int64_t i) {
+            npr_read_result &r = b->results[i];
+            if (r.status != NPR_OK) return;
+            r.n_ops = b->rs_kept[i], b->ops_off[i + 1] = b->rs_kept[i];
+            r.score = have_dev_score ? dev_score[i]
+                                     : rescore(b->guide_ops.data() + 2 * b->guide_off[i], b->guide_off[i + 1] - b->guide_off[i], b->pairs.data() + b->pair_off[i], r.n_pairs);
+        });
+        for (int64_t i = 0; i < n; ++i) b->ops_off[i + 1] += b->ops_off[i];
+        b->ops_words = 2 * b->ops_off[n];
+        b->ops_from_guide = true, b->have_pairs_form = false, b->have_packed_form = false;
+        tm.lap("scores");
+        b->finished = true;
+        return NPR_OK;
     }
     std::vector<std::vector<int32_t>> per_read_ops(n);
     parallel_for(n, ctx->host_threads, [&](int64_t i) {
         npr_read_result &r = b->results[i];
         if (r.status != NPR_OK) return;
-        const Pair *pp = b->pairs.data() + b->pair_off[i];
-        const int64_t c = r.n_pairs;
-        if (b->params.mode == NPR_MODE_RESCORE_ORIGINAL) {
-            const int32_t *g = b->guide_ops.data() + 2 * b->guide_off[i];
-            const int64_t ng = b->guide_off[i + 1] - b->guide_off[i];
-            // --rescoreOriginalAlignment: ops verbatim (alignmentUncertainty.py:51-52), new score
-            for (int64_t q = 0; q < ng; ++q)
-                if (g[2 * q + 1] > 0) per_read_ops[i].insert(per_read_ops[i].end(), {g[2 * q], g[2 * q + 1]});
-            r.score = rescore(g, ng, pp, c);
-        } else {
-            const int32_t rc = mea_cigar(b->ref_len[i], b->read_len[i], pp, c, b->params.gap_gamma, b->params.match_gamma, per_read_ops[i], r.score);
-            if (rc != NPR_OK) r.status = rc;
-        }
+        const int32_t rc = mea_cigar(b->ref_len[i], b->read_len[i], b->pairs.data() + b->pair_off[i], r.n_pairs, b->params.gap_gamma, b->params.match_gamma, per_read_ops[i], r.score);
+        if (rc != NPR_OK) r.status = rc;
         r.n_ops = static_cast<int64_t>(per_read_ops[i].size() / 2);
     });
     tm.lap("MEA + cigar");
@@ -1863,8 +1991,22 @@ int32_t npr_batch_results(const npr_batch *b, npr_read_result *out) {
     return NPR_OK;
 }
 
+static void ops_from_guide(npr_batch *b) {  // rescore mode: the guide's operations of non-zero length, in the pairs form
+    const int64_t total = b->ops_off[b->n_reads];
+    if (2 * total > b->ops_cap) b->ops.reset(new int32_t[2 * total]), b->ops_cap = 2 * total;
+    parallel_for(b->n_reads, b->ctx->host_threads, [&](int64_t i) {
+        if (b->results[i].status != NPR_OK) return;
+        const int32_t *g = b->guide_ops.data() + 2 * b->guide_off[i];
+        const int64_t ng = b->guide_off[i + 1] - b->guide_off[i];
+        int32_t *out = b->ops.get() + 2 * b->ops_off[i];
+        for (int64_t q = 0; q < ng; ++q)
+            if (g[2 * q + 1] > 0) *out++ = g[2 * q], *out++ = g[2 * q + 1];
+    });
+    b->have_pairs_form = true;
+}
 static void ensure_pairs_form(npr_batch *b) {
     if (b->have_pairs_form) return;
+    if (b->ops_from_guide) return ops_from_guide(b);
     const int64_t total = b->ops_off[b->n_reads];
     if (2 * total > b->ops_cap) b->ops.reset(new int32_t[2 * total]), b->ops_cap = 2 * total;
     const uint32_t *src = b->packed.get();
@@ -1878,6 +2020,7 @@ static void ensure_pairs_form(npr_batch *b) {
 }
 static void ensure_packed_form(npr_batch *b) {
     if (b->have_packed_form) return;
+    if (b->ops_from_guide && !b->have_pairs_form) ops_from_guide(b);
     const int64_t total = b->ops_off[b->n_reads];
     if (total > b->packed_cap) b->packed.reset(new uint32_t[total]), b->packed_cap = total;
     const int32_t *src = b->ops.get();

@@ -257,6 +257,27 @@ struct ExpectArgs {
     uint8_t *seen;          // [positions]
 };
 int launch_base_expectations(const ExpectArgs &a, void *stream);
+// NPR_MODE_RESCORE_ORIGINAL on the device (npr_stats.hip; cactus_realign --rescoreOriginalAlignment, nanopore/analyses/alignmentUncertainty.py:41):
+// the mean posterior over the M columns of the guide.  k_rescore_table spreads the guide's M runs into a table of one entry per reference
+// position of the read's window (the read position the guide aligns it to, -1: none); k_rescore_sum looks every posterior pair up in it where the
+// DP kernels left the pairs and adds the hits in FIXED POINT: p * 2^shift is an integer for an fp32 p at or above the posterior threshold, so a
+// read's sum is the exact sum of its terms whatever order the atomics land in -- and equal to npr_host.cpp's `rescore`, whose double sum over
+// the sorted pair list is exact too as long as columns * 2^shift stays below 2^53.
+struct RescoreArgs {
+    int32_t n_reads, ntasks;
+    const int64_t *run_off;  // [n_reads + 1]: the M runs of each read's guide in `runs`
+    const int32_t *runs;     // (x0, y0, length) per run, window coordinates
+    const int64_t *gx_off;   // [n_reads + 1]: the read's slice of `gy` (reference span of its window + 1 entries)
+    int32_t *gy;
+    const Task *tasks;
+    const TaskOut *outs;
+    const int32_t *px, *py;
+    const float *pp;
+    unsigned long long *sum;  // [n_reads]
+    int32_t shift;
+};
+int launch_rescore_table(const RescoreArgs &a, void *stream);
+int launch_rescore_sum(const RescoreArgs &a, void *stream);
 size_t mea_chain_lds_bytes(int ring);
 int launch_mea_sort(const MeaArgs &a, void *stream);
 int launch_mea_chain(const MeaArgs &a, void *stream);

@@ -525,7 +525,12 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
         if (!good) {
             out.status = TASK_RERUN, out.btot_m = ratio, out.btot_e = de, out.npairs = why;  // (also when nothing arrives at the cut: the per-cell kernel says whether the band carries no probability)
         } else if (nA + nB > pair_cap) {
+            // The two halves of the list have run into each other.  The read is reported and run again with a larger list, but whoever looks at
+            // this one meanwhile (the MEA stage takes every task's first pair_cap entries) must find posteriors in it, not candidates: the
+            // coordinates are some cell's either way (the two wavefronts' cells are disjoint: no pair twice), the values are made harmless.
             out.npairs = nA + nB, out.status = NPR_ERR_CAPACITY;
+            float *const pp = a.pp + pair_off;
+            for (int i = threadIdx.x; i < pair_cap; i += 2 * WAVE) pp[i] = a.threshold;
         } else {
             const float inv = 1.0f / tot_m, thr = a.threshold;
             int32_t *const px = a.px + pair_off, *const py = a.py + pair_off;

@@ -144,7 +144,53 @@ __global__ void __launch_bounds__(256) k_base_expectations(ExpectArgs a) {
     }
 }
 
+// NPR_MODE_RESCORE_ORIGINAL (npr_device.h RescoreArgs): the guide's M runs as a table over the reference positions of each read's window ...
+__global__ void __launch_bounds__(256) k_rescore_table(RescoreArgs a) {
+    for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+        int32_t *gy = a.gy + a.gx_off[r];
+        const int64_t span = a.gx_off[r + 1] - a.gx_off[r];
+        for (int64_t q = a.run_off[r] + threadIdx.x; q < a.run_off[r + 1]; q += blockDim.x) {
+            const int x0 = a.runs[3 * q], y0 = a.runs[3 * q + 1], len = a.runs[3 * q + 2];
+            for (int t = 0; t < len; ++t)
+                if (x0 + t >= 0 && x0 + t < span) gy[x0 + t] = y0 + t;
+        }
+    }
+}
+// ... and the posterior mass of the pairs that lie on it, per read, in fixed point (one 64-bit atomic per wavefront and task)
+__global__ void __launch_bounds__(256) k_rescore_sum(RescoreArgs a) {
+    const float one = __builtin_ldexpf(1.0f, a.shift);
+    for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
+        const Task &tk = a.tasks[t];
+        const int r = tk.read;
+        const int n = min(a.outs[t].npairs, tk.pair_cap);
+        const int32_t *gy = a.gy + a.gx_off[r];
+        const int64_t span = a.gx_off[r + 1] - a.gx_off[r];
+        unsigned long long local = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int x = a.px[tk.pair_off + i];
+            if (x >= 0 && x < span && gy[x] == a.py[tk.pair_off + i]) local += __float2ull_rz(a.pp[tk.pair_off + i] * one);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned lo = __shfl_xor(static_cast<unsigned>(local), o, WAVE), hi = __shfl_xor(static_cast<unsigned>(local >> 32), o, WAVE);
+            local += (static_cast<unsigned long long>(hi) << 32) | lo;
+        }
+        if ((threadIdx.x & (WAVE - 1)) == 0 && local) atomicAdd(a.sum + r, local);
+    }
+}
+
 }  // namespace
+
+int launch_rescore_table(const RescoreArgs &a, void *stream) {
+    const int g1 = a.n_reads < 16384 ? (a.n_reads > 0 ? a.n_reads : 1) : 16384;
+    hipLaunchKernelGGL(k_rescore_table, dim3(g1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return static_cast<int>(hipGetLastError());
+}
+int launch_rescore_sum(const RescoreArgs &a, void *stream) {
+    const int g2 = a.ntasks < 8192 ? (a.ntasks > 0 ? a.ntasks : 1) : 8192;
+    hipLaunchKernelGGL(k_rescore_sum, dim3(g2), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return static_cast<int>(hipGetLastError());
+}
 
 int launch_base_expectations(const ExpectArgs &a, void *stream) {
     const int grid = a.ntasks < 8192 ? (a.ntasks > 0 ? a.ntasks : 1) : 8192;

@@ -189,6 +189,7 @@ def test_edge_cases(gpu_ctx):
     assert gpu_ctx.realign(P, [], [], []) == []
 
 
+@pytest.mark.timeout(300)
 def test_posterior_capacity_overflow_is_reported_and_retried(gpu_ctx):
     """A sparse posterior list that does not fit its capacity is a per-read NPR_ERR_CAPACITY from the C ABI; the
     Python layer re-runs such reads with a larger capacity and ends with the same answer."""
@@ -209,6 +210,23 @@ def test_posterior_capacity_overflow_is_reported_and_retried(gpu_ctx):
     c = gpu_ctx.realign(R.make_params(band_mode=1, fixed_width=100), refs, reads, guides, want_pairs=True)
     for u, v in zip(a, c):
         assert u["status"] == 0 and u["ops"] == v["ops"] and np.array_equal(u["p"], v["p"])
+    # A batch in which SOME lists overflow: the device MEA stage walks every task's list, so a list that overflowed must still hold
+    # posteriors (k_dp_mid_rs's two wavefronts fill it from both ends with candidates that are only rescaled when it did not overflow --
+    # round 5: a chain kernel fed such values did not come back), and the reads that fit are not disturbed by their neighbours.
+    cases = [random_pair(rng, int(rng.integers(200, 1500)), indel=float(rng.choice([0.05, 0.3])), max_indel=12) for _ in range(160)]
+    refs = [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases]
+    reads = [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases]
+    guides = [g for _, _, g in cases]
+    b = gpu_ctx.stage(R.make_params(band_mode=1, fixed_width=100, max_pairs_per_base=2), refs, reads, guides)
+    b.run()
+    b.finish()
+    st = b.results()["status"].copy()
+    off, ops = b.ops()
+    b.close()
+    assert (st == -3).sum() >= 20 and (st == 0).sum() >= 20 and set(st.tolist()) <= {0, -3}
+    roomy = gpu_ctx.realign(R.make_params(band_mode=1, fixed_width=100), refs, reads, guides)
+    for i in np.nonzero(st == 0)[0]:
+        assert [tuple(o) for o in ops[off[i]:off[i + 1]].tolist()] == [tuple(o) for o in roomy[i]["ops"]]
 
 
 def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
@@ -248,6 +266,41 @@ def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
             assert u["ops"] == v["ops"] and u["score"] == v["score"] and u["n_pairs"] == v["n_pairs"], kw
             assert t["ops"] == v["ops"] and t["score"] == v["score"], kw
             assert len(u["p"]) == u["n_pairs"]
+
+
+def test_rescore_and_all_posteriors_modes_finish_on_the_device(gpu_ctx):
+    """The call-site modes of the posterior consumers (nanopore/analyses/alignmentUncertainty.py:41 -- the analysis every experiment runs by
+    default, pipeline.py:81 --, marginAlignSnpCaller.py:136-146) no longer copy the pairs out to be finished (round 5).
+    NPR_MODE_RESCORE_ORIGINAL: the guide's M columns looked up where the pairs lie, summed in fixed point -- the SAME double as the host
+    stage's walk over the sorted pair list (NPR_OPT_HOST_MEA = 1), and as the oracle's rescore of the fp32 mirror's pairs; the ops are the
+    guide's.  NPR_MODE_ALL_POSTERIORS: the realign mode's device chain; the pairs come when asked for and are the host stage's.
+    Guides with long indels (runs that start anywhere), N bases, a read of one base, anchors with the analyses' split 100, a fixed band."""
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(71)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    h = oracle_hmm()
+    cases = [random_pair(rng, int(rng.integers(30, 2500)), indel=0.2, max_indel=40) for _ in range(30)]
+    cases += [random_pair(rng, 1, indel=0.0), random_pair(rng, 3000, indel=0.3, max_indel=150)]
+    cases[2][0][5:40] = 4
+    refs = [bytes(b"ACGTN"[c] for c in X) for X, _, _ in cases]
+    reads = [bytes(b"ACGTN"[c] for c in Y) for _, Y, _ in cases]
+    guides = [g for _, _, g in cases]
+    for kw in (dict(band_mode=0, diagonal_expansion=10, constraint_trim=14, split_threshold=100), dict(band_mode=1, fixed_width=100)):
+        for mode in (R.MODE_RESCORE_ORIGINAL, R.MODE_ALL_POSTERIORS):
+            got = {}
+            for where in ("device", "host"):
+                gpu_ctx.set_option(_lib.OPTIONS["host_mea"], int(where == "host"))
+                got[where] = gpu_ctx.realign(R.make_params(mode=mode, **kw), refs, reads, guides, want_pairs=True)
+            gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 0)
+            for (X, Y, ops), u, v in zip(cases, got["device"], got["host"]):
+                assert u["status"] == v["status"] == 0
+                assert u["ops"] == v["ops"] and u["score"] == v["score"] and u["n_pairs"] == v["n_pairs"], (kw, mode)
+                assert np.array_equal(u["x"], v["x"]) and np.array_equal(u["y"], v["y"]) and np.array_equal(u["p"].view(np.uint32), v["p"].view(np.uint32))
+                if mode == R.MODE_RESCORE_ORIGINAL:
+                    assert u["ops"] == [(o, l) for o, l in ops if l > 0]
+                    assert u["score"] == orc.rescore(np.asarray(ops, dtype=np.int32), u["x"], u["y"], u["p"])
+                    m32 = orc.realign_read(h, orc.make_params(mode=orc.MODE_RESCORE_ORIGINAL, **kw), X, Y, ops, precision=1, seg_arith=u["seg_arith"])
+                    assert u["score"] == m32["score"]
 
 
 def test_device_mea_long_spans(gpu_ctx, monkeypatch):
