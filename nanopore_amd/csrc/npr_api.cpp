@@ -586,6 +586,18 @@ bool rs_model_ok(const DevModel &m) {
     return grow <= std::exp2(6.0 / NPR_RS_K);
 }
 
+// Whether every loaded model emits every base from every gap state with probability exactly 2^-2 (N included: make_dev_model gives it 1/4): the
+// row-scaled kernels then take the gap emissions from a select instead of their LDS tables (npr_rs.h rs_cell_emissions; same bits).
+bool flat_gap_emissions(const npr_ctx *ctx) {
+    for (int sl = 0; sl < NPR_MAX_MODELS; ++sl) {
+        if (!ctx->model_set[sl]) continue;
+        const DevModel &m = ctx->models[sl];
+        for (int b2 = 0; b2 < 5; ++b2)
+            if (m.ex[5 + b2] != 0.25f || m.ex[15 + b2] != 0.25f || m.ey[10 + b2] != 0.25f || m.ey[20 + b2] != 0.25f) return false;
+    }
+    return true;
+}
+
 // Stripe table of k_dp_tile for one segment (npr_kernel_tile.hip): the lattice columns 0..lX cut into stripes of 64*R
 // columns; per stripe the first / last anti-diagonal on which the band has cells in it and the index of its first row in
 // the task's scratch (one row per anti-diagonal of a stripe).  out[0] is the header {stripes, rows}.
@@ -1358,6 +1370,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     bool sw = false;
     for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
         if (ctx->model_set[sl] && (ctx->models[sl].T[1 * 5 + 2] != 0.f || ctx->models[sl].T[2 * 5 + 1] != 0.f)) sw = true;
+    const bool flat = !sw && flat_gap_emissions(ctx);
     for (size_t i = 0; i < order.size(); ++i) {
         const npr_batch::Launch &L = *order[i];
         const bool last = i + 1 == order.size();
@@ -1373,8 +1386,8 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
-        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_mid_rs(a, kc.R, L.grid, s, sw) : launch_pair(a, kc.R, L.grid, s))
-                       : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw)
+        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_mid_rs(a, kc.R, L.grid, s, sw, flat) : launch_pair(a, kc.R, L.grid, s))
+                       : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw, flat)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
                        : kc.kind == K_TILE_RS ? launch_tile_rs(a, L.wcap, L.grid, s)
@@ -2646,6 +2659,7 @@ int32_t npr_batch_rs_forward(npr_batch *b, int64_t read_index, float *Fm_v, int3
     bool sw = false;
     for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
         if (ctx->model_set[sl] && (ctx->models[sl].T[1 * 5 + 2] != 0.f || ctx->models[sl].T[2 * 5 + 1] != 0.f)) sw = true;
+    const bool flat = !sw && flat_gap_emissions(ctx);
     int64_t written = 0;
     for (int32_t s = 0; s < b->read_ntasks[read_index]; ++s) {
         const int32_t k = b->task_of[b->read_first_task[read_index] + s];
@@ -2657,7 +2671,7 @@ int32_t npr_batch_rs_forward(npr_batch *b, int64_t read_index, float *Fm_v, int3
         KernelArgs a = make_args(b);
         a.tasks = b->d_tasks.p + k, a.ntasks = 1, a.outs = d_out1.p, a.slot_base = 0, a.region = nullptr;
         HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p, 0, sizeof(int32_t) * kQueueSlots, ctx->stream));
-        const int rc = launch_rs(a, R, 1, ctx->stream, sw);
+        const int rc = launch_rs(a, R, 1, ctx->stream, sw, flat);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "k_dp_rs launch", static_cast<hipError_t>(rc));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const int64_t half = rs_half_cells(static_cast<int64_t>(static_cast<uint32_t>(t.cells_pad)));

@@ -310,7 +310,7 @@ int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
 #define NPR_RS_S_LIMIT (126 - 60 - (NPR_RS_TOP + 6) - 1)
 constexpr int32_t TASK_RERUN = 1;  // TaskOut::status of such a task between the two launches (never leaves npr_batch_run)
 NPR_HD constexpr int64_t rs_half_cells(int64_t cells_pad) { return (cells_pad + 63) & ~int64_t(63); }
-int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);  // sw: a loaded model has short-gap switches (npr_rs.h)
+int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw, bool flat);  // sw: a loaded model has short-gap switches; flat: all gap emissions are 2^-2 (npr_rs.h)
 // k_dp_mid_rs (npr_kernel_mid.hip): k_dp_rs's sweeps on two wavefronts that meet in the middle -- the forward one from row 0, the backward one from
 // row D, each going on past the cut against the other's stored rows.  Tasks of fewer than MID_MIN_D anti-diagonals stay with k_dp_rs.
 constexpr int32_t MID_MIN_D = 4 * NPR_RS_K;
@@ -319,7 +319,7 @@ constexpr int32_t MID_MIN_D = 4 * NPR_RS_K;
 #endif
 // resident wavefronts per CU of k_dp_mid_rs<R> (80 / .. / 124 registers)
 inline int mid_waves_per_cu(int R) { return R == 1 ? 24 : (R == 2 ? 4 * NPR_MID_WAVES2 : 16); }
-int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw);
+int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw, bool flat);
 int launch_tile_rs(const KernelArgs &a, int NW, int grid, void *stream);  // k_dp_tile_rs: k_dp_tile's stripes, one exponent per stripe row
 size_t tile_rs_lds_bytes(int nw);
 size_t rs_lds_bytes();  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once

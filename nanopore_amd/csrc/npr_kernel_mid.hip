@@ -36,13 +36,13 @@ constexpr int MID_REJ_CAP = 64;  // candidates of one task that may fall below t
 // candidates of one anti-diagonal: q = f * ldexp(b, s) where k_dp_rs forms p = (f * ldexp(b, s)) * inv_tot; BACK: slots from the end of the list
 template <int R, bool BACK>
 __device__ __forceinline__ void mid_emit(const PairSink &S, const float (&f)[R], const float (&b)[R], int d, int x0, int y0, const Masks<R> &mk, int s,
-                                         float inv_tot, const int (&jr)[R], int &cnt) {
+                                         float q_min, const int (&jr)[R], int &cnt) {
     float q[R];
     uint64_t hit[R], any = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         q[r] = f[r] * __builtin_ldexpf(b[r], s);
-        hit[r] = __ballot(q[r] * inv_tot >= S.threshold) & mk.cell[r];  // (S.threshold: the lowered one)
+        hit[r] = __ballot(q[r] >= q_min) & mk.cell[r];  // (q_min = the lowered threshold times total's mantissa: the test needs no division)
         any |= hit[r];
     }
     if (d >= 2 && any) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
-template <int R, bool SW>
+template <int R, bool SW, bool FLAT>
 __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R == 1 ? 6 : (R == 2 ? NPR_MID_WAVES2 : 4)))) k_dp_mid_rs(KernelArgs a) {
     __shared__ __attribute__((aligned(16))) RsTables ltab_s;
     __shared__ __attribute__((aligned(16))) float lmodel[MODEL_FLOATS];
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
         CtlPair w0{0u, 0u, 0u, 0u}, w1 = w0, w2 = w0;  // control words: the pair being computed, the next one, the one after (wavefront 1: w2 only)
         RowCtl<R> cur = c0, nxt = c0;
         uint32_t m1 = 0, m2 = 0;
-        float inv_tot = 0.f;
+        float q_min = 0.f;  // candidates: q' >= threshold * (1 - 2^-10) * totMant'
         int pte = 0;
         PairSink sink{a.px + pair_off, a.py + pair_off, a.pp + pair_off, 0, pair_cap, xs, ys, a.threshold * (1.0f - 0x1p-10f)};
 
@@ -172,12 +172,12 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             const RowCtl<R> cx = row_ctl_of_words<R>(w.a0, w.a1);
             if constexpr (EMIT && decltype(ahead)::value) rs_load_row<R>(frs, ra, row_ctl_of_words<R>(w.b0, w.b1), voff);  // for the step after this one
             RS_FWD_REBASE(cx.reb);
-            rs_fwd_x_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.x0, cx.mk, cx.moved);
+            rs_fwd_x_step<R, false, SW, FLAT>(E, Q.B, Q.A, Q.S, Q.x0, cx.mk, cx.moved);
             if constexpr (EMIT) {
                 float fv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) fv[r] = Q.B.c[r].m;
-                mid_emit<R, false>(sink, fv, rb.v, d, Q.x0, Q.y0, cx.mk, sblk, inv_tot, jr, cnt);
+                mid_emit<R, false>(sink, fv, rb.v, d, Q.x0, Q.y0, cx.mk, sblk, q_min, jr, cnt);
             } else {
                 rs_store_row<R>(frs, Q.B, cx, voff);
             }
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 rs_load_row<R>(frs, rb, row_ctl_of_words<R>(more ? w1.a0 : w.b0, more ? w1.a1 : w.b1), voff);
             }
             RS_FWD_REBASE(cy.reb);
-            rs_fwd_y_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.y0, cy.mk, cy.moved);
+            rs_fwd_y_step<R, false, SW, FLAT>(E, Q.A, Q.B, Q.S, Q.y0, cy.mk, cy.moved);
             if constexpr (decltype(last)::value) {
                 Q.e += rs_renorm<R>(Q.A, Q.B);
                 if constexpr (EMIT) sblk = note_s(smax, Q.e + eo) - pte;
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 float fv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) fv[r] = Q.A.c[r].m;
-                mid_emit<R, false>(sink, fv, ra.v, d + 1, Q.x0, Q.y0, cy.mk, sblk, inv_tot, jr, cnt);
+                mid_emit<R, false>(sink, fv, ra.v, d + 1, Q.x0, Q.y0, cy.mk, sblk, q_min, jr, cnt);
             } else {
                 rs_store_row<R>(frs, Q.A, cy, voff);
             }
@@ -232,13 +232,13 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             nxt = row_ctl_of_words<R>(q.b0, q.b1);
             if constexpr (EMIT) rs_load_row<R>(frs, ra, nxt, voff);  // for the step after this one
             RS_BWD_REBASE(reb);
-            rs_bwd_y_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+            rs_bwd_y_step<R, false, SW, FLAT>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
             m2 = m1, m1 = cur.moved;
             if constexpr (EMIT) {
                 float bv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) bv[r] = Q.B.c[r].m;
-                mid_emit<R, true>(sink, rb.v, bv, d, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
+                mid_emit<R, true>(sink, rb.v, bv, d, Q.x0, Q.y0, cur.mk, sblk, q_min, jr, cnt);
             } else {
                 rs_store_row<R>(frs, Q.B, cur, voff);
             }
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 if constexpr (EMIT) rs_load_row<R>(frs, rb, nxt, voff);
             }
             RS_BWD_REBASE(reb);
-            rs_bwd_x_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+            rs_bwd_x_step<R, false, SW, FLAT>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
             m2 = m1, m1 = cur.moved;
             if constexpr (decltype(last)::value) {
                 Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 float bv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) bv[r] = Q.A.c[r].m;
-                mid_emit<R, true>(sink, ra.v, bv, d - 1, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
+                mid_emit<R, true>(sink, ra.v, bv, d - 1, Q.x0, Q.y0, cur.mk, sblk, q_min, jr, cnt);
             } else {
                 // (not the cut row's: wavefront 0's forward row lies there.  A scalar test around the store alone: two variants of the pair behind
                 // a test would meet at a join, which is paid with a second copy of the rows' registers)
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             {
                 const RowCtl<R> cx = row_ctl_of_words<R>(w0.a0, w0.a1);
                 RS_FWD_REBASE(cx.reb);
-                rs_fwd_x_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.x0, cx.mk, cx.moved);
+                rs_fwd_x_step<R, false, SW, FLAT>(E, Q.B, Q.A, Q.S, Q.x0, cx.mk, cx.moved);
             }
             // F(c), five states, and F_match(c + 1) by slot (wavefront 1 knows how the two frames lie to each other: [9])
 #pragma unroll
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             ptm = unif(reinterpret_cast<float *>(lmisc)[10]);
             pte = uni(lmisc[11]);
             if (ptm > 0.f) {
-                inv_tot = 1.0f / ptm;
+                q_min = sink.threshold * ptm;
                 // rows c + 1 (held in B) and c + 2: the backward rows they pair with; then the Y-step that completes the pair
                 fhead(Y);
                 rs_load_row<R>(frs, rb, row_ctl_of_words<R>(w0.a0, w0.a1), voff);
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                     float fv[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) fv[r] = Q.B.c[r].m;
-                    mid_emit<R, false>(sink, fv, rb.v, d, Q.x0, Q.y0, cx.mk, sblk, inv_tot, jr, cnt);
+                    mid_emit<R, false>(sink, fv, rb.v, d, Q.x0, Q.y0, cx.mk, sblk, q_min, jr, cnt);
                 }
                 yhalf(Y, N, w0);
                 d += 2;
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                 cur = nxt;
                 nxt = read_row_ctl<R>(ctl, d - 1);
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                rs_bwd_x_step<R, true, SW, FLAT>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 if ((d & (RS_K - 1)) == 0) {
                     Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
             ptm = unif(reinterpret_cast<float *>(lmisc)[10]);
             pte = uni(lmisc[11]);
             if (ptm > 0.f) {
-                inv_tot = 1.0f / ptm;
+                q_min = sink.threshold * ptm;
                 // row c against its forward row, then k_dp_rs's blocks from c - 1 down
                 rs_load_row<R>(frs, ra, cur, voff);
                 rs_load_row<R>(frs, rb, nxt, voff);
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                     float bv[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) bv[r] = Q.A.c[r].m;
-                    mid_emit<R, true>(sink, ra.v, bv, c, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
+                    mid_emit<R, true>(sink, ra.v, bv, c, Q.x0, Q.y0, cur.mk, sblk, q_min, jr, cnt);
                 }
                 while (d >= 1) {  // whole blocks: d = c - 1 = RS_K m - 1
                     bhead(Y);
@@ -594,17 +594,21 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
 
 }  // namespace
 
+// sw: some loaded model has a short-gap switch (shortGapX <-> shortGapY); without one the two multiply-adds per cell and direction that would
+// add an exact zero are not issued.  flat: every loaded model's gap emissions are exactly 2^-2 for every base (the shipped ones' are): they come
+// from a select instead of the LDS tables.  Same bits either way (npr_rs.h).
 template <int R>
-static int launch_mid_rs_r(const KernelArgs &a, bool sw, int grid, hipStream_t s) {
-    if (sw) hipLaunchKernelGGL((k_dp_mid_rs<R, true>), dim3(grid), dim3(2 * WAVE), 0, s, a);
-    else hipLaunchKernelGGL((k_dp_mid_rs<R, false>), dim3(grid), dim3(2 * WAVE), 0, s, a);
+static int launch_mid_rs_r(const KernelArgs &a, bool sw, bool flat, int grid, hipStream_t s) {
+    if (sw) hipLaunchKernelGGL((k_dp_mid_rs<R, true, false>), dim3(grid), dim3(2 * WAVE), 0, s, a);
+    else if (flat) hipLaunchKernelGGL((k_dp_mid_rs<R, false, true>), dim3(grid), dim3(2 * WAVE), 0, s, a);
+    else hipLaunchKernelGGL((k_dp_mid_rs<R, false, false>), dim3(grid), dim3(2 * WAVE), 0, s, a);
     return static_cast<int>(hipGetLastError());
 }
-int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw) {
+int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw, bool flat) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (R == 1) return launch_mid_rs_r<1>(a, sw, grid, s);
-    if (R == 2) return launch_mid_rs_r<2>(a, sw, grid, s);
-    if (R == 4) return launch_mid_rs_r<4>(a, sw, grid, s);
+    if (R == 1) return launch_mid_rs_r<1>(a, sw, flat, grid, s);
+    if (R == 2) return launch_mid_rs_r<2>(a, sw, flat, grid, s);
+    if (R == 4) return launch_mid_rs_r<4>(a, sw, flat, grid, s);
     return static_cast<int>(hipErrorInvalidValue);
 }
 

@@ -19,7 +19,7 @@ namespace npr {
 
 namespace {
 
-template <int R, bool SW>
+template <int R, bool SW, bool FLAT>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? NPR_RS_WAVES2 : 1))) k_dp_rs(KernelArgs a) {
     // static LDS: the tables' addresses are compile-time constants and fold into the ds_read offsets
     __shared__ __attribute__((aligned(16))) RsTables ltab_s;
@@ -110,12 +110,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                 {
                     const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
                     RS_FWD_REBASE(cur.reb);
-                    rs_fwd_x_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+                    rs_fwd_x_step<R, false, SW, FLAT>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
                     rs_store_row<R>(frs, Q.B, cur, voff);
                 }
                 const RowCtl<R> cur = row_ctl_of_words<R>(w.b0, w.b1);
                 RS_FWD_REBASE(cur.reb);
-                rs_fwd_y_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
+                rs_fwd_y_step<R, false, SW, FLAT>(E, Q.A, Q.B, Q.S, Q.y0, cur.mk, cur.moved);
                 if constexpr (decltype(last)::value) {
                     Q.e += rs_renorm<R>(Q.A, Q.B);
                     if (lane == 0) fexp[(d + 1) / RS_K] = Q.e;
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
             const CtlPair w = wn;
             const RowCtl<R> cur = row_ctl_of_words<R>(w.a0, w.a1);
             RS_FWD_REBASE(cur.reb);
-            rs_fwd_x_step<R, true, SW>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
+            rs_fwd_x_step<R, true, SW, FLAT>(E, Q.B, Q.A, Q.S, Q.x0, cur.mk, cur.moved);
             rs_store_row<R>(frs, Q.B, cur, voff);
         }
         // total probability at the end corner (lX, lY): slot lX - x0 of the last anti-diagonal
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     rs_load_row<R>(frs, fb, nxt, voff);
                 }
                 RS_BWD_REBASE(reb);
-                rs_bwd_x_step<R, true, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                rs_bwd_x_step<R, true, SW, FLAT>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                 m2 = m1, m1 = cur.moved;
                 if ((d2 & (RS_K - 1)) == 0) Q.e += rs_renorm<R>(Q.A, Q.B);
                 rs_emit_pairs<R>(sink, Q.A, fa, d2, Q.x0, Q.y0, cur.mk, note_s(smax, fexp_c[d2 / RS_K] + Q.e - tot_e), inv_tot, jr, cnt);
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                     nxt = row_ctl_of_words<R>(q.b0, q.b1);
                     rs_load_row<R>(frs, fa, nxt, voff);  // for the step after this one
                     RS_BWD_REBASE(reb);
-                    rs_bwd_y_step<R, false, SW>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
+                    rs_bwd_y_step<R, false, SW, FLAT>(E, Q.B, Q.A, Q.S, Q.y0, cur.mk, m2);
                     m2 = m1, m1 = cur.moved;
                     rs_emit_pairs<R>(sink, Q.B, fb, d2, Q.x0, Q.y0, cur.mk, sblk, inv_tot, jr, cnt);
                     reb = cur.reb;
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
                         rs_load_row<R>(frs, fb, nxt, voff);
                     }
                     RS_BWD_REBASE(reb);
-                    rs_bwd_x_step<R, false, SW>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
+                    rs_bwd_x_step<R, false, SW, FLAT>(E, Q.A, Q.B, Q.S, Q.x0, cur.mk, m2);
                     m2 = m1, m1 = cur.moved;
                     if constexpr (decltype(last)::value) {
                         Q.e += rs_renorm<R>(Q.A, Q.B);
@@ -334,19 +334,21 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 
 size_t rs_lds_bytes() { return 0; }  // static LDS only
 
-// sw: some loaded model has a short-gap switch (shortGapX <-> shortGapY); without one the two multiply-adds per cell and
-// direction that would add an exact zero are not issued (same bits: npr_rs.h)
+// sw: some loaded model has a short-gap switch (shortGapX <-> shortGapY); without one the two multiply-adds per cell and direction that would
+// add an exact zero are not issued.  flat: every loaded model's gap emissions are exactly 2^-2 for every base (the shipped ones' are): they come
+// from a select instead of the LDS tables.  Same bits either way (npr_rs.h).
 template <int R>
-static int launch_rs_r(const KernelArgs &a, bool sw, int grid, hipStream_t s) {
-    if (sw) hipLaunchKernelGGL((k_dp_rs<R, true>), dim3(grid), dim3(WAVE), 0, s, a);
-    else hipLaunchKernelGGL((k_dp_rs<R, false>), dim3(grid), dim3(WAVE), 0, s, a);
+static int launch_rs_r(const KernelArgs &a, bool sw, bool flat, int grid, hipStream_t s) {
+    if (sw) hipLaunchKernelGGL((k_dp_rs<R, true, false>), dim3(grid), dim3(WAVE), 0, s, a);
+    else if (flat) hipLaunchKernelGGL((k_dp_rs<R, false, true>), dim3(grid), dim3(WAVE), 0, s, a);
+    else hipLaunchKernelGGL((k_dp_rs<R, false, false>), dim3(grid), dim3(WAVE), 0, s, a);
     return static_cast<int>(hipGetLastError());
 }
-int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw) {
+int launch_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw, bool flat) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (R == 1) return launch_rs_r<1>(a, sw, grid, s);
-    if (R == 2) return launch_rs_r<2>(a, sw, grid, s);
-    if (R == 4) return launch_rs_r<4>(a, sw, grid, s);
+    if (R == 1) return launch_rs_r<1>(a, sw, flat, grid, s);
+    if (R == 2) return launch_rs_r<2>(a, sw, flat, grid, s);
+    if (R == 4) return launch_rs_r<4>(a, sw, flat, grid, s);
     return static_cast<int>(hipErrorInvalidValue);
 }
 

@@ -156,6 +156,30 @@ __device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, fl
     exs = ex.x, exl = ex.y, eys = ey.x, eyl = ey.y;
 }
 
+// The emissions of one cell of a step.  Slots outside the band: up to NPR_RS_DEADCODE_MAX_R slots per lane they take the dead base code (every
+// emission 0: the cell comes out as exact zeros), above that the step runs under the band's lane mask.
+// FLAT: every loaded model emits every base from every gap state with probability exactly 2^-2 (all shipped ones do: blasr_hmm_0 / _20 / _40;
+// a model trained by EM does not).  The four gap emissions then carry one bit -- in the band or not -- and come from a select instead of two
+// 8-byte LDS loads per cell and direction; the same factor 0.25f or 0.f multiplies the same sums, so not a bit changes.
+template <int R, bool FLAT>
+__device__ __forceinline__ void rs_cell_emissions(const char *tab, uint64_t in_band, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
+    if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
+        if constexpr (FLAT) {
+            em = *reinterpret_cast<const float *>(tab + ((lanes_of(in_band) ? bx : RS_DEADX) + by));  // (a dead reference code alone: em8[6 * 5 + y] = 0 for every y)
+            exs = exl = eys = eyl = lanes_of(in_band) ? 0.25f : 0.f;
+        } else {
+            rs_emissions(tab, lanes_of(in_band) ? bx : RS_DEADX, lanes_of(in_band) ? by : RS_DEAD8, em, exs, exl, eys, eyl);
+        }
+    } else {
+        if constexpr (FLAT) {
+            em = *reinterpret_cast<const float *>(tab + (bx + by));
+            exs = exl = eys = eyl = 0.25f;
+        } else {
+            rs_emissions(tab, bx, by, em, exs, exl, eys, eyl);
+        }
+    }
+}
+
 // ---- the recurrence (same operand order as npr_cell.h, minus the scale factors) ----
 // forward: L = (x-1, y), M = (x-1, y-1), U = (x, y-1)
 // SW: whether the model has short-gap switches (shortGapX <-> shortGapY).  None of the shipped models has (13 of cPecan's 15
@@ -611,7 +635,7 @@ __device__ __forceinline__ void rs_clear_outside(RDiag<R> &io, const Masks<R> &m
 }
 
 // One forward anti-diagonal: `io` holds d-2 on entry and d on exit, `p1` holds d-1.  S.X / S.Y: X[x-1]*8, Y[y-1]*8.
-template <int R, bool CHK = true, bool SW = true>
+template <int R, bool CHK = true, bool SW = true, bool FLAT = false>
 __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
     x0 += 1;
@@ -623,17 +647,17 @@ __device__ __forceinline__ void rs_fwd_x_step(const StepEnv &E, RDiag<R> &io, co
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             o.c[r] = rs_fwd_cell<SW>(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl);
         } else {
-            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell<SW>(E.tr, p1.c[r], io.c[r], U.c[r], em, exs, exl, eys, eyl); });
         }
     }
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
     else rs_clear_outside<R>(io, mk, moved);
 }
-template <int R, bool CHK = true, bool SW = true>
+template <int R, bool CHK = true, bool SW = true, bool FLAT = false>
 __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &p1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
     y0 += 1;
@@ -645,10 +669,10 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, co
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             o.c[r] = rs_fwd_cell<SW>(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl);
         } else {
-            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             rs_put(io.c[r], mk.cell[r], [&] { return rs_fwd_cell<SW>(E.tr, L.c[r], io.c[r], p1.c[r], em, exs, exl, eys, eyl); });
         }
     }
@@ -656,7 +680,7 @@ __device__ __forceinline__ void rs_fwd_y_step(const StepEnv &E, RDiag<R> &io, co
     else rs_clear_outside<R>(io, mk, moved);
 }
 // One backward anti-diagonal d: `io` holds d+2 on entry and d on exit, `s1` holds d+1.  S.X / S.Y: X[x]*8, Y[y]*8.
-template <int R, bool CHK = true, bool SW = true>
+template <int R, bool CHK = true, bool SW = true, bool FLAT = false>
 __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &x0,
                                               const Masks<R> &mk, uint32_t moved) {
     x0 -= 1;
@@ -668,17 +692,17 @@ __device__ __forceinline__ void rs_bwd_x_step(const StepEnv &E, RDiag<R> &io, co
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             o.c[r] = rs_bwd_cell<SW>(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl);
         } else {
-            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell<SW>(E.tr, io.c[r], s1.c[r], Ys.c[r], em, exs, exl, eys, eyl); });
         }
     }
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) io = o;
     else rs_clear_outside<R>(io, mk, moved);
 }
-template <int R, bool CHK = true, bool SW = true>
+template <int R, bool CHK = true, bool SW = true, bool FLAT = false>
 __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, const RDiag<R> &s1, Streams<R> &S, int &y0,
                                               const Masks<R> &mk, uint32_t moved) {
     y0 -= 1;
@@ -690,10 +714,10 @@ __device__ __forceinline__ void rs_bwd_y_step(const StepEnv &E, RDiag<R> &io, co
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
         if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
-            rs_emissions(E.ltab, lanes_of(mk.cell[r]) ? S.X.b[r] : RS_DEADX, lanes_of(mk.cell[r]) ? S.Y.b[r] : RS_DEAD8, em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             o.c[r] = rs_bwd_cell<SW>(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl);
         } else {
-            rs_emissions(E.ltab, S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
+            rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], S.X.b[r], S.Y.b[r], em, exs, exl, eys, eyl);
             rs_put(io.c[r], mk.cell[r], [&] { return rs_bwd_cell<SW>(E.tr, io.c[r], Xs.c[r], s1.c[r], em, exs, exl, eys, eyl); });
         }
     }
