@@ -75,10 +75,12 @@ __device__ __forceinline__ RDiag<R> rs_shift_down(const RDiag<R> &in) {
     return o;
 }
 
-// ---- base streams: codes pre-multiplied by 8 (byte offsets into the tables below); code 4 (N) = 32 ----
-//      The read's codes (Y) by 8, the reference's (X) by 48 = 6 * 8: the match emission of (x, y) is then at byte offset bx + by of
-//      em8 -- one add per cell instead of a multiply and an add.
-constexpr int RS_YS = 8, RS_XS = 48;
+// ---- base streams: codes pre-multiplied by the byte strides of the tables below; code 4 is N ----
+//      The read's codes (Y) by 4, the reference's (X) by 24 = 6 * 4: the match emission of (x, y) is then at byte offset bx + by of
+//      em4 -- one add per cell instead of a multiply and an add.  (Round 3-4: 8 and 48, an 8-byte stride; round 5's counters showed
+//      two conflict cycles per LDS instruction once the match emission was the only look-up left -- at eight bytes per entry the 25
+//      live entries share 16 of the 32 banks; at four bytes each has its own.)
+constexpr int RS_YS = 4, RS_XS = 24;
 constexpr int RS_N8 = 4 * RS_YS, RS_NX = 4 * RS_XS;
 template <int S = RS_YS>
 __device__ __forceinline__ int base8(const uint8_t *seq, int len, int idx) {
@@ -121,17 +123,18 @@ __device__ __forceinline__ int feed8_take(Feed &f, const uint8_t *seq, int len, 
     else return __builtin_amdgcn_readlane(f.cur, uni(DIR * (idx - f.base)));
 }
 
-// ---- emission tables in LDS, laid out for byte offsets that are base codes * 8 ----
-//   em8[6x + y] (8-byte stride: byte offset bx + by), ex2[x] = (shortGapX, longGapX) at byte offset bx (48-byte stride),
-//   ey2[y] = (shortGapY, longGapY) at byte offset by
+// ---- emission tables in LDS, laid out for byte offsets that are scaled base codes ----
+//   em4[6x + y] (4-byte stride: byte offset bx + by; the 25 entries of real bases and N lie in 25 different banks),
+//   ex2[x] = (shortGapX, longGapX) at byte offset bx (24-byte stride), eys[y] / eyl[y] = shortGapY / longGapY at byte offset by
 //   Code 5 (byte offsets RS_DEAD8 / RS_DEADX) is the base of a slot OUTSIDE the band: all its emissions are 0, so every state of the cell
 //   computed there is an exact zero (two selects per cell instead of an EXEC-mask region per cell row and the clearing of what the band left behind; NPR_RS_DEADCODE_MAX_R).
 struct RsTables {
-    float em8[36][2];  // [6 x + y]
+    float em4[36];            // [6 x + y]
     float ex2[6][RS_XS / 4];  // [x][0 .. 1]
-    float ey2[6][2];
+    float eys[6], eyl[6];
 };
 constexpr int RS_DEAD8 = 5 * RS_YS, RS_DEADX = 5 * RS_XS;
+constexpr int RS_ZERO_EM = RS_DEADX;  // byte offset of an entry of em4 that is 0 and shares its bank with no live entry: (x = 5, y = 0), entry 30
 #ifndef NPR_RS_DEADCODE_MAX_R
 #define NPR_RS_DEADCODE_MAX_R 2  // slots per lane up to which it is used: one cell per lane gains 4 % (config 2: 1.75 -> 1.69 ms); two lost 1 % in round 3 and
                                  // gain since round 4 (no switch terms, seven wavefronts per SIMD): a 1/8 shard of config 3 -- a launch that is its longest read's
@@ -141,19 +144,19 @@ constexpr int RS_TABLE_FLOATS = sizeof(RsTables) / sizeof(float);
 __device__ __forceinline__ void rs_build_tables(RsTables *t, const DevModel *m, int tid, int nthreads) {
     for (int i = tid; i < 36; i += nthreads) {
         const int x = i / 6, y = i % 6;
-        t->em8[i][0] = (x < 5 && y < 5) ? m->em[5 * x + y] : 0.f, t->em8[i][1] = 0.f;
+        t->em4[i] = (x < 5 && y < 5) ? m->em[5 * x + y] : 0.f;
     }
     for (int i = tid; i < 6; i += nthreads) {
         t->ex2[i][0] = i < 5 ? m->ex[5 + i] : 0.f, t->ex2[i][1] = i < 5 ? m->ex[15 + i] : 0.f;
-        t->ey2[i][0] = i < 5 ? m->ey[10 + i] : 0.f, t->ey2[i][1] = i < 5 ? m->ey[20 + i] : 0.f;
+        t->eys[i] = i < 5 ? m->ey[10 + i] : 0.f, t->eyl[i] = i < 5 ? m->ey[20 + i] : 0.f;
     }
 }
 __device__ __forceinline__ void rs_emissions(const char *tab, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
-    constexpr int OFF_EX = offsetof(RsTables, ex2), OFF_EY = offsetof(RsTables, ey2);
+    constexpr int OFF_EX = offsetof(RsTables, ex2), OFF_EYS = offsetof(RsTables, eys), OFF_EYL = offsetof(RsTables, eyl);
     em = *reinterpret_cast<const float *>(tab + (bx + by));
     const float2 ex = *reinterpret_cast<const float2 *>(tab + OFF_EX + bx);
-    const float2 ey = *reinterpret_cast<const float2 *>(tab + OFF_EY + by);
-    exs = ex.x, exl = ex.y, eys = ey.x, eyl = ey.y;
+    exs = ex.x, exl = ex.y;
+    eys = *reinterpret_cast<const float *>(tab + OFF_EYS + by), eyl = *reinterpret_cast<const float *>(tab + OFF_EYL + by);
 }
 
 // The emissions of one cell of a step.  Slots outside the band: up to NPR_RS_DEADCODE_MAX_R slots per lane they take the dead base code (every
@@ -165,7 +168,8 @@ template <int R, bool FLAT>
 __device__ __forceinline__ void rs_cell_emissions(const char *tab, uint64_t in_band, int bx, int by, float &em, float &exs, float &exl, float &eys, float &eyl) {
     if constexpr (R <= NPR_RS_DEADCODE_MAX_R) {
         if constexpr (FLAT) {
-            em = *reinterpret_cast<const float *>(tab + ((lanes_of(in_band) ? bx : RS_DEADX) + by));  // (a dead reference code alone: em8[6 * 5 + y] = 0 for every y)
+            const int at = bx + by;
+            em = *reinterpret_cast<const float *>(tab + (lanes_of(in_band) ? at : RS_ZERO_EM));  // (every slot outside the band reads ONE zero entry: a broadcast)
             exs = exl = eys = eyl = lanes_of(in_band) ? 0.25f : 0.f;
         } else {
             rs_emissions(tab, lanes_of(in_band) ? bx : RS_DEADX, lanes_of(in_band) ? by : RS_DEAD8, em, exs, exl, eys, eyl);
