@@ -147,7 +147,7 @@ const char *npr_last_error(npr_ctx *ctx);
  * and changing no choice of kernel: NPR_TIMING=1 stage times on stderr, NPR_POISON=<byte> device buffers filled when handed
  * out, NPR_TILE_PROF=1 wait cycles of the stripe kernel, NPR_HOST_THREADS=<n> host worker threads.) */
 #define NPR_OPT_KERNEL 3           /* 1: the any-band kernel (k_dp_generic) for every task */
-#define NPR_OPT_ARITH 4            /* 1: one exponent per cell (k_dp_stair / k_dp_pair) instead of one per row (k_dp_rs / k_dp_mid_rs) */
+#define NPR_OPT_ARITH 4            /* 1: one exponent per cell (k_dp_stair) instead of one per row (k_dp_rs / k_dp_mid_rs) */
 #define NPR_OPT_PAIR 5             /* a read's two sweeps on two wavefronts: 0 the default rule (row-scaled arithmetic: every task of 64+ anti-diagonals), 1 never, 2 the tasks longer than a fair share, 3 always */
 #define NPR_OPT_NO_TILE 6          /* 1: no stripe kernel (wide bands take k_dp_wide / k_dp_generic) */
 #define NPR_OPT_NO_WIDE 7          /* 1: no multi-wavefront frame kernel */
@@ -217,13 +217,11 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
  *   7-9  generic kernel, LDS ring for at most 512 / 1024 / 2270 cells per anti-diagonal;  10  generic kernel, HBM ring
  *   11   register kernel on column stripes, any width (k_dp_tile; k_em_tile for npr_batch_expectations); takes what 3-10
  *        would take unless NPR_OPT_NO_TILE is set
- *   12-14  classes 0-2 / 15-17 with the forward and the backward sweep of a task on two wavefronts at once.  In row-scaled arithmetic
- *        k_dp_mid_rs<1|2|4> (round 5): the sweeps start at the two ends and MEET IN THE MIDDLE, each going on past the cut against the rows
- *        the other one stored -- a task's serial chain halves, no more bytes than k_dp_rs moves, the same bits; the default for every
- *        task of 64+ anti-diagonals (shorter ones stay in 15-17).  Under NPR_OPT_ARITH = 1 k_dp_pair<1|2|4>: both sweeps whole, then a
- *        pass over the rows of both; a class of more than 256 tasks that fills at most half of the launch's wavefront slots.
- *        NPR_OPT_PAIR 1: never, 3: every task, 2: the tasks longer than a wavefront's fair share of their class as far as second
- *        wavefronts are free
+ *   12-14  classes 15-17 with the forward and the backward sweep of a task on two wavefronts at once, k_dp_mid_rs<1|2|4> (round 5): the
+ *        sweeps start at the two ends and MEET IN THE MIDDLE, each going on past the cut against the rows the other one stored -- a task's
+ *        serial chain halves, no more bytes or instructions than k_dp_rs, the same bits; the default for every row-scaled task of 64+
+ *        anti-diagonals (shorter ones stay in 15-17).  NPR_OPT_PAIR 1: never, 2: only the tasks longer than a wavefront's fair share of
+ *        their class as far as second wavefronts are free
  *   15-17  classes 0-2 in row-scaled arithmetic (k_dp_rs<1|2|4>: one exponent per anti-diagonal row of the wavefront instead of
  *        one per cell, about 1.4 times the cells per second): every task of 0-2 unless NPR_OPT_ARITH = 1 is set or a loaded model's
  *        values can grow from one anti-diagonal to the next.  A task for which one exponent per row was not enough (a stretch of
@@ -233,7 +231,7 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* Which device arithmetic each segment (matrix split) of each read ran in, in read order: seg_off[n_reads + 1], arith[seg_off
  * [n_reads]] (pass arith == NULL for the offsets alone).  0: one exponent per cell (npr_cell.h: k_dp_tile, k_dp_generic, k_dp_wide
- * k_dp_stair / k_dp_pair); 1: one exponent per anti-diagonal row (npr_rs.h: k_dp_rs, k_dp_mid_rs; classes 15-17, 12-14).  Both are fp32 evaluations of the same recurrences (cactus_realign's forward / backward pass, reference call
+ * k_dp_stair); 1: one exponent per anti-diagonal row (npr_rs.h: k_dp_rs, k_dp_mid_rs; classes 15-17, 12-14).  Both are fp32 evaluations of the same recurrences (cactus_realign's forward / backward pass, reference call
  * site nanopore/analyses/utils.py:587) within the stated 1e-4 of the fp64 oracle; the parity tests ask so that they can
  * compare bit for bit with the matching CPU restatement (oracle/realign_oracle_f32.c / realign_oracle_rs.c). */
 int32_t npr_batch_segment_arith(const npr_batch *b, int64_t *seg_off, int32_t *arith, int64_t cap);

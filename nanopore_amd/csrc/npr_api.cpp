@@ -282,7 +282,7 @@ struct npr_batch {
     std::vector<int64_t> region_end;  // ... and one past its last (host copy: the E-step sizes its planes for the regions it uses)
     size_t scratch_cells = 0;  // forward scratch this batch needs from the context arena
     bool variable_regions = false;  // the one-wavefront frame launches have regions of their own size (not E-step capable)
-    bool pair_rs = false;  // classes 12-14 run k_dp_mid_rs (row-scaled arithmetic, the sweeps meet in the middle) rather than k_dp_pair
+    bool pair_rs = false;  // the batch was staged for the row-scaled kernels (classes 12-17: k_dp_mid_rs, k_dp_rs)
     DevBuf<int32_t> d_px, d_py;
     DevBuf<float> d_pp;
     int64_t slot_stride = 0;
@@ -530,7 +530,7 @@ bool build_stair_schedule(const Segment &s, int R, int NW, uint32_t *ctl, int64_
 // lane), the register kernel with NW wavefronts per task (k_dp_wide), the generic kernel with an LDS ring in three
 // width classes, the generic kernel with its ring in HBM.
 namespace {
-enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4, K_PAIR = 5, K_RS = 6, K_TILE_RS = 7 };
+enum { K_STAIR = 0, K_WIDE = 1, K_GENERIC_LDS = 2, K_GENERIC_GLOBAL = 3, K_TILE = 4, K_MID = 5, K_RS = 6, K_TILE_RS = 7 };
 struct KClass {
     int kind, R, NW;
     int slots() const { return 64 * R * NW; }
@@ -539,14 +539,14 @@ constexpr int kClasses = 19;
 constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STAIR, 4, 1}, {K_WIDE, 2, 4}, {K_WIDE, 2, 8},
                                         {K_WIDE, 4, 8}, {K_WIDE, 4, 12}, {K_GENERIC_LDS, 0, 0}, {K_GENERIC_LDS, 0, 0},
                                         {K_GENERIC_LDS, 0, 0}, {K_GENERIC_GLOBAL, 0, 0}, {K_TILE, 2, 0},
-                                        // k_dp_pair<R>: the one-wavefront frame classes 0-2 with the two sweeps on two wavefronts
-                                        {K_PAIR, 1, 1}, {K_PAIR, 2, 1}, {K_PAIR, 4, 1},
+                                        // k_dp_mid_rs<R>: the one-wavefront frame classes in row-scaled arithmetic with the two sweeps on two wavefronts that meet in the middle
+                                        {K_MID, 1, 1}, {K_MID, 2, 1}, {K_MID, 4, 1},
                                         // k_dp_rs<R>: the one-wavefront frame classes 0-2 in row-scaled arithmetic (npr_rs.h)
                                         {K_RS, 1, 1}, {K_RS, 2, 1}, {K_RS, 4, 1},
                                         // k_dp_tile_rs: class 11's column stripes in row-scaled arithmetic (one exponent per stripe row)
                                         {K_TILE_RS, 2, 0}};
 constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kFirstRs = 15, kTileRsClass = 18, kQueueSlots = 24;
-inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_PAIR || kClassTab[c].kind == K_RS; }
+inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_MID || kClassTab[c].kind == K_RS; }
 inline bool is_one_wave_kind(int kind) { return kind == K_STAIR || kind == K_RS; }
 inline bool is_tile_kind(int kind) { return kind == K_TILE || kind == K_TILE_RS; }  // column stripes, NW wavefronts per task  // one wavefront per task on the frame schedule
 // resident wavefronts per CU of the one-wavefront frame kernels (VGPR-limited: 71 / 80 / 162 registers: 7 / 6 / 3 per SIMD)
@@ -939,15 +939,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         }
         any_generic |= kClassTab[c].kind == K_GENERIC_LDS || kClassTab[c].kind == K_GENERIC_GLOBAL;
     }
-    // A read on ONE wavefront is a serial chain of 2 * (lX + lY) steps: a launch lasts at least as long as its longest task,
-    // and a class with fewer tasks than the chip has wavefront slots leaves the rest idle.  Tasks longer than a wavefront's
-    // fair share of their class go to k_dp_pair (both sweeps at once on two wavefronts: half the chain, twice the memory
-    // traffic), the longest first, as far as a second wavefront is to be had: all of them when the class does not fill the
-    // chip anyway, else those that would outlast the others.  NPR_OPT_PAIR 1 / 3: never / every task (A/B runs, tests).
-    // The one-wavefront frame tasks run in row-scaled arithmetic: classes 15-17, k_dp_rs -- every one of them, provided the
-    // loaded models let a row's values be renormalised every NPR_RS_K anti-diagonals (rs_model_ok); a task for which one exponent
-    // per row turns out not to be enough says so and npr_batch_run runs it again in class 0-2's kernel.  NPR_OPT_ARITH = 1: none
-    // (the per-cell-exponent kernels throughout, A/B).
+    // The one-wavefront frame tasks run in row-scaled arithmetic (npr_rs.h) -- every one of them, provided the loaded models let a row's
+    // values be renormalised every NPR_RS_K anti-diagonals (rs_model_ok); a task for which one exponent per row turns out not to be
+    // enough says so and npr_batch_run runs it again in class 0-2's kernel.  NPR_OPT_ARITH = 1: none (the per-cell-exponent kernels
+    // throughout, A/B).
     {
         bool rs = ctx->opt[NPR_OPT_ARITH] != 1 && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS;
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
@@ -961,38 +956,33 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
                 else if (cls_of[k] == kTileClass && ctx->opt[NPR_OPT_TILE_RS] != 0) cls_of[k] = static_cast<int8_t>(kTileRsClass);
             }
     }
+    // A read on ONE wavefront is a serial chain of 2 * (lX + lY) steps: a launch lasts at least as long as its longest task, and a class
+    // with fewer tasks than the chip has wavefront slots leaves the rest idle.  k_dp_mid_rs (classes 12-14, round 5) runs a task's two
+    // sweeps on two wavefronts that meet in the middle: half the chain for the bytes and instructions of k_dp_rs, so EVERY row-scaled
+    // task of MID_MIN_D anti-diagonals or more goes there (a 1/8 shard of configs[3]: DP launch 41.7 -> 28.5 ms, configs[1] 1.27 -> 0.75 ms,
+    // the headline batch 138.9 -> 131.6 ms with round 5's other changes); shorter ones stay with k_dp_rs.  (Rounds 3-4 had kernels with both
+    // sweeps whole and a third pass over the rows of both, k_dp_pair / k_dp_pair_rs, for classes that filled at most half of the chip.)
+    // NPR_OPT_PAIR 1: never; 2: only the tasks longer than a wavefront's fair share of their class, as far as second wavefronts are free;
+    // 0 / 3: every task.
     bool any_pair = false;
     {
-        // By default a class of more than 256 tasks that fill at most half of the chip's wavefront slots goes to the pair kernel as a whole
-        // (BASELINE.json configs[1]: 1000 reads on 7168 slots -- DP 1.71 -> 1.42 ms); a fuller class does not (a 1/8 shard of
-        // configs[3], 6250 reads, round 4: 41 -> 49.5 ms with every read on two wavefronts; with the longest ones only 59 -- the
-        // two launches then share one of the runtime's four hardware queues and run one after the other, tools/queues_of.py -- and
-        // 44 with GPU_MAX_HW_QUEUES=8, side by side: the second wavefronts compete with the reads that have one, and a higher
-        // s_setprio for them changes nothing).  NPR_OPT_PAIR 1: never; 2: the tasks longer than a wavefront's fair share; 3: every task.
         const int64_t pe = ctx->opt[NPR_OPT_PAIR];
-        const bool pair_all = pe == 3, pair_off = pe == 1, pair_long = pe == 2;
-        if (!pair_off && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS)
+        const bool pair_off = pe == 1, pair_long = pe == 2;
+        if (b->pair_rs && !pair_off)
             for (int c = 0; c < 3; ++c) {
                 std::vector<int32_t> mine;
                 int64_t cost = 0;
-                const int from = b->pair_rs ? kFirstRs + c : c;  // the one-wavefront class the tasks come from
                 for (int64_t k = 0; k < ntasks; ++k)
-                    if (cls_of[k] == from) mine.push_back(static_cast<int32_t>(k)), cost += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
+                    if (cls_of[k] == kFirstRs + c) mine.push_back(static_cast<int32_t>(k)), cost += static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
                 if (mine.empty()) continue;
-                const int64_t slots = static_cast<int64_t>(ctx->cu_count) * (b->pair_rs ? mid_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R));
+                const int64_t slots = static_cast<int64_t>(ctx->cu_count) * mid_waves_per_cu(kClassTab[c].R);
                 const int64_t n = static_cast<int64_t>(mine.size()), fair = cost / slots;
-                // (default rule of the kernel with a third pass, k_dp_pair -- and of round 3-4's k_dp_pair_rs --: not when the class fills more than half of the chip, or is too
-                // small for it to matter.  k_dp_mid_rs has no third pass and moves no more bytes than k_dp_rs: every task, round 5 -- a 1/8 shard of
-                // configs[3] 41.7 -> 29.4 ms, configs[1] 1.27 -> 0.77 ms, the headline batch 138.9 -> 137.1 ms)
-                const bool mid_all = b->pair_rs && !pair_long;
-                if (!pair_all && !pair_long && !mid_all && (2 * n > slots || n <= 256)) continue;
-                const bool whole = pair_all || !pair_long;
-                int64_t room = whole ? n : (n < slots ? slots - n : n);  // second wavefronts to be had
+                int64_t room = !pair_long ? n : (n < slots ? slots - n : n);  // second wavefronts to be had
                 std::sort(mine.begin(), mine.end(), [&](int32_t x, int32_t y) { return pseg[x].lX + pseg[x].lY > pseg[y].lX + pseg[y].lY; });
                 for (int32_t k : mine) {
                     const int64_t len = static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1;
-                    if (room <= 0 || (!whole && (len <= fair || len < 256))) break;
-                    if (b->pair_rs && len - 1 < MID_MIN_D) break;  // (sorted by length: the rest is shorter still; k_dp_mid_rs needs a block on either side of its cut)
+                    if (room <= 0 || (pair_long && (len <= fair || len < 256))) break;
+                    if (len - 1 < MID_MIN_D) break;  // (sorted by length: the rest is shorter still; k_dp_mid_rs needs a block on either side of its cut)
                     cls_of[k] = static_cast<int8_t>(kFirstPair + c), --room, any_pair = true;
                 }
             }
@@ -1116,8 +1106,8 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         L.width = cls_width[c];
         first += cls_count[c];
         int waves_per_cu;
-        if (kClassTab[c].kind == K_PAIR) {  // workgroups of two wavefronts
-            waves_per_cu = (b->pair_rs ? mid_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R)) / 2;
+        if (kClassTab[c].kind == K_MID) {  // workgroups of two wavefronts
+            waves_per_cu = mid_waves_per_cu(kClassTab[c].R) / 2;
             if (ctx->overlap == 1 && kClassTab[c].R <= 2) waves_per_cu -= 2;  // (a wavefront slot per SIMD left free: see the one-wavefront classes below)
             L.wcap = 0;
             L.lds = stair_lds_bytes();
@@ -1194,7 +1184,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
                           !force_generic;
     if (any_pair) b->variable_regions = true;  // (their regions hold two sets of rows: not a layout the E-step kernels know)
     auto uniform = [&](const npr_batch::Launch &L) {
-        return &L != tileL && kClassTab[L.cls].kind != K_PAIR && !(b->variable_regions && is_one_wave_kind(kClassTab[L.cls].kind));
+        return &L != tileL && kClassTab[L.cls].kind != K_MID && !(b->variable_regions && is_one_wave_kind(kClassTab[L.cls].kind));
     };
     int64_t sum_grid = 0;
     for (auto &L : b->launches)
@@ -1241,9 +1231,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     };
     for (auto &L : b->launches) {
         const int kind = kClassTab[L.cls].kind;
-        if ((is_one_wave_kind(kind) && b->variable_regions && !uniform(L)) || kind == K_PAIR) {
-            const int64_t sets = kind == K_PAIR && !b->pair_rs ? 2 : 1;  // k_dp_pair keeps the backward rows too; k_dp_mid_rs's two sweeps share one set
-            if (own_regions(L, [&](int32_t g) { return sets * ((pad_of[g] + 63) & ~int64_t(63)); }) != NPR_OK)
+        if ((is_one_wave_kind(kind) && b->variable_regions && !uniform(L)) || kind == K_MID) {
+            // (k_dp_mid_rs's two sweeps share one set of rows: the forward one stores up to the cut, the backward one above it)
+            if (own_regions(L, [&](int32_t g) { return (pad_of[g] + 63) & ~int64_t(63); }) != NPR_OK)
                 return fail(ctx, NPR_ERR_NOMEM, "npr_batch_create: not enough device memory for the forward scratch of the largest task");
         }
     }
@@ -1386,7 +1376,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         a.region = L.own_regions ? b->d_region.p + L.region_first : nullptr;
         a.prof = d_prof.p;
         const KClass &kc = kClassTab[L.cls];
-        const int rc = kc.kind == K_PAIR   ? (b->pair_rs ? launch_mid_rs(a, kc.R, L.grid, s, sw, flat) : launch_pair(a, kc.R, L.grid, s))
+        const int rc = kc.kind == K_MID   ? launch_mid_rs(a, kc.R, L.grid, s, sw, flat)
                        : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw, flat)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
@@ -1413,7 +1403,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     b->outs.resize(b->tasks.size());
     b->task_rerun.assign(b->tasks.size(), 0);
     for (const auto &L : b->launches) {
-        if (kClassTab[L.cls].kind != K_RS && kClassTab[L.cls].kind != K_TILE_RS && !(kClassTab[L.cls].kind == K_PAIR && b->pair_rs)) continue;
+        if (kClassTab[L.cls].kind != K_RS && kClassTab[L.cls].kind != K_TILE_RS && kClassTab[L.cls].kind != K_MID) continue;
         HIP_TRY(ctx, hipMemcpy(b->outs.data() + L.first, b->d_outs.p + L.first, sizeof(TaskOut) * L.count, hipMemcpyDeviceToHost));
         std::vector<int32_t> again;
         for (int k = L.first; k < L.first + L.count; ++k)
@@ -1471,7 +1461,7 @@ int32_t npr_batch_segment_arith(const npr_batch *b, int64_t *seg_off, int32_t *a
     if (!b || !seg_off) return NPR_ERR_INVALID;
     std::vector<int8_t> of_task(b->tasks.size(), 0);
     for (const auto &L : b->launches)
-        if (kClassTab[L.cls].kind == K_RS || (kClassTab[L.cls].kind == K_PAIR && b->pair_rs))
+        if (kClassTab[L.cls].kind == K_RS || kClassTab[L.cls].kind == K_MID)
             for (int k = L.first; k < L.first + L.count; ++k) of_task[k] = (static_cast<size_t>(k) < b->task_rerun.size() && b->task_rerun[k]) ? 0 : 1;
     int64_t n = 0;
     for (int64_t r = 0; r < b->n_reads; ++r) {
@@ -2666,7 +2656,7 @@ int32_t npr_batch_rs_forward(npr_batch *b, int64_t read_index, float *Fm_v, int3
         const Task &t = b->tasks[k];
         int R = 0;
         for (const auto &L : b->launches)
-            if (k >= L.first && k < L.first + L.count && (kClassTab[L.cls].kind == K_RS || (kClassTab[L.cls].kind == K_PAIR && b->pair_rs))) R = kClassTab[L.cls].R;
+            if (k >= L.first && k < L.first + L.count && (kClassTab[L.cls].kind == K_RS || kClassTab[L.cls].kind == K_MID)) R = kClassTab[L.cls].R;
         if (R == 0 || t.ctl_off < 0) return fail(ctx, NPR_ERR_STATE, "npr_batch_rs_forward: the read has a segment that k_dp_rs does not run");
         KernelArgs a = make_args(b);
         a.tasks = b->d_tasks.p + k, a.ntasks = 1, a.outs = d_out1.p, a.slot_base = 0, a.region = nullptr;

@@ -285,7 +285,6 @@ int launch_mea_gather(const MeaArgs &a, void *stream);
 int launch_em_wide(const KernelArgs &a, int R, int NW, int grid, void *stream);
 int launch_em_tile(const KernelArgs &a, int R, int grid, void *stream);  // k_em_tile: the E-step on column stripes
 size_t em_tile_lds_bytes(int nw);
-int launch_pair(const KernelArgs &a, int R, int grid, void *stream);
 // k_dp_rs<R> (npr_kernel_rs.hip): the one-wavefront frame kernel in row-scaled arithmetic (npr_rs.h) -- one exponent per
 // anti-diagonal row instead of one per cell.  A task's scratch region (8 bytes per cell of its frame schedule, as for
 // k_dp_stair) holds the forward rows at 4 bytes per cell in its first half and the row exponents, one word per NPR_RS_K
@@ -322,7 +321,7 @@ inline int mid_waves_per_cu(int R) { return R == 1 ? 24 : (R == 2 ? 4 * NPR_MID_
 int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw, bool flat);
 int launch_tile_rs(const KernelArgs &a, int NW, int grid, void *stream);  // k_dp_tile_rs: k_dp_tile's stripes, one exponent per stripe row
 size_t tile_rs_lds_bytes(int nw);
-size_t rs_lds_bytes();  // k_dp_pair: k_dp_stair's sweeps on two wavefronts at once
+size_t rs_lds_bytes();
 int em_tile_waves();
 int em_tile_waves_per_cu();
 size_t em_wide_lds_bytes(int nw);

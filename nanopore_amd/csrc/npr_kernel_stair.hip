@@ -276,318 +276,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(R == 
 }
 
 // =====================================================================================================================
-// k_dp_pair<R>: k_dp_stair with the two sweeps of a read on TWO wavefronts at the same time (round 3).
-//
-// One wavefront per read makes a read a serial chain of 2 * (lX + lY) steps, so a launch lasts at least as long as its
-// longest read and a batch with fewer reads than the chip has wavefront slots leaves the rest of them idle
-// (BASELINE.json configs[1]: 1000 reads on 7168 slots; one rank's eighth of configs[3]; the longest reads of any chunk).
-// The forward and the backward sweep do not depend on each other -- only the posterior needs both --, so here wavefront 0
-// of a two-wavefront workgroup runs the forward sweep exactly as k_dp_stair does (storing its match rows) while wavefront 1
-// runs the backward sweep, storing ITS match rows in a second scratch area instead of meeting the forward rows on the
-// way; after one barrier both wavefronts stream the two sets of rows back, half of the anti-diagonals each, and emit the
-// posteriors.  Same cells, same total (the forward sweep's), same posterior expression: the same bits as k_dp_stair; the
-// pairs land in the task's list in another order (slots claimed from an LDS counter), which every consumer sorts away.
-// The price is memory traffic (the backward rows are stored and re-read: 32 B/cell instead of 16), so the host sends a
-// task here only when its chain is what a launch would wait for (npr_api.cpp: tasks longer than a wavefront's fair share).
-// =====================================================================================================================
-template <int R>
-__device__ __forceinline__ void emit_pairs_shared(const PairSink &S, const FRow<R> &bq, const FRow<R> &f, int d, int x0, int y0, const Masks<R> &mk,
-                                                  int tot_e, float inv_tot, const int (&jr)[R], int *lds_cnt) {
-    float p[R];
-    uint64_t hit[R], any = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        p[r] = posterior(f.v[r], f.e[r], bq.v[r], bq.e[r], tot_e, inv_tot);
-        hit[r] = __ballot(p[r] >= S.threshold) & mk.cell[r];
-        any |= hit[r];
-    }
-    if (d >= 2 && any) {
-        int total = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) total += __popcll(hit[r]);
-        int base = 0;
-        if (threadIdx.x % WAVE == 0) base = atomicAdd(lds_cnt, total);
-        base = uni(base);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (hit[r]) {
-                const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
-                const int slot = base + before;
-                if (__builtin_amdgcn_inverse_ballot_w64(hit[r]) && slot < S.cap) {
-                    S.px[S.off + slot] = x0 + jr[r] - 1 + S.xs;
-                    S.py[S.off + slot] = y0 - jr[r] - 1 + S.ys;
-                    S.pp[S.off + slot] = p[r];
-                }
-                base += __popcll(hit[r]);
-            }
-        }
-    }
-}
-
-// the rebase a control word asks for, whatever the class's word format
-template <int R>
-__device__ __forceinline__ int ctl_rebase(uint32_t w) {
-    return R == 2 ? static_cast<int>((w >> 28) & 3u) - 1 : static_cast<int>((w >> 26) & 3u) - 1;
-}
-
-template <int R>
-__global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R == 2 ? 6 : 1))) k_dp_pair(KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *lmodel = reinterpret_cast<float *>(smem);
-    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] sum of rebases, [5] pair counter, [6] next task
-
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
-    char *const F = a.F + uni64(a.region[blockIdx.x]) * 8;  // the workgroup's region: forward rows, then backward rows
-    const int voff = 8 * R * lane;
-    int jr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
-
-    int t = blockIdx.x;
-    while (t < a.ntasks) {
-        const Task *tp = a.tasks + t;
-        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off), pair_off = uni64(tp->pair_off);
-        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap), flags = uni(tp->flags),
-                  model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
-        const int64_t half = (static_cast<int64_t>(static_cast<uint32_t>(uni(tp->cells_pad))) + 63) & ~int64_t(63);  // cells of the forward rows
-        cptr32 ctl = (cptr32)(a.ctl + 2 * ctl_off);
-        const __amdgpu_buffer_rsrc_t frs = task_rsrc<R>(F), brs = task_rsrc<R>(F + half * 8);
-        const int rs = flags & 1, re = (flags >> 1) & 1;
-
-        __syncthreads();
-        {
-            const float *gm = reinterpret_cast<const float *>(a.models + model);
-            for (int i = threadIdx.x; i < MODEL_FLOATS; i += 2 * WAVE) lmodel[i] = gm[i];
-            if (threadIdx.x < 8) lmisc[threadIdx.x] = threadIdx.x == 1 || threadIdx.x == 3 ? E_DEAD : 0;
-        }
-        __syncthreads();
-        StepEnv E;
-        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
-        E.ltab = reinterpret_cast<const char *>(lmodel);
-        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
-        {
-            Trans tr = load_trans(E.mdl->T);
-            if constexpr (R >= NPR_T_SGPR_MIN_R) {
-                tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
-                tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
-                tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
-                tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
-            }
-            E.tr = tr;
-        }
-        const DevModel *mdl = E.mdl;
-        const RowCtl<R> c0 = read_row_ctl<R>(ctl, 0);
-        const int j0 = c0.jlo;  // slot of the lattice point (0, 0)
-        // where the frame stands on the last anti-diagonal: an X-step into every odd one, a Y-step into every even one, and the
-        // rebases of the schedule (the forward sweep arrives there by itself; the backward sweep starts there)
-        {
-            int sum = 0;
-            const uint32_t *gw = a.ctl + 2 * ctl_off;
-            for (int dd = 1 + static_cast<int>(threadIdx.x); dd <= D; dd += 2 * WAVE) sum += ctl_rebase<R>(gw[2 * dd + 1]);
-            if (sum) atomicAdd(&lmisc[4], sum);
-        }
-        __syncthreads();
-        const int rebs = uni(lmisc[4]);
-        const int xD = -j0 + (D + 1) / 2 + rebs, yD = j0 + D / 2 - rebs;
-
-        Diag<R> A = dead_diag<R>(), B = dead_diag<R>();
-        Streams<R> S;
-        if (wv == 0) {
-            // =============================== wavefront 0: forward, as k_dp_stair ===============================
-            int x0 = -j0, y0 = j0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                S.X.b[r] = base4(E.X, lX, x0 + jr[r] - 1);
-                S.Y.b[r] = base4(E.Y, lY, y0 - jr[r] - 1);
-            }
-            S.xcap = S.ycap = 16;
-            feed_init<+1>(S.fx, E.X, lX, x0 + 64 * R - 1, lane);
-            feed_init<+1>(S.fy, E.Y, lY, y0, lane);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (jr[r] == j0) {
-                    Cell c;
-                    c.m = mdl->start[rs * 5 + 0], c.sx = mdl->start[rs * 5 + 1], c.sy = mdl->start[rs * 5 + 2];
-                    c.lx = mdl->start[rs * 5 + 3], c.ly = mdl->start[rs * 5 + 4];
-                    normalise(c, 0);
-                    A.c[r] = c;
-                }
-            store_row<R>(frs, A, c0, voff);
-            RowCtl<R> nx = c0;
-            if (D >= 1) nx = read_row_ctl<R>(ctl, 1);
-            int d = 1;
-            cptr32 cp = ctl + 2;
-            for (; d + 1 <= D; d += 2, cp += 4) {
-                RowCtl<R> cur = nx;
-                nx = read_row_ctl_at<R>(cp + 2);
-                if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-                fwd_x_step<R>(d, E, B, A, S, x0, cur.mk);
-                store_row<R>(frs, B, cur, voff);
-                cur = nx;
-                if (d + 2 <= D) nx = read_row_ctl_at<R>(cp + 4);
-                if (cur.reb) fwd_rebase<R>(E, cur.reb, A, B, S, x0, y0);
-                fwd_y_step<R>(d + 1, E, A, B, S, y0, cur.mk);
-                store_row<R>(frs, A, cur, voff);
-            }
-            if (d <= D) {
-                if (nx.reb) fwd_rebase<R>(E, nx.reb, A, B, S, x0, y0);
-                fwd_x_step<R>(d, E, B, A, S, x0, nx.mk);
-                store_row<R>(frs, B, nx, voff);
-            }
-            const int je = lX - x0;
-            const bool oddD = D & 1;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (jr[r] == je) {
-                    const Cell c = oddD ? B.c[r] : A.c[r];
-                    const float raw = dot5(mdl->end + re * 5, c);
-                    float tm = 0.f;
-                    int te = E_DEAD;
-                    if (raw > 0.f) {
-                        int k;
-                        tm = __builtin_frexpf(raw, &k);
-                        te = c.e + k;
-                    }
-                    reinterpret_cast<float *>(lmisc)[0] = tm;
-                    lmisc[1] = te;
-                }
-        } else {
-            // ===================== wavefront 1: backward, as k_dp_stair's, its match rows stored =====================
-            int x0 = xD, y0 = yD;
-            const bool oddD = D & 1;
-            RowCtl<R> cur = read_row_ctl<R>(ctl, D);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                S.X.b[r] = base4(E.X, lX, x0 + jr[r]);
-                S.Y.b[r] = base4(E.Y, lY, y0 - jr[r]);
-                if (x0 + jr[r] == lX) {
-                    Cell c;
-                    c.m = mdl->end[re * 5 + 0], c.sx = mdl->end[re * 5 + 1], c.sy = mdl->end[re * 5 + 2];
-                    c.lx = mdl->end[re * 5 + 3], c.ly = mdl->end[re * 5 + 4];
-                    normalise(c, 0);
-                    if (oddD) B.c[r] = c; else A.c[r] = c;
-                }
-            }
-            S.xcap = S.ycap = 16;
-            feed_init<-1>(S.fx, E.X, lX, x0 - 1, lane);
-            feed_init<-1>(S.fy, E.Y, lY, y0 - 64 * R, lane);
-            store_row<R>(brs, oddD ? B : A, cur, voff);
-            RowCtl<R> nxt = cur;
-            if (D >= 1) nxt = read_row_ctl<R>(ctl, D - 1);
-            int d2 = D - 1;
-            if (oddD) {  // peel one even anti-diagonal so that the loop below always starts on an odd one
-                const int reb = cur.reb;
-                cur = nxt;
-                if (d2 >= 1) nxt = read_row_ctl<R>(ctl, d2 - 1);
-                if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(d2, E, A, B, S, x0, cur.mk);
-                store_row<R>(brs, A, cur, voff);
-                d2 -= 1;
-            }
-            cptr32 cq = ctl + 2 * static_cast<int64_t>(d2 - 2);
-            for (; d2 >= 1; d2 -= 2, cq -= 4) {
-                int reb = cur.reb;
-                cur = nxt;
-                nxt = read_row_ctl_at<R>(cq + 2);
-                if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_y_step<R>(d2, E, B, A, S, y0, cur.mk);
-                store_row<R>(brs, B, cur, voff);
-                reb = cur.reb;
-                cur = nxt;
-                if (d2 >= 2) nxt = read_row_ctl_at<R>(cq);
-                if (reb) bwd_rebase<R>(E, reb, A, B, S, x0, y0);
-                bwd_x_step<R>(d2 - 1, E, A, B, S, x0, cur.mk);
-                store_row<R>(brs, A, cur, voff);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (jr[r] == j0) {
-                    const Cell cz = A.c[r];
-                    const float raw = dot5(mdl->start + rs * 5, cz);
-                    float bm = 0.f;
-                    int be = E_DEAD;
-                    if (raw > 0.f) {
-                        int k;
-                        bm = __builtin_frexpf(raw, &k);
-                        be = cz.e + k;
-                    }
-                    reinterpret_cast<float *>(lmisc)[2] = bm;
-                    lmisc[3] = be;
-                }
-        }
-        __builtin_amdgcn_s_waitcnt(0);  // the rows of both sweeps are on their way to memory before the barrier is passed
-        __threadfence_block();
-        __syncthreads();
-        const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
-        const int tot_e = uni(lmisc[1]);
-        TaskOut out;
-        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]), out.btot_e = uni(lmisc[3]);
-        out.npairs = 0, out.status = NPR_OK;
-        const bool alive = tot_m > 0.f;
-        if (!alive) out.status = NPR_ERR_ZERO_PROB, out.btot_m = 0.f, out.btot_e = E_DEAD;
-
-        // ================= both: the posteriors of half of the anti-diagonals each, rows streamed back =================
-        // Pure streaming, arranged so that nothing waits for memory row by row: the control words of 64 anti-diagonals come
-        // with ONE vector load (a lane each) and are handed out by v_readlane -- through the scalar cache every row cost a
-        // dependent s_load --, and the row loads of G anti-diagonals are issued before the first of them is used.  (With one
-        // row in flight this pass cost as much as the sweeps: C2 no faster than one wavefront per read.)
-        if (alive) {
-            const float inv_tot = 1.0f / tot_m;
-            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
-            constexpr int G = R == 1 ? 8 : 4;
-            const int mid = D / 2;  // wavefront 0: d = 0 .. mid walking up from (0, 0); wavefront 1: d = D .. mid + 1 walking down
-            const int first = wv == 0 ? 0 : D, dir = wv == 0 ? 1 : -1, count = wv == 0 ? mid + 1 : D - mid;
-            int x0 = wv == 0 ? -j0 : xD, y0 = wv == 0 ? j0 : yD;  // the frame of anti-diagonal `first`
-            const uint2 *gw = reinterpret_cast<const uint2 *>(a.ctl + 2 * ctl_off);
-            FRow<R> fr[G], br[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int r = 0; r < R; ++r) fr[g].v[r] = br[g].v[r] = 0.f, fr[g].e[r] = br[g].e[r] = E_DEAD;
-            for (int base = 0; base < count; base += WAVE) {
-                const int rows = min(WAVE, count - base);
-                uint2 w = make_uint2(0u, 0u);
-                if (lane < rows) w = gw[first + dir * (base + lane)];  // lane l: the words of the l-th anti-diagonal of this block
-                for (int q = 0; q < rows; q += G) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        if (q + g < rows) {
-                            const RowCtl<R> c = row_ctl_of_words<R>(__builtin_amdgcn_readlane(w.x, q + g), __builtin_amdgcn_readlane(w.y, q + g));
-                            load_row<R>(frs, fr[g], c, voff), load_row<R>(brs, br[g], c, voff);
-                        }
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        if (q + g < rows) {
-                            const int d = first + dir * (base + q + g);
-                            const RowCtl<R> c = row_ctl_of_words<R>(__builtin_amdgcn_readlane(w.x, q + g), __builtin_amdgcn_readlane(w.y, q + g));
-                            if (wv == 0 && d > 0) {  // walking up: the rebase that leads into d, then its step
-                                x0 += c.reb, y0 -= c.reb;
-                                if (d & 1) x0 += 1; else y0 += 1;
-                            }
-                            emit_pairs_shared<R>(sink, br[g], fr[g], d, x0, y0, c.mk, tot_e, inv_tot, jr, &lmisc[5]);
-                            if (wv != 0) {  // walking down: undo the step into d, then the rebase that led into it
-                                if (d & 1) x0 -= 1; else y0 -= 1;
-                                x0 -= c.reb, y0 += c.reb;
-                            }
-                        }
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            out.npairs = lmisc[5];
-            if (out.npairs > pair_cap) out.status = NPR_ERR_CAPACITY;
-            a.outs[t] = out;
-            lmisc[6] = atomicAdd(a.queue, 1);
-        }
-        __syncthreads();
-        t = uni(lmisc[6]) + static_cast<int>(gridDim.x);
-    }
-}
-
-// =====================================================================================================================
 // k_dp_wide<R, NW>: the same register-resident sweep for bands too wide for one wavefront.  A workgroup of NW wavefronts
 // holds ONE frame of NW*64*R slots, wavefront w the slots [w*64R, (w+1)*64R).  What changes against k_dp_stair:
 //   * the neighbour that crosses a wavefront boundary comes through LDS: after every anti-diagonal each wavefront
@@ -1688,20 +1376,6 @@ int launch_em_stair(const KernelArgs &a, int R, int grid, void *stream) {
         hipLaunchKernelGGL(k_em_stair<2>, dim3(grid), dim3(WAVE), lds, s, a);
     else if (R == 4)
         hipLaunchKernelGGL(k_em_stair<4>, dim3(grid), dim3(WAVE), lds, s, a);
-    else
-        return static_cast<int>(hipErrorInvalidValue);
-    return static_cast<int>(hipGetLastError());
-}
-
-int launch_pair(const KernelArgs &a, int R, int grid, void *stream) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = stair_lds_bytes();
-    if (R == 1)
-        hipLaunchKernelGGL(k_dp_pair<1>, dim3(grid), dim3(2 * WAVE), lds, s, a);
-    else if (R == 2)
-        hipLaunchKernelGGL(k_dp_pair<2>, dim3(grid), dim3(2 * WAVE), lds, s, a);
-    else if (R == 4)
-        hipLaunchKernelGGL(k_dp_pair<4>, dim3(grid), dim3(2 * WAVE), lds, s, a);
     else
         return static_cast<int>(hipErrorInvalidValue);
     return static_cast<int>(hipGetLastError());

@@ -6,7 +6,7 @@ import pytest
 
 from nanopore_amd import _lib
 
-from helpers import load_model_arrays, orc, seg_arith_of
+from helpers import cigar_spans, load_model_arrays, orc, seg_arith_of
 
 pytestmark = pytest.mark.gpu
 
@@ -64,6 +64,21 @@ def test_north_star_shape_properties_and_oracle_sample(gpu_ctx):
         assert [tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]] == m["ops"]
         order = np.lexsort((m["py"], m["px"]))
         assert np.array_equal(pp[poff[i]:poff[i + 1]], m["pp"].astype(np.float32)[order])
+        # ... and against the fp64 log-space oracle at this shape: every posterior within the 1e-4 north_star states (a pair may sit on
+        # either side of the 0.01 threshold), the cigar identical or differing only where an exact tie is placed, the likelihood to 2e-6
+        m64 = orc.realign_read(h, P, X, Y, g, precision=0)
+        dev = {(int(a), int(c)): float(v) for a, c, v in zip(px[poff[i]:poff[i + 1]], py[poff[i]:poff[i + 1]], pp[poff[i]:poff[i + 1]])}
+        ref = {(int(a), int(c)): float(v) for a, c, v in zip(m64["px"], m64["py"], m64["pp"])}
+        worst = 0.0
+        for k in set(dev) | set(ref):
+            a, c = dev.get(k), ref.get(k)
+            if a is None or c is None:
+                assert abs((a if a is not None else c) - 0.01) < 1e-4
+            else:
+                worst = max(worst, abs(a - c))
+        assert worst < 1e-4, worst
+        assert res["loglik"][i] == pytest.approx(m64["total_ll"], rel=2e-6)
+        assert cigar_spans(m64["ops"]) == cigar_spans([tuple(int(v) for v in r) for r in ops[off[i]:off[i + 1]]])
 
 
 def test_north_star_windowed_guides_match_explicit_slices(gpu_ctx):
