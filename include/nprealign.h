@@ -202,10 +202,13 @@ int32_t npr_batch_create_at(npr_ctx *ctx, const npr_params *params, int64_t n_re
  * resident in HBM.  Blocks until done; kernel_ms (nullable) receives the HIP-event time of the DP launch
  * measured on the context's stream.  May be called repeatedly (benchmarks). */
 int32_t npr_batch_run(npr_batch *b, float *kernel_ms);
-/* Stage 3: MEA chain / rescore, cigars.  In NPR_MODE_REALIGN the chain and the cigar are computed on the device from
- * the posterior pairs where they lie (integer arithmetic: the same ops and scores as the host stage, npr_mea_cigar) and
- * only the run-length ops come back; the other modes, and batches whose tables do not fit the device, copy the pairs
- * to the host and chain there. */
+/* Stage 3: MEA chain / rescore, cigars.  In NPR_MODE_REALIGN and NPR_MODE_ALL_POSTERIORS the chain and the cigar are computed on
+ * the device from the posterior pairs where they lie (integer arithmetic: the same ops and scores as the host stage, npr_mea_cigar)
+ * and only the run-length ops come back.  In NPR_MODE_RESCORE_ORIGINAL the guide's M columns -- spread into a table on the device
+ * when the batch was staged -- are looked up where the pairs lie and summed in fixed point (the host stage's double exactly, npr_rescore);
+ * eight bytes per read come back, and the cigars are the guide's (made when npr_batch_ops / npr_batch_ops_packed ask).  No mode moves
+ * the pairs over PCIe unless npr_batch_pairs asks for them.  Batches whose tables do not fit the device, a rescore sum that could not be
+ * exact (a threshold below 2^-20, a guide of 2^23 M columns) and NPR_OPT_HOST_MEA copy the pairs to the host and finish there. */
 int32_t npr_batch_finish(npr_batch *b);
 void npr_batch_destroy(npr_batch *b);
 
