@@ -1717,25 +1717,40 @@ int32_t device_mea(npr_batch *b) {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
         const size_t need = al(8 * 5 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (12 * total + 16)) +
                             al(4 * 5 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]) + al(4 * (4 * n_pieces + 4 * n));
-        const bool in_arena = !ctx->overlap && ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells) * 8 && ctx->opt[NPR_OPT_MEA_OWN_SCRATCH] == 0;
-        char *cur = ctx->arena->F;
-        if (in_arena && poison_byte() >= 0) {  // the DP launches are done (their streams feed this one): the tables start from poison
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            poison(ctx->arena->F, need);
-        }
-        auto take = [&](auto &buf, size_t count) -> hipError_t {
-            using T = std::remove_pointer_t<decltype(buf.p)>;
-            if (!in_arena) return buf.reserve(count);
-            buf.borrow(reinterpret_cast<T *>(cur), count);
-            cur += al(sizeof(T) * count);
-            return hipSuccess;
-        };
-        if ((e = take(m.off, 5 * (n + 1))) != hipSuccess || (e = take(m.mass, n)) != hipSuccess || (e = take(m.od, n + 1)) != hipSuccess ||
-            (e = take(m.cnt, n_cnt)) != hipSuccess || (e = take(m.start, n_cnt)) != hipSuccess || (e = take(m.col, ry[n] + 1)) != hipSuccess ||
-            (e = take(m.sorted, 12 * total + 16)) != hipSuccess || (e = take(m.small, 5 * n)) != hipSuccess || (e = take(m.tmp, 2 * ot[n])) != hipSuccess ||
-            (e = take(m.map, 3 * n + ntask_map)) != hipSuccess || (e = take(m.dense, ot[n])) != hipSuccess ||
-            (e = take(m.pieces, 4 * n_pieces + 4 * n)) != hipSuccess) {
+        const bool arena_fits = ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells.load()) * 8 && ctx->opt[NPR_OPT_MEA_OWN_SCRATCH] == 0;
+        bool in_arena = !ctx->overlap && arena_fits;
+        for (;;) {
+            char *cur = ctx->arena->F;
+            if (in_arena && poison_byte() >= 0) {  // the DP launches are done (their streams feed this one): the tables start from poison
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                poison(ctx->arena->F, need);
+            }
+            auto take = [&](auto &buf, size_t count) -> hipError_t {
+                using T = std::remove_pointer_t<decltype(buf.p)>;
+                if (!in_arena) return buf.reserve(count);
+                buf.borrow(reinterpret_cast<T *>(cur), count);
+                cur += al(sizeof(T) * count);
+                return hipSuccess;
+            };
+            if ((e = take(m.off, 5 * (n + 1))) == hipSuccess && (e = take(m.mass, n)) == hipSuccess && (e = take(m.od, n + 1)) == hipSuccess &&
+                (e = take(m.cnt, n_cnt)) == hipSuccess && (e = take(m.start, n_cnt)) == hipSuccess && (e = take(m.col, ry[n] + 1)) == hipSuccess &&
+                (e = take(m.sorted, 12 * total + 16)) == hipSuccess && (e = take(m.small, 5 * n)) == hipSuccess && (e = take(m.tmp, 2 * ot[n])) == hipSuccess &&
+                (e = take(m.map, 3 * n + ntask_map)) == hipSuccess && (e = take(m.dense, ot[n])) == hipSuccess &&
+                (e = take(m.pieces, 4 * n_pieces + 4 * n)) == hipSuccess)
+                break;
             (void)hipGetLastError();
+            if (!in_arena && ctx->overlap && arena_fits) {
+                // A pipelined job's context keeps these tables in buffers of its own (NPR_OPT_OVERLAP) so that it need not wait for the batch
+                // that is running in the device's shared scratch -- when they do not fit beside the batches in flight (long reads: 48 bytes per
+                // pair, three chunks on the device) it waits after all, and gives back what it had reserved.
+                m.off.release(), m.mass.release(), m.od.release(), m.cnt.release(), m.start.release(), m.col.release(), m.sorted.release();
+                m.small.release(), m.tmp.release(), m.map.release(), m.dense.release(), m.pieces.release();
+                ctx->cache_flush();
+                arena_lock.lock();
+                ++ctx->arena->epoch;
+                in_arena = true;
+                continue;
+            }
             return 1;  // no room on the device: the host stage takes the batch
         }
     }

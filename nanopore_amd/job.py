@@ -31,9 +31,9 @@ import numpy as np
 from . import _lib
 from . import dist as npd
 
-_DEFAULT_CHUNK_BASES = 100_000_000
-CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", _DEFAULT_CHUNK_BASES))  # ~12 k reads of 8 kb: two per resident wavefront
-MIN_CHUNK_READS = int(os.environ.get("NPR_JOB_MIN_CHUNK_READS", 12288))  # reads of a chunk at the default chunk size (a caller who asks for smaller chunks gets them)
+_DEFAULT_CHUNK_BASES = 50_000_000
+CHUNK_BASES = int(os.environ.get("NPR_JOB_CHUNK_BASES", _DEFAULT_CHUNK_BASES))  # ~6 k reads of 8 kb (round 5; rounds 3-4: 10^8, see chunk_bounds)
+MIN_CHUNK_READS = int(os.environ.get("NPR_JOB_MIN_CHUNK_READS", 4096))  # reads of a chunk at the default chunk size (a caller who asks for smaller chunks gets them)
 WORKERS = int(os.environ.get("NPR_JOB_WORKERS", 3))  # chunks in flight (contexts per GPU): one in its DP, one being finished / fetched, one staged ahead
 TRACE = os.environ.get("NPR_JOB_TRACE") is not None  # timings["trace"]: (phase, start, end) per chunk, seconds (tools/job_trace.py)
 
@@ -294,10 +294,15 @@ def chunk_bounds(lengths, lo, hi, chunk_bases=None, workers=None):
         return []
     total = float(np.sum(lengths[lo:hi]))
     k = max(1, int(round(total / chunk_bases)))
-    # A DP launch lasts at least as long as its longest read on its one wavefront (a 20 kb read: 45 ms, what 12 000 reads of 8 kb
-    # take when they fill the chip), so a chunk below ~12 k reads buys its overlap with DP time: 12 500 reads as three chunks ran
-    # 3 x 40 ms of DP launches where one launch takes 59 (round 4).  Fewer, fuller chunks; one when the range is small.
+    # A DP launch lasts at least as long as its longest read's chain.  On one wavefront per read (rounds 3-4) a 20 kb read took 45 ms, what
+    # 12 000 reads of 8 kb take when they fill the chip, so chunks held 12 288 reads or more and 10^8 bases.  With a read's sweeps on two
+    # wavefronts that meet in the middle (round 5) the chain is 21 ms and chunks of half the size pay: measured on one GPU, ms per step for
+    # 12 500 / 25 000 / 50 000 reads of 8 kb -- chunks of 10^8 bases 143 / 232 / 380, of 5 x 10^7 122 / 198 / 367, of 3.3 x 10^7 115 / 211 / 398,
+    # of 2.5 x 10^7 123 / 223 / 431 (6 250 reads as one chunk 75, as two 78).  A range worth two chunks takes three: with two, nothing runs
+    # beside the first one's staging or the second one's finishing.
     k = max(1, min(k, n // min_reads))
+    if k == 2 and n >= 3 * min_reads:
+        k = 3
     # ... but never more than four times the bases asked for: MIN_CHUNK_READS reads of 50-100 kb would be six to twelve chunks' worth, three
     # of them in flight -- such a job would live in the halve-and-stage-again path that is meant for the exception
     k = max(k, int(total // (4 * chunk_bases)))

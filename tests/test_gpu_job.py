@@ -281,3 +281,13 @@ def test_config5_at_full_size_through_the_job_with_device_statistics(tmp_path, g
         for path in (sam, fa, fq, out):
             os.unlink(path)
     assert total_cells > 1.5e11
+
+
+def teardown_module(module):
+    """The job keeps its contexts (and their device buffers) for the life of the process; the tests after this module want the memory.
+    (Released, not closed: a caller's context -- the session's -- joins the pool when it is passed to realignSamFile.)"""
+    from nanopore_amd import job
+    for pool in job._ctx_pool.values():
+        for c in pool:
+            if getattr(c, "_h", None):
+                c.release_scratch()

@@ -187,8 +187,9 @@ def test_collector_is_held_off_once_for_jobs_side_by_side():
 
 
 def test_chunks_are_capped_by_bases_as_well_as_floored_by_reads():
-    short = np.full(50000, 8000, dtype=np.int64)     # BASELINE configs[2]: four chunks of 12 500 reads
-    assert len(job.chunk_bounds(short, 0, len(short))) == 4
+    short = np.full(50000, 8000, dtype=np.int64)     # BASELINE configs[2]: eight chunks of 6 250 reads
+    assert len(job.chunk_bounds(short, 0, len(short))) == 8
+    assert len(job.chunk_bounds(short, 0, 12500)) == 3 and len(job.chunk_bounds(short, 0, 6250)) == 1  # a rank's share at N = 4 / 8
     long_ = np.full(30000, 80000, dtype=np.int64)    # 30 000 reads of 80 kb: 12 288 reads would be ten chunks' worth of bases each
     cuts = job.chunk_bounds(long_, 0, len(long_))
     assert max(b - a for a, b in cuts) * 80000 <= 4.2 * job.CHUNK_BASES and cuts[0][0] == 0 and cuts[-1][1] == len(long_)
