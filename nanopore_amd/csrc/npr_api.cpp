@@ -1379,7 +1379,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         const int rc = kc.kind == K_MID   ? launch_mid_rs(a, kc.R, L.grid, s, sw, flat)
                        : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw, flat)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
-                       : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s)
+                       : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s, flat_gap_emissions(ctx))
                        : kc.kind == K_TILE_RS ? launch_tile_rs(a, L.wcap, L.grid, s)
                        : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
                                            : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);

@@ -145,7 +145,7 @@ struct MeaArgs {
     uint32_t *ops_dense;     // one word per op: length << 2 | op
     const int64_t *od_off;
 };
-int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream);
+int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream, bool flat = false);
 size_t tile_lds_bytes(int nw);
 int64_t tile_scratch_cells(int64_t rows, int R);  // forward scratch (8-byte cells) of a task with that many stripe rows
 // ---- device planner (npr_plan.hip): band rows, frame schedules, stripe tables and generic row offsets of a batch,

@@ -149,7 +149,19 @@ __device__ __forceinline__ Cell dpp_cell_from_above(const Cell &v, const Cell &e
 // One forward anti-diagonal of a stripe.  `io`: d-2 on entry, d on exit; `p1`: d-1; `carry`: the slot-below copy of
 // d-2's top register (made by the step before) on entry, that of d-1 on exit; `edge`: the left stripe's last column on
 // d-1 (every lane holds it, lane 0 uses it).  bx / by: X[x-1]*4 and Y[y-1]*4 of every slot.
-template <int R>
+// FLAT: every loaded model emits every base from every gap state with probability exactly 2^-2 (the shipped ones do; npr_rs.h rs_cell_emissions has
+// the same switch): the four gap emissions are the constant, one LDS look-up per cell and direction instead of five.  The same factor in the same
+// products: no bit changes.
+template <int R, bool FLAT>
+__device__ __forceinline__ void tile_emissions(const StepEnv &E, const Bases<R> &bx, const Bases<R> &by, int r, float &em, float &exs, float &exl, float &eys, float &eyl) {
+    if constexpr (FLAT) {
+        em = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, em) + 5 * bx.b[r] + by.b[r]);
+        exs = exl = eys = eyl = 0.25f;
+    } else {
+        emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
+    }
+}
+template <int R, bool FLAT = false>
 __device__ __forceinline__ void tile_fwd_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &p1, Cell &carry, const Cell &edge,
                                               const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
     const Cell Le = dpp_cell_from_below(p1.c[R - 1], edge);  // (x-1, y) of every lane's register 0
@@ -157,7 +169,7 @@ __device__ __forceinline__ void tile_fwd_step(int d, const StepEnv &E, Diag<R> &
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
-        emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
+        tile_emissions<R, FLAT>(E, bx, by, r, em, exs, exl, eys, eyl);
         o.c[r] = fwd_cell<false>(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : carry, p1.c[r], em, exs, exl, eys, eyl);
     }
     settle_diag<R>(d, o, mk);
@@ -166,7 +178,7 @@ __device__ __forceinline__ void tile_fwd_step(int d, const StepEnv &E, Diag<R> &
 }
 // One backward anti-diagonal.  `io`: d+2 -> d; `s1`: d+1; `carry`: the slot-above copy of d+2's register 0 -> that of
 // d+1; `edge`: the right stripe's first column on d+1 (lane 63 uses it).  bx / by: X[x]*4 and Y[y]*4 of every slot.
-template <int R>
+template <int R, bool FLAT = false>
 __device__ __forceinline__ void tile_bwd_step(int d, const StepEnv &E, Diag<R> &io, const Diag<R> &s1, Cell &carry, const Cell &edge,
                                               const Bases<R> &bx, const Bases<R> &by, const Masks<R> &mk) {
     const Cell Xe = dpp_cell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register
@@ -174,7 +186,7 @@ __device__ __forceinline__ void tile_bwd_step(int d, const StepEnv &E, Diag<R> &
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float em, exs, exl, eys, eyl;
-        emissions<R>(E, bx, by, r, em, exs, exl, eys, eyl);
+        tile_emissions<R, FLAT>(E, bx, by, r, em, exs, exl, eys, eyl);
         o.c[r] = bwd_cell<false>(E.tr, r + 1 < R ? io.c[r + 1] : carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
     }
     settle_diag<R>(d, o, mk);
@@ -186,7 +198,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::
 
 // PROF (NPR_TILE_PROF=1, bring-up): cycles every wavefront spends waiting -- for a neighbour's cells, for its own stores
 // before it publishes, at the barriers between the sweeps -- summed into a.prof[0..3] next to its total.
-template <int R, bool PROF>
+template <int R, bool PROF, bool FLAT>
 __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves_per_eu(R == 2 ? 6 : 1))) k_dp_tile(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmodel = reinterpret_cast<float *>(smem);
@@ -310,7 +322,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                     edge = edge_get(stage, q - blk_lo);
                 }
                 bases_down<R>(by, feed_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
-                tile_fwd_step<R>(d, E, io, p1, carry, edge, bx, by, mk);
+                tile_fwd_step<R, FLAT>(d, E, io, p1, carry, edge, bx, by, mk);
                 if (d == 0) {  // the start cell (0, 0): slot 0 of the first stripe
                     if (lane == 0) {
                         Cell c;
@@ -437,7 +449,7 @@ __global__ void __launch_bounds__(WAVE *TILE_MAX_NW) __attribute__((amdgpu_waves
                         edge = edge_get(stage, q - blk_lo);
                     }
                     bases_up<R>(by, feed_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
-                    tile_bwd_step<R>(d, E, io, s1, carry, edge, bx, by, mk);
+                    tile_bwd_step<R, FLAT>(d, E, io, s1, carry, edge, bx, by, mk);
                     if (d == D) {  // the end corner (lX, lY)
 #pragma unroll
                         for (int r = 0; r < R; ++r)
@@ -1007,14 +1019,16 @@ int launch_em_tile(const KernelArgs &a, int R, int grid, void *stream) {
     return static_cast<int>(hipGetLastError());
 }
 
-int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream) {
+int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream, bool flat) {  // flat: every loaded model's gap emissions are exactly 2^-2
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (NW < 1 || NW > TILE_MAX_NW) return static_cast<int>(hipErrorInvalidValue);
     const size_t lds = tile_lds_bytes(NW);
     if (R == 2 && a.prof)
-        hipLaunchKernelGGL((k_dp_tile<2, true>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+        hipLaunchKernelGGL((k_dp_tile<2, true, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+    else if (R == 2 && flat)
+        hipLaunchKernelGGL((k_dp_tile<2, false, true>), dim3(grid), dim3(WAVE * NW), lds, s, a);
     else if (R == 2)
-        hipLaunchKernelGGL((k_dp_tile<2, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+        hipLaunchKernelGGL((k_dp_tile<2, false, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
     else
         return static_cast<int>(hipErrorInvalidValue);
     return static_cast<int>(hipGetLastError());
