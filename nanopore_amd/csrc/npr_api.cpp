@@ -83,6 +83,7 @@ struct npr_ctx {
     // the D2H rate and the copy is a GB per batch
     void *pin_pairs = nullptr;
     size_t pin_pairs_bytes = 0;
+    std::vector<hipEvent_t> ops_events;  // one per piece of the ops' D2H (device_mea)
     // the packed cigars of the last batch or two that were destroyed: a batch's 75-150 MB, whose pages cost 3 ms to touch when the
     // next batch is finished and 6 ms to give back when it is destroyed (with a caller waiting for the context)
     struct HostWords {
@@ -439,6 +440,7 @@ void npr_destroy(npr_ctx *ctx) {
     if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
     if (ctx->pin_stage) (void)hipHostFree(ctx->pin_stage);
     delete ctx->mea;
+    for (hipEvent_t ev : ctx->ops_events) (void)hipEventDestroy(ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1716,7 +1718,7 @@ int32_t device_mea(npr_batch *b) {
     {
         auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
         const size_t need = al(8 * 5 * (n + 1)) + al(8 * n) + al(8 * (n + 1)) + 2 * al(4 * n_cnt) + al(4 * (ry[n] + 1)) + al(4 * (12 * total + 16)) +
-                            al(4 * 5 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]) + al(4 * (4 * n_pieces + 4 * n));
+                            al(4 * 6 * n) + al(4 * 2 * ot[n]) + al(4 * (3 * n + ntask_map)) + al(4 * ot[n]) + al(4 * (4 * n_pieces + 4 * n));
         const bool arena_fits = ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells.load()) * 8 && ctx->opt[NPR_OPT_MEA_OWN_SCRATCH] == 0;
         bool in_arena = !ctx->overlap && arena_fits;
         for (;;) {
@@ -1734,7 +1736,7 @@ int32_t device_mea(npr_batch *b) {
             };
             if ((e = take(m.off, 5 * (n + 1))) == hipSuccess && (e = take(m.mass, n)) == hipSuccess && (e = take(m.od, n + 1)) == hipSuccess &&
                 (e = take(m.cnt, n_cnt)) == hipSuccess && (e = take(m.start, n_cnt)) == hipSuccess && (e = take(m.col, ry[n] + 1)) == hipSuccess &&
-                (e = take(m.sorted, 12 * total + 16)) == hipSuccess && (e = take(m.small, 5 * n)) == hipSuccess && (e = take(m.tmp, 2 * ot[n])) == hipSuccess &&
+                (e = take(m.sorted, 12 * total + 16)) == hipSuccess && (e = take(m.small, 6 * n)) == hipSuccess && (e = take(m.tmp, 2 * ot[n])) == hipSuccess &&
                 (e = take(m.map, 3 * n + ntask_map)) == hipSuccess && (e = take(m.dense, ot[n])) == hipSuccess &&
                 (e = take(m.pieces, 4 * n_pieces + 4 * n)) == hipSuccess)
                 break;
@@ -1790,7 +1792,7 @@ int32_t device_mea(npr_batch *b) {
     a.sx = m.sorted.p, a.sy = m.sorted.p + total + 1, a.sq = m.sorted.p + 2 * (total + 1), a.back = m.sorted.p + 3 * (total + 1);
     a.kx = m.sorted.p + 4 * (total + 1), a.ky = m.sorted.p + 5 * (total + 1), a.kq = m.sorted.p + 6 * (total + 1), a.kback = m.sorted.p + 7 * (total + 1);
     a.vrec = reinterpret_cast<int4 *>(m.sorted.p + ((8 * (total + 1) + 3) & ~int64_t(3)));  // (16-byte records: the arena's tables start 256-byte aligned)
-    a.best_who = m.small.p, a.read_flag = m.small.p + n, a.n_ops = m.small.p + 2 * n, a.chain_len = m.small.p + 3 * n, a.kept = m.small.p + 4 * n;
+    a.best_who = m.small.p, a.read_flag = m.small.p + n, a.n_ops = m.small.p + 2 * n, a.chain_len = m.small.p + 3 * n, a.kept = m.small.p + 4 * n, a.max_run = m.small.p + 5 * n;
     a.chain_mass = m.mass.p;
     a.np = m.pieces.p, a.poff = m.pieces.p + n, a.pboff = m.pieces.p + 2 * n, a.lane_read = m.pieces.p + 3 * n, a.lane_piece = m.pieces.p + 3 * n + n_pieces;
     a.pbest = m.pieces.p + 3 * n + 2 * n_pieces, a.pb = m.pieces.p + 3 * n + 3 * n_pieces, a.n_pieces = static_cast<int32_t>(n_pieces);
@@ -1804,13 +1806,14 @@ int32_t device_mea(npr_batch *b) {
     int rc = launch_mea_sort(a, ctx->stream);
     if (rc == 0) rc = launch_mea_chain(a, ctx->stream);
     if (rc != 0) return fail(ctx, NPR_ERR_HIP, "MEA kernel launch", static_cast<hipError_t>(rc));
-    std::vector<int32_t> small(5 * n);
+    std::vector<int32_t> small(6 * n);
     std::vector<int64_t> mass(n);
     HIP_TRY(ctx, hipMemcpyAsync(small.data(), m.small.p, m.small.bytes(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mass.data(), m.mass.p, m.mass.bytes(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     tm.lap("sort + chain + trace");
     const int32_t *flag = small.data() + n, *nops = small.data() + 2 * n, *clen = small.data() + 3 * n;
+    int32_t longest = 0;  // run of the batch's cigars
     for (int64_t i = 0; i < n; ++i)
         if (b->results[i].status == NPR_OK && flag[i] == NPR_ERR_CAPACITY) return 1;
     for (int64_t i = 0; i < n; ++i) {
@@ -1818,6 +1821,7 @@ int32_t device_mea(npr_batch *b) {
         if (r.status == NPR_OK && flag[i] != 0) r.status = flag[i];
         const int64_t k = r.status == NPR_OK ? nops[i] : 0;
         od[i + 1] = od[i] + k;
+        if (k) longest = std::max(longest, small[5 * n + i]);
         r.n_ops = k;
         r.score = (r.status == NPR_OK && clen[i] > 0) ? static_cast<double>(mass[i]) / (static_cast<double>(clen[i]) * PROB_ONE) : 0.0;
     }
@@ -1836,11 +1840,16 @@ int32_t device_mea(npr_batch *b) {
         b->packed_cap = od[n] + od[n] / 8;
     }
     if (od[n]) {
-        // one packed word per op (length << 2 | op) through the pinned staging; (op, length) pairs are made on demand
+        // One packed word per op (length << 2 | op), through the pinned staging in pieces: the host threads move a piece into the
+        // batch's buffer while the next ones cross.  When no run of the batch is longer than 14 bits (a deletion of 16 k bases: the rule)
+        // the words cross as their low halves, 147 MB instead of 295 for the bench's 24576 reads, and the move widens them.
+        const bool narrow = longest < (1 << 14) && ctx->opt[NPR_OPT_MEA_WIDE_OPS] == 0 &&
+                            sizeof(uint16_t) * static_cast<size_t>(od[n]) <= m.sorted.bytes();  // (the sorted pairs are done with)
         a.ops_dense = m.dense.p;  // (sized for the bound ot[n] >= od[n])
+        a.ops_dense16 = narrow ? reinterpret_cast<uint16_t *>(m.sorted.p) : nullptr;
         HIP_TRY(ctx, hipMemcpyAsync(m.od.p, od.data(), m.od.bytes(), hipMemcpyHostToDevice, ctx->stream));
         if ((rc = launch_mea_gather(a, ctx->stream)) != 0) return fail(ctx, NPR_ERR_HIP, "k_mea_gather launch", static_cast<hipError_t>(rc));
-        const size_t need = sizeof(uint32_t) * static_cast<size_t>(od[n]);
+        const size_t word = narrow ? sizeof(uint16_t) : sizeof(uint32_t), need = word * static_cast<size_t>(od[n]);
         if (need > ctx->pin_pairs_bytes) {
             if (ctx->pin_pairs) (void)hipHostFree(ctx->pin_pairs);
             ctx->pin_pairs = nullptr, ctx->pin_pairs_bytes = 0;
@@ -1848,14 +1857,37 @@ int32_t device_mea(npr_batch *b) {
                 return fail(ctx, NPR_ERR_NOMEM, "npr_batch_finish: hipHostMalloc", e);
             ctx->pin_pairs_bytes = need + need / 4;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_pairs, m.dense.p, need, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        const uint32_t *src = static_cast<const uint32_t *>(ctx->pin_pairs);
+        constexpr int64_t kOpsPieces = 48;
+        const int64_t nops_all = od[n], pieces = std::min<int64_t>(kOpsPieces, (nops_all + (1 << 20) - 1) >> 20);
+        const int64_t piece = ((nops_all + pieces - 1) / pieces + 63) & ~int64_t(63);
+        while (static_cast<int64_t>(ctx->ops_events.size()) < pieces) {
+            hipEvent_t ev;
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(ctx, NPR_ERR_HIP, "hipEventCreate", e);
+            ctx->ops_events.push_back(ev);
+        }
+        const char *dev = narrow ? reinterpret_cast<const char *>(a.ops_dense16) : reinterpret_cast<const char *>(m.dense.p);
+        char *pin = static_cast<char *>(ctx->pin_pairs);
+        for (int64_t c = 0; c < pieces; ++c) {
+            const int64_t lo = std::min(nops_all, c * piece), hi = std::min(nops_all, lo + piece);
+            if (hi > lo) HIP_TRY(ctx, hipMemcpyAsync(pin + word * lo, dev + word * lo, word * static_cast<size_t>(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ops_events[c], ctx->stream));
+        }
         uint32_t *out = b->packed.get();
-        const int64_t nops_all = od[n], chunk = 1 << 20, nchunks = (nops_all + chunk - 1) / chunk;
-        parallel_for(nchunks, ctx->host_threads, [&](int64_t c) {
-            std::memcpy(out + c * chunk, src + c * chunk, sizeof(uint32_t) * static_cast<size_t>(std::min(nops_all, (c + 1) * chunk) - c * chunk));
+        std::atomic<int> failed{0};
+        parallel_for(pieces, ctx->host_threads, [&](int64_t c) {  // (the items are handed out in order)
+            if (hipEventSynchronize(ctx->ops_events[c]) != hipSuccess) {
+                failed = 1;
+                return;
+            }
+            const int64_t lo = std::min(nops_all, c * piece), hi = std::min(nops_all, lo + piece);
+            if (narrow) {
+                const uint16_t *src = reinterpret_cast<const uint16_t *>(pin);
+                for (int64_t i = lo; i < hi; ++i) out[i] = src[i];
+            } else {
+                std::memcpy(out + lo, pin + word * lo, word * static_cast<size_t>(hi - lo));
+            }
         });
+        if (failed) return fail(ctx, NPR_ERR_HIP, "npr_batch_finish: D2H of the ops", hipGetLastError());
     }
     tm.lap("gather + D2H of the ops");
     if (od[n]) b->dev_ops = m.dense.p, b->dev_od = m.od.p, b->dev_ops_epoch = ctx->arena->epoch;

@@ -144,6 +144,8 @@ struct MeaArgs {
     int64_t *chain_mass;
     uint32_t *ops_dense;     // one word per op: length << 2 | op
     const int64_t *od_off;
+    int32_t *max_run;        // per read: its longest run (k_mea_trace) ...
+    uint16_t *ops_dense16;   // ... when none of the batch exceeds 14 bits: the words' low halves, the form that crosses PCIe (else null)
 };
 int launch_tile(const KernelArgs &a, int R, int NW, int grid, void *stream, bool flat = false);
 size_t tile_lds_bytes(int nw);

@@ -23,7 +23,8 @@
 //                  on usual data; forced in the tests)
 //   k_mea_trace    one wavefront per read: walk the back pointers from the best chain's last pair, writing the ops
 //                  backwards (run-length merged) into the read's scratch, and sum the chain's posterior mass
-//   k_mea_gather   dense copy of every read's ops, one word each, for one D2H
+//   k_mea_gather   dense copy of every read's ops, one word each (and the words' low halves when every run of the batch fits 14 bits: what
+//                  crosses PCIe then)
 #include <hip/hip_runtime.h>
 
 #include "npr_device.h"
@@ -626,7 +627,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
     const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
     int2 *const lo = reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r];
     int2 *p = reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r + 1];  // filled from the end
-    int hop = -1, hlen = 0;
+    int hop = -1, hlen = 0, longest = 0;
     auto emit = [&](int op, int len) {
         if (len <= 0) return;
         if (op == hop) {
@@ -636,6 +637,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
         if (hop >= 0 && p > lo) {
             --p;
             if (lane == 0) *p = make_int2(hop, hlen);
+            longest = max(longest, hlen);
         }
         hop = op, hlen = len;
     };
@@ -677,8 +679,10 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
     if (hop >= 0 && p > lo) {
         --p;
         if (lane == 0) *p = make_int2(hop, hlen);
+        longest = max(longest, hlen);
     }
     if (lane == 0) {
+        a.max_run[r] = longest;
         a.n_ops[r] = static_cast<int>(reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r + 1] - p);
         a.chain_len[r] = len;
         a.chain_mass[r] = mass;
@@ -690,7 +694,12 @@ __global__ void __launch_bounds__(256) k_mea_gather(MeaArgs a) {
         const int n = static_cast<int>(a.od_off[r + 1] - a.od_off[r]);
         const int2 *src = reinterpret_cast<const int2 *>(a.ops_tmp) + a.ot_off[r + 1] - a.n_ops[r];
         uint32_t *dst = a.ops_dense + a.od_off[r];
-        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = static_cast<uint32_t>(src[i].y) << 2 | static_cast<uint32_t>(src[i].x);
+        uint16_t *const dst16 = a.ops_dense16 ? a.ops_dense16 + a.od_off[r] : nullptr;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t w = static_cast<uint32_t>(src[i].y) << 2 | static_cast<uint32_t>(src[i].x);
+            dst[i] = w;
+            if (dst16) dst16[i] = static_cast<uint16_t>(w);
+        }
     }
 }
 

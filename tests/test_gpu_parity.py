@@ -321,6 +321,21 @@ def test_device_mea_long_spans(gpu_ctx, monkeypatch):
     for u, v, (X, Y, _) in zip(dev, host, cases):
         assert u["status"] == v["status"] == 0 and u["ops"] == v["ops"] and u["score"] == v["score"]
         assert cigar_spans(u["ops"]) == (len(X), len(Y))
+    # The packed cigars cross PCIe as 16-bit words when no run of the batch needs more than 14 bits (round 5) and as whole words
+    # otherwise: both forms of the same batch, and a batch with runs of 17 000 and 21 000 (matchGamma 1 keeps no pair: a read's cigar
+    # is its length inserted and its reference deleted).
+    gpu_ctx.set_option(_lib.OPTIONS["mea_wide_ops"], 1)
+    wide = gpu_ctx.realign(P, refs, reads, guides)
+    gpu_ctx.set_option(_lib.OPTIONS["mea_wide_ops"], 0)
+    assert [u["ops"] for u in wide] == [u["ops"] for u in dev]
+    P1 = R.make_params(band_mode=1, fixed_width=80, match_gamma=1.0)
+    dev = gpu_ctx.realign(P1, refs, reads, guides)
+    gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 1)
+    host = gpu_ctx.realign(P1, refs, reads, guides)
+    gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 0)
+    for u, v, (X, Y, _) in zip(dev, host, cases):
+        assert u["status"] == v["status"] == 0 and u["ops"] == v["ops"] and u["score"] == v["score"] == 0.0
+        assert sorted(u["ops"]) == sorted([(_lib.OP_I, len(Y)), (_lib.OP_D, len(X))])
 
 
 def test_base_dependent_gap_emissions(gpu_ctx):
