@@ -131,10 +131,11 @@ const char *npr_last_error(npr_ctx *ctx);
  * (nanopore_amd/job.py; the reference's analogue is jobTree running several cactus_realign processes at once,
  * /root/reference/Makefile:1 maxThreads).  The contexts of a device share its forward scratch and take turns in it; with this
  * option the device MEA stage keeps its tables in buffers of the context's own instead (so npr_batch_finish need not wait for
- * another batch's DP pass), and the DP launches of narrow bands leave one wavefront slot per SIMD free so that the staging
- * and MEA kernels of the other batches find room beside them.  Value 2: the tables of its own only -- the next batch's DP pass
+ * another batch's DP pass), and the DP launches of narrow bands take four wavefronts per SIMD instead of seven, so that the staging
+ * and MEA kernels of the other batches find slots and registers beside them (a persistent launch that fills the chip leaves room for
+ * nothing; nanopore_amd/job.py's default since the end of round 5).  Value 2: the tables of its own only -- the next batch's DP pass
  * starts when it is staged, not when this batch's MEA stage has given the shared scratch back; the MEA kernels take the slots the
- * DP pass leaves as its wavefronts run out (nanopore_amd/job.py's default since round 4).  Results do not change. */
+ * DP pass leaves as its wavefronts run out.  Results do not change. */
 #define NPR_OPT_OVERLAP 1
 /* NPR_OPT_RELEASE_SCRATCH (an action; value 2: only the context's cache of released device buffers, the scratch stays): the device's forward scratch (shared by the contexts of the device; the
  * next batch that needs it allocates it again) and this context's cache of released device buffers go back to the driver.  For

@@ -74,7 +74,7 @@ struct npr_ctx {
     std::string last_error;
     int host_threads = 1;
     DeviceArena *arena = nullptr;  // the device's forward scratch (shared with the other contexts on this device)
-    int overlap = 0;               // NPR_OPT_OVERLAP: see include/nprealign.h (1: own MEA tables + a wavefront slot per SIMD left free; 2: own MEA tables only)
+    int overlap = 0;               // NPR_OPT_OVERLAP: see include/nprealign.h (1: own MEA tables + half of every SIMD left free by the DP launches; 2: own MEA tables only)
     int64_t opt[NPR_OPT_COUNT] = {};  // npr_ctx_option: the test / bring-up switches (all 0 by default)
     static constexpr size_t kArenaPad = DeviceArena::kPad;
     float *arena_Fx = nullptr;  // E-step only: four more forward planes (per context)
@@ -1110,15 +1110,17 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         int waves_per_cu;
         if (kClassTab[c].kind == K_MID) {  // workgroups of two wavefronts
             waves_per_cu = mid_waves_per_cu(kClassTab[c].R) / 2;
-            if (ctx->overlap == 1 && kClassTab[c].R <= 2) waves_per_cu -= 2;  // (a wavefront slot per SIMD left free: see the one-wavefront classes below)
+            // NPR_OPT_OVERLAP = 1: half of every SIMD's wavefront slots, and 224 of its 512 registers, left to the staging and MEA kernels of
+            // the batches this one runs next to.  A persistent DP launch that fills the chip (7 x 72 registers) leaves room for nothing: every
+            // other kernel of the job then waits for the launch's last wavefronts (profiles/r05_c3_job_trace.txt).  Measured on the files ->
+            // file job of 50 000 reads, wavefronts per SIMD 7 / 6 / 5 / 4 / 3: 372 / 372 / 371 / 352-361 / 388 ms.
+            if (ctx->overlap == 1 && kClassTab[c].R <= 2) waves_per_cu = std::min(waves_per_cu, 8);
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 128;
         } else if (is_one_wave_kind(kClassTab[c].kind)) {  // VGPR-limited: 71 / 80 (held there by amdgpu_waves_per_eu) / 162 registers: 7 / 6 / 3 waves per SIMD
             waves_per_cu = kClassTab[c].kind == K_RS ? rs_waves_per_cu(kClassTab[c].R) : stair_waves_per_cu(kClassTab[c].R);
-            // NPR_OPT_OVERLAP: one wavefront slot per SIMD (and its registers) left to the staging and MEA kernels of the
-            // batches this one runs next to; the DP pass alone loses about 2 % (98 % VALU-busy at 5 wavefronts per SIMD)
-            if (ctx->overlap == 1 && kClassTab[c].R <= 2) waves_per_cu -= 4;
+            if (ctx->overlap == 1 && kClassTab[c].R <= 2) waves_per_cu = std::min(waves_per_cu, 16);  // (four per SIMD, as for the two-wavefront classes above)
             L.wcap = 0;
             L.lds = stair_lds_bytes();
             L.threads = 64;
@@ -1800,6 +1802,7 @@ int32_t device_mea(npr_batch *b) {
     a.ring_only = ctx->opt[NPR_OPT_MEA_RING_ONLY] != 0 ? 1 : 0;
     a.read_first = m.map.p, a.read_ntasks = m.map.p + n, a.task_of = m.map.p + 2 * n, a.order = m.map.p + 2 * n + ntask_map;
     a.sort_lds_bytes = static_cast<int32_t>(4 * span);
+    a.sort_threads = ctx->overlap == 1 ? 512 : 0;  // (beside a DP pass: workgroups that fit the half it leaves -- 1024 threads: the job 388 ms instead of 353, 256: 361)  // (beside a DP pass that leaves part of every SIMD: a workgroup that fits there)
     a.any_global_sort = sort_in_lds ? 0 : 1;
     a.cnt_off = m.off.p + 4 * (n + 1);
     a.ops_tmp = m.tmp.p, a.od_off = m.od.p;

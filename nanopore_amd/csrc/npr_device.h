@@ -135,6 +135,7 @@ struct MeaArgs {
     const int32_t *order;    // reads by decreasing pair count: the per-read kernels take them in this order (no long read last)
     const int32_t *read_first, *read_ntasks, *task_of;  // the tasks of a read: task_of[read_first[r] + s]
     int32_t sort_lds_bytes;  // > 0: k_mea_sort_lds with this much LDS for the reads whose spans fit it
+    int32_t sort_threads;    // threads of its workgroups (0: 1024)
     int32_t any_global_sort; // some read's span does not: the three global-memory kernels for those
     const int64_t *cnt_off;  // per read: its slice of cnt / start (lX + 1 entries), -1 for a read sorted in LDS
     int32_t ring_only;       // tests: every read through the LDS-ring kernel

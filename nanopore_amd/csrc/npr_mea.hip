@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
     extern __shared__ int h[];
     __shared__ int wsum[SORT_THREADS / WAVE];
     const int r = a.order[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nthreads = static_cast<int>(blockDim.x);  // (SORT_THREADS, or fewer when the launch shares the chip with a DP pass: MeaArgs::sort_threads)
     const int64_t rx = a.rx_off[r], ry = a.ry_off[r], rp = a.rp_off[r];
     const int lX = static_cast<int>(a.rx_off[r + 1] - rx) - 1, lY = static_cast<int>(a.ry_off[r + 1] - ry);
     if (a.rp_off[r + 1] == rp || a.cnt_off[r] >= 0) return;  // (no pairs; or a span beyond the LDS: the three kernels above)
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
             const int t = a.task_of[ft + s];
             const Task &tk = a.tasks[t];
             const int n = min(a.outs[t].npairs, tk.pair_cap);
-            for (int i = tid; i < n; i += SORT_THREADS) {
+            for (int i = tid; i < n; i += nthreads) {
                 const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
                 if (x < 0 || x >= lX || y < 0 || y >= lY) {
                     bad = 1;
@@ -154,18 +155,18 @@ __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
             }
         }
     };
-    for (int i = tid; i < lY; i += SORT_THREADS) h[i] = 0;
+    for (int i = tid; i < lY; i += nthreads) h[i] = 0;
     __syncthreads();
     for_pairs([&](int, int y, int q) { atomicAdd(&h[y], q); });
     __syncthreads();
-    for (int i = tid; i < lY; i += SORT_THREADS) a.colsum[ry + i] = h[i];
+    for (int i = tid; i < lY; i += nthreads) a.colsum[ry + i] = h[i];
     __syncthreads();
-    for (int i = tid; i <= lX; i += SORT_THREADS) h[i] = 0;
+    for (int i = tid; i <= lX; i += nthreads) h[i] = 0;
     __syncthreads();
     for_pairs([&](int x, int, int) { atomicAdd(&h[x], 1); });
     __syncthreads();
     int carry = 0;
-    for (int base = 0; base <= lX; base += SORT_THREADS) {
+    for (int base = 0; base <= lX; base += nthreads) {
         const int i = base + tid;
         const int v = i <= lX ? h[i] : 0;
         int sc = v;
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
         if (lane == WAVE - 1) wsum[wv] = sc;
         __syncthreads();
         int before = 0, total = 0;
-        for (int k = 0; k < SORT_THREADS / WAVE; ++k) before += k < wv ? wsum[k] : 0, total += wsum[k];
+        for (int k = 0; k < nthreads / WAVE; ++k) before += k < wv ? wsum[k] : 0, total += wsum[k];
         if (i <= lX) h[i] = carry + before + sc - v;
         carry += total;
         __syncthreads();
@@ -712,7 +713,7 @@ int launch_mea_sort(const MeaArgs &a, void *stream) {
     if (a.sort_lds_bytes > 0) {  // the reads whose per-position tables fit the LDS
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mea_sort_lds), hipFuncAttributeMaxDynamicSharedMemorySize, a.sort_lds_bytes);
         if (e != hipSuccess) return static_cast<int>(e);
-        hipLaunchKernelGGL(k_mea_sort_lds, dim3(a.n_reads), dim3(SORT_THREADS), a.sort_lds_bytes, s, a);
+        hipLaunchKernelGGL(k_mea_sort_lds, dim3(a.n_reads), dim3(a.sort_threads >= WAVE && a.sort_threads < SORT_THREADS ? a.sort_threads & ~(WAVE - 1) : SORT_THREADS), a.sort_lds_bytes, s, a);
     }
     if (a.any_global_sort) {  // the others (a read of more than 16 k bases among 12 000 shorter ones used to send ALL of them this way)
         const int tg = a.ntasks < 8192 ? (a.ntasks > 0 ? a.ntasks : 1) : 8192;

@@ -22,60 +22,91 @@ namespace npr {
 namespace {
 
 constexpr int BAND_THREADS = 256;
+constexpr int BAND_SUB = 4;                          // anti-diagonals per thread and tile
+constexpr int BAND_TILE = BAND_THREADS * BAND_SUB;   // anti-diagonals per tile
+constexpr int BAND_STAGE = BAND_TILE;                // plan points of a tile staged in LDS (a piece owns at least one anti-diagonal, as a rule)
 
+// One workgroup per segment, tiles of 1024 anti-diagonals.  The plan points a tile can fall into are staged in LDS first (one coalesced
+// load), so that every row's search for its piece reads LDS: rounds 2-4 searched global memory per row, in tiles of 256 with four barriers
+// each -- 3 ms for 6 250 reads on an idle chip and 38 ms in the wavefront slots a running DP pass leaves (every dependent load at the
+// latency of a loaded memory system), which is what a pipelined job's next DP pass waited for.  Same rows, same
+// summary as before: npr_batch_plan_check compares them with the host planner's.
 __global__ void __launch_bounds__(BAND_THREADS) k_plan_bands(PlanArgs a) {
     __shared__ long long s_cells[BAND_THREADS], s_gen[BAND_THREADS];
     __shared__ int s_w[BAND_THREADS], s_bad[BAND_THREADS], s_rough[BAND_THREADS];
-    __shared__ int s_k[2];
-    __shared__ int s_lo[BAND_THREADS + 1], s_hi[BAND_THREADS + 1];  // this tile's rows, [0] = the row before the tile
+    __shared__ int s_k;                                   // piece of the tile's first anti-diagonal
+    __shared__ int s_lo[BAND_TILE], s_hi[BAND_TILE];      // this tile's rows ...
+    __shared__ int s_carry[2][2];                         // ... and the last row of the tile before (by the tile's parity)
+    __shared__ PlanPoint s_pt[BAND_STAGE + 1];
+    const int tid = threadIdx.x;
     for (int g = blockIdx.x; g < a.n_segs; g += gridDim.x) {
         const PlanSeg sg = a.segs[g];
         const PlanPoint *P = a.points + sg.point_first;
-        const int D = sg.lX + sg.lY;
+        const int D = sg.lX + sg.lY, m = sg.pieces;
         long long cells = 0, gen = 0;
         int wmax = 0, bad = 0, rough = 0;
-        for (int d0 = 0; d0 <= D; d0 += BAND_THREADS) {
-            // the pieces this tile of anti-diagonals can fall into
-            if (threadIdx.x < 2) s_k[threadIdx.x] = band_piece(P, sg.pieces, threadIdx.x == 0 ? d0 : min(d0 + BAND_THREADS - 1, D));
+        if (tid == 0) s_k = band_piece(P, m, 0);
+        __syncthreads();
+        int par = 0;
+        for (int d0 = 0; d0 <= D; d0 += BAND_TILE, par ^= 1) {
+            const int k0 = s_k;
+            const int staged = min(BAND_STAGE + 1, m + 1 - k0);  // points k0 .. k0 + staged - 1 (P has m + 1 points)
+            for (int i = tid; i < staged; i += BAND_THREADS) s_pt[i] = P[k0 + i];
             __syncthreads();
-            const int d = d0 + threadIdx.x;
-            if (d <= D) {
-                int lo = s_k[0], hi = s_k[1];
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (P[mid].d0() <= d) lo = mid; else hi = mid - 1;
+            auto pt = [&](int k) -> PlanPoint { return k - k0 < staged ? s_pt[k - k0] : P[k]; };
+            const int kmax = min(k0 + staged - 2, m - 1);  // last piece whose end point is staged too
+            int klast = k0;
+#pragma unroll
+            for (int j = 0; j < BAND_SUB; ++j) {
+                const int q = j * BAND_THREADS + tid, d = d0 + q;
+                if (d <= D) {
+                    int lo = k0, hi = kmax;  // the last k in [k0, kmax] with d0(P_k) <= d
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (s_pt[mid - k0].d0() <= d) lo = mid; else hi = mid - 1;
+                    }
+                    if (lo == kmax && kmax < m - 1 && pt(kmax + 1).d0() <= d) lo = band_piece(P, m, d);  // (pieces without a row: beyond what is staged)
+                    const BandRow r = band_row_of_piece(a.fixed_mode, a.width, sg.lX, sg.lY, pt(lo), pt(lo + 1), d);
+                    a.lo[sg.band_off + d] = r.lo;
+                    a.n[sg.band_off + d] = r.n;
+                    cells += r.n > 0 ? r.n : 0;
+                    gen += r.n > 0 ? ((r.n + 3) & ~3) : 0;
+                    wmax = max(wmax, r.n);
+                    bad += r.n < 1;
+                    s_lo[q] = r.lo, s_hi[q] = r.lo + 2 * (r.n - 1);
+                    klast = lo;
                 }
-                const BandRow r = band_row_of_piece(a.fixed_mode, a.width, sg.lX, sg.lY, P[lo], P[lo + 1], d);
-                a.lo[sg.band_off + d] = r.lo;
-                a.n[sg.band_off + d] = r.n;
-                cells += r.n > 0 ? r.n : 0;
-                gen += r.n > 0 ? ((r.n + 3) & ~3) : 0;
-                wmax = max(wmax, r.n);
-                bad += r.n < 1;
-                s_lo[threadIdx.x + 1] = r.lo, s_hi[threadIdx.x + 1] = r.lo + 2 * (r.n - 1);
+            }
+            if (tid == BAND_THREADS - 1 && d0 + BAND_TILE <= D) {  // on to the next tile: its first row's piece, this tile's last row
+                int k = klast;
+                while (k + 1 < m && pt(k + 1).d0() <= d0 + BAND_TILE) ++k;
+                s_k = k;
+                s_carry[par][0] = s_lo[BAND_TILE - 1], s_carry[par][1] = s_hi[BAND_TILE - 1];
             }
             __syncthreads();
             // both edges must move by exactly one cell per anti-diagonal (what the stripe table's binary searches and the
             // frame schedules rely on); a band that does not is flagged and takes the general paths
-            if (d <= D && d > 0) {
-                const int dl = s_lo[threadIdx.x + 1] - s_lo[threadIdx.x], dh = s_hi[threadIdx.x + 1] - s_hi[threadIdx.x];
-                rough += (dl != 1 && dl != -1) || (dh != 1 && dh != -1);
+#pragma unroll
+            for (int j = 0; j < BAND_SUB; ++j) {
+                const int q = j * BAND_THREADS + tid, d = d0 + q;
+                if (d <= D && d > 0) {
+                    const int pl = q ? s_lo[q - 1] : s_carry[par ^ 1][0], ph = q ? s_hi[q - 1] : s_carry[par ^ 1][1];
+                    const int dl = s_lo[q] - pl, dh = s_hi[q] - ph;
+                    rough += (dl != 1 && dl != -1) || (dh != 1 && dh != -1);
+                }
             }
-            __syncthreads();
-            if (threadIdx.x == BAND_THREADS - 1) s_lo[0] = s_lo[BAND_THREADS], s_hi[0] = s_hi[BAND_THREADS];
-            __syncthreads();
         }
-        s_cells[threadIdx.x] = cells, s_gen[threadIdx.x] = gen, s_w[threadIdx.x] = wmax, s_bad[threadIdx.x] = bad, s_rough[threadIdx.x] = rough;
+        s_cells[tid] = cells, s_gen[tid] = gen, s_w[tid] = wmax, s_bad[tid] = bad, s_rough[tid] = rough;
         __syncthreads();
         for (int k = BAND_THREADS / 2; k > 0; k >>= 1) {
-            if (threadIdx.x < k) {
-                s_cells[threadIdx.x] += s_cells[threadIdx.x + k], s_gen[threadIdx.x] += s_gen[threadIdx.x + k];
-                s_w[threadIdx.x] = max(s_w[threadIdx.x], s_w[threadIdx.x + k]), s_bad[threadIdx.x] += s_bad[threadIdx.x + k];
-                s_rough[threadIdx.x] += s_rough[threadIdx.x + k];
+            if (tid < k) {
+                s_cells[tid] += s_cells[tid + k], s_gen[tid] += s_gen[tid + k];
+                s_w[tid] = max(s_w[tid], s_w[tid + k]), s_bad[tid] += s_bad[tid + k];
+                s_rough[tid] += s_rough[tid + k];
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) a.summary[g] = SegSummary{s_cells[0], s_gen[0], s_w[0], s_bad[0], s_rough[0], 0};
+        if (tid == 0) a.summary[g] = SegSummary{s_cells[0], s_gen[0], s_w[0], s_bad[0], s_rough[0], 0};
         __syncthreads();
     }
 }

@@ -377,10 +377,14 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     pending = list(reversed(chunk_bounds(src.lengths(), lo, hi, chunk_bases, len(ctxs))))  # a stack: splits go back on top
     # NPR_OPT_OVERLAP = 2: the MEA tables of a chunk off the device's shared scratch, so that the next chunk's DP pass starts when it
     # is staged and not when this chunk's MEA stage has given the scratch back (a kernel trace showed 10-15 ms per chunk of exactly
-    # that wait: 414 -> 403 ms per 50 000 reads, 393 with GPU_MAX_HW_QUEUES=8).  Value 1 also leaves a wavefront slot per SIMD free
-    # beside a DP pass: measured twice, it gives the DP pass 5 % more time and the other kernels nothing they do not get anyway
-    # (DESIGN.md section 6b).  NPR_JOB_OVERLAP=0 / 1 / 2 picks one for an A/B run.
-    overlap = int(os.environ.get("NPR_JOB_OVERLAP") or "2") if (len(ctxs) > 1 and len(pending) > 1) else 0  # (set but empty: the default)
+    # that wait: 414 -> 403 ms per 50 000 reads, 393 with GPU_MAX_HW_QUEUES=8).  Value 1 (the default since the end of round 5) also has
+    # the DP launches leave half of every SIMD to the other chunks' staging and MEA kernels: with ONE slot per SIMD left free (rounds
+    # 4-5) it bought nothing -- 80 registers and one wavefront hold none of the kernels that matter --, with four the job of 50 000
+    # reads takes 352-361 ms instead of 367-372.  NPR_JOB_OVERLAP=0 / 1 / 2 picks one for an A/B run.
+    # A rank held to a few host threads (NPR_HOST_THREADS, as bench.py sets it per rank) is bound by its host phases: the DP passes
+    # keep the whole chip there (2 threads, 50 000 reads: 645 ms against 672).
+    few_threads = 0 < int(os.environ.get("NPR_HOST_THREADS") or "0") < 4
+    overlap = int(os.environ.get("NPR_JOB_OVERLAP") or ("2" if few_threads else "1")) if (len(ctxs) > 1 and len(pending) > 1) else 0  # (set but empty: the default)
     for c in ctxs:
         c.set_option(_lib.OPT_OVERLAP, overlap)
     n_planned = len(pending)
