@@ -645,7 +645,7 @@ def c3_job(env, n_reads, steps, warmup, from_files):
                    "input_bytes": in_bytes, "output_bytes": sam_bytes},
         "reads_per_s": n_reads * steps / elapsed,
         "ok_reads": ok,
-        "step": ("per rank: map SAM + FASTA, parse its shard (native), then chunks of ~12 k reads as a pipeline on its GPU (stage = plan + pack + "
+        "step": ("per rank: map SAM + FASTA, parse its shard (native), then chunks of ~6 k reads (5e7 bases) as a pipeline on its GPU (stage = plan + pack + "
                  "H2D + device planner | DP | finish = MEA chain + cigar | fetch + splice of the records' bytes: one thread per phase), blocks written at "
                  "the rank's offset of the one output; per-read results gathered to rank 0 (RCCL) inside the timed region") if from_files else
                 "per rank: the same pipeline over arrays resident in host memory, records formatted natively",
