@@ -17,7 +17,8 @@ class FakeCtx(object):
         self.peak = 0
 
     def set_option(self, option, value):
-        pass
+        self.options = getattr(self, "options", {})
+        self.options[option] = value
 
 
 class FakeBatch(object):
@@ -110,6 +111,23 @@ def test_blocks_come_in_record_order_and_chunks_that_do_not_fit_are_halved(kw):
     if kw:
         assert max(b - a for a, b in src.staged if not kw.get("fail_run") or True) >= 50 and len(src.staged) > 10
     _all_back(src, ctxs, before)
+
+
+@pytest.mark.parametrize("threads,want", [(None, 1), ("16", 1), ("2", 2)])
+def test_contexts_of_a_pipelined_job_leave_room_beside_their_dp_passes(monkeypatch, threads, want):
+    """NPR_OPT_OVERLAP of a job of several chunks: 1 (own MEA tables, DP launches that leave half of every SIMD to the other chunks' kernels),
+    2 (the tables only) for a rank held to a few host threads; 0 for a job of one chunk (nothing to run beside)."""
+    if threads is None:
+        monkeypatch.delenv("NPR_HOST_THREADS", raising=False)
+    else:
+        monkeypatch.setenv("NPR_HOST_THREADS", threads)
+    monkeypatch.delenv("NPR_JOB_OVERLAP", raising=False)
+    ctxs = [FakeCtx() for _ in range(3)]
+    _run(FakeSrc(1000), ctxs)
+    assert all(c.options[_lib.OPT_OVERLAP] == want for c in ctxs)
+    one = [FakeCtx() for _ in range(3)]
+    _run(FakeSrc(40), one)
+    assert all(c.options[_lib.OPT_OVERLAP] == 0 for c in one)
 
 
 @pytest.mark.parametrize("kw,exc", [(dict(fail_run="boom"), RuntimeError), (dict(fail_finish=True), RuntimeError),
