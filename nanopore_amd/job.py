@@ -383,7 +383,10 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
     # reads takes 352-361 ms instead of 367-372.  NPR_JOB_OVERLAP=0 / 1 / 2 picks one for an A/B run.
     # A rank held to a few host threads (NPR_HOST_THREADS, as bench.py sets it per rank) is bound by its host phases: the DP passes
     # keep the whole chip there (2 threads, 50 000 reads: 645 ms against 672).
-    few_threads = 0 < int(os.environ.get("NPR_HOST_THREADS") or "0") < 4
+    try:
+        few_threads = 0 < int(os.environ.get("NPR_HOST_THREADS") or "0") < 4
+    except ValueError:  # (the library reads the variable with atoi: anything else is "one thread" there)
+        few_threads = True
     overlap = int(os.environ.get("NPR_JOB_OVERLAP") or ("2" if few_threads else "1")) if (len(ctxs) > 1 and len(pending) > 1) else 0  # (set but empty: the default)
     for c in ctxs:
         c.set_option(_lib.OPT_OVERLAP, overlap)
