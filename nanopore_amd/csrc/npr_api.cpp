@@ -1878,7 +1878,7 @@ int32_t device_mea(npr_batch *b) {
         uint32_t *out = b->packed.get();
         std::atomic<int> failed{0};
         parallel_for(pieces, ctx->host_threads, [&](int64_t c) {  // (the items are handed out in order)
-            if (hipEventSynchronize(ctx->ops_events[c]) != hipSuccess) {
+            if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(ctx->ops_events[c]) != hipSuccess) {  // (a worker thread starts on device 0)
                 failed = 1;
                 return;
             }
