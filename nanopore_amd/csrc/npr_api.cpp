@@ -1141,7 +1141,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             if (ctx->opt[NPR_OPT_TILE_WAVES] > 0) nw = static_cast<int>(std::min<int64_t>(8, ctx->opt[NPR_OPT_TILE_WAVES]));
             waves_per_cu = std::max(1, 24 / nw);
             L.wcap = nw;
-            L.lds = kClassTab[c].kind == K_TILE_RS ? tile_rs_lds_bytes(nw) : tile_lds_bytes(nw);
+            L.lds = kClassTab[c].kind == K_TILE_RS ? tile_cs_lds_bytes(nw) : tile_lds_bytes(nw);
             L.threads = 64 * nw;
         } else if (kClassTab[c].kind == K_GENERIC_LDS) {
             // several wavefronts per task: these tasks are big, their forward scratch caps how many can be
@@ -1384,7 +1384,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
                        : kc.kind == K_RS    ? launch_rs(a, kc.R, L.grid, s, sw, flat)
                        : kc.kind == K_STAIR ? launch_stair(a, kc.R, L.grid, s)
                        : kc.kind == K_TILE ? launch_tile(a, kc.R, L.wcap, L.grid, s, flat_gap_emissions(ctx))
-                       : kc.kind == K_TILE_RS ? launch_tile_rs(a, L.wcap, L.grid, s)
+                       : kc.kind == K_TILE_RS ? launch_tile_cs(a, L.wcap, L.grid, s, sw, flat)
                        : kc.kind == K_WIDE ? launch_wide(a, kc.R, kc.NW, L.grid, s)
                                            : launch_generic(a, L.grid, L.threads, L.lds, false, kc.kind == K_GENERIC_GLOBAL, s);
         if (rc != 0) return fail(ctx, NPR_ERR_HIP, "DP kernel launch", static_cast<hipError_t>(rc));

@@ -322,8 +322,10 @@ constexpr int32_t MID_MIN_D = 4 * NPR_RS_K;
 // resident wavefronts per CU of k_dp_mid_rs<R> (80 / .. / 124 registers)
 inline int mid_waves_per_cu(int R) { return R == 1 ? 24 : (R == 2 ? 4 * NPR_MID_WAVES2 : 16); }
 int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw, bool flat);
-int launch_tile_rs(const KernelArgs &a, int NW, int grid, void *stream);  // k_dp_tile_rs: k_dp_tile's stripes, one exponent per stripe row
-size_t tile_rs_lds_bytes(int nw);
+// k_dp_tile_cs (npr_kernel_tile_cs.hip): k_dp_tile's stripes in column-scaled arithmetic -- one exponent per lane (pair of lattice columns);
+// sw / flat as for launch_rs
+int launch_tile_cs(const KernelArgs &a, int NW, int grid, void *stream, bool sw, bool flat);
+size_t tile_cs_lds_bytes(int nw);
 size_t rs_lds_bytes();
 int em_tile_waves();
 int em_tile_waves_per_cu();

@@ -1,0 +1,692 @@
+// npr_kernel_tile_cs.hip -- k_dp_tile_cs<SW, FLAT>: the column-stripe kernel for WIDE bands (k_dp_tile's mapping, npr_kernel_tile.hip)
+// in COLUMN-SCALED arithmetic: one binary exponent per LANE of a stripe -- per pair of lattice columns -- instead of one per cell
+// (npr_cell.h: ~20 of a cell's ~55 vector instructions per sweep) or one per anti-diagonal row (npr_rs.h: cheap, but a row of a
+// 3000-cell-wide rectangle spans more binary orders than fp32 has).
+//
+// Same recurrences -- cactus_realign's banded five-state forward / backward / posterior pass, SURVEY.md 8a rows a5.3-a5.5, reference
+// call site nanopore/analyses/utils.py:587, for the band the reference's own parameters give (anchors +- diagonalExpansion 10, 14
+// trimmed columns, splitMatrixBiggerThanThis 3000) --, same stripes, stripe tables, row masks and barrier-free pipeline of wavefronts
+// as k_dp_tile, same outputs.  What differs:
+//   * slot j of a stripe is lattice column X + j for the stripe's whole life, so a LANE sees one pair of columns: its values change
+//     by a few binary orders per step, never by hundreds.  A lane keeps five plain fp32 values per cell relative to 2^e, e its own
+//     (a VGPR); the recurrence inside a lane is npr_rs.h's 16-20 multiplies and FMAs and nothing else;
+//   * what a lane takes from its neighbour (the lane below in the forward sweep, above in the backward sweep: one DPP move per state
+//     and step, as in k_dp_tile) is multiplied by c = 2^(e_neighbour - e), a per-lane constant between two renormalisations;
+//   * after every 16th anti-diagonal (d % 16 == 0 forward, 15 backward: the rows [16k, 16k+15] share their exponents in both sweeps)
+//     every lane brings its largest value to 2^TCS_TOP and the exponents are made LIPSCHITZ along the data flow: e_l >= e_(l-1) -
+//     TCS_C (one prefix maximum across the wavefront), so that c never exceeds 2^TCS_C and nothing overflows however far a value
+//     travels inside a block (16 steps = 8 lanes: 2^(TCS_TOP + 6 + 8 TCS_C) < 2^127);
+//   * the cell a stripe hands to its neighbour stripe travels with its lane's exponent, constant over a block of 16 rows: the blocks
+//     of neighbour cells are staged aligned to those rows and the receiver's lane 0 (63) treats the exponent like a neighbour lane's;
+//   * slots outside the band take the dead base code: all emissions 0, every state an exact zero (npr_rs.h) -- no EXEC masks;
+//   * a forward row is 4 bytes per cell in the scratch, written whole; the lanes' exponents of a block go into the unused half of the
+//     block's first row;
+//   * the range certificate is per lane: a value a sweep flushed (below 2^-126 in its lane's units) times the largest value the other
+//     sweep can hold in that lane and block (its exponent maximised over the lanes a value can have come from) must stay below
+//     2^-89 of the total; a task with a lane above that (TCS_S_LIMIT) runs again in k_dp_tile (TASK_RERUN, npr_device.h).
+// Scaling by powers of two is exact: wherever nothing leaves fp32's range relative to its lane the results are those of the
+// per-cell-exponent kernels bit for bit, and the parity tests compare them with that mirror (tests/test_gpu_tile.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "npr_device.h"
+#include "npr_frame.h"
+#include "npr_rs.h"
+
+namespace npr {
+
+namespace {
+
+constexpr int TCS_MAX_NW = 8;           // wavefronts per workgroup (launch bound)
+constexpr int TCS_BLOCK = 16;           // rows that share their exponents = neighbour cells staged / published at a time
+static_assert(TCS_BLOCK == RS_K && TCS_BLOCK == 16, "the blocks of k_dp_tile_cs are npr_rs.h's");
+constexpr int TCS_EDGE = 8;             // one neighbour cell in memory: m, sx, sy, lx | ly, e, e^, -
+constexpr int TCS_TOP = 50;             // a renormalised lane's largest value lies in [2^49, 2^50)
+constexpr int TCS_C = 8;                // a lane's exponent is at least (the exponent of the lane its data comes from) - TCS_C
+constexpr int TCS_REACH = 8;            // lanes a value can cross inside one block (16 steps, two slots per lane)
+constexpr int TCS_NONE = -(1 << 24);    // exponent of "nothing there"
+constexpr int TCS_BIAS = 1 << 25;       // makes every exponent a positive number for the unsigned wave scan
+// lost mass per flushed value < 2^(cert + TCS_TOP + 6 - 126 + 1) of the total, cert = e^F + e^B - eTot of its lane and block; at most 2^28
+// values (cells x states x sweeps) per task: below 2^-60 in all while cert stays below this
+constexpr int TCS_S_LIMIT = 126 - 60 - 28 - (TCS_TOP + 6) - 1;
+static_assert(TCS_TOP + 6 + TCS_REACH * TCS_C < 127, "a value that crosses TCS_REACH lanes inside a block must stay finite");
+
+typedef const __attribute__((address_space(4))) int32_t *cptr_i32;
+
+struct UStripe {
+    int X, K, df, dl;
+    uint32_t row0;
+};
+__device__ __forceinline__ UStripe load_stripe(const Stripe *tab, int s) {
+    cptr_i32 p = (cptr_i32)(tab + s);
+    return UStripe{p[0], p[1], p[2], p[3], static_cast<uint32_t>(p[4])};
+}
+__device__ __forceinline__ Masks<2> row_masks(uint32_t w) {
+    Masks<2> m;
+    m.cell[0] = (~0ull << (w & 63u)) & (~0ull >> ((w >> 6) & 63u));
+    m.cell[1] = (~0ull << ((w >> 12) & 63u)) & (~0ull >> ((w >> 18) & 63u));
+    m.lanes = m.cell[0] | m.cell[1];
+    m.l0 = 0;
+    return m;
+}
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ int lds_peek(const int *p) { return *(const volatile lds_int *)(p); }
+__device__ __forceinline__ void lds_poke(int *p, int v) { *(volatile lds_int *)(p) = v; }
+
+// One row per anti-diagonal of a stripe: 128 cells of 4 bytes, lane l at 8 l, in the first half of the row's space (the region is laid
+// out for k_dp_tile's 8-byte cells, which may have to run the task again); bytes 512 + 8 l of a block's first row: (e, e^) of lane l.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stripe_rsrc(char *base, uint32_t row0, int row_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base + static_cast<int64_t>(row0) * row_bytes, 0, -1, 0x00020000);
+}
+constexpr int TCS_ROW_BYTES = 1024, TCS_EXP_AT = 512;
+
+// `cnt` neighbour cells of the rows [first, first + 16) of the neighbour stripe into this wavefront's LDS staging, record i = row first + i;
+// rows outside [lo_row, hi_row] (the neighbour stripe has none there) become zeros.  Lane i takes record i; the loads bypass the vector
+// L1 (sc1): the producer is another wavefront of this workgroup.  Returns the records' (e, e^) in the lanes that loaded one.
+struct EdgeExp {
+    int e, eh;
+};
+__device__ __forceinline__ EdgeExp tcs_edge_stage(char *Eb, uint32_t row0N, int dfN, int first, int lo_row, int hi_row, float *stage, int lane) {
+    const int row = first + lane;
+    v4i q = v4i{0, 0, 0, 0}, g = v4i{0, TCS_NONE, TCS_NONE, 0};
+    if (lane < TCS_BLOCK) {
+        if (row >= lo_row && row <= hi_row) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Eb + (static_cast<int64_t>(row0N) - dfN) * (4 * TCS_EDGE), 0, -1, 0x00020000);
+            q = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * row, 0, 16);
+            g = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * row + 16, 0, 16);
+        }
+        *reinterpret_cast<v4i *>(stage + TCS_EDGE * lane) = q;
+        *reinterpret_cast<v4i *>(stage + TCS_EDGE * lane + 4) = g;
+    }
+    return EdgeExp{g.y, g.z};
+}
+__device__ __forceinline__ RCell tcs_edge_get(const float *stage, int i) {
+    const float4 q = *reinterpret_cast<const float4 *>(stage + TCS_EDGE * i);
+    const float g = stage[TCS_EDGE * i + 4];
+    return RCell{q.x, q.y, q.z, q.w, g};
+}
+
+__device__ __forceinline__ RCell dpp_rcell_from_below(const RCell &v, const RCell &edge) {
+    RCell o;
+    o.m = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.m), fbits(v.m), 0x138, 0xf, 0xf, false));
+    o.sx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sx), fbits(v.sx), 0x138, 0xf, 0xf, false));
+    o.sy = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sy), fbits(v.sy), 0x138, 0xf, 0xf, false));
+    o.lx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.lx), fbits(v.lx), 0x138, 0xf, 0xf, false));
+    o.ly = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.ly), fbits(v.ly), 0x138, 0xf, 0xf, false));
+    return o;
+}
+__device__ __forceinline__ RCell dpp_rcell_from_above(const RCell &v, const RCell &edge) {
+    RCell o;
+    o.m = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.m), fbits(v.m), 0x130, 0xf, 0xf, false));
+    o.sx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sx), fbits(v.sx), 0x130, 0xf, 0xf, false));
+    o.sy = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.sy), fbits(v.sy), 0x130, 0xf, 0xf, false));
+    o.lx = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.lx), fbits(v.lx), 0x130, 0xf, 0xf, false));
+    o.ly = bitsf(__builtin_amdgcn_update_dpp(fbits(edge.ly), fbits(v.ly), 0x130, 0xf, 0xf, false));
+    return o;
+}
+
+// 2^k, k clamped to [-127, 127]; 2^-127 and below: 0 (what is that far down is flushed)
+__device__ __forceinline__ float tcs_pow2(int k) { return bitsf((min(max(k, -127), 127) + 127) << 23); }
+
+// inclusive prefix maximum across the wavefront (lane l: the largest of lanes 0 .. l), positive 32-bit numbers: npr_rs.h's wave_max_u32 without
+// the final read of lane 63
+__device__ __forceinline__ uint32_t tcs_prefix_max(uint32_t v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int tcs_lane_get(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(4 * src_lane, v); }
+
+// What one lattice column costs: the largest transition x emission of a move that advances x (into match, shortGapX, longGapX, from any state) is
+// at most 2^-(this many) -- rounded towards 0, clamped to [0, 8].  Both sweeps advance columns by the same moves.
+__device__ __forceinline__ int tcs_column_cost(const DevModel *m) {
+    float g = 0.f;
+    const int to[3] = {0, 1, 3};
+    for (int j = 0; j < 3; ++j) {
+        float tmax = 0.f, emax = 0.f;
+        for (int from = 0; from < 5; ++from) tmax = fmaxf(tmax, m->T[from * 5 + to[j]]);
+        if (j == 0)
+            for (int i = 0; i < 25; ++i) emax = fmaxf(emax, m->em[i]);
+        else
+            for (int i = 0; i < 5; ++i) emax = fmaxf(emax, m->ex[to[j] * 5 + i]);
+        g = fmaxf(g, tmax * emax);
+    }
+    if (!(g > 0.f)) return 8;
+    int k;
+    (void)__builtin_frexpf(g, &k);  // g = f 2^k, f in [0.5, 1): -log2 g >= -k
+    return min(max(-k, 0), 8);
+}
+
+// A stripe's register state: the rows of the two previous anti-diagonals and the carried neighbour copy in THIS lane's units 2^e; c = 2^(e of
+// the lane the data comes from - e); eh: the largest e of the lanes a value of this block can have come from (the certificate's bound).
+struct CsState {
+    RDiag<2> A, B;
+    RCell carry;
+    int e, eh;
+    float c;
+};
+// The exponents of a stripe nothing has entered yet: going down by TCS_C per lane from where its first values will appear -- from the neighbour
+// stripe's edge lane (origin -1 / 64, exponent e_in; TCS_NONE: no neighbour, 0) or from the lane of the start / end cell (whose exponent is then -TCS_TOP).
+template <bool FWD>
+__device__ __forceinline__ void tcs_init(CsState &Q, int lane, int e_in, int eh_in, int origin, int dslot) {
+    Q.A = zero_rdiag<2>(), Q.B = zero_rdiag<2>(), Q.carry = zero_rcell();
+    const bool cell = origin >= 0 && origin < WAVE;  // the start / end cell goes in at 2^TCS_TOP like a renormalised value
+    const int base = cell ? -TCS_TOP : (e_in == TCS_NONE ? 0 : e_in);
+    const int src = FWD ? lane - 1 : lane + 1;  // the lane this one's neighbour values come from
+    Q.e = base - TCS_C * abs(lane - origin);
+    // what can be in this lane before the first renormalisation: what the neighbour stripe's edge lane holds, TCS_REACH lanes far at most and discounted
+    // by the columns in between (tcs_renorm); around the start / end cell: that cell's 2^0
+    const int pos = FWD ? lane : WAVE - 1 - lane;
+    Q.eh = cell ? base : (pos <= TCS_REACH ? eh_in - dslot * (2 * pos + 1) : TCS_NONE);
+    Q.c = (src < 0 || src >= WAVE) ? (e_in == TCS_NONE ? 0.f : tcs_pow2(e_in - Q.e)) : tcs_pow2(TCS_C * (abs(lane - origin) - abs(src - origin)));
+}
+// Renormalisation of everything a stripe holds, lane by lane, with the exponents kept Lipschitz along the data flow; e_in / eh_in: the
+// neighbour stripe's edge lane for the block to come (uniform; TCS_NONE: it has no rows there).
+template <bool FWD>
+__device__ __forceinline__ void tcs_renorm(CsState &Q, int lane, int e_in, int eh_in, int dslot) {
+    const int pos = FWD ? lane : WAVE - 1 - lane;
+    uint32_t u = rcell_max_bits(Q.carry);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) u = umax3(u, rcell_max_bits(Q.A.c[r]), rcell_max_bits(Q.B.c[r]));
+    const int eb = static_cast<int>(u >> 23);  // biased exponent of the lane's largest value; 0: nothing (or less than a normal number)
+    const int own = eb ? Q.e + eb - (126 + TCS_TOP) : TCS_NONE;
+    int t = own + TCS_C * pos + TCS_BIAS;
+    if (pos == 0) t = max(t, e_in - TCS_C + TCS_BIAS);
+    if constexpr (!FWD) t = tcs_lane_get(t, WAVE - 1 - lane);
+    t = static_cast<int>(tcs_prefix_max(static_cast<uint32_t>(t)));
+    if constexpr (!FWD) t = tcs_lane_get(t, WAVE - 1 - lane);
+    const int en = t - TCS_BIAS - TCS_C * pos;
+    const float f = tcs_pow2(Q.e - en);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) rcell_scale(Q.A.c[r], f), rcell_scale(Q.B.c[r], f);
+    rcell_scale(Q.carry, f);
+    const int eu = FWD ? dpp_from_below(en, e_in) : dpp_from_above(en, e_in);
+    Q.c = tcs_pow2(eu - en);
+    Q.e = en;
+    // What bounds the values this lane can hold during the coming block: its own exponent, and the exponents of the TCS_REACH lanes a value can
+    // arrive from, each DISCOUNTED by what the trip costs -- a value that advances one lattice column was multiplied by a transition and an
+    // emission, at most 2^-dslot (tcs_column_cost), and from k lanes away it advances 2 k - 1 columns at least.  Without the discount the bound
+    // counts the natural decay away from an alignment's ridge (4-5 binary orders per lane) as if it were headroom used: one task in five then
+    // fails a certificate that nothing threatens.
+    // A lane that holds nothing (own == TCS_NONE: its exponent is only its place in the chain) has nothing to send and bounds nothing.
+    const int have = own == TCS_NONE ? TCS_NONE : en;
+    int w = tcs_lane_get(have, FWD ? max(lane - 1, 0) : min(lane + 1, WAVE - 1)) - dslot;  // k = 1 (the edge lane reads itself: harmless, it is below `have`)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // k = 2 .. 8: windows of 2, 4, 8 lanes, 2 dslot per lane
+        const int s = 1 << i;
+        w = max(w, tcs_lane_get(w, FWD ? max(lane - s, 0) : min(lane + s, WAVE - 1)) - 2 * dslot * s);
+    }
+    const int m = max(have, w);
+    Q.eh = pos <= TCS_REACH ? max(m, eh_in - dslot * (2 * pos + 1)) : m;
+}
+
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Waiting for a neighbour stripe's progress word.  Bounded: a table that promised rows no wavefront will ever write must not hang the device --
+// after ~2^22 polls (seconds) the wait gives up and the task is reported for the second pass (TASK_RERUN), whose kernel has the same bound.
+constexpr int TCS_SPIN_LIMIT = 1 << 22;
+__device__ __forceinline__ void tcs_wait_at_least(const int *p, int need, int &stuck) {
+    int spins = 0;
+    while (uni(lds_peek(p)) < need && spins < TCS_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2), ++spins;
+    if (spins >= TCS_SPIN_LIMIT) stuck = 1;
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void tcs_wait_at_most(const int *p, int need, int &stuck) {
+    int spins = 0;
+    while (uni(lds_peek(p)) > need && spins < TCS_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2), ++spins;
+    if (spins >= TCS_SPIN_LIMIT) stuck = 1;
+    asm volatile("" ::: "memory");
+}
+
+#ifndef NPR_TCS_WAVES
+#define NPR_TCS_WAVES 6
+#endif
+#ifndef NPR_TCS_T_SGPR
+#define NPR_TCS_T_SGPR 1
+#endif
+template <bool SW, bool FLAT>
+__global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_per_eu(NPR_TCS_WAVES))) k_dp_tile_cs(KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RsTables *ltab = reinterpret_cast<RsTables *>(smem);
+    float *lmodel = reinterpret_cast<float *>(smem) + ((RS_TABLE_FLOATS + 3) & ~3);
+    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] pair counter, [5] next task, [6] largest certificate value
+    int *prog = lmisc + 8;                                        // [TCS_MAX_NW] rows whose neighbour cells are out
+    constexpr int R = 2, K = 64 * R;
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
+    const int NW = static_cast<int>(blockDim.x) >> 6;
+    float *const stage = reinterpret_cast<float *>(prog + TCS_MAX_NW) + wv * (TCS_BLOCK * TCS_EDGE);
+    char *const F = a.F + uni64(a.region[blockIdx.x]) * 8;
+    const int voff = 4 * R * lane;
+    int jr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
+
+    int t = blockIdx.x;
+    while (t < a.ntasks) {
+        const Task *tp = a.tasks + t;
+        const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), pair_off = uni64(tp->pair_off),
+                      tile_off = uni64(tp->tile_off), rowmask_off = uni64(tp->rowmask_off);
+        const int lX = uni(tp->lX), lY = uni(tp->lY), D = uni(tp->D), pair_cap = uni(tp->pair_cap),
+                  flags = uni(tp->flags), model = uni(tp->model), xs = uni(tp->xs), ys = uni(tp->ys);
+        cptr32 rowmask = (cptr32)(a.rowmask + rowmask_off);  // one packed word per row, through the scalar cache
+        const Stripe *tab = a.stripes + tile_off;
+        const UStripe hd = load_stripe(tab, 0);
+        const int S = hd.X;
+        const uint32_t rows = static_cast<uint32_t>(hd.K);
+        tab += 1;
+        char *const Ef = F + static_cast<int64_t>(rows) * (K * 8);          // neighbour cells of the forward sweep (+ their lane's exponents)
+        char *const Eb = Ef + static_cast<int64_t>(rows) * (4 * TCS_EDGE);  // ... of the backward sweep
+        const int rs = flags & 1, re = (flags >> 1) & 1;
+
+        __syncthreads();
+        {
+            const float *gm = reinterpret_cast<const float *>(a.models + model);
+            for (int i = threadIdx.x; i < MODEL_FLOATS; i += blockDim.x) lmodel[i] = gm[i];
+            if (threadIdx.x == 0) lmisc[0] = 0, lmisc[1] = E_DEAD, lmisc[2] = 0, lmisc[3] = E_DEAD, lmisc[4] = 0, lmisc[6] = -(1 << 30);
+            if (threadIdx.x < TCS_MAX_NW) prog[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        rs_build_tables(ltab, reinterpret_cast<const DevModel *>(lmodel), threadIdx.x, blockDim.x);
+        if (threadIdx.x == 0) lmisc[7] = tcs_column_cost(reinterpret_cast<const DevModel *>(lmodel));
+        __syncthreads();
+        const int dslot = uni(lmisc[7]);
+        StepEnv E;
+        E.mdl = reinterpret_cast<const DevModel *>(lmodel);
+        E.ltab = reinterpret_cast<const char *>(ltab);
+        E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
+        {
+            Trans tr = load_trans(E.mdl->T);
+#if NPR_TCS_T_SGPR
+            tr.mm = unif(tr.mm), tr.sxm = unif(tr.sxm), tr.sym = unif(tr.sym), tr.lxm = unif(tr.lxm), tr.lym = unif(tr.lym);
+            tr.msx = unif(tr.msx), tr.sxsx = unif(tr.sxsx), tr.sysx = unif(tr.sysx);
+            tr.msy = unif(tr.msy), tr.sysy = unif(tr.sysy), tr.sxsy = unif(tr.sxsy);
+            tr.mlx = unif(tr.mlx), tr.lxlx = unif(tr.lxlx), tr.mly = unif(tr.mly), tr.lyly = unif(tr.lyly);
+#endif
+            E.tr = tr;
+        }
+        const DevModel *mdl = E.mdl;
+        int stuck = 0;
+
+        // =============================== forward ===============================
+        for (int s = wv; s < S; s += NW) {
+            const UStripe st = load_stripe(tab, s);
+            if (st.dl >= st.df) {
+            int dfL = 1, dlL = 0, wL = 0;
+            uint32_t row0L = 0;
+            if (s > 0) {
+                const UStripe sl = load_stripe(tab, s - 1);
+                dfL = sl.df, dlL = sl.dl, row0L = sl.row0;
+                wL = (s - 1) % NW;
+            }
+            Bases<R> bx, by;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bx.b[r] = base8<RS_XS>(E.X, lX, st.X + jr[r] - 1);
+                by.b[r] = base8(E.Y, lY, (st.df - 1) - st.X - jr[r] - 1);  // as of anti-diagonal df - 1
+            }
+            Feed fy;
+            feed8_init<+1>(fy, E.Y, lY, st.df - st.X - 1, lane);
+            cptr32 rm = rowmask + st.row0;
+            uint32_t w_n = rm[0];
+            const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc(F, st.row0, TCS_ROW_BYTES), rsE = stripe_rsrc(Ef, st.row0, 4 * TCS_EDGE);
+            // the left stripe's block of rows [16 kb, 16 kb + 15]: wait until it is out, stage it, its lane-63 exponents
+            auto take_block = [&](int kb, int &e_in, int &eh_in) {
+                const int first = kb * TCS_BLOCK, lo = max(first, dfL), hi = min(first + TCS_BLOCK - 1, dlL);
+                if (hi >= lo) {  // uniform
+                    const int need = static_cast<int>(row0L) + (hi - dfL) + 1;
+                    tcs_wait_at_least(prog + wL, need, stuck);
+                }
+                const EdgeExp x = tcs_edge_stage(Ef, row0L, dfL, first, lo, hi, stage, lane);
+                e_in = hi >= lo ? __builtin_amdgcn_readlane(x.e, lo - first) : TCS_NONE;
+                eh_in = hi >= lo ? __builtin_amdgcn_readlane(x.eh, lo - first) : TCS_NONE;
+            };
+            CsState Q;
+            {
+                int e_in, eh_in;
+                take_block((st.df - 1) >> 4, e_in, eh_in);
+                tcs_init<true>(Q, lane, e_in, eh_in, s == 0 ? 0 : -1, dslot);  // (the start cell (0, 0) is slot 0 of the first stripe)
+                // (x-1, y-1) of slot 0 on the first anti-diagonal: the left stripe's cell on df - 2 -- in the block before when df - 1 opens one
+                const int q0 = st.df - 2;
+                if (q0 >= dfL && q0 <= dlL) {  // uniform
+                    const int need = static_cast<int>(row0L) + (q0 - dfL) + 1;
+                    tcs_wait_at_least(prog + wL, need, stuck);
+                    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(Ef + (static_cast<int64_t>(row0L) + (q0 - dfL)) * (4 * TCS_EDGE), 0, -1, 0x00020000);
+                    const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rq, 0, 0, 16);
+                    const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rq, 16, 0, 16);
+                    if (lane == 0) {
+                        const int k = g.y - Q.e;
+                        Q.carry = RCell{__builtin_ldexpf(bitsf(q.x), k), __builtin_ldexpf(bitsf(q.y), k), __builtin_ldexpf(bitsf(q.z), k),
+                                        __builtin_ldexpf(bitsf(q.w), k), __builtin_ldexpf(bitsf(g.x), k)};
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(v2i{Q.e, Q.eh}, rsF, TCS_EXP_AT + 8 * lane, 0, 0);
+            }
+
+            auto step = [&](int d, RDiag<R> &io, const RDiag<R> &p1) {
+                const int k = d - st.df;
+                const Masks<R> mk = row_masks(w_n);
+                if (d < st.dl) w_n = rm[1];
+                rm += 1;
+                const RCell edge = tcs_edge_get(stage, (d - 1) & (TCS_BLOCK - 1));
+                bases_down<R>(by, feed8_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
+                // one forward anti-diagonal: io d-2 -> d; p1 d-1; carry: the slot-below copy of d-2's top register -> that of d-1
+                RCell Le = dpp_rcell_from_below(p1.c[R - 1], edge);  // (x-1, y) of every lane's register 0, in the units of the lane it comes from
+                rcell_scale(Le, Q.c);
+                RDiag<R> o;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float em, exs, exl, eys, eyl;
+                    rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em, exs, exl, eys, eyl);
+                    o.c[r] = rs_fwd_cell<SW>(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : Q.carry, p1.c[r], em, exs, exl, eys, eyl);
+                }
+                io = o;
+                Q.carry = Le;
+                if (d == 0) {  // the start cell (0, 0): slot 0 of the first stripe
+                    if (lane == 0) {
+                        const int k0 = -Q.e;
+                        io.c[0] = RCell{__builtin_ldexpf(mdl->start[rs * 5 + 0], k0), __builtin_ldexpf(mdl->start[rs * 5 + 1], k0), __builtin_ldexpf(mdl->start[rs * 5 + 2], k0),
+                                        __builtin_ldexpf(mdl->start[rs * 5 + 3], k0), __builtin_ldexpf(mdl->start[rs * 5 + 4], k0)};
+                    }
+                }
+                if ((d & (TCS_BLOCK - 1)) == 0) {  // the rows from d on share new exponents; the left stripe's block of the steps to come
+                    if (d < st.dl) {
+                        int e_in, eh_in;
+                        take_block(d >> 4, e_in, eh_in);
+                        tcs_renorm<true>(Q, lane, e_in, eh_in, dslot);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(v2i{Q.e, Q.eh}, rsF, k * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(io.c[0].m), fbits(io.c[1].m)}, rsF, voff + k * TCS_ROW_BYTES, 0, 0);
+                if (lane == st.K / R - 1) {  // holds the stripe's last column in its top register
+                    const int vo = 4 * TCS_EDGE * k;
+                    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[R - 1].m), fbits(io.c[R - 1].sx), fbits(io.c[R - 1].sy), fbits(io.c[R - 1].lx)}, rsE, vo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[R - 1].ly), Q.e, Q.eh, 0}, rsE, vo + 16, 0, 0);
+                }
+                if ((d & (TCS_BLOCK - 1)) == TCS_BLOCK - 1 || d == st.dl) {
+                    wait_vm();
+                    if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k + 1);
+                }
+            };
+            int d = st.df;
+            for (; d + 1 <= st.dl; d += 2) {
+                step(d, Q.B, Q.A);
+                step(d + 1, Q.A, Q.B);
+            }
+            if (d <= st.dl) step(d, Q.B, Q.A);
+            if (s == S - 1) {  // total probability at the end corner (lX, lY), anti-diagonal D = this stripe's last row
+                const bool inB = ((st.dl - st.df) & 1) == 0;
+                const int je = lX - st.X;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (jr[r] == je) {
+                        const RCell c = inB ? Q.B.c[r] : Q.A.c[r];
+                        const float raw = rs_dot5(mdl->end + re * 5, c);
+                        if (raw > 0.f) {
+                            int k;
+                            reinterpret_cast<float *>(lmisc)[0] = __builtin_frexpf(raw, &k);
+                            lmisc[1] = Q.e + k;
+                        }
+                    }
+            }
+            }
+        }
+        __syncthreads();  // (every wavefront's stores are out: the rows and their exponents are in L2)
+        const float tot_m = unif(reinterpret_cast<float *>(lmisc)[0]);
+        const int tot_e = uni(lmisc[1]);
+
+        TaskOut out;
+        out.tot_m = tot_m, out.tot_e = tot_e, out.btot_m = 0.f, out.btot_e = E_DEAD, out.npairs = 0;
+        out.status = NPR_OK;
+        const bool alive = tot_m > 0.f;
+        if (!alive) out.status = NPR_ERR_ZERO_PROB;
+
+        // =============================== backward + posteriors ===============================
+        if (alive) {
+            const float inv_tot = 1.0f / tot_m;
+            const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
+            if (threadIdx.x < TCS_MAX_NW) prog[threadIdx.x] = 0x7fffffff;  // now: the LOWEST row whose neighbour cell is out
+            __syncthreads();
+            int vsmax = -(1 << 30);
+#ifdef NPR_TCS_DEBUG
+            int dbg_d = 0, dbg_s = 0, dbg_ef = 0, dbg_efh = 0, dbg_eb = 0, dbg_ebh = 0;
+#endif
+            int s_top = S - 1 - ((S - 1 - wv) % NW + NW) % NW;  // the last stripe of this wavefront (s == wv mod NW)
+            for (int s = s_top; s >= 0; s -= NW) {
+                const UStripe st = load_stripe(tab, s);
+                if (st.dl >= st.df) {
+                int dfR = 1, dlR = 0, wR = 0;
+                uint32_t row0R = 0;
+                if (s + 1 < S) {
+                    const UStripe sr = load_stripe(tab, s + 1);
+                    dfR = sr.df, dlR = sr.dl, row0R = sr.row0;
+                    wR = (s + 1) % NW;
+                }
+                const int X0 = st.X;
+                Bases<R> bx, by;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    bx.b[r] = base8<RS_XS>(E.X, lX, X0 + jr[r]);
+                    by.b[r] = base8(E.Y, lY, (st.dl + 1) - X0 - jr[r]);  // as of anti-diagonal dl + 1
+                }
+                Feed fy;
+                feed8_init<-1>(fy, E.Y, lY, st.dl - X0 - (K - 1), lane);
+                RFRow<R> fa, fb;
+#pragma unroll
+                for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f;
+                cptr32 rm = rowmask + st.row0 + static_cast<uint32_t>(st.dl - st.df);
+                const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc(F, st.row0, TCS_ROW_BYTES), rsE = stripe_rsrc(Eb, st.row0, 4 * TCS_EDGE);
+                Masks<R> mk_n = row_masks(rm[0]);
+                {
+                    const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (st.dl - st.df) * TCS_ROW_BYTES, 0, 0);
+                    fb.v[0] = bitsf(q.x), fb.v[1] = bitsf(q.y);
+                }
+                // the right stripe's block of rows [16 kb, 16 kb + 15]
+                auto take_block = [&](int kb, int &e_in, int &eh_in) {
+                    const int first = kb * TCS_BLOCK, lo = max(first, dfR), hi = min(first + TCS_BLOCK - 1, dlR);
+                    if (hi >= lo) {  // uniform
+                        const int need = static_cast<int>(row0R) + (lo - dfR);
+                        tcs_wait_at_most(prog + wR, need, stuck);
+                    }
+                    const EdgeExp x = tcs_edge_stage(Eb, row0R, dfR, first, lo, hi, stage, lane);
+                    e_in = hi >= lo ? __builtin_amdgcn_readlane(x.e, lo - first) : TCS_NONE;
+                    eh_in = hi >= lo ? __builtin_amdgcn_readlane(x.eh, lo - first) : TCS_NONE;
+                };
+                // the forward sweep's exponents of the block that holds row d, and what turns F * B of a lane into a posterior there
+                // (in two factors: a lane a value has just entered holds mantissas far above 2^TCS_TOP until its next renormalisation -- up to
+                // 2^(TCS_TOP + 6 + 8 TCS_C) in each sweep --, so neither F * B nor 2^(eF + eB - eTot) alone is safe in fp32.  Both factors are
+                // powers of two: F * B is still rounded once, as npr_rs.h's rs_posterior rounds it.)
+                float G1 = 0.f, G2 = 0.f;
+                CsState Q;
+                auto enter_block = [&](int d) {
+                    const int kf = max(d & ~(TCS_BLOCK - 1), st.df) - st.df;
+                    const v2i x = __builtin_amdgcn_raw_buffer_load_b64(rsF, kf * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
+                    const int sx = x.x + Q.e - tot_e;
+                    G1 = tcs_pow2(sx >> 1), G2 = tcs_pow2(sx - (sx >> 1));
+#ifdef NPR_TCS_DEBUG
+                    if (x.y + Q.eh - tot_e > vsmax) dbg_d = d, dbg_s = s, dbg_ef = x.x, dbg_efh = x.y, dbg_eb = Q.e, dbg_ebh = Q.eh;
+#endif
+                    vsmax = max(vsmax, x.y + Q.eh - tot_e);
+                };
+                {
+                    int e_in, eh_in;
+                    take_block((st.dl + 1) >> 4, e_in, eh_in);
+                    tcs_init<false>(Q, lane, e_in, eh_in, s == S - 1 ? (lX - X0) / R : WAVE, dslot);  // (the end cell (lX, lY) lies in the last stripe)
+                    // (x+1, y+1) of the top slot on the first anti-diagonal: the right stripe's cell on dl + 2
+                    const int q0 = st.dl + 2;
+                    if (q0 >= dfR && q0 <= dlR) {  // uniform
+                        const int need = static_cast<int>(row0R) + (q0 - dfR);
+                        tcs_wait_at_most(prog + wR, need, stuck);
+                        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(Eb + (static_cast<int64_t>(row0R) + (q0 - dfR)) * (4 * TCS_EDGE), 0, -1, 0x00020000);
+                        const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rq, 0, 0, 16);
+                        const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rq, 16, 0, 16);
+                        if (lane == WAVE - 1) {
+                            const int k = g.y - Q.e;
+                            Q.carry = RCell{__builtin_ldexpf(bitsf(q.x), k), __builtin_ldexpf(bitsf(q.y), k), __builtin_ldexpf(bitsf(q.z), k),
+                                            __builtin_ldexpf(bitsf(q.w), k), __builtin_ldexpf(bitsf(g.x), k)};
+                        }
+                    }
+                    enter_block(st.dl);
+                }
+
+                // f: the forward row of d (loaded a step ago); fnext: where the row of d-1 goes
+                auto step = [&](int d, RDiag<R> &io, const RDiag<R> &s1, RFRow<R> &f, RFRow<R> &fnext) {
+                    const int k = d - st.df;
+                    const Masks<R> mk = mk_n;
+                    if (d > st.df) {
+                        rm -= 1;
+                        mk_n = row_masks(rm[0]);
+                        const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (k - 1) * TCS_ROW_BYTES, 0, 0);
+                        fnext.v[0] = bitsf(q.x), fnext.v[1] = bitsf(q.y);
+                    }
+                    const RCell edge = tcs_edge_get(stage, (d + 1) & (TCS_BLOCK - 1));
+                    bases_up<R>(by, feed8_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
+                    // one backward anti-diagonal: io d+2 -> d; s1 d+1; carry: the slot-above copy of d+2's register 0 -> that of d+1
+                    RCell Xe = dpp_rcell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register, in the units of the lane it comes from
+                    rcell_scale(Xe, Q.c);
+                    RDiag<R> o;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float em, exs, exl, eys, eyl;
+                        rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em, exs, exl, eys, eyl);
+                        o.c[r] = rs_bwd_cell<SW>(E.tr, r + 1 < R ? io.c[r + 1] : Q.carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
+                    }
+                    io = o;
+                    Q.carry = Xe;
+                    if (d == D) {  // the end corner (lX, lY)
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (X0 + jr[r] == lX) {
+                                const int k0 = -Q.e;
+                                io.c[r] = RCell{__builtin_ldexpf(mdl->end[re * 5 + 0], k0), __builtin_ldexpf(mdl->end[re * 5 + 1], k0), __builtin_ldexpf(mdl->end[re * 5 + 2], k0),
+                                                __builtin_ldexpf(mdl->end[re * 5 + 3], k0), __builtin_ldexpf(mdl->end[re * 5 + 4], k0)};
+                            }
+                    }
+                    if ((d & (TCS_BLOCK - 1)) == TCS_BLOCK - 1) {  // the rows from d down share new exponents; the right stripe's block of the steps to come
+                        if (d > st.df) {
+                            int e_in, eh_in;
+                            take_block(d >> 4, e_in, eh_in);
+                            tcs_renorm<false>(Q, lane, e_in, eh_in, dslot);
+                        }
+                        enter_block(d);
+                    }
+                    if (lane == 0) {  // holds the stripe's first column in its register 0
+                        const int vo = 4 * TCS_EDGE * k;
+                        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[0].m), fbits(io.c[0].sx), fbits(io.c[0].sy), fbits(io.c[0].lx)}, rsE, vo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[0].ly), Q.e, Q.eh, 0}, rsE, vo + 16, 0, 0);
+                    }
+                    // posteriors of this anti-diagonal, slots claimed from the workgroup's LDS counter
+                    {
+                        float p[R];
+                        uint64_t hit[R];
+                        int total = 0;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            p[r] = ((f.v[r] * G1) * (io.c[r].m * G2)) * inv_tot;
+                            hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
+                            total += __popcll(hit[r]);
+                        }
+                        if (d >= 2 && total) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(lmisc + 4, total);
+                            base = uni(base);
+                            const int y0 = d - X0;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                if (hit[r]) {
+                                    const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                                    const int slot = base + before;
+                                    if (lanes_of(hit[r]) && slot < sink.cap) {
+                                        sink.px[sink.off + slot] = X0 + jr[r] - 1 + sink.xs;
+                                        sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
+                                        sink.pp[sink.off + slot] = p[r];
+                                    }
+                                    base += __popcll(hit[r]);
+                                }
+                            }
+                        }
+                    }
+                    if ((d & (TCS_BLOCK - 1)) == 0 || d == st.df) {
+                        wait_vm();
+                        if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k);
+                    }
+                };
+                int d = st.dl;
+                for (; d - 1 >= st.df; d -= 2) {
+                    step(d, Q.B, Q.A, fb, fa);
+                    step(d - 1, Q.A, Q.B, fa, fb);
+                }
+                if (d >= st.df) step(d, Q.B, Q.A, fb, fa);
+                if (s == 0) {  // total from the backward side: the lattice point (0, 0) is the stripe's first slot on d = 0
+                    const bool inB = ((st.dl - st.df) & 1) == 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (X0 + jr[r] == 0) {
+                            const RCell cz = inB ? Q.B.c[r] : Q.A.c[r];
+                            const float raw = rs_dot5(mdl->start + rs * 5, cz);
+                            if (raw > 0.f) {
+                                int k;
+                                reinterpret_cast<float *>(lmisc)[2] = __builtin_frexpf(raw, &k);
+                                lmisc[3] = Q.e + k;
+                            }
+                        }
+                }
+                }
+            }
+            atomicMax(lmisc + 6, vsmax);
+            __syncthreads();
+#ifdef NPR_TCS_DEBUG
+            if (vsmax == lmisc[6] && vsmax >= TCS_S_LIMIT)
+                printf("task %d cert %d: stripe %d of %d row %d (df %d dl %d) lane %d eF %d e^F %d eB %d e^B %d eTot %d\n", t, vsmax, dbg_s, S, dbg_d, 0, 0, lane, dbg_ef, dbg_efh, dbg_eb, dbg_ebh, tot_e);
+#endif
+            out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
+            out.btot_e = uni(lmisc[3]);
+        }
+        if (stuck) atomicMax(lmisc + 6, 1 << 30);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = lmisc[4];
+            out.npairs = cnt;
+            if (cnt > pair_cap) out.status = NPR_ERR_CAPACITY;
+            if (!alive || lmisc[6] >= TCS_S_LIMIT) out.status = TASK_RERUN, out.npairs = lmisc[6];  // one exponent per lane may not have been enough (or nothing arrived: k_dp_tile decides)
+            a.outs[t] = out;
+            lmisc[5] = atomicAdd(a.queue, 1);
+        }
+        __syncthreads();
+        t = uni(lmisc[5]) + static_cast<int>(gridDim.x);
+    }
+}
+
+}  // namespace
+
+size_t tile_cs_lds_bytes(int nw) {
+    return sizeof(float) * (((RS_TABLE_FLOATS + 3) & ~3) + MODEL_FLOATS + 8 + TCS_MAX_NW + static_cast<size_t>(nw) * TCS_BLOCK * TCS_EDGE);
+}
+
+int launch_tile_cs(const KernelArgs &a, int NW, int grid, void *stream, bool sw, bool flat) {
+    if (NW < 1 || NW > TCS_MAX_NW) return static_cast<int>(hipErrorInvalidValue);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = tile_cs_lds_bytes(NW);
+    if (sw) hipLaunchKernelGGL((k_dp_tile_cs<true, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+    else if (flat) hipLaunchKernelGGL((k_dp_tile_cs<false, true>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+    else hipLaunchKernelGGL((k_dp_tile_cs<false, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace npr
