@@ -61,7 +61,7 @@ NOMINAL_CYCLES_PER_VALU = 2.0  # one wave64 VALU instruction per 2 cycles per SI
 # kernel class (npr_batch_class_stats) -> kernel name in profiles/kernel_table.json
 CLASS_KERNEL = {0: "k_dp_stair<1>", 1: "k_dp_stair<2>", 2: "k_dp_stair<4>", 3: "k_dp_wide", 4: "k_dp_wide", 5: "k_dp_wide",
                 6: "k_dp_wide", 7: "k_dp_generic", 8: "k_dp_generic", 9: "k_dp_generic", 10: "k_dp_generic", 11: "k_dp_tile<2>",
-                12: "k_dp_mid_rs<1>", 13: "k_dp_mid_rs<2>", 14: "k_dp_mid_rs<4>", 15: "k_dp_rs<1>", 16: "k_dp_rs<2>", 17: "k_dp_rs<4>", 18: "k_dp_tile_rs"}
+                12: "k_dp_mid_rs<1>", 13: "k_dp_mid_rs<2>", 14: "k_dp_mid_rs<4>", 15: "k_dp_rs<1>", 16: "k_dp_rs<2>", 17: "k_dp_rs<4>", 18: "k_dp_tile_cs"}
 RS_BYTES_PER_CELL = 8.0     # k_dp_rs / k_dp_mid_rs (row-scaled arithmetic: the exponent is per row, not per cell): 4 B stored + 4 B reloaded
                             # (k_dp_mid_rs: the forward sweep stores the rows up to the cut and the backward sweep the rows above it: the same bytes)
 EM_CLASS_KERNEL = {0: "k_em_stair<1>", 1: "k_em_stair<2>", 2: "k_em_stair<4>", 11: "k_em_tile<2>"}
@@ -213,7 +213,7 @@ def roofline_block(cells, pairs, kms, class_cells, clock_hz):
     kname = CLASS_KERNEL.get(dom, "k_dp")
     tab = kernel_table().get(kname, {})
     t = kms * 1e-3
-    rs_kernel = kname.startswith("k_dp_rs") or kname.startswith("k_dp_mid_rs") or kname == "k_dp_tile_rs"
+    rs_kernel = kname.startswith("k_dp_rs") or kname.startswith("k_dp_mid_rs") or kname == "k_dp_tile_cs"
     per_cell = RS_BYTES_PER_CELL if rs_kernel else BYTES_PER_CELL
     achieved = (per_cell * cells + BYTES_PER_PAIR * pairs) / t / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

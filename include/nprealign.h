@@ -152,7 +152,7 @@ const char *npr_last_error(npr_ctx *ctx);
 #define NPR_OPT_PAIR 5             /* a read's two sweeps on two wavefronts: 0 the default rule (row-scaled arithmetic: every task of 64+ anti-diagonals), 1 never, 2 the tasks longer than a fair share, 3 always */
 #define NPR_OPT_NO_TILE 6          /* 1: no stripe kernel (wide bands take k_dp_wide / k_dp_generic) */
 #define NPR_OPT_NO_WIDE 7          /* 1: no multi-wavefront frame kernel */
-#define NPR_OPT_TILE_RS 8          /* 1: the stripe kernel in row-scaled arithmetic */
+#define NPR_OPT_TILE_RS 8          /* the stripe kernel: 0 / 1 column-scaled arithmetic (k_dp_tile_cs, the default), 2 one exponent per cell (k_dp_tile) */
 #define NPR_OPT_TILE_WAVES 9       /* wavefronts per stripe task (1 .. 8; 0: default 4) */
 #define NPR_OPT_WAVES_PER_CU 10    /* resident wavefronts / workgroups per CU of every DP launch (0: per class) */
 #define NPR_OPT_CLASS_MIN 11       /* smallest frame class considered */
@@ -232,7 +232,8 @@ int32_t npr_batch_get_stats(const npr_batch *b, npr_batch_stats *st);
  *        values can grow from one anti-diagonal to the next.  A task for which one exponent per row was not enough (a stretch of
  *        its alignment ~110 binary orders below the row's largest values: an indel of 70+ bases) is run again by npr_batch_run
  *        with the kernel of 0-2; npr_batch_segment_arith says which arithmetic a segment's results come from.
- *   18   class 11's column stripes in row-scaled arithmetic (k_dp_tile_rs; only under NPR_OPT_TILE_RS: same bits, not faster yet) */
+ *   18   class 11's column stripes in column-scaled arithmetic (k_dp_tile_cs: one exponent per lane of a stripe; the default for the stripe
+ *        tasks since round 6, same bits as class 11; a task without its per-lane range certificate runs again in class 11's kernel) */
 int32_t npr_batch_class_stats(const npr_batch *b, int64_t *tasks, int64_t *cells, int32_t cap);
 /* Which device arithmetic each segment (matrix split) of each read ran in, in read order: seg_off[n_reads + 1], arith[seg_off
  * [n_reads]] (pass arith == NULL for the offsets alone).  0: one exponent per cell (npr_cell.h: k_dp_tile, k_dp_generic, k_dp_wide

@@ -545,7 +545,7 @@ constexpr KClass kClassTab[kClasses] = {{K_STAIR, 1, 1}, {K_STAIR, 2, 1}, {K_STA
                                         {K_MID, 1, 1}, {K_MID, 2, 1}, {K_MID, 4, 1},
                                         // k_dp_rs<R>: the one-wavefront frame classes 0-2 in row-scaled arithmetic (npr_rs.h)
                                         {K_RS, 1, 1}, {K_RS, 2, 1}, {K_RS, 4, 1},
-                                        // k_dp_tile_rs: class 11's column stripes in row-scaled arithmetic (one exponent per stripe row)
+                                        // k_dp_tile_cs: class 11's column stripes in column-scaled arithmetic (one exponent per lane of a stripe)
                                         {K_TILE_RS, 2, 0}};
 constexpr int kFirstGeneric = 7, kTileClass = 11, kFirstPair = 12, kFirstRs = 15, kTileRsClass = 18, kQueueSlots = 24;
 inline bool is_register_class(int c) { return kClassTab[c].kind <= K_WIDE || kClassTab[c].kind == K_MID || kClassTab[c].kind == K_RS; }
@@ -953,9 +953,10 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         if (rs)
             for (int64_t k = 0; k < ntasks; ++k) {
                 if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
-                // (the stripe kernel in row-scaled arithmetic, k_dp_tile_rs, is opt-in: same bits, first pass 7 % faster on the
-                // reference's band, but one task in eight fails the range certificate there and runs twice -- DESIGN.md 5.1f)
-                else if (cls_of[k] == kTileClass && ctx->opt[NPR_OPT_TILE_RS] != 0) cls_of[k] = static_cast<int8_t>(kTileRsClass);
+                // the stripe tasks run in column-scaled arithmetic (k_dp_tile_cs, round 6: one exponent per lane of a stripe; same bits, and a
+                // per-lane range certificate that the reference's 3000-cell-wide rectangles pass -- DESIGN.md 5.1f); NPR_OPT_TILE_RS = 2: the
+                // per-cell-exponent k_dp_tile throughout (A/B)
+                else if (cls_of[k] == kTileClass && ctx->opt[NPR_OPT_TILE_RS] != 2) cls_of[k] = static_cast<int8_t>(kTileRsClass);
             }
     }
     // A read on ONE wavefront is a serial chain of 2 * (lX + lY) steps: a launch lasts at least as long as its longest task, and a class

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "npr_device.h"
@@ -252,6 +253,64 @@ __device__ __forceinline__ void tcs_wait_at_most(const int *p, int need, int &st
     asm volatile("" ::: "memory");
 }
 
+// ---- one anti-diagonal of a stripe, the part every step has ----
+// forward: io d-2 -> d; p1 d-1; carry: the slot-below copy of d-2's top register -> that of d-1; erec: the left stripe's cell on d-1 (LDS)
+// FULL: every slot of the row is a band cell (its mask word is 0): the emissions come without the in-band selects
+template <bool SW, bool FLAT, bool FULL = false>
+__device__ __forceinline__ void tcs_fwd_core(const StepEnv &E, RDiag<2> &io, const RDiag<2> &p1, RCell &carry, float c, const Masks<2> &mk, const float *erec,
+                                             const Bases<2> &bx, Bases<2> &by, int inject) {
+    const RCell edge = tcs_edge_get(erec, 0);
+    bases_down<2>(by, inject);
+    RCell Le = dpp_rcell_from_below(p1.c[1], edge);  // (x-1, y) of every lane's register 0, in the units of the lane it comes from
+    rcell_scale(Le, c);
+    float em[2], exs[2], exl[2], eys[2], eyl[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) rs_cell_emissions<FULL ? 4 : 2, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
+    RDiag<2> o;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) o.c[r] = rs_fwd_cell<SW>(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : carry, p1.c[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
+    io = o;
+    carry = Le;
+}
+// backward: io d+2 -> d; s1 d+1; carry: the slot-above copy of d+2's register 0 -> that of d+1; erec: the right stripe's cell on d+1
+template <bool SW, bool FLAT, bool FULL = false>
+__device__ __forceinline__ void tcs_bwd_core(const StepEnv &E, RDiag<2> &io, const RDiag<2> &s1, RCell &carry, float c, const Masks<2> &mk, const float *erec,
+                                             const Bases<2> &bx, Bases<2> &by, int inject) {
+    const RCell edge = tcs_edge_get(erec, 0);
+    bases_up<2>(by, inject);
+    RCell Xe = dpp_rcell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register, in the units of the lane it comes from
+    rcell_scale(Xe, c);
+    float em[2], exs[2], exl[2], eys[2], eyl[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) rs_cell_emissions<FULL ? 4 : 2, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
+    RDiag<2> o;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) o.c[r] = rs_bwd_cell<SW>(E.tr, r + 1 < 2 ? io.c[r + 1] : carry, r + 1 < 2 ? s1.c[r + 1] : Xe, s1.c[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
+    io = o;
+    carry = Xe;
+}
+// the two held rows trade places (a generic step is written for an odd anti-diagonal: the row it makes goes to Q.A)
+__device__ __forceinline__ void tcs_swap_rows(RDiag<2> &A, RDiag<2> &B) {
+    const RDiag<2> t = A;
+    A = B, B = t;
+}
+__device__ __forceinline__ void tcs_store_row(__amdgpu_buffer_rsrc_t rsF, int vo, const RDiag<2> &io) {
+    __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(io.c[0].m), fbits(io.c[1].m)}, rsF, vo, 0, 0);
+}
+__device__ __forceinline__ void tcs_store_edge(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, int e, int eh) {
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.sy), fbits(c.lx)}, rsE, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.ly), e, eh, 0}, rsE, vo + 16, 0, 0);
+}
+
+// LDS of a workgroup (static: the table offsets fold into the LDS instructions, npr_rs.h)
+struct __attribute__((aligned(16))) CsLds {
+    float stage[TCS_MAX_NW][TCS_BLOCK * TCS_EDGE];  // per wavefront: the neighbour stripe's block of cells
+    RsTables tab;
+    float model[MODEL_FLOATS];
+    int misc[8];            // [0..3] totals, [4] pair counter, [5] next task, [6] largest certificate value, [7] column cost
+    int prog[TCS_MAX_NW];   // rows whose neighbour cells are out
+};
+
 #ifndef NPR_TCS_WAVES
 #define NPR_TCS_WAVES 6
 #endif
@@ -260,17 +319,16 @@ __device__ __forceinline__ void tcs_wait_at_most(const int *p, int need, int &st
 #endif
 template <bool SW, bool FLAT>
 __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_per_eu(NPR_TCS_WAVES))) k_dp_tile_cs(KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    RsTables *ltab = reinterpret_cast<RsTables *>(smem);
-    float *lmodel = reinterpret_cast<float *>(smem) + ((RS_TABLE_FLOATS + 3) & ~3);
-    int *lmisc = reinterpret_cast<int *>(lmodel + MODEL_FLOATS);  // [0..3] totals, [4] pair counter, [5] next task, [6] largest certificate value
-    int *prog = lmisc + 8;                                        // [TCS_MAX_NW] rows whose neighbour cells are out
+    __shared__ CsLds L;
+    float *lmodel = L.model;
+    int *lmisc = L.misc;
+    int *prog = L.prog;
     constexpr int R = 2, K = 64 * R;
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = uni(static_cast<int>(threadIdx.x) >> 6);
     const int NW = static_cast<int>(blockDim.x) >> 6;
-    float *const stage = reinterpret_cast<float *>(prog + TCS_MAX_NW) + wv * (TCS_BLOCK * TCS_EDGE);
+    float *const stage = L.stage[wv];
     char *const F = a.F + uni64(a.region[blockIdx.x]) * 8;
     const int voff = 4 * R * lane;
     int jr[R];
@@ -302,13 +360,13 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
             if (threadIdx.x < TCS_MAX_NW) prog[threadIdx.x] = 0;
         }
         __syncthreads();
-        rs_build_tables(ltab, reinterpret_cast<const DevModel *>(lmodel), threadIdx.x, blockDim.x);
+        rs_build_tables(&L.tab, reinterpret_cast<const DevModel *>(lmodel), threadIdx.x, blockDim.x);
         if (threadIdx.x == 0) lmisc[7] = tcs_column_cost(reinterpret_cast<const DevModel *>(lmodel));
         __syncthreads();
         const int dslot = uni(lmisc[7]);
         StepEnv E;
         E.mdl = reinterpret_cast<const DevModel *>(lmodel);
-        E.ltab = reinterpret_cast<const char *>(ltab);
+        E.ltab = reinterpret_cast<const char *>(&L.tab);
         E.X = a.seq + x_off, E.Y = a.seq + y_off, E.lX = lX, E.lY = lY, E.lane = lane;
         {
             Trans tr = load_trans(E.mdl->T);
@@ -324,6 +382,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
         int stuck = 0;
 
         // =============================== forward ===============================
+        // The row of an ODD anti-diagonal lives in Q.A, of an even one in Q.B (whatever the stripe's first row: both start as zeros).
         for (int s = wv; s < S; s += NW) {
             const UStripe st = load_stripe(tab, s);
             if (st.dl >= st.df) {
@@ -342,9 +401,9 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
             }
             Feed fy;
             feed8_init<+1>(fy, E.Y, lY, st.df - st.X - 1, lane);
-            cptr32 rm = rowmask + st.row0;
-            uint32_t w_n = rm[0];
+            cptr32 rm = rowmask + st.row0;  // the word of the row in hand is rm[0]
             const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc(F, st.row0, TCS_ROW_BYTES), rsE = stripe_rsrc(Ef, st.row0, 4 * TCS_EDGE);
+            const bool edge_lane = lane == st.K / R - 1;  // holds the stripe's last column in its top register
             // the left stripe's block of rows [16 kb, 16 kb + 15]: wait until it is out, stage it, its lane-63 exponents
             auto take_block = [&](int kb, int &e_in, int &eh_in) {
                 const int first = kb * TCS_BLOCK, lo = max(first, dfL), hi = min(first + TCS_BLOCK - 1, dlL);
@@ -378,25 +437,12 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 __builtin_amdgcn_raw_buffer_store_b64(v2i{Q.e, Q.eh}, rsF, TCS_EXP_AT + 8 * lane, 0, 0);
             }
 
+            // any row: the start cell, the block boundaries, the hand-over
             auto step = [&](int d, RDiag<R> &io, const RDiag<R> &p1) {
                 const int k = d - st.df;
-                const Masks<R> mk = row_masks(w_n);
-                if (d < st.dl) w_n = rm[1];
+                const Masks<R> mk = row_masks(rm[0]);
                 rm += 1;
-                const RCell edge = tcs_edge_get(stage, (d - 1) & (TCS_BLOCK - 1));
-                bases_down<R>(by, feed8_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
-                // one forward anti-diagonal: io d-2 -> d; p1 d-1; carry: the slot-below copy of d-2's top register -> that of d-1
-                RCell Le = dpp_rcell_from_below(p1.c[R - 1], edge);  // (x-1, y) of every lane's register 0, in the units of the lane it comes from
-                rcell_scale(Le, Q.c);
-                RDiag<R> o;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float em, exs, exl, eys, eyl;
-                    rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em, exs, exl, eys, eyl);
-                    o.c[r] = rs_fwd_cell<SW>(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : Q.carry, p1.c[r], em, exs, exl, eys, eyl);
-                }
-                io = o;
-                Q.carry = Le;
+                tcs_fwd_core<SW, FLAT>(E, io, p1, Q.carry, Q.c, mk, stage + TCS_EDGE * ((d - 1) & (TCS_BLOCK - 1)), bx, by, feed8_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
                 if (d == 0) {  // the start cell (0, 0): slot 0 of the first stripe
                     if (lane == 0) {
                         const int k0 = -Q.e;
@@ -412,30 +458,58 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                     }
                     __builtin_amdgcn_raw_buffer_store_b64(v2i{Q.e, Q.eh}, rsF, k * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(io.c[0].m), fbits(io.c[1].m)}, rsF, voff + k * TCS_ROW_BYTES, 0, 0);
-                if (lane == st.K / R - 1) {  // holds the stripe's last column in its top register
-                    const int vo = 4 * TCS_EDGE * k;
-                    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[R - 1].m), fbits(io.c[R - 1].sx), fbits(io.c[R - 1].sy), fbits(io.c[R - 1].lx)}, rsE, vo, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[R - 1].ly), Q.e, Q.eh, 0}, rsE, vo + 16, 0, 0);
-                }
+                tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
+                if (edge_lane) tcs_store_edge(rsE, 4 * TCS_EDGE * k, io.c[R - 1], Q.e, Q.eh);
                 if ((d & (TCS_BLOCK - 1)) == TCS_BLOCK - 1 || d == st.dl) {
                     wait_vm();
                     if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k + 1);
                 }
             };
+            // any row, whatever its parity: the step above is instantiated once, for an odd anti-diagonal
+            auto gstep = [&](int d) {
+                if (!(d & 1)) tcs_swap_rows(Q.A, Q.B);
+                step(d, Q.A, Q.B);
+                if (!(d & 1)) tcs_swap_rows(Q.A, Q.B);
+            };
+            // ONE loop with ONE instance of the general step (the kernel has to stay small for the instruction cache).  Where a row 16 kb + 1 opens a whole block
+            // of sixteen rows inside the stripe, its first fifteen -- no corner cell, no boundary, one hand-over at the end: nothing but the recurrence, the
+            // stores and the stream -- run in the fast loop (d is odd: pairs of an A step and a B step) and the general step takes the boundary row 16 kb + 16.
             int d = st.df;
-            for (; d + 1 <= st.dl; d += 2) {
-                step(d, Q.B, Q.A);
-                step(d + 1, Q.A, Q.B);
+            while (d <= st.dl) {
+                if ((d & (TCS_BLOCK - 1)) == 1 && d + TCS_BLOCK - 1 <= st.dl) {
+                feed8_ahead<+1>(fy, E.Y, lY, d - st.X - 1, lane);  // (the window serves the sixteen bases the block asks for)
+                int yi = uni(d - st.X - 1 - fy.base);
+                int vo = voff + (d - st.df) * TCS_ROW_BYTES, ve = 4 * TCS_EDGE * (d - st.df);
+                const float *er = stage;  // record (d - 1) & 15 = 0
+                // the rows' mask words by one vector load (lane i mod 16: row d + i), handed out by v_readlane: no scalar load to wait for in the loop
+                const int wv16 = static_cast<int>(a.rowmask[rowmask_off + st.row0 + static_cast<uint32_t>(d - st.df) + (lane & (TCS_BLOCK - 1))]);
+#pragma unroll 1
+                for (int i = 0; i < 7; ++i) {
+                    tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                    tcs_store_row(rsF, vo, Q.A);
+                    if (edge_lane) tcs_store_edge(rsE, ve, Q.A.c[R - 1], Q.e, Q.eh);
+                    tcs_fwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1)), er + TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
+                    tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
+                    if (edge_lane) tcs_store_edge(rsE, ve + 4 * TCS_EDGE, Q.B.c[R - 1], Q.e, Q.eh);
+                    yi += 2, vo += 2 * TCS_ROW_BYTES, ve += 2 * 4 * TCS_EDGE, er += 2 * TCS_EDGE;
+                }
+                tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 14)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                tcs_store_row(rsF, vo, Q.A);
+                if (edge_lane) tcs_store_edge(rsE, ve, Q.A.c[R - 1], Q.e, Q.eh);
+                wait_vm();
+                if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + (d + 14 - st.df) + 1);
+                rm += TCS_BLOCK - 1;
+                d += TCS_BLOCK - 1;
+                }
+                gstep(d);
+                ++d;
             }
-            if (d <= st.dl) step(d, Q.B, Q.A);
             if (s == S - 1) {  // total probability at the end corner (lX, lY), anti-diagonal D = this stripe's last row
-                const bool inB = ((st.dl - st.df) & 1) == 0;
                 const int je = lX - st.X;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (jr[r] == je) {
-                        const RCell c = inB ? Q.B.c[r] : Q.A.c[r];
+                        const RCell c = (st.dl & 1) ? Q.A.c[r] : Q.B.c[r];
                         const float raw = rs_dot5(mdl->end + re * 5, c);
                         if (raw > 0.f) {
                             int k;
@@ -463,9 +537,6 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
             if (threadIdx.x < TCS_MAX_NW) prog[threadIdx.x] = 0x7fffffff;  // now: the LOWEST row whose neighbour cell is out
             __syncthreads();
             int vsmax = -(1 << 30);
-#ifdef NPR_TCS_DEBUG
-            int dbg_d = 0, dbg_s = 0, dbg_ef = 0, dbg_efh = 0, dbg_eb = 0, dbg_ebh = 0;
-#endif
             int s_top = S - 1 - ((S - 1 - wv) % NW + NW) % NW;  // the last stripe of this wavefront (s == wv mod NW)
             for (int s = s_top; s >= 0; s -= NW) {
                 const UStripe st = load_stripe(tab, s);
@@ -486,15 +557,15 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 }
                 Feed fy;
                 feed8_init<-1>(fy, E.Y, lY, st.dl - X0 - (K - 1), lane);
-                RFRow<R> fa, fb;
+                RFRow<R> fa, fb;  // the forward row of an odd anti-diagonal in fa, of an even one in fb: loaded one step ahead of its use
 #pragma unroll
                 for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f;
-                cptr32 rm = rowmask + st.row0 + static_cast<uint32_t>(st.dl - st.df);
+                cptr32 rm = rowmask + st.row0 + static_cast<uint32_t>(st.dl - st.df);  // the word of the row in hand is rm[0]
                 const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc(F, st.row0, TCS_ROW_BYTES), rsE = stripe_rsrc(Eb, st.row0, 4 * TCS_EDGE);
-                Masks<R> mk_n = row_masks(rm[0]);
                 {
                     const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (st.dl - st.df) * TCS_ROW_BYTES, 0, 0);
-                    fb.v[0] = bitsf(q.x), fb.v[1] = bitsf(q.y);
+                    RFRow<R> &f0 = (st.dl & 1) ? fa : fb;
+                    f0.v[0] = bitsf(q.x), f0.v[1] = bitsf(q.y);
                 }
                 // the right stripe's block of rows [16 kb, 16 kb + 15]
                 auto take_block = [&](int kb, int &e_in, int &eh_in) {
@@ -518,9 +589,6 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                     const v2i x = __builtin_amdgcn_raw_buffer_load_b64(rsF, kf * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
                     const int sx = x.x + Q.e - tot_e;
                     G1 = tcs_pow2(sx >> 1), G2 = tcs_pow2(sx - (sx >> 1));
-#ifdef NPR_TCS_DEBUG
-                    if (x.y + Q.eh - tot_e > vsmax) dbg_d = d, dbg_s = s, dbg_ef = x.x, dbg_efh = x.y, dbg_eb = Q.e, dbg_ebh = Q.eh;
-#endif
                     vsmax = max(vsmax, x.y + Q.eh - tot_e);
                 };
                 {
@@ -543,31 +611,49 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                     }
                     enter_block(st.dl);
                 }
+                // posteriors of anti-diagonal d, slots claimed from the workgroup's LDS counter
+                auto emit = [&](int d, const RDiag<R> &io, const RFRow<R> &f, const Masks<R> &mk) {
+                    float p[R];
+                    uint64_t hit[R];
+                    int total = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        p[r] = ((f.v[r] * G1) * (io.c[r].m * G2)) * inv_tot;
+                        hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
+                        total += __popcll(hit[r]);
+                    }
+                    if (d >= 2 && total) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(lmisc + 4, total);
+                        base = uni(base);
+                        const int y0 = d - X0;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if (hit[r]) {
+                                const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                                const int slot = base + before;
+                                if (lanes_of(hit[r]) && slot < sink.cap) {
+                                    sink.px[sink.off + slot] = X0 + jr[r] - 1 + sink.xs;
+                                    sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
+                                    sink.pp[sink.off + slot] = p[r];
+                                }
+                                base += __popcll(hit[r]);
+                            }
+                        }
+                    }
+                };
 
-                // f: the forward row of d (loaded a step ago); fnext: where the row of d-1 goes
+                // any row.  f: the forward row of d (loaded a step ago); fnext: where the row of d-1 goes
                 auto step = [&](int d, RDiag<R> &io, const RDiag<R> &s1, RFRow<R> &f, RFRow<R> &fnext) {
                     const int k = d - st.df;
-                    const Masks<R> mk = mk_n;
+                    const Masks<R> mk = row_masks(rm[0]);
                     if (d > st.df) {
                         rm -= 1;
-                        mk_n = row_masks(rm[0]);
                         const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (k - 1) * TCS_ROW_BYTES, 0, 0);
                         fnext.v[0] = bitsf(q.x), fnext.v[1] = bitsf(q.y);
                     }
-                    const RCell edge = tcs_edge_get(stage, (d + 1) & (TCS_BLOCK - 1));
-                    bases_up<R>(by, feed8_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
-                    // one backward anti-diagonal: io d+2 -> d; s1 d+1; carry: the slot-above copy of d+2's register 0 -> that of d+1
-                    RCell Xe = dpp_rcell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register, in the units of the lane it comes from
-                    rcell_scale(Xe, Q.c);
-                    RDiag<R> o;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float em, exs, exl, eys, eyl;
-                        rs_cell_emissions<R, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em, exs, exl, eys, eyl);
-                        o.c[r] = rs_bwd_cell<SW>(E.tr, r + 1 < R ? io.c[r + 1] : Q.carry, r + 1 < R ? s1.c[r + 1] : Xe, s1.c[r], em, exs, exl, eys, eyl);
-                    }
-                    io = o;
-                    Q.carry = Xe;
+                    tcs_bwd_core<SW, FLAT>(E, io, s1, Q.carry, Q.c, mk, stage + TCS_EDGE * ((d + 1) & (TCS_BLOCK - 1)), bx, by, feed8_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
                     if (d == D) {  // the end corner (lX, lY)
 #pragma unroll
                         for (int r = 0; r < R; ++r)
@@ -585,60 +671,80 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         }
                         enter_block(d);
                     }
-                    if (lane == 0) {  // holds the stripe's first column in its register 0
-                        const int vo = 4 * TCS_EDGE * k;
-                        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[0].m), fbits(io.c[0].sx), fbits(io.c[0].sy), fbits(io.c[0].lx)}, rsE, vo, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[0].ly), Q.e, Q.eh, 0}, rsE, vo + 16, 0, 0);
-                    }
-                    // posteriors of this anti-diagonal, slots claimed from the workgroup's LDS counter
-                    {
-                        float p[R];
-                        uint64_t hit[R];
-                        int total = 0;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            p[r] = ((f.v[r] * G1) * (io.c[r].m * G2)) * inv_tot;
-                            hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
-                            total += __popcll(hit[r]);
-                        }
-                        if (d >= 2 && total) {
-                            int base = 0;
-                            if (lane == 0) base = atomicAdd(lmisc + 4, total);
-                            base = uni(base);
-                            const int y0 = d - X0;
-#pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                if (hit[r]) {
-                                    const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
-                                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
-                                    const int slot = base + before;
-                                    if (lanes_of(hit[r]) && slot < sink.cap) {
-                                        sink.px[sink.off + slot] = X0 + jr[r] - 1 + sink.xs;
-                                        sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
-                                        sink.pp[sink.off + slot] = p[r];
-                                    }
-                                    base += __popcll(hit[r]);
-                                }
-                            }
-                        }
-                    }
+                    if (lane == 0) tcs_store_edge(rsE, 4 * TCS_EDGE * k, io.c[0], Q.e, Q.eh);  // holds the stripe's first column in its register 0
+                    emit(d, io, f, mk);
                     if ((d & (TCS_BLOCK - 1)) == 0 || d == st.df) {
                         wait_vm();
                         if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k);
                     }
                 };
+                auto gstep = [&](int d) {
+                    if (!(d & 1)) {
+                        tcs_swap_rows(Q.A, Q.B);
+                        const RFRow<R> t = fa;
+                        fa = fb, fb = t;
+                    }
+                    step(d, Q.A, Q.B, fa, fb);
+                    if (!(d & 1)) {
+                        tcs_swap_rows(Q.A, Q.B);
+                        const RFRow<R> t = fa;
+                        fa = fb, fb = t;
+                    }
+                };
+                // one loop, one instance of the general step; where a row 16 kb + 14 opens a whole block inside the stripe (the end cell's row never does), the fast loop
+                // takes the fifteen rows 16 kb + 14 .. 16 kb (d is even: pairs of a B step and an A step) and the general step the boundary row 16 kb - 1
                 int d = st.dl;
-                for (; d - 1 >= st.df; d -= 2) {
-                    step(d, Q.B, Q.A, fb, fa);
-                    step(d - 1, Q.A, Q.B, fa, fb);
+                while (d >= st.df) {
+                    if ((d & (TCS_BLOCK - 1)) == TCS_BLOCK - 2 && d - (TCS_BLOCK - 1) >= st.df && d < D) {
+                    feed8_ahead<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane);
+                    int yi = uni(fy.base - (d - X0 - (K - 1)));
+                    int vo = voff + (d - 1 - st.df) * TCS_ROW_BYTES, ve = 4 * TCS_EDGE * (d - st.df);  // vo: the row loaded ahead, d - 1
+                    const float *er = stage + TCS_EDGE * (TCS_BLOCK - 1);  // record (d + 1) & 15 = 15
+                    // the mask words of rows d .. d - 15: lane i (mod 16) holds row d - i's
+                    const int wv16 = static_cast<int>(a.rowmask[rowmask_off + st.row0 + static_cast<uint32_t>(d - st.df) - (lane & (TCS_BLOCK - 1))]);
+#pragma unroll 1
+                    for (int i = 0; i < 7; ++i) {
+                        {
+                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
+                            fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
+                        }
+                        const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i));
+                        tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                        if (lane == 0) tcs_store_edge(rsE, ve, Q.B.c[0], Q.e, Q.eh);
+                        emit(d - 2 * i, Q.B, fb, m0);
+                        {
+                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo - TCS_ROW_BYTES, 0, 0);
+                            fb.v[0] = bitsf(q.x), fb.v[1] = bitsf(q.y);
+                        }
+                        const Masks<R> m1 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1));
+                        tcs_bwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, m1, er - TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
+                        if (lane == 0) tcs_store_edge(rsE, ve - 4 * TCS_EDGE, Q.A.c[0], Q.e, Q.eh);
+                        emit(d - 2 * i - 1, Q.A, fa, m1);
+                        yi += 2, vo -= 2 * TCS_ROW_BYTES, ve -= 2 * 4 * TCS_EDGE, er -= 2 * TCS_EDGE;
+                    }
+                    {
+                        {
+                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
+                            fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
+                        }
+                        const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 14));
+                        tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                        if (lane == 0) tcs_store_edge(rsE, ve, Q.B.c[0], Q.e, Q.eh);
+                        emit(d - 14, Q.B, fb, m0);
+                        wait_vm();
+                        if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + (d - 14 - st.df));
+                    }
+                    rm -= TCS_BLOCK - 1;
+                    d -= TCS_BLOCK - 1;
+                    }
+                    gstep(d);
+                    --d;
                 }
-                if (d >= st.df) step(d, Q.B, Q.A, fb, fa);
                 if (s == 0) {  // total from the backward side: the lattice point (0, 0) is the stripe's first slot on d = 0
-                    const bool inB = ((st.dl - st.df) & 1) == 0;
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         if (X0 + jr[r] == 0) {
-                            const RCell cz = inB ? Q.B.c[r] : Q.A.c[r];
+                            const RCell cz = (st.df & 1) ? Q.A.c[r] : Q.B.c[r];
                             const float raw = rs_dot5(mdl->start + rs * 5, cz);
                             if (raw > 0.f) {
                                 int k;
@@ -651,10 +757,6 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
             }
             atomicMax(lmisc + 6, vsmax);
             __syncthreads();
-#ifdef NPR_TCS_DEBUG
-            if (vsmax == lmisc[6] && vsmax >= TCS_S_LIMIT)
-                printf("task %d cert %d: stripe %d of %d row %d (df %d dl %d) lane %d eF %d e^F %d eB %d e^B %d eTot %d\n", t, vsmax, dbg_s, S, dbg_d, 0, 0, lane, dbg_ef, dbg_efh, dbg_eb, dbg_ebh, tot_e);
-#endif
             out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
             out.btot_e = uni(lmisc[3]);
         }
@@ -675,17 +777,14 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
 
 }  // namespace
 
-size_t tile_cs_lds_bytes(int nw) {
-    return sizeof(float) * (((RS_TABLE_FLOATS + 3) & ~3) + MODEL_FLOATS + 8 + TCS_MAX_NW + static_cast<size_t>(nw) * TCS_BLOCK * TCS_EDGE);
-}
+size_t tile_cs_lds_bytes(int) { return 0; }  // (static LDS: sizeof(CsLds))
 
 int launch_tile_cs(const KernelArgs &a, int NW, int grid, void *stream, bool sw, bool flat) {
     if (NW < 1 || NW > TCS_MAX_NW) return static_cast<int>(hipErrorInvalidValue);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = tile_cs_lds_bytes(NW);
-    if (sw) hipLaunchKernelGGL((k_dp_tile_cs<true, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
-    else if (flat) hipLaunchKernelGGL((k_dp_tile_cs<false, true>), dim3(grid), dim3(WAVE * NW), lds, s, a);
-    else hipLaunchKernelGGL((k_dp_tile_cs<false, false>), dim3(grid), dim3(WAVE * NW), lds, s, a);
+    if (sw) hipLaunchKernelGGL((k_dp_tile_cs<true, false>), dim3(grid), dim3(WAVE * NW), 0, s, a);
+    else if (flat) hipLaunchKernelGGL((k_dp_tile_cs<false, true>), dim3(grid), dim3(WAVE * NW), 0, s, a);
+    else hipLaunchKernelGGL((k_dp_tile_cs<false, false>), dim3(grid), dim3(WAVE * NW), 0, s, a);
     return static_cast<int>(hipGetLastError());
 }
 

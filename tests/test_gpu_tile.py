@@ -66,6 +66,7 @@ def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(
     for P in (R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=3000),
               R.make_params(band_mode=R.BAND_ANCHOR, diagonal_expansion=10, constraint_trim=14, split_threshold=700,
                             max_pairs_per_base=40)):
+        gpu_ctx.set_option(_lib.OPTIONS["tile_rs"], 2)  # k_dp_tile, one exponent per cell: what the other kernels are compared with
         ref = run(P)
         res, tasks, cells, st = ref[0], ref[3], ref[4], ref[5]
         assert (res["status"] == 0).all() and np.abs(res["loglik"] - res["loglik_bwd"]).max() < 1e-2
@@ -79,15 +80,16 @@ def test_tile_kernel_takes_the_reference_band_and_agrees_with_the_other_kernels(
         gpu_ctx.set_option(_lib.OPTIONS["no_tile"], 0)
         assert old[3][11] == 0 and old[3][3:11].sum() == tasks[11]
         same(ref, old)
-
-    # the stripes in row-scaled arithmetic (k_dp_tile_rs, opt-in: one exponent per stripe row, neighbour cells handed over with
-    # their row's exponent, tasks without a range certificate run again in k_dp_tile): the same bits
-    ref = run(R.make_params(band_mode=R.BAND_ANCHOR))
-    gpu_ctx.set_option(_lib.OPTIONS["tile_rs"], 1)
-    rs = run(R.make_params(band_mode=R.BAND_ANCHOR))
-    gpu_ctx.set_option(_lib.OPTIONS["tile_rs"], 0)
-    assert rs[3][18] > 0 and rs[3][11] == 0 and ref[3][11] == rs[3][18]
-    same(ref, rs)
+        # the stripes in column-scaled arithmetic (k_dp_tile_cs, the default since round 6: one exponent per lane of a stripe, neighbour cells
+        # handed over with their lane's exponent, tasks without a range certificate run again in k_dp_tile): the same bits, whatever the number
+        # of wavefronts per task
+        gpu_ctx.set_option(_lib.OPTIONS["tile_rs"], 0)
+        for nw in ("0", "1", "3"):
+            gpu_ctx.set_option(_lib.OPTIONS["tile_waves"], int(nw))
+            cs = run(P)
+            assert cs[3][18] > 0 and cs[3][11] == 0 and ref[3][11] == cs[3][18]
+            same(ref, cs)
+        gpu_ctx.set_option(_lib.OPTIONS["tile_waves"], 0)
 
     # two reads against the oracle's fp32 mirror
     h = orc.make_hmm(T, E)

@@ -15,7 +15,7 @@ w = synth.make_workload(1004, n, length, h.transitions, h.emissions)
 ctx = R.Context(0); ctx.set_hmm(h)
 P = R.make_params(band_mode=R.BAND_ANCHOR, max_pairs_per_base=24)
 out = {}
-for name, opt in (("tile", 0), ("tile_cs", 1)) * reps:
+for name, opt in (("tile", 2), ("tile_cs", 0)) * reps:
     ctx.set_option(_lib.OPTIONS["tile_rs"], opt)
     b = ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
     sys.stderr.write("==== %s\n" % name)
