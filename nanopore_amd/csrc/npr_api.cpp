@@ -1138,7 +1138,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
             // parallelism of about four stripes on average (rectangles of ~1000 columns, each stripe starting 128 + 16..31
             // anti-diagonals after its left neighbour): measured on 8192 x 8 kb reads in the reference's band, 2 / 3 / 4 / 6 / 8
             // wavefronts per task give 1.26 / 1.71 / 2.06 / 1.42 / 1.64e11 cells/s (more tasks in flight need more scratch)
-            int nw = 4;
+            // (k_dp_tile_cs, round 6, same batch: 2 / 3 / 4 / 6 / 8 wavefronts per task 338 / 281 / 294 / 396 / 365 ms -- its steps are shorter, the
+            // hand-overs are not, so a fourth wavefront waits more than it works)
+            int nw = kClassTab[c].kind == K_TILE_RS ? 3 : 4;
             if (ctx->opt[NPR_OPT_TILE_WAVES] > 0) nw = static_cast<int>(std::min<int64_t>(8, ctx->opt[NPR_OPT_TILE_WAVES]));
             waves_per_cu = std::max(1, 24 / nw);
             L.wcap = nw;
@@ -1398,8 +1400,8 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     if (d_prof.p) {
         unsigned long long pf[8];
         HIP_TRY(ctx, hipMemcpy(pf, d_prof.p, sizeof(pf), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[npr tile prof] wavefront cycles: waiting for a neighbour %.3g, for own stores %.3g, at barriers %.3g, total %.3g\n",
-                     (double)pf[0], (double)pf[1], (double)pf[2], (double)pf[3]);
+        std::fprintf(stderr, "[npr tile prof] wavefront cycles: waiting for a neighbour %.3g, for own stores %.3g, at barriers %.3g, total %.3g (k_dp_tile_cs built with -DNPR_TCS_PROF: neighbour, general step, fast loops, total; stripe set-up %.3g, barriers %.3g, task set-up %.3g, own stores %.3g)\n",
+                     (double)pf[0], (double)pf[1], (double)pf[2], (double)pf[3], (double)pf[4], (double)pf[5], (double)pf[6], (double)pf[7]);
     }
     // The row-scaled kernels report the tasks for which one exponent per row may not have been enough (TASK_RERUN,
     // npr_device.h): those run again here, with the per-cell-exponent kernel of their frame class, on the scratch regions the

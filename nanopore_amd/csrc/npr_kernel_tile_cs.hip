@@ -533,6 +533,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
         // =============================== backward + posteriors ===============================
         if (alive) {
             const float inv_tot = 1.0f / tot_m;
+            const float thr_lo = a.threshold * tot_m * (1.0f - 1.0f / 1024.0f);
             const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
             if (threadIdx.x < TCS_MAX_NW) prog[threadIdx.x] = 0x7fffffff;  // now: the LOWEST row whose neighbour cell is out
             __syncthreads();
@@ -613,32 +614,41 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 }
                 // posteriors of anti-diagonal d, slots claimed from the workgroup's LDS counter
                 auto emit = [&](int d, const RDiag<R> &io, const RFRow<R> &f, const Masks<R> &mk) {
-                    float p[R];
-                    uint64_t hit[R];
-                    int total = 0;
+                    float q[R];
+                    uint64_t cand[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        p[r] = ((f.v[r] * G1) * (io.c[r].m * G2)) * inv_tot;
-                        hit[r] = __ballot(p[r] >= sink.threshold) & mk.cell[r];
-                        total += __popcll(hit[r]);
+                        q[r] = (f.v[r] * G1) * (io.c[r].m * G2);
+                        cand[r] = __ballot(q[r] >= thr_lo) & mk.cell[r];
                     }
-                    if (d >= 2 && total) {
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(lmisc + 4, total);
-                        base = uni(base);
-                        const int y0 = d - X0;
+                    if (d >= 2 && (cand[0] | cand[1])) {
+                        float p[R];
+                        uint64_t hit[R];
+                        int total = 0;
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            if (hit[r]) {
-                                const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
-                                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
-                                const int slot = base + before;
-                                if (lanes_of(hit[r]) && slot < sink.cap) {
-                                    sink.px[sink.off + slot] = X0 + jr[r] - 1 + sink.xs;
-                                    sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
-                                    sink.pp[sink.off + slot] = p[r];
+                            p[r] = q[r] * inv_tot;
+                            hit[r] = __ballot(p[r] >= sink.threshold) & cand[r];
+                            total += __popcll(hit[r]);
+                        }
+                        if (total) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(lmisc + 4, total);
+                            base = uni(base);
+                            const int y0 = d - X0;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                if (hit[r]) {
+                                    const int before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hit[r] >> 32),
+                                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hit[r]), 0));
+                                    const int slot = base + before;
+                                    if (lanes_of(hit[r]) && slot < sink.cap) {
+                                        sink.px[sink.off + slot] = X0 + jr[r] - 1 + sink.xs;
+                                        sink.py[sink.off + slot] = y0 - jr[r] - 1 + sink.ys;
+                                        sink.pp[sink.off + slot] = p[r];
+                                    }
+                                    base += __popcll(hit[r]);
                                 }
-                                base += __popcll(hit[r]);
                             }
                         }
                     }
