@@ -44,8 +44,8 @@ sys.path.insert(0, ROOT)
 # The ROCm runtime multiplexes a process's HIP streams over four hardware queues by default, and two streams on one queue run their
 # kernels in submission order.  The files -> file job keeps three batches in flight on 21 streams: with four queues the MEA stage of
 # one chunk and the DP pass of the next regularly share one (tools/queues_of.py), with eight they do not -- 403 -> 393 ms per job.
-# Read by the runtime when it starts: nanopore_amd/_lib.py sets it when the binding is imported (so a plugin user gets it too); set here
-# as well because this script touches the GPU through torch before it imports the binding.
+# Read by the runtime when it starts; a deployment setting (the job's entry points ask for it through _lib.want_hw_queues(), which
+# leaves a host's own choice alone) -- set here because this script touches the GPU through torch before it calls the job.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable

@@ -254,6 +254,11 @@ int32_t npr_batch_ops_packed(const npr_batch *b, int64_t *ops_off, uint32_t *wor
  * --outputAllPosteriorProbs (marginAlignSnpCaller.py:149).  After a device-side npr_batch_finish the pairs are
  * still in HBM: the first call with x != NULL copies and sorts them (pair_off alone costs nothing). */
 int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32_t *y, float *p, int64_t cap);
+/* TEST HOOK (tests/test_gpu_parity.py: the finish stages against malformed input).  Replaces, on the device, the posterior pairs the DP pass left for
+ * `read` -- which must have a single segment -- by the n given ones (window coordinates; n at most the list's capacity), as if the DP kernel had
+ * written them with status `task_status` (NPR_OK, or e.g. NPR_ERR_CAPACITY for a list that overflowed).  Between npr_batch_run and npr_batch_finish.
+ * Nothing in the product calls it. */
+int32_t npr_batch_debug_set_pairs(npr_batch *b, int64_t read, const int32_t *x, const int32_t *y, const float *p, int64_t n, int32_t task_status);
 
 /* ---- post-alignment statistics on the device ----
  * The per-read integer reductions the reference's analyses make by walking every aligned pair in Python:

@@ -10,12 +10,26 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue runs its kernels in
-# submission order.  The files -> file job (job.py) keeps three batches in flight, each with its own streams: with four queues the MEA
-# stage of one chunk and the DP pass of the next regularly share one (403 against 393 ms per 50 000 reads).  The
-# runtime reads the variable when it starts, i.e. at the process's first HIP call -- so it is set here, when the binding is imported,
-# unless the host application has chosen a value itself.  (Too late if the process has already used the GPU; harmless then.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+LIB_LOADED = False  # set when the library (and with it the HIP runtime) has been loaded into this process
+
+
+def want_hw_queues(n=8):
+    """The files -> file job (job.py) keeps three batches in flight, each with its own streams; the HIP runtime spreads a process's streams over
+    GPU_MAX_HW_QUEUES hardware queues (default 4) and a queue runs its kernels in submission order, so with four the MEA stage of one chunk
+    and the DP pass of the next regularly share one (403 against 393 ms per 50 000 reads).  The runtime reads the variable
+    at the process's first HIP call.  This is a DEPLOYMENT setting: importing the binding changes nothing in the host
+    application's environment -- the job's entry points and bench.py call this, it leaves a value the host has chosen alone, and it says on
+    stderr (NPR_TIMING / NPR_JOB_TRACE) what it did, including when it comes too late to matter."""
+    have = os.environ.get("GPU_MAX_HW_QUEUES")
+    if have is None:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    if os.environ.get("NPR_TIMING") or os.environ.get("NPR_JOB_TRACE"):
+        import sys
+        sys.stderr.write("[npr] GPU_MAX_HW_QUEUES %s%s\n" % (
+            "left at the host's %s" % have if have is not None else "set to %d for this process and its children" % n,
+            " (the library is already loaded: the runtime may have read it before)" if LIB_LOADED and have is None else ""))
+
+
 LIB_PATH = os.environ.get("NPR_LIB") or os.path.join(_HERE, "libnprealign.so")  # NPR_LIB: a variant build (bring-up, tools/variant_bench.py)
 
 OK = 0
@@ -95,7 +109,7 @@ class NprError(RuntimeError):
 EXPORTS = [
     "npr_abi_version", "npr_strerror", "npr_create", "npr_destroy", "npr_last_error", "npr_set_hmm",
     "npr_batch_create", "npr_batch_create_at", "npr_batch_run", "npr_batch_finish", "npr_batch_destroy", "npr_batch_get_stats", "npr_batch_class_stats",
-    "npr_batch_results", "npr_batch_ops", "npr_batch_ops_packed", "npr_batch_pairs", "npr_batch_dense", "npr_batch_rs_forward", "npr_batch_expectations",
+    "npr_batch_results", "npr_batch_ops", "npr_batch_ops_packed", "npr_batch_pairs", "npr_batch_debug_set_pairs", "npr_batch_dense", "npr_batch_rs_forward", "npr_batch_expectations",
     "npr_batch_align_stats", "npr_align_stats", "npr_batch_plan_check", "npr_batch_base_expectations",
     "npr_realign_batch",
     "npr_plan_create", "npr_plan_destroy", "npr_plan_segments", "npr_plan_segment_info",
@@ -115,7 +129,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libnprealign.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
                            "g.build()'` or `make -C nanopore_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    global LIB_LOADED
     L = C.CDLL(LIB_PATH)
+    LIB_LOADED = True
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.npr_abi_version.restype = i32
     L.npr_strerror.restype = C.c_char_p
@@ -156,6 +172,8 @@ def load():
     L.npr_batch_ops_packed.argtypes = [vp, vp, vp, i64]
     L.npr_batch_pairs.restype = i32
     L.npr_batch_pairs.argtypes = [vp, vp, vp, vp, vp, i64]
+    L.npr_batch_debug_set_pairs.restype = i32
+    L.npr_batch_debug_set_pairs.argtypes = [vp, i64, vp, vp, vp, i64, i32]
     L.npr_batch_expectations.restype = i32
     L.npr_batch_expectations.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.npr_batch_base_expectations.restype = i32

@@ -1416,7 +1416,7 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
         for (int k = L.first; k < L.first + L.count; ++k)
             if (b->outs[k].status == TASK_RERUN) {
                 again.push_back(k);
-                if (std::getenv("NPR_TIMING")) std::fprintf(stderr, "[npr] task %d (D %d) runs again: why %d ratio %.9g de %d tot %g %d\n", k, b->tasks[k].D, b->outs[k].npairs, b->outs[k].btot_m, b->outs[k].btot_e, b->outs[k].tot_m, b->outs[k].tot_e);
+                if (std::getenv("NPR_TIMING")) std::fprintf(stderr, "[npr] task %d (D %d) runs again; the first pass left in its result: npairs (k_dp_mid_rs: why, 1 nothing at the cut / 2 no total / 3 exponents apart / 4 totals apart / 5 range certificate; k_dp_tile_cs: its certificate value) %d, btot_m (k_dp_mid_rs: total' / total) %.9g, btot_e (k_dp_mid_rs: exponent difference) %d, total %g x 2^%d\n", k, b->tasks[k].D, b->outs[k].npairs, b->outs[k].btot_m, b->outs[k].btot_e, b->outs[k].tot_m, b->outs[k].tot_e);
             }
         if (again.empty()) continue;
         std::vector<Task> sub(again.size());
@@ -1754,6 +1754,8 @@ int32_t device_mea(npr_batch *b) {
                 m.small.release(), m.tmp.release(), m.map.release(), m.dense.release(), m.pieces.release();
                 ctx->cache_flush();
                 arena_lock.lock();
+                // (`arena_fits` was read before the lock: another context may have released or regrown the shared scratch since)
+                if (!(ctx->arena->F && need <= static_cast<size_t>(ctx->arena->cells.load()) * 8)) return 1;
                 ++ctx->arena->epoch;
                 in_arena = true;
                 continue;
@@ -2145,6 +2147,28 @@ int32_t npr_batch_pairs(const npr_batch *b, int64_t *pair_off, int32_t *x, int32
         const int32_t gx = static_cast<int32_t>(b->gstart[2 * r]), gy = static_cast<int32_t>(b->gstart[2 * r + 1]);
         for (int64_t i = b->pair_off[r]; i < b->pair_off[r + 1]; ++i) x[i] = b->pairs[i].x + gx, y[i] = b->pairs[i].y + gy, p[i] = b->pairs[i].p;
     }
+    return NPR_OK;
+}
+
+int32_t npr_batch_debug_set_pairs(npr_batch *b, int64_t read, const int32_t *x, const int32_t *y, const float *p, int64_t n, int32_t task_status) {
+    if (!b || read < 0 || read >= b->n_reads || n < 0 || (n > 0 && (!x || !y || !p))) return NPR_ERR_INVALID;
+    npr_ctx *ctx = b->ctx;
+    if (!b->ran) return fail(ctx, NPR_ERR_STATE, "npr_batch_debug_set_pairs before npr_batch_run");
+    if (b->read_ntasks[read] != 1) return fail(ctx, NPR_ERR_INVALID, "npr_batch_debug_set_pairs: the read has more than one segment");
+    const int32_t k = b->task_of[b->read_first_task[read]];
+    const Task &tk = b->tasks[k];
+    if (n > tk.pair_cap) return NPR_ERR_CAPACITY;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n) {
+        HIP_TRY(ctx, hipMemcpy(b->d_px.p + tk.pair_off, x, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_py.p + tk.pair_off, y, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(b->d_pp.p + tk.pair_off, p, sizeof(float) * n, hipMemcpyHostToDevice));
+    }
+    TaskOut o;
+    HIP_TRY(ctx, hipMemcpy(&o, b->d_outs.p + k, sizeof(TaskOut), hipMemcpyDeviceToHost));
+    o.npairs = static_cast<int32_t>(n), o.status = task_status;
+    HIP_TRY(ctx, hipMemcpy(b->d_outs.p + k, &o, sizeof(TaskOut), hipMemcpyHostToDevice));
+    b->finished = false;
     return NPR_OK;
 }
 

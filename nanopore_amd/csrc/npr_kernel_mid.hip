@@ -544,14 +544,16 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                     if (k < MID_REJ_CAP) lrej[k] = i;
                 }
             }
-            // wavefront 1's, from the lowest address up: a block moved towards lower addresses, 128 entries read, then written
-            const bool tight = pair_cap - nB - nA < 2 * WAVE;
+            // wavefront 1's, from the lowest address up: a block moved towards lower addresses, 128 entries read by BOTH wavefronts, then written by both.
+            // The two meet before and after every block's writes whatever the free gap between the halves: the wavefronts are not synchronised when
+            // they get here (the loop above has divergent atomics), and with a gap below nB a wavefront one block ahead would write what the other has
+            // not read yet (round 5 took the barriers only for gaps below 128 entries: ADVICE r5).  The pass covers a hundredth of the cells.
             for (int base = 0; base < nB; base += 2 * WAVE) {
                 const int k = base + tid;
                 int x = 0, y = 0;
                 float q = 0.f;
                 if (k < nB) x = px[pair_cap - nB + k], y = py[pair_cap - nB + k], q = pp[pair_cap - nB + k];
-                if (tight) __syncthreads();
+                __syncthreads();
                 if (k < nB) {
                     const float p = __builtin_ldexpf(q, de) * inv;
                     px[nA + k] = x, py[nA + k] = y, pp[nA + k] = p;
@@ -560,7 +562,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
                         if (j < MID_REJ_CAP) lrej[j] = nA + k;
                     }
                 }
-                if (tight) __syncthreads();
+                __syncthreads();
             }
             __syncthreads();
             const int nrej = uni(lmisc[14]);

@@ -52,6 +52,13 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ bool beats(int64_t s, int w, int64_t os, int ow) { return s > os || (s == os && w > ow); }
 
 // the tables of the reads whose spans do not fit the LDS (the others never touch global tables): counts and column sums start from zero
+// What this stage reads of a task's pair list: nothing unless its DP pass ended NPR_OK -- a list that overflowed its capacity, or belongs to a task
+// that failed, is no input (round 5 lost 25 GPU-minutes to lists that held candidates instead of posteriors; npr_batch_finish gives such a read
+// empty tables as well, so either guard alone keeps the stage off them).  And a value that is no probability -- NaN, negative, above 1 -- makes its
+// read NPR_ERR_INVALID instead of a weight.
+__device__ __forceinline__ int mea_task_pairs(const TaskOut &o, const Task &tk) { return o.status == NPR_OK ? min(max(o.npairs, 0), tk.pair_cap) : 0; }
+__device__ __forceinline__ bool mea_is_posterior(float p) { return p >= 0.f && p <= 1.0f + 0x1p-20f; }
+
 __global__ void __launch_bounds__(256) k_mea_zero(MeaArgs a) {
     const int r = blockIdx.x;
     const int64_t c0 = a.cnt_off[r];
@@ -64,14 +71,14 @@ __global__ void __launch_bounds__(256) k_mea_zero(MeaArgs a) {
 __global__ void __launch_bounds__(256) k_mea_count(MeaArgs a) {
     for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
         const Task &tk = a.tasks[t];
-        const int n = min(a.outs[t].npairs, tk.pair_cap);
+        const int n = mea_task_pairs(a.outs[t], tk);
         const int r = tk.read;
         const int64_t rx = a.cnt_off[r], ry = a.ry_off[r];
         if (rx < 0) continue;  // (a read whose tables fit the LDS: k_mea_sort_lds)
         const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - ry);
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
-            if (x < 0 || x >= lX || y < 0 || y >= lY) {
+            if (x < 0 || x >= lX || y < 0 || y >= lY || !mea_is_posterior(a.pp[tk.pair_off + i])) {
                 a.read_flag[r] = NPR_ERR_INVALID;
                 continue;
             }
@@ -111,14 +118,14 @@ __global__ void __launch_bounds__(256) k_mea_scan(MeaArgs a) {
 __global__ void __launch_bounds__(256) k_mea_scatter(MeaArgs a) {
     for (int t = blockIdx.x; t < a.ntasks; t += gridDim.x) {
         const Task &tk = a.tasks[t];
-        const int n = min(a.outs[t].npairs, tk.pair_cap);
+        const int n = mea_task_pairs(a.outs[t], tk);
         const int r = tk.read;
         const int64_t rx = a.cnt_off[r], rp = a.rp_off[r];
         if (rx < 0) continue;
         const int lX = static_cast<int>(a.rx_off[r + 1] - a.rx_off[r]) - 1, lY = static_cast<int>(a.ry_off[r + 1] - a.ry_off[r]);
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
-            if (x < 0 || x >= lX || y < 0 || y >= lY) continue;
+            if (x < 0 || x >= lX || y < 0 || y >= lY || !mea_is_posterior(a.pp[tk.pair_off + i])) continue;
             const int q = static_cast<int>(floor(static_cast<double>(a.pp[tk.pair_off + i]) * static_cast<double>(P1)));
             const int64_t pos = rp + a.start[rx + x] + (atomicSub(a.cnt + rx + x, 1) - 1);
             a.sx[pos] = x, a.sy[pos] = y, a.sq[pos] = q;
@@ -144,10 +151,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_mea_sort_lds(MeaArgs a) {
         for (int s = 0; s < nt; ++s) {
             const int t = a.task_of[ft + s];
             const Task &tk = a.tasks[t];
-            const int n = min(a.outs[t].npairs, tk.pair_cap);
+            const int n = mea_task_pairs(a.outs[t], tk);
             for (int i = tid; i < n; i += nthreads) {
                 const int x = a.px[tk.pair_off + i], y = a.py[tk.pair_off + i];
-                if (x < 0 || x >= lX || y < 0 || y >= lY) {
+                if (x < 0 || x >= lX || y < 0 || y >= lY || !mea_is_posterior(a.pp[tk.pair_off + i])) {
                     bad = 1;
                     continue;
                 }
@@ -644,6 +651,7 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
     };
     int cx = lX, cy = lY, len = 0;
     int64_t mass = 0;
+    bool broken = false;
     // the pieces of the read from the last to the first, each from its heaviest chain's last pair down (by_id); one chain else
     const bool alive = a.read_flag[r] == 0;
     int piece = by_id ? __builtin_amdgcn_readfirstlane(a.np[r]) : 1;
@@ -671,9 +679,16 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
             emit(NPR_OP_D, cx - x - 1);
             emit(NPR_OP_M, x - hx + 1);  // the run's pairs
             cx = hx, cy = hy, mass += rdlane(val, l) + rdlane(vq, h), len += x - hx + 1;
-            i = rdlane(vb, h);
+            const int to = rdlane(vb, h);
+            if (to >= i) {  // a chain's back pointers go DOWN the list: anything else is a malformed table, and following it need not end
+                broken = true;
+                i = -1;
+                break;
+            }
+            i = to;
         }
     }
+    if (broken) break;
     }
     emit(NPR_OP_I, cy);
     emit(NPR_OP_D, cx);
@@ -683,8 +698,9 @@ __global__ void __launch_bounds__(WAVE) k_mea_trace(MeaArgs a) {
         longest = max(longest, hlen);
     }
     if (lane == 0) {
+        if (broken) a.read_flag[r] = NPR_ERR_INVALID;
         a.max_run[r] = longest;
-        a.n_ops[r] = static_cast<int>(reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r + 1] - p);
+        a.n_ops[r] = broken ? 0 : static_cast<int>(reinterpret_cast<int2 *>(a.ops_tmp) + a.ot_off[r + 1] - p);
         a.chain_len[r] = len;
         a.chain_mass[r] = mass;
     }

@@ -149,9 +149,20 @@ __global__ void __launch_bounds__(256) k_rescore_table(RescoreArgs a) {
     for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
         int32_t *gy = a.gy + a.gx_off[r];
         const int64_t span = a.gx_off[r + 1] - a.gx_off[r];
+        // short runs (a noisy read's: a few dozen columns): a thread each; long ones (a near-exact guide, = / X collapsed into M: tens of thousands of
+        // columns) by the whole workgroup, so that no single lane writes a run alone while npr_batch_create holds the stream
+        constexpr int LONG_RUN = 64;
         for (int64_t q = a.run_off[r] + threadIdx.x; q < a.run_off[r + 1]; q += blockDim.x) {
             const int x0 = a.runs[3 * q], y0 = a.runs[3 * q + 1], len = a.runs[3 * q + 2];
+            if (len > LONG_RUN) continue;
             for (int t = 0; t < len; ++t)
+                if (x0 + t >= 0 && x0 + t < span) gy[x0 + t] = y0 + t;
+        }
+        for (int64_t q = a.run_off[r]; q < a.run_off[r + 1]; ++q) {
+            const int len = a.runs[3 * q + 2];
+            if (len <= LONG_RUN) continue;
+            const int x0 = a.runs[3 * q], y0 = a.runs[3 * q + 1];
+            for (int t = threadIdx.x; t < len; t += blockDim.x)
                 if (x0 + t >= 0 && x0 + t < span) gy[x0 + t] = y0 + t;
         }
     }

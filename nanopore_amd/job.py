@@ -487,6 +487,8 @@ def run_pipeline(src, params, lo, hi, ctxs, sink, want_stats=False, chunk_bases=
                         while gate is not None and not gate.wait(0.2):
                             if stop.is_set():  # a later phase failed (it closes what it was handed): nothing more is staged here
                                 raise RuntimeError("pipeline stopped while a chunk's first half was in flight")
+                        if gate is not None and stop.is_set():  # (a failing finisher SETS the gate on its way out: the wait above ends without having looked)
+                            raise RuntimeError("pipeline stopped while a chunk's first half was in flight")
                 except BaseException:
                     free[j].release()
                     raise
@@ -686,6 +688,7 @@ def run_source(src, params, bounds, out_path, ctxs=None, gpu=None, group=None, w
     gathered to rank 0 (RCCL over xGMI under backend nccl).  Returns a dict: on rank 0 `results` (structured array in input order),
     `n_ops`, `stats` (if asked for), `timings`; on the others `timings` only."""
     import torch
+    _lib.want_hw_queues()  # (a deployment setting, INTEGRATION.md: asked for here, not when the binding is imported)
     dist, world, rank = _dist_state(group)
     gpu = default_gpu() if gpu is None else gpu
     dev = torch.device(coll_device) if coll_device is not None else _collective_device(dist, group, gpu)

@@ -148,6 +148,15 @@ class Batch(object):
             raise NprError(rc, "npr_batch_ops_packed", self.ctx.last_error())
         return off, buffer[:total], buffer
 
+    def debug_set_pairs(self, read, x, y, p, task_status=0):
+        """TEST HOOK (include/nprealign.h npr_batch_debug_set_pairs): replaces on the device the posterior pairs the DP pass left for `read`."""
+        x = np.ascontiguousarray(x, np.int32)
+        y = np.ascontiguousarray(y, np.int32)
+        p = np.ascontiguousarray(p, np.float32)
+        rc = self._L.npr_batch_debug_set_pairs(self._h, int(read), ptr(x), ptr(y), ptr(p), len(x), int(task_status))
+        if rc != 0:
+            raise NprError(rc, "npr_batch_debug_set_pairs")
+
     def pairs(self):
         """-> (pair_off[n+1], x, y, p) sparse posterior match probabilities sorted by (x, y)."""
         off = np.zeros(self.n_reads + 1, dtype=np.int64)

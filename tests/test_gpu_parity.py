@@ -229,6 +229,77 @@ def test_posterior_capacity_overflow_is_reported_and_retried(gpu_ctx):
         assert [tuple(o) for o in ops[off[i]:off[i + 1]].tolist()] == [tuple(o) for o in roomy[i]["ops"]]
 
 
+@pytest.mark.timeout(120)
+def test_finish_stages_refuse_malformed_pair_lists_in_bounded_time(gpu_ctx):
+    """The MEA stage against input no DP kernel should ever produce (round 5 lost 25 GPU-minutes to a chain kernel that was fed candidates instead
+    of posteriors): pair lists overwritten on the device through the test hook npr_batch_debug_set_pairs -- out of order, the same pair twice,
+    NaN / negative / above-1 values, coordinates outside the read, a list marked as overflowed -- must come back as a PER-READ status within
+    a second, the reads beside them untouched; and the public host stage npr_mea_cigar refuses the same lists."""
+    import time
+    from nanopore_amd import realign as R
+    rng = np.random.default_rng(29)
+    gpu_ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    cases = [random_pair(rng, 500) for _ in range(12)]
+    refs = [bytes(b"ACGT"[c] for c in X) for X, _, _ in cases]
+    reads = [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases]
+    guides = [g for _, _, g in cases]
+    P = R.make_params(band_mode=1, fixed_width=100)
+    good = gpu_ctx.realign(P, refs, reads, guides)
+    n = 400
+    diag = np.arange(n, dtype=np.int32)
+    ones = np.full(n, 0.9, np.float32)
+    nan = ones.copy(); nan[::7] = np.nan
+    neg = ones.copy(); neg[5] = -0.5
+    big = ones.copy(); big[11] = 3.0e9
+    inf = ones.copy(); inf[3] = np.inf
+    bad_lists = {
+        0: (diag[::-1].copy(), diag[::-1].copy(), ones),                       # descending
+        1: (np.repeat(diag[: n // 2], 2), np.repeat(diag[: n // 2], 2), ones),  # every pair twice
+        2: (diag, diag, nan),
+        3: (diag, diag, neg),
+        4: (diag, diag, big),
+        5: (diag, diag, inf),
+        6: (diag + 100000, diag, ones),                                        # outside the reference
+        7: (rng.permutation(diag).astype(np.int32), rng.permutation(diag).astype(np.int32), ones),  # no order at all
+    }
+    for host_mea in (0, 1):
+        gpu_ctx.set_option(_lib.OPTIONS["host_mea"], host_mea)
+        b = gpu_ctx.stage(P, refs, reads, guides)
+        b.run()
+        for r, (x, y, p) in bad_lists.items():
+            b.debug_set_pairs(r, x, y, p)
+        b.debug_set_pairs(8, diag, diag, ones, task_status=-3)                   # a list its kernel reported as overflowed: not read at all
+        t0 = time.perf_counter()
+        b.finish()
+        dt = time.perf_counter() - t0
+        st = b.results()["status"].copy()
+        off, ops = b.ops()
+        b.close()
+        assert dt < 1.0, dt
+        # values that are no probabilities and coordinates outside the read are refused by both stages; the device stage sorts whatever order it is
+        # given (its pairs come unordered from the DP kernels) and takes a repeated pair as two pairs, the host stage gets its lists sorted
+        for r in (2, 3, 4, 5, 6):
+            assert st[r] == -1, (host_mea, r, st)
+        assert st[8] == -3
+        for r in (0, 1, 7):
+            assert st[r] in (0, -1)
+        for r in range(9, len(cases)):
+            assert st[r] == 0 and [tuple(o) for o in ops[off[r]:off[r + 1]].tolist()] == [tuple(o) for o in good[r]["ops"]]
+    gpu_ctx.set_option(_lib.OPTIONS["host_mea"], 0)
+    # the public host stage on the same lists: it sorts what it is given (any order is fine), and refuses the rest
+    want = R.mea_cigar(600, 600, diag, diag, ones)
+    for r in (0, 7):
+        x, y, p = bad_lists[r]
+        if r == 0:
+            assert R.mea_cigar(600, 600, x, y, p) == want
+        else:
+            R.mea_cigar(600, 600, x, y, p)
+    for r in (1, 2, 3, 4, 5, 6):
+        x, y, p = bad_lists[r]
+        with pytest.raises(R.NprError):
+            R.mea_cigar(600, 600, x, y, p)
+
+
 def test_device_mea_matches_host_stage(gpu_ctx, monkeypatch):
     """The chain + cigar stage runs on the device in realign mode (npr_mea.hip) and on the host in the other modes,
     for hand-made pair lists (npr_mea_cigar) and with NPR_OPT_HOST_MEA: same integers, so same ops and same scores --
@@ -508,3 +579,22 @@ def test_sweeps_that_meet_in_the_middle(gpu_ctx, monkeypatch):
         assert np.array_equal(u["x"][ku], v["x"][kv]) and np.array_equal(u["y"][ku], v["y"][kv])
         assert np.array_equal(u["p"][ku].view(np.uint32), v["p"][kv].view(np.uint32))
         assert u["ops"] == v["ops"] and u["loglik"] == v["loglik"] and u["loglik_bwd"] == v["loglik_bwd"] and u["score"] == v["score"]
+    # ... and with pair lists that are nearly full: wavefront 1's candidates are moved down over a free gap of a few dozen to a few hundred
+    # entries, every block read by both wavefronts before either writes (a gap of 129 .. 255 entries, or any gap below the backward half's
+    # length, could lose pairs silently in round 5: the two wavefronts met only for gaps below 128).  Two pairs per base of capacity against
+    # the ~1.8 found; a read whose list overflows runs again with four times the capacity, as everywhere.
+    gpu_ctx.set_option(_lib.OPTIONS["pair"], 0)
+    cases = [random_pair(rng, int(L)) for L in rng.integers(200, 1300, 32)]
+    refs, reads, guides = ([bytes(b"ACGT"[c] for c in X) for X, _, _ in cases], [bytes(b"ACGT"[c] for c in Y) for _, Y, _ in cases], [g for _, _, g in cases])
+    P2 = R.make_params(band_mode=1, fixed_width=40, max_pairs_per_base=2)
+    mid = gpu_ctx.realign(P2, refs, reads, guides, want_pairs=True)
+    gpu_ctx.set_option(_lib.OPTIONS["pair"], 1)
+    one = gpu_ctx.realign(P2, refs, reads, guides, want_pairs=True)
+    gpu_ctx.set_option(_lib.OPTIONS["pair"], 0)
+    gaps = [2 * min(len(X), len(Y)) + 64 - len(u["x"]) for (X, Y, _), u in zip(cases, mid)]
+    assert sum(0 <= g < 128 for g in gaps) >= 2 and sum(128 <= g < 256 for g in gaps) >= 2, gaps
+    for u, v in zip(mid, one):
+        ku, kv = np.lexsort((u["y"], u["x"])), np.lexsort((v["y"], v["x"]))
+        assert np.array_equal(u["x"][ku], v["x"][kv]) and np.array_equal(u["y"][ku], v["y"][kv])
+        assert np.array_equal(u["p"][ku].view(np.uint32), v["p"][kv].view(np.uint32))
+        assert u["ops"] == v["ops"] and u["score"] == v["score"]
