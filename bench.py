@@ -275,9 +275,20 @@ def gpu_clock_hz():
     return 2.4e9
 
 
-def timed_resident(ctx, h, w, W, steps, warmup, sync):
+ALSO_STEPS = int(os.environ.get("NPR_BENCH_ALSO_STEPS") or 7)  # timed steps of every secondary line (two or three decide nothing inside a 5 % box spread)
+
+
+def spread(ms):
+    """median and min - max of a list of per-step times: what a secondary line reports next to its mean"""
+    v = np.asarray(ms, dtype=np.float64)
+    return {"n": int(v.size), "median_ms": float(np.median(v)), "min_ms": float(v.min()), "max_ms": float(v.max())}
+
+
+def timed_resident(ctx, h, w, W, steps, warmup, sync, options=None):
     """Stages one batch and times `steps` passes of run + finish.  Returns everything the line needs."""
     params = make_params(W)
+    for k, v in (options or {}).items():  # (context options that pick a kernel take effect when a batch is staged)
+        ctx.set_option(k, v)
     t0 = time.perf_counter()
     batch = ctx.stage_csr(params, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"],
                           guide_start=w.get("guide_start"))
@@ -288,18 +299,21 @@ def timed_resident(ctx, h, w, W, steps, warmup, sync):
         batch.finish()
     sync()
     t0 = time.perf_counter()
-    kernel_ms, finish_ms = [], []
+    kernel_ms, finish_ms, step_ms = [], [], []
     for _ in range(steps):
+        ts = time.perf_counter()
         kernel_ms.append(batch.run())  # blocks until the DP launch has finished on the library's stream
         tf = time.perf_counter()
         batch.finish()
-        finish_ms.append((time.perf_counter() - tf) * 1e3)
+        te = time.perf_counter()
+        finish_ms.append((te - tf) * 1e3)
+        step_ms.append((te - ts) * 1e3)
     sync()
     elapsed = time.perf_counter() - t0
     res = batch.results()
     _, class_cells = batch.class_stats()
-    return dict(batch=batch, params=params, stats=st, elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)),
-                finish_ms=float(np.mean(finish_ms)), res=res, class_cells=np.asarray(class_cells), first_create_s=first_create_s)
+    return dict(batch=batch, params=params, stats=st, elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)), kernel_ms_all=kernel_ms,
+                finish_ms=float(np.mean(finish_ms)), step_ms=step_ms, res=res, class_cells=np.asarray(class_cells), first_create_s=first_create_s)
 
 
 def from_cold(ctx, w, params, cells):
@@ -351,6 +365,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary lines of the default run (the reference's own band; the "
                     "files -> file strong-scaling job of configs[2]/[3])")
+    ap.add_argument("--ab", default="", help="NAME=a,b: a paired A/B inside ONE process on ONE box -- the steps alternate between the two values of a context "
+                    "option (nanopore_amd._lib.OPTIONS, e.g. tile_rs=0,2; resident workloads: one staged batch per value) or of the job's NPR_JOB_OVERLAP "
+                    "(job_overlap=1,2 with --workload c3); prints per-value median / min - max and the paired differences with their spread")
+    ap.add_argument("--ab-pairs", type=int, default=7)
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -402,7 +420,9 @@ def main():
     ctx = R.Context(local_rank)
     job._ctx_pool.setdefault(local_rank, []).insert(0, ctx)  # the job's pipeline uses this context and one more on the same GPU
     env = dict(args=args, ctx=ctx, rank=rank, world=world, dist=dist, coll_dev=coll_dev, sync=sync, allreduce=allreduce, gpu=local_rank)
-    if args.workload == "c3":
+    if args.ab:
+        out = ab_run(env)
+    elif args.workload == "c3":
         out = c3_job(env, args.reads or 50000, args.steps, args.warmup, from_files=not args.resident_arrays)
     elif args.workload == "em":
         out = em_step(env)
@@ -411,7 +431,7 @@ def main():
         if args.workload == "northstar" and not args.no_also:
             # collective: the strong-scaling job of configs[2]/[3], files -> file, at this N
             # (NPR_BENCH_ALSO_READS: a smaller set for the shared-GPU test hook, where two ranks' scratch must fit one device)
-            entry = c3_job(env, int(os.environ.get("NPR_BENCH_ALSO_READS", 50000)), 2, 1, from_files=True)
+            entry = c3_job(env, int(os.environ.get("NPR_BENCH_ALSO_READS", 50000)), ALSO_STEPS, 1, from_files=True)
             if rank == 0:
                 out.setdefault("also", []).append(entry)
     if rank == 0:
@@ -419,6 +439,76 @@ def main():
     job.close_contexts()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ab_run(env):
+    """--ab NAME=a,b: the two values step by step in one process, so that what is compared shares the box, its clocks and its neighbours.  One GPU."""
+    args, ctx, sync, gpu, coll_dev = (env[k] for k in ("args", "ctx", "sync", "gpu", "coll_dev"))
+    from nanopore_amd import _lib, job
+    name, _, vals = args.ab.partition("=")
+    va, vb = (int(v) for v in vals.split(","))
+    pairs = max(1, args.ab_pairs)
+    times = {va: [], vb: []}
+    dp = {va: [], vb: []}
+    if name == "job_overlap":
+        n_reads = args.reads or 50000
+        h, w, W, tmp, sam, fa = c3_inputs(n_reads, 0, None, True)
+        ctxs = job.contexts(gpu, job.WORKERS)
+        for c in ctxs:
+            c.release_scratch()
+            c.set_hmm(h)
+        params = make_params(W)
+        k = [0]
+
+        def one(v):
+            k[0] += 1
+            os.environ["NPR_JOB_OVERLAP"] = str(v)
+            t0 = time.perf_counter()
+            r = job.realign_sam_file(sam, os.path.join(tmp, "ab_%d.sam" % k[0]), fa, params=params, gpu=gpu, set_models=False, coll_device=coll_dev)
+            times[v].append((time.perf_counter() - t0) * 1e3)
+            dp[v].append(r["timings"]["kernel_ms"])
+        one(va), one(vb)
+        for v in (va, vb):
+            times[v].clear(), dp[v].clear()
+        for i in range(pairs):
+            first, second = (va, vb) if i % 2 == 0 else (vb, va)  # (the order alternates too: whatever a step leaves behind for the next one is shared out)
+            one(first), one(second)
+        os.environ.pop("NPR_JOB_OVERLAP", None)
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+        what = "files -> file job of %d reads, NPR_JOB_OVERLAP" % n_reads
+    else:
+        opt = _lib.OPTIONS[name]
+        wl = args.workload if args.workload in ("northstar", "c2", "anchor", "rescore") else "anchor"
+        n_reads = args.reads or {"northstar": 24576, "c2": 1000, "anchor": 8192, "rescore": 8192}[wl]
+        h, w, W, label = build_workload(wl, n_reads, 0)
+        ctx.set_hmm(h)
+        batches = {}
+        for v in (va, vb):
+            ctx.set_option(opt, v)
+            batches[v] = ctx.stage_csr(make_params(W), w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"], guide_start=w.get("guide_start"))
+            batches[v].run(), batches[v].finish()
+
+        def one(v):
+            t0 = time.perf_counter()
+            dp[v].append(batches[v].run())
+            batches[v].finish()
+            times[v].append((time.perf_counter() - t0) * 1e3)
+        sync()
+        for i in range(pairs):
+            first, second = (va, vb) if i % 2 == 0 else (vb, va)
+            one(first), one(second)
+        for v in (va, vb):
+            batches[v].close()
+        what = "%s, context option %s" % (label, name)
+    d = np.asarray(times[vb]) - np.asarray(times[va])
+    dd = np.asarray(dp[vb]) - np.asarray(dp[va])
+    return {"ab": what, "values": [va, vb], "pairs": pairs,
+            "step": {str(v): spread(times[v]) for v in (va, vb)}, "dp_launches": {str(v): spread(dp[v]) for v in (va, vb)},
+            "paired_difference_ms": {"of": "%d minus %d, step by step" % (vb, va), "mean": float(d.mean()), "std": float(d.std(ddof=1)) if d.size > 1 else 0.0,
+                                     "min": float(d.min()), "max": float(d.max()),
+                                     "verdict": ("%d is faster" % (vb if d.mean() < 0 else va)) if abs(d.mean()) > 2.0 * d.std(ddof=1) / np.sqrt(d.size) and d.size > 1 else "no difference beyond the spread"},
+            "paired_difference_dp_ms": {"mean": float(dd.mean()), "std": float(dd.std(ddof=1)) if dd.size > 1 else 0.0}}
 
 
 def resident(env):
@@ -500,20 +590,22 @@ def resident(env):
     if world == 1 and args.workload == "northstar" and not args.no_also:
         # the band the drop-in path actually runs (realignSamFile: the reference's own call parameters), driver-visible
         h2, w2, W2, label2 = build_workload("anchor", 8192, 0)
-        r2 = timed_resident(ctx, h2, w2, W2, 3, 1, sync)
+        r2 = timed_resident(ctx, h2, w2, W2, ALSO_STEPS, 1, sync)
         c2, k2 = r2["stats"]["cells"], r2["kernel_ms"]
-        out["also"] = [{"workload": label2, "reads": 8192, "value": c2 * 3 / r2["elapsed"], "unit": "cells/s",
-                        "reads_per_s": 8192 * 3 / r2["elapsed"], "ms_per_step": r2["elapsed"] / 3 * 1e3,
+        out["also"] = [{"workload": label2, "reads": 8192, "value": c2 * ALSO_STEPS / r2["elapsed"], "unit": "cells/s", "steps": ALSO_STEPS,
+                        "reads_per_s": 8192 * ALSO_STEPS / r2["elapsed"], "ms_per_step": r2["elapsed"] / ALSO_STEPS * 1e3,
+                        "step_spread": spread(r2["step_ms"]), "dp_launch_spread": spread(r2["kernel_ms_all"]),
                         "dp_sweep_only": {"value": c2 / (k2 * 1e-3), "unit": "cells/s", "ms": k2},
                         "roofline": roofline_block(c2, int(r2["res"]["n_pairs"].sum()), k2, r2["class_cells"], gpu_clock_hz()),
                         "ok_reads": int((r2["res"]["status"] == 0).sum())}]
         r2["batch"].close()
         # ... and the posterior consumers' call-site mode (alignmentUncertainty.py:41), finished on the device since round 5
         h3, w3, W3, label3 = build_workload("rescore", 8192, 0)
-        r3 = timed_resident(ctx, h3, w3, W3, 3, 1, sync)
+        r3 = timed_resident(ctx, h3, w3, W3, ALSO_STEPS, 1, sync)
         c3_, k3 = r3["stats"]["cells"], r3["kernel_ms"]
-        out["also"].append({"workload": label3, "reads": 8192, "value": c3_ * 3 / r3["elapsed"], "unit": "cells/s",
-                            "reads_per_s": 8192 * 3 / r3["elapsed"], "ms_per_step": r3["elapsed"] / 3 * 1e3,
+        out["also"].append({"workload": label3, "reads": 8192, "value": c3_ * ALSO_STEPS / r3["elapsed"], "unit": "cells/s", "steps": ALSO_STEPS,
+                            "reads_per_s": 8192 * ALSO_STEPS / r3["elapsed"], "ms_per_step": r3["elapsed"] / ALSO_STEPS * 1e3,
+                            "step_spread": spread(r3["step_ms"]), "dp_launch_spread": spread(r3["kernel_ms_all"]),
                             "dp_sweep_only": {"value": c3_ / (k3 * 1e-3), "unit": "cells/s", "ms": k3}, "finish_ms": r3["finish_ms"],
                             "roofline": roofline_block(c3_, int(r3["res"]["n_pairs"].sum()), k3, r3["class_cells"], gpu_clock_hz()),
                             "ok_reads": int((r3["res"]["status"] == 0).sum())})
@@ -576,14 +668,16 @@ def c3_job(env, n_reads, steps, warmup, from_files):
         last = one()
     sync()
     t0 = time.perf_counter()
-    tms = []
+    tms, step_ms = [], []
     for _ in range(steps):
+        ts = time.perf_counter()
         last = one()
+        step_ms.append((time.perf_counter() - ts) * 1e3)  # (this rank's; the line's ms_per_step is the maximum over the ranks of the whole region)
         tms.append(last["timings"])
     sync()
     elapsed = time.perf_counter() - t0
     cells_rank = tms[-1]["cells"]
-    solo = None
+    solo, solo_ms = None, None
     if dist is not None:
         elapsed = allreduce([elapsed], dist.ReduceOp.MAX)[0]
         total_cells = int(allreduce([cells_rank], dist.ReduceOp.SUM)[0])
@@ -600,10 +694,12 @@ def c3_job(env, n_reads, steps, warmup, from_files):
                     return job.realign_sam_file(sam, os.path.join(tmp, "realigned_solo_%d.sam" % step_no[0]), fa, params=params, gpu=gpu,
                                                 set_models=False, group=job.SOLO)
                 alone()
-                ts = time.perf_counter()
+                solo_ms = []
                 for _ in range(steps):
+                    ts = time.perf_counter()
                     alone()
-                solo = (time.perf_counter() - ts) / steps
+                    solo_ms.append((time.perf_counter() - ts) * 1e3)
+                solo = float(np.median(solo_ms)) * 1e-3  # (the median: one slow step of seven must not move the series' reference point)
                 if threads_env is None:
                     del os.environ["NPR_HOST_THREADS"]
                 else:
@@ -633,6 +729,7 @@ def c3_job(env, n_reads, steps, warmup, from_files):
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": wall * 1e3,
+        "step_spread_rank0": spread(step_ms),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -653,6 +750,7 @@ def c3_job(env, n_reads, steps, warmup, from_files):
         "dp_share_of_wall": (kms * 1e-3) / wall,
         "speedup_vs_n1": None if solo is None else solo / wall,
         "n1_ms_per_step": None if solo is None else solo * 1e3,
+        "n1_step_spread": None if solo is None else spread(solo_ms),
         "n1_reads_per_s": None if solo is None else n_reads / solo,
         "speedup_note": ("the same files -> file job run by rank 0 ALONE inside this launch (the other ranks wait), all host cores "
                          "to it: ms_per_step(N = 1) / ms_per_step(N = %d); the >= 6x target at N = 8 is read off this field" % world)

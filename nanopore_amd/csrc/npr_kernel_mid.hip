@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
 #pragma unroll
     for (int r = 0; r < R; ++r) jr[r] = R * lane + r;
 
-    int t = blockIdx.x;
+    int t = blockIdx.x, last_model = -1;
     while (t < a.ntasks) {
         const Task *tp = a.tasks + t;
         const int64_t x_off = uni64(tp->x_off), y_off = uni64(tp->y_off), ctl_off = uni64(tp->ctl_off), pair_off = uni64(tp->pair_off);
@@ -111,13 +111,15 @@ __global__ void __launch_bounds__(2 * WAVE) __attribute__((amdgpu_waves_per_eu(R
         const int c = (D / (2 * RS_K)) * RS_K;  // the cut row; D >= MID_MIN_D: c >= RS_K and D - c >= 2 RS_K
 
         __syncthreads();
-        {
+        const bool new_model = model != last_model;  // (uniform.  The model and the tables made of it stay in LDS from task to task: a batch has one model, or a few)
+        if (new_model) {
             const float *gm = reinterpret_cast<const float *>(a.models + model);
             for (int i = threadIdx.x; i < MODEL_FLOATS; i += 2 * WAVE) lmodel[i] = gm[i];
-            if (threadIdx.x < 16) lmisc[threadIdx.x] = threadIdx.x == 1 || threadIdx.x == 3 ? E_DEAD : (threadIdx.x == 7 || threadIdx.x == 13 ? -(1 << 30) : 0);
         }
+        if (threadIdx.x < 16) lmisc[threadIdx.x] = threadIdx.x == 1 || threadIdx.x == 3 ? E_DEAD : (threadIdx.x == 7 || threadIdx.x == 13 ? -(1 << 30) : 0);
         __syncthreads();
-        rs_build_tables(ltab, reinterpret_cast<const DevModel *>(lmodel), threadIdx.x, 2 * WAVE);
+        if (new_model) rs_build_tables(ltab, reinterpret_cast<const DevModel *>(lmodel), threadIdx.x, 2 * WAVE);
+        last_model = model;
         StepEnv E;
         E.mdl = reinterpret_cast<const DevModel *>(lmodel);
         E.ltab = reinterpret_cast<const char *>(ltab);
