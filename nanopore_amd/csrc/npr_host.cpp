@@ -247,7 +247,7 @@ int32_t mea_cigar(int64_t lX, int64_t lY, const Pair *pairs, int64_t n, double g
         if (pairs[i].x < 0 || pairs[i].x >= lX || pairs[i].y < 0 || pairs[i].y >= lY) return NPR_ERR_INVALID;
         // the list is a caller's (npr_mea_cigar is public): values that are no probabilities (NaN, negative, above 1) and pairs out of (x, y) order or
         // twice in the list are refused -- the chain below assumes the order, and a weight made of NaN is undefined behaviour before it is a wrong cigar
-        if (!(pairs[i].p >= 0.f && pairs[i].p <= 1.0f + 0x1p-20f)) return NPR_ERR_INVALID;
+        if (!(pairs[i].p >= 0.f && pairs[i].p <= 1.0f + 0x1p-10f)) return NPR_ERR_INVALID;  // (fp32 rounding puts a certain match a few 2^-23 above 1)
         if (i > 0 && (pairs[i].x < pairs[i - 1].x || (pairs[i].x == pairs[i - 1].x && pairs[i].y <= pairs[i - 1].y))) return NPR_ERR_INVALID;
         q[i] = static_cast<int64_t>(std::floor(static_cast<double>(pairs[i].p) * static_cast<double>(PROB_ONE)));
         if (i == 0 || pairs[i].y < ymin) ymin = pairs[i].y;

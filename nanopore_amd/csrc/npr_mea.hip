@@ -57,7 +57,7 @@ __device__ __forceinline__ bool beats(int64_t s, int w, int64_t os, int ow) { re
 // empty tables as well, so either guard alone keeps the stage off them).  And a value that is no probability -- NaN, negative, above 1 -- makes its
 // read NPR_ERR_INVALID instead of a weight.
 __device__ __forceinline__ int mea_task_pairs(const TaskOut &o, const Task &tk) { return o.status == NPR_OK ? min(max(o.npairs, 0), tk.pair_cap) : 0; }
-__device__ __forceinline__ bool mea_is_posterior(float p) { return p >= 0.f && p <= 1.0f + 0x1p-20f; }
+__device__ __forceinline__ bool mea_is_posterior(float p) { return p >= 0.f && p <= 1.0f + 0x1p-10f; }  // (fp32 rounding puts a certain match at 1 + a few 2^-23: 1.0000013 in configs[1])
 
 __global__ void __launch_bounds__(256) k_mea_zero(MeaArgs a) {
     const int r = blockIdx.x;
