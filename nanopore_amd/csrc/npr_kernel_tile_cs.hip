@@ -174,9 +174,13 @@ __device__ __forceinline__ int tcs_column_cost(const DevModel *m) {
 
 // A stripe's register state: the rows of the two previous anti-diagonals and the carried neighbour copy in THIS lane's units 2^e; c = 2^(e of
 // the lane the data comes from - e); eh: the largest e of the lanes a value of this block can have come from (the certificate's bound).
+// carry: what slot 0 (forward) / the top slot (backward) takes from the neighbour lane's cell of TWO anti-diagonals ago -- forward the dot product of
+// that cell's states with the transitions into match (made by the lane that owns the cell: umA / umB hold it for the top cells of A / B), backward the
+// cell's match value -- already in this lane's units.  Of the neighbour's cell of ONE anti-diagonal ago a step takes m, sx, lx (and sy under SW) as they
+// are, in the neighbour's units: c is folded into the x-gap emissions that multiply them (a power of two: the same bits).
 struct CsState {
     RDiag<2> A, B;
-    RCell carry;
+    float carry, umA, umB;
     int e, eh;
     float c;
 };
@@ -184,7 +188,7 @@ struct CsState {
 // stripe's edge lane (origin -1 / 64, exponent e_in; TCS_NONE: no neighbour, 0) or from the lane of the start / end cell (whose exponent is then -TCS_TOP).
 template <bool FWD>
 __device__ __forceinline__ void tcs_init(CsState &Q, int lane, int e_in, int eh_in, int origin, int dslot) {
-    Q.A = zero_rdiag<2>(), Q.B = zero_rdiag<2>(), Q.carry = zero_rcell();
+    Q.A = zero_rdiag<2>(), Q.B = zero_rdiag<2>(), Q.carry = 0.f, Q.umA = 0.f, Q.umB = 0.f;
     const bool cell = origin >= 0 && origin < WAVE;  // the start / end cell goes in at 2^TCS_TOP like a renormalised value
     const int base = cell ? -TCS_TOP : (e_in == TCS_NONE ? 0 : e_in);
     const int src = FWD ? lane - 1 : lane + 1;  // the lane this one's neighbour values come from
@@ -200,7 +204,7 @@ __device__ __forceinline__ void tcs_init(CsState &Q, int lane, int e_in, int eh_
 template <bool FWD>
 __device__ __forceinline__ void tcs_renorm(CsState &Q, int lane, int e_in, int eh_in, int dslot) {
     const int pos = FWD ? lane : WAVE - 1 - lane;
-    uint32_t u = rcell_max_bits(Q.carry);
+    uint32_t u = static_cast<uint32_t>(fbits(Q.carry));
 #pragma unroll
     for (int r = 0; r < 2; ++r) u = umax3(u, rcell_max_bits(Q.A.c[r]), rcell_max_bits(Q.B.c[r]));
     const int eb = static_cast<int>(u >> 23);  // biased exponent of the lane's largest value; 0: nothing (or less than a normal number)
@@ -214,7 +218,7 @@ __device__ __forceinline__ void tcs_renorm(CsState &Q, int lane, int e_in, int e
     const float f = tcs_pow2(Q.e - en);
 #pragma unroll
     for (int r = 0; r < 2; ++r) rcell_scale(Q.A.c[r], f), rcell_scale(Q.B.c[r], f);
-    rcell_scale(Q.carry, f);
+    Q.carry *= f, Q.umA *= f, Q.umB *= f;
     const int eu = FWD ? dpp_from_below(en, e_in) : dpp_from_above(en, e_in);
     Q.c = tcs_pow2(eu - en);
     Q.e = en;
@@ -254,40 +258,109 @@ __device__ __forceinline__ void tcs_wait_at_most(const int *p, int need, int &st
 }
 
 // ---- one anti-diagonal of a stripe, the part every step has ----
-// forward: io d-2 -> d; p1 d-1; carry: the slot-below copy of d-2's top register -> that of d-1; erec: the left stripe's cell on d-1 (LDS)
+__device__ __forceinline__ float tcs_dpp_below(float v, float edge) { return bitsf(__builtin_amdgcn_update_dpp(fbits(edge), fbits(v), 0x138, 0xf, 0xf, false)); }
+__device__ __forceinline__ float tcs_dpp_above(float v, float edge) { return bitsf(__builtin_amdgcn_update_dpp(fbits(edge), fbits(v), 0x130, 0xf, 0xf, false)); }
+// the transitions into match applied to a cell: what the cell diagonally above-right of it starts from (rs_fwd_cell's first five operations)
+__device__ __forceinline__ float tcs_into_match(const Trans &t, const RCell &c) {
+    float a = t.mm * c.m;
+    a = __builtin_fmaf(t.sxm, c.sx, a);
+    a = __builtin_fmaf(t.sym, c.sy, a);
+    a = __builtin_fmaf(t.lxm, c.lx, a);
+    a = __builtin_fmaf(t.lym, c.ly, a);
+    return a;
+}
+// forward: io d-2 -> d; p1 d-1; um_p1: tcs_into_match of p1's top cell, um_io: that of io's new one; erec: the left stripe's record of d-1 (LDS: um, m, sx,
+// lx | sy).  Same operations in the same order as rs_fwd_cell on every cell (npr_rs.h); only WHO makes the match dot product of a lane's top cell differs.
 // FULL: every slot of the row is a band cell (its mask word is 0): the emissions come without the in-band selects
 template <bool SW, bool FLAT, bool FULL = false>
-__device__ __forceinline__ void tcs_fwd_core(const StepEnv &E, RDiag<2> &io, const RDiag<2> &p1, RCell &carry, float c, const Masks<2> &mk, const float *erec,
-                                             const Bases<2> &bx, Bases<2> &by, int inject) {
-    const RCell edge = tcs_edge_get(erec, 0);
+__device__ __forceinline__ void tcs_fwd_core(const StepEnv &E, RDiag<2> &io, const RDiag<2> &p1, float &carry, float &um_io, float um_p1, float c, const Masks<2> &mk,
+                                             const float *erec, const Bases<2> &bx, Bases<2> &by, int inject) {
+    const float4 edge = *reinterpret_cast<const float4 *>(erec);
     bases_down<2>(by, inject);
-    RCell Le = dpp_rcell_from_below(p1.c[1], edge);  // (x-1, y) of every lane's register 0, in the units of the lane it comes from
-    rcell_scale(Le, c);
+    const float um_s = tcs_dpp_below(um_p1, edge.x) * c;  // (x-1, y-1)'s share of the NEXT anti-diagonal's slot 0, in this lane's units from here on
+    const float Lm = tcs_dpp_below(p1.c[1].m, edge.y), Lsx = tcs_dpp_below(p1.c[1].sx, edge.z), Llx = tcs_dpp_below(p1.c[1].lx, edge.w);  // (x-1, y), the neighbour's units
+    float Lsy = 0.f;
+    if constexpr (SW) Lsy = tcs_dpp_below(p1.c[1].sy, erec[4]);
     float em[2], exs[2], exl[2], eys[2], eyl[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) rs_cell_emissions<FULL ? 4 : 2, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
     RDiag<2> o;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) o.c[r] = rs_fwd_cell<SW>(E.tr, r ? p1.c[r - 1] : Le, r ? io.c[r - 1] : carry, p1.c[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
+    {
+        const Trans &t = E.tr;
+        const RCell &U = p1.c[0];
+        const float exs_c = exs[0] * c, exl_c = FLAT ? exs_c : exl[0] * c;
+        RCell q;
+        float a;
+        q.m = em[0] * carry;
+        a = t.msx * Lm;
+        a = __builtin_fmaf(t.sxsx, Lsx, a);
+        if constexpr (SW) a = __builtin_fmaf(t.sysx, Lsy, a);
+        q.sx = exs_c * a;
+        a = t.mlx * Lm;
+        a = __builtin_fmaf(t.lxlx, Llx, a);
+        q.lx = exl_c * a;
+        a = t.msy * U.m;
+        a = __builtin_fmaf(t.sysy, U.sy, a);
+        if constexpr (SW) a = __builtin_fmaf(t.sxsy, U.sx, a);
+        q.sy = eys[0] * a;
+        a = t.mly * U.m;
+        a = __builtin_fmaf(t.lyly, U.ly, a);
+        q.ly = eyl[0] * a;
+        o.c[0] = q;
+    }
+    o.c[1] = rs_fwd_cell<SW>(E.tr, p1.c[0], io.c[0], p1.c[1], em[1], exs[1], exl[1], eys[1], eyl[1]);
     io = o;
-    carry = Le;
+    carry = um_s;
+    um_io = tcs_into_match(E.tr, o.c[1]);
 }
-// backward: io d+2 -> d; s1 d+1; carry: the slot-above copy of d+2's register 0 -> that of d+1; erec: the right stripe's cell on d+1
+// backward: io d+2 -> d; s1 d+1; carry: the match value of (x+1, y+1) of the top slot, in this lane's units; erec: the right stripe's record of d+1 (m, sx, lx)
 template <bool SW, bool FLAT, bool FULL = false>
-__device__ __forceinline__ void tcs_bwd_core(const StepEnv &E, RDiag<2> &io, const RDiag<2> &s1, RCell &carry, float c, const Masks<2> &mk, const float *erec,
+__device__ __forceinline__ void tcs_bwd_core(const StepEnv &E, RDiag<2> &io, const RDiag<2> &s1, float &carry, float c, const Masks<2> &mk, const float *erec,
                                              const Bases<2> &bx, Bases<2> &by, int inject) {
-    const RCell edge = tcs_edge_get(erec, 0);
+    const float4 edge = *reinterpret_cast<const float4 *>(erec);
     bases_up<2>(by, inject);
-    RCell Xe = dpp_rcell_from_above(s1.c[0], edge);  // (x+1, y) of every lane's top register, in the units of the lane it comes from
-    rcell_scale(Xe, c);
+    const float Xm = tcs_dpp_above(s1.c[0].m, edge.x) * c;  // becomes (x+1, y+1) of the next anti-diagonal
+    const float Xsx = tcs_dpp_above(s1.c[0].sx, edge.y), Xlx = tcs_dpp_above(s1.c[0].lx, edge.z);  // (x+1, y), the neighbour's units
     float em[2], exs[2], exl[2], eys[2], eyl[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) rs_cell_emissions<FULL ? 4 : 2, FLAT>(E.ltab, mk.cell[r], bx.b[r], by.b[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
     RDiag<2> o;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) o.c[r] = rs_bwd_cell<SW>(E.tr, r + 1 < 2 ? io.c[r + 1] : carry, r + 1 < 2 ? s1.c[r + 1] : Xe, s1.c[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
+    o.c[0] = rs_bwd_cell<SW>(E.tr, io.c[1], s1.c[1], s1.c[0], em[0], exs[0], exl[0], eys[0], eyl[0]);
+    {
+        const Trans &t = E.tr;
+        const RCell &Ys = s1.c[1];
+        const float exs_c = exs[1] * c, exl_c = FLAT ? exs_c : exl[1] * c;
+        const float am = em[1] * carry, asx = exs_c * Xsx, alx = exl_c * Xlx, asy = eys[1] * Ys.sy, aly = eyl[1] * Ys.ly;
+        RCell q;
+        float b;
+        b = t.mm * am;
+        b = __builtin_fmaf(t.msx, asx, b);
+        b = __builtin_fmaf(t.mlx, alx, b);
+        b = __builtin_fmaf(t.msy, asy, b);
+        b = __builtin_fmaf(t.mly, aly, b);
+        q.m = b;
+        b = t.sxm * am;
+        b = __builtin_fmaf(t.sxsx, asx, b);
+        if constexpr (SW) b = __builtin_fmaf(t.sxsy, asy, b);
+        q.sx = b;
+        b = t.sym * am;
+        b = __builtin_fmaf(t.sysy, asy, b);
+        if constexpr (SW) b = __builtin_fmaf(t.sysx, asx, b);
+        q.sy = b;
+        b = t.lxm * am;
+        b = __builtin_fmaf(t.lxlx, alx, b);
+        q.lx = b;
+        b = t.lym * am;
+        b = __builtin_fmaf(t.lyly, aly, b);
+        q.ly = b;
+        o.c[1] = q;
+    }
     io = o;
-    carry = Xe;
+    carry = Xm;
+}
+__device__ __forceinline__ void tcs_swap(float &x, float &y) {
+    const float t = x;
+    x = y, y = t;
 }
 // the two held rows trade places (a generic step is written for an odd anti-diagonal: the row it makes goes to Q.A)
 __device__ __forceinline__ void tcs_swap_rows(RDiag<2> &A, RDiag<2> &B) {
@@ -297,9 +370,15 @@ __device__ __forceinline__ void tcs_swap_rows(RDiag<2> &A, RDiag<2> &B) {
 __device__ __forceinline__ void tcs_store_row(__amdgpu_buffer_rsrc_t rsF, int vo, const RDiag<2> &io) {
     __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(io.c[0].m), fbits(io.c[1].m)}, rsF, vo, 0, 0);
 }
-__device__ __forceinline__ void tcs_store_edge(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, int e, int eh) {
-    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.sy), fbits(c.lx)}, rsE, vo, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.ly), e, eh, 0}, rsE, vo + 16, 0, 0);
+// the record a stripe leaves for its neighbour stripe: forward (um, m, sx, lx | sy, e, e^, -) of its last column's cell, backward (m, sx, lx, - | -, e, e^, -)
+// of its first column's
+__device__ __forceinline__ void tcs_store_edge_fwd(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, float um, int e, int eh) {
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(um), fbits(c.m), fbits(c.sx), fbits(c.lx)}, rsE, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.sy), e, eh, 0}, rsE, vo + 16, 0, 0);
+}
+__device__ __forceinline__ void tcs_store_edge_bwd(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, int e, int eh) {
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.lx), 0}, rsE, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{0, e, eh, 0}, rsE, vo + 16, 0, 0);
 }
 
 // LDS of a workgroup (static: the table offsets fold into the LDS instructions, npr_rs.h)
@@ -428,11 +507,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(Ef + (static_cast<int64_t>(row0L) + (q0 - dfL)) * (4 * TCS_EDGE), 0, -1, 0x00020000);
                     const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rq, 0, 0, 16);
                     const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rq, 16, 0, 16);
-                    if (lane == 0) {
-                        const int k = g.y - Q.e;
-                        Q.carry = RCell{__builtin_ldexpf(bitsf(q.x), k), __builtin_ldexpf(bitsf(q.y), k), __builtin_ldexpf(bitsf(q.z), k),
-                                        __builtin_ldexpf(bitsf(q.w), k), __builtin_ldexpf(bitsf(g.x), k)};
-                    }
+                    if (lane == 0) Q.carry = __builtin_ldexpf(bitsf(q.x), g.y - Q.e);  // (the record's um, in this lane's units)
                 }
                 __builtin_amdgcn_raw_buffer_store_b64(v2i{Q.e, Q.eh}, rsF, TCS_EXP_AT + 8 * lane, 0, 0);
             }
@@ -442,7 +517,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 const int k = d - st.df;
                 const Masks<R> mk = row_masks(rm[0]);
                 rm += 1;
-                tcs_fwd_core<SW, FLAT>(E, io, p1, Q.carry, Q.c, mk, stage + TCS_EDGE * ((d - 1) & (TCS_BLOCK - 1)), bx, by, feed8_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));
+                tcs_fwd_core<SW, FLAT>(E, io, p1, Q.carry, Q.umA, Q.umB, Q.c, mk, stage + TCS_EDGE * ((d - 1) & (TCS_BLOCK - 1)), bx, by, feed8_get<+1>(fy, E.Y, lY, d - st.X - 1, lane));  // (io is Q.A, p1 is Q.B: gstep)
                 if (d == 0) {  // the start cell (0, 0): slot 0 of the first stripe
                     if (lane == 0) {
                         const int k0 = -Q.e;
@@ -459,7 +534,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                     __builtin_amdgcn_raw_buffer_store_b64(v2i{Q.e, Q.eh}, rsF, k * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
                 }
                 tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
-                if (edge_lane) tcs_store_edge(rsE, 4 * TCS_EDGE * k, io.c[R - 1], Q.e, Q.eh);
+                if (edge_lane) tcs_store_edge_fwd(rsE, 4 * TCS_EDGE * k, io.c[R - 1], Q.umA, Q.e, Q.eh);
                 if ((d & (TCS_BLOCK - 1)) == TCS_BLOCK - 1 || d == st.dl) {
                     wait_vm();
                     if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k + 1);
@@ -467,9 +542,9 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
             };
             // any row, whatever its parity: the step above is instantiated once, for an odd anti-diagonal
             auto gstep = [&](int d) {
-                if (!(d & 1)) tcs_swap_rows(Q.A, Q.B);
+                if (!(d & 1)) tcs_swap_rows(Q.A, Q.B), tcs_swap(Q.umA, Q.umB);
                 step(d, Q.A, Q.B);
-                if (!(d & 1)) tcs_swap_rows(Q.A, Q.B);
+                if (!(d & 1)) tcs_swap_rows(Q.A, Q.B), tcs_swap(Q.umA, Q.umB);
             };
             // ONE loop with ONE instance of the general step (the kernel has to stay small for the instruction cache).  Where a row 16 kb + 1 opens a whole block
             // of sixteen rows inside the stripe, its first fifteen -- no corner cell, no boundary, one hand-over at the end: nothing but the recurrence, the
@@ -485,17 +560,17 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 const int wv16 = static_cast<int>(a.rowmask[rowmask_off + st.row0 + static_cast<uint32_t>(d - st.df) + (lane & (TCS_BLOCK - 1))]);
 #pragma unroll 1
                 for (int i = 0; i < 7; ++i) {
-                    tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                    tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
                     tcs_store_row(rsF, vo, Q.A);
-                    if (edge_lane) tcs_store_edge(rsE, ve, Q.A.c[R - 1], Q.e, Q.eh);
-                    tcs_fwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1)), er + TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
+                    if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
+                    tcs_fwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.umB, Q.umA, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1)), er + TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
                     tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
-                    if (edge_lane) tcs_store_edge(rsE, ve + 4 * TCS_EDGE, Q.B.c[R - 1], Q.e, Q.eh);
+                    if (edge_lane) tcs_store_edge_fwd(rsE, ve + 4 * TCS_EDGE, Q.B.c[R - 1], Q.umB, Q.e, Q.eh);
                     yi += 2, vo += 2 * TCS_ROW_BYTES, ve += 2 * 4 * TCS_EDGE, er += 2 * TCS_EDGE;
                 }
-                tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 14)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 14)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
                 tcs_store_row(rsF, vo, Q.A);
-                if (edge_lane) tcs_store_edge(rsE, ve, Q.A.c[R - 1], Q.e, Q.eh);
+                if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
                 wait_vm();
                 if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + (d + 14 - st.df) + 1);
                 rm += TCS_BLOCK - 1;
@@ -604,11 +679,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(Eb + (static_cast<int64_t>(row0R) + (q0 - dfR)) * (4 * TCS_EDGE), 0, -1, 0x00020000);
                         const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rq, 0, 0, 16);
                         const v4i g = __builtin_amdgcn_raw_buffer_load_b128(rq, 16, 0, 16);
-                        if (lane == WAVE - 1) {
-                            const int k = g.y - Q.e;
-                            Q.carry = RCell{__builtin_ldexpf(bitsf(q.x), k), __builtin_ldexpf(bitsf(q.y), k), __builtin_ldexpf(bitsf(q.z), k),
-                                            __builtin_ldexpf(bitsf(q.w), k), __builtin_ldexpf(bitsf(g.x), k)};
-                        }
+                        if (lane == WAVE - 1) Q.carry = __builtin_ldexpf(bitsf(q.x), g.y - Q.e);  // (the record's m, in this lane's units)
                     }
                     enter_block(st.dl);
                 }
@@ -681,7 +752,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         }
                         enter_block(d);
                     }
-                    if (lane == 0) tcs_store_edge(rsE, 4 * TCS_EDGE * k, io.c[0], Q.e, Q.eh);  // holds the stripe's first column in its register 0
+                    if (lane == 0) tcs_store_edge_bwd(rsE, 4 * TCS_EDGE * k, io.c[0], Q.e, Q.eh);  // holds the stripe's first column in its register 0
                     emit(d, io, f, mk);
                     if ((d & (TCS_BLOCK - 1)) == 0 || d == st.df) {
                         wait_vm();
@@ -720,7 +791,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         }
                         const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i));
                         tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
-                        if (lane == 0) tcs_store_edge(rsE, ve, Q.B.c[0], Q.e, Q.eh);
+                        if (lane == 0) tcs_store_edge_bwd(rsE, ve, Q.B.c[0], Q.e, Q.eh);
                         emit(d - 2 * i, Q.B, fb, m0);
                         {
                             const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo - TCS_ROW_BYTES, 0, 0);
@@ -728,7 +799,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         }
                         const Masks<R> m1 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1));
                         tcs_bwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, m1, er - TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
-                        if (lane == 0) tcs_store_edge(rsE, ve - 4 * TCS_EDGE, Q.A.c[0], Q.e, Q.eh);
+                        if (lane == 0) tcs_store_edge_bwd(rsE, ve - 4 * TCS_EDGE, Q.A.c[0], Q.e, Q.eh);
                         emit(d - 2 * i - 1, Q.A, fa, m1);
                         yi += 2, vo -= 2 * TCS_ROW_BYTES, ve -= 2 * 4 * TCS_EDGE, er -= 2 * TCS_EDGE;
                     }
@@ -739,7 +810,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         }
                         const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 14));
                         tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
-                        if (lane == 0) tcs_store_edge(rsE, ve, Q.B.c[0], Q.e, Q.eh);
+                        if (lane == 0) tcs_store_edge_bwd(rsE, ve, Q.B.c[0], Q.e, Q.eh);
                         emit(d - 14, Q.B, fb, m0);
                         wait_vm();
                         if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + (d - 14 - st.df));
