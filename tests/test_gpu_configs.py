@@ -87,7 +87,10 @@ def test_config2_every_read_against_the_oracle(gpu_ctx):
     for i in ties:  # a tie moves an indel along a repeat: same spans, same number of aligned pairs +- a handful, scores within 1e-4
         a, b_ = ops[off[i]:off[i + 1]], m64["ops"][i]
         assert abs(int(a[a[:, 0] == 0, 1].sum()) - int(b_[b_[:, 0] == 0, 1].sum())) <= 8
-    assert same64 >= 995
+    # north_star asks for bit-exact cigars: on this configuration -- seeded, deterministic on the device -- every one of the 1000 is also the fp64
+    # oracle's (rounds 3-5 accepted 995; the count was 1000 in every run).  A change of the workload generator that brings a tie in will fail here
+    # and be looked at, not absorbed.
+    assert same64 == 1000
 
 
 def test_config3_shared_contig_50k_reads(gpu_ctx):
