@@ -93,7 +93,7 @@ def _check_frame_schedule(seg, sch, slots, per_lane):
 
 @pytest.mark.parametrize("seed", range(3))
 def test_register_kernel_frame_schedule(seed):
-    """build_stair_schedule (npr_api.cpp) through npr_plan_frame_schedule: the band stays inside the frame, rebases
+    """build_stair_schedule (npr_api_internal.h) through npr_plan_frame_schedule: the band stays inside the frame, rebases
     obey the parity rule the kernels rely on, rows are laid out as the kernels address them."""
     rng = np.random.default_rng(900 + seed)
     followed = rebases = 0
