@@ -587,6 +587,11 @@ __device__ __forceinline__ Cell edge_load(char *Eb, uint32_t row) {
     return Cell{bitsf(q.x), bitsf(q.y), bitsf(q.z), bitsf(q.w), bitsf(g.x), g.y};
 }
 
+#ifndef NPR_EM_SKIP
+#define NPR_EM_SKIP (-40)
+#endif
+constexpr int EM_SKIP = NPR_EM_SKIP;
+__device__ __forceinline__ int Fm_e_of(const Cell &c) { return c.e; }
 __device__ __forceinline__ float &tile_bin_at(float *lbins, int byte_off) {
     return *reinterpret_cast<float *>(reinterpret_cast<char *>(lbins) + byte_off);
 }
@@ -606,7 +611,11 @@ __device__ __forceinline__ void tile_em_cells(const StepEnv &E, const Diag<R> &i
         const int ex4 = eX.b[r], ey4 = eY.b[r];
         const int lane4 = 4 * lane;
         float bM = 0.f, bXs = 0.f, bXl = 0.f, bYs = 0.f, bYl = 0.f;  // this cell's emission posteriors
-        if (lanes_of(here & vm[r])) {
+        // (round 6) A region whose every lane's F * B / total is below 2^EM_SKIP contributes nothing a count can see (2.7e8 terms of 2^-40 each are
+        // 2.4e-4 of a count): the wavefront steps over it -- a stripe row that lies off the alignment's path, a third of the rows of the trainer's band.
+        const int s_m = Fm_e_of(Gm.c[r]) + c.e - tot_e, s_l = Fm_e_of(Gl.c[r]) + c.e - tot_e, s_u = Fm_e_of(Gu.c[r]) + c.e - tot_e;
+        const uint64_t live_m = here & vm[r] & __ballot(s_m > EM_SKIP), live_l = here & vl[r] & __ballot(s_l > EM_SKIP), live_u = here & vu[r] & __ballot(s_u > EM_SKIP);
+        if (lanes_of(live_m)) {
             const Cell &Fm = Gm.c[r];
             const int s = min(max(Fm.e + c.e - tot_e, -200), 200);
             const float em = *reinterpret_cast<const float *>(E.ltab + offsetof(DevModel, em) + 5 * ex4 + ey4);
@@ -616,7 +625,7 @@ __device__ __forceinline__ void tile_em_cells(const StepEnv &E, const Diag<R> &i
             acc[0] += t0, acc[1] += t1, acc[2] += t2, acc[3] += t3, acc[4] += t4;
             bM = (t0 + t1) + (t2 + t3) + t4;
         }
-        if (lanes_of(here & vl[r])) {
+        if (lanes_of(live_l)) {
             const Cell &Fl = Gl.c[r];
             const int s = min(max(Fl.e + c.e - tot_e, -200), 200);
             const float g = __builtin_ldexpf(inv_tot, s);
@@ -628,7 +637,7 @@ __device__ __forceinline__ void tile_em_cells(const StepEnv &E, const Diag<R> &i
             acc[5] += t0, acc[6] += t1, acc[7] += t2, acc[8] += u0, acc[9] += u1;
             bXs = (t0 + t1) + t2, bXl = u0 + u1;
         }
-        if (lanes_of(here & vu[r])) {
+        if (lanes_of(live_u)) {
             const Cell &Fu = Gu.c[r];
             const int s = min(max(Fu.e + c.e - tot_e, -200), 200);
             const float g = __builtin_ldexpf(inv_tot, s);
@@ -640,7 +649,7 @@ __device__ __forceinline__ void tile_em_cells(const StepEnv &E, const Diag<R> &i
             acc[10] += t0, acc[11] += t1, acc[12] += t2, acc[13] += u0, acc[14] += u1;
             bYs = (t0 + t1) + t2, bYl = u0 + u1;
         }
-        if (lanes_of(here)) {  // the five bins of this cell (disjoint tables): all reads, then all writes; an N base goes to the scratch row
+        if (lanes_of(live_m | live_l | live_u)) {  // the five bins of this cell (disjoint tables): all reads, then all writes; an N base goes to the scratch row
             constexpr int TRASH = EM_BINS * 256;
             const bool nx = ex4 >= 16, ny = ey4 >= 16;
             const int aM = ((nx || ny) ? TRASH : ex4 * 256 + ey4 * 64) + lane4;
