@@ -10,7 +10,7 @@ for reads in (6250, 12500, 25000, 50000):
         env = dict(os.environ)
         if threads:
             env["NPR_HOST_THREADS"] = str(threads)
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--reads", str(reads), "--steps", "3", "--warmup", "1"],
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--reads", str(reads), "--steps", "7", "--warmup", "1"],
                            env=env, capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if not line:
@@ -23,7 +23,7 @@ for reads in (6250, 12500, 25000, 50000):
             row["ms_per_step_2_host_threads"] = d["ms_per_step"]
     rows.append(row)
     print(reads, round(row.get("ms_per_step", 0), 1), round(row.get("ms_per_step_2_host_threads", 0), 1), flush=True)
-out = {"what": "bench.py --workload c3 --reads n --steps 3 --warmup 1 on ONE GPU: the share of one rank of the strong-scaling job (BASELINE.json "
+out = {"what": "bench.py --workload c3 --reads n --steps 7 --warmup 1 on ONE GPU: the share of one rank of the strong-scaling job (BASELINE.json "
                "configs[3]) at N = 8 / 4 / 2 / 1, files -> file, with the box's host threads and with NPR_HOST_THREADS=2", "rows": rows}
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)
