@@ -43,7 +43,7 @@ OPT_RELEASE_SCRATCH = 2
 # test / bring-up switches (include/nprealign.h: NPR_OPT_*; none changes a result)
 OPTIONS = dict(kernel=3, arith=4, pair=5, no_tile=6, no_wide=7, tile_rs=8, tile_waves=9, waves_per_cu=10, class_min=11,
                variable_scratch=12, host_mea=13, mea_ring_only=14, mea_global_sort=15, mea_own_scratch=16, em_generic=17,
-               em_serial=18, em_waves=19, mea_wide_ops=20)
+               em_serial=18, em_waves=19, mea_wide_ops=20, em_tile=21)
 KERNEL_GENERIC, ARITH_CELL, PAIR_NEVER, PAIR_LONG, PAIR_ALL = 1, 1, 1, 2, 3
 STATS_WORDS = 40  # NPR_STATS_WORDS
 MAX_MODELS = 8

@@ -326,6 +326,10 @@ int launch_mid_rs(const KernelArgs &a, int R, int grid, void *stream, bool sw, b
 // sw / flat as for launch_rs
 int launch_tile_cs(const KernelArgs &a, int NW, int grid, void *stream, bool sw, bool flat);
 size_t tile_cs_lds_bytes(int nw);
+// ... and its E-step instance (k_dp_tile_cs<.., EM>): k_em_tile's job in that arithmetic; a task whose certificate fails comes back TASK_RERUN, uncounted
+int launch_em_tile_cs(const KernelArgs &a, int NW, int grid, void *stream, bool sw, bool flat);
+int em_tile_cs_waves();
+int em_tile_cs_waves_per_cu();
 size_t rs_lds_bytes();
 int em_tile_waves();
 int em_tile_waves_per_cu();

@@ -201,8 +201,9 @@ __device__ __forceinline__ void tcs_init(CsState &Q, int lane, int e_in, int eh_
 }
 // Renormalisation of everything a stripe holds, lane by lane, with the exponents kept Lipschitz along the data flow; e_in / eh_in: the
 // neighbour stripe's edge lane for the block to come (uniform; TCS_NONE: it has no rows there).
+// Returns the biased exponent of the largest value the lane held (0: nothing).
 template <bool FWD>
-__device__ __forceinline__ void tcs_renorm(CsState &Q, int lane, int e_in, int eh_in, int dslot) {
+__device__ __forceinline__ int tcs_renorm(CsState &Q, int lane, int e_in, int eh_in, int dslot) {
     const int pos = FWD ? lane : WAVE - 1 - lane;
     uint32_t u = static_cast<uint32_t>(fbits(Q.carry));
 #pragma unroll
@@ -237,6 +238,7 @@ __device__ __forceinline__ void tcs_renorm(CsState &Q, int lane, int e_in, int e
     }
     const int m = max(have, w);
     Q.eh = pos <= TCS_REACH ? max(m, eh_in - dslot * (2 * pos + 1)) : m;
+    return eb;
 }
 
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -370,11 +372,18 @@ __device__ __forceinline__ void tcs_swap_rows(RDiag<2> &A, RDiag<2> &B) {
 __device__ __forceinline__ void tcs_store_row(__amdgpu_buffer_rsrc_t rsF, int vo, const RDiag<2> &io) {
     __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(io.c[0].m), fbits(io.c[1].m)}, rsF, vo, 0, 0);
 }
-// the record a stripe leaves for its neighbour stripe: forward (um, m, sx, lx | sy, e, e^, -) of its last column's cell, backward (m, sx, lx, - | -, e, e^, -)
+// the record a stripe leaves for its neighbour stripe: forward (um, m, sx, lx | sy, e, e^, ly) of its last column's cell, backward (m, sx, lx, - | -, e, e^, -)
 // of its first column's
 __device__ __forceinline__ void tcs_store_edge_fwd(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, float um, int e, int eh) {
     __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(um), fbits(c.m), fbits(c.sx), fbits(c.lx)}, rsE, vo, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.sy), e, eh, 0}, rsE, vo + 16, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.sy), e, eh, fbits(c.ly)}, rsE, vo + 16, 0, 0);
+}
+// E-step: the other four states of a row, 16 bytes per cell in the planes' region (row stride 2048: slot 0's sx sy lx ly of lane l at 16 l, slot 1's at
+// 1024 + 16 l -- each store and each load instruction covers one whole KiB)
+constexpr int TCS_XROW_BYTES = 2048;
+__device__ __forceinline__ void tcs_store_planes(__amdgpu_buffer_rsrc_t rsX, int vo, const RDiag<2> &io) {
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[0].sx), fbits(io.c[0].sy), fbits(io.c[0].lx), fbits(io.c[0].ly)}, rsX, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[1].sx), fbits(io.c[1].sy), fbits(io.c[1].lx), fbits(io.c[1].ly)}, rsX, vo + 1024, 0, 0);
 }
 __device__ __forceinline__ void tcs_store_edge_bwd(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, int e, int eh) {
     __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.lx), 0}, rsE, vo, 0, 0);
@@ -382,23 +391,56 @@ __device__ __forceinline__ void tcs_store_edge_bwd(__amdgpu_buffer_rsrc_t rsE, i
 }
 
 // LDS of a workgroup (static: the table offsets fold into the LDS instructions, npr_rs.h)
+template <int NWMAX>
 struct __attribute__((aligned(16))) CsLds {
-    float stage[TCS_MAX_NW][TCS_BLOCK * TCS_EDGE];  // per wavefront: the neighbour stripe's block of cells
+    float stage[NWMAX][TCS_BLOCK * TCS_EDGE];  // per wavefront: the neighbour stripe's block of cells
     RsTables tab;
     float model[MODEL_FLOATS];
     int misc[8];            // [0..3] totals, [4] pair counter, [5] next task, [6] largest certificate value, [7] column cost
-    int prog[TCS_MAX_NW];   // rows whose neighbour cells are out
+    int prog[NWMAX];   // rows whose neighbour cells are out
 };
 
+// ... and what the E-step variant adds: per wavefront the emission bins (one column per lane, no atomics in the loop: k_em_tile's) and the block
+// of the LEFT stripe's forward records its lane 0 counts transitions from
+#ifndef NPR_TCS_EM_NW
+#define NPR_TCS_EM_NW 1
+#endif
+constexpr int TCS_EM_NW = NPR_TCS_EM_NW;
+constexpr int TCS_EM_ROWS = EM_BINS + 5;  // the bins' rows and a scratch zone for N bases: a short-gap bin's long-gap partner lies 4 rows on, there too
+struct __attribute__((aligned(16))) CsEmLds {
+    float stageF[TCS_EM_NW][TCS_BLOCK * TCS_EDGE];
+    float bins[TCS_EM_NW][TCS_EM_ROWS * WAVE];
+};
+#ifndef NPR_TCS_EM_WAVES
+#define NPR_TCS_EM_WAVES 2
+#endif
+// a lane whose backward values outgrew 2^(TCS_TOP + this) inside a block (values entering it down a steep exponent gradient) would count its
+// transitions with forward factors scaled further down than fp32 holds exactly: the task is counted by k_em_tile instead
+constexpr int TCS_EM_BOOST = 40;
+#ifndef NPR_TCS_EM_DEAD
+#define NPR_TCS_EM_DEAD (-40)
+#endif
+constexpr int TCS_EM_DEAD = NPR_TCS_EM_DEAD;  // (k_em_tile's EM_SKIP: 2.7e8 terms of 2^-40 each are 2.4e-4 of a count)
 #ifndef NPR_TCS_WAVES
 #define NPR_TCS_WAVES 6
 #endif
 #ifndef NPR_TCS_T_SGPR
 #define NPR_TCS_T_SGPR 1
 #endif
-template <bool SW, bool FLAT>
-__global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_per_eu(NPR_TCS_WAVES))) k_dp_tile_cs(KernelArgs a) {
-    __shared__ CsLds L;
+// EM: the Baum-Welch E-step on the same sweeps (k_em_tile's job, npr_kernel_tile.hip; nanopore/analyses/utils.py:509-528): the forward sweep also keeps
+// the other four states of every cell, and the backward sweep, instead of emitting posteriors, adds the posterior of every transition into the cells of
+// an anti-diagonal to 15 per-lane accumulators and of every emitted symbol to per-lane bins in LDS.  In this arithmetic a forward row comes back from
+// memory scaled ONCE by 2^(eF + eB - eTot) of its lane and block, so a count is three multiplies and no exponent; cells outside the band are exact
+// zeros on both sides, so there is no mask and no branch in the counting.
+template <bool SW, bool FLAT, bool EM = false>
+__global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribute__((amdgpu_waves_per_eu(EM ? NPR_TCS_EM_WAVES : NPR_TCS_WAVES))) k_dp_tile_cs(KernelArgs a) {
+    constexpr int NWMAX = EM ? TCS_EM_NW : TCS_MAX_NW;
+    __shared__ CsLds<NWMAX> L;
+    float *lbins = nullptr, *stageF = nullptr;
+    if constexpr (EM) {
+        __shared__ CsEmLds LE;
+        lbins = LE.bins[uni(static_cast<int>(threadIdx.x) >> 6)], stageF = LE.stageF[uni(static_cast<int>(threadIdx.x) >> 6)];
+    }
     float *lmodel = L.model;
     int *lmisc = L.misc;
     int *prog = L.prog;
@@ -409,6 +451,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
     const int NW = static_cast<int>(blockDim.x) >> 6;
     float *const stage = L.stage[wv];
     char *const F = a.F + uni64(a.region[blockIdx.x]) * 8;
+    char *const Fx = EM ? reinterpret_cast<char *>(a.Fx) + uni64(a.region[blockIdx.x]) * 16 : nullptr;  // E-step: the other four states, 16 bytes per cell
     const int voff = 4 * R * lane;
     int jr[R];
 #pragma unroll
@@ -436,7 +479,9 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
             const float *gm = reinterpret_cast<const float *>(a.models + model);
             for (int i = threadIdx.x; i < MODEL_FLOATS; i += blockDim.x) lmodel[i] = gm[i];
             if (threadIdx.x == 0) lmisc[0] = 0, lmisc[1] = E_DEAD, lmisc[2] = 0, lmisc[3] = E_DEAD, lmisc[4] = 0, lmisc[6] = -(1 << 30);
-            if (threadIdx.x < TCS_MAX_NW) prog[threadIdx.x] = 0;
+            if (threadIdx.x < NWMAX) prog[threadIdx.x] = 0;
+            if constexpr (EM)
+                for (int i = 0; i < TCS_EM_ROWS; ++i) lbins[i * WAVE + lane] = 0.f;
         }
         __syncthreads();
         rs_build_tables(&L.tab, reinterpret_cast<const DevModel *>(lmodel), threadIdx.x, blockDim.x);
@@ -482,6 +527,7 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
             feed8_init<+1>(fy, E.Y, lY, st.df - st.X - 1, lane);
             cptr32 rm = rowmask + st.row0;  // the word of the row in hand is rm[0]
             const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc(F, st.row0, TCS_ROW_BYTES), rsE = stripe_rsrc(Ef, st.row0, 4 * TCS_EDGE);
+            const __amdgpu_buffer_rsrc_t rsX = EM ? stripe_rsrc(Fx, st.row0, TCS_XROW_BYTES) : rsF;
             const bool edge_lane = lane == st.K / R - 1;  // holds the stripe's last column in its top register
             // the left stripe's block of rows [16 kb, 16 kb + 15]: wait until it is out, stage it, its lane-63 exponents
             auto take_block = [&](int kb, int &e_in, int &eh_in) {
@@ -533,7 +579,14 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                     }
                     __builtin_amdgcn_raw_buffer_store_b64(v2i{Q.e, Q.eh}, rsF, k * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
                 }
-                tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
+                if constexpr (EM) {  // (the lanes that hold a band cell only: the E-step is bound by these bytes)
+                    if (lanes_of(mk.lanes)) {
+                        tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
+                        tcs_store_planes(rsX, 2 * voff + k * TCS_XROW_BYTES, io);
+                    }
+                } else {
+                    tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
+                }
                 if (edge_lane) tcs_store_edge_fwd(rsE, 4 * TCS_EDGE * k, io.c[R - 1], Q.umA, Q.e, Q.eh);
                 if ((d & (TCS_BLOCK - 1)) == TCS_BLOCK - 1 || d == st.dl) {
                     wait_vm();
@@ -560,16 +613,40 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 const int wv16 = static_cast<int>(a.rowmask[rowmask_off + st.row0 + static_cast<uint32_t>(d - st.df) + (lane & (TCS_BLOCK - 1))]);
 #pragma unroll 1
                 for (int i = 0; i < 7; ++i) {
-                    tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
-                    tcs_store_row(rsF, vo, Q.A);
+                    const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i));
+                    tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                    if constexpr (EM) {
+                        if (lanes_of(m0.lanes)) {
+                            tcs_store_row(rsF, vo, Q.A);
+                            tcs_store_planes(rsX, 2 * voff + 2 * (vo - voff), Q.A);  // (vo - voff: k rows of 1024 bytes; the planes' rows are 2048)
+                        }
+                    } else {
+                        tcs_store_row(rsF, vo, Q.A);
+                    }
                     if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
-                    tcs_fwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.umB, Q.umA, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1)), er + TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
-                    tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
+                    const Masks<R> m1 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1));
+                    tcs_fwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.umB, Q.umA, Q.c, m1, er + TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
+                    if constexpr (EM) {
+                        if (lanes_of(m1.lanes)) {
+                            tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
+                            tcs_store_planes(rsX, 2 * voff + 2 * (vo - voff) + TCS_XROW_BYTES, Q.B);
+                        }
+                    } else {
+                        tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
+                    }
                     if (edge_lane) tcs_store_edge_fwd(rsE, ve + 4 * TCS_EDGE, Q.B.c[R - 1], Q.umB, Q.e, Q.eh);
                     yi += 2, vo += 2 * TCS_ROW_BYTES, ve += 2 * 4 * TCS_EDGE, er += 2 * TCS_EDGE;
                 }
-                tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, row_masks(__builtin_amdgcn_readlane(wv16, 14)), er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
-                tcs_store_row(rsF, vo, Q.A);
+                const Masks<R> m14 = row_masks(__builtin_amdgcn_readlane(wv16, 14));
+                tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, m14, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
+                if constexpr (EM) {
+                    if (lanes_of(m14.lanes)) {
+                        tcs_store_row(rsF, vo, Q.A);
+                        tcs_store_planes(rsX, 2 * voff + 2 * (vo - voff), Q.A);
+                    }
+                } else {
+                    tcs_store_row(rsF, vo, Q.A);
+                }
                 if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
                 wait_vm();
                 if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + (d + 14 - st.df) + 1);
@@ -605,12 +682,20 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
         const bool alive = tot_m > 0.f;
         if (!alive) out.status = NPR_ERR_ZERO_PROB;
 
+        float em_acc[15];  // E-step: the expected transition counts of this lane's cells (k_em_tile's order)
+        int boost = 0;     // ... and how far its backward values outgrew 2^TCS_TOP inside a block
+#pragma unroll
+        for (int i = 0; i < 15; ++i) em_acc[i] = 0.f;
         // =============================== backward + posteriors ===============================
+#ifdef NPR_TCS_EM_EXP
+        if (alive && !(EM && NPR_TCS_EM_EXP == 1)) {
+#else
         if (alive) {
+#endif
             const float inv_tot = 1.0f / tot_m;
             const float thr_lo = a.threshold * tot_m * (1.0f - 1.0f / 1024.0f);
             const PairSink sink{a.px, a.py, a.pp, pair_off, pair_cap, xs, ys, a.threshold};
-            if (threadIdx.x < TCS_MAX_NW) prog[threadIdx.x] = 0x7fffffff;  // now: the LOWEST row whose neighbour cell is out
+            if (threadIdx.x < NWMAX) prog[threadIdx.x] = 0x7fffffff;  // now: the LOWEST row whose neighbour cell is out
             __syncthreads();
             int vsmax = -(1 << 30);
             int s_top = S - 1 - ((S - 1 - wv) % NW + NW) % NW;  // the last stripe of this wavefront (s == wv mod NW)
@@ -638,10 +723,34 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 for (int r = 0; r < R; ++r) fa.v[r] = fb.v[r] = 0.f;
                 cptr32 rm = rowmask + st.row0 + static_cast<uint32_t>(st.dl - st.df);  // the word of the row in hand is rm[0]
                 const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc(F, st.row0, TCS_ROW_BYTES), rsE = stripe_rsrc(Eb, st.row0, 4 * TCS_EDGE);
-                {
+                const __amdgpu_buffer_rsrc_t rsX = EM ? stripe_rsrc(Fx, st.row0, TCS_XROW_BYTES) : rsF;
+                if constexpr (!EM) {
                     const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (st.dl - st.df) * TCS_ROW_BYTES, 0, 0);
                     RFRow<R> &f0 = (st.dl & 1) ? fa : fb;
                     f0.v[0] = bitsf(q.x), f0.v[1] = bitsf(q.y);
+                }
+                // ---- E-step: the left stripe (its forward records feed lane 0's counts), the symbols emitted INTO every slot's cell, the bins' rows ----
+                int dfL = 1, dlL = 0;
+                uint32_t row0L = 0;
+                Bases<R> bxm, bym;
+                Feed fym;
+                int binx[R];     // byte offset of the match bins' row of X[x-1] + this lane's column; N: the scratch zone
+                float xbs[R], xbl[R];  // this stripe's counts of X[x-1] emitted by shortGapX / longGapX into the slot's column: one base per slot, so registers
+#pragma unroll
+                for (int r = 0; r < R; ++r) xbs[r] = xbl[r] = 0.f;
+                if constexpr (EM) {
+                    if (s > 0) {
+                        const UStripe sl = load_stripe(tab, s - 1);
+                        dfL = sl.df, dlL = sl.dl, row0L = sl.row0;
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int xi = X0 + jr[r] - 1;
+                        bxm.b[r] = base8<RS_XS>(E.X, lX, xi);
+                        bym.b[r] = base8(E.Y, lY, (st.dl + 1) - X0 - jr[r] - 1);
+                        binx[r] = (bxm.b[r] >= RS_NX ? EM_BINS * 256 : base8<1024>(E.X, lX, xi)) + 4 * lane;  // (N, or no base: the scratch zone)
+                    }
+                    feed8_init<-1>(fym, E.Y, lY, st.dl - X0 - (K - 1) - 1, lane);
                 }
                 // the right stripe's block of rows [16 kb, 16 kb + 15]
                 auto take_block = [&](int kb, int &e_in, int &eh_in) {
@@ -660,12 +769,86 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 // powers of two: F * B is still rounded once, as npr_rs.h's rs_posterior rounds it.)
                 float G1 = 0.f, G2 = 0.f;
                 CsState Q;
-                auto enter_block = [&](int d) {
+                // E-step: the forward exponents of the block that holds row d (kbCur) and of the one below it: the rows d - 1 .. d - 3 lie in one of the two
+                int kbCur = 0, efCur = TCS_NONE, efPrev = TCS_NONE;
+                bool cnt_on = true;
+                float cb = 1.f;  // 2^(e - e of the lane below): what the lane below's scaled forward cells are multiplied by on their way up
+                auto enter_block = [&](int d) __attribute__((always_inline)) {
                     const int kf = max(d & ~(TCS_BLOCK - 1), st.df) - st.df;
                     const v2i x = __builtin_amdgcn_raw_buffer_load_b64(rsF, kf * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
-                    const int sx = x.x + Q.e - tot_e;
-                    G1 = tcs_pow2(sx >> 1), G2 = tcs_pow2(sx - (sx >> 1));
+                    if constexpr (EM) {
+                        kbCur = d >> 4;
+                        efCur = x.x, efPrev = TCS_NONE;
+                        int ehF = x.y;  // the bound on the forward values the rows d - 1, d - 2 of this block's rows can hold: the two blocks', and the lane below's
+                        const int below = kbCur * TCS_BLOCK - 1;  // the highest row of the block below
+                        if (below >= st.df) {
+                            const v2i y = __builtin_amdgcn_raw_buffer_load_b64(rsF, (max(below & ~(TCS_BLOCK - 1), st.df) - st.df) * TCS_ROW_BYTES + TCS_EXP_AT + 8 * lane, 0, 0);
+                            efPrev = y.x, ehF = max(ehF, y.y);
+                        }
+                        ehF = max(ehF, dpp_from_below(ehF, ehF));
+                        cb = tcs_pow2(Q.e - dpp_from_below(Q.e, Q.e));
+                        // A block in which no lane's F B / total can reach 2^TCS_EM_DEAD (values are below 2^(TCS_TOP + 6) in units of their bound) adds nothing a
+                        // count can see: its rows are not counted -- where the band crosses a stripe ahead of or behind the alignment, two rows in five.
+                        // (+ TCS_C: lane 0 takes the left stripe's last column, whose exponents the chain keeps within TCS_C of its own)
+                        cnt_on = __ballot(ehF + TCS_C + Q.eh - tot_e + 2 * (TCS_TOP + 6) + 1 > TCS_EM_DEAD) != 0;
+                    } else {
+                        const int sx = x.x + Q.e - tot_e;
+                        G1 = tcs_pow2(sx >> 1), G2 = tcs_pow2(sx - (sx >> 1));
+                    }
                     vsmax = max(vsmax, x.y + Q.eh - tot_e);
+                };
+                // E-step: the forward rows d - 1 and d - 2 in this lane's posterior units -- F 2^(eF + eB - eTot) --, the lane below's top cell of
+                // each (GAb, GBb; lane 0: the left stripe's last column) in the same units, and the row d - 3 in flight as loaded
+                // (odd d: row d - 1 in GA, row d - 2 in GB; even d: the other way round -- the row that arrives takes the registers of the one that leaves)
+                RDiag<R> GA = zero_rdiag<R>(), GB = zero_rdiag<R>();
+                RCell GAb = zero_rcell(), GBb = zero_rcell();
+                struct EmRow {
+                    v2i f;
+                    v4i x0, x1;
+                };
+                EmRow S0{v2i{0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}, S1 = S0;  // two rows in flight: an even row lands in S0, an odd one in S1
+                int kbF = -(1 << 30);  // the block of the left stripe's forward records in stageF
+                // issue the loads of a row (zeros outside the stripe's rows and in the lanes that hold no band cell: those were not stored); w: the row's mask word
+                auto em_fetch_w = [&](int row, uint32_t w, EmRow &S) __attribute__((always_inline)) {
+                    S.f = v2i{0, 0}, S.x0 = v4i{0, 0, 0, 0}, S.x1 = v4i{0, 0, 0, 0};
+                    if (row >= st.df && row <= st.dl) {  // uniform
+                        const int k = row - st.df;
+#ifdef NPR_TCS_EM_EXP
+                        if (NPR_TCS_EM_EXP != 2)
+#endif
+                        if (lanes_of(row_masks(w).lanes)) {
+                            S.f = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + k * TCS_ROW_BYTES, 0, 0);
+                            S.x0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, 2 * voff + k * TCS_XROW_BYTES, 0, 0);
+                            S.x1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, 2 * voff + k * TCS_XROW_BYTES + 1024, 0, 0);
+                        }
+                    }
+                };
+                auto em_fetch = [&](int row, EmRow &S) __attribute__((always_inline)) {  // ... the word by a scalar load (the general step, the stripe's first rows)
+                    const int k = min(max(row - st.df, 0), st.dl - st.df);
+                    em_fetch_w(row, rowmask[st.row0 + static_cast<uint32_t>(k)], S);
+                };
+                auto em_scaled = [&](int row, const EmRow &S) __attribute__((always_inline)) -> RDiag<R> {  // a fetched row in this lane's posterior units
+                    const int sF = min(max(((row >> 4) == kbCur ? efCur : efPrev) + Q.e - tot_e, -300), 300);
+                    RDiag<R> G;
+                    G.c[0] = RCell{__builtin_ldexpf(bitsf(S.f.x), sF), __builtin_ldexpf(bitsf(S.x0.x), sF), __builtin_ldexpf(bitsf(S.x0.y), sF), __builtin_ldexpf(bitsf(S.x0.z), sF), __builtin_ldexpf(bitsf(S.x0.w), sF)};
+                    G.c[1] = RCell{__builtin_ldexpf(bitsf(S.f.y), sF), __builtin_ldexpf(bitsf(S.x1.x), sF), __builtin_ldexpf(bitsf(S.x1.y), sF), __builtin_ldexpf(bitsf(S.x1.z), sF), __builtin_ldexpf(bitsf(S.x1.w), sF)};
+                    return G;
+                };
+                auto em_left = [&](int row) __attribute__((always_inline)) -> RCell {  // the left stripe's last column on `row`, in the posterior units of the lane that asks (lane 0 uses it)
+                    if ((row >> 4) != kbF) {  // uniform: once per sixteen rows
+                        kbF = row >> 4;
+                        const int first = kbF * TCS_BLOCK;
+                        (void)tcs_edge_stage(Ef, row0L, dfL, first, max(first, dfL), min(first + TCS_BLOCK - 1, dlL), stageF, lane);
+                    }
+                    const float *rec = stageF + TCS_EDGE * (row & (TCS_BLOCK - 1));
+                    const float4 q = *reinterpret_cast<const float4 *>(rec), g = *reinterpret_cast<const float4 *>(rec + 4);
+                    const int sF = min(max(fbits(g.y) + Q.e - tot_e, -300), 300);
+                    return RCell{__builtin_ldexpf(q.y, sF), __builtin_ldexpf(q.z, sF), __builtin_ldexpf(g.x, sF), __builtin_ldexpf(q.w, sF), __builtin_ldexpf(g.w, sF)};
+                };
+                auto em_take = [&](int row, const EmRow &S, RDiag<R> &G, RCell &Gbelow) __attribute__((always_inline)) {  // a fetched row, and the lane below's top cell of it in this lane's units (lane 0: cb = 1)
+                    G = em_scaled(row, S);
+                    Gbelow = dpp_rcell_from_below(G.c[R - 1], em_left(row));
+                    rcell_scale(Gbelow, cb);
                 };
                 {
                     int e_in, eh_in;
@@ -682,7 +865,67 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         if (lane == WAVE - 1) Q.carry = __builtin_ldexpf(bitsf(q.x), g.y - Q.e);  // (the record's m, in this lane's units)
                     }
                     enter_block(st.dl);
+                    if constexpr (EM) {
+                        const int ra = (st.dl & 1) ? st.dl - 1 : st.dl - 2;  // (GA holds the row of an even anti-diagonal, GB of an odd one)
+                        em_fetch(ra, S0);
+                        em_take(ra, S0, GA, GAb);
+                        em_fetch(2 * st.dl - 3 - ra, S1);  // (the odd one of dl - 1, dl - 2)
+                        em_take(2 * st.dl - 3 - ra, S1, GB, GBb);
+                        if (st.dl & 1) em_fetch(st.dl - 3, S0);  // the row the first step takes: fetched two steps ahead from here on
+                        else em_fetch(st.dl - 3, S1);
+                    }
                 }
+                // E-step: the expected counts of the transitions into the cells of anti-diagonal d (k_em_tile's tile_em_cells, in this arithmetic)
+                // P1 / P1b: row d - 1 and its lane-below cell, P2 / P2b: row d - 2's.  An accumulator adds up F' * w of its transition (the transition itself
+                // multiplies the sum once, at the end of the task); a bin gets w * (the recurrence's sum over the states the symbol can be emitted from).
+                auto em_count = [&](const RDiag<R> &io, const RDiag<R> &P1, const RCell &P1b, const RDiag<R> &P2, const RCell &P2b) __attribute__((always_inline)) {
+                    float em[R], exs[R], exl[R], eys[R], eyl[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) rs_cell_emissions<4, FLAT>(E.ltab, ~0ull, bxm.b[r], bym.b[r], em[r], exs[r], exl[r], eys[r], eyl[r]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const RCell &c = io.c[r];
+                        const RCell &Pm = r ? P2.c[r - 1] : P2b, &Pl = r ? P1.c[r - 1] : P1b, &Pu = P1.c[r];
+                        const Trans &t = E.tr;
+                        float bM, bYs, bYl;
+                        {
+                            const float w = em[r] * c.m * inv_tot;
+                            em_acc[0] = __builtin_fmaf(Pm.m, w, em_acc[0]), em_acc[1] = __builtin_fmaf(Pm.sx, w, em_acc[1]), em_acc[2] = __builtin_fmaf(Pm.sy, w, em_acc[2]);
+                            em_acc[3] = __builtin_fmaf(Pm.lx, w, em_acc[3]), em_acc[4] = __builtin_fmaf(Pm.ly, w, em_acc[4]);
+                            bM = tcs_into_match(t, Pm) * w;
+                        }
+                        {
+                            const float ws = exs[r] * c.sx * inv_tot, wl = exl[r] * c.lx * inv_tot;
+                            em_acc[5] = __builtin_fmaf(Pl.m, ws, em_acc[5]), em_acc[6] = __builtin_fmaf(Pl.sx, ws, em_acc[6]);
+                            em_acc[8] = __builtin_fmaf(Pl.m, wl, em_acc[8]), em_acc[9] = __builtin_fmaf(Pl.lx, wl, em_acc[9]);
+                            float as = __builtin_fmaf(t.sxsx, Pl.sx, t.msx * Pl.m);
+                            if constexpr (SW) em_acc[7] = __builtin_fmaf(Pl.sy, ws, em_acc[7]), as = __builtin_fmaf(t.sysx, Pl.sy, as);
+                            xbs[r] = __builtin_fmaf(as, ws, xbs[r]);
+                            xbl[r] = __builtin_fmaf(__builtin_fmaf(t.lxlx, Pl.lx, t.mlx * Pl.m), wl, xbl[r]);
+                        }
+                        {
+                            const float ws = eys[r] * c.sy * inv_tot, wl = eyl[r] * c.ly * inv_tot;
+                            em_acc[10] = __builtin_fmaf(Pu.m, ws, em_acc[10]), em_acc[11] = __builtin_fmaf(Pu.sy, ws, em_acc[11]);
+                            em_acc[13] = __builtin_fmaf(Pu.m, wl, em_acc[13]), em_acc[14] = __builtin_fmaf(Pu.ly, wl, em_acc[14]);
+                            float as = __builtin_fmaf(t.sysy, Pu.sy, t.msy * Pu.m);
+                            if constexpr (SW) em_acc[12] = __builtin_fmaf(Pu.sx, ws, em_acc[12]), as = __builtin_fmaf(t.sxsy, Pu.sx, as);
+                            bYs = as * ws;
+                            bYl = __builtin_fmaf(t.lyly, Pu.ly, t.mly * Pu.m) * wl;
+                        }
+                        // the bins the read's base decides (k_em_tile's layout; the long-gap bin 4 rows after the short-gap one): reads, then writes
+                        constexpr int TRASH = EM_BINS * 256;
+                        const int ey4 = bym.b[r];  // (the read's codes come scaled by 4: RS_YS; 16: N)
+                        const bool ny = ey4 >= 16;
+                        const int aM = (ny ? TRASH : ey4 * 64) + binx[r];  // (binx of an N: beyond every bin row, so the sum is clamped into the scratch zone)
+                        const int aMc = min(aM, TRASH + 4 * lane);
+                        const int aY = (ny ? TRASH : 24 * 256 + ey4 * 64) + 4 * lane;
+                        char *const lb = reinterpret_cast<char *>(lbins);
+                        const float v0 = *reinterpret_cast<float *>(lb + aMc), v3 = *reinterpret_cast<float *>(lb + aY), v4 = *reinterpret_cast<float *>(lb + aY + 1024);
+                        *reinterpret_cast<float *>(lb + aMc) = v0 + bM;
+                        *reinterpret_cast<float *>(lb + aY) = v3 + bYs;
+                        *reinterpret_cast<float *>(lb + aY + 1024) = v4 + bYl;
+                    }
+                };
                 // posteriors of anti-diagonal d, slots claimed from the workgroup's LDS counter
                 auto emit = [&](int d, const RDiag<R> &io, const RFRow<R> &f, const Masks<R> &mk) {
                     float q[R];
@@ -726,13 +969,19 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 };
 
                 // any row.  f: the forward row of d (loaded a step ago); fnext: where the row of d-1 goes
-                auto step = [&](int d, RDiag<R> &io, const RDiag<R> &s1, RFRow<R> &f, RFRow<R> &fnext) {
+                auto step = [&](int d, RDiag<R> &io, const RDiag<R> &s1, RFRow<R> &f, RFRow<R> &fnext, RDiag<R> &P1, RCell &P1b, const RDiag<R> &P2, const RCell &P2b) __attribute__((always_inline)) {
                     const int k = d - st.df;
                     const Masks<R> mk = row_masks(rm[0]);
                     if (d > st.df) {
                         rm -= 1;
-                        const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (k - 1) * TCS_ROW_BYTES, 0, 0);
-                        fnext.v[0] = bitsf(q.x), fnext.v[1] = bitsf(q.y);
+                        if constexpr (!EM) {
+                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (k - 1) * TCS_ROW_BYTES, 0, 0);
+                            fnext.v[0] = bitsf(q.x), fnext.v[1] = bitsf(q.y);
+                        }
+                    }
+                    if constexpr (EM) {
+                        em_fetch(d - 4, S1);  // (d is odd here: taken at the end of the NEXT step -- two rows in flight)
+                        bases_up<R>(bym, feed8_get<-1>(fym, E.Y, lY, d - X0 - (K - 1) - 1, lane));
                     }
                     tcs_bwd_core<SW, FLAT>(E, io, s1, Q.carry, Q.c, mk, stage + TCS_EDGE * ((d + 1) & (TCS_BLOCK - 1)), bx, by, feed8_get<-1>(fy, E.Y, lY, d - X0 - (K - 1), lane));
                     if (d == D) {  // the end corner (lX, lY)
@@ -748,12 +997,25 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         if (d > st.df) {
                             int e_in, eh_in;
                             take_block(d >> 4, e_in, eh_in);
-                            tcs_renorm<false>(Q, lane, e_in, eh_in, dslot);
+                            const int e_was = Q.e;
+                            const int eb = tcs_renorm<false>(Q, lane, e_in, eh_in, dslot);
+                            if constexpr (EM) {  // the held forward rows are in units of 2^(eF + eB - eTot): eB has moved
+                                boost = max(boost, eb - (126 + TCS_TOP));
+                                const float gf = tcs_pow2(Q.e - e_was);
+#pragma unroll
+                                for (int r = 0; r < R; ++r) rcell_scale(GA.c[r], gf), rcell_scale(GB.c[r], gf);
+                                rcell_scale(GAb, gf), rcell_scale(GBb, gf);
+                            }
                         }
                         enter_block(d);
                     }
                     if (lane == 0) tcs_store_edge_bwd(rsE, 4 * TCS_EDGE * k, io.c[0], Q.e, Q.eh);  // holds the stripe's first column in its register 0
-                    emit(d, io, f, mk);
+                    if constexpr (EM) {
+                        if (cnt_on) em_count(io, P1, P1b, P2, P2b);
+                        em_take(d - 3, S0, P1, P1b);  // (into the registers of the row that leaves)
+                    } else {
+                        emit(d, io, f, mk);
+                    }
                     if ((d & (TCS_BLOCK - 1)) == 0 || d == st.df) {
                         wait_vm();
                         if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + k);
@@ -764,9 +1026,23 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                         tcs_swap_rows(Q.A, Q.B);
                         const RFRow<R> t = fa;
                         fa = fb, fb = t;
+                        if constexpr (EM) {  // (the held rows and the rows in flight follow the parity too)
+                            tcs_swap_rows(GA, GB);
+                            const RCell u = GAb;
+                            GAb = GBb, GBb = u;
+                            const EmRow v = S0;
+                            S0 = S1, S1 = v;
+                        }
                     }
-                    step(d, Q.A, Q.B, fa, fb);
+                    step(d, Q.A, Q.B, fa, fb, GA, GAb, GB, GBb);
                     if (!(d & 1)) {
+                        if constexpr (EM) {
+                            tcs_swap_rows(GA, GB);
+                            const RCell u = GAb;
+                            GAb = GBb, GBb = u;
+                            const EmRow v = S0;
+                            S0 = S1, S1 = v;
+                        }
                         tcs_swap_rows(Q.A, Q.B);
                         const RFRow<R> t = fa;
                         fa = fb, fb = t;
@@ -782,44 +1058,75 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                     int vo = voff + (d - 1 - st.df) * TCS_ROW_BYTES, ve = 4 * TCS_EDGE * (d - st.df);  // vo: the row loaded ahead, d - 1
                     const float *er = stage + TCS_EDGE * (TCS_BLOCK - 1);  // record (d + 1) & 15 = 15
                     // the mask words of rows d .. d - 15: lane i (mod 16) holds row d - i's
-                    const int wv16 = static_cast<int>(a.rowmask[rowmask_off + st.row0 + static_cast<uint32_t>(d - st.df) - (lane & (TCS_BLOCK - 1))]);
+                    // (E-step: of rows d .. d - 31, lane i mod 32 -- the rows d - 3 .. d - 17 it loads are masked by theirs; below the stripe's first row: unused)
+                    const int wv16 = static_cast<int>(a.rowmask[rowmask_off + st.row0 + static_cast<uint32_t>(max(d - st.df - (lane & (EM ? 2 * TCS_BLOCK - 1 : TCS_BLOCK - 1)), 0))]);
 #pragma unroll 1
                     for (int i = 0; i < 7; ++i) {
-                        {
+                        if constexpr (EM) {  // (the symbols emitted into the cells: the read's bases one step further along the window)
+                            em_fetch_w(d - 2 * i - 4, __builtin_amdgcn_readlane(wv16, 2 * i + 4), S0);
+                            bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 1));
+                        } else {
                             const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
                             fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
                         }
                         const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i));
                         tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
                         if (lane == 0) tcs_store_edge_bwd(rsE, ve, Q.B.c[0], Q.e, Q.eh);
-                        emit(d - 2 * i, Q.B, fb, m0);
-                        {
+                        if constexpr (EM) {
+                            if (cnt_on) em_count(Q.B, GB, GBb, GA, GAb);
+                            em_take(d - 2 * i - 3, S1, GB, GBb);
+                            em_fetch_w(d - 2 * i - 5, __builtin_amdgcn_readlane(wv16, 2 * i + 5), S1);
+                            bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 2));
+                        } else {
+                            emit(d - 2 * i, Q.B, fb, m0);
                             const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo - TCS_ROW_BYTES, 0, 0);
                             fb.v[0] = bitsf(q.x), fb.v[1] = bitsf(q.y);
                         }
                         const Masks<R> m1 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1));
                         tcs_bwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, m1, er - TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
                         if (lane == 0) tcs_store_edge_bwd(rsE, ve - 4 * TCS_EDGE, Q.A.c[0], Q.e, Q.eh);
-                        emit(d - 2 * i - 1, Q.A, fa, m1);
+                        if constexpr (EM) {
+                            if (cnt_on) em_count(Q.A, GA, GAb, GB, GBb);
+                            em_take(d - 2 * i - 4, S0, GA, GAb);
+                        } else {
+                            emit(d - 2 * i - 1, Q.A, fa, m1);
+                        }
                         yi += 2, vo -= 2 * TCS_ROW_BYTES, ve -= 2 * 4 * TCS_EDGE, er -= 2 * TCS_EDGE;
                     }
                     {
-                        {
+                        if constexpr (EM) {
+                            em_fetch_w(d - 18, __builtin_amdgcn_readlane(wv16, 18), S0);
+                            bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 1));
+                        } else {
                             const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
                             fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
                         }
                         const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 14));
                         tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
                         if (lane == 0) tcs_store_edge_bwd(rsE, ve, Q.B.c[0], Q.e, Q.eh);
-                        emit(d - 14, Q.B, fb, m0);
+                        if constexpr (EM) {
+                            if (cnt_on) em_count(Q.B, GB, GBb, GA, GAb);
+                            em_take(d - 17, S1, GB, GBb);
+                        } else {
+                            emit(d - 14, Q.B, fb, m0);
+                        }
                         wait_vm();
                         if (lane == 0) lds_poke(prog + wv, static_cast<int>(st.row0) + (d - 14 - st.df));
                     }
                     rm -= TCS_BLOCK - 1;
                     d -= TCS_BLOCK - 1;
+                    if constexpr (EM) feed8_init<-1>(fym, E.Y, lY, d - X0 - (K - 1) - 1, lane);  // (the general step's own window of those bases, where the block left off)
                     }
                     gstep(d);
                     --d;
+                }
+                if constexpr (EM) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {  // this stripe's gap-X emission counts into the bins of its slots' bases (binx: the match row of the base, 4 bins wide)
+                        float *const at = reinterpret_cast<float *>(reinterpret_cast<char *>(lbins) + (binx[r] - 4 * lane >= EM_BINS * 256 ? EM_BINS * 256 : 16 * 256 + ((binx[r] - 4 * lane) >> 2)) + 4 * lane);
+                        at[0] += xbs[r];
+                        at[256] += xbl[r];
+                    }
                 }
                 if (s == 0) {  // total from the backward side: the lattice point (0, 0) is the stripe's first slot on d = 0
 #pragma unroll
@@ -837,12 +1144,33 @@ __global__ void __launch_bounds__(WAVE *TCS_MAX_NW) __attribute__((amdgpu_waves_
                 }
             }
             atomicMax(lmisc + 6, vsmax);
+            if constexpr (EM)
+                if (boost > TCS_EM_BOOST) atomicMax(lmisc + 6, (1 << 29) + boost);
             __syncthreads();
             out.btot_m = unif(reinterpret_cast<float *>(lmisc)[2]);
             out.btot_e = uni(lmisc[3]);
         }
         if (stuck) atomicMax(lmisc + 6, 1 << 30);
         __syncthreads();
+        if constexpr (EM) {
+            // The counts of a task leave the workgroup only when its certificate holds (else k_em_tile counts the task: TASK_RERUN): every wavefront
+            // adds up its own bins, then its transition accumulators through the same rows (k_em_tile's reduction).
+            if (alive && uni(lmisc[6]) < TCS_S_LIMIT) {
+                if (lane < EM_BINS) {
+                    double sum = 0.0;
+                    for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
+                    atomicAdd(a.em_E + model * EM_BINS + lane, sum);
+                }
+#pragma unroll
+                for (int i = 0; i < 15; ++i) lbins[i * WAVE + lane] = em_acc[i];  // (sums of F' * w: the transition multiplies below)
+                if (lane < 15) {
+                    double sum = 0.0;
+                    for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
+                    const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
+                    atomicAdd(a.em_T + model * 25 + map[lane], sum * static_cast<double>(mdl->T[map[lane]]));
+                }
+            }
+        }
         if (threadIdx.x == 0) {
             const int cnt = lmisc[4];
             out.npairs = cnt;
@@ -866,6 +1194,26 @@ int launch_tile_cs(const KernelArgs &a, int NW, int grid, void *stream, bool sw,
     if (sw) hipLaunchKernelGGL((k_dp_tile_cs<true, false>), dim3(grid), dim3(WAVE * NW), 0, s, a);
     else if (flat) hipLaunchKernelGGL((k_dp_tile_cs<false, true>), dim3(grid), dim3(WAVE * NW), 0, s, a);
     else hipLaunchKernelGGL((k_dp_tile_cs<false, false>), dim3(grid), dim3(WAVE * NW), 0, s, a);
+    return static_cast<int>(hipGetLastError());
+}
+
+
+// k_dp_tile_cs<.., EM>: the E-step on the same stripes (static LDS; TCS_EM_NW wavefronts per task at most)
+int em_tile_cs_waves() {  // wavefronts per task (NPR_EM_CS_WAVES: bring-up)
+    const char *e = std::getenv("NPR_EM_CS_WAVES");
+    const int n = e ? std::atoi(e) : TCS_EM_NW;
+    return n >= 1 && n <= TCS_EM_NW ? n : TCS_EM_NW;
+}
+int em_tile_cs_waves_per_cu() {  // what the registers (NPR_TCS_EM_WAVES per SIMD) and the workgroups' static LDS leave room for
+    const int by_lds = static_cast<int>((160 * 1024) / (sizeof(CsLds<TCS_EM_NW>) + sizeof(CsEmLds))) * em_tile_cs_waves();
+    return std::min(4 * NPR_TCS_EM_WAVES, by_lds);
+}
+int launch_em_tile_cs(const KernelArgs &a, int NW, int grid, void *stream, bool sw, bool flat) {
+    if (NW < 1 || NW > TCS_EM_NW) return static_cast<int>(hipErrorInvalidValue);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sw) hipLaunchKernelGGL((k_dp_tile_cs<true, false, true>), dim3(grid), dim3(WAVE * NW), 0, s, a);
+    else if (flat) hipLaunchKernelGGL((k_dp_tile_cs<false, true, true>), dim3(grid), dim3(WAVE * NW), 0, s, a);
+    else hipLaunchKernelGGL((k_dp_tile_cs<false, false, true>), dim3(grid), dim3(WAVE * NW), 0, s, a);
     return static_cast<int>(hipGetLastError());
 }
 

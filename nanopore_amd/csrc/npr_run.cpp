@@ -56,7 +56,9 @@ int32_t npr_batch_run(npr_batch *b, float *kernel_ms) {
     std::vector<const npr_batch::Launch *> order;
     for (const auto &L : b->launches) order.push_back(&L);
     std::sort(order.begin(), order.end(), [](const npr_batch::Launch *x, const npr_batch::Launch *y) { return x->cells < y->cells; });
-    if (b->pair_rs)  // (staged for the row-scaled kernels under the models of that moment)
+    bool scaled = b->pair_rs;  // (staged for the row- / column-scaled kernels under the models of that moment)
+    for (const auto &L : b->launches) scaled |= kClassTab[L.cls].kind == K_TILE_RS;
+    if (scaled)
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
             if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl]))
                 return fail(ctx, NPR_ERR_MODEL, "npr_batch_run: a model loaded after the batch was staged grows faster than the row-scaled kernels allow: stage the batch again");
@@ -206,6 +208,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         int stair_R;  // > 0: the register-kernel E-step (k_em_stair<R>), else the generic kernel
         int wide_NW;  // > 0: stair_R slots per lane on wide_NW wavefronts per task (k_dp_wide<R, NW, EM>)
         bool tile;    // the stripe-kernel E-step (k_em_tile<stair_R>): scratch regions per workgroup, as in the DP launch
+        bool tile_cs;  // ... in column-scaled arithmetic first (k_dp_tile_cs<.., EM>); what its certificate refuses goes to k_em_tile
         int slot_base;    // first uniform forward-scratch region: the one its class had in the DP launch (the classes run concurrently)
         int dp_grid;      // ... and how many of them that launch owned
         int64_t cells;
@@ -233,7 +236,9 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
             // launch gave them (region i is sized for task i, and everything the queue hands out later is smaller)
             l.stair_R = 2, l.tile = true;
             l.lds = em_tile_lds_bytes(em_tile_waves());
-            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(l.count, dl.grid), static_cast<int64_t>(ctx->cu_count) * (em_tile_waves_per_cu() / em_tile_waves()))));
+            l.tile_cs = kClassTab[dl.cls].kind == K_TILE_RS && ctx->opt[NPR_OPT_TILE_RS] != 2 && ctx->opt[NPR_OPT_EM_TILE] != 1;
+            const int per_cu = l.tile_cs ? em_tile_cs_waves_per_cu() / em_tile_cs_waves() : em_tile_waves_per_cu() / em_tile_waves();
+            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(l.count, dl.grid), static_cast<int64_t>(ctx->cu_count) * per_cu)));
             launches.push_back(l);
             continue;
         }
@@ -318,6 +323,14 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     for (const auto &l : launches) order.push_back(&l);
     std::stable_sort(order.begin(), order.end(), [](const L *x, const L *y) { return x->cells < y->cells; });
     const bool serial = ctx->opt[NPR_OPT_EM_SERIAL] != 0;  // A/B switch: one launch after the other, as before round 3
+    bool sw = false;  // (as npr_batch_run: the column-scaled kernel leaves out the short-gap switch terms no loaded model has)
+    for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
+        if (ctx->model_set[sl] && (ctx->models[sl].T[1 * 5 + 2] != 0.f || ctx->models[sl].T[2 * 5 + 1] != 0.f)) sw = true;
+    const bool flat = !sw && flat_gap_emissions(ctx);
+    for (auto &l : launches)
+        if (l.tile_cs)
+            for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
+                if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) l.tile_cs = false;
     for (size_t i = 0; i < order.size(); ++i) {
         const L &l = *order[i];
         const bool last = serial || i + 1 == order.size();
@@ -336,7 +349,8 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         a.Fx = ctx->arena_Fx + l.fx_off;
         a.em_T = d_T.p;
         a.em_E = d_E.p;
-        const int rc = l.tile      ? launch_em_tile(a, l.stair_R, l.grid, st)
+        const int rc = l.tile_cs   ? launch_em_tile_cs(a, em_tile_cs_waves(), l.grid, st, sw, flat)
+                       : l.tile    ? launch_em_tile(a, l.stair_R, l.grid, st)
                        : l.wide_NW ? launch_em_wide(a, l.stair_R, l.wide_NW, l.grid, st)
                        : l.stair_R ? launch_em_stair(a, l.stair_R, l.grid, st)
                                    : launch_em(a, l.grid, l.lds, l.global_ring, st);
@@ -348,10 +362,50 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (kernel_ms) HIP_TRY(ctx, hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    b->outs.resize(b->tasks.size());
+    HIP_TRY(ctx, hipMemcpy(b->outs.data(), b->d_outs.p, b->d_outs.bytes(), hipMemcpyDeviceToHost));
+    // The tasks the column-scaled kernel did not count (TASK_RERUN: its range certificate, or backward values far above a lane's scale) are counted
+    // here by k_em_tile, on the scratch regions and planes the first launch had, into the same sums.
+    for (size_t i = 0; i < order.size(); ++i) {
+        const L &l = *order[i];
+        if (!l.tile_cs) continue;
+        std::vector<int32_t> again;
+        for (int k = l.first; k < l.first + l.count; ++k)
+            if (b->outs[k].status == TASK_RERUN) again.push_back(k);
+        if (std::getenv("NPR_TIMING")) std::fprintf(stderr, "[npr] E-step: %zu of %d stripe tasks counted again with a per-cell exponent\n", again.size(), l.count);
+        if (again.empty()) continue;
+        std::vector<Task> sub(again.size());
+        for (size_t j = 0; j < again.size(); ++j) sub[j] = b->tasks[again[j]];
+        DevBuf<Task> d_sub;
+        DevBuf<TaskOut> d_subout;
+        if (d_sub.alloc(sub.size()) != hipSuccess || d_subout.alloc(sub.size()) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc");
+        HIP_TRY(ctx, hipMemcpy(d_sub.p, sub.data(), sizeof(Task) * sub.size(), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p + static_cast<int>(i), 0, sizeof(int32_t), ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        KernelArgs a = make_args(b);
+        a.tasks = d_sub.p, a.outs = d_subout.p, a.ntasks = static_cast<int32_t>(sub.size());
+        a.queue += static_cast<int>(i);
+        a.slot_base = l.slot_base;
+        a.region = l.region_first >= 0 ? b->d_region.p + l.region_first : nullptr;  // (task j of `again` is no larger than the j-th task of the class)
+        a.Fx = ctx->arena_Fx + l.fx_off;
+        a.em_T = d_T.p, a.em_E = d_E.p;
+        const int grid = static_cast<int>(std::min<size_t>(sub.size(), static_cast<size_t>(l.grid)));
+        const int rc = launch_em_tile(a, l.stair_R, grid, ctx->stream);
+        if (rc != 0) return fail(ctx, NPR_ERR_HIP, "E-step kernel launch (second pass)", static_cast<hipError_t>(rc));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (kernel_ms) {
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            *kernel_ms += ms;
+        }
+        std::vector<TaskOut> subout(sub.size());
+        HIP_TRY(ctx, hipMemcpy(subout.data(), d_subout.p, sizeof(TaskOut) * sub.size(), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < again.size(); ++j) b->outs[again[j]] = subout[j];
+    }
     std::vector<double> hE(NPR_MAX_MODELS * EM_BINS);
     HIP_TRY(ctx, hipMemcpy(T_exp, d_T.p, d_T.bytes(), hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(hE.data(), d_E.p, d_E.bytes(), hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(b->outs.data(), b->d_outs.p, b->d_outs.bytes(), hipMemcpyDeviceToHost));
     for (int m = 0; m < NPR_MAX_MODELS; ++m) {
         const double *s = hE.data() + m * EM_BINS;
         double *d = E_exp + m * 80;

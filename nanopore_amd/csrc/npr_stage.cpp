@@ -247,6 +247,12 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     const bool no_wide = ctx->opt[NPR_OPT_NO_WIDE] != 0;  // no multi-wavefront register kernel (A/B runs, tests)
     const int cmin = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(kSchedClasses, ctx->opt[NPR_OPT_CLASS_MIN])));  // bring-up: smallest register class to use
     const bool use_tile = !force_generic && ctx->opt[NPR_OPT_NO_TILE] == 0;  // (E-step batches too: k_em_tile)
+    // E-step batches whose stripe tasks run in column-scaled arithmetic (k_dp_tile_cs's E-step instance, below): the four-slot frame class goes there
+    // too -- k_em_stair<4> is one long dependent chain per task
+    bool em_stripes_cs = b->params.mode == NPR_MODE_EXPECTATIONS && use_tile && ctx->opt[NPR_OPT_ARITH] != 1 && ctx->opt[NPR_OPT_EM_TILE] != 1 &&
+                         ctx->opt[NPR_OPT_TILE_RS] != 2;
+    for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
+        if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) em_stripes_cs = false;
     std::vector<uint32_t> cand(ntasks, 0);
     std::vector<int64_t> sched_off(ntasks, -1);
     // (the first task's words start kCtlFrontPad rows into d_ctl: the backward sweep of k_dp_rs reads its control words up to
@@ -257,6 +263,7 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
         if (force_generic) break;
         for (int c = cmin; c < kSchedClasses; ++c) {
             if (kClassTab[c].kind == K_WIDE && (use_tile || no_wide)) continue;
+            if (em_stripes_cs && kClassTab[c].kind == K_STAIR && kClassTab[c].R == 4) continue;
             if (kClassTab[c].kind == K_STAIR && !stair_fits(static_cast<int64_t>(pseg[k].lX) + pseg[k].lY + 1, kClassTab[c].slots())) continue;
             if (summary[k].max_width <= stair_max_width(kClassTab[c].R, kClassTab[c].NW)) cand[k] |= 1u << c;
         }
@@ -327,13 +334,16 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     // enough says so and npr_batch_run runs it again in class 0-2's kernel.  NPR_OPT_ARITH = 1: none (the per-cell-exponent kernels
     // throughout, A/B).
     {
-        bool rs = ctx->opt[NPR_OPT_ARITH] != 1 && !force_generic && b->params.mode != NPR_MODE_EXPECTATIONS;
+        bool scaled = ctx->opt[NPR_OPT_ARITH] != 1 && !force_generic;
         for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
-            if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) rs = false;
+            if (ctx->model_set[sl] && !rs_model_ok(ctx->models[sl])) scaled = false;
+        // (the E-step has kernels in this arithmetic for the stripe tasks only: k_dp_tile_cs's E-step instance, NPR_OPT_EM_TILE)
+        const bool em = b->params.mode == NPR_MODE_EXPECTATIONS;
+        const bool rs = scaled && !em;
         b->pair_rs = rs;
-        if (rs)
+        if (scaled && !(em && ctx->opt[NPR_OPT_EM_TILE] == 1))
             for (int64_t k = 0; k < ntasks; ++k) {
-                if (cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
+                if (rs && cls_of[k] >= 0 && cls_of[k] < 3) cls_of[k] = static_cast<int8_t>(kFirstRs + cls_of[k]);
                 // the stripe tasks run in column-scaled arithmetic (k_dp_tile_cs, round 6: one exponent per lane of a stripe; same bits, and a
                 // per-lane range certificate that the reference's 3000-cell-wide rectangles pass -- DESIGN.md 5.1f); NPR_OPT_TILE_RS = 2: the
                 // per-cell-exponent k_dp_tile throughout (A/B)

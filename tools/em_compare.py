@@ -11,7 +11,7 @@ ctx = R.Context(0); ctx.set_hmm(h)
 P = (R.make_params(band_mode=1, fixed_width=W, mode=R.MODE_EXPECTATIONS) if W > 0 else
      R.make_params(band_mode=0, split_threshold=300, mode=R.MODE_EXPECTATIONS))
 got = {}
-for name, env in (('stripes', {}), ('frames', {'no_tile': 1}), ('generic', {'em_generic': 1})):  # context options (include/nprealign.h)
+for name, env in (('stripes', {}), ('stripes_percell', {'em_tile': 1}), ('frames', {'no_tile': 1}), ('generic', {'em_generic': 1})):  # context options (include/nprealign.h)
     for k, v in env.items(): ctx.set_option(_lib.OPTIONS[k], v)
     b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
     tasks, _ = b.class_stats()
@@ -21,6 +21,11 @@ for name, env in (('stripes', {}), ('frames', {'no_tile': 1}), ('generic', {'em_
     for k in env: ctx.set_option(_lib.OPTIONS[k], 0)
     got[name] = (T[0], E[0], ll[0])
     print(name, 'classes', np.nonzero(tasks)[0].tolist(), 'kernel %.1f ms' % ms2, 'll %.6f' % ll[0], 'repeat dT %.2e' % (np.abs(T2[0] - T[0]).max() / T[0].sum()), flush=True)
+s = got['frames'][0].sum()
+for name in ('stripes', 'stripes_percell'):
+    print(name, 'vs frames: dT %.2e dE %.2e dll %.3e' % (np.abs(got[name][0] - got['frames'][0]).max() / s, np.abs(got[name][1] - got['frames'][1]).max() / s, got[name][2] - got['frames'][2]))
+print('T stripes', got['stripes'][0].round(1).tolist())
+print('T percell', got['stripes_percell'][0].round(1).tolist())
 s = got['generic'][0].sum()
-for name in ('stripes', 'frames'):
+for name in ('stripes', 'stripes_percell', 'frames'):
     print(name, 'vs generic: dT %.2e dE %.2e dll %.3e' % (np.abs(got[name][0] - got['generic'][0]).max() / s, np.abs(got[name][1] - got['generic'][1]).max() / s, got[name][2] - got['generic'][2]))
