@@ -378,12 +378,35 @@ __device__ __forceinline__ void tcs_store_edge_fwd(__amdgpu_buffer_rsrc_t rsE, i
     __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(um), fbits(c.m), fbits(c.sx), fbits(c.lx)}, rsE, vo, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.sy), e, eh, fbits(c.ly)}, rsE, vo + 16, 0, 0);
 }
-// E-step: the other four states of a row, 16 bytes per cell in the planes' region (row stride 2048: slot 0's sx sy lx ly of lane l at 16 l, slot 1's at
-// 1024 + 16 l -- each store and each load instruction covers one whole KiB)
-constexpr int TCS_XROW_BYTES = 2048;
-__device__ __forceinline__ void tcs_store_planes(__amdgpu_buffer_rsrc_t rsX, int vo, const RDiag<2> &io) {
-    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[0].sx), fbits(io.c[0].sy), fbits(io.c[0].lx), fbits(io.c[0].ly)}, rsX, vo, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(io.c[1].sx), fbits(io.c[1].sy), fbits(io.c[1].lx), fbits(io.c[1].ly)}, rsX, vo + 1024, 0, 0);
+// E-step: the other four states of a row, 12 bytes per cell in the planes' region: each as the top 24 bits of its fp32 word (the sign, the exponent
+// whole, 15 mantissa bits, rounded), four to three words.  The forward sweep of the E-step is bound by the bytes it stores (13 ms of a 34 ms sweep
+// without these planes; as 16-byte cells they cost 21 ms), and what a count needs of a forward value is its leading bits -- the counts add thousands
+// of them in fp32; half floats (8 bytes) lack the range: a lane's long-gap states lie 2^-10 .. 2^-20 below its match values.
+// Row stride 1536: lane l's words 0-3 (slot 0's sx sy lx ly and the first byte-triple of slot 1's) at 16 l, words 4-5 at 1024 + 8 l.
+constexpr int TCS_XROW_BYTES = 1536;
+__device__ __forceinline__ void tcs_pack24(const RCell &c, int &d0, int &d1, int &d2) {
+    const uint32_t r0 = static_cast<uint32_t>(fbits(c.sx)) + 0x80u, r1 = static_cast<uint32_t>(fbits(c.sy)) + 0x80u, r2 = static_cast<uint32_t>(fbits(c.lx)) + 0x80u,
+                   r3 = static_cast<uint32_t>(fbits(c.ly)) + 0x80u;  // (values are finite and not negative: the carry can only reach the exponent)
+    d0 = static_cast<int>(__builtin_amdgcn_perm(r1, r0, 0x05030201u));  // r0's bytes 1 2 3, r1's byte 1
+    d1 = static_cast<int>(__builtin_amdgcn_perm(r2, r1, 0x06050302u));  // r1's bytes 2 3, r2's bytes 1 2
+    d2 = static_cast<int>(__builtin_amdgcn_perm(r3, r2, 0x07060503u));  // r2's byte 3, r3's bytes 1 2 3
+}
+__device__ __forceinline__ void tcs_unpack24(int d0, int d1, int d2, float &sx, float &sy, float &lx, float &ly) {
+    const uint32_t u0 = static_cast<uint32_t>(d0), u1 = static_cast<uint32_t>(d1), u2 = static_cast<uint32_t>(d2);
+    sx = bitsf(static_cast<int>(__builtin_amdgcn_perm(0u, u0, 0x0201000cu)));
+    sy = bitsf(static_cast<int>(__builtin_amdgcn_perm(u1, u0, 0x0504030cu)));
+    lx = bitsf(static_cast<int>(__builtin_amdgcn_perm(u2, u1, 0x0403020cu)));
+    ly = bitsf(static_cast<int>(u2 & 0xffffff00u));
+}
+__device__ __forceinline__ void tcs_store_planes(__amdgpu_buffer_rsrc_t rsX, int vo_a, int vo_b, const RDiag<2> &io) {
+#ifdef NPR_TCS_EM_EXP
+    if (NPR_TCS_EM_EXP == 3) return;
+#endif
+    int d[6];
+    tcs_pack24(io.c[0], d[0], d[1], d[2]);
+    tcs_pack24(io.c[1], d[3], d[4], d[5]);
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{d[0], d[1], d[2], d[3]}, rsX, vo_a, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v2i{d[4], d[5]}, rsX, vo_b, 0, 0);
 }
 __device__ __forceinline__ void tcs_store_edge_bwd(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, int e, int eh) {
     __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.lx), 0}, rsE, vo, 0, 0);
@@ -582,7 +605,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 if constexpr (EM) {  // (the lanes that hold a band cell only: the E-step is bound by these bytes)
                     if (lanes_of(mk.lanes)) {
                         tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
-                        tcs_store_planes(rsX, 2 * voff + k * TCS_XROW_BYTES, io);
+                        tcs_store_planes(rsX, 2 * voff + k * TCS_XROW_BYTES, 1024 + voff + k * TCS_XROW_BYTES, io);
                     }
                 } else {
                     tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
@@ -608,6 +631,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 feed8_ahead<+1>(fy, E.Y, lY, d - st.X - 1, lane);  // (the window serves the sixteen bases the block asks for)
                 int yi = uni(d - st.X - 1 - fy.base);
                 int vo = voff + (d - st.df) * TCS_ROW_BYTES, ve = 4 * TCS_EDGE * (d - st.df);
+                [[maybe_unused]] int xo = (d - st.df) * TCS_XROW_BYTES;  // (E-step: the planes' row)
                 const float *er = stage;  // record (d - 1) & 15 = 0
                 // the rows' mask words by one vector load (lane i mod 16: row d + i), handed out by v_readlane: no scalar load to wait for in the loop
                 const int wv16 = static_cast<int>(a.rowmask[rowmask_off + st.row0 + static_cast<uint32_t>(d - st.df) + (lane & (TCS_BLOCK - 1))]);
@@ -618,7 +642,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                     if constexpr (EM) {
                         if (lanes_of(m0.lanes)) {
                             tcs_store_row(rsF, vo, Q.A);
-                            tcs_store_planes(rsX, 2 * voff + 2 * (vo - voff), Q.A);  // (vo - voff: k rows of 1024 bytes; the planes' rows are 2048)
+                            tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                         }
                     } else {
                         tcs_store_row(rsF, vo, Q.A);
@@ -629,20 +653,20 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                     if constexpr (EM) {
                         if (lanes_of(m1.lanes)) {
                             tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
-                            tcs_store_planes(rsX, 2 * voff + 2 * (vo - voff) + TCS_XROW_BYTES, Q.B);
+                            tcs_store_planes(rsX, 2 * voff + xo + TCS_XROW_BYTES, 1024 + voff + xo + TCS_XROW_BYTES, Q.B);
                         }
                     } else {
                         tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
                     }
                     if (edge_lane) tcs_store_edge_fwd(rsE, ve + 4 * TCS_EDGE, Q.B.c[R - 1], Q.umB, Q.e, Q.eh);
-                    yi += 2, vo += 2 * TCS_ROW_BYTES, ve += 2 * 4 * TCS_EDGE, er += 2 * TCS_EDGE;
+                    yi += 2, vo += 2 * TCS_ROW_BYTES, xo += 2 * TCS_XROW_BYTES, ve += 2 * 4 * TCS_EDGE, er += 2 * TCS_EDGE;
                 }
                 const Masks<R> m14 = row_masks(__builtin_amdgcn_readlane(wv16, 14));
                 tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, m14, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
                 if constexpr (EM) {
                     if (lanes_of(m14.lanes)) {
                         tcs_store_row(rsF, vo, Q.A);
-                        tcs_store_planes(rsX, 2 * voff + 2 * (vo - voff), Q.A);
+                        tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                     }
                 } else {
                     tcs_store_row(rsF, vo, Q.A);
@@ -688,7 +712,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
         for (int i = 0; i < 15; ++i) em_acc[i] = 0.f;
         // =============================== backward + posteriors ===============================
 #ifdef NPR_TCS_EM_EXP
-        if (alive && !(EM && NPR_TCS_EM_EXP == 1)) {
+        if (alive && !(EM && (NPR_TCS_EM_EXP == 1 || NPR_TCS_EM_EXP == 3))) {
 #else
         if (alive) {
 #endif
@@ -804,13 +828,14 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 RCell GAb = zero_rcell(), GBb = zero_rcell();
                 struct EmRow {
                     v2i f;
-                    v4i x0, x1;
+                    v4i x0;
+                    v2i x1;
                 };
-                EmRow S0{v2i{0, 0}, v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}}, S1 = S0;  // two rows in flight: an even row lands in S0, an odd one in S1
+                EmRow S0{v2i{0, 0}, v4i{0, 0, 0, 0}, v2i{0, 0}}, S1 = S0;  // two rows in flight: an even row lands in S0, an odd one in S1
                 int kbF = -(1 << 30);  // the block of the left stripe's forward records in stageF
                 // issue the loads of a row (zeros outside the stripe's rows and in the lanes that hold no band cell: those were not stored); w: the row's mask word
                 auto em_fetch_w = [&](int row, uint32_t w, EmRow &S) __attribute__((always_inline)) {
-                    S.f = v2i{0, 0}, S.x0 = v4i{0, 0, 0, 0}, S.x1 = v4i{0, 0, 0, 0};
+                    S.f = v2i{0, 0}, S.x0 = v4i{0, 0, 0, 0}, S.x1 = v2i{0, 0};
                     if (row >= st.df && row <= st.dl) {  // uniform
                         const int k = row - st.df;
 #ifdef NPR_TCS_EM_EXP
@@ -819,7 +844,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                         if (lanes_of(row_masks(w).lanes)) {
                             S.f = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + k * TCS_ROW_BYTES, 0, 0);
                             S.x0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, 2 * voff + k * TCS_XROW_BYTES, 0, 0);
-                            S.x1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, 2 * voff + k * TCS_XROW_BYTES + 1024, 0, 0);
+                            S.x1 = __builtin_amdgcn_raw_buffer_load_b64(rsX, 1024 + voff + k * TCS_XROW_BYTES, 0, 0);
                         }
                     }
                 };
@@ -830,8 +855,12 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 auto em_scaled = [&](int row, const EmRow &S) __attribute__((always_inline)) -> RDiag<R> {  // a fetched row in this lane's posterior units
                     const int sF = min(max(((row >> 4) == kbCur ? efCur : efPrev) + Q.e - tot_e, -300), 300);
                     RDiag<R> G;
-                    G.c[0] = RCell{__builtin_ldexpf(bitsf(S.f.x), sF), __builtin_ldexpf(bitsf(S.x0.x), sF), __builtin_ldexpf(bitsf(S.x0.y), sF), __builtin_ldexpf(bitsf(S.x0.z), sF), __builtin_ldexpf(bitsf(S.x0.w), sF)};
-                    G.c[1] = RCell{__builtin_ldexpf(bitsf(S.f.y), sF), __builtin_ldexpf(bitsf(S.x1.x), sF), __builtin_ldexpf(bitsf(S.x1.y), sF), __builtin_ldexpf(bitsf(S.x1.z), sF), __builtin_ldexpf(bitsf(S.x1.w), sF)};
+                    G.c[0].m = bitsf(S.f.x), G.c[1].m = bitsf(S.f.y);
+                    tcs_unpack24(S.x0.x, S.x0.y, S.x0.z, G.c[0].sx, G.c[0].sy, G.c[0].lx, G.c[0].ly);
+                    tcs_unpack24(S.x0.w, S.x1.x, S.x1.y, G.c[1].sx, G.c[1].sy, G.c[1].lx, G.c[1].ly);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        G.c[r] = RCell{__builtin_ldexpf(G.c[r].m, sF), __builtin_ldexpf(G.c[r].sx, sF), __builtin_ldexpf(G.c[r].sy, sF), __builtin_ldexpf(G.c[r].lx, sF), __builtin_ldexpf(G.c[r].ly, sF)};
                     return G;
                 };
                 auto em_left = [&](int row) __attribute__((always_inline)) -> RCell {  // the left stripe's last column on `row`, in the posterior units of the lane that asks (lane 0 uses it)
@@ -1153,22 +1182,27 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
         if (stuck) atomicMax(lmisc + 6, 1 << 30);
         __syncthreads();
         if constexpr (EM) {
-            // The counts of a task leave the workgroup only when its certificate holds (else k_em_tile counts the task: TASK_RERUN): every wavefront
-            // adds up its own bins, then its transition accumulators through the same rows (k_em_tile's reduction).
-            if (alive && uni(lmisc[6]) < TCS_S_LIMIT) {
-                if (lane < EM_BINS) {
-                    double sum = 0.0;
-                    for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
-                    atomicAdd(a.em_E + model * EM_BINS + lane, sum);
-                }
+            // The counts of a task leave the workgroup only when its certificate holds and every sum is a finite number (else k_em_tile counts the task:
+            // TASK_RERUN): every wavefront adds up its own bins, then its transition accumulators through the same rows (k_em_tile's reduction).
+            const bool cert = alive && uni(lmisc[6]) < TCS_S_LIMIT;
+            double sumE = 0.0, sumT = 0.0;
+            const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
+            if (cert) {
+                if (lane < EM_BINS)
+                    for (int q = 0; q < WAVE; ++q) sumE += static_cast<double>(lbins[lane * WAVE + q]);
 #pragma unroll
                 for (int i = 0; i < 15; ++i) lbins[i * WAVE + lane] = em_acc[i];  // (sums of F' * w: the transition multiplies below)
                 if (lane < 15) {
-                    double sum = 0.0;
-                    for (int q = 0; q < WAVE; ++q) sum += static_cast<double>(lbins[lane * WAVE + q]);
-                    const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
-                    atomicAdd(a.em_T + model * 25 + map[lane], sum * static_cast<double>(mdl->T[map[lane]]));
+                    for (int q = 0; q < WAVE; ++q) sumT += static_cast<double>(lbins[lane * WAVE + q]);
+                    sumT *= static_cast<double>(mdl->T[map[lane]]);
                 }
+                const double big = 1e300;
+                if (__ballot(!(sumE > -big && sumE < big && sumT > -big && sumT < big)) != 0 && lane == 0) atomicMax(lmisc + 6, 1 << 30);
+            }
+            __syncthreads();
+            if (cert && uni(lmisc[6]) < TCS_S_LIMIT) {
+                if (lane < EM_BINS) atomicAdd(a.em_E + model * EM_BINS + lane, sumE);
+                if (lane < 15) atomicAdd(a.em_T + model * 25 + map[lane], sumT);
             }
         }
         if (threadIdx.x == 0) {
