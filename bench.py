@@ -64,7 +64,9 @@ CLASS_KERNEL = {0: "k_dp_stair<1>", 1: "k_dp_stair<2>", 2: "k_dp_stair<4>", 3: "
                 12: "k_dp_mid_rs<1>", 13: "k_dp_mid_rs<2>", 14: "k_dp_mid_rs<4>", 15: "k_dp_rs<1>", 16: "k_dp_rs<2>", 17: "k_dp_rs<4>", 18: "k_dp_tile_cs"}
 RS_BYTES_PER_CELL = 8.0     # k_dp_rs / k_dp_mid_rs (row-scaled arithmetic: the exponent is per row, not per cell): 4 B stored + 4 B reloaded
                             # (k_dp_mid_rs: the forward sweep stores the rows up to the cut and the backward sweep the rows above it: the same bytes)
-EM_CLASS_KERNEL = {0: "k_em_stair<1>", 1: "k_em_stair<2>", 2: "k_em_stair<4>", 11: "k_em_tile<2>"}
+EM_CLASS_KERNEL = {0: "k_em_stair<1>", 1: "k_em_stair<2>", 2: "k_em_stair<4>", 11: "k_em_tile<2>", 18: "k_dp_tile_cs<EM>"}
+EM_CS_BYTES_PER_CELL = 32.0  # k_dp_tile_cs's E-step instance (round 6): 4 B match value + 12 B for the other four states as 24-bit floats, stored once
+                             # and reloaded once (the exponents are per lane and block of sixteen rows)
 
 
 def load_model(name="blasr_hmm_0.txt"):
@@ -795,7 +797,8 @@ def em_step(env):
         return None
     kms = float(np.mean(kms))
     dom = int(np.argmax(class_cells))
-    achieved = EM_BYTES_PER_CELL * cells / (kms * 1e-3) / 1e9
+    em_bytes = EM_CS_BYTES_PER_CELL if dom == 18 else EM_BYTES_PER_CELL
+    achieved = em_bytes * cells / (kms * 1e-3) / 1e9
     tab = kernel_table().get(EM_CLASS_KERNEL.get(dom, ""), {})
     out = {
         "metric": "DP cells/sec (Baum-Welch E-step: forward + backward + expected counts per cell)",
@@ -809,8 +812,10 @@ def em_step(env):
                      "traffic": (tab["hbm_bytes_per_cell"] * cells / 1e9) if tab.get("hbm_bytes_per_cell") else None,
                      "kernel": EM_CLASS_KERNEL.get(dom, "k_dp_generic<EM>"), "kernel_ms": kms,
                      "kernel_share_of_cells": float(class_cells[dom]) / max(float(np.sum(class_cells)), 1.0),
-                     "algorithmic_bytes": "%g B/cell: the five forward states of every cell (match mantissa + exponent 8 B, the other four 16 B) "
-                                          "stored by the forward sweep and reloaded by the backward sweep" % EM_BYTES_PER_CELL,
+                     "algorithmic_bytes": ("%g B/cell: the five forward states of every cell (match value 4 B, the other four as 24-bit floats 12 B; exponents per "
+                                           "lane and block) stored by the forward sweep and reloaded by the backward sweep" % em_bytes) if dom == 18 else
+                                          ("%g B/cell: the five forward states of every cell (match mantissa + exponent 8 B, the other four 16 B) "
+                                           "stored by the forward sweep and reloaded by the backward sweep" % em_bytes),
                      "note": "kernel_ms = HIP-event time of ALL E-step launches of the batch (one per kernel class, concurrent)"},
         "loglik": float(ll[0]),
     }

@@ -165,7 +165,7 @@ const char *npr_last_error(npr_ctx *ctx);
 #define NPR_OPT_EM_SERIAL 18       /* 1: the E-step's launches one after the other */
 #define NPR_OPT_EM_WAVES 19        /* wavefronts per CU of k_em_stair (0: per class) */
 #define NPR_OPT_MEA_WIDE_OPS 20    /* 1: the packed cigars cross PCIe as whole words even when every run fits 14 bits */
-#define NPR_OPT_EM_TILE 21         /* the E-step of stripe tasks: 0 column-scaled arithmetic first (k_dp_tile_cs's E-step instance; what its certificate refuses goes to k_em_tile), 1 k_em_tile only */
+#define NPR_OPT_EM_TILE 21         /* the E-step of stripe tasks: 0 column-scaled arithmetic first (k_dp_tile_cs's E-step instance; what its certificate refuses goes to k_em_tile), 1 k_em_tile only, 2 (tests) as 0 with every other task refused */
 #define NPR_OPT_COUNT 22
 int32_t npr_ctx_option(npr_ctx *ctx, int32_t option, int64_t value);
 

@@ -1184,7 +1184,8 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
         if constexpr (EM) {
             // The counts of a task leave the workgroup only when its certificate holds and every sum is a finite number (else k_em_tile counts the task:
             // TASK_RERUN): every wavefront adds up its own bins, then its transition accumulators through the same rows (k_em_tile's reduction).
-            const bool cert = alive && uni(lmisc[6]) < TCS_S_LIMIT;
+            const bool refused = a.wcap == 1 && (t & 1);  // NPR_OPT_EM_TILE = 2 (tests): every other task goes to the second pass whatever its certificate says
+            const bool cert = alive && uni(lmisc[6]) < TCS_S_LIMIT && !refused;
             double sumE = 0.0, sumT = 0.0;
             const int map[15] = {0, 5, 10, 15, 20, 1, 6, 11, 3, 18, 2, 12, 7, 4, 24};  // accumulator order -> T[from*5+to]
             if (cert) {
@@ -1199,6 +1200,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 const double big = 1e300;
                 if (__ballot(!(sumE > -big && sumE < big && sumT > -big && sumT < big)) != 0 && lane == 0) atomicMax(lmisc + 6, 1 << 30);
             }
+            if (refused && threadIdx.x == 0) atomicMax(lmisc + 6, 1 << 30);
             __syncthreads();
             if (cert && uni(lmisc[6]) < TCS_S_LIMIT) {
                 if (lane < EM_BINS) atomicAdd(a.em_E + model * EM_BINS + lane, sumE);

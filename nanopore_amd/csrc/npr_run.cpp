@@ -349,6 +349,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         a.Fx = ctx->arena_Fx + l.fx_off;
         a.em_T = d_T.p;
         a.em_E = d_E.p;
+        if (l.tile_cs) a.wcap = ctx->opt[NPR_OPT_EM_TILE] == 2 ? 1 : 0;  // (the column-scaled kernel has no ring: the field carries the test switch)
         const int rc = l.tile_cs   ? launch_em_tile_cs(a, em_tile_cs_waves(), l.grid, st, sw, flat)
                        : l.tile    ? launch_em_tile(a, l.stair_R, l.grid, st)
                        : l.wide_NW ? launch_em_wide(a, l.stair_R, l.wide_NW, l.grid, st)
