@@ -208,6 +208,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         int stair_R;  // > 0: the register-kernel E-step (k_em_stair<R>), else the generic kernel
         int wide_NW;  // > 0: stair_R slots per lane on wide_NW wavefronts per task (k_dp_wide<R, NW, EM>)
         bool tile;    // the stripe-kernel E-step (k_em_tile<stair_R>): scratch regions per workgroup, as in the DP launch
+        bool uses_others_regions;  // a generic launch over a class without uniform regions: not beside the others
         bool tile_cs;  // ... in column-scaled arithmetic first (k_dp_tile_cs<.., EM>); what its certificate refuses goes to k_em_tile
         int slot_base;    // first uniform forward-scratch region: the one its class had in the DP launch (the classes run concurrently)
         int dp_grid;      // ... and how many of them that launch owned
@@ -257,6 +258,16 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         if (l.global_ring) l.lds = generic_lds_bytes(0) + em_extra_lds_bytes();
         const int waves = l.global_ring ? 8 : std::min<int>(12, static_cast<int>(std::max<size_t>(1, (160 * 1024) / (l.lds + 256))));
         l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.count, static_cast<int64_t>(ctx->cu_count) * waves)));
+        if (dl.own_regions) {
+            // A class laid out in scratch regions of its own (the stripe class under NPR_OPT_EM_GENERIC) has no uniform regions: the generic kernel
+            // counts it in regions 0, 1, .. of the arena, which belong to the other classes' launches -- so one launch after the other then, and no
+            // more workgroups than the arena has room for.  (Until round 6 the launches ran side by side there: NaN counts on a batch of four classes.)
+            l.uses_others_regions = true;
+            l.slot_base = 0;
+            const int64_t arena_cells = b->region_end.empty() ? b->slot_stride : b->region_end.back();
+            l.grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(l.grid, arena_cells / std::max<int64_t>(b->slot_stride, 1))));
+            l.dp_grid = l.grid;
+        }
         launches.push_back(l);
     }
     // The launches run concurrently, like the DP launches of npr_batch_run (serialised, a batch in the trainer's band spent
@@ -322,7 +333,8 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     std::vector<const L *> order;
     for (const auto &l : launches) order.push_back(&l);
     std::stable_sort(order.begin(), order.end(), [](const L *x, const L *y) { return x->cells < y->cells; });
-    const bool serial = ctx->opt[NPR_OPT_EM_SERIAL] != 0;  // A/B switch: one launch after the other, as before round 3
+    bool serial = ctx->opt[NPR_OPT_EM_SERIAL] != 0;  // A/B switch: one launch after the other, as before round 3
+    for (const auto &l : launches) serial |= l.uses_others_regions;
     bool sw = false;  // (as npr_batch_run: the column-scaled kernel leaves out the short-gap switch terms no loaded model has)
     for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
         if (ctx->model_set[sl] && (ctx->models[sl].T[1 * 5 + 2] != 0.f || ctx->models[sl].T[2 * 5 + 1] != 0.f)) sw = true;
