@@ -25,7 +25,8 @@ value = cells of the whole set / that time; reads_per_s likewise.  The default r
 entry, so that a --gpus 1/2/4/8 series measures the strong-scaling target next to the weak-scaling headline.
 
 `--workload em` is the Baum-Welch E-step (npr_batch_expectations: what the trainer runs 3 x 100 times per model,
-utils.py:509-523) over one resident batch in the trainer's own band (anchors, splitMatrixBiggerThanThis 300, utils.py:511).
+utils.py:509-523) over one resident batch in the trainer's own band (anchors, splitMatrixBiggerThanThis 300, utils.py:511).  The default
+run at N = 1 carries it as an `also` entry too (seven timed steps, after the reference's own band and the rescore mode).
 
 Rank 0 prints ONE JSON line.
 """
@@ -612,6 +613,11 @@ def resident(env):
                             "roofline": roofline_block(c3_, int(r3["res"]["n_pairs"].sum()), k3, r3["class_cells"], gpu_clock_hz()),
                             "ok_reads": int((r3["res"]["status"] == 0).sum())})
         r3["batch"].close()
+        # ... and the trainer's pass (utils.py:509-528: 3 x 100 of these per trained model): the Baum-Welch E-step on the trainer's own band
+        em = em_step(env, steps=ALSO_STEPS, warmup=1, cpu=False, reads=6144)
+        out["also"].append({"workload": "E-step: " + em["config"]["workload"], "reads": em["config"]["reads_per_gpu"], "value": em["value"], "unit": em["unit"],
+                            "steps": em["steps"], "ms_per_step": em["ms_per_step"], "step_spread": em["step_spread"], "roofline": em["roofline"],
+                            "class_cells": em["config"]["class_cells"]})
     return out
 
 
@@ -763,27 +769,30 @@ def c3_job(env, n_reads, steps, warmup, from_files):
     }
 
 
-def em_step(env):
+def em_step(env, steps=None, warmup=None, cpu=True, reads=None):
     """Baum-Welch E-step over one resident batch in the trainer's band: a step = npr_batch_expectations (forward with all five
     states kept, backward with the expected transition / emission counts accumulated, one reduction per model slot)."""
     args, ctx, rank, world, dist, sync, allreduce = (env[k] for k in ("args", "ctx", "rank", "world", "dist", "sync", "allreduce"))
     from nanopore_amd import realign as R, synth
     h = load_model()
-    n_reads = args.reads or 6144
+    steps, warmup = steps or args.steps, args.warmup if warmup is None else warmup
+    n_reads = reads or args.reads or 6144
     w = synth.make_workload(1006 + 7919 * rank, n_reads, 4000, h.transitions, h.emissions, flank=0)
     ctx.set_hmm(h)
     P = R.make_params(band_mode=R.BAND_ANCHOR, split_threshold=300, mode=R.MODE_EXPECTATIONS)  # options.optionsToRealign, utils.py:511
     b = ctx.stage_csr(P, w["ref"], w["ref_off"], w["read"], w["read_off"], w["guide_ops"], w["guide_off"])
     st = b.stats()
     _, class_cells = b.class_stats()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         b.expectations()
     sync()
     t0 = time.perf_counter()
-    kms = []
-    for _ in range(args.steps):
+    kms, step_ms = [], []
+    for _ in range(steps):
+        t1 = time.perf_counter()
         T, E, ll, ms = b.expectations()
         kms.append(ms)
+        step_ms.append((time.perf_counter() - t1) * 1e3)
     sync()
     elapsed = time.perf_counter() - t0
     cells = st["cells"]
@@ -802,8 +811,8 @@ def em_step(env):
     tab = kernel_table().get(EM_CLASS_KERNEL.get(dom, ""), {})
     out = {
         "metric": "DP cells/sec (Baum-Welch E-step: forward + backward + expected counts per cell)",
-        "value": total_cells * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "value": total_cells * steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "step_spread": spread(step_ms), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "synthetic ~4kb reads in the trainer's band (anchors +- 10, trim 14, splitMatrixBiggerThanThis 300: "
                                "nanopore/analyses/utils.py:511), blasr_hmm_0", "reads_per_gpu": n_reads, "cells_per_gpu": int(cells),
@@ -819,7 +828,7 @@ def em_step(env):
                      "note": "kernel_ms = HIP-event time of ALL E-step launches of the batch (one per kernel class, concurrent)"},
         "loglik": float(ll[0]),
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and cpu and not args.no_cpu_baseline:
         out["cpu_baseline"] = em_cpu_baseline(h, w, P)
     b.close()
     return out

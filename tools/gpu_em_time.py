@@ -8,6 +8,9 @@ h = Hmm.loadHmm(os.path.join(ROOT, 'nanopore_amd', 'mappers', 'blasr_hmm_0.txt')
 n=int(sys.argv[1]); L=int(sys.argv[2]); W=int(sys.argv[3])
 w = synth.make_workload(7, n, L, h.transitions, h.emissions, flank=0)
 ctx = R.Context(0); ctx.set_hmm(h)
+from nanopore_amd import _lib
+for kv in filter(None, os.environ.get('NPR_OPTS', '').split(',')):  # e.g. NPR_OPTS=class_min=3,em_tile=1 (context options, include/nprealign.h)
+    k, v = kv.split('='); ctx.set_option(_lib.OPTIONS[k], int(v))
 P = R.make_params(band_mode=1, fixed_width=W, mode=R.MODE_EXPECTATIONS) if W > 0 else R.make_params(band_mode=0, split_threshold=300, mode=R.MODE_EXPECTATIONS)  # the trainer's own options (utils.py:511)
 b = ctx.stage_csr(P, w['ref'], w['ref_off'], w['read'], w['read_off'], w['guide_ops'], w['guide_off'])
 st = b.stats()
