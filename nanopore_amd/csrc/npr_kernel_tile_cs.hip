@@ -447,6 +447,10 @@ constexpr int TCS_EM_DEAD = NPR_TCS_EM_DEAD;  // (k_em_tile's EM_SKIP: 2.7e8 ter
 #ifndef NPR_TCS_WAVES
 #define NPR_TCS_WAVES 6
 #endif
+#ifndef NPR_TCS_DP_MASK
+#define NPR_TCS_DP_MASK 0
+#endif
+constexpr bool TCS_DP_MASK = NPR_TCS_DP_MASK != 0;  // the DP instances' row stores and loads in the fast loops only in the lanes that hold a band cell: what halved the E-step's traffic buys nothing here (8192 reads in the reference's band, two runs each: 268.6 / 269.2 ms without, 272.9 / 273.1 with -- the DP sweeps are not bound by these bytes)
 #ifndef NPR_TCS_T_SGPR
 #define NPR_TCS_T_SGPR 1
 #endif
@@ -645,7 +649,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                         }
                     } else {
-                        tcs_store_row(rsF, vo, Q.A);
+                        if (!TCS_DP_MASK || lanes_of(m0.lanes)) tcs_store_row(rsF, vo, Q.A);
                     }
                     if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
                     const Masks<R> m1 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1));
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             tcs_store_planes(rsX, 2 * voff + xo + TCS_XROW_BYTES, 1024 + voff + xo + TCS_XROW_BYTES, Q.B);
                         }
                     } else {
-                        tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
+                        if (!TCS_DP_MASK || lanes_of(m1.lanes)) tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
                     }
                     if (edge_lane) tcs_store_edge_fwd(rsE, ve + 4 * TCS_EDGE, Q.B.c[R - 1], Q.umB, Q.e, Q.eh);
                     yi += 2, vo += 2 * TCS_ROW_BYTES, xo += 2 * TCS_XROW_BYTES, ve += 2 * 4 * TCS_EDGE, er += 2 * TCS_EDGE;
@@ -669,7 +673,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                         tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                     }
                 } else {
-                    tcs_store_row(rsF, vo, Q.A);
+                    if (!TCS_DP_MASK || lanes_of(m14.lanes)) tcs_store_row(rsF, vo, Q.A);
                 }
                 if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
                 wait_vm();
@@ -1095,8 +1099,10 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             em_fetch_w(d - 2 * i - 4, __builtin_amdgcn_readlane(wv16, 2 * i + 4), S0);
                             bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 1));
                         } else {
-                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
-                            fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
+                            if (!TCS_DP_MASK || lanes_of(row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1)).lanes)) {
+                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
+                                fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
+                            }
                         }
                         const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i));
                         tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
@@ -1108,8 +1114,10 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 2));
                         } else {
                             emit(d - 2 * i, Q.B, fb, m0);
-                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo - TCS_ROW_BYTES, 0, 0);
-                            fb.v[0] = bitsf(q.x), fb.v[1] = bitsf(q.y);
+                            if (!TCS_DP_MASK || lanes_of(row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 2)).lanes)) {
+                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo - TCS_ROW_BYTES, 0, 0);
+                                fb.v[0] = bitsf(q.x), fb.v[1] = bitsf(q.y);
+                            }
                         }
                         const Masks<R> m1 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1));
                         tcs_bwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.c, m1, er - TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
@@ -1127,8 +1135,10 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             em_fetch_w(d - 18, __builtin_amdgcn_readlane(wv16, 18), S0);
                             bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 1));
                         } else {
-                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
-                            fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
+                            if (!TCS_DP_MASK || lanes_of(row_masks(__builtin_amdgcn_readlane(wv16, 15)).lanes)) {
+                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
+                                fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
+                            }
                         }
                         const Masks<R> m0 = row_masks(__builtin_amdgcn_readlane(wv16, 14));
                         tcs_bwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
