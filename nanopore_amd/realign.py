@@ -6,6 +6,7 @@ all reads of a SAM file go to the GPU in one call.  Device work only -- no CPU f
 """
 import contextlib
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -70,6 +71,7 @@ class Batch(object):
         if rc != _lib.OK:
             raise NprError(rc, "npr_batch_create", ctx.last_error())
         self._h = h
+        ctx._open.add(self)
 
     def class_stats(self):
         """(tasks, cells) per kernel class (include/nprealign.h: npr_batch_class_stats)."""
@@ -257,6 +259,7 @@ class Context(object):
         self._h = h
         self.device = device
         self._models = {}  # slot -> (T, E) or None, as installed: what another context on the same GPU copies
+        self._open = weakref.WeakSet()  # the batches staged on this context and not closed yet: close() closes them first
 
     def set_option(self, option, value):
         """include/nprealign.h: npr_ctx_option (e.g. _lib.OPT_OVERLAP for a context of a pipelined job)."""
@@ -413,6 +416,10 @@ class Context(object):
 
     def close(self):
         if getattr(self, "_h", None):
+            # a batch that outlives its context (a test that failed with one open, at interpreter exit) would hand npr_batch_destroy
+            # a batch whose context is gone: the library has no way to know
+            for b in list(getattr(self, "_open", ())):
+                b.close()
             self._L.npr_destroy(self._h)
             self._h = None
 

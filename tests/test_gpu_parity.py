@@ -598,3 +598,19 @@ def test_sweeps_that_meet_in_the_middle(gpu_ctx, monkeypatch):
         assert np.array_equal(u["x"][ku], v["x"][kv]) and np.array_equal(u["y"][ku], v["y"][kv])
         assert np.array_equal(u["p"][ku].view(np.uint32), v["p"][kv].view(np.uint32))
         assert u["ops"] == v["ops"] and u["score"] == v["score"]
+
+
+def test_a_context_closes_the_batches_still_staged_on_it():
+    """A batch left open (a caller that raised half way) must not outlive its context: npr_batch_destroy on a batch whose context is gone reads freed
+    memory -- at interpreter exit that was a core dump after any failing test.  Context.close() closes what is still staged on it first."""
+    from nanopore_amd import realign as R
+    ctx = R.Context(0)
+    ctx.set_hmm(_hmm_obj("blasr_hmm_0.txt"))
+    rng = np.random.default_rng(3)
+    X, Y, g = random_pair(rng, 300)
+    b = ctx.stage(R.make_params(band_mode=1, fixed_width=60), [bytes(b"ACGT"[c] for c in X)], [bytes(b"ACGT"[c] for c in Y)], [g])
+    b.run()
+    ctx.close()
+    assert b._h is None
+    b.close()   # (nothing left to do)
+    del b
