@@ -321,8 +321,9 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
     }
     DevBuf<float> ring;
     DevBuf<double> d_T, d_E;
-    if ((e = ring.alloc(ring_floats)) != hipSuccess || (e = d_T.alloc(NPR_MAX_MODELS * 25)) != hipSuccess ||
-        (e = d_E.alloc(NPR_MAX_MODELS * EM_BINS)) != hipSuccess)
+    // (from the context's cache of released buffers: the trainer calls this hundreds of times on one staged batch -- no hipMalloc / hipFree per call)
+    if ((e = ring.alloc_from(ctx, ring_floats)) != hipSuccess || (e = d_T.alloc_from(ctx, NPR_MAX_MODELS * 25)) != hipSuccess ||
+        (e = d_E.alloc_from(ctx, NPR_MAX_MODELS * EM_BINS)) != hipSuccess)
         return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc", e);
     HIP_TRY(ctx, hipMemsetAsync(d_T.p, 0, d_T.bytes(), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_E.p, 0, d_E.bytes(), ctx->stream));
@@ -391,7 +392,7 @@ int32_t npr_batch_expectations(npr_batch *b, double *T_exp, double *E_exp, doubl
         for (size_t j = 0; j < again.size(); ++j) sub[j] = b->tasks[again[j]];
         DevBuf<Task> d_sub;
         DevBuf<TaskOut> d_subout;
-        if (d_sub.alloc(sub.size()) != hipSuccess || d_subout.alloc(sub.size()) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc");
+        if (d_sub.alloc_from(ctx, sub.size()) != hipSuccess || d_subout.alloc_from(ctx, sub.size()) != hipSuccess) return fail(ctx, NPR_ERR_NOMEM, "npr_batch_expectations: hipMalloc");
         HIP_TRY(ctx, hipMemcpy(d_sub.p, sub.data(), sizeof(Task) * sub.size(), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemsetAsync(b->d_queue.p + static_cast<int>(i), 0, sizeof(int32_t), ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
