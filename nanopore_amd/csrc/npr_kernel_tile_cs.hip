@@ -398,6 +398,8 @@ __device__ __forceinline__ void tcs_unpack24(int d0, int d1, int d2, float &sx, 
     lx = bitsf(static_cast<int>(__builtin_amdgcn_perm(u2, u1, 0x0403020cu)));
     ly = bitsf(static_cast<int>(u2 & 0xffffff00u));
 }
+// (NPR_TCS_EM_EXP, bring-up builds only -- WRONG counts, for timing: 1 the E-step stops after its forward sweep, 2 its backward sweep loads no forward
+// rows, 3 the forward sweep alone and without these planes.  How DESIGN.md 5.3e's "measured by leaving things out" numbers were taken.)
 __device__ __forceinline__ void tcs_store_planes(__amdgpu_buffer_rsrc_t rsX, int vo_a, int vo_b, const RDiag<2> &io) {
 #ifdef NPR_TCS_EM_EXP
     if (NPR_TCS_EM_EXP == 3) return;
