@@ -369,8 +369,9 @@ __device__ __forceinline__ void tcs_swap_rows(RDiag<2> &A, RDiag<2> &B) {
     const RDiag<2> t = A;
     A = B, B = t;
 }
+template <int AUX = 0>
 __device__ __forceinline__ void tcs_store_row(__amdgpu_buffer_rsrc_t rsF, int vo, const RDiag<2> &io) {
-    __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(io.c[0].m), fbits(io.c[1].m)}, rsF, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(io.c[0].m), fbits(io.c[1].m)}, rsF, vo, 0, AUX);
 }
 // the record a stripe leaves for its neighbour stripe: forward (um, m, sx, lx | sy, e, e^, ly) of its last column's cell, backward (m, sx, lx, - | -, e, e^, -)
 // of its first column's
@@ -384,6 +385,17 @@ __device__ __forceinline__ void tcs_store_edge_fwd(__amdgpu_buffer_rsrc_t rsE, i
 // of them in fp32; half floats (8 bytes) lack the range: a lane's long-gap states lie 2^-10 .. 2^-20 below its match values.
 // Row stride 1536: lane l's words 0-3 (slot 0's sx sy lx ly and the first byte-triple of slot 1's) at 16 l, words 4-5 at 1024 + 8 l.
 constexpr int TCS_XROW_BYTES = 1536;
+// The E-step's rows are written once and read once, tens of milliseconds later, by a sweep that moves 39 bytes per cell at 2.9 TB/s: as non-temporal
+// stores and loads (aux 2: nt) they stay out of the way of what the caches can help with -- the records between stripes, the exponents, the tables:
+// 55.2 -> 51.0 ms per step of the bench's batch (four runs, alternating: 55.2 / 56.3 against 51.0 / 50.7); nt on the planes alone 51.5, sc0 | nt 51.2.
+#ifndef NPR_TCS_EM_AUX
+#define NPR_TCS_EM_AUX 2
+#endif
+#ifndef NPR_TCS_EM_ROW_AUX
+#define NPR_TCS_EM_ROW_AUX NPR_TCS_EM_AUX
+#endif
+constexpr int TCS_EM_ROW_AUX = NPR_TCS_EM_ROW_AUX;
+constexpr int TCS_EM_AUX = NPR_TCS_EM_AUX;  // cache policy of the planes' stores and of the backward sweep's row loads
 __device__ __forceinline__ void tcs_pack24(const RCell &c, int &d0, int &d1, int &d2) {
     const uint32_t r0 = static_cast<uint32_t>(fbits(c.sx)) + 0x80u, r1 = static_cast<uint32_t>(fbits(c.sy)) + 0x80u, r2 = static_cast<uint32_t>(fbits(c.lx)) + 0x80u,
                    r3 = static_cast<uint32_t>(fbits(c.ly)) + 0x80u;  // (values are finite and not negative: the carry can only reach the exponent)
@@ -407,8 +419,8 @@ __device__ __forceinline__ void tcs_store_planes(__amdgpu_buffer_rsrc_t rsX, int
     int d[6];
     tcs_pack24(io.c[0], d[0], d[1], d[2]);
     tcs_pack24(io.c[1], d[3], d[4], d[5]);
-    __builtin_amdgcn_raw_buffer_store_b128(v4i{d[0], d[1], d[2], d[3]}, rsX, vo_a, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b64(v2i{d[4], d[5]}, rsX, vo_b, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4i{d[0], d[1], d[2], d[3]}, rsX, vo_a, 0, TCS_EM_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(v2i{d[4], d[5]}, rsX, vo_b, 0, TCS_EM_AUX);
 }
 __device__ __forceinline__ void tcs_store_edge_bwd(__amdgpu_buffer_rsrc_t rsE, int vo, const RCell &c, int e, int eh) {
     __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(c.m), fbits(c.sx), fbits(c.lx), 0}, rsE, vo, 0, 0);
@@ -610,7 +622,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 }
                 if constexpr (EM) {  // (the lanes that hold a band cell only: the E-step is bound by these bytes)
                     if (lanes_of(mk.lanes)) {
-                        tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
+                        tcs_store_row<TCS_EM_ROW_AUX>(rsF, voff + k * TCS_ROW_BYTES, io);
                         tcs_store_planes(rsX, 2 * voff + k * TCS_XROW_BYTES, 1024 + voff + k * TCS_XROW_BYTES, io);
                     }
                 } else {
@@ -647,7 +659,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                     tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, m0, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
                     if constexpr (EM) {
                         if (lanes_of(m0.lanes)) {
-                            tcs_store_row(rsF, vo, Q.A);
+                            tcs_store_row<TCS_EM_ROW_AUX>(rsF, vo, Q.A);
                             tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                         }
                     } else {
@@ -658,7 +670,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                     tcs_fwd_core<SW, FLAT>(E, Q.B, Q.A, Q.carry, Q.umB, Q.umA, Q.c, m1, er + TCS_EDGE, bx, by, __builtin_amdgcn_readlane(fy.cur, yi + 1));
                     if constexpr (EM) {
                         if (lanes_of(m1.lanes)) {
-                            tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
+                            tcs_store_row<TCS_EM_ROW_AUX>(rsF, vo + TCS_ROW_BYTES, Q.B);
                             tcs_store_planes(rsX, 2 * voff + xo + TCS_XROW_BYTES, 1024 + voff + xo + TCS_XROW_BYTES, Q.B);
                         }
                     } else {
@@ -671,7 +683,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 tcs_fwd_core<SW, FLAT>(E, Q.A, Q.B, Q.carry, Q.umA, Q.umB, Q.c, m14, er, bx, by, __builtin_amdgcn_readlane(fy.cur, yi));
                 if constexpr (EM) {
                     if (lanes_of(m14.lanes)) {
-                        tcs_store_row(rsF, vo, Q.A);
+                        tcs_store_row<TCS_EM_ROW_AUX>(rsF, vo, Q.A);
                         tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                     }
                 } else {
@@ -848,9 +860,9 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                         if (NPR_TCS_EM_EXP != 2)
 #endif
                         if (lanes_of(row_masks(w).lanes)) {
-                            S.f = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + k * TCS_ROW_BYTES, 0, 0);
-                            S.x0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, 2 * voff + k * TCS_XROW_BYTES, 0, 0);
-                            S.x1 = __builtin_amdgcn_raw_buffer_load_b64(rsX, 1024 + voff + k * TCS_XROW_BYTES, 0, 0);
+                            S.f = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + k * TCS_ROW_BYTES, 0, TCS_EM_AUX);
+                            S.x0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, 2 * voff + k * TCS_XROW_BYTES, 0, TCS_EM_AUX);
+                            S.x1 = __builtin_amdgcn_raw_buffer_load_b64(rsX, 1024 + voff + k * TCS_XROW_BYTES, 0, TCS_EM_AUX);
                         }
                     }
                 };
