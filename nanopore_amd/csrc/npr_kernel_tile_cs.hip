@@ -464,6 +464,12 @@ constexpr int TCS_EM_DEAD = NPR_TCS_EM_DEAD;  // (k_em_tile's EM_SKIP: 2.7e8 ter
 #ifndef NPR_TCS_DP_MASK
 #define NPR_TCS_DP_MASK 0
 #endif
+// (the DP instances' forward rows too are written once and read once, much later: as non-temporal stores and loads 270.9 / 270.0 -> 263.5 / 263.2 ms
+// per launch of the reference's band, 8192 reads, alternating runs)
+#ifndef NPR_TCS_DP_AUX
+#define NPR_TCS_DP_AUX 2
+#endif
+constexpr int TCS_DP_AUX = NPR_TCS_DP_AUX;  // cache policy of the DP instances' row stores and loads (2: nt)
 constexpr bool TCS_DP_MASK = NPR_TCS_DP_MASK != 0;  // the DP instances' row stores and loads in the fast loops only in the lanes that hold a band cell: what halved the E-step's traffic buys nothing here (8192 reads in the reference's band, two runs each: 268.6 / 269.2 ms without, 272.9 / 273.1 with -- the DP sweeps are not bound by these bytes)
 #ifndef NPR_TCS_T_SGPR
 #define NPR_TCS_T_SGPR 1
@@ -626,7 +632,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                         tcs_store_planes(rsX, 2 * voff + k * TCS_XROW_BYTES, 1024 + voff + k * TCS_XROW_BYTES, io);
                     }
                 } else {
-                    tcs_store_row(rsF, voff + k * TCS_ROW_BYTES, io);
+                    tcs_store_row<TCS_DP_AUX>(rsF, voff + k * TCS_ROW_BYTES, io);
                 }
                 if (edge_lane) tcs_store_edge_fwd(rsE, 4 * TCS_EDGE * k, io.c[R - 1], Q.umA, Q.e, Q.eh);
                 if ((d & (TCS_BLOCK - 1)) == TCS_BLOCK - 1 || d == st.dl) {
@@ -663,7 +669,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                         }
                     } else {
-                        if (!TCS_DP_MASK || lanes_of(m0.lanes)) tcs_store_row(rsF, vo, Q.A);
+                        if (!TCS_DP_MASK || lanes_of(m0.lanes)) tcs_store_row<TCS_DP_AUX>(rsF, vo, Q.A);
                     }
                     if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
                     const Masks<R> m1 = row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1));
@@ -674,7 +680,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             tcs_store_planes(rsX, 2 * voff + xo + TCS_XROW_BYTES, 1024 + voff + xo + TCS_XROW_BYTES, Q.B);
                         }
                     } else {
-                        if (!TCS_DP_MASK || lanes_of(m1.lanes)) tcs_store_row(rsF, vo + TCS_ROW_BYTES, Q.B);
+                        if (!TCS_DP_MASK || lanes_of(m1.lanes)) tcs_store_row<TCS_DP_AUX>(rsF, vo + TCS_ROW_BYTES, Q.B);
                     }
                     if (edge_lane) tcs_store_edge_fwd(rsE, ve + 4 * TCS_EDGE, Q.B.c[R - 1], Q.umB, Q.e, Q.eh);
                     yi += 2, vo += 2 * TCS_ROW_BYTES, xo += 2 * TCS_XROW_BYTES, ve += 2 * 4 * TCS_EDGE, er += 2 * TCS_EDGE;
@@ -687,7 +693,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                         tcs_store_planes(rsX, 2 * voff + xo, 1024 + voff + xo, Q.A);
                     }
                 } else {
-                    if (!TCS_DP_MASK || lanes_of(m14.lanes)) tcs_store_row(rsF, vo, Q.A);
+                    if (!TCS_DP_MASK || lanes_of(m14.lanes)) tcs_store_row<TCS_DP_AUX>(rsF, vo, Q.A);
                 }
                 if (edge_lane) tcs_store_edge_fwd(rsE, ve, Q.A.c[R - 1], Q.umA, Q.e, Q.eh);
                 wait_vm();
@@ -767,7 +773,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                 const __amdgpu_buffer_rsrc_t rsF = stripe_rsrc(F, st.row0, TCS_ROW_BYTES), rsE = stripe_rsrc(Eb, st.row0, 4 * TCS_EDGE);
                 const __amdgpu_buffer_rsrc_t rsX = EM ? stripe_rsrc(Fx, st.row0, TCS_XROW_BYTES) : rsF;
                 if constexpr (!EM) {
-                    const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (st.dl - st.df) * TCS_ROW_BYTES, 0, 0);
+                    const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (st.dl - st.df) * TCS_ROW_BYTES, 0, TCS_DP_AUX);
                     RFRow<R> &f0 = (st.dl & 1) ? fa : fb;
                     f0.v[0] = bitsf(q.x), f0.v[1] = bitsf(q.y);
                 }
@@ -1022,7 +1028,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                     if (d > st.df) {
                         rm -= 1;
                         if constexpr (!EM) {
-                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (k - 1) * TCS_ROW_BYTES, 0, 0);
+                            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, voff + (k - 1) * TCS_ROW_BYTES, 0, TCS_DP_AUX);
                             fnext.v[0] = bitsf(q.x), fnext.v[1] = bitsf(q.y);
                         }
                     }
@@ -1114,7 +1120,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 1));
                         } else {
                             if (!TCS_DP_MASK || lanes_of(row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 1)).lanes)) {
-                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
+                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, TCS_DP_AUX);
                                 fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
                             }
                         }
@@ -1129,7 +1135,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                         } else {
                             emit(d - 2 * i, Q.B, fb, m0);
                             if (!TCS_DP_MASK || lanes_of(row_masks(__builtin_amdgcn_readlane(wv16, 2 * i + 2)).lanes)) {
-                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo - TCS_ROW_BYTES, 0, 0);
+                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo - TCS_ROW_BYTES, 0, TCS_DP_AUX);
                                 fb.v[0] = bitsf(q.x), fb.v[1] = bitsf(q.y);
                             }
                         }
@@ -1150,7 +1156,7 @@ __global__ void __launch_bounds__(WAVE *(EM ? TCS_EM_NW : TCS_MAX_NW)) __attribu
                             bases_up<R>(bym, __builtin_amdgcn_readlane(fy.cur, yi + 1));
                         } else {
                             if (!TCS_DP_MASK || lanes_of(row_masks(__builtin_amdgcn_readlane(wv16, 15)).lanes)) {
-                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, 0);
+                                const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rsF, vo, 0, TCS_DP_AUX);
                                 fa.v[0] = bitsf(q.x), fa.v[1] = bitsf(q.y);
                             }
                         }
