@@ -462,7 +462,7 @@ constexpr int TCS_EM_DEAD = NPR_TCS_EM_DEAD;  // (k_em_tile's EM_SKIP: 2.7e8 ter
 #define NPR_TCS_WAVES 6
 #endif
 #ifndef NPR_TCS_DP_MASK
-#define NPR_TCS_DP_MASK 0
+#define NPR_TCS_DP_MASK 1
 #endif
 // (the DP instances' forward rows too are written once and read once, much later: as non-temporal stores and loads 270.9 / 270.0 -> 263.5 / 263.2 ms
 // per launch of the reference's band, 8192 reads, alternating runs)
@@ -470,7 +470,7 @@ constexpr int TCS_EM_DEAD = NPR_TCS_EM_DEAD;  // (k_em_tile's EM_SKIP: 2.7e8 ter
 #define NPR_TCS_DP_AUX 2
 #endif
 constexpr int TCS_DP_AUX = NPR_TCS_DP_AUX;  // cache policy of the DP instances' row stores and loads (2: nt)
-constexpr bool TCS_DP_MASK = NPR_TCS_DP_MASK != 0;  // the DP instances' row stores and loads in the fast loops only in the lanes that hold a band cell: what halved the E-step's traffic buys nothing here (8192 reads in the reference's band, two runs each: 268.6 / 269.2 ms without, 272.9 / 273.1 with -- the DP sweeps are not bound by these bytes)
+constexpr bool TCS_DP_MASK = NPR_TCS_DP_MASK != 0;  // the DP instances' row stores and loads in the fast loops only in the lanes that hold a band cell (what halved the E-step's traffic): with plain stores and loads 268.6 / 269.2 -> 272.9 / 273.1 ms per launch of the reference's band, with non-temporal ones 262.1 / 262.2 -> 260.0 / 259.7: on since then
 #ifndef NPR_TCS_T_SGPR
 #define NPR_TCS_T_SGPR 1
 #endif
