@@ -737,21 +737,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_task_rsrc(char *F) {
     return __builtin_amdgcn_make_buffer_rsrc(F - static_cast<int64_t>(row_bias<R>() / 2), 0, -1, 0x00020000);
 }
 // cache policy of the forward rows' stores and loads.  Non-temporal (2), which pays in the stripe kernels (npr_kernel_tile_cs.hip), costs here: the headline
-// launch 134.7 / 134.9 -> 139.8 / 139.7 ms, alternating runs -- a frame kernel's rows are read back by the partner sweep from the L2 they were written to.
+// launch 134.7 / 134.9 -> 139.8 / 139.7 ms, alternating runs (the stores alone 134.1 -> 137.6 / 138.6, the loads alone 136.7 / 136.7) -- a frame kernel's rows are
+// read back by the partner sweep from the L2 they were written to.
 #ifndef NPR_RS_ROW_AUX
 #define NPR_RS_ROW_AUX 0
 #endif
-constexpr int RS_ROW_AUX = NPR_RS_ROW_AUX;
+#ifndef NPR_RS_ROW_ST_AUX
+#define NPR_RS_ROW_ST_AUX NPR_RS_ROW_AUX
+#endif
+#ifndef NPR_RS_ROW_LD_AUX
+#define NPR_RS_ROW_LD_AUX NPR_RS_ROW_AUX
+#endif
+constexpr int RS_ROW_ST_AUX = NPR_RS_ROW_ST_AUX, RS_ROW_LD_AUX = NPR_RS_ROW_LD_AUX;
 template <int R>
 __device__ __forceinline__ void rs_store_row(__amdgpu_buffer_rsrc_t rs, const RDiag<R> &C, const RowCtl<R> &ct, int voff) {
     if (lanes_of(ct.mk.lanes)) {
         const int vo = voff + static_cast<int>(ct.soff >> 1);
         if constexpr (R == 1) {
-            __builtin_amdgcn_raw_buffer_store_b32(fbits(C.c[0].m), rs, vo, 0, RS_ROW_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(fbits(C.c[0].m), rs, vo, 0, RS_ROW_ST_AUX);
         } else if constexpr (R == 2) {
-            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), fbits(C.c[1].m)}, rs, vo, 0, RS_ROW_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(v2i{fbits(C.c[0].m), fbits(C.c[1].m)}, rs, vo, 0, RS_ROW_ST_AUX);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), fbits(C.c[1].m), fbits(C.c[2].m), fbits(C.c[3].m)}, rs, vo, 0, RS_ROW_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{fbits(C.c[0].m), fbits(C.c[1].m), fbits(C.c[2].m), fbits(C.c[3].m)}, rs, vo, 0, RS_ROW_ST_AUX);
         }
     }
 }
@@ -768,12 +775,12 @@ __device__ __forceinline__ void rs_load_row(__amdgpu_buffer_rsrc_t rs, RFRow<R> 
     {
         const int vo = voff + static_cast<int>(ct.soff >> 1);
         if constexpr (R == 1) {
-            f.v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, RS_ROW_AUX));
+            f.v[0] = bitsf(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, RS_ROW_LD_AUX));
         } else if constexpr (R == 2) {
-            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, RS_ROW_AUX);
+            const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, RS_ROW_LD_AUX);
             f.v[0] = bitsf(q.x), f.v[1] = bitsf(q.y);
         } else {
-            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, RS_ROW_AUX);
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, RS_ROW_LD_AUX);
             f.v[0] = bitsf(q.x), f.v[1] = bitsf(q.y), f.v[2] = bitsf(q.z), f.v[3] = bitsf(q.w);
         }
     }
