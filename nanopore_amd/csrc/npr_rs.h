@@ -742,6 +742,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_task_rsrc(char *F) {
 #ifndef NPR_RS_ROW_AUX
 #define NPR_RS_ROW_AUX 0
 #endif
+#ifndef NPR_RS_PAIR_NT
+#define NPR_RS_PAIR_NT 0  // the posterior triples as non-temporal stores (read once, by the finish): nothing on the headline launch (132.6 / 132.6 ms without, 132.9 / 132.9 with)
+#endif
 #ifndef NPR_RS_ROW_ST_AUX
 #define NPR_RS_ROW_ST_AUX NPR_RS_ROW_AUX
 #endif
@@ -812,9 +815,15 @@ __device__ __forceinline__ void rs_emit_pairs(const PairSink &S, const RDiag<R> 
                 const int slot = cnt + before;
                 if (lanes_of(hit[r]) && slot < S.cap) {  // (S.off is 0: the sink's pointers are the task's; unsigned slots: scalar base + 32-bit offset)
                     const uint32_t u = static_cast<uint32_t>(slot) << 2;  // a byte offset that fits 32 bits (pair_cap < 2^29): one shift, the arrays' addresses stay scalar
+#if NPR_RS_PAIR_NT
+                    __builtin_nontemporal_store(x0 + jr[r] - 1 + S.xs, &rs_at<int32_t>(S.px, u));
+                    __builtin_nontemporal_store(y0 - jr[r] - 1 + S.ys, &rs_at<int32_t>(S.py, u));
+                    __builtin_nontemporal_store(p[r], &rs_at<float>(S.pp, u));
+#else
                     rs_at<int32_t>(S.px, u) = x0 + jr[r] - 1 + S.xs;
                     rs_at<int32_t>(S.py, u) = y0 - jr[r] - 1 + S.ys;
                     rs_at<float>(S.pp, u) = p[r];
+#endif
                 }
                 cnt += __popcll(hit[r]);
             }
