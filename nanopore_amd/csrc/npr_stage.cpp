@@ -248,7 +248,9 @@ static int32_t batch_create_at_impl(npr_ctx *ctx, const npr_params *params, int6
     const int cmin = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(kSchedClasses, ctx->opt[NPR_OPT_CLASS_MIN])));  // bring-up: smallest register class to use
     const bool use_tile = !force_generic && ctx->opt[NPR_OPT_NO_TILE] == 0;  // (E-step batches too: k_em_tile)
     // E-step batches whose stripe tasks run in column-scaled arithmetic (k_dp_tile_cs's E-step instance, below): the four-slot frame class goes there
-    // too -- k_em_stair<4> is one long dependent chain per task
+    // too -- k_em_stair<4> is one long dependent chain per task.  (Not the two-slot class: bands of 150 / 200 cells gain 19 / 9 % on the stripes, but
+    // one wavefront walks a task's stripes one after the other, and the long thin tasks of that class -- 24 000 stripe rows where the frame has
+    // 16 000 anti-diagonals -- become the launch's critical path: the bench's batch 51 -> 60 ms.)
     bool em_stripes_cs = b->params.mode == NPR_MODE_EXPECTATIONS && use_tile && ctx->opt[NPR_OPT_ARITH] != 1 && ctx->opt[NPR_OPT_EM_TILE] != 1 &&
                          ctx->opt[NPR_OPT_TILE_RS] != 2;
     for (int sl = 0; sl < NPR_MAX_MODELS; ++sl)
