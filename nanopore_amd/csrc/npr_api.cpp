@@ -75,8 +75,15 @@ int32_t npr_create(int32_t device_id, npr_ctx **out, char *err, size_t errlen) {
     ctx->cu_count = prop.multiProcessorCount;
     ctx->total_mem = prop.totalGlobalMem;
     ctx->host_threads = usable_cpus();
+    // The side streams carry the SMALL launches of a pass (the classes with few cells beside the one that fills the chip): at the highest priority,
+    // so that when all of a pass's launches become ready together the small ones are dispatched first -- a kernel that fills every SIMD's
+    // registers with persistent workgroups leaves no room for a late one until it drains (NPR_SIDE_PRIORITY=0: default priority, A/B)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char *pe = std::getenv("NPR_SIDE_PRIORITY");
+    const int side_prio = (pe && std::atoi(pe) == 0) ? prio_lo : prio_hi;
     for (int i = 0; i < npr_ctx::kSideStreams; ++i)
-        if ((e = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess ||
+        if ((e = hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, side_prio)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->side_done[i], hipEventDisableTiming)) != hipSuccess) {
             say("npr_create: side stream allocation", e);
             npr_destroy(ctx);
