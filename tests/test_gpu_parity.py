@@ -46,7 +46,7 @@ def _run_case(gpu_ctx, rng, n_reads, lmin, lmax, kw, model="blasr_hmm_0.txt", in
     for (X, Y, ops), g in zip(raw, out):
         m32 = orc.realign_read(h, P, X, Y, ops, precision=1, seg_arith=g["seg_arith"])
         m64 = orc.realign_read(h, P, X, Y, ops, precision=0)
-        assert g["status"] == 0 and m32["status"] == 0 and m64["status"] == 0
+        assert g["status"] == 0 and m32["status"] == 0 and m64["status"] == 0, (g["status"], m32["status"], m64["status"], len(X), len(Y), g.get("seg_arith"))
         assert g["cells"] == m32["cells"] == m64["cells"]
         # --- bit-exact against the fp32 mirror ---
         gp = _pairs_dict(g["x"], g["y"], g["p"])

@@ -11,7 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = R.Context(0)
-t0 = time.time(); cases = reads = 0
+t0 = time.time(); cases = reads = skipped = 0
 classes = np.zeros(16, dtype=np.int64)
 while time.time() - t0 < budget:
     kind = int(rng.integers(0, 4))
@@ -34,8 +34,16 @@ while time.time() - t0 < budget:
         extra = dict(indel=float(rng.random() * 0.35), max_indel=int(rng.integers(1, 150)))
     try:
         T._run_case(ctx, rng, args[0], args[1], args[2], kw, **extra)
+    except AssertionError as e:
+        # (the ORACLE's pair list has a fixed capacity; the product runs an overflowed read again with four times the room.  A read of 990 bases
+        # against 2653 under a band of 1961 cells is such a case: statuses (0, -3, -3): nothing to compare)
+        if e.args and isinstance(e.args[0], tuple) and e.args[0][:3] == (0, -3, -3):
+            skipped += 1
+            continue
+        print("FAILED case", cases, "seed", seed, kw, args, extra, flush=True)
+        raise
     except Exception:
         print("FAILED case", cases, "seed", seed, kw, args, extra, flush=True)
         raise
     cases += 1; reads += args[0]
-print("parity stress ok: %d cases, %d reads, %.0f s" % (cases, reads, time.time() - t0))
+print("parity stress ok: %d cases, %d reads, %.0f s (%d cases skipped: the oracle's pair list overflowed)" % (cases, reads, time.time() - t0, skipped))
